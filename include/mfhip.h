@@ -1,0 +1,200 @@
+/*
+ * mfhip.h -- C ABI of libmfhip.so: MI355X (gfx950) kernels for MoreFusion's
+ * volumetric pose hot path (voxelize -> trilinear sample -> TDF / pseudo-occupancy
+ * -> ICC / ICP refinement -> KNN).
+ *
+ * The reference has NO binary FFI for this path: its CUDA code is source text
+ * handed to cupy.ElementwiseKernel / cupy.RawKernel at run time.
+ * Each entry point below therefore replaces one such JIT-kernel call site (cited
+ * as file:line under /root/reference/) and is what a maintainer's ctypes stub
+ * binds instead.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked host; buffers are borrowed,
+ *     never freed or reallocated here; outputs and workspaces are caller-allocated;
+ *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*), never
+ *     synchronise, never allocate device memory (mf_icc_* keep a small host-side
+ *     hipGraph cache);
+ *   - return 0 on success, a negative hipError_t otherwise (mf_last_error_string());
+ *   - float = IEEE binary32, arithmetic un-fused (no FMA contraction) so that voxel
+ *     indices and arg-min decisions are bit-identical to the CPU oracle;
+ *   - voxel index = round-half-away((p - origin) / pitch)  (CUDA round());
+ *   - layouts: points [n,3] row-major; voxel grids [B,C,X,Y,Z] (z fastest).
+ */
+#ifndef MFHIP_H_
+#define MFHIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *mfStream_t; /* hipStream_t */
+
+int mf_version(void);
+const char *mf_last_error_string(void);
+
+/* ---- A1/A2 average_voxelization_3d -------------------------------------
+ * replaces ElementwiseKernel "average_voxelization_3d_fwd" + the nonzero/divide
+ * epilogue   morefusion/functions/geometry/average_voxelization_3d.py:42-118
+ * and "voxelize_bwd"                                              :146-220.
+ * matrix [B,C,X,Y,Z] and counts [B,X,Y,Z] are written completely (no pre-zero).
+ * head [B*X*Y*Z] int32 and link [n] int32 are scratch.  nan_flag (1 int32, may
+ * be NULL) is set to 1 if any point coordinate is NaN (reference raises
+ * ValueError("points include nan"); the host wrapper does after reading it).
+ * Sums are taken in increasing point index (== the reference's CPU loop order),
+ * so results are run-to-run deterministic and bit-equal to forward_cpu. */
+int mf_average_voxelization_3d_fwd(const float *values, const float *points,
+                                   const int32_t *batch_indices, int64_t n, int C,
+                                   int B, int X, int Y, int Z, float ox, float oy,
+                                   float oz, float pitch, float *matrix,
+                                   int32_t *counts, int32_t *head, int32_t *link,
+                                   int32_t *nan_flag, mfStream_t stream);
+int mf_average_voxelization_3d_bwd(const float *gmatrix, const float *points,
+                                   const int32_t *batch_indices,
+                                   const int32_t *counts, int64_t n, int C, int B,
+                                   int X, int Y, int Z, float ox, float oy, float oz,
+                                   float pitch, float *gvalues, mfStream_t stream);
+
+/* ---- A3 max_voxelization_3d ---------------------------------------------
+ * replaces "max_voxelization_3d_fwd" + gather, "max_voxelization_3d_bwd"
+ *   morefusion/functions/geometry/max_voxelization_3d.py:58-138, :140-185.
+ * Winner = max intensity, lowest point index among ties (the CPU rule :33-38;
+ * the CUDA CAS/Max/Exch sequence is racy).  indices [B,X,Y,Z] (-1 = empty),
+ * matrix [B,C,X,Y,Z] both written completely; key [B*X*Y*Z] uint64 scratch. */
+int mf_max_voxelization_3d_fwd(const float *values, const float *points,
+                               const int32_t *batch_indices, const float *intensities,
+                               int64_t n, int C, int B, int X, int Y, int Z, float ox,
+                               float oy, float oz, float pitch, float *matrix,
+                               int32_t *indices, uint64_t *key, int32_t *nan_flag,
+                               mfStream_t stream);
+/* gvalues [n,C] must be zeroed by the caller. */
+int mf_max_voxelization_3d_bwd(const float *gmatrix, const int32_t *indices, int64_t n,
+                               int C, int B, int X, int Y, int Z, float *gvalues,
+                               mfStream_t stream);
+
+/* ---- A4 interpolate_voxel_grid ------------------------------------------
+ * replaces "interpolate_voxel_grid_fwd" / "_bwd"
+ *   morefusion/functions/geometry/interpolate_voxel_grid.py:159-214, :216-268.
+ * points are in voxel-index units; low corner = (int)coord (trunc toward zero).
+ * values: [n,C] if channels_first == 0, else [C,n] (coalesced layout the pose
+ * network consumes).  gvox [B,C,X,Y,Z] is written completely by _bwd. */
+int mf_interpolate_voxel_grid_fwd(const float *vox, const float *points,
+                                  const int32_t *batch_indices, int64_t n, int B, int C,
+                                  int X, int Y, int Z, float *values,
+                                  int channels_first, mfStream_t stream);
+int mf_interpolate_voxel_grid_bwd(const float *gvalues, const float *points,
+                                  const int32_t *batch_indices, int64_t n, int B, int C,
+                                  int X, int Y, int Z, float *gvox, int channels_first,
+                                  mfStream_t stream);
+
+/* ---- A5 occupancy_grid_3d -------------------------------------------------
+ * replaces the dense [X,Y,Z,P] composite
+ *   morefusion/functions/geometry/occupancy_grid_3d.py:31-85
+ * with one fused min-over-points kernel.  grid [X,Y,Z]; dmin [X,Y,Z] (saved for
+ * backward).  _bwd: gradient to EVERY point at the minimum distance (chainer
+ * F.min rule); gpoints [P,3] must be zeroed by the caller. */
+int mf_occupancy_grid_3d_fwd(const float *points, int64_t P, float pitch, float ox,
+                             float oy, float oz, int X, int Y, int Z, float threshold,
+                             float *grid, float *dmin, mfStream_t stream);
+int mf_occupancy_grid_3d_bwd(const float *ggrid, const float *points, int64_t P,
+                             float pitch, float ox, float oy, float oz, int X, int Y,
+                             int Z, float threshold, const float *dmin, float *gpoints,
+                             mfStream_t stream);
+
+/* ---- A6/A7 truncated_distance_function, pseudo_occupancy_voxelization ----
+ * replaces "truncated_distance_function_fwd" / "_bwd"
+ *   morefusion/functions/geometry/truncated_distance_function.py:21-103, :105-166
+ * tdf [X,Y,Z]; flat [X,Y,Z] int32 = p*K+k of the arg-min candidate (-1 none;
+ * exact arg-min, lowest flat index among equal distances -- the reference's
+ * atomicMin/atomicExch pair is racy).  K = ksize^3, ksize = ceil(trunc/pitch)
+ * made odd (:36-38).  _bwd: gpoints [P,3] must be zeroed by the caller. */
+int mf_truncated_distance_function_fwd(const float *points, int64_t P, float pitch,
+                                       float ox, float oy, float oz, int X, int Y, int Z,
+                                       float truncation, float *tdf, int32_t *flat,
+                                       mfStream_t stream);
+int mf_truncated_distance_function_bwd(const float *gtdf, const float *points,
+                                       const int32_t *flat, int64_t P, float pitch,
+                                       float ox, float oy, float oz, int X, int Y, int Z,
+                                       float truncation, float *gpoints,
+                                       mfStream_t stream);
+/* pseudo_occupancy_voxelization epilogue (:181-213) on the TDF result:
+ * grids [3,X,Y,Z] = uniform, surface, inside; wmax: 1 float scratch (zeroed here). */
+int mf_pseudo_occupancy_weights(const float *tdf, const int32_t *flat, const float *sdf,
+                                int X, int Y, int Z, int K, float truncation,
+                                float sdf_offset, float *grids, float *wsurf, float *win,
+                                float *wmax, mfStream_t stream);
+
+/* ---- A11 geometry.nn ------------------------------------------------------
+ * replaces RawKernel cuComputeDistanceGlobal + cupy.argmin
+ *   morefusion/geometry/knn/nn.py:18-49, knn/cuComputeDistanceGlobal.cu:20-86
+ * without materialising the R x Q matrix.  dim = 3.  out [Q] int64; optional
+ * out_dist [Q] float (squared distance to the match; may be NULL). */
+int mf_nn(const float *ref, int64_t R, const float *query, int64_t Q, int64_t *out,
+          float *out_dist, mfStream_t stream);
+
+/* ---- A10 IterativeClosestPointLink ----------------------------------------
+ *   morefusion/contrib/iterative_closest_point_link.py:26-44
+ * source [S,3] model frame, target [T,3]; Rt [12] = row-major R(3x3) then t.
+ * out [16]: loss, n_matched, pad, pad, gRt[12] (d loss / d R, d loss / d t).
+ * out must be zeroed by the caller. */
+int mf_icp_loss_grad(const float *source, int64_t S, const float *target, int64_t T,
+                     const float *Rt, float thresh, float *out, mfStream_t stream);
+
+/* ---- A9 IterativeCollisionCheckLink (fused) --------------------------------
+ *   morefusion/contrib/iterative_collision_check_link.py:31-99 (forward),
+ *   truncated_distance_function.py:105-166 (backward), driver loop
+ *   examples/ycb_video/pose_refinement/check_iterative_collision_check_link.py:44-79
+ *
+ * A batch holds S independent scenes with O objects in total.  Device arrays:
+ *   pts4      [Ptot] float4  model-frame point (x,y,z) + its sdf value (w)
+ *   obj_off   [O+1]  int32   point range of object o
+ *   scene_off [S+1]  int32   object range of scene s
+ *   obj_scene [O]    int32
+ *   pitch [O], origin [O,3], grid_target [O,D,D,D], grid_ne [O,D,D,D]
+ *   q [O,4] (wxyz), t [O,3]          -- parameters (updated in place by refine)
+ *   adam_m, adam_v [O,7]             -- chainer-Adam moments (q then t)
+ * ws: workspace of mf_icc_workspace_bytes() bytes.
+ */
+typedef struct {
+  const void *pts4;
+  const int32_t *obj_off;
+  const int32_t *scene_off;
+  const int32_t *obj_scene;
+  const float *pitch;
+  const float *origin;
+  const float *grid_target;
+  const float *grid_ne;
+  int32_t n_objects; /* O */
+  int32_t n_scenes;  /* S */
+  int32_t n_points;  /* Ptot */
+  int32_t dim;       /* D (32) */
+  float voxel_threshold;
+  float sdf_offset;
+} mfIccBatch;
+
+int64_t mf_icc_workspace_bytes(int32_t n_objects, int32_t n_scenes, int32_t dim);
+
+/* One forward+backward: loss [S], gq [O,4], gt [O,3]; q,t not modified. */
+int mf_icc_loss_grad(const mfIccBatch *batch, const float *q, const float *t,
+                     float *loss, float *gq, float *gt, void *ws, mfStream_t stream);
+
+/* n_iter x {forward, backward, chainer-Adam step} entirely on device (one
+ * hipGraph launch; no host sync).  losses [n_iter,S] and traj [n_iter,O,7]
+ * (pose BEFORE each step) may be NULL.  step0 = number of Adam steps already
+ * taken (bias correction). */
+int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float *adam_m,
+                  float *adam_v, int32_t n_iter, int32_t step0, float alpha_q,
+                  float alpha_t, float *losses, float *traj, void *ws,
+                  mfStream_t stream);
+
+/* small fused helpers of the same path */
+/* pack [Ptot,3] points + [Ptot] sdf into float4 */
+int mf_pack_points_sdf(const float *points, const float *sdf, int64_t n, void *pts4,
+                       mfStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFHIP_H_ */

@@ -1,0 +1,117 @@
+"""ctypes binding of libmfhip.so (include/mfhip.h).
+
+The HIP library is THE implementation of the voxel / refinement ops: there is no
+Python or CPU fallback.  If the shared object is missing (or a tensor is not on a
+HIP device) the ops raise -- loudly -- instead of computing something else.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libmfhip.so")
+_lib = None
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_f = ctypes.c_float
+
+
+class IccBatch(ctypes.Structure):
+    """mfIccBatch (include/mfhip.h)."""
+
+    _fields_ = [
+        ("pts4", _p), ("obj_off", _p), ("scene_off", _p), ("obj_scene", _p),
+        ("pitch", _p), ("origin", _p), ("grid_target", _p), ("grid_ne", _p),
+        ("n_objects", ctypes.c_int32), ("n_scenes", ctypes.c_int32),
+        ("n_points", ctypes.c_int32), ("dim", ctypes.c_int32),
+        ("voxel_threshold", _f), ("sdf_offset", _f),
+    ]
+
+
+_SIGNATURES = {
+    "mf_version": ([], _i),
+    "mf_last_error_string": ([], ctypes.c_char_p),
+    "mf_average_voxelization_3d_fwd": ([_p, _p, _p, _i64, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p], _i),
+    "mf_average_voxelization_3d_bwd": ([_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p], _i),
+    "mf_max_voxelization_3d_fwd": ([_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p], _i),
+    "mf_max_voxelization_3d_bwd": ([_p, _p, _i64, _i, _i, _i, _i, _i, _p, _p], _i),
+    "mf_interpolate_voxel_grid_fwd": ([_p, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _i, _p], _i),
+    "mf_interpolate_voxel_grid_bwd": ([_p, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _i, _p], _i),
+    "mf_occupancy_grid_3d_fwd": ([_p, _i64, _f, _f, _f, _f, _i, _i, _i, _f, _p, _p, _p], _i),
+    "mf_occupancy_grid_3d_bwd": ([_p, _p, _i64, _f, _f, _f, _f, _i, _i, _i, _f, _p, _p, _p], _i),
+    "mf_truncated_distance_function_fwd": ([_p, _i64, _f, _f, _f, _f, _i, _i, _i, _f, _p, _p, _p], _i),
+    "mf_truncated_distance_function_bwd": ([_p, _p, _p, _i64, _f, _f, _f, _f, _i, _i, _i, _f, _p, _p], _i),
+    "mf_pseudo_occupancy_weights": ([_p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p], _i),
+    "mf_nn": ([_p, _i64, _p, _i64, _p, _p, _p], _i),
+    "mf_icp_loss_grad": ([_p, _i64, _p, _i64, _p, _f, _p, _p], _i),
+    "mf_icc_workspace_bytes": ([ctypes.c_int32, ctypes.c_int32, ctypes.c_int32], _i64),
+    "mf_icc_loss_grad": ([ctypes.POINTER(IccBatch), _p, _p, _p, _p, _p, _p, _p], _i),
+    "mf_icc_refine": ([ctypes.POINTER(IccBatch), _p, _p, _p, _p, ctypes.c_int32, ctypes.c_int32, _f, _f, _p, _p, _p, _p], _i),
+    "mf_pack_points_sdf": ([_p, _p, _i64, _p, _p], _i),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load libmfhip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+                "morefusion_amd/csrc`). morefusion_amd has no CPU fallback."
+            )
+        handle = ctypes.CDLL(SO_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is absent
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().mf_last_error_string().decode()
+        raise RuntimeError(f"{what} failed ({code}): {msg}")
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"expected torch.Tensor, got {type(t)}")
+        if not t.is_cuda:
+            raise RuntimeError(
+                "morefusion_amd voxel/refinement ops run on the MI355X only: got a "
+                f"{t.device} tensor (there is no CPU fallback; move inputs to 'cuda')."
+            )
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def i32c(t):
+    return t.detach().to(torch.int32).contiguous()
+
+
+def as_float3(origin):
+    if isinstance(origin, torch.Tensor):
+        origin = origin.detach().cpu().tolist()
+    o = [float(x) for x in origin]
+    if len(o) != 3:
+        raise ValueError("origin must have 3 elements")
+    return o

@@ -1,0 +1,5 @@
+# flake8: noqa
+# the hot-path subset of morefusion/contrib/__init__.py:3-11
+from .icc_batch import IccScenes
+from .iterative_closest_point_link import IterativeClosestPointLink
+from .iterative_collision_check_link import IterativeCollisionCheckLink

@@ -1,0 +1,778 @@
+// Fused Iterative Collision Check (ICC) for gfx950: forward, backward and the
+// chainer-Adam step of IterativeCollisionCheckLink, batched over independent scenes.
+//
+// Reference call graph (one iteration, N objects):
+//   contrib/iterative_collision_check_link.py:31-99   transformation_matrix, N x
+//   transform_points, 2N x pseudo_occupancy_voxelization (each: TDF kernel K7 with
+//   global float atomics + ~15 elementwise launches), N x isnan().any() D2H syncs,
+//   stack/maximum/sum; backward = 2N x K8 (truncated_distance_function.py:105-166)
+//   + matmul/quaternion backward; optimizer.update().  ~300 launches and N host
+//   syncs per iteration, x100 iterations
+//   (examples/ycb_video/pose_refinement/check_iterative_collision_check_link.py:52-79).
+//
+// Here one iteration is THREE launches and the whole n_iter loop is one hipGraph:
+//   k_icc_tdf    grid (slab, 2*O): pose -> world point -> TDF of the "own" / "other"
+//                point set of object o, tile of the 32^3 grid resident in LDS as packed
+//                u64 keys (distance bits << 32 | global candidate id), ds_min_u64 gives
+//                exact min + deterministic arg-min; epilogue stores the winners and
+//                the per-grid max of the raw inside weight (integer atomicMax).
+//   k_icc_accum  grid (block, O): per voxel pseudo-occupancy weights, max() with the
+//                no-entry grid, partial sums of reward / penalty AND the pose-gradient
+//                moments.  The loss gradient is linear in {1/S_t, 1/S_in, PN/S_in^2},
+//                so moments are accumulated per coefficient and combined later --
+//                no second pass over the grids once the global sums are known.
+//   k_icc_step   grid (scene): fixed-order reduction of the partials, loss, chain rule
+//                to (q, t), chainer-Adam update, next iteration's rotation matrices.
+// Every reduction has a fixed order (wave shuffles, ordered partials, integer
+// fixed-point atomics for the rare cross-object collision terms): bitwise
+// reproducible run to run.  No host synchronisation anywhere.
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "mf_common.h"
+
+namespace {
+
+constexpr int kTdfThreads = 512;
+constexpr int kAccThreads = 256;
+constexpr int kVoxPerBlock = 1024;  // k_icc_accum: voxels per workgroup
+constexpr int kNumOwn = 39;         // RN, S_in, PN + 3 x 12 gradient moments
+constexpr uint32_t kNoCand = 0xffffffffu;
+constexpr double kFix = 4294967296.0;  // 2^32 fixed point for the collision moments
+
+struct IccArgs {
+  const float4 *pts4;
+  const int32_t *obj_off;
+  const int32_t *scene_off;
+  const int32_t *obj_scene;
+  const float *pitch;
+  const float *origin;
+  const float *grid_target;
+  const float *grid_ne;
+  int O, S, D;
+  float thr, sdf_offset;
+  // workspace
+  unsigned long long *W;  // [2*O][V]
+  uint32_t *Mbits;        // [2*O]
+  float *Rt;              // [O][12]  R row-major, then t
+  float *bound;           // [O][4]   model-frame bounding sphere
+  float *St;              // [S]
+  float *part;            // [O][NB][kNumOwn]
+  long long *oth;         // [O][12] fixed-point collision moments
+  int32_t *step;          // [S] adam step counter per scene
+};
+
+__device__ __forceinline__ void quat_to_R(const float *q, float *R) {
+  // morefusion/functions/geometry/quaternion_matrix.py:65-78, :14-34
+  const float n = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
+  const float s = sqrtf(2.0f / n);
+  const float qs[4] = {q[0] * s, q[1] * s, q[2] * s, q[3] * s};
+  float Q[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Q[i][j] = qs[i] * qs[j];
+  R[0] = 1.0f - Q[2][2] - Q[3][3];
+  R[1] = Q[1][2] - Q[3][0];
+  R[2] = Q[1][3] + Q[2][0];
+  R[3] = Q[1][2] + Q[3][0];
+  R[4] = 1.0f - Q[1][1] - Q[3][3];
+  R[5] = Q[2][3] - Q[1][0];
+  R[6] = Q[1][3] - Q[2][0];
+  R[7] = Q[2][3] + Q[1][0];
+  R[8] = 1.0f - Q[1][1] - Q[2][2];
+}
+
+__device__ __forceinline__ void quat_backward(const float *q, const float *gR, float *gq) {
+  // quaternion_matrix.py:36-51 (dR/dQ), outer product :54-62, scaling :71-72
+  float gQ[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gQ[i][j] = 0.0f;
+  gQ[1][0] = -gR[5] + gR[7];
+  gQ[1][1] = -gR[4] - gR[8];
+  gQ[1][2] = gR[1] + gR[3];
+  gQ[1][3] = gR[2] + gR[6];
+  gQ[2][0] = gR[2] - gR[6];
+  gQ[2][2] = -gR[0] - gR[8];
+  gQ[2][3] = gR[5] + gR[7];
+  gQ[3][0] = -gR[1] + gR[3];
+  gQ[3][3] = -gR[0] - gR[4];
+  const float n = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
+  const float s = sqrtf(2.0f / n);
+  const float qs[4] = {q[0] * s, q[1] * s, q[2] * s, q[3] * s};
+  float gqs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a += gQ[i][j] * qs[j]; b += gQ[j][i] * qs[j]; }
+    gqs[i] = a + b;
+  }
+  const float dot = ((gqs[0] * q[0] + gqs[1] * q[1]) + gqs[2] * q[2]) + gqs[3] * q[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gq[i] = s * gqs[i] - (s / n) * dot * q[i];
+}
+
+// ---- setup: bounding spheres, sum(grid_target) per scene, R|t from (q,t) -----------
+__global__ __launch_bounds__(256) void k_icc_bound(IccArgs a) {
+  __shared__ float s_red[4][4];
+  const int o = blockIdx.x;
+  const int p0 = a.obj_off[o], p1 = a.obj_off[o + 1];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+    const float4 m = a.pts4[p];
+    lo[0] = fminf(lo[0], m.x); hi[0] = fmaxf(hi[0], m.x);
+    lo[1] = fminf(lo[1], m.y); hi[1] = fmaxf(hi[1], m.y);
+    lo[2] = fminf(lo[2], m.z); hi[2] = fmaxf(hi[2], m.z);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float c[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float l = -mf::wave_max(-lo[d]), h = mf::wave_max(hi[d]);
+    __syncthreads();
+    if (lane == 0) { s_red[wave][0] = l; s_red[wave][1] = h; }
+    __syncthreads();
+    const float L = fminf(fminf(s_red[0][0], s_red[1][0]), fminf(s_red[2][0], s_red[3][0]));
+    const float H = fmaxf(fmaxf(s_red[0][1], s_red[1][1]), fmaxf(s_red[2][1], s_red[3][1]));
+    c[d] = 0.5f * (L + H);
+  }
+  float r2 = 0.0f;
+  for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+    const float4 m = a.pts4[p];
+    const float dx = m.x - c[0], dy = m.y - c[1], dz = m.z - c[2];
+    r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
+  }
+  r2 = mf::wave_max(r2);
+  __syncthreads();
+  if (lane == 0) s_red[wave][0] = r2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    r2 = fmaxf(fmaxf(s_red[0][0], s_red[1][0]), fmaxf(s_red[2][0], s_red[3][0]));
+    const bool empty = p1 <= p0;
+    a.bound[4 * o + 0] = empty ? 0.0f : c[0];
+    a.bound[4 * o + 1] = empty ? 0.0f : c[1];
+    a.bound[4 * o + 2] = empty ? 0.0f : c[2];
+    a.bound[4 * o + 3] = empty ? -1.0f : sqrtf(r2) * 1.0001f + 1e-6f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_icc_scene_setup(IccArgs a, int32_t step0) {
+  __shared__ float s_red[4];
+  const int s = blockIdx.x;
+  if (threadIdx.x == 0) a.step[s] = step0;
+  const int V = a.D * a.D * a.D;
+  const int64_t b0 = (int64_t)a.scene_off[s] * V, b1 = (int64_t)a.scene_off[s + 1] * V;
+  float acc = 0.0f;
+  for (int64_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) acc += a.grid_target[i];
+  acc = mf::wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.St[s] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(64) void k_icc_pose(IccArgs a, const float *__restrict__ q,
+                                                 const float *__restrict__ t) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= a.O) return;
+  float R[9];
+  quat_to_R(q + 4 * o, R);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a.Rt[12 * o + i] = R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) a.Rt[12 * o + 9 + i] = t[3 * o + i];
+  a.Mbits[2 * o] = 0;
+  a.Mbits[2 * o + 1] = 0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) a.oth[12 * o + i] = 0;
+}
+
+// ---- launch 1: TDF tiles in LDS -------------------------------------------------
+// KS = kernel size of truncated_distance_function.py:36-38 (3 for voxel_threshold 2).
+template <int KS>
+__global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, int SX) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];
+  __shared__ float s_max[kTdfThreads / 64];
+  const int ks = KS > 0 ? KS : ks_rt;
+  const int h = ks / 2, K = ks * ks * ks;
+  const int D = a.D;
+  const int g = blockIdx.y, o = g >> 1, other = g & 1;
+  const int sc = a.obj_scene[o];
+  const int ja = a.scene_off[sc], jb = a.scene_off[sc + 1];
+  const int x0 = blockIdx.x * SX;
+  const int sx = min(SX, D - x0);
+  const int nvox = sx * D * D;
+  const float pitch = a.pitch[o];
+  const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
+  const float trunc = a.thr * pitch;
+  const unsigned long long init = ((unsigned long long)__float_as_uint(trunc) << 32) | kNoCand;
+  for (int i = threadIdx.x; i < nvox; i += kTdfThreads) s_key[i] = init;
+  __syncthreads();
+  if (!(other && jb - ja <= 1)) {
+    const uint32_t *s_hi = reinterpret_cast<const uint32_t *>(s_key);
+    const float fh = (float)h, inv_pitch = 1.0f / pitch;
+    // conservative (approximate-arithmetic) rejection bounds, in voxel units
+    const float xlo = (float)x0 - fh - 0.51f, xhi = (float)(x0 + sx - 1) + fh + 0.51f;
+    const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
+    for (int j = ja; j < jb; ++j) {
+      if (other ? (j == o) : (j != o)) continue;
+      const float *Rt = a.Rt + 12 * j;  // wave-uniform -> scalar loads
+      const float R0 = Rt[0], R1 = Rt[1], R2 = Rt[2], R3 = Rt[3], R4 = Rt[4], R5 = Rt[5],
+                  R6 = Rt[6], R7 = Rt[7], R8 = Rt[8], T0 = Rt[9], T1 = Rt[10], T2 = Rt[11];
+      {  // whole-object rejection with the model's bounding sphere
+        const float *b = a.bound + 4 * j;
+        if (b[3] < 0.0f) continue;
+        const float cx = (((R0 * b[0] + R1 * b[1]) + R2 * b[2]) + T0 - ox) * inv_pitch;
+        const float cy = (((R3 * b[0] + R4 * b[1]) + R5 * b[2]) + T1 - oy) * inv_pitch;
+        const float cz = (((R6 * b[0] + R7 * b[1]) + R8 * b[2]) + T2 - oz) * inv_pitch;
+        const float r = b[3] * inv_pitch + 0.05f + 1e-4f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
+        if (cx + r < xlo || cx - r > xhi || cy + r < glo || cy - r > ghi || cz + r < glo ||
+            cz - r > ghi)
+          continue;
+      }
+      const int p1 = a.obj_off[j + 1];
+      for (int p = a.obj_off[j] + threadIdx.x; p < p1; p += kTdfThreads) {
+        const float4 m = a.pts4[p];
+        // transform_points: ((R0 x + R1 y) + R2 z) + t, un-fused (oracle order)
+        const float wx = ((R0 * m.x + R1 * m.y) + R2 * m.z) + T0;
+        {  // cheap reject on x (7 of 8 slabs) before paying for IEEE divides
+          const float ax = (wx - ox) * inv_pitch;
+          const float e = 0.01f + 1e-5f * fabsf(ax);
+          if (!(ax >= xlo - e && ax <= xhi + e)) continue;
+        }
+        const float wy = ((R3 * m.x + R4 * m.y) + R5 * m.z) + T1;
+        const float wz = ((R6 * m.x + R7 * m.y) + R8 * m.z) + T2;
+        const float fx = (wx - ox) / pitch, fy = (wy - oy) / pitch, fz = (wz - oz) / pitch;
+        const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
+        if (!(rx + fh >= (float)x0 && rx - fh < (float)(x0 + sx) && ry + fh >= 0.0f &&
+              ry - fh < (float)D && rz + fh >= 0.0f && rz - fh < (float)D))
+          continue;
+        const int irx = (int)rx, iry = (int)ry, irz = (int)rz;
+#pragma unroll
+        for (int aa = 0; aa < ks; ++aa) {
+          const int iy = iry + aa - h;
+          if (iy < 0 || iy >= D) continue;
+          const float dy = fy - (float)iy;
+#pragma unroll
+          for (int bb = 0; bb < ks; ++bb) {
+            const int ix = irx + bb - h;
+            if (ix < x0 || ix >= x0 + sx) continue;
+            const float dx = fx - (float)ix;
+            const float dxy = dx * dx + dy * dy;
+#pragma unroll
+            for (int cc = 0; cc < ks; ++cc) {
+              const int iz = irz + cc - h;
+              if (iz < 0 || iz >= D) continue;
+              const float dz = fz - (float)iz;
+              const float dist = pitch * sqrtf(dxy + dz * dz);
+              if (dist < trunc) {
+                const int li = ((ix - x0) * D + iy) * D + iz;
+                const uint32_t db = __float_as_uint(dist);
+                if (db <= s_hi[2 * li + 1]) {
+                  const uint32_t id = (uint32_t)p * (uint32_t)K + (uint32_t)((aa * ks + bb) * ks + cc);
+                  atomicMin(&s_key[li], ((unsigned long long)db << 32) | id);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // epilogue: winners out (coalesced 8 B/lane) + max raw inside weight of this tile
+  // (truncated_distance_function.py:198-204: -1 where no winner, + offset, clamp at 0)
+  const float offset = other ? 0.0f : a.sdf_offset;
+  unsigned long long *Wg = a.W + (int64_t)g * D * D * D + (int64_t)x0 * D * D;
+  float wmax = 0.0f;
+  for (int i = threadIdx.x; i < nvox; i += kTdfThreads) {
+    const unsigned long long k = s_key[i];
+    Wg[i] = k;
+    const uint32_t lo = (uint32_t)k;
+    float w = (lo != kNoCand ? a.pts4[lo / (uint32_t)K].w : -1.0f) + offset;
+    w = w < 0.0f ? 0.0f : w;
+    wmax = fmaxf(wmax, w);
+  }
+  wmax = mf::wave_max(wmax);
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = wmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = s_max[0];
+#pragma unroll
+    for (int i = 1; i < kTdfThreads / 64; ++i) m = fmaxf(m, s_max[i]);
+    atomicMax(&a.Mbits[g], __float_as_uint(m));  // m >= 0: uint order == float order
+  }
+}
+
+// ---- launch 2: weights, sums, gradient moments ------------------------------------
+__device__ __forceinline__ void world_frac(const float *Rt, const float4 m, float ox, float oy,
+                                           float oz, float pitch, int ix, int iy, int iz,
+                                           float &ux, float &uy, float &uz, bool &ok) {
+  const float wx = ((Rt[0] * m.x + Rt[1] * m.y) + Rt[2] * m.z) + Rt[9];
+  const float wy = ((Rt[3] * m.x + Rt[4] * m.y) + Rt[5] * m.z) + Rt[10];
+  const float wz = ((Rt[6] * m.x + Rt[7] * m.y) + Rt[8] * m.z) + Rt[11];
+  const float dx = (wx - ox) / pitch - (float)ix;
+  const float dy = (wy - oy) / pitch - (float)iy;
+  const float dz = (wz - oz) / pitch - (float)iz;
+  const float n = sqrtf((dx * dx + dy * dy) + dz * dz);
+  ok = n > 0.0f;  // truncated_distance_function.py:141
+  ux = dx / n; uy = dy / n; uz = dz / n;
+}
+
+__global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
+  __shared__ float s_red[kAccThreads / 64][kNumOwn];
+  const int o = blockIdx.y;
+  const int D = a.D, V = D * D * D;
+  const int sc = a.obj_scene[o];
+  const int ja = a.scene_off[sc], jb = a.scene_off[sc + 1];
+  const float pitch = a.pitch[o];
+  const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
+  const float trunc = a.thr * pitch;
+  const float M_own = __uint_as_float(a.Mbits[2 * o]);
+  const float M_oth = __uint_as_float(a.Mbits[2 * o + 1]);
+  // iterative_collision_check_link.py:82: skip the max() when grid_other has NaN,
+  // which happens iff its normaliser max(weight) is 0 (0/0 everywhere).
+  const bool use_oth = (jb - ja > 1) && (M_oth != 0.0f);
+  const unsigned long long *W_own = a.W + (int64_t)(2 * o) * V;
+  const unsigned long long *W_oth = a.W + (int64_t)(2 * o + 1) * V;
+  const float *tgt = a.grid_target + (int64_t)o * V;
+  const float *gne = a.grid_ne + (int64_t)o * V;
+  const float *Rt_o = a.Rt + 12 * o;
+
+  float acc[kNumOwn];
+#pragma unroll
+  for (int i = 0; i < kNumOwn; ++i) acc[i] = 0.0f;
+
+  for (int it = 0; it < kVoxPerBlock / kAccThreads; ++it) {
+    const int v = blockIdx.x * kVoxPerBlock + it * kAccThreads + threadIdx.x;
+    if (v >= V) break;
+    const int iz = v % D, iy = (v / D) % D, ix = v / (D * D);
+    const unsigned long long ko = W_own[v];
+    const uint32_t lo = (uint32_t)ko;
+    const bool has = lo != kNoCand;
+    const float g = 1.0f - __uint_as_float((uint32_t)(ko >> 32)) / trunc;  // grid = 1 - tdf/trunc
+    float4 m_own = make_float4(0, 0, 0, -1.0f);
+    if (has) m_own = a.pts4[lo / (uint32_t)K];
+    float w = m_own.w + a.sdf_offset;
+    const bool neg = w < 0.0f;
+    if (neg) w = 0.0f;
+    const float win = w / M_own;
+    const float wsurf = neg ? win : 1.0f - win;
+    const float surf = g * wsurf, ins = g * win;
+    const float ne = gne[v], tg = tgt[v];
+    float ne_eff = ne;
+    bool oth_wins = false;
+    float wo_in = 0.0f;
+    uint32_t lo_o = kNoCand;
+    if (use_oth) {
+      const unsigned long long kk = W_oth[v];
+      lo_o = (uint32_t)kk;
+      const float go = 1.0f - __uint_as_float((uint32_t)(kk >> 32)) / trunc;
+      float wo = (lo_o != kNoCand ? a.pts4[lo_o / (uint32_t)K].w : -1.0f) + 0.0f;
+      if (wo < 0.0f) wo = 0.0f;
+      wo_in = wo / M_oth;
+      const float oth = go * wo_in;
+      // F.maximum(grid_nontarget_empty, grid_other): gradient to `other` only if larger
+      oth_wins = !(ne >= oth);
+      if (oth_wins) ne_eff = oth;
+    }
+    acc[0] += surf * tg;
+    acc[1] += ins;
+    acc[2] += ins * ne_eff;
+    if (has) {
+      float ux, uy, uz;
+      bool ok;
+      world_frac(Rt_o, m_own, ox, oy, oz, pitch, ix, iy, iz, ux, uy, uz, ok);
+      if (ok) {
+        const float A[3] = {wsurf * tg / trunc, win * ne_eff / trunc, win / trunc};
+        const float u[3] = {ux, uy, uz};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const float s = u[d] * A[k];
+            acc[3 + 12 * k + 4 * d + 0] += s * m_own.x;
+            acc[3 + 12 * k + 4 * d + 1] += s * m_own.y;
+            acc[3 + 12 * k + 4 * d + 2] += s * m_own.z;
+            acc[3 + 12 * k + 4 * d + 3] += s;
+          }
+      }
+    }
+    if (oth_wins && lo_o != kNoCand && ins != 0.0f) {
+      // collision term: gradient flows to the OTHER object's pose (rare -> fixed-point
+      // integer atomics: associative, hence deterministic)
+      const uint32_t p = lo_o / (uint32_t)K;
+      int j = ja;
+      while (j + 1 < jb && (int)p >= a.obj_off[j + 1]) ++j;
+      const float4 m = a.pts4[p];
+      float ux, uy, uz;
+      bool ok;
+      world_frac(a.Rt + 12 * j, m, ox, oy, oz, pitch, ix, iy, iz, ux, uy, uz, ok);
+      const float B = wo_in * ins / trunc;
+      if (ok && isfinite(B)) {
+        const float u[3] = {ux, uy, uz};
+        long long *dst = a.oth + 12 * j;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const float s = u[d] * B;
+          atomicAdd((unsigned long long *)&dst[4 * d + 0],
+                    (unsigned long long)__double2ll_rn((double)(s * m.x) * kFix));
+          atomicAdd((unsigned long long *)&dst[4 * d + 1],
+                    (unsigned long long)__double2ll_rn((double)(s * m.y) * kFix));
+          atomicAdd((unsigned long long *)&dst[4 * d + 2],
+                    (unsigned long long)__double2ll_rn((double)(s * m.z) * kFix));
+          atomicAdd((unsigned long long *)&dst[4 * d + 3],
+                    (unsigned long long)__double2ll_rn((double)s * kFix));
+        }
+      }
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < kNumOwn; ++i) {
+    const float s = mf::wave_sum(acc[i]);
+    if (lane == 0) s_red[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNumOwn) {
+    const float s = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) +
+                    (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+    a.part[((int64_t)o * gridDim.x + blockIdx.x) * kNumOwn + threadIdx.x] = s;
+  }
+}
+
+// ---- launch 3: reduce, loss, chain rule, chainer-Adam -----------------------------
+// mode 0: write loss/gq/gt only.  mode 1: Adam update in place + refresh R|t.
+__global__ __launch_bounds__(256) void k_icc_step(IccArgs a, int NB, int mode, float *q, float *t,
+                                                  float *adam_m, float *adam_v, float alpha_q,
+                                                  float alpha_t, float *loss_out, float *gq_out,
+                                                  float *gt_out, float *traj, int it) {
+  extern __shared__ float s_tot[];  // [Ns][kNumOwn] then [Ns][12] G
+  __shared__ float s_coef[4];
+  const int sc = blockIdx.x;
+  const int ja = a.scene_off[sc], jb = a.scene_off[sc + 1];
+  const int Ns = jb - ja;
+  float *s_G = s_tot + Ns * kNumOwn;
+  for (int i = threadIdx.x; i < Ns * kNumOwn; i += blockDim.x) {
+    const int jo = i / kNumOwn, c = i % kNumOwn;
+    const float *p = a.part + (int64_t)(ja + jo) * NB * kNumOwn + c;
+    float s = 0.0f;
+    for (int b = 0; b < NB; ++b) s += p[(int64_t)b * kNumOwn];
+    s_tot[i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float RN = 0.0f, S_in = 0.0f, PN = 0.0f;
+    for (int jo = 0; jo < Ns; ++jo) {
+      RN += s_tot[jo * kNumOwn + 0];
+      S_in += s_tot[jo * kNumOwn + 1];
+      PN += s_tot[jo * kNumOwn + 2];
+    }
+    const float S_t = a.St[sc];
+    // iterative_collision_check_link.py:91-98
+    const float reward = RN / S_t, penalty = PN / S_in;
+    if (loss_out) loss_out[sc] = penalty - reward;
+    s_coef[0] = 1.0f / S_t;
+    s_coef[1] = 1.0f / S_in;
+    s_coef[2] = PN / (S_in * S_in);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Ns * 12; i += blockDim.x) {
+    const int jo = i / 12, c = i % 12;
+    const float *U = s_tot + jo * kNumOwn + 3;
+    const float oth = (float)((double)a.oth[(int64_t)(ja + jo) * 12 + c] / kFix);
+    s_G[i] = ((s_coef[0] * U[c] - s_coef[1] * U[12 + c]) + s_coef[2] * U[24 + c]) -
+             s_coef[1] * oth;
+  }
+  __syncthreads();
+  if (threadIdx.x < Ns) {
+    const int o = ja + threadIdx.x;
+    const float *G = s_G + threadIdx.x * 12;
+    float gR[9], gt[3], gq[4], qq[4], tt[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      gR[3 * d + 0] = G[4 * d + 0];
+      gR[3 * d + 1] = G[4 * d + 1];
+      gR[3 * d + 2] = G[4 * d + 2];
+      gt[d] = G[4 * d + 3];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qq[i] = q[4 * o + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tt[i] = t[3 * o + i];
+    quat_backward(qq, gR, gq);
+    if (gq_out) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gq_out[4 * o + i] = gq[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) gt_out[3 * o + i] = gt[i];
+    }
+    if (mode == 1) {
+      if (traj) {
+        float *tr = traj + ((int64_t)it * a.O + o) * 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tr[i] = qq[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tr[4 + i] = tt[i];
+      }
+      // chainer.optimizers.Adam (v7): alpha_t in double, then float32 update
+      const int step = a.step[sc] + 1;
+      const double fix1 = 1.0 - pow(0.9, (double)step), fix2 = 1.0 - pow(0.999, (double)step);
+      const float aq = (float)((double)alpha_q * sqrt(fix2) / fix1);
+      const float at = (float)((double)alpha_t * sqrt(fix2) / fix1);
+      const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-8f;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const float gi = i < 4 ? gq[i] : gt[i - 4];
+        float mm = adam_m[7 * o + i], vv = adam_v[7 * o + i];
+        mm += omb1 * (gi - mm);
+        vv += omb2 * (gi * gi - vv);
+        adam_m[7 * o + i] = mm;
+        adam_v[7 * o + i] = vv;
+        const float upd = (i < 4 ? aq : at) * mm / (sqrtf(vv) + eps);
+        if (i < 4) qq[i] -= upd; else tt[i - 4] -= upd;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[4 * o + i] = qq[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t[3 * o + i] = tt[i];
+      float R[9];
+      quat_to_R(qq, R);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) a.Rt[12 * o + i] = R[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a.Rt[12 * o + 9 + i] = tt[i];
+    }
+    // reset the per-iteration accumulators for the next launch 1 / 2
+    a.Mbits[2 * o] = 0;
+    a.Mbits[2 * o + 1] = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) a.oth[12 * o + i] = 0;
+  }
+  __syncthreads();
+  if (mode == 1 && threadIdx.x == 0) a.step[sc] += 1;
+}
+
+__global__ void k_pack(const float *__restrict__ points, const float *__restrict__ sdf, int64_t n,
+                       float4 *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = make_float4(points[3 * i], points[3 * i + 1], points[3 * i + 2], sdf[i]);
+}
+
+// ---- host side ---------------------------------------------------------------------
+inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+struct WsLayout {
+  int64_t W, M, Rt, bound, St, part, oth, step, total;
+  int NB;
+};
+
+WsLayout ws_layout(int O, int S, int D) {
+  WsLayout l;
+  const int64_t V = (int64_t)D * D * D;
+  l.NB = (int)((V + kVoxPerBlock - 1) / kVoxPerBlock);
+  int64_t off = 0;
+  l.W = off; off = align256(off + 2 * O * V * 8);
+  l.M = off; off = align256(off + 2 * O * 4);
+  l.Rt = off; off = align256(off + O * 12 * 4);
+  l.bound = off; off = align256(off + O * 4 * 4);
+  l.St = off; off = align256(off + S * 4);
+  l.part = off; off = align256(off + (int64_t)O * l.NB * kNumOwn * 4);
+  l.oth = off; off = align256(off + O * 12 * 8);
+  l.step = off; off = align256(off + S * 4);
+  l.total = off;
+  return l;
+}
+
+IccArgs make_args(const mfIccBatch *b, void *ws) {
+  IccArgs a;
+  a.pts4 = (const float4 *)b->pts4;
+  a.obj_off = b->obj_off;
+  a.scene_off = b->scene_off;
+  a.obj_scene = b->obj_scene;
+  a.pitch = b->pitch;
+  a.origin = b->origin;
+  a.grid_target = b->grid_target;
+  a.grid_ne = b->grid_ne;
+  a.O = b->n_objects;
+  a.S = b->n_scenes;
+  a.D = b->dim;
+  a.thr = b->voxel_threshold;
+  a.sdf_offset = b->sdf_offset;
+  const WsLayout l = ws_layout(a.O, a.S, a.D);
+  char *p = (char *)ws;
+  a.W = (unsigned long long *)(p + l.W);
+  a.Mbits = (uint32_t *)(p + l.M);
+  a.Rt = (float *)(p + l.Rt);
+  a.bound = (float *)(p + l.bound);
+  a.St = (float *)(p + l.St);
+  a.part = (float *)(p + l.part);
+  a.oth = (long long *)(p + l.oth);
+  a.step = (int32_t *)(p + l.step);
+  return a;
+}
+
+int ksize_host(float thr) {
+  // truncation / pitch == thr exactly (truncation = thr * pitch in float32 is exact for
+  // thr = 2; for other thresholds the float32 quotient is what the reference evaluates)
+  int ks = (int)ceilf(thr);
+  if (ks % 2 == 0) ks += 1;
+  return ks;
+}
+
+int max_scene_objects_host(const mfIccBatch *b, hipStream_t stream, int *out) {
+  std::vector<int32_t> so(b->n_scenes + 1);
+  MF_TRY(hipMemcpyAsync(so.data(), b->scene_off, sizeof(int32_t) * so.size(),
+                        hipMemcpyDeviceToHost, stream));
+  MF_TRY(hipStreamSynchronize(stream));
+  int m = 0;
+  for (int s = 0; s < b->n_scenes; ++s) m = std::max(m, so[s + 1] - so[s]);
+  *out = m;
+  return 0;
+}
+
+void launch_iteration(const IccArgs &a, int ks, int SX, int NB, int max_ns, int mode, float *q,
+                      float *t, float *adam_m, float *adam_v, float alpha_q, float alpha_t,
+                      float *loss, float *gq, float *gt, float *traj, int it, hipStream_t stream) {
+  const int D = a.D;
+  const dim3 g1((D + SX - 1) / SX, 2 * a.O);
+  const size_t lds1 = (size_t)SX * D * D * sizeof(unsigned long long);
+  if (ks == 3)
+    hipLaunchKernelGGL(k_icc_tdf<3>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
+  else
+    hipLaunchKernelGGL(k_icc_tdf<0>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
+  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), 0, stream, a, ks * ks * ks);
+  const size_t lds3 = (size_t)max_ns * (kNumOwn + 12) * sizeof(float);
+  hipLaunchKernelGGL(k_icc_step, dim3(a.S), dim3(256), lds3, stream, a, NB, mode, q, t, adam_m,
+                     adam_v, alpha_q, alpha_t, loss, gq, gt, traj, it);
+}
+
+struct GraphKey {
+  std::vector<uint64_t> v;
+  bool operator<(const GraphKey &o) const { return v < o.v; }
+};
+std::map<GraphKey, hipGraphExec_t> g_graphs;
+std::mutex g_graph_mu;
+
+}  // namespace
+
+extern "C" int64_t mf_icc_workspace_bytes(int32_t n_objects, int32_t n_scenes, int32_t dim) {
+  return ws_layout(n_objects, n_scenes, dim).total;
+}
+
+extern "C" int mf_pack_points_sdf(const float *points, const float *sdf, int64_t n, void *pts4,
+                                  mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, points, sdf,
+                     n, (float4 *)pts4);
+  return mf::check_launch("mf_pack_points_sdf");
+}
+
+static int icc_validate(const mfIccBatch *b) {
+  if (!b || b->n_objects <= 0 || b->n_scenes <= 0 || b->dim <= 0 || b->dim > 64 ||
+      (double)b->n_points * 343.0 >= 4294967295.0) {
+    mf::set_last_error(hipErrorInvalidValue, "mf_icc: invalid batch descriptor");
+    return -(int)hipErrorInvalidValue;
+  }
+  return 0;
+}
+
+static int slab_planes(int D, int n_grids) {
+  // tile <= 64 KB of keys; prefer >= 512 workgroups so that 256 CUs stay busy
+  int SX = std::max(1, std::min(D, 8192 / (D * D)));
+  while (SX > 1 && (int64_t)((D + SX - 1) / SX) * n_grids < 512) SX = (SX + 1) / 2;
+  return SX;
+}
+
+extern "C" int mf_icc_loss_grad(const mfIccBatch *batch, const float *q, const float *t,
+                                float *loss, float *gq, float *gt, void *ws,
+                                mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int e = icc_validate(batch)) return e;
+  IccArgs a = make_args(batch, ws);
+  int max_ns = 0;
+  if (int e = max_scene_objects_host(batch, stream, &max_ns)) return e;
+  const WsLayout l = ws_layout(a.O, a.S, a.D);
+  const int ks = ksize_host(a.thr);
+  const int SX = slab_planes(a.D, 2 * a.O);
+  hipLaunchKernelGGL(k_icc_bound, dim3(a.O), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_icc_scene_setup, dim3(a.S), dim3(256), 0, stream, a, 0);
+  hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t);
+  launch_iteration(a, ks, SX, l.NB, max_ns, 0, const_cast<float *>(q), const_cast<float *>(t),
+                   nullptr, nullptr, 0.0f, 0.0f, loss, gq, gt, nullptr, 0, stream);
+  return mf::check_launch("mf_icc_loss_grad");
+}
+
+extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float *adam_m,
+                             float *adam_v, int32_t n_iter, int32_t step0, float alpha_q,
+                             float alpha_t, float *losses, float *traj, void *ws,
+                             mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int e = icc_validate(batch)) return e;
+  if (n_iter <= 0) return 0;
+  IccArgs a = make_args(batch, ws);
+  const WsLayout l = ws_layout(a.O, a.S, a.D);
+  const int ks = ksize_host(a.thr);
+  const int SX = slab_planes(a.D, 2 * a.O);
+
+  GraphKey key;
+  auto push = [&](const void *p) { key.v.push_back((uint64_t)(uintptr_t)p); };
+  push(batch->pts4); push(batch->obj_off); push(batch->scene_off); push(batch->obj_scene);
+  push(batch->pitch); push(batch->origin); push(batch->grid_target); push(batch->grid_ne);
+  push(q); push(t); push(adam_m); push(adam_v); push(losses); push(traj); push(ws);
+  uint32_t fb[4];
+  memcpy(&fb[0], &alpha_q, 4); memcpy(&fb[1], &alpha_t, 4);
+  memcpy(&fb[2], &a.thr, 4); memcpy(&fb[3], &a.sdf_offset, 4);
+  key.v.push_back(((uint64_t)fb[0] << 32) | fb[1]);
+  key.v.push_back(((uint64_t)fb[2] << 32) | fb[3]);
+  key.v.push_back(((uint64_t)(uint32_t)a.O << 32) | (uint32_t)a.S);
+  key.v.push_back(((uint64_t)(uint32_t)a.D << 32) | (uint32_t)batch->n_points);
+  key.v.push_back(((uint64_t)(uint32_t)n_iter << 32) | (uint32_t)step0);
+
+  std::lock_guard<std::mutex> lock(g_graph_mu);
+  auto itg = g_graphs.find(key);
+  if (itg == g_graphs.end()) {
+    int max_ns = 0;
+    if (int e = max_scene_objects_host(batch, stream, &max_ns)) return e;
+    hipGraph_t graph = nullptr;
+    // The caller's stream may be the legacy NULL stream (torch's default), which cannot be
+    // captured: record the graph on a private stream, replay it on the caller's.
+    static hipStream_t cap = nullptr;
+    if (!cap) MF_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    MF_TRY(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    hipLaunchKernelGGL(k_icc_bound, dim3(a.O), dim3(256), 0, cap, a);
+    hipLaunchKernelGGL(k_icc_scene_setup, dim3(a.S), dim3(256), 0, cap, a, step0);
+    hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, cap, a, q, t);
+    for (int it = 0; it < n_iter; ++it)
+      launch_iteration(a, ks, SX, l.NB, max_ns, 1, q, t, adam_m, adam_v, alpha_q, alpha_t,
+                       losses ? losses + (int64_t)it * a.S : nullptr, nullptr, nullptr, traj, it,
+                       cap);
+    hipError_t ce = hipStreamEndCapture(cap, &graph);
+    if (ce != hipSuccess) {
+      mf::set_last_error(ce, "hipStreamEndCapture(icc)");
+      return -(int)ce;
+    }
+    hipGraphExec_t exec = nullptr;
+    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) {
+      mf::set_last_error(ie, "hipGraphInstantiate(icc)");
+      return -(int)ie;
+    }
+    if (g_graphs.size() >= 64) {  // bounded cache
+      for (auto &kv : g_graphs) (void)hipGraphExecDestroy(kv.second);
+      g_graphs.clear();
+    }
+    itg = g_graphs.emplace(key, exec).first;
+  }
+  MF_TRY(hipGraphLaunch(itg->second, stream));
+  return 0;
+}

@@ -1,0 +1,255 @@
+// interpolate_voxel_grid forward / backward for gfx950.
+//
+// Reference: morefusion/functions/geometry/interpolate_voxel_grid.py:159-214 (K5),
+// :216-268 (K6): one thread per (point, channel), 8 corner gathers each from a
+// channel-major [B,C,X,Y,Z] grid -> every corner read of neighbouring threads is
+// X*Y*Z*4 bytes apart (uncoalesced), and the backward is 8 float atomics per thread
+// into a zero-filled global tensor.
+//
+// MI355X design: a workgroup owns (batch item b, chunk of `cpw` channels) and stages
+// that chunk of the grid in LDS with coalesced 16 B loads (the grid is read from HBM
+// exactly once); the points of item b then gather their 8 corners from LDS.
+// Backward mirrors it: ds_add_f32 into an LDS-resident chunk, one coalesced write-out
+// (gvox is written completely -- no memset, no global atomics).
+// 16^3 x 4 ch = 64 KB, 8^3 x 32 ch = 64 KB -> two workgroups per CU (160 KB LDS).
+#include <algorithm>
+
+#include "mf_common.h"
+
+namespace {
+
+constexpr int kInterpThreads = 256;
+
+struct Corner {
+  int off[8];
+  float w[8];
+};
+
+// Weights/offsets in the reference's order w000,w100,w010,w001,w110,w011,w101,w111
+// (interpolate_voxel_grid.py:27-58); low = (int)coord (trunc toward zero, :11-13);
+// out-of-grid corners get offset -1.
+__device__ __forceinline__ void corners(float px, float py, float pz, int X, int Y, int Z,
+                                        Corner &k) {
+  int lx = (int)px, ly = (int)py, lz = (int)pz;
+  float fx = px - (float)lx, fy = py - (float)ly, fz = pz - (float)lz;
+  float hx = 1.0f - fx, hy = 1.0f - fy, hz = 1.0f - fz;
+  const int dx[8] = {0, 1, 0, 0, 1, 0, 1, 1};
+  const int dy[8] = {0, 0, 1, 0, 1, 1, 0, 1};
+  const int dz[8] = {0, 0, 0, 1, 0, 1, 1, 1};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int ix = lx + dx[j], iy = ly + dy[j], iz = lz + dz[j];
+    bool ok = ix >= 0 && ix < X && iy >= 0 && iy < Y && iz >= 0 && iz < Z;
+    k.off[j] = ok ? (ix * Y + iy) * Z + iz : -1;
+    k.w[j] = ((dx[j] ? fx : hx) * (dy[j] ? fy : hy)) * (dz[j] ? fz : hz);
+  }
+}
+
+// Finite coordinates far outside the grid would overflow (int)coord; clamp the test.
+__device__ __forceinline__ bool plausible(float px, float py, float pz) {
+  const float L = 1.0e9f;
+  return fabsf(px) < L && fabsf(py) < L && fabsf(pz) < L;  // false for NaN too
+}
+
+// grid: x = channel chunk, y = batch item.  LDS: cpw * V floats.
+__global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_lds(
+    const float *__restrict__ vox, const float *__restrict__ points,
+    const int32_t *__restrict__ batch_indices, int64_t n, int C, int X, int Y, int Z, int cpw,
+    float *__restrict__ values, int channels_first) {
+  extern __shared__ __attribute__((aligned(16))) float s_grid[];
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * cpw;
+  const int nc = min(cpw, C - c0);
+  const int V = X * Y * Z;
+  const float *src = vox + ((int64_t)b * C + c0) * V;
+  const int total = nc * V;
+  if ((V & 3) == 0) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(s_grid);
+    for (int i = threadIdx.x; i < total / 4; i += kInterpThreads) d4[i] = s4[i];
+  } else {
+    for (int i = threadIdx.x; i < total; i += kInterpThreads) s_grid[i] = src[i];
+  }
+  __syncthreads();
+  for (int64_t p = threadIdx.x; p < n; p += kInterpThreads) {
+    if (batch_indices[p] != b) continue;
+    float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+    Corner k;
+    if (plausible(px, py, pz)) {
+      corners(px, py, pz, X, Y, Z, k);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { k.off[j] = -1; k.w[j] = 0.0f; }
+    }
+    for (int c = 0; c < nc; ++c) {
+      const float *g = s_grid + c * V;
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k.off[j] >= 0) acc += k.w[j] * g[k.off[j]];
+      if (channels_first)
+        values[(int64_t)(c0 + c) * n + p] = acc;
+      else
+        values[p * C + c0 + c] = acc;
+    }
+  }
+}
+
+// Fallback for grids too large for LDS: direct gathers (thread per point x channel chunk).
+__global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_direct(
+    const float *__restrict__ vox, const float *__restrict__ points,
+    const int32_t *__restrict__ batch_indices, int64_t n, int B, int C, int X, int Y, int Z,
+    float *__restrict__ values, int channels_first) {
+  int64_t p = (int64_t)blockIdx.x * kInterpThreads + threadIdx.x;
+  if (p >= n) return;
+  const int b = batch_indices[p];
+  const int V = X * Y * Z;
+  float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+  Corner k;
+  bool ok = plausible(px, py, pz) && b >= 0 && b < B;
+  if (ok) corners(px, py, pz, X, Y, Z, k);
+  for (int c = blockIdx.y; c < C; c += gridDim.y) {
+    float acc = 0.0f;
+    if (ok) {
+      const float *g = vox + ((int64_t)b * C + c) * V;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k.off[j] >= 0) acc += k.w[j] * g[k.off[j]];
+    }
+    if (channels_first)
+      values[(int64_t)c * n + p] = acc;
+    else
+      values[p * C + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(kInterpThreads) void k_interp_bwd_lds(
+    const float *__restrict__ gvalues, const float *__restrict__ points,
+    const int32_t *__restrict__ batch_indices, int64_t n, int C, int X, int Y, int Z, int cpw,
+    float *__restrict__ gvox, int channels_first) {
+  extern __shared__ __attribute__((aligned(16))) float s_grid[];
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * cpw;
+  const int nc = min(cpw, C - c0);
+  const int V = X * Y * Z;
+  const int total = nc * V;
+  for (int i = threadIdx.x; i < total; i += kInterpThreads) s_grid[i] = 0.0f;
+  __syncthreads();
+  for (int64_t p = threadIdx.x; p < n; p += kInterpThreads) {
+    if (batch_indices[p] != b) continue;
+    float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+    if (!plausible(px, py, pz)) continue;
+    Corner k;
+    corners(px, py, pz, X, Y, Z, k);
+    for (int c = 0; c < nc; ++c) {
+      float g = channels_first ? gvalues[(int64_t)(c0 + c) * n + p] : gvalues[p * C + c0 + c];
+      float *dst = s_grid + c * V;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k.off[j] >= 0) atomicAdd(&dst[k.off[j]], k.w[j] * g);
+    }
+  }
+  __syncthreads();
+  float *out = gvox + ((int64_t)b * C + c0) * V;
+  if ((V & 3) == 0) {
+    float4 *o4 = reinterpret_cast<float4 *>(out);
+    const float4 *s4 = reinterpret_cast<const float4 *>(s_grid);
+    for (int i = threadIdx.x; i < total / 4; i += kInterpThreads) o4[i] = s4[i];
+  } else {
+    for (int i = threadIdx.x; i < total; i += kInterpThreads) out[i] = s_grid[i];
+  }
+}
+
+__global__ __launch_bounds__(kInterpThreads) void k_interp_bwd_direct(
+    const float *__restrict__ gvalues, const float *__restrict__ points,
+    const int32_t *__restrict__ batch_indices, int64_t n, int B, int C, int X, int Y, int Z,
+    float *__restrict__ gvox, int channels_first) {
+  int64_t p = (int64_t)blockIdx.x * kInterpThreads + threadIdx.x;
+  if (p >= n) return;
+  const int b = batch_indices[p];
+  const int V = X * Y * Z;
+  float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+  if (!(plausible(px, py, pz) && b >= 0 && b < B)) return;
+  Corner k;
+  corners(px, py, pz, X, Y, Z, k);
+  for (int c = blockIdx.y; c < C; c += gridDim.y) {
+    float g = channels_first ? gvalues[(int64_t)c * n + p] : gvalues[p * C + c];
+    float *dst = gvox + ((int64_t)b * C + c) * V;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (k.off[j] >= 0) atomicAdd(&dst[k.off[j]], k.w[j] * g);
+  }
+}
+
+constexpr int kMaxLds = 160 * 1024;
+
+// channels per workgroup: fill <= 64 KB of LDS (2 WGs/CU) but keep the grid large.
+int pick_cpw(int C, int B, int64_t V) {
+  int64_t bytes_per_ch = V * 4;
+  int cpw = (int)std::max<int64_t>(1, (64 * 1024) / bytes_per_ch);
+  cpw = std::min(cpw, C);
+  while (cpw > 1 && (int64_t)B * ((C + cpw - 1) / cpw) < 512) cpw >>= 1;
+  return cpw;
+}
+
+}  // namespace
+
+extern "C" int mf_interpolate_voxel_grid_fwd(const float *vox, const float *points,
+                                             const int32_t *batch_indices, int64_t n, int B,
+                                             int C, int X, int Y, int Z, float *values,
+                                             int channels_first, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0 || C == 0) return 0;
+  const int64_t V = (int64_t)X * Y * Z;
+  if (V * 4 <= kMaxLds) {
+    const int cpw = pick_cpw(C, B, V);
+    const size_t lds = (size_t)cpw * V * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      MF_TRY(hipFuncSetAttribute((const void *)k_interp_fwd_lds,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_interp_fwd_lds, dim3((C + cpw - 1) / cpw, B), dim3(kInterpThreads), lds,
+                       stream, vox, points, batch_indices, n, C, X, Y, Z, cpw, values,
+                       channels_first);
+  } else {
+    hipLaunchKernelGGL(k_interp_fwd_direct,
+                       dim3((unsigned)((n + kInterpThreads - 1) / kInterpThreads),
+                            std::min(C, 64)),
+                       dim3(kInterpThreads), 0, stream, vox, points, batch_indices, n, B, C, X, Y,
+                       Z, values, channels_first);
+  }
+  return mf::check_launch("mf_interpolate_voxel_grid_fwd");
+}
+
+extern "C" int mf_interpolate_voxel_grid_bwd(const float *gvalues, const float *points,
+                                             const int32_t *batch_indices, int64_t n, int B,
+                                             int C, int X, int Y, int Z, float *gvox,
+                                             int channels_first, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t V = (int64_t)X * Y * Z;
+  if (C == 0 || B == 0 || V == 0) return 0;
+  if (V * 4 <= kMaxLds) {
+    const int cpw = pick_cpw(C, B, V);
+    const size_t lds = (size_t)cpw * V * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      MF_TRY(hipFuncSetAttribute((const void *)k_interp_bwd_lds,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_interp_bwd_lds, dim3((C + cpw - 1) / cpw, B), dim3(kInterpThreads), lds,
+                       stream, gvalues, points, batch_indices, n, C, X, Y, Z, cpw, gvox,
+                       channels_first);
+  } else {
+    MF_TRY(hipMemsetAsync(gvox, 0, sizeof(float) * B * C * V, stream));
+    if (n > 0)
+      hipLaunchKernelGGL(k_interp_bwd_direct,
+                         dim3((unsigned)((n + kInterpThreads - 1) / kInterpThreads),
+                              std::min(C, 64)),
+                         dim3(kInterpThreads), 0, stream, gvalues, points, batch_indices, n, B, C,
+                         X, Y, Z, gvox, channels_first);
+  }
+  return mf::check_launch("mf_interpolate_voxel_grid_bwd");
+}

@@ -1,0 +1,240 @@
+// truncated_distance_function forward / backward, pseudo-occupancy weights (gfx950).
+//
+// Reference: morefusion/functions/geometry/truncated_distance_function.py:21-103
+// (K7: one thread per (point, kernel offset); float atomicMin on a global grid, then
+// a racy atomicExch of the candidate id), :105-166 (K8), :181-213 (weights).
+//
+// MI355X design: a workgroup owns a tile of the voxel grid in LDS as packed 64-bit
+// keys (distance bits << 32 | flat candidate id).  Distances are >= 0, so unsigned
+// integer order == float order and ONE ds_min_u64 per candidate yields the exact
+// minimum AND a deterministic arg-min (lowest flat id among equal distances) -- the
+// reference's two-atomic sequence can record a non-minimal writer.  A 32-bit peek at
+// the current minimum skips the atomic for candidates that cannot win (most of
+// them: every voxel sees ~20 candidates).  Tiles are x-slabs (optionally split in
+// y) of <= 64 KB, so two workgroups share a CU's 160 KB LDS; every workgroup streams
+// the whole point list (12 B/point, L2-resident) and keeps only candidates that land
+// in its tile.  No global atomics, no pre-filled global grids, one coalesced write.
+#include <algorithm>
+
+#include "mf_common.h"
+
+namespace mf {
+
+__device__ __forceinline__ int tdf_ksize(float pitch, float trunc) {
+  int ks = (int)ceilf(trunc / pitch);
+  return (ks & 1) ? ks : ks + 1;
+}
+
+}  // namespace mf
+
+namespace {
+
+constexpr int kTdfThreads = 256;
+constexpr unsigned long long kNoCand = 0xffffffffull;
+
+// Kernel offsets follow numpy.meshgrid's default 'xy' indexing used at
+// truncated_distance_function.py:39-41: flat k = (a*ks + b)*ks + c  ->  (b, a, c) - ks/2.
+template <int KS>
+__global__ __launch_bounds__(kTdfThreads) void k_tdf_fwd(const float *__restrict__ points,
+                                                         int64_t P, float pitch, float ox,
+                                                         float oy, float oz, int X, int Y, int Z,
+                                                         float trunc, int ks_rt, int SX, int SY,
+                                                         float *__restrict__ tdf,
+                                                         int32_t *__restrict__ flat) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];
+  const int ks = KS > 0 ? KS : ks_rt;
+  const int h = ks / 2, K = ks * ks * ks;
+  const int x0 = blockIdx.x * SX, y0 = blockIdx.y * SY;
+  const int sx = min(SX, X - x0), sy = min(SY, Y - y0);
+  const int nvox = sx * sy * Z;
+  const unsigned long long init = ((unsigned long long)__float_as_uint(trunc) << 32) | kNoCand;
+  for (int i = threadIdx.x; i < nvox; i += kTdfThreads) s_key[i] = init;
+  __syncthreads();
+  const uint32_t *s_hi = reinterpret_cast<const uint32_t *>(s_key);
+  const float fh = (float)h;
+  for (int64_t p = threadIdx.x; p < P; p += kTdfThreads) {
+    float fx = (points[3 * p] - ox) / pitch;
+    float fy = (points[3 * p + 1] - oy) / pitch;
+    float fz = (points[3 * p + 2] - oz) / pitch;
+    float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
+    // neighbourhood vs tile (false for NaN)
+    if (!(rx + fh >= (float)x0 && rx - fh < (float)(x0 + sx) && ry + fh >= (float)y0 &&
+          ry - fh < (float)(y0 + sy) && rz + fh >= 0.0f && rz - fh < (float)Z))
+      continue;
+    const int irx = (int)rx, iry = (int)ry, irz = (int)rz;
+#pragma unroll
+    for (int a = 0; a < ks; ++a) {
+      const int iy = iry + a - h;
+      if (iy < y0 || iy >= y0 + sy) continue;
+      const float dy = fy - (float)iy;
+#pragma unroll
+      for (int b = 0; b < ks; ++b) {
+        const int ix = irx + b - h;
+        if (ix < x0 || ix >= x0 + sx) continue;
+        const float dx = fx - (float)ix;
+        const float dxy = dx * dx + dy * dy;
+#pragma unroll
+        for (int c = 0; c < ks; ++c) {
+          const int iz = irz + c - h;
+          if (iz < 0 || iz >= Z) continue;
+          const float dz = fz - (float)iz;
+          const float dist = pitch * sqrtf(dxy + dz * dz);
+          if (dist < trunc) {
+            const int li = ((ix - x0) * sy + (iy - y0)) * Z + iz;
+            const uint32_t db = __float_as_uint(dist);
+            if (db <= s_hi[2 * li + 1]) {
+              const uint32_t id = (uint32_t)(p * K + (a * ks + b) * ks + c);
+              atomicMin(&s_key[li], ((unsigned long long)db << 32) | id);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nvox; i += kTdfThreads) {
+    const unsigned long long k = s_key[i];
+    const int iz = i % Z, iy = (i / Z) % sy, ix = i / (Z * sy);
+    const int64_t g = ((int64_t)(x0 + ix) * Y + (y0 + iy)) * Z + iz;
+    tdf[g] = __uint_as_float((uint32_t)(k >> 32));
+    const uint32_t lo = (uint32_t)k;
+    flat[g] = lo == 0xffffffffu ? -1 : (int32_t)lo;
+  }
+}
+
+// One thread per voxel (truncated_distance_function.py:121-146).  The voxel IS
+// round(p_f)+kernel[k], so k is not needed to rebuild the unit vector.
+__global__ __launch_bounds__(256) void k_tdf_bwd(const float *__restrict__ gtdf,
+                                                 const float *__restrict__ points,
+                                                 const int32_t *__restrict__ flat, float pitch,
+                                                 float ox, float oy, float oz, int X, int Y,
+                                                 int Z, int K, float *__restrict__ gpoints) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= X * Y * Z) return;
+  const int f = flat[v];
+  if (f < 0) return;
+  const int p = f / K;
+  const int iz = v % Z, iy = (v / Z) % Y, ix = v / (Z * Y);
+  const float dx = (points[3 * p] - ox) / pitch - (float)ix;
+  const float dy = (points[3 * p + 1] - oy) / pitch - (float)iy;
+  const float dz = (points[3 * p + 2] - oz) / pitch - (float)iz;
+  const float n = sqrtf((dx * dx + dy * dy) + dz * dz);
+  if (n > 0.0f) {
+    const float g = gtdf[v];
+    atomicAdd(&gpoints[3 * p], dx / n * g);
+    atomicAdd(&gpoints[3 * p + 1], dy / n * g);
+    atomicAdd(&gpoints[3 * p + 2], dz / n * g);
+  }
+}
+
+// truncated_distance_function.py:198-204, pass 1: raw inside weight + its maximum.
+__global__ __launch_bounds__(256) void k_pocc_wraw(const int32_t *__restrict__ flat,
+                                                   const float *__restrict__ sdf, int V, int K,
+                                                   float sdf_offset, float *__restrict__ win,
+                                                   float *__restrict__ wsurf,
+                                                   uint32_t *__restrict__ wmax_bits) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  float w = 0.0f;
+  if (v < V) {
+    const int f = flat[v];
+    w = (f >= 0 ? sdf[f / K] : -1.0f) + sdf_offset;
+    const bool neg = w < 0.0f;
+    if (neg) w = 0.0f;
+    win[v] = w;
+    wsurf[v] = neg ? 0.0f : 1.0f;  // marker, finished in pass 2
+  }
+  float m = mf::wave_max(w);
+  if ((threadIdx.x & 63) == 0) atomicMax(wmax_bits, __float_as_uint(m));  // w >= 0
+}
+
+// :204-213, pass 2: normalise, surface weight, the three weighted grids.
+__global__ __launch_bounds__(256) void k_pocc_grids(const float *__restrict__ tdf, int V,
+                                                    float trunc,
+                                                    const uint32_t *__restrict__ wmax_bits,
+                                                    float *__restrict__ win,
+                                                    float *__restrict__ wsurf,
+                                                    float *__restrict__ grids) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const float M = __uint_as_float(*wmax_bits);
+  const float wi = win[v] / M;  // 0/0 -> NaN exactly like the reference
+  const float ws = wsurf[v] != 0.0f ? 1.0f - wi : wi;
+  const float g = 1.0f - tdf[v] / trunc;
+  win[v] = wi;
+  wsurf[v] = ws;
+  grids[v] = g;
+  grids[V + v] = g * ws;
+  grids[2 * V + v] = g * wi;
+}
+
+}  // namespace
+
+extern "C" int mf_truncated_distance_function_fwd(const float *points, int64_t P, float pitch,
+                                                  float ox, float oy, float oz, int X, int Y,
+                                                  int Z, float truncation, float *tdf,
+                                                  int32_t *flat, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if ((int64_t)X * Y * Z == 0) return 0;
+  int ks = (int)ceilf(truncation / pitch);
+  if (ks % 2 == 0) ks += 1;
+  if ((double)P * ks * ks * ks >= 4294967295.0) {
+    mf::set_last_error(hipErrorInvalidValue, "tdf: P*K exceeds 32-bit candidate ids");
+    return -(int)hipErrorInvalidValue;
+  }
+  // tile: <= 8192 voxels (64 KB of keys); split x first, then y.
+  const int cap = 8192;
+  int SX, SY;
+  if (Z > cap) {
+    mf::set_last_error(hipErrorInvalidValue, "tdf: Z dimension too large for an LDS tile");
+    return -(int)hipErrorInvalidValue;
+  }
+  if ((int64_t)Y * Z <= cap) {
+    SY = Y;
+    SX = std::max(1, std::min(X, cap / (Y * Z)));
+    // keep at least ~8 workgroups when the grid allows it
+    while (SX > 1 && (X + SX - 1) / SX < 8) SX = (SX + 1) / 2;
+  } else {
+    SX = 1;
+    SY = std::max(1, cap / Z);
+  }
+  dim3 grid((X + SX - 1) / SX, (Y + SY - 1) / SY);
+  const size_t lds = (size_t)SX * SY * Z * sizeof(unsigned long long);
+  if (ks == 3)
+    hipLaunchKernelGGL(k_tdf_fwd<3>, grid, dim3(kTdfThreads), lds, stream, points, P, pitch, ox,
+                       oy, oz, X, Y, Z, truncation, ks, SX, SY, tdf, flat);
+  else
+    hipLaunchKernelGGL(k_tdf_fwd<0>, grid, dim3(kTdfThreads), lds, stream, points, P, pitch, ox,
+                       oy, oz, X, Y, Z, truncation, ks, SX, SY, tdf, flat);
+  return mf::check_launch("mf_truncated_distance_function_fwd");
+}
+
+extern "C" int mf_truncated_distance_function_bwd(const float *gtdf, const float *points,
+                                                  const int32_t *flat, int64_t P, float pitch,
+                                                  float ox, float oy, float oz, int X, int Y,
+                                                  int Z, float truncation, float *gpoints,
+                                                  mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int V = X * Y * Z;
+  if (V == 0 || P == 0) return 0;
+  int ks = (int)ceilf(truncation / pitch);
+  if (ks % 2 == 0) ks += 1;
+  hipLaunchKernelGGL(k_tdf_bwd, dim3((V + 255) / 256), dim3(256), 0, stream, gtdf, points, flat,
+                     pitch, ox, oy, oz, X, Y, Z, ks * ks * ks, gpoints);
+  return mf::check_launch("mf_truncated_distance_function_bwd");
+}
+
+extern "C" int mf_pseudo_occupancy_weights(const float *tdf, const int32_t *flat,
+                                           const float *sdf, int X, int Y, int Z, int K,
+                                           float truncation, float sdf_offset, float *grids,
+                                           float *wsurf, float *win, float *wmax,
+                                           mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int V = X * Y * Z;
+  if (V == 0) return 0;
+  MF_TRY(hipMemsetAsync(wmax, 0, sizeof(float), stream));
+  hipLaunchKernelGGL(k_pocc_wraw, dim3((V + 255) / 256), dim3(256), 0, stream, flat, sdf, V, K,
+                     sdf_offset, win, wsurf, (uint32_t *)wmax);
+  hipLaunchKernelGGL(k_pocc_grids, dim3((V + 255) / 256), dim3(256), 0, stream, tdf, V, truncation,
+                     (const uint32_t *)wmax, win, wsurf, grids);
+  return mf::check_launch("mf_pseudo_occupancy_weights");
+}

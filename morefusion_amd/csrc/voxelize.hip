@@ -1,0 +1,314 @@
+// average_voxelization_3d / max_voxelization_3d for gfx950.
+//
+// Reference: morefusion/functions/geometry/average_voxelization_3d.py:42-118 (K1),
+// :146-220 (K2); max_voxelization_3d.py:58-138 (K3), :140-185 (K4).
+//
+// MI355X design (not the reference's thread-per-(point,channel) float atomics into
+// a zero-filled [B,C,X,Y,Z] tensor followed by nonzero/divide launches):
+//   1. link pass   -- one thread per point: integer atomics only (count += 1,
+//                     head = exch(point id)) build a per-voxel chain.  128 KB of
+//                     int32 per 32^3 object instead of 2 x 18.9 MB of atomics targets.
+//   2. write pass  -- output-stationary: every element of the dense [B,C,X,Y,Z]
+//                     result is written exactly once, 16 B per lane, fully coalesced;
+//                     the ~3 % occupied voxels sum their chain in increasing point
+//                     index (== the CPU loop order, so bit-equal to forward_cpu and
+//                     run-to-run deterministic), divide, and store.  No memset of the
+//                     output, no float atomics, no nonzero(): HBM traffic is the
+//                     compulsory C*V*4 bytes per object.
+#include <algorithm>
+
+#include "mf_common.h"
+
+namespace {
+
+__device__ __forceinline__ bool voxel_of(const float *__restrict__ points, int64_t i, float ox,
+                                         float oy, float oz, float pitch, int X, int Y, int Z,
+                                         int &v, bool &has_nan) {
+  float x = points[3 * i], y = points[3 * i + 1], z = points[3 * i + 2];
+  has_nan = (x != x) || (y != y) || (z != z);
+  float rx = roundf(mf::voxel_coord(x, ox, pitch));
+  float ry = roundf(mf::voxel_coord(y, oy, pitch));
+  float rz = roundf(mf::voxel_coord(z, oz, pitch));
+  bool ok = rx >= 0.0f && rx < (float)X && ry >= 0.0f && ry < (float)Y && rz >= 0.0f &&
+            rz < (float)Z;
+  v = ok ? ((int)rx * Y + (int)ry) * Z + (int)rz : -1;
+  return ok;
+}
+
+__global__ __launch_bounds__(256) void k_avgvox_link(const float *__restrict__ points,
+                                                     const int32_t *__restrict__ batch_indices,
+                                                     int64_t n, int B, int X, int Y, int Z,
+                                                     float ox, float oy, float oz, float pitch,
+                                                     int32_t *__restrict__ counts,
+                                                     int32_t *__restrict__ head,
+                                                     int32_t *__restrict__ link,
+                                                     int32_t *__restrict__ nan_flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int v;
+  bool has_nan;
+  bool ok = voxel_of(points, i, ox, oy, oz, pitch, X, Y, Z, v, has_nan);
+  if (has_nan && nan_flag) atomicOr(nan_flag, 1);
+  int b = batch_indices[i];
+  ok = ok && b >= 0 && b < B;
+  int32_t l = -2;
+  if (ok) {
+    int64_t key = (int64_t)b * X * Y * Z + v;
+    atomicAdd(&counts[key], 1);
+    l = atomicExch(&head[key], (int32_t)i);
+  }
+  link[i] = l;
+}
+
+// Sum of values[:, c] over the chain of voxel `key`, in increasing point index.
+__device__ __forceinline__ float chain_mean(const float *__restrict__ values,
+                                            const int32_t *__restrict__ link, int32_t h, int cnt,
+                                            int C, int c) {
+  if (cnt == 1) return values[(int64_t)h * C + c] / 1.0f;
+  float s = 0.0f;
+  int last = -1;
+  for (int k = 0; k < cnt; ++k) {
+    int best = 0x7fffffff;
+    for (int m = h; m >= 0; m = link[m])
+      if (m > last && m < best) best = m;
+    s += values[(int64_t)best * C + c];
+    last = best;
+  }
+  return s / (float)cnt;
+}
+
+// grid: x = voxel tiles of 256*VEC, y = channel chunks of cpw, z = batch item.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_avgvox_write(const float *__restrict__ values,
+                                                      const int32_t *__restrict__ counts,
+                                                      const int32_t *__restrict__ head,
+                                                      const int32_t *__restrict__ link, int C,
+                                                      int V, int cpw, float *__restrict__ matrix) {
+  const int b = blockIdx.z;
+  const int v0 = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (v0 >= V) return;
+  const int c0 = blockIdx.y * cpw;
+  const int c1 = min(C, c0 + cpw);
+  const int64_t kb = (int64_t)b * V + v0;
+  int cnt[VEC], hd[VEC];
+  bool any = false;
+  if (VEC == 4) {
+    int4 c4 = *reinterpret_cast<const int4 *>(counts + kb);
+    cnt[0] = c4.x; cnt[1 % VEC] = c4.y; cnt[2 % VEC] = c4.z; cnt[3 % VEC] = c4.w;
+  } else {
+    cnt[0] = counts[kb];
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    hd[j] = -1;
+    if (cnt[j] > 0) { hd[j] = head[kb + j]; any = true; }
+  }
+  float *out = matrix + ((int64_t)b * C + c0) * V + v0;
+  for (int c = c0; c < c1; ++c, out += V) {
+    float r[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) r[j] = 0.0f;
+    if (any) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        if (cnt[j] > 0) r[j] = chain_mean(values, link, hd[j], cnt[j], C, c);
+    }
+    if (VEC == 4) {
+      *reinterpret_cast<float4 *>(out) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+    } else {
+      out[0] = r[0];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_avgvox_bwd(const float *__restrict__ gmatrix,
+                                                    const float *__restrict__ points,
+                                                    const int32_t *__restrict__ batch_indices,
+                                                    const int32_t *__restrict__ counts, int64_t n,
+                                                    int C, int B, int X, int Y, int Z, float ox,
+                                                    float oy, float oz, float pitch,
+                                                    float *__restrict__ gvalues) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over n*C
+  if (i >= n * C) return;
+  int64_t p = i / C;
+  int c = (int)(i - p * C);
+  int v;
+  bool has_nan;
+  bool ok = voxel_of(points, p, ox, oy, oz, pitch, X, Y, Z, v, has_nan);
+  int b = batch_indices[p];
+  float g = 0.0f;
+  if (ok && b >= 0 && b < B) {
+    int64_t V = (int64_t)X * Y * Z;
+    g = gmatrix[((int64_t)b * C + c) * V + v] / (float)counts[(int64_t)b * V + v];
+  }
+  gvalues[i] = g;
+}
+
+// ---- max voxelization -----------------------------------------------------
+__device__ __forceinline__ uint32_t orderable(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void k_maxvox_key(const float *__restrict__ points,
+                                                    const int32_t *__restrict__ batch_indices,
+                                                    const float *__restrict__ intensities,
+                                                    int64_t n, int B, int X, int Y, int Z, float ox,
+                                                    float oy, float oz, float pitch,
+                                                    unsigned long long *__restrict__ key,
+                                                    int32_t *__restrict__ nan_flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int v;
+  bool has_nan;
+  bool ok = voxel_of(points, i, ox, oy, oz, pitch, X, Y, Z, v, has_nan);
+  if (has_nan && nan_flag) atomicOr(nan_flag, 1);
+  int b = batch_indices[i];
+  if (!(ok && b >= 0 && b < B)) return;
+  // max intensity first, then LOWEST point index: (orderable(intensity), ~i)
+  unsigned long long k =
+      ((unsigned long long)orderable(intensities[i]) << 32) | (0xffffffffu - (uint32_t)i);
+  atomicMax(&key[(int64_t)b * X * Y * Z + v], k);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_maxvox_write(const float *__restrict__ values,
+                                                      const unsigned long long *__restrict__ key,
+                                                      int C, int V, int cpw,
+                                                      float *__restrict__ matrix,
+                                                      int32_t *__restrict__ indices) {
+  const int b = blockIdx.z;
+  const int v0 = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (v0 >= V) return;
+  const int c0 = blockIdx.y * cpw;
+  const int c1 = min(C, c0 + cpw);
+  const int64_t kb = (int64_t)b * V + v0;
+  int idx[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    unsigned long long k = key[kb + j];
+    idx[j] = k ? (int)(0xffffffffu - (uint32_t)(k & 0xffffffffu)) : -1;
+    if (blockIdx.y == 0) indices[kb + j] = idx[j];
+  }
+  float *out = matrix + ((int64_t)b * C + c0) * V + v0;
+  for (int c = c0; c < c1; ++c, out += V) {
+    float r[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) r[j] = idx[j] >= 0 ? values[(int64_t)idx[j] * C + c] : 0.0f;
+    if (VEC == 4) {
+      *reinterpret_cast<float4 *>(out) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+    } else {
+      out[0] = r[0];
+    }
+  }
+}
+
+// A point wins at most one voxel (its own), so the backward scatter needs no atomics.
+__global__ __launch_bounds__(256) void k_maxvox_bwd(const float *__restrict__ gmatrix,
+                                                    const int32_t *__restrict__ indices, int C,
+                                                    int64_t V, int64_t total,
+                                                    float *__restrict__ gvalues) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*C*V
+  if (i >= total) return;
+  int64_t v = i % V;
+  int64_t bc = i / V;
+  int c = (int)(bc % C);
+  int64_t b = bc / C;
+  int n = indices[b * V + v];
+  if (n >= 0) gvalues[(int64_t)n * C + c] = gmatrix[i];
+}
+
+// channels per workgroup: enough workgroups to cover 256 CUs several times, but
+// keep >= 2 channels so the per-thread count/head loads amortise.
+int pick_cpw(int C, int B, int tiles) {
+  int cpw = 16;
+  while (cpw > 2 && (int64_t)tiles * B * ((C + cpw - 1) / cpw) < 2048) cpw >>= 1;
+  return cpw;
+}
+
+}  // namespace
+
+extern "C" int mf_average_voxelization_3d_fwd(const float *values, const float *points,
+                                              const int32_t *batch_indices, int64_t n, int C,
+                                              int B, int X, int Y, int Z, float ox, float oy,
+                                              float oz, float pitch, float *matrix,
+                                              int32_t *counts, int32_t *head, int32_t *link,
+                                              int32_t *nan_flag, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t V = (int64_t)X * Y * Z;
+  if (B <= 0 || C <= 0 || V <= 0) return 0;
+  MF_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * B * V, stream));
+  MF_TRY(hipMemsetAsync(head, 0xff, sizeof(int32_t) * B * V, stream));
+  if (nan_flag) MF_TRY(hipMemsetAsync(nan_flag, 0, sizeof(int32_t), stream));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_avgvox_link, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       points, batch_indices, n, B, X, Y, Z, ox, oy, oz, pitch, counts, head, link,
+                       nan_flag);
+  }
+  const bool vec4 = (V % 4 == 0);
+  const int per = 256 * (vec4 ? 4 : 1);
+  const int tiles = (int)((V + per - 1) / per);
+  const int cpw = pick_cpw(C, B, tiles);
+  dim3 grid(tiles, (C + cpw - 1) / cpw, B);
+  if (vec4)
+    hipLaunchKernelGGL(k_avgvox_write<4>, grid, dim3(256), 0, stream, values, counts, head, link,
+                       C, (int)V, cpw, matrix);
+  else
+    hipLaunchKernelGGL(k_avgvox_write<1>, grid, dim3(256), 0, stream, values, counts, head, link,
+                       C, (int)V, cpw, matrix);
+  return mf::check_launch("mf_average_voxelization_3d_fwd");
+}
+
+extern "C" int mf_average_voxelization_3d_bwd(const float *gmatrix, const float *points,
+                                              const int32_t *batch_indices,
+                                              const int32_t *counts, int64_t n, int C, int B,
+                                              int X, int Y, int Z, float ox, float oy, float oz,
+                                              float pitch, float *gvalues, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n * C == 0) return 0;
+  hipLaunchKernelGGL(k_avgvox_bwd, dim3((unsigned)((n * C + 255) / 256)), dim3(256), 0, stream,
+                     gmatrix, points, batch_indices, counts, n, C, B, X, Y, Z, ox, oy, oz, pitch,
+                     gvalues);
+  return mf::check_launch("mf_average_voxelization_3d_bwd");
+}
+
+extern "C" int mf_max_voxelization_3d_fwd(const float *values, const float *points,
+                                          const int32_t *batch_indices, const float *intensities,
+                                          int64_t n, int C, int B, int X, int Y, int Z, float ox,
+                                          float oy, float oz, float pitch, float *matrix,
+                                          int32_t *indices, uint64_t *key, int32_t *nan_flag,
+                                          mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t V = (int64_t)X * Y * Z;
+  if (B <= 0 || C <= 0 || V <= 0) return 0;
+  MF_TRY(hipMemsetAsync(key, 0, sizeof(uint64_t) * B * V, stream));
+  if (nan_flag) MF_TRY(hipMemsetAsync(nan_flag, 0, sizeof(int32_t), stream));
+  if (n > 0)
+    hipLaunchKernelGGL(k_maxvox_key, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       points, batch_indices, intensities, n, B, X, Y, Z, ox, oy, oz, pitch,
+                       (unsigned long long *)key, nan_flag);
+  const bool vec4 = (V % 4 == 0);
+  const int per = 256 * (vec4 ? 4 : 1);
+  const int tiles = (int)((V + per - 1) / per);
+  const int cpw = pick_cpw(C, B, tiles);
+  dim3 grid(tiles, (C + cpw - 1) / cpw, B);
+  if (vec4)
+    hipLaunchKernelGGL(k_maxvox_write<4>, grid, dim3(256), 0, stream, values,
+                       (const unsigned long long *)key, C, (int)V, cpw, matrix, indices);
+  else
+    hipLaunchKernelGGL(k_maxvox_write<1>, grid, dim3(256), 0, stream, values,
+                       (const unsigned long long *)key, C, (int)V, cpw, matrix, indices);
+  return mf::check_launch("mf_max_voxelization_3d_fwd");
+}
+
+extern "C" int mf_max_voxelization_3d_bwd(const float *gmatrix, const int32_t *indices, int64_t n,
+                                          int C, int B, int X, int Y, int Z, float *gvalues,
+                                          mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t V = (int64_t)X * Y * Z;
+  const int64_t total = (int64_t)B * C * V;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(k_maxvox_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     gmatrix, indices, C, V, total, gvalues);
+  return mf::check_launch("mf_max_voxelization_3d_bwd");
+}

@@ -1,0 +1,54 @@
+"""interpolate_voxel_grid -- trilinear sampling of [B,C,X,Y,Z] grids at points.
+
+API of morefusion/functions/geometry/interpolate_voxel_grid.py:271-272; kernels
+(:170-212, :224-266) replaced by ``mf_interpolate_voxel_grid_{fwd,bwd}``
+(morefusion_amd/csrc/interp.hip).  Points are in voxel-index units.
+"""
+import torch
+
+from ... import _lib
+
+
+class InterpolateVoxelGrid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, voxelized, points, batch_indices, channels_first):
+        _lib.require_gpu(voxelized, points, batch_indices)
+        if voxelized.dtype != torch.float32 or voxelized.ndim != 5:
+            raise TypeError("voxelized must be float32 [B, C, X, Y, Z]")
+        if points.dtype != torch.float32 or points.ndim != 2 or points.shape[1] != 3:
+            raise TypeError("points must be float32 [P, 3]")
+        if (batch_indices.dtype != torch.int32 or batch_indices.ndim != 1
+                or batch_indices.shape[0] != points.shape[0]):
+            raise TypeError("batch_indices must be int32 [P]")
+        vox, pts, bi = voxelized.contiguous(), points.contiguous(), batch_indices.contiguous()
+        B, C, X, Y, Z = vox.shape
+        n = pts.shape[0]
+        shape = (C, n) if channels_first else (n, C)
+        values = torch.empty(shape, dtype=torch.float32, device=vox.device)
+        _lib.check(
+            _lib.lib().mf_interpolate_voxel_grid_fwd(
+                vox.data_ptr(), pts.data_ptr(), bi.data_ptr(), n, B, C, X, Y, Z,
+                values.data_ptr(), int(channels_first), _lib.stream_ptr()),
+            "mf_interpolate_voxel_grid_fwd")
+        ctx.save_for_backward(pts, bi)
+        ctx.meta = (B, C, X, Y, Z, bool(channels_first))
+        return values
+
+    @staticmethod
+    def backward(ctx, gvalues):
+        pts, bi = ctx.saved_tensors
+        B, C, X, Y, Z, channels_first = ctx.meta
+        gvalues = gvalues.contiguous()
+        gvox = torch.empty((B, C, X, Y, Z), dtype=torch.float32, device=gvalues.device)
+        _lib.check(
+            _lib.lib().mf_interpolate_voxel_grid_bwd(
+                gvalues.data_ptr(), pts.data_ptr(), bi.data_ptr(), pts.shape[0], B, C, X, Y, Z,
+                gvox.data_ptr(), int(channels_first), _lib.stream_ptr()),
+            "mf_interpolate_voxel_grid_bwd")
+        return gvox, None, None, None
+
+
+def interpolate_voxel_grid(voxelized, points, batch_indices, channels_first=False):
+    """Returns [P, C] like the reference; ``channels_first=True`` returns [C, P]
+    (the coalesced layout the pose network consumes, saving a transpose)."""
+    return InterpolateVoxelGrid.apply(voxelized, points, batch_indices, channels_first)

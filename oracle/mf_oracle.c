@@ -459,7 +459,8 @@ void mfo_adam_step(float *p, const float *g, float *m, float *v, int64_t n, doub
 void mfo_icc_refine(const float *points, const float *sdf, const int64_t *offs, int N,
                     const float *pitch, const float *origin, const float *grid_target,
                     const float *grid_ne, float *q, float *t, int D, float voxel_threshold,
-                    float sdf_offset, int n_iter, double alpha, float *losses, float *traj) {
+                    float sdf_offset, int n_iter, double alpha, float *losses, float *traj,
+                    float *adam_hist /* [n_iter,2,N,7] m,v BEFORE each step, or NULL */) {
   float *gq = (float *)malloc(sizeof(float) * 4 * N), *gt = (float *)malloc(sizeof(float) * 3 * N);
   float *mq = (float *)calloc(4 * N, sizeof(float)), *vq = (float *)calloc(4 * N, sizeof(float));
   float *mt = (float *)calloc(3 * N, sizeof(float)), *vt = (float *)calloc(3 * N, sizeof(float));
@@ -473,6 +474,13 @@ void mfo_icc_refine(const float *points, const float *sdf, const int64_t *offs, 
     float loss = mfo_icc_loss_grad(points, sdf, offs, N, pitch, origin, grid_target, grid_ne,
                                    q, t, D, voxel_threshold, sdf_offset, gq, gt, sums);
     if (losses) losses[it] = loss;
+    if (adam_hist)
+      for (int i = 0; i < N; ++i) {
+        float *hm = adam_hist + (((int64_t)it * 2 + 0) * N + i) * 7;
+        float *hv = adam_hist + (((int64_t)it * 2 + 1) * N + i) * 7;
+        memcpy(hm, mq + 4 * i, 4 * sizeof(float)); memcpy(hm + 4, mt + 3 * i, 3 * sizeof(float));
+        memcpy(hv, vq + 4 * i, 4 * sizeof(float)); memcpy(hv + 4, vt + 3 * i, 3 * sizeof(float));
+      }
     mfo_adam_step(q, gq, mq, vq, 4 * N, alpha, it + 1);
     mfo_adam_step(t, gt, mt, vt, 3 * N, alpha * 0.1, it + 1);
   }

@@ -129,8 +129,9 @@ def icc_loss_grad(points, sdf, pitch, origin, grid_target, grid_ne, q, t, voxel_
 
 
 def icc_refine(points, sdf, pitch, origin, grid_target, grid_ne, q, t, n_iter=100, voxel_dim=32,
-               voxel_threshold=2, sdf_offset=0.02, alpha=0.01):
-    """q,t: initial float32 arrays (copied).  Returns q, t, losses, traj[n_iter,N,7]."""
+               voxel_threshold=2, sdf_offset=0.02, alpha=0.01, return_adam=False):
+    """q,t: initial float32 arrays (copied).  Returns q, t, losses, traj[n_iter,N,7]
+    (+ adam_hist[n_iter,2,N,7] = (m, v) before each step if return_adam)."""
     P, S, offs = _scene(points, sdf)
     N = len(points)
     pi, ppi = _f(pitch)
@@ -141,11 +142,15 @@ def icc_refine(points, sdf, pitch, origin, grid_target, grid_ne, q, t, n_iter=10
     t = np.array(t, dtype=np.float32, copy=True)
     losses = np.empty(n_iter, np.float32)
     traj = np.empty((n_iter, N, 7), np.float32)
+    hist = np.empty((n_iter, 2, N, 7), np.float32) if return_adam else None
     lib().mfo_icc_refine(
         P.ctypes.data_as(c_f), S.ctypes.data_as(c_f), offs.ctypes.data_as(c_i64), N, ppi, po, pgt,
         pgn, q.ctypes.data_as(c_f), t.ctypes.data_as(c_f), voxel_dim,
         ctypes.c_float(voxel_threshold), ctypes.c_float(sdf_offset), n_iter,
-        ctypes.c_double(alpha), losses.ctypes.data_as(c_f), traj.ctypes.data_as(c_f))
+        ctypes.c_double(alpha), losses.ctypes.data_as(c_f), traj.ctypes.data_as(c_f),
+        hist.ctypes.data_as(c_f) if return_adam else None)
+    if return_adam:
+        return q, t, losses, traj, hist
     return q, t, losses, traj
 
 
