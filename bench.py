@@ -1,0 +1,293 @@
+#!/usr/bin/env python
+"""Headline benchmark: objects/sec through voxelize -> 3D-CNN -> ICC refine on 32^3 grids.
+
+One "step" = one pass of the whole path over one batch of synthetic input, per GPU:
+  ``--scenes-per-gpu`` scenes x 8 objects:
+    Model.predict   (ResNet18 + PSPNet, HIP average_voxelization_3d, occupancy branch +
+                     conv3/conv4 3D-CNN, HIP interpolate_voxel_grid, 3 pose heads; B = objects)
+    arg-max confidence -> per-object pose
+    ICC joint refinement of every scene, 100 x {forward, backward, chainer-Adam} on device
+    (N > 1) RCCL all-gather of the refined [n,7] poses
+Inputs are resident in HBM before the timed region.  Weights are random (no pretrained
+file is reachable offline), so the network's poses are meaningless: the ICC stage starts
+from the scene's synthetic perturbed-ground-truth poses instead -- same work, real grids.
+
+Contract: python bench.py --gpus N --steps K --warmup W  -> ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import morefusion_amd as mf  # noqa: E402
+from morefusion_amd import parallel  # noqa: E402
+from morefusion_amd.contrib.singleview_3d.models import Model  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenes-per-gpu", type=int, default=1)
+    ap.add_argument("--objects", type=int, default=8)
+    ap.add_argument("--icc-iters", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-breakdown", action="store_true", default=True)
+    return ap.parse_args()
+
+
+def load_fixtures():
+    fx = []
+    for i in range(3):
+        p = os.path.join(ROOT, "tests", "golden", f"fixture_pose_refinement_0000000{i}.npz")
+        if os.path.exists(p):
+            fx.append(dict(np.load(p)))
+    return fx
+
+
+class Workload:
+    """Device-resident synthetic inputs + the step function for this rank."""
+
+    def __init__(self, args, rank, device):
+        self.args = args
+        self.device = device
+        S, Nobj = args.scenes_per_gpu, args.objects
+        self.B = S * Nobj
+        torch.manual_seed(0)
+        self.model = Model(n_fg_class=21, with_occupancy=True).to(device).eval()
+        batch = mf.synthetic.make_singleview_batch(self.B, seed=1000 * rank)
+        to = lambda x: torch.as_tensor(x).to(device)  # noqa: E731
+        self.inputs = dict(class_id=to(batch["class_id"]), rgb=to(batch["rgb"]), pcd=to(batch["pcd"]),
+                           pitch=to(batch["pitch"]), origin=to(batch["origin"]),
+                           grid_nontarget_empty=to(batch["grid_nontarget_empty"]))
+        fixtures = load_fixtures()
+        self.scenes_np = [mf.synthetic.make_icc_scene(Nobj, seed=1000 * rank + s, fixtures=fixtures)
+                          for s in range(S)]
+        dicts = [dict(points=s["points"], sdf=s["sdf"], pitch=s["pitch"], origin=s["origin"],
+                      grid_target=s["grid_target"], grid_nontarget_empty=s["grid_nontarget_empty"])
+                 for s in self.scenes_np]
+        self.icc = mf.contrib.IccScenes(dicts, sdf_offset=0.02, device=device)
+        from morefusion_amd.geometry import quaternion_from_matrix
+        q0 = np.concatenate([np.stack([quaternion_from_matrix(T) for T in s["transform_init"]])
+                             for s in self.scenes_np]).astype(np.float32)
+        t0 = np.concatenate([s["transform_init"][:, :3, 3] for s in self.scenes_np]).astype(np.float32)
+        self.q0, self.t0 = to(q0), to(t0)
+        self.q, self.t = self.q0.clone(), self.t0.clone()
+        self.m = torch.zeros((self.B, 7), device=device)
+        self.v = torch.zeros((self.B, 7), device=device)
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.gathered = torch.empty((self.world * self.B, 7), device=device)
+        self.events = []
+
+    def _mark(self, name):
+        if self._timing:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.events.append((name, e))
+
+    @torch.no_grad()
+    def step(self, timing=False):
+        self._timing = timing
+        self._mark("start")
+        rot, trans, conf = self.model.predict(**self.inputs)
+        idx = conf.argmax(dim=1)
+        ar = torch.arange(self.B, device=self.device)
+        pred = torch.cat([rot[ar, idx], trans[ar, idx]], dim=1)  # [B,7] network poses
+        self._mark("predict")
+        self.q.copy_(self.q0)
+        self.t.copy_(self.t0)
+        self.m.zero_()
+        self.v.zero_()
+        self.icc.refine(self.q, self.t, self.m, self.v, self.args.icc_iters, step0=0,
+                        alpha_q=0.01, alpha_t=0.001)
+        self._mark("icc")
+        poses = torch.cat([self.q, self.t], dim=1)
+        out = parallel.all_gather_poses_equal(poses, out=self.gathered if self.world > 1 else None)
+        self._mark("gather")
+        return out, pred
+
+
+def time_kernel_live(fn, reps):
+    """Average duration (ms) of ``fn``'s launches measured with HIP events on the stream
+    they are issued to (torch's current stream)."""
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def roofline_voxelize(wl):
+    """Dominant hand-written HBM-bound kernel of Model.predict: k_avgvox_write inside
+    mf_average_voxelization_3d_fwd at the model's shape (B objects, P=1000, C=144, 32^3).
+    Algorithmic bytes / object: read P*(12+4C+4) + write C*D^3*4 + D^3*4."""
+    B, P, C, D = wl.B, 1000, 144, 32
+    dev = wl.device
+    g = torch.Generator(device="cpu").manual_seed(0)
+    values = torch.rand((B * P, C), generator=g).to(dev)
+    points = (torch.rand((B * P, 3), generator=g) * 20 + 6).to(dev)
+    bi = torch.arange(B, dtype=torch.int32).repeat_interleave(P).to(dev)
+    kw = dict(batch_size=B, origin=(0, 0, 0), pitch=1.0, dimensions=(D, D, D), check_nan=False)
+    ms = time_kernel_live(lambda: mf.functions.average_voxelization_3d(values, points, bi, **kw), 50)
+    alg = B * (P * (12 + 4 * C + 4) + C * D ** 3 * 4 + D ** 3 * 4)
+    achieved = alg / (ms * 1e-3) / 1e9
+    return dict(kernel="mf_average_voxelization_3d_fwd (k_avgvox_link + k_avgvox_write)",
+                bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                algorithmic_bytes_per_launch=alg, avg_launch_ms=round(ms, 5))
+
+
+def cpu_baseline(wl, args):
+    """The same workload on the host cores: torch-CPU convolutions/GEMMs + the C port of
+    the voxel ops and of the ICC loop (oracle/mf_oracle.c, OpenMP over grids).  Bounded
+    sample: predict on 2 objects (scaled to B), ICC on 10 iterations (scaled to 100)."""
+    from oracle import oracle_c as OC
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = Model(n_fg_class=21, with_occupancy=True).eval()
+    model.load_state_dict({k: v.cpu() for k, v in wl.model.state_dict().items()})
+    nb = min(2, wl.B)
+    inp = {k: v[:nb].cpu() for k, v in wl.inputs.items()}
+
+    # route the two HIP ops of predict through the C port for this leg only
+    F = mf.functions
+
+    def avg_cpu(values, points, batch_indices, *, batch_size, origin, pitch, dimensions, **kw):
+        m, _ = OC.average_voxelization_3d(values.numpy(), points.numpy(), batch_indices.numpy(),
+                                          batch_size=batch_size, origin=origin, pitch=pitch,
+                                          dimensions=dimensions)
+        return torch.from_numpy(m)
+
+    def interp_cpu(vox, points, batch_indices, channels_first=False):
+        out = torch.from_numpy(OC.interpolate_voxel_grid(vox.numpy(), points.numpy(), batch_indices.numpy()))
+        return out.t().contiguous() if channels_first else out
+
+    import morefusion_amd.contrib.singleview_3d.models.model as model_mod
+    saved = (model_mod.functions_module.average_voxelization_3d,
+             model_mod.functions_module.interpolate_voxel_grid)
+    model_mod.functions_module.average_voxelization_3d = avg_cpu
+    model_mod.functions_module.interpolate_voxel_grid = interp_cpu
+    try:
+        with torch.no_grad():
+            model.predict(**inp)  # warm-up
+            t0 = time.perf_counter()
+            model.predict(**inp)
+            t_pred = (time.perf_counter() - t0) * (wl.B / nb)
+    finally:
+        (model_mod.functions_module.average_voxelization_3d,
+         model_mod.functions_module.interpolate_voxel_grid) = saved
+    del F
+    iters = min(10, args.icc_iters)
+    t_icc = 0.0
+    for s, sc in enumerate(wl.scenes_np[:1]):
+        q0 = wl.q0[: len(sc["points"])].cpu().numpy()
+        t0_ = wl.t0[: len(sc["points"])].cpu().numpy()
+        a = (sc["points"], sc["sdf"], sc["pitch"], sc["origin"], sc["grid_target"], sc["grid_nontarget_empty"])
+        OC.icc_refine(*a, q0, t0_, n_iter=1, sdf_offset=0.02)
+        t0 = time.perf_counter()
+        OC.icc_refine(*a, q0, t0_, n_iter=iters, sdf_offset=0.02)
+        t_icc = (time.perf_counter() - t0) * (args.icc_iters / iters) * args.scenes_per_gpu
+    value = wl.B / (t_pred + t_icc)
+    return dict(value=round(value, 3), unit="objects/sec", cores=cores, kind="port",
+                sample=f"predict on {nb} of {wl.B} objects (torch-CPU convs + C port of voxelize/"
+                       f"interpolate) scaled x{wl.B / nb:g}; ICC C port (OpenMP) {iters} of "
+                       f"{args.icc_iters} iterations of 1 scene scaled; predict {t_pred:.2f}s + "
+                       f"icc {t_icc:.2f}s per step")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    wl = Workload(args, rank, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # un-timed extras: stage breakdown, live kernel timing, CPU baseline (rank 0, N=1)
+    wl.events = []
+    for _ in range(5):
+        wl.step(timing=True)
+    torch.cuda.synchronize()
+    stages = {}
+    ev = wl.events
+    for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+        if n1 != "start":
+            stages[n1] = stages.get(n1, 0.0) + e0.elapsed_time(e1) / 5
+    out = None
+    if rank == 0:
+        total_objects = world * wl.B * args.steps
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "objects/sec (32^3 voxelize+3D-CNN+ICC refine)",
+            "value": round(total_objects / elapsed, 3),
+            "unit": "objects/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.scenes_per_gpu} scene(s) x {args.objects} objects per GPU: "
+                            "singleview_3d Model.predict (ResNet18+PSPNet, 32^3 voxelize, occupancy "
+                            f"3D-CNN, heads; B={wl.B}) -> ICC joint refine {args.icc_iters} iters "
+                            "(BASELINE configs[1]+configs[2]); random weights, ICC starts from "
+                            "synthetic perturbed-GT poses",
+                "objects_per_gpu": wl.B, "icc_iters": args.icc_iters,
+                "parallelism": f"scene-sharded x{world}, pose all_gather",
+            },
+            "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+        }
+        out["roofline"] = roofline_voxelize(wl)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

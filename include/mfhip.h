@@ -170,6 +170,7 @@ typedef struct {
   int32_t n_scenes;  /* S */
   int32_t n_points;  /* Ptot */
   int32_t dim;       /* D (32) */
+  int32_t max_scene_objects; /* max objects in one scene (<= 32) */
   float voxel_threshold;
   float sdf_offset;
 } mfIccBatch;

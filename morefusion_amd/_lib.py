@@ -27,6 +27,7 @@ class IccBatch(ctypes.Structure):
         ("pitch", _p), ("origin", _p), ("grid_target", _p), ("grid_ne", _p),
         ("n_objects", ctypes.c_int32), ("n_scenes", ctypes.c_int32),
         ("n_points", ctypes.c_int32), ("dim", ctypes.c_int32),
+        ("max_scene_objects", ctypes.c_int32),
         ("voxel_threshold", _f), ("sdf_offset", _f),
     ]
 

@@ -3,3 +3,4 @@
 from .icc_batch import IccScenes
 from .iterative_closest_point_link import IterativeClosestPointLink
 from .iterative_collision_check_link import IterativeCollisionCheckLink
+from . import singleview_3d

@@ -72,7 +72,9 @@ class IccScenes:
             self.pts4.data_ptr(), self.obj_off.data_ptr(), self.scene_off.data_ptr(),
             self.obj_scene.data_ptr(), self.pitch.data_ptr(), self.origin.data_ptr(),
             self.grid_target.data_ptr(), self.grid_ne.data_ptr(), self.n_objects, self.n_scenes,
-            self.n_points, voxel_dim, float(voxel_threshold), float(sdf_offset))
+            self.n_points, voxel_dim,
+            max(scene_off[i + 1] - scene_off[i] for i in range(len(scenes))),
+            float(voxel_threshold), float(sdf_offset))
 
     def loss_grad(self, q, t):
         """q [O,4], t [O,3] float32 cuda -> (loss [S], gq [O,4], gt [O,3])."""

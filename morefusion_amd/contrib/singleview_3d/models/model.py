@@ -1,0 +1,244 @@
+"""singleview_3d pose network: RGB crop + masked point cloud + no-entry grid -> per-point
+(quaternion, translation, confidence).
+
+Restates morefusion/contrib/singleview_3d/models/model.py:11-481 on torch.  The 3-D part
+is the hot path: ``average_voxelization_3d`` (HIP) -> occupancy branch + conv3/conv4
+(Conv3d -> MIOpen / MFMA) -> ``interpolate_voxel_grid`` (HIP) -> three per-point heads.
+Differences that are deliberate:
+  * the per-object host loop of ``predict`` (:195-229, one D2H sync per object) is one
+    batched gather with a single sync for the point counts (NumPy RNG kept bit-for-bit:
+    ``RandomState(1234).permutation(n)[:1000]`` in eval mode);
+  * interpolated features are produced channels-first ([C, B*P]), the layout the heads
+    consume, instead of [B*P, C] + transpose;
+  * CAD models / voxel pitches come from an injectable ``models`` provider because the
+    YCB downloads (datasets/ycb_video/models.py:33-42) are unreachable offline.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .... import extra
+from .... import functions as functions_module
+from .... import metrics
+from ....models import PSPNetExtractor, ResNet18
+from ....synthetic import CLASS_IDS_SYMMETRIC, CLASS_PITCH
+
+
+class PitchTableModels:
+    """Stand-in for ``YCBVideoModels``: voxel pitch from the per-class table
+    (ros/.../utils/data.h:12-32 == bbox_diagonal/32, models.py:113-115); CAD point clouds
+    must be supplied (``pcds`` dict class_id -> [n,3]) for evaluate()/loss()."""
+
+    def __init__(self, pcds=None):
+        self._pcds = dict(pcds or {})
+
+    def get_voxel_pitch(self, dimension, class_id):
+        return CLASS_PITCH[int(class_id)] * 32.0 / dimension
+
+    def get_pcd(self, class_id):
+        if int(class_id) not in self._pcds:
+            raise KeyError(f"no CAD point cloud registered for class {class_id}")
+        return self._pcds[int(class_id)]
+
+
+class Model(nn.Module):
+
+    _lambda_confidence = 0.015
+    _n_point = 1000
+    _voxel_dim = 32
+
+    def __init__(self, *, n_fg_class, pretrained_resnet18=False, with_occupancy=False, loss=None,
+                 loss_scale=None, models=None):
+        super().__init__()
+        if pretrained_resnet18:
+            raise NotImplementedError("pretrained chainercv2 weights are not reachable offline")
+        self._n_fg_class = n_fg_class
+        self._with_occupancy = with_occupancy
+        if loss is None:
+            loss = "add/add_s"
+        assert loss in ["add", "add/add_s"]
+        self._loss = loss
+        self._models = models or PitchTableModels()
+
+        self.resnet_extractor = ResNet18()
+        self.pspnet_extractor = PSPNetExtractor()
+        self.conv1_rgb = nn.Conv1d(32, 64, 1)
+        self.conv1_pcd = nn.Conv1d(3, 8, 1)
+        self.conv2_rgb = nn.Conv1d(64, 128, 1)
+        self.conv2_pcd = nn.Conv1d(8, 16, 1)
+        c_vox = 144
+        if with_occupancy:
+            self.conv1_occ = nn.Conv3d(1, 8, 3, 1, padding=1)
+            self.conv2_occ = nn.Conv3d(8, 16, 3, 1, padding=2, dilation=2)
+            c_vox += 16
+        self.conv3 = nn.Conv3d(c_vox, 256, 4, 2, padding=1)
+        self.conv4 = nn.Conv3d(256, 512, 4, 2, padding=1)
+        c_feat = 72 + 144 + 256 + 512
+        for name, c_out in (("rot", 4), ("trans", 3), ("conf", 1)):
+            setattr(self, f"conv1_{name}", nn.Conv1d(c_feat, 640, 1))
+            setattr(self, f"conv2_{name}", nn.Conv1d(640, 256, 1))
+            setattr(self, f"conv3_{name}", nn.Conv1d(256, 128, 1))
+            setattr(self, f"conv4_{name}", nn.Conv1d(128, n_fg_class * c_out, 1))
+
+    # ---- 3-D feature extraction (model.py:93-164) --------------------------------------
+    def _voxelize(self, values, points):
+        B, P, _ = values.shape
+        assert P == self._n_point
+        batch_indices = torch.arange(B, dtype=torch.int32, device=values.device).repeat_interleave(P)
+        return functions_module.average_voxelization_3d(
+            values.reshape(B * P, -1), points.reshape(B * P, 3).contiguous(), batch_indices,
+            batch_size=B, origin=(0, 0, 0), pitch=1.0, dimensions=(self._voxel_dim,) * 3,
+            check_nan=False)
+
+    def _extract(self, values, points, grid_nontarget_empty):
+        B, _, P = values.shape
+        to_center = (self._voxel_dim / 2.0 - 0.5) - points
+        batch_indices = torch.arange(B, dtype=torch.int32, device=values.device).repeat_interleave(P)
+        indices = points.transpose(1, 2).reshape(B * P, 3).contiguous()
+
+        h_rgb = F.relu(self.conv1_rgb(values))
+        h_pcd = F.relu(self.conv1_pcd(to_center))
+        feat1 = torch.cat((h_rgb, h_pcd), dim=1)
+        h_rgb = F.relu(self.conv2_rgb(h_rgb))
+        h_pcd = F.relu(self.conv2_pcd(h_pcd))
+        feat2 = torch.cat((h_rgb, h_pcd), dim=1)
+        voxelized = self._voxelize(values=feat2.transpose(1, 2).float().contiguous(),
+                                   points=points.transpose(1, 2))
+        if self._with_occupancy:
+            g = grid_nontarget_empty.to(values.dtype)[:, None, :, :, :]
+            h_occ = F.relu(self.conv1_occ(g))
+            h_occ = F.relu(self.conv2_occ(h_occ))
+            voxelized = torch.cat([voxelized.to(h_occ.dtype), h_occ], dim=1)
+
+        h = F.relu(self.conv3(voxelized))
+        assert h.shape == (B, 256, 16, 16, 16)
+        feat3 = functions_module.interpolate_voxel_grid(h.float(), indices / 2.0, batch_indices,
+                                                        channels_first=True)
+        feat3 = feat3.reshape(256, B, P).transpose(0, 1)
+        h = F.relu(self.conv4(h))
+        assert h.shape == (B, 512, 8, 8, 8)
+        feat4 = functions_module.interpolate_voxel_grid(h.float(), indices / 4.0, batch_indices,
+                                                        channels_first=True)
+        feat4 = feat4.reshape(512, B, P).transpose(0, 1)
+        dt = feat1.dtype
+        return torch.cat((feat1, feat2, feat3.to(dt), feat4.to(dt)), dim=1)
+
+    # ---- point selection (model.py:191-230) ---------------------------------------------
+    def _select_points(self, mask):
+        """mask [B,H,W] -> flat pixel indices [B,P] (row-major order of ``where``, then the
+        reference's NumPy-RNG subsample / pad)."""
+        B = mask.shape[0]
+        counts = mask.reshape(B, -1).sum(dim=1).cpu().numpy()  # the one host sync
+        flat = []
+        for i in range(B):
+            n_point = int(counts[i])
+            if n_point == 0:
+                raise ValueError("an example has no valid point")
+            random_state = np.random.mtrand._rand if self.training else np.random.RandomState(1234)
+            if n_point >= self._n_point:
+                keep = random_state.permutation(n_point)[: self._n_point]
+            else:
+                keep = np.r_[np.arange(n_point),
+                             random_state.randint(0, n_point, self._n_point - n_point)]
+            flat.append(keep)
+        keep = torch.from_numpy(np.stack(flat).astype(np.int64)).to(mask.device)
+        # position of the k-th valid pixel of each image
+        order = torch.argsort((~mask).reshape(B, -1).to(torch.uint8), dim=1, stable=True)
+        return torch.gather(order, 1, keep)
+
+    def predict(self, *, class_id, rgb, pcd, pitch=None, origin=None, grid_nontarget_empty=None):
+        B, H, W, _ = rgb.shape
+        dev = rgb.device
+        mask = ~torch.isnan(pcd).any(dim=3)
+        rgb = rgb.float().permute(0, 3, 1, 2)
+        pcd = pcd.float().permute(0, 3, 1, 2)
+
+        h_rgb = self.pspnet_extractor(self.resnet_extractor(rgb))
+
+        if pitch is None:
+            pitch = torch.tensor([self._models.get_voxel_pitch(self._voxel_dim, int(c))
+                                  for c in class_id.tolist()], dtype=torch.float32, device=dev)
+        else:
+            pitch = torch.as_tensor(pitch, dtype=torch.float32, device=dev)
+        if origin is None:
+            centers = []
+            for i in range(B):
+                centers.append(extra.median(pcd[i].reshape(3, -1)[:, mask[i].reshape(-1)].T, axis=0))
+            origin = torch.stack(centers) - pitch[:, None] * (self._voxel_dim / 2.0 - 0.5)
+        else:
+            origin = torch.as_tensor(origin, dtype=torch.float32, device=dev)
+
+        pix = self._select_points(mask)  # [B,P]
+        values = torch.gather(h_rgb.reshape(B, h_rgb.shape[1], -1), 2,
+                              pix[:, None, :].expand(B, h_rgb.shape[1], -1))
+        points = torch.gather(pcd.reshape(B, 3, -1), 2, pix[:, None, :].expand(B, 3, -1))
+
+        points = (points - origin[:, :, None]) / pitch[:, None, None]  # camera -> voxel frame
+        h = self._extract(values, points, grid_nontarget_empty)
+
+        outs = {}
+        for name in ("rot", "trans", "conf"):
+            x = F.relu(getattr(self, f"conv1_{name}")(h))
+            x = F.relu(getattr(self, f"conv2_{name}")(x))
+            x = F.relu(getattr(self, f"conv3_{name}")(x))
+            outs[name] = getattr(self, f"conv4_{name}")(x).float()
+        P = self._n_point
+        cls_rot = outs["rot"].reshape(B, self._n_fg_class, 4, P)
+        cls_trans = outs["trans"].reshape(B, self._n_fg_class, 3, P)
+        cls_conf = torch.sigmoid(outs["conf"]).reshape(B, self._n_fg_class, P)
+
+        points = points * pitch[:, None, None] + origin[:, :, None]  # voxel -> camera frame
+        cls_trans = points[:, None, :, :] + cls_trans * pitch[:, None, None, None]
+
+        fg_class_id = (torch.as_tensor(class_id, device=dev) - 1).long()
+        ar = torch.arange(B, device=dev)
+        rot = F.normalize(cls_rot[ar, fg_class_id], dim=1).transpose(1, 2)  # B4P -> BP4
+        trans = cls_trans[ar, fg_class_id].transpose(1, 2)  # B3P -> BP3
+        conf = cls_conf[ar, fg_class_id]
+        return rot, trans, conf
+
+    # ---- training (model.py:277-481) ------------------------------------------------------
+    def forward(self, *, class_id, rgb, pcd, quaternion_true, translation_true, pitch=None,
+                origin=None, grid_target=None, grid_nontarget_empty=None):
+        quaternion_pred, translation_pred, confidence_pred = self.predict(
+            class_id=class_id, rgb=rgb, pcd=pcd, pitch=pitch, origin=origin,
+            grid_nontarget_empty=grid_nontarget_empty)
+        return self.loss(class_id=class_id, quaternion_true=quaternion_true,
+                         translation_true=translation_true, quaternion_pred=quaternion_pred,
+                         translation_pred=translation_pred, confidence_pred=confidence_pred)
+
+    @torch.no_grad()
+    def evaluate(self, *, class_id, quaternion_true, translation_true, quaternion_pred,
+                 translation_pred):
+        """ADD / ADD-S of the given poses (model.py:325-375), returned as a dict of means."""
+        T_true = functions_module.transformation_matrix(
+            quaternion_true.float(), translation_true.float()).cpu().numpy()
+        T_pred = functions_module.transformation_matrix(quaternion_pred, translation_pred).cpu().numpy()
+        adds, add_ss, mixed = [], [], []
+        for i, cid in enumerate(torch.as_tensor(class_id).tolist()):
+            add, add_s = metrics.average_distance([self._models.get_pcd(cid)], [T_true[i]], [T_pred[i]])
+            adds.append(add[0])
+            add_ss.append(add_s[0])
+            mixed.append(add_s[0] if cid in CLASS_IDS_SYMMETRIC else add[0])
+        return dict(add=float(np.mean(adds)), add_s=float(np.mean(add_ss)),
+                    add_or_add_s=float(np.mean(mixed)))
+
+    def loss(self, *, class_id, quaternion_true, translation_true, quaternion_pred,
+             translation_pred, confidence_pred):
+        B = quaternion_pred.shape[0]
+        dev = quaternion_pred.device
+        loss = 0
+        for i, cid in enumerate(torch.as_tensor(class_id).tolist()):
+            T_pred = functions_module.transformation_matrix(quaternion_pred[i], translation_pred[i])
+            T_true = functions_module.transformation_matrix(
+                quaternion_true[i].float(), translation_true[i].float())
+            cad_pcd = self._models.get_pcd(cid)
+            cad_pcd = cad_pcd[np.random.permutation(cad_pcd.shape[0])[:500]]
+            cad_pcd = torch.as_tensor(cad_pcd, dtype=torch.float32, device=dev)
+            is_symmetric = cid in CLASS_IDS_SYMMETRIC and self._loss != "add"
+            add = functions_module.average_distance(cad_pcd, T_true, T_pred, symmetric=is_symmetric)
+            keep = confidence_pred[i].detach() > 0
+            conf = confidence_pred[i][keep]
+            loss = loss + (add[keep] * conf - self._lambda_confidence * torch.log(conf)).mean()
+        return loss / B

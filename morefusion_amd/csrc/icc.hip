@@ -26,6 +26,8 @@
 // Every reduction has a fixed order (wave shuffles, ordered partials, integer
 // fixed-point atomics for the rare cross-object collision terms): bitwise
 // reproducible run to run.  No host synchronisation anywhere.
+#include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -38,12 +40,13 @@
 
 namespace {
 
-constexpr int kTdfThreads = 512;
+constexpr int kTdfThreads = 1024;
 constexpr int kAccThreads = 256;
 constexpr int kVoxPerBlock = 1024;  // k_icc_accum: voxels per workgroup
 constexpr int kNumOwn = 39;         // RN, S_in, PN + 3 x 12 gradient moments
 constexpr uint32_t kNoCand = 0xffffffffu;
-constexpr double kFix = 4294967296.0;  // 2^32 fixed point for the collision moments
+constexpr double kFix = 17592186044416.0;  // 2^44 fixed point for the collision moments
+constexpr int kMaxSceneObjects = 32;
 
 struct IccArgs {
   const float4 *pts4;
@@ -63,8 +66,11 @@ struct IccArgs {
   float *bound;           // [O][4]   model-frame bounding sphere
   float *St;              // [S]
   float *part;            // [O][NB][kNumOwn]
-  long long *oth;         // [O][12] fixed-point collision moments
-  int32_t *step;          // [S] adam step counter per scene
+  long long *oth;         // [O][NB][max_ns][12] fixed-point collision moments per block
+  int max_ns;
+  int32_t *step;          // [S] (unused scratch)
+  int4 *meta;             // [O] {scene first object, scene end object, point begin, point end}
+  int dbg;                // tuning aid: MF_ICC_DEBUG bit mask (0 in production)
 };
 
 __device__ __forceinline__ void quat_to_R(const float *q, float *R) {
@@ -161,6 +167,8 @@ __global__ __launch_bounds__(256) void k_icc_bound(IccArgs a) {
     a.bound[4 * o + 1] = empty ? 0.0f : c[1];
     a.bound[4 * o + 2] = empty ? 0.0f : c[2];
     a.bound[4 * o + 3] = empty ? -1.0f : sqrtf(r2) * 1.0001f + 1e-6f;
+    const int sc = a.obj_scene[o];
+    a.meta[o] = make_int4(a.scene_off[sc], a.scene_off[sc + 1], p0, p1);
   }
 }
 
@@ -190,100 +198,155 @@ __global__ __launch_bounds__(64) void k_icc_pose(IccArgs a, const float *__restr
   for (int i = 0; i < 3; ++i) a.Rt[12 * o + 9 + i] = t[3 * o + i];
   a.Mbits[2 * o] = 0;
   a.Mbits[2 * o + 1] = 0;
-#pragma unroll
-  for (int i = 0; i < 12; ++i) a.oth[12 * o + i] = 0;
 }
 
 // ---- launch 1: TDF tiles in LDS -------------------------------------------------
+// Latency design.  A dependent global load costs ~0.3-0.7 us on this part, so the kernel
+// is organised to have O(1) of them: (1) the <= 32 source objects' R|t, bounding spheres
+// and point ranges are fetched by one lane each, in parallel; (2) the flattened source
+// point list streams through in chunks of kTdfThreads with the NEXT chunk's loads issued
+// before the current one is processed; (3) points whose 3^3 neighbourhood touches this
+// tile are compacted into an LDS survivor list and (survivor, offset) work items are
+// then spread evenly over all lanes -- no idle lanes behind a divergent 27-way loop.
 // KS = kernel size of truncated_distance_function.py:36-38 (3 for voxel_threshold 2).
 template <int KS>
 __global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, int SX) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];
+  __shared__ float s_Rt[kMaxSceneObjects][12];
+  __shared__ int s_start[kMaxSceneObjects + 1];
+  __shared__ int s_pbase[kMaxSceneObjects];
+  __shared__ int s_cnt[kMaxSceneObjects];
+  __shared__ float4 s_surv[kTdfThreads / 64][64];  // per-wave survivor list: fx,fy,fz,bits(id)
   __shared__ float s_max[kTdfThreads / 64];
   const int ks = KS > 0 ? KS : ks_rt;
   const int h = ks / 2, K = ks * ks * ks;
   const int D = a.D;
   const int g = blockIdx.y, o = g >> 1, other = g & 1;
-  const int sc = a.obj_scene[o];
-  const int ja = a.scene_off[sc], jb = a.scene_off[sc + 1];
+  const int4 meta = a.meta[o];  // {ja, jb, p0, p1}
+  const int ja = meta.x, jb = meta.y;
+  const int Ns = jb - ja;
   const int x0 = blockIdx.x * SX;
   const int sx = min(SX, D - x0);
   const int nvox = sx * D * D;
   const float pitch = a.pitch[o];
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
   const float trunc = a.thr * pitch;
+  const float fh = (float)h, inv_pitch = 1.0f / pitch;
+  // conservative (approximate-arithmetic) rejection bounds, in voxel units
+  const float xlo = (float)x0 - fh - 0.51f, xhi = (float)(x0 + sx - 1) + fh + 0.51f;
+  const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
   const unsigned long long init = ((unsigned long long)__float_as_uint(trunc) << 32) | kNoCand;
   for (int i = threadIdx.x; i < nvox; i += kTdfThreads) s_key[i] = init;
+  // (1) per-object metadata, one lane per object
+  if (threadIdx.x < Ns) {
+    const int j = ja + threadIdx.x;
+    int cnt = 0;
+    if (other ? (j != o) : (j == o)) {
+      const float4 r0 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j);
+      const float4 r1 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 4);
+      const float4 r2 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 8);
+      const float4 b = *reinterpret_cast<const float4 *>(a.bound + 4 * j);
+      const int4 mj = a.meta[j];
+      const int p0 = mj.z, p1 = mj.w;
+      float *R = s_Rt[threadIdx.x];
+      R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y;
+      R[6] = r1.z; R[7] = r1.w; R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w;
+      // whole-object rejection with the model's bounding sphere
+      const float cx = (((R[0] * b.x + R[1] * b.y) + R[2] * b.z) + R[9] - ox) * inv_pitch;
+      const float cy = (((R[3] * b.x + R[4] * b.y) + R[5] * b.z) + R[10] - oy) * inv_pitch;
+      const float cz = (((R[6] * b.x + R[7] * b.y) + R[8] * b.z) + R[11] - oz) * inv_pitch;
+      const float r = b.w * inv_pitch + 0.05f + 1e-4f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
+      const bool hit = b.w >= 0.0f && !(cx + r < xlo || cx - r > xhi || cy + r < glo ||
+                                        cy - r > ghi || cz + r < glo || cz - r > ghi);
+      cnt = hit ? p1 - p0 : 0;
+      s_pbase[threadIdx.x] = p0;
+    }
+    s_cnt[threadIdx.x] = cnt;
+  }
   __syncthreads();
-  if (!(other && jb - ja <= 1)) {
-    const uint32_t *s_hi = reinterpret_cast<const uint32_t *>(s_key);
-    const float fh = (float)h, inv_pitch = 1.0f / pitch;
-    // conservative (approximate-arithmetic) rejection bounds, in voxel units
-    const float xlo = (float)x0 - fh - 0.51f, xhi = (float)(x0 + sx - 1) + fh + 0.51f;
-    const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
-    for (int j = ja; j < jb; ++j) {
-      if (other ? (j == o) : (j != o)) continue;
-      const float *Rt = a.Rt + 12 * j;  // wave-uniform -> scalar loads
-      const float R0 = Rt[0], R1 = Rt[1], R2 = Rt[2], R3 = Rt[3], R4 = Rt[4], R5 = Rt[5],
-                  R6 = Rt[6], R7 = Rt[7], R8 = Rt[8], T0 = Rt[9], T1 = Rt[10], T2 = Rt[11];
-      {  // whole-object rejection with the model's bounding sphere
-        const float *b = a.bound + 4 * j;
-        if (b[3] < 0.0f) continue;
-        const float cx = (((R0 * b[0] + R1 * b[1]) + R2 * b[2]) + T0 - ox) * inv_pitch;
-        const float cy = (((R3 * b[0] + R4 * b[1]) + R5 * b[2]) + T1 - oy) * inv_pitch;
-        const float cz = (((R6 * b[0] + R7 * b[1]) + R8 * b[2]) + T2 - oz) * inv_pitch;
-        const float r = b[3] * inv_pitch + 0.05f + 1e-4f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
-        if (cx + r < xlo || cx - r > xhi || cy + r < glo || cy - r > ghi || cz + r < glo ||
-            cz - r > ghi)
-          continue;
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int e = 0; e < Ns; ++e) { s_start[e] = acc; acc += s_cnt[e]; }
+    s_start[Ns] = acc;
+  }
+  __syncthreads();
+  const int total = (a.dbg & 1) ? 0 : s_start[Ns];
+  const uint32_t *s_hi = reinterpret_cast<const uint32_t *>(s_key);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 *wl = s_surv[wave];
+
+  constexpr int U = 8;  // points in flight per lane: total/(1024*8) dependent round trips
+  for (int c0 = 0; c0 < total; c0 += kTdfThreads * U) {
+    int ee[U];
+    uint32_t pp[U];
+    float4 mm[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // (2) all loads of this super-chunk issued back to back
+      const int idx = c0 + u * kTdfThreads + threadIdx.x;
+      ee[u] = -1;
+      pp[u] = 0;
+      mm[u] = make_float4(0, 0, 0, 0);
+      if (idx < total) {
+        int e = 0;
+        while (idx >= s_start[e + 1]) ++e;
+        ee[u] = e;
+        pp[u] = (uint32_t)(s_pbase[e] + (idx - s_start[e]));
+        mm[u] = a.pts4[pp[u]];
       }
-      const int p1 = a.obj_off[j + 1];
-      for (int p = a.obj_off[j] + threadIdx.x; p < p1; p += kTdfThreads) {
-        const float4 m = a.pts4[p];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bool surv = false;
+      float fx = 0, fy = 0, fz = 0;
+      if (ee[u] >= 0) {
+        const float *R = s_Rt[ee[u]];
+        const float4 m = mm[u];
         // transform_points: ((R0 x + R1 y) + R2 z) + t, un-fused (oracle order)
-        const float wx = ((R0 * m.x + R1 * m.y) + R2 * m.z) + T0;
-        {  // cheap reject on x (7 of 8 slabs) before paying for IEEE divides
-          const float ax = (wx - ox) * inv_pitch;
-          const float e = 0.01f + 1e-5f * fabsf(ax);
-          if (!(ax >= xlo - e && ax <= xhi + e)) continue;
+        const float wx = ((R[0] * m.x + R[1] * m.y) + R[2] * m.z) + R[9];
+        const float ax = (wx - ox) * inv_pitch;  // cheap reject before paying IEEE divides
+        const float ex = 0.01f + 1e-5f * fabsf(ax);
+        if (ax >= xlo - ex && ax <= xhi + ex) {
+          const float wy = ((R[3] * m.x + R[4] * m.y) + R[5] * m.z) + R[10];
+          const float wz = ((R[6] * m.x + R[7] * m.y) + R[8] * m.z) + R[11];
+          fx = (wx - ox) / pitch; fy = (wy - oy) / pitch; fz = (wz - oz) / pitch;
+          const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
+          surv = rx + fh >= (float)x0 && rx - fh < (float)(x0 + sx) && ry + fh >= 0.0f &&
+                 ry - fh < (float)D && rz + fh >= 0.0f && rz - fh < (float)D;
         }
-        const float wy = ((R3 * m.x + R4 * m.y) + R5 * m.z) + T1;
-        const float wz = ((R6 * m.x + R7 * m.y) + R8 * m.z) + T2;
-        const float fx = (wx - ox) / pitch, fy = (wy - oy) / pitch, fz = (wz - oz) / pitch;
-        const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
-        if (!(rx + fh >= (float)x0 && rx - fh < (float)(x0 + sx) && ry + fh >= 0.0f &&
-              ry - fh < (float)D && rz + fh >= 0.0f && rz - fh < (float)D))
-          continue;
-        const int irx = (int)rx, iry = (int)ry, irz = (int)rz;
-#pragma unroll
-        for (int aa = 0; aa < ks; ++aa) {
-          const int iy = iry + aa - h;
-          if (iy < 0 || iy >= D) continue;
-          const float dy = fy - (float)iy;
-#pragma unroll
-          for (int bb = 0; bb < ks; ++bb) {
-            const int ix = irx + bb - h;
-            if (ix < x0 || ix >= x0 + sx) continue;
-            const float dx = fx - (float)ix;
-            const float dxy = dx * dx + dy * dy;
-#pragma unroll
-            for (int cc = 0; cc < ks; ++cc) {
-              const int iz = irz + cc - h;
-              if (iz < 0 || iz >= D) continue;
-              const float dz = fz - (float)iz;
-              const float dist = pitch * sqrtf(dxy + dz * dz);
-              if (dist < trunc) {
-                const int li = ((ix - x0) * D + iy) * D + iz;
-                const uint32_t db = __float_as_uint(dist);
-                if (db <= s_hi[2 * li + 1]) {
-                  const uint32_t id = (uint32_t)p * (uint32_t)K + (uint32_t)((aa * ks + bb) * ks + cc);
-                  atomicMin(&s_key[li], ((unsigned long long)db << 32) | id);
-                }
-              }
-            }
+      }
+      // (3) wave-level compaction: survivors -> this wave's LDS list, then
+      // (survivor, kernel offset) work items over all 64 lanes.  No block barrier.
+      const unsigned long long mask = (a.dbg & 2) ? 0ull : __ballot(surv);
+      if (mask == 0ull) continue;  // wave-uniform
+      const int ns = __popcll(mask);
+      if (surv) {
+        const int slot = __popcll(mask & ((1ull << lane) - 1ull));
+        wl[slot] = make_float4(fx, fy, fz, __uint_as_float(pp[u]));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int w = lane; w < ns * K; w += 64) {
+        const int si = w / K, k = w - si * K;
+        const float4 sv = wl[si];
+        const int aa = k / (ks * ks), bb = (k / ks) % ks, cc = k % ks;
+        const int ix = (int)roundf(sv.x) + bb - h;
+        const int iy = (int)roundf(sv.y) + aa - h;
+        const int iz = (int)roundf(sv.z) + cc - h;
+        if (ix < x0 || ix >= x0 + sx || iy < 0 || iy >= D || iz < 0 || iz >= D) continue;
+        const float dx = sv.x - (float)ix, dy = sv.y - (float)iy, dz = sv.z - (float)iz;
+        const float dist = pitch * sqrtf((dx * dx + dy * dy) + dz * dz);
+        if (dist < trunc) {
+          const int li = ((ix - x0) * D + iy) * D + iz;
+          const uint32_t db = __float_as_uint(dist);
+          if (!(a.dbg & 4) && db <= s_hi[2 * li + 1]) {
+            const uint32_t id = __float_as_uint(sv.w) * (uint32_t)K + (uint32_t)k;
+            atomicMin(&s_key[li], ((unsigned long long)db << 32) | id);
           }
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // list is reused by the next round
     }
   }
   __syncthreads();
@@ -326,56 +389,84 @@ __device__ __forceinline__ void world_frac(const float *Rt, const float4 m, floa
   ux = dx / n; uy = dy / n; uz = dz / n;
 }
 
+constexpr int kVPT = kVoxPerBlock / kAccThreads;  // voxels per thread
+
 __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
-  __shared__ float s_red[kAccThreads / 64][kNumOwn];
+  __shared__ float s_red[6][kNumOwn];
+  __shared__ float s_tr[kAccThreads * (kNumOwn + 1)];
+  __shared__ unsigned long long s_oth[kMaxSceneObjects * 12];
+  __shared__ float s_Rt[kMaxSceneObjects][12];
+  __shared__ int s_off[kMaxSceneObjects + 1];
   const int o = blockIdx.y;
   const int D = a.D, V = D * D * D;
-  const int sc = a.obj_scene[o];
-  const int ja = a.scene_off[sc], jb = a.scene_off[sc + 1];
+  const int4 meta = a.meta[o];
+  const int ja = meta.x, jb = meta.y;
+  const int Ns = jb - ja;
+  // all independent loads first: scene tables, scalars, and this thread's voxels
+  if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
+  if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
+  for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) s_oth[i] = 0ull;
   const float pitch = a.pitch[o];
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
-  const float trunc = a.thr * pitch;
   const float M_own = __uint_as_float(a.Mbits[2 * o]);
   const float M_oth = __uint_as_float(a.Mbits[2 * o + 1]);
+  const float trunc = a.thr * pitch;
   // iterative_collision_check_link.py:82: skip the max() when grid_other has NaN,
   // which happens iff its normaliser max(weight) is 0 (0/0 everywhere).
-  const bool use_oth = (jb - ja > 1) && (M_oth != 0.0f);
+  const bool use_oth = (Ns > 1) && (M_oth != 0.0f);
   const unsigned long long *W_own = a.W + (int64_t)(2 * o) * V;
   const unsigned long long *W_oth = a.W + (int64_t)(2 * o + 1) * V;
   const float *tgt = a.grid_target + (int64_t)o * V;
   const float *gne = a.grid_ne + (int64_t)o * V;
-  const float *Rt_o = a.Rt + 12 * o;
+
+  unsigned long long ko[kVPT], kk[kVPT];
+  float ne_[kVPT], tg_[kVPT];
+  float4 m_own[kVPT];
+  float w_oth[kVPT];
+#pragma unroll
+  for (int it = 0; it < kVPT; ++it) {
+    const int v = blockIdx.x * kVoxPerBlock + it * kAccThreads + threadIdx.x;
+    const bool in = v < V;
+    ko[it] = in ? W_own[v] : (((unsigned long long)__float_as_uint(trunc) << 32) | kNoCand);
+    kk[it] = (in && use_oth) ? W_oth[v] : (unsigned long long)kNoCand;
+    ne_[it] = in ? gne[v] : 0.0f;
+    tg_[it] = in ? tgt[v] : 0.0f;
+  }
+#pragma unroll
+  for (int it = 0; it < kVPT; ++it) {  // second level: winner gathers
+    const uint32_t lo = (uint32_t)ko[it], lo_o = (uint32_t)kk[it];
+    m_own[it] = lo != kNoCand ? a.pts4[lo / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
+    w_oth[it] = lo_o != kNoCand ? a.pts4[lo_o / (uint32_t)K].w : -1.0f;
+  }
+  __syncthreads();
+  const float *Rt_o = s_Rt[o - ja];
 
   float acc[kNumOwn];
 #pragma unroll
   for (int i = 0; i < kNumOwn; ++i) acc[i] = 0.0f;
 
-  for (int it = 0; it < kVoxPerBlock / kAccThreads; ++it) {
+#pragma unroll
+  for (int it = 0; it < kVPT; ++it) {
     const int v = blockIdx.x * kVoxPerBlock + it * kAccThreads + threadIdx.x;
-    if (v >= V) break;
+    if (v >= V) continue;
     const int iz = v % D, iy = (v / D) % D, ix = v / (D * D);
-    const unsigned long long ko = W_own[v];
-    const uint32_t lo = (uint32_t)ko;
+    const uint32_t lo = (uint32_t)ko[it];
     const bool has = lo != kNoCand;
-    const float g = 1.0f - __uint_as_float((uint32_t)(ko >> 32)) / trunc;  // grid = 1 - tdf/trunc
-    float4 m_own = make_float4(0, 0, 0, -1.0f);
-    if (has) m_own = a.pts4[lo / (uint32_t)K];
-    float w = m_own.w + a.sdf_offset;
+    const float g = 1.0f - __uint_as_float((uint32_t)(ko[it] >> 32)) / trunc;  // 1 - tdf/trunc
+    float w = m_own[it].w + a.sdf_offset;
     const bool neg = w < 0.0f;
     if (neg) w = 0.0f;
     const float win = w / M_own;
     const float wsurf = neg ? win : 1.0f - win;
     const float surf = g * wsurf, ins = g * win;
-    const float ne = gne[v], tg = tgt[v];
+    const float ne = ne_[it], tg = tg_[it];
     float ne_eff = ne;
     bool oth_wins = false;
     float wo_in = 0.0f;
-    uint32_t lo_o = kNoCand;
+    const uint32_t lo_o = (uint32_t)kk[it];
     if (use_oth) {
-      const unsigned long long kk = W_oth[v];
-      lo_o = (uint32_t)kk;
-      const float go = 1.0f - __uint_as_float((uint32_t)(kk >> 32)) / trunc;
-      float wo = (lo_o != kNoCand ? a.pts4[lo_o / (uint32_t)K].w : -1.0f) + 0.0f;
+      const float go = 1.0f - __uint_as_float((uint32_t)(kk[it] >> 32)) / trunc;
+      float wo = w_oth[it] + 0.0f;
       if (wo < 0.0f) wo = 0.0f;
       wo_in = wo / M_oth;
       const float oth = go * wo_in;
@@ -389,7 +480,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
     if (has) {
       float ux, uy, uz;
       bool ok;
-      world_frac(Rt_o, m_own, ox, oy, oz, pitch, ix, iy, iz, ux, uy, uz, ok);
+      world_frac(Rt_o, m_own[it], ox, oy, oz, pitch, ix, iy, iz, ux, uy, uz, ok);
       if (ok) {
         const float A[3] = {wsurf * tg / trunc, win * ne_eff / trunc, win / trunc};
         const float u[3] = {ux, uy, uz};
@@ -398,74 +489,131 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
 #pragma unroll
           for (int d = 0; d < 3; ++d) {
             const float s = u[d] * A[k];
-            acc[3 + 12 * k + 4 * d + 0] += s * m_own.x;
-            acc[3 + 12 * k + 4 * d + 1] += s * m_own.y;
-            acc[3 + 12 * k + 4 * d + 2] += s * m_own.z;
+            acc[3 + 12 * k + 4 * d + 0] += s * m_own[it].x;
+            acc[3 + 12 * k + 4 * d + 1] += s * m_own[it].y;
+            acc[3 + 12 * k + 4 * d + 2] += s * m_own[it].z;
             acc[3 + 12 * k + 4 * d + 3] += s;
           }
       }
     }
     if (oth_wins && lo_o != kNoCand && ins != 0.0f) {
-      // collision term: gradient flows to the OTHER object's pose (rare -> fixed-point
-      // integer atomics: associative, hence deterministic)
+      // collision term: gradient flows to the OTHER object's pose.  Accumulated in LDS as
+      // 2^44 fixed point with integer atomics: associative, hence order-independent and
+      // bitwise reproducible (float atomics would not be)
       const uint32_t p = lo_o / (uint32_t)K;
-      int j = ja;
-      while (j + 1 < jb && (int)p >= a.obj_off[j + 1]) ++j;
+      int e = 0;
+      while (e + 1 < Ns && (int)p >= s_off[e + 1]) ++e;
       const float4 m = a.pts4[p];
       float ux, uy, uz;
       bool ok;
-      world_frac(a.Rt + 12 * j, m, ox, oy, oz, pitch, ix, iy, iz, ux, uy, uz, ok);
+      world_frac(s_Rt[e], m, ox, oy, oz, pitch, ix, iy, iz, ux, uy, uz, ok);
       const float B = wo_in * ins / trunc;
       if (ok && isfinite(B)) {
         const float u[3] = {ux, uy, uz};
-        long long *dst = a.oth + 12 * j;
+        unsigned long long *dst = s_oth + 12 * e;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
           const float s = u[d] * B;
-          atomicAdd((unsigned long long *)&dst[4 * d + 0],
-                    (unsigned long long)__double2ll_rn((double)(s * m.x) * kFix));
-          atomicAdd((unsigned long long *)&dst[4 * d + 1],
-                    (unsigned long long)__double2ll_rn((double)(s * m.y) * kFix));
-          atomicAdd((unsigned long long *)&dst[4 * d + 2],
-                    (unsigned long long)__double2ll_rn((double)(s * m.z) * kFix));
-          atomicAdd((unsigned long long *)&dst[4 * d + 3],
-                    (unsigned long long)__double2ll_rn((double)s * kFix));
+          atomicAdd(&dst[4 * d + 0], (unsigned long long)__double2ll_rn((double)(s * m.x) * kFix));
+          atomicAdd(&dst[4 * d + 1], (unsigned long long)__double2ll_rn((double)(s * m.y) * kFix));
+          atomicAdd(&dst[4 * d + 2], (unsigned long long)__double2ll_rn((double)(s * m.z) * kFix));
+          atomicAdd(&dst[4 * d + 3], (unsigned long long)__double2ll_rn((double)s * kFix));
         }
       }
     }
   }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // fixed-order block reduction through LDS (39 x 256 values): one row of 40 floats per
+  // lane, then kSeg partial sums per component, then the final kSeg-term sum.  ~1.5k
+  // cycles instead of 234 dependent cross-lane shuffles per wave.
+  constexpr int kRow = kNumOwn + 1, kSeg = 6, kRows = (kAccThreads + kSeg - 1) / kSeg;
+  __syncthreads();  // s_tr aliases nothing live; all lanes are past the voxel loop
 #pragma unroll
-  for (int i = 0; i < kNumOwn; ++i) {
-    const float s = mf::wave_sum(acc[i]);
-    if (lane == 0) s_red[wave][i] = s;
+  for (int i = 0; i < kNumOwn; ++i) s_tr[threadIdx.x * kRow + i] = acc[i];
+  __syncthreads();
+  if (threadIdx.x < kNumOwn * kSeg) {
+    const int c = threadIdx.x % kNumOwn, seg = threadIdx.x / kNumOwn;
+    const int r1 = min(kAccThreads, (seg + 1) * kRows);
+    float s = 0.0f;
+    for (int r = seg * kRows; r < r1; ++r) s += s_tr[r * kRow + c];
+    s_red[seg][c] = s;
   }
   __syncthreads();
   if (threadIdx.x < kNumOwn) {
-    const float s = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) +
-                    (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+    float s = s_red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kSeg; ++w) s += s_red[w][threadIdx.x];
     a.part[((int64_t)o * gridDim.x + blockIdx.x) * kNumOwn + threadIdx.x] = s;
   }
+  // (the barrier above also orders every LDS atomic of this block)
+  long long *po = a.oth + ((int64_t)o * gridDim.x + blockIdx.x) * a.max_ns * 12;
+  for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) po[i] = (long long)s_oth[i];
 }
 
 // ---- launch 3: reduce, loss, chain rule, chainer-Adam -----------------------------
+// One 1024-lane workgroup per scene.  Every partial is fetched with independent,
+// coalesced loads (one memory latency), reduced in LDS in a fixed order.
 // mode 0: write loss/gq/gt only.  mode 1: Adam update in place + refresh R|t.
-__global__ __launch_bounds__(256) void k_icc_step(IccArgs a, int NB, int mode, float *q, float *t,
-                                                  float *adam_m, float *adam_v, float alpha_q,
-                                                  float alpha_t, float *loss_out, float *gq_out,
-                                                  float *gt_out, float *traj, int it) {
-  extern __shared__ float s_tot[];  // [Ns][kNumOwn] then [Ns][12] G
+// aq/at: alpha_t of chainer's Adam for this step (evaluated in double on the host).
+constexpr int kStepThreads = 1024;
+constexpr int kMaxNB = 64;
+
+__global__ __launch_bounds__(kStepThreads) void k_icc_step(IccArgs a, int NB, int mode, float *q,
+                                                           float *t, float *adam_m, float *adam_v,
+                                                           float aq, float at, float *loss_out,
+                                                           float *gq_out, float *gt_out,
+                                                           float *traj, int it) {
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  __shared__ long long s_o[kMaxSceneObjects * 12];
   __shared__ float s_coef[4];
   const int sc = blockIdx.x;
   const int ja = a.scene_off[sc], jb = a.scene_off[sc + 1];
   const int Ns = jb - ja;
-  float *s_G = s_tot + Ns * kNumOwn;
-  for (int i = threadIdx.x; i < Ns * kNumOwn; i += blockDim.x) {
-    const int jo = i / kNumOwn, c = i % kNumOwn;
-    const float *p = a.part + (int64_t)(ja + jo) * NB * kNumOwn + c;
+  float *s_part = s_dyn;                      // [Ns*NB][kNumOwn] raw copy
+  float *s_tot = s_part + Ns * NB * kNumOwn;  // [Ns][kNumOwn]
+  float *s_G = s_tot + Ns * kNumOwn;          // [Ns][12]
+  const float S_t = a.St[sc];
+  // independent loads: own partials -> LDS, collision partials -> integer LDS atomics
+  const float *src = a.part + (int64_t)ja * NB * kNumOwn;
+  const int n_own = Ns * NB * kNumOwn;
+  for (int i = threadIdx.x; i < n_own; i += kStepThreads) s_part[i] = src[i];
+  for (int i = threadIdx.x; i < Ns * 12; i += kStepThreads) s_o[i] = 0;
+  __syncthreads();
+  {
+    const int row = a.max_ns * 12;  // one (grid, block) row of collision partials
+    const long long *po = a.oth + (int64_t)ja * NB * row;
+    const int n_rows = Ns * NB;
+    // lane -> (row, column); 8 independent loads in flight per lane, then integer adds
+    const int n_el = n_rows * Ns * 12;
+    const int ncol = Ns * 12;
+    for (int i0 = threadIdx.x; i0 < n_el; i0 += kStepThreads * 8) {
+      long long v[8];
+      int cidx[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * kStepThreads;
+        v[u] = 0;
+        cidx[u] = 0;
+        if (i < n_el) {
+          const int r = i / ncol, c = i - r * ncol;
+          cidx[u] = c;
+          v[u] = po[(int64_t)r * row + c];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v[u] != 0) atomicAdd((unsigned long long *)&s_o[cidx[u]], (unsigned long long)v[u]);
+    }
+  }
+  // fixed-order reduction over blocks: 4 lanes per (object, component), 2 shuffle steps
+  for (int i = threadIdx.x; i < Ns * kNumOwn * 4; i += kStepThreads) {
+    const int oc = i >> 2, sub = i & 3;
+    const int jo = oc / kNumOwn, c = oc - jo * kNumOwn;
+    const float *p = s_part + (int64_t)jo * NB * kNumOwn + c;
     float s = 0.0f;
-    for (int b = 0; b < NB; ++b) s += p[(int64_t)b * kNumOwn];
-    s_tot[i] = s;
+    for (int b = sub; b < NB; b += 4) s += p[b * kNumOwn];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (sub == 0) s_tot[oc] = s;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -475,7 +623,6 @@ __global__ __launch_bounds__(256) void k_icc_step(IccArgs a, int NB, int mode, f
       S_in += s_tot[jo * kNumOwn + 1];
       PN += s_tot[jo * kNumOwn + 2];
     }
-    const float S_t = a.St[sc];
     // iterative_collision_check_link.py:91-98
     const float reward = RN / S_t, penalty = PN / S_in;
     if (loss_out) loss_out[sc] = penalty - reward;
@@ -484,12 +631,12 @@ __global__ __launch_bounds__(256) void k_icc_step(IccArgs a, int NB, int mode, f
     s_coef[2] = PN / (S_in * S_in);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < Ns * 12; i += blockDim.x) {
-    const int jo = i / 12, c = i % 12;
+  if (threadIdx.x < Ns * 12) {
+    const int jo = threadIdx.x / 12, c = threadIdx.x % 12;
     const float *U = s_tot + jo * kNumOwn + 3;
-    const float oth = (float)((double)a.oth[(int64_t)(ja + jo) * 12 + c] / kFix);
-    s_G[i] = ((s_coef[0] * U[c] - s_coef[1] * U[12 + c]) + s_coef[2] * U[24 + c]) -
-             s_coef[1] * oth;
+    const float oth = (float)((double)s_o[threadIdx.x] / kFix);
+    s_G[threadIdx.x] = ((s_coef[0] * U[c] - s_coef[1] * U[12 + c]) + s_coef[2] * U[24 + c]) -
+                       s_coef[1] * oth;
   }
   __syncthreads();
   if (threadIdx.x < Ns) {
@@ -522,11 +669,7 @@ __global__ __launch_bounds__(256) void k_icc_step(IccArgs a, int NB, int mode, f
 #pragma unroll
         for (int i = 0; i < 3; ++i) tr[4 + i] = tt[i];
       }
-      // chainer.optimizers.Adam (v7): alpha_t in double, then float32 update
-      const int step = a.step[sc] + 1;
-      const double fix1 = 1.0 - pow(0.9, (double)step), fix2 = 1.0 - pow(0.999, (double)step);
-      const float aq = (float)((double)alpha_q * sqrt(fix2) / fix1);
-      const float at = (float)((double)alpha_t * sqrt(fix2) / fix1);
+      // chainer.optimizers.Adam (v7) update rule in float32
       const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-8f;
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
@@ -550,14 +693,10 @@ __global__ __launch_bounds__(256) void k_icc_step(IccArgs a, int NB, int mode, f
 #pragma unroll
       for (int i = 0; i < 3; ++i) a.Rt[12 * o + 9 + i] = tt[i];
     }
-    // reset the per-iteration accumulators for the next launch 1 / 2
+    // reset the per-iteration accumulators for the next launch 1
     a.Mbits[2 * o] = 0;
     a.Mbits[2 * o + 1] = 0;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) a.oth[12 * o + i] = 0;
   }
-  __syncthreads();
-  if (mode == 1 && threadIdx.x == 0) a.step[sc] += 1;
 }
 
 __global__ void k_pack(const float *__restrict__ points, const float *__restrict__ sdf, int64_t n,
@@ -570,11 +709,11 @@ __global__ void k_pack(const float *__restrict__ points, const float *__restrict
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 struct WsLayout {
-  int64_t W, M, Rt, bound, St, part, oth, step, total;
+  int64_t W, M, Rt, bound, St, part, oth, step, meta, total;
   int NB;
 };
 
-WsLayout ws_layout(int O, int S, int D) {
+WsLayout ws_layout(int O, int S, int D, int max_ns = kMaxSceneObjects) {
   WsLayout l;
   const int64_t V = (int64_t)D * D * D;
   l.NB = (int)((V + kVoxPerBlock - 1) / kVoxPerBlock);
@@ -585,13 +724,14 @@ WsLayout ws_layout(int O, int S, int D) {
   l.bound = off; off = align256(off + O * 4 * 4);
   l.St = off; off = align256(off + S * 4);
   l.part = off; off = align256(off + (int64_t)O * l.NB * kNumOwn * 4);
-  l.oth = off; off = align256(off + O * 12 * 8);
+  l.oth = off; off = align256(off + (int64_t)O * l.NB * max_ns * 12 * 8);
   l.step = off; off = align256(off + S * 4);
+  l.meta = off; off = align256(off + (int64_t)O * 16);
   l.total = off;
   return l;
 }
 
-IccArgs make_args(const mfIccBatch *b, void *ws) {
+IccArgs make_args(const mfIccBatch *b, void *ws, int max_ns) {
   IccArgs a;
   a.pts4 = (const float4 *)b->pts4;
   a.obj_off = b->obj_off;
@@ -606,6 +746,8 @@ IccArgs make_args(const mfIccBatch *b, void *ws) {
   a.D = b->dim;
   a.thr = b->voxel_threshold;
   a.sdf_offset = b->sdf_offset;
+  a.max_ns = max_ns;
+  a.dbg = getenv("MF_ICC_DEBUG") ? atoi(getenv("MF_ICC_DEBUG")) : 0;
   const WsLayout l = ws_layout(a.O, a.S, a.D);
   char *p = (char *)ws;
   a.W = (unsigned long long *)(p + l.W);
@@ -616,6 +758,7 @@ IccArgs make_args(const mfIccBatch *b, void *ws) {
   a.part = (float *)(p + l.part);
   a.oth = (long long *)(p + l.oth);
   a.step = (int32_t *)(p + l.step);
+  a.meta = (int4 *)(p + l.meta);
   return a;
 }
 
@@ -627,20 +770,10 @@ int ksize_host(float thr) {
   return ks;
 }
 
-int max_scene_objects_host(const mfIccBatch *b, hipStream_t stream, int *out) {
-  std::vector<int32_t> so(b->n_scenes + 1);
-  MF_TRY(hipMemcpyAsync(so.data(), b->scene_off, sizeof(int32_t) * so.size(),
-                        hipMemcpyDeviceToHost, stream));
-  MF_TRY(hipStreamSynchronize(stream));
-  int m = 0;
-  for (int s = 0; s < b->n_scenes; ++s) m = std::max(m, so[s + 1] - so[s]);
-  *out = m;
-  return 0;
-}
-
 void launch_iteration(const IccArgs &a, int ks, int SX, int NB, int max_ns, int mode, float *q,
                       float *t, float *adam_m, float *adam_v, float alpha_q, float alpha_t,
-                      float *loss, float *gq, float *gt, float *traj, int it, hipStream_t stream) {
+                      int adam_step, float *loss, float *gq, float *gt, float *traj, int it,
+                      hipStream_t stream) {
   const int D = a.D;
   const dim3 g1((D + SX - 1) / SX, 2 * a.O);
   const size_t lds1 = (size_t)SX * D * D * sizeof(unsigned long long);
@@ -649,9 +782,13 @@ void launch_iteration(const IccArgs &a, int ks, int SX, int NB, int max_ns, int 
   else
     hipLaunchKernelGGL(k_icc_tdf<0>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
   hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), 0, stream, a, ks * ks * ks);
-  const size_t lds3 = (size_t)max_ns * (kNumOwn + 12) * sizeof(float);
-  hipLaunchKernelGGL(k_icc_step, dim3(a.S), dim3(256), lds3, stream, a, NB, mode, q, t, adam_m,
-                     adam_v, alpha_q, alpha_t, loss, gq, gt, traj, it);
+  // chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once
+  const double fix1 = 1.0 - pow(0.9, (double)adam_step), fix2 = 1.0 - pow(0.999, (double)adam_step);
+  const float aq = (float)((double)alpha_q * sqrt(fix2) / fix1);
+  const float at = (float)((double)alpha_t * sqrt(fix2) / fix1);
+  const size_t lds3 = (size_t)max_ns * (NB * kNumOwn + kNumOwn + 12) * sizeof(float);
+  hipLaunchKernelGGL(k_icc_step, dim3(a.S), dim3(kStepThreads), lds3, stream, a, NB, mode, q, t,
+                     adam_m, adam_v, aq, at, loss, gq, gt, traj, it);
 }
 
 struct GraphKey {
@@ -676,8 +813,26 @@ extern "C" int mf_pack_points_sdf(const float *points, const float *sdf, int64_t
   return mf::check_launch("mf_pack_points_sdf");
 }
 
+static int icc_prepare_kernels() {
+  static bool done = false;
+  if (done) return 0;
+  // static + dynamic LDS above 64 KB is opt-in
+  MF_TRY(hipFuncSetAttribute((const void *)k_icc_tdf<3>,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  MF_TRY(hipFuncSetAttribute((const void *)k_icc_tdf<0>,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  MF_TRY(hipFuncSetAttribute((const void *)k_icc_step,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  done = true;
+  return 0;
+}
+
 static int icc_validate(const mfIccBatch *b) {
+  if (int e = icc_prepare_kernels()) return e;
   if (!b || b->n_objects <= 0 || b->n_scenes <= 0 || b->dim <= 0 || b->dim > 64 ||
+      b->max_scene_objects <= 0 || b->max_scene_objects > kMaxSceneObjects ||
+      (size_t)b->max_scene_objects * (ws_layout(1, 1, b->dim).NB * kNumOwn + kNumOwn + 12) * 4 >
+          150 * 1024 ||
       (double)b->n_points * 343.0 >= 4294967295.0) {
     mf::set_last_error(hipErrorInvalidValue, "mf_icc: invalid batch descriptor");
     return -(int)hipErrorInvalidValue;
@@ -686,6 +841,10 @@ static int icc_validate(const mfIccBatch *b) {
 }
 
 static int slab_planes(int D, int n_grids) {
+  if (const char *e = getenv("MF_ICC_SX")) {
+    const int v = atoi(e);
+    if (v >= 1 && v * D * D <= 8192) return std::min(v, D);
+  }
   // tile <= 64 KB of keys; prefer >= 512 workgroups so that 256 CUs stay busy
   int SX = std::max(1, std::min(D, 8192 / (D * D)));
   while (SX > 1 && (int64_t)((D + SX - 1) / SX) * n_grids < 512) SX = (SX + 1) / 2;
@@ -697,9 +856,8 @@ extern "C" int mf_icc_loss_grad(const mfIccBatch *batch, const float *q, const f
                                 mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = icc_validate(batch)) return e;
-  IccArgs a = make_args(batch, ws);
-  int max_ns = 0;
-  if (int e = max_scene_objects_host(batch, stream, &max_ns)) return e;
+  const int max_ns = batch->max_scene_objects;
+  IccArgs a = make_args(batch, ws, max_ns);
   const WsLayout l = ws_layout(a.O, a.S, a.D);
   const int ks = ksize_host(a.thr);
   const int SX = slab_planes(a.D, 2 * a.O);
@@ -707,7 +865,7 @@ extern "C" int mf_icc_loss_grad(const mfIccBatch *batch, const float *q, const f
   hipLaunchKernelGGL(k_icc_scene_setup, dim3(a.S), dim3(256), 0, stream, a, 0);
   hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t);
   launch_iteration(a, ks, SX, l.NB, max_ns, 0, const_cast<float *>(q), const_cast<float *>(t),
-                   nullptr, nullptr, 0.0f, 0.0f, loss, gq, gt, nullptr, 0, stream);
+                   nullptr, nullptr, 0.0f, 0.0f, 1, loss, gq, gt, nullptr, 0, stream);
   return mf::check_launch("mf_icc_loss_grad");
 }
 
@@ -718,7 +876,8 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = icc_validate(batch)) return e;
   if (n_iter <= 0) return 0;
-  IccArgs a = make_args(batch, ws);
+  const int max_ns = batch->max_scene_objects;
+  IccArgs a = make_args(batch, ws, max_ns);
   const WsLayout l = ws_layout(a.O, a.S, a.D);
   const int ks = ksize_host(a.thr);
   const int SX = slab_planes(a.D, 2 * a.O);
@@ -736,12 +895,11 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
   key.v.push_back(((uint64_t)(uint32_t)a.O << 32) | (uint32_t)a.S);
   key.v.push_back(((uint64_t)(uint32_t)a.D << 32) | (uint32_t)batch->n_points);
   key.v.push_back(((uint64_t)(uint32_t)n_iter << 32) | (uint32_t)step0);
+  key.v.push_back((uint64_t)max_ns);
 
   std::lock_guard<std::mutex> lock(g_graph_mu);
   auto itg = g_graphs.find(key);
   if (itg == g_graphs.end()) {
-    int max_ns = 0;
-    if (int e = max_scene_objects_host(batch, stream, &max_ns)) return e;
     hipGraph_t graph = nullptr;
     // The caller's stream may be the legacy NULL stream (torch's default), which cannot be
     // captured: record the graph on a private stream, replay it on the caller's.
@@ -753,8 +911,8 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
     hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, cap, a, q, t);
     for (int it = 0; it < n_iter; ++it)
       launch_iteration(a, ks, SX, l.NB, max_ns, 1, q, t, adam_m, adam_v, alpha_q, alpha_t,
-                       losses ? losses + (int64_t)it * a.S : nullptr, nullptr, nullptr, traj, it,
-                       cap);
+                       step0 + it + 1, losses ? losses + (int64_t)it * a.S : nullptr, nullptr,
+                       nullptr, traj, it, cap);
     hipError_t ce = hipStreamEndCapture(cap, &graph);
     if (ce != hipSuccess) {
       mf::set_last_error(ce, "hipStreamEndCapture(icc)");

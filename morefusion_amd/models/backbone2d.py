@@ -1,0 +1,107 @@
+"""2-D backbone of the pose network: DenseFusion-style ResNet18 + PSPNet decoder.
+
+Restates morefusion/models/dense_fusion/resnet.py:9-136 and pspnet.py:10-82 with stock
+``torch.nn`` layers (dense 2-D convolutions -> MIOpen; not hand-written).
+No BatchNorm anywhere (the reference has none); ``F.resize_images`` == bilinear with
+align_corners=True; PReLU has one shared slope initialised to 0.25.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, stride, dilate, residual_conv=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, stride, padding=dilate,
+                               dilation=dilate, bias=False)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, padding=dilate,
+                               dilation=dilate, bias=False)
+        self.residual_conv = (
+            nn.Conv2d(in_channels, out_channels, 1, stride, bias=False) if residual_conv else None)
+
+    def forward(self, x):
+        h = self.conv2(F.relu(self.conv1(x)))
+        residual = x if self.residual_conv is None else self.residual_conv(x)
+        return F.relu(h + residual)
+
+
+class ResBlock(nn.Sequential):
+    def __init__(self, n_layer, in_channels, out_channels, stride, dilate, residual_conv=True):
+        blocks = [BasicBlock(in_channels, out_channels, stride, 1, residual_conv=residual_conv)]
+        for _ in range(n_layer - 1):
+            blocks.append(BasicBlock(out_channels, out_channels, 1, dilate))
+        super().__init__(*blocks)
+
+
+class ResNet18(nn.Module):
+    """[B,3,H,W] uint8-range float -> [B,512,H/8,W/8] (dense_fusion/resnet.py:9-58)."""
+
+    mean_rgb = (0.485, 0.456, 0.406)
+    std_rgb = (0.229, 0.224, 0.225)
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.res2 = ResBlock(2, 64, 64, 1, 1, residual_conv=False)
+        self.res3 = ResBlock(2, 64, 128, 2, 1)
+        self.res4 = ResBlock(2, 128, 256, 1, 2)
+        self.res5 = ResBlock(2, 256, 512, 1, 4)
+        self.register_buffer("mean", torch.tensor(self.mean_rgb).view(1, 3, 1, 1))
+        self.register_buffer("std", torch.tensor(self.std_rgb).view(1, 3, 1, 1))
+
+    def forward(self, x):
+        h = (x / 255.0 - self.mean) / self.std
+        h = self.conv1(h)
+        h = F.max_pool2d(h, 3, 2, 1)
+        return self.res5(self.res4(self.res3(self.res2(h))))
+
+
+class PSPModule(nn.Module):
+    def __init__(self, in_channels, out_channels, sizes):
+        super().__init__()
+        self.sizes = sizes
+        self.convs = nn.ModuleList(
+            [nn.Conv2d(in_channels, in_channels, 1, bias=False) for _ in sizes])
+        self.bottleneck = nn.Conv2d(in_channels * (len(sizes) + 1), out_channels, 1)
+
+    def forward(self, x):
+        H, W = x.shape[2:]
+        hs = []
+        for size, conv in zip(self.sizes, self.convs):
+            k = (H // size, W // size)
+            h = conv(F.avg_pool2d(x, k, k))
+            hs.append(F.interpolate(h, (H, W), mode="bilinear", align_corners=True))
+        hs.append(x)
+        return F.relu(self.bottleneck(torch.cat(hs, dim=1)))
+
+
+class PSPUpsample(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, 3, 1, padding=1)
+        self.prelu = nn.PReLU()
+
+    def forward(self, x):
+        H, W = x.shape[2:]
+        h = F.interpolate(x, (H * 2, W * 2), mode="bilinear", align_corners=True)
+        return self.prelu(self.conv(h))
+
+
+class PSPNetExtractor(nn.Module):
+    """[B,512,h,w] -> log-softmax features [B,32,8h,8w] (dense_fusion/pspnet.py:10-35)."""
+
+    def __init__(self):
+        super().__init__()
+        self.psp = PSPModule(512, 1024, [1, 2, 3, 6])
+        self.up1 = PSPUpsample(1024, 256)
+        self.up2 = PSPUpsample(256, 64)
+        self.up3 = PSPUpsample(64, 64)
+        self.conv1 = nn.Conv2d(64, 32, 1)
+
+    def forward(self, x):
+        h = F.dropout(self.psp(x), 0.3, self.training)
+        h = F.dropout(self.up1(h), 0.15, self.training)
+        h = F.dropout(self.up2(h), 0.15, self.training)
+        h = self.up3(h)
+        return F.log_softmax(self.conv1(h), dim=1)

@@ -28,9 +28,16 @@ def to_dev(args):
 
 
 def add_between(points, qa, ta, qb, tb):
+    """ADD (metrics/average_distance.py:10-13) between two pose sets, float64."""
     Ta = O.transformation_matrix(qa.astype(np.float64), ta.astype(np.float64))
     Tb = O.transformation_matrix(qb.astype(np.float64), tb.astype(np.float64))
-    return np.array([O.metrics_average_distance(points[i], Ta[i], Tb[i])[0] for i in range(len(points))])
+    out = []
+    for i in range(len(points)):
+        p = np.asarray(points[i], dtype=np.float64)
+        pa = p @ Ta[i][:3, :3].T + Ta[i][:3, 3]
+        pb = p @ Tb[i][:3, :3].T + Tb[i][:3, 3]
+        out.append(np.linalg.norm(pa - pb, axis=1).mean())
+    return np.array(out)
 
 
 @pytest.fixture(scope="module")
@@ -129,7 +136,7 @@ def test_icc_refine_free_running_quality(scene8):
 
     def add_to_gt(q, t):
         T = O.transformation_matrix(q[syn].astype(np.float64), t[syn].astype(np.float64))
-        return np.array([O.metrics_average_distance(pts[j], Tgt[j], T[j])[0] for j in range(len(syn))])
+        return np.array([np.linalg.norm((pts[j] @ Tgt[j][:3, :3].T + Tgt[j][:3, 3]) - (pts[j] @ T[j][:3, :3].T + T[j][:3, 3]), axis=1).mean() for j in range(len(syn))])
 
     a0, ag, ao = add_to_gt(q0, t0), add_to_gt(qg, tg), add_to_gt(q_o, t_o)
     assert ag.mean() < a0.mean(), (a0, ag)
