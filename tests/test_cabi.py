@@ -1,0 +1,75 @@
+"""The C-ABI library loads here (no GPU) and exports exactly what include/mfhip.h
+declares; ops refuse CPU tensors instead of falling back.  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import morefusion_amd as mf
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mfhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = mf._lib.lib()  # dlopen works without a GPU
+    declared = _declared()
+    assert len(declared) >= 19
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mfhip.h but not exported"
+    assert sorted(mf._lib.EXPORTED_SYMBOLS) == declared  # python binding covers the whole ABI
+    assert lib.mf_version() >= 100
+    assert isinstance(lib.mf_last_error_string(), bytes)
+
+
+def test_icc_batch_struct_matches_header():
+    text = open(os.path.join(ROOT, "include", "mfhip.h")).read()
+    body = text[text.index("typedef struct {"):text.index("} mfIccBatch;")]
+    fields = re.findall(r"\b(\w+);", body)
+    assert fields == [f[0] for f in mf._lib.IccBatch._fields_]
+    assert ctypes.sizeof(mf._lib.IccBatch) == 8 * 8 + 5 * 4 + 2 * 4 + 4  # incl. tail padding
+
+
+def test_workspace_size_is_host_only_arithmetic():
+    n = mf._lib.lib().mf_icc_workspace_bytes(8, 1, 32)
+    assert n >= 2 * 8 * 32 ** 3 * 8
+    assert mf._lib.lib().mf_icc_workspace_bytes(64, 8, 32) > n
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    v = torch.zeros(4, 2)
+    p = torch.zeros(4, 3)
+    b = torch.zeros(4, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mf.functions.average_voxelization_3d(v, p, b, batch_size=1, origin=(0, 0, 0), pitch=1.0,
+                                             dimensions=(4, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mf.functions.interpolate_voxel_grid(torch.zeros(1, 1, 2, 2, 2), p, b)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mf.functions.truncated_distance_function(p, pitch=1.0, origin=(0, 0, 0), dims=(4, 4, 4), truncation=2.0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mf.functions.occupancy_grid_3d(p, pitch=1.0, origin=(0, 0, 0), dims=(4, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mf.geometry.nn(p, p)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(mf._lib, "_lib", None)
+    monkeypatch.setattr(mf._lib, "SO_PATH", str(tmp_path / "libmfhip.so"))
+    with pytest.raises(RuntimeError, match="not built"):
+        mf._lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "morefusion_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", "").replace("oracle order", "").replace("oracle)", ""), os.path.join(dp, f)

@@ -1,0 +1,166 @@
+"""Host-side logic of the path on CPU: rigid-transform ops (device-agnostic torch),
+chainer-style Adam, quaternion_from_matrix, metrics, pre-processing helpers, synthetic
+inputs, point selection of Model.predict, shard arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+import morefusion_amd as mf
+from conftest import golden
+from oracle import oracle_np as O
+
+F = mf.functions
+
+
+def test_transform_functions_match_reference_golden_and_squeeze_rules():
+    g = golden("ref_transforms.npz")
+    q, t = torch.from_numpy(g["q"]), torch.from_numpy(g["t"])
+    np.testing.assert_allclose(F.quaternion_matrix(q).numpy(), g["quaternion_matrix"], atol=1e-6)
+    np.testing.assert_allclose(F.quaternion_matrix(q[0]).numpy(), g["quaternion_matrix_1d"], atol=1e-6)
+    np.testing.assert_allclose(F.transformation_matrix(q, t).numpy(), g["transformation_matrix"], atol=1e-6)
+    np.testing.assert_allclose(F.transformation_matrix(q[0], t[0]).numpy(), g["transformation_matrix_1d"], atol=1e-6)
+    np.testing.assert_array_equal(F.translation_matrix(t).numpy(), g["translation_matrix"])
+    assert F.translation_matrix(t[0]).shape == (4, 4)
+    np.testing.assert_array_equal(
+        F.compose_transform(torch.from_numpy(g["quaternion_matrix"][:, :3, :3]), t).numpy(), g["compose_transform"])
+    pts = torch.from_numpy(g["points"])
+    T = torch.from_numpy(g["transformation_matrix"])
+    np.testing.assert_allclose(F.transform_points(pts, T).numpy(), g["transform_points"], atol=1e-6)
+    np.testing.assert_allclose(F.transform_points(pts, T[0]).numpy(), g["transform_points_1"], atol=1e-6)
+    # bit-equal to the oracle's fixed evaluation order (what the HIP kernels use)
+    np.testing.assert_array_equal(F.transform_points(pts, T).numpy(), O.transform_points(g["points"], g["transformation_matrix"]))
+
+
+def test_quaternion_matrix_autograd_equals_reference_backward_rule():
+    g = golden("ref_transforms.npz")
+    q = torch.from_numpy(g["q"]).double().requires_grad_(True)
+    gR = torch.from_numpy(g["gR"]).double()
+    (F.quaternion_matrix(q) * gR).sum().backward()
+    np.testing.assert_allclose(q.grad.numpy(), O.quaternion_matrix_backward(g["q"].astype(np.float64), g["gR"].astype(np.float64)),
+                               rtol=1e-9, atol=1e-12)
+    # the hand-written dR/dQ of the reference (quaternion_matrix.py:36-51), via its golden
+    qs = g["q"].astype(np.float64)
+    qs = qs * np.sqrt(2.0 / (qs ** 2).sum(1, keepdims=True))
+    Q = torch.from_numpy(qs[:, :, None] * qs[:, None, :]).requires_grad_(True)
+    R = torch.eye(4, dtype=torch.float64).repeat(5, 1, 1).clone()
+    R[:, 0, 0] = 1 - Q[:, 2, 2] - Q[:, 3, 3]; R[:, 0, 1] = Q[:, 1, 2] - Q[:, 3, 0]; R[:, 0, 2] = Q[:, 1, 3] + Q[:, 2, 0]
+    R[:, 1, 0] = Q[:, 1, 2] + Q[:, 3, 0]; R[:, 1, 1] = 1 - Q[:, 1, 1] - Q[:, 3, 3]; R[:, 1, 2] = Q[:, 2, 3] - Q[:, 1, 0]
+    R[:, 2, 0] = Q[:, 1, 3] - Q[:, 2, 0]; R[:, 2, 1] = Q[:, 2, 3] + Q[:, 1, 0]; R[:, 2, 2] = 1 - Q[:, 1, 1] - Q[:, 2, 2]
+    (R * gR).sum().backward()
+    np.testing.assert_allclose(Q.grad.numpy(), g["gq_outer"], rtol=1e-6, atol=1e-6)
+
+
+def test_average_distance_add_on_cpu_tensors():
+    g = golden("ref_average_distance.npz")
+    add = F.average_distance(torch.from_numpy(g["points"]), torch.from_numpy(g["transform_true"]),
+                             torch.from_numpy(g["transforms_pred"]))
+    np.testing.assert_allclose(add.numpy(), g["add"], rtol=1e-6, atol=1e-7)
+
+
+def test_chainer_adam_matches_restatement_including_per_param_alpha():
+    rs = np.random.RandomState(0)
+    q0, t0 = rs.normal(size=(3, 4)).astype(np.float32), rs.normal(size=(3, 3)).astype(np.float32)
+
+    class Link(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.quaternion = torch.nn.Parameter(torch.from_numpy(q0.copy()))
+            self.translation = torch.nn.Parameter(torch.from_numpy(t0.copy()))
+
+    link = Link()
+    opt = mf.optimizers.Adam(alpha=0.01).setup(link)
+    link.translation.update_rule.hyperparam.alpha *= 0.1
+    qo, to = q0.copy(), t0.copy()
+    ref = O.ChainerAdam([qo, to], [0.01, 0.001])
+    for k in range(25):
+        gq, gt = rs.normal(size=(3, 4)).astype(np.float32), rs.normal(size=(3, 3)).astype(np.float32) * 10
+        link.quaternion.grad, link.translation.grad = torch.from_numpy(gq), torch.from_numpy(gt)
+        opt.update()
+        ref.update([gq, gt])
+    np.testing.assert_allclose(link.quaternion.detach().numpy(), qo, rtol=0, atol=2e-7)
+    np.testing.assert_allclose(link.translation.detach().numpy(), to, rtol=0, atol=2e-7)
+    # first step of Adam moves every coordinate by alpha (bias-corrected, sign-like)
+    assert abs(abs(qo - q0).max() - 0.01 * 25) < 0.25
+
+
+def test_quaternion_from_matrix_roundtrip_and_sign(fixtures3):
+    for f in fixtures3:
+        q = mf.geometry.quaternion_from_matrix(f["transform_init"])
+        np.testing.assert_allclose(q, O.quaternion_from_matrix(f["transform_init"]), atol=1e-12)
+        assert q[0] >= 0 and abs(np.linalg.norm(q) - 1) < 1e-6
+        R = O.quaternion_matrix(q)[:3, :3]
+        np.testing.assert_allclose(R, f["transform_init"][:3, :3], atol=1e-5)
+
+
+def test_metrics_match_reference_golden():
+    g = golden("ref_metrics.npz")
+    auc, x, y = mf.metrics.ycb_video_add_auc(g["errors"], return_xy=True)
+    np.testing.assert_allclose(auc, g["add_auc"], rtol=1e-12)
+    np.testing.assert_allclose(x, g["add_auc_x"])
+    np.testing.assert_allclose(y, g["add_auc_y"])
+    np.testing.assert_allclose(mf.metrics.ycb_video_add_auc(g["errors"] * 10), g["add_auc_x10"], rtol=1e-12)
+    assert mf.metrics.ycb_video_add_auc(np.full(5, 1.0)) == 0
+    np.testing.assert_allclose(mf.metrics.auc_for_errors(g["errors"], 0.1), g["auc_for_errors"], rtol=1e-9)
+    a = golden("ref_average_distance.npz")
+    adds, add_ss = mf.metrics.average_distance([a["points"]] * 2, [a["transform_true"]] * 2,
+                                               list(a["transforms_pred"][:2]))
+    np.testing.assert_allclose(adds, a["add"][:2], rtol=1e-5)
+    assert (add_ss <= adds + 1e-12).all()
+
+
+def test_preprocessing_helpers_match_reference_golden():
+    g = golden("ref_preprocess.npz")
+    np.testing.assert_array_equal(
+        mf.geometry.pointcloud_from_depth(g["depth"], fx=30.0, fy=31.0, cx=15.5, cy=11.5), g["pc_z"])
+    np.testing.assert_array_equal(
+        mf.geometry.pointcloud_from_depth(g["depth"], fx=30.0, fy=31.0, cx=15.5, cy=11.5, depth_type="euclidean"),
+        g["pc_euclid"])
+    np.testing.assert_array_equal(mf.geometry.masks_to_bboxes(g["masks"]), g["bboxes"])  # incl. empty mask
+    assert mf.geometry.masks_to_bboxes(g["masks"][0]).shape == (4,)
+    x = torch.from_numpy(g["median_in"])
+    np.testing.assert_array_equal(mf.extra.median(x, axis=0).numpy(), g["median_even"])  # mean of middles
+    np.testing.assert_array_equal(mf.extra.median(x[:9], axis=0).numpy(), g["median_odd"])
+    np.testing.assert_array_equal(mf.extra.median(x).numpy(), g["median_flat"])
+    T = mf.geometry.compose_transform(R=np.eye(3) * 2, t=np.array([1.0, 2, 3]))
+    assert T[3, 3] == 1 and T[0, 0] == 2 and T[2, 3] == 3
+
+
+def test_synthetic_scene_shapes(fixtures3):
+    sc = mf.synthetic.make_icc_scene(8, seed=0, fixtures=fixtures3)
+    assert len(sc["points"]) == len(sc["sdf"]) == 8
+    assert sc["grid_target"].shape == sc["grid_nontarget_empty"].shape == (8, 32, 32, 32)
+    assert sc["pitch"].dtype == np.float32 and sc["origin"].shape == (8, 3)
+    for p, s in zip(sc["points"], sc["sdf"]):
+        assert p.dtype == np.float32 and p.shape == (len(s), 3) and 2500 < len(s) < 6000
+    assert sc["transform_gt"][0] is None and sc["transform_gt"][3] is not None
+    b = mf.synthetic.make_singleview_batch(2, seed=0)
+    assert b["rgb"].dtype == np.uint8 and b["rgb"].shape == (2, 256, 256, 3)
+    assert b["pcd"].shape == (2, 256, 256, 3) and np.isnan(b["pcd"]).any()
+    assert b["grid_nontarget_empty"].dtype == bool
+
+
+def test_model_point_selection_follows_reference_rng():
+    from morefusion_amd.contrib.singleview_3d.models import Model
+    m = Model(n_fg_class=21, with_occupancy=True).eval()
+    mask = torch.zeros(2, 64, 64, dtype=torch.bool)
+    mask[0, 10:50, 5:60] = True  # 2200 > 1000 points: permutation[:1000]
+    mask[1, 3:13, 4:24] = True  # 200 < 1000 points: arange + randint padding
+    pix = m._select_points(mask).numpy()
+    iy, ix = np.where(mask[0].numpy())
+    keep = np.random.RandomState(1234).permutation(len(iy))[:1000]  # model.py:211-213
+    np.testing.assert_array_equal(pix[0], iy[keep] * 64 + ix[keep])
+    iy, ix = np.where(mask[1].numpy())
+    keep = np.r_[np.arange(200), np.random.RandomState(1234).randint(0, 200, 800)]  # :214-218
+    np.testing.assert_array_equal(pix[1], iy[keep] * 64 + ix[keep])
+    assert sum(p.numel() for p in m.parameters()) > 30e6
+
+
+def test_shard_range_partitions_everything_once():
+    from morefusion_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
