@@ -133,23 +133,38 @@ def time_kernel_live(fn, reps):
 
 
 def roofline_voxelize(wl):
-    """Dominant hand-written HBM-bound kernel of Model.predict: k_avgvox_write inside
-    mf_average_voxelization_3d_fwd at the model's shape (B objects, P=1000, C=144, 32^3).
+    """Dominant hand-written HBM-bound op of Model.predict: mf_average_voxelization_3d_fwd
+    (dense fill + link + scatter launches), timed on the EXACT arguments one predict() passes it
+    (B objects, P=1000 clustered surface points, C=144 features, 32^3 grid).
     Algorithmic bytes / object: read P*(12+4C+4) + write C*D^3*4 + D^3*4."""
-    B, P, C, D = wl.B, 1000, 144, 32
-    dev = wl.device
-    g = torch.Generator(device="cpu").manual_seed(0)
-    values = torch.rand((B * P, C), generator=g).to(dev)
-    points = (torch.rand((B * P, 3), generator=g) * 20 + 6).to(dev)
-    bi = torch.arange(B, dtype=torch.int32).repeat_interleave(P).to(dev)
-    kw = dict(batch_size=B, origin=(0, 0, 0), pitch=1.0, dimensions=(D, D, D), check_nan=False)
-    ms = time_kernel_live(lambda: mf.functions.average_voxelization_3d(values, points, bi, **kw), 50)
+    import morefusion_amd.contrib.singleview_3d.models.model as model_mod
+
+    captured = {}
+    real = model_mod.functions_module.average_voxelization_3d
+
+    def spy(values, points, batch_indices, **kw):
+        captured["args"] = (values.clone(), points.clone(), batch_indices.clone())
+        captured["kw"] = kw
+        return real(values, points, batch_indices, **kw)
+
+    model_mod.functions_module.average_voxelization_3d = spy
+    try:
+        with torch.no_grad():
+            wl.model.predict(**wl.inputs)
+    finally:
+        model_mod.functions_module.average_voxelization_3d = real
+    values, points, bi = captured["args"]
+    kw = captured["kw"]
+    ms = time_kernel_live(lambda: real(values, points, bi, **kw), 50)
+    B, D = kw["batch_size"], kw["dimensions"][0]
+    P, C = values.shape[0] // B, values.shape[1]
     alg = B * (P * (12 + 4 * C + 4) + C * D ** 3 * 4 + D ** 3 * 4)
     achieved = alg / (ms * 1e-3) / 1e9
-    return dict(kernel="mf_average_voxelization_3d_fwd (k_avgvox_link + k_avgvox_write)",
+    return dict(kernel="mf_average_voxelization_3d_fwd (memset fill + k_avgvox_link + k_avgvox_scatter)",
                 bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
-                algorithmic_bytes_per_launch=alg, avg_launch_ms=round(ms, 5))
+                algorithmic_bytes_per_launch=alg, avg_launch_ms=round(ms, 5),
+                shape=dict(B=B, P=P, C=C, D=D))
 
 
 def cpu_baseline(wl, args):

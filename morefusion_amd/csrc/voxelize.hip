@@ -5,16 +5,16 @@
 //
 // MI355X design (not the reference's thread-per-(point,channel) float atomics into
 // a zero-filled [B,C,X,Y,Z] tensor followed by nonzero/divide launches):
-//   1. link pass   -- one thread per point: integer atomics only (count += 1,
-//                     head = exch(point id)) build a per-voxel chain.  128 KB of
-//                     int32 per 32^3 object instead of 2 x 18.9 MB of atomics targets.
-//   2. write pass  -- output-stationary: every element of the dense [B,C,X,Y,Z]
-//                     result is written exactly once, 16 B per lane, fully coalesced;
-//                     the ~3 % occupied voxels sum their chain in increasing point
-//                     index (== the CPU loop order, so bit-equal to forward_cpu and
-//                     run-to-run deterministic), divide, and store.  No memset of the
-//                     output, no float atomics, no nonzero(): HBM traffic is the
-//                     compulsory C*V*4 bytes per object.
+//   1. link pass    -- one thread per point: integer atomics only (count += 1,
+//                      head = exch(point id)) build a per-voxel chain.  128 KB of
+//                      int32 per 32^3 object instead of 2 x 18.9 MB of atomic targets.
+//   2. dense part   -- the [B,C,X,Y,Z] result is zero-filled at memset speed
+//                      (the compulsory C*V*4 bytes per object; ~97 % of it stays zero).
+//   3. sparse part  -- one wave per occupied voxel (the wave of its chain head): walk
+//                      the chain once, rank-sort the ids, lanes over channels read the
+//                      value rows coalesced, sum in increasing point index (== the CPU
+//                      loop order, so bit-equal to forward_cpu and run-to-run
+//                      deterministic), divide, store.  No float atomics, no nonzero().
 #include <algorithm>
 
 #include "mf_common.h"
@@ -60,63 +60,69 @@ __global__ __launch_bounds__(256) void k_avgvox_link(const float *__restrict__ p
   link[i] = l;
 }
 
-// Sum of values[:, c] over the chain of voxel `key`, in increasing point index.
-__device__ __forceinline__ float chain_mean(const float *__restrict__ values,
-                                            const int32_t *__restrict__ link, int32_t h, int cnt,
-                                            int C, int c) {
-  if (cnt == 1) return values[(int64_t)h * C + c] / 1.0f;
-  float s = 0.0f;
-  int last = -1;
-  for (int k = 0; k < cnt; ++k) {
-    int best = 0x7fffffff;
-    for (int m = h; m >= 0; m = link[m])
-      if (m > last && m < best) best = m;
-    s += values[(int64_t)best * C + c];
-    last = best;
-  }
-  return s / (float)cnt;
-}
-
-// grid: x = voxel tiles of 256*VEC, y = channel chunks of cpw, z = batch item.
-template <int VEC>
-__global__ __launch_bounds__(256) void k_avgvox_write(const float *__restrict__ values,
-                                                      const int32_t *__restrict__ counts,
-                                                      const int32_t *__restrict__ head,
-                                                      const int32_t *__restrict__ link, int C,
-                                                      int V, int cpw, float *__restrict__ matrix) {
-  const int b = blockIdx.z;
-  const int v0 = (blockIdx.x * 256 + threadIdx.x) * VEC;
-  if (v0 >= V) return;
-  const int c0 = blockIdx.y * cpw;
-  const int c1 = min(C, c0 + cpw);
-  const int64_t kb = (int64_t)b * V + v0;
-  int cnt[VEC], hd[VEC];
-  bool any = false;
-  if (VEC == 4) {
-    int4 c4 = *reinterpret_cast<const int4 *>(counts + kb);
-    cnt[0] = c4.x; cnt[1 % VEC] = c4.y; cnt[2 % VEC] = c4.z; cnt[3 % VEC] = c4.w;
-  } else {
-    cnt[0] = counts[kb];
-  }
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    hd[j] = -1;
-    if (cnt[j] > 0) { hd[j] = head[kb + j]; any = true; }
-  }
-  float *out = matrix + ((int64_t)b * C + c0) * V + v0;
-  for (int c = c0; c < c1; ++c, out += V) {
-    float r[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) r[j] = 0.0f;
-    if (any) {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j)
-        if (cnt[j] > 0) r[j] = chain_mean(values, link, hd[j], cnt[j], C, c);
+// Sparse half of the forward: one WAVE per point; only the wave of a voxel's chain head
+// (exactly one per occupied voxel) continues.  Lane 0 walks the chain once, the ids are
+// rank-sorted by the lanes, then lanes run over channels: coalesced reads of the value
+// rows, sum in increasing point index, divide, store.  The dense [B,C,X,Y,Z] tensor was
+// zero-filled beforehand at memset speed, so only ~3 % of its lines are touched twice.
+__global__ __launch_bounds__(256) void k_avgvox_scatter(const float *__restrict__ values,
+                                                        const float *__restrict__ points,
+                                                        const int32_t *__restrict__ batch_indices,
+                                                        const int32_t *__restrict__ counts,
+                                                        const int32_t *__restrict__ head,
+                                                        const int32_t *__restrict__ link, int64_t n,
+                                                        int C, int B, int X, int Y, int Z, float ox,
+                                                        float oy, float oz, float pitch,
+                                                        float *__restrict__ matrix) {
+  __shared__ int s_ids[4][64];
+  __shared__ int s_sorted[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  int v;
+  bool has_nan;
+  const bool ok = voxel_of(points, i, ox, oy, oz, pitch, X, Y, Z, v, has_nan);
+  const int b = batch_indices[i];
+  if (!(ok && b >= 0 && b < B)) return;
+  const int64_t V = (int64_t)X * Y * Z;
+  const int64_t key = (int64_t)b * V + v;
+  if (head[key] != (int32_t)i) return;  // not this voxel's chain head (wave-uniform)
+  const int cnt = counts[key];
+  float *out = matrix + (int64_t)b * C * V + v;
+  if (cnt <= 64) {
+    if (lane == 0) {
+      int m = (int)i;
+      for (int k = 0; k < cnt; ++k) { s_ids[wave][k] = m; m = link[m]; }
     }
-    if (VEC == 4) {
-      *reinterpret_cast<float4 *>(out) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
-    } else {
-      out[0] = r[0];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < cnt) {
+      const int mine = s_ids[wave][lane];
+      int rank = 0;
+      for (int k = 0; k < cnt; ++k) rank += s_ids[wave][k] < mine ? 1 : 0;
+      s_sorted[wave][rank] = mine;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int ch = lane; ch < C; ch += 64) {
+      float s = 0.0f;
+      for (int k = 0; k < cnt; ++k) s += values[(int64_t)s_sorted[wave][k] * C + ch];
+      out[(int64_t)ch * V] = s / (float)cnt;
+    }
+  } else {  // pathological pile-up in one voxel: repeated selection, still in index order
+    for (int ch = lane; ch < C; ch += 64) {
+      float s = 0.0f;
+      int last = -1;
+      for (int k = 0; k < cnt; ++k) {
+        int best = 0x7fffffff;
+        for (int m = (int)i; m >= 0; m = link[m])
+          if (m > last && m < best) best = m;
+        s += values[(int64_t)best * C + ch];
+        last = best;
+      }
+      out[(int64_t)ch * V] = s / (float)cnt;
     }
   }
 }
@@ -245,17 +251,12 @@ extern "C" int mf_average_voxelization_3d_fwd(const float *values, const float *
                        points, batch_indices, n, B, X, Y, Z, ox, oy, oz, pitch, counts, head, link,
                        nan_flag);
   }
-  const bool vec4 = (V % 4 == 0);
-  const int per = 256 * (vec4 ? 4 : 1);
-  const int tiles = (int)((V + per - 1) / per);
-  const int cpw = pick_cpw(C, B, tiles);
-  dim3 grid(tiles, (C + cpw - 1) / cpw, B);
-  if (vec4)
-    hipLaunchKernelGGL(k_avgvox_write<4>, grid, dim3(256), 0, stream, values, counts, head, link,
-                       C, (int)V, cpw, matrix);
-  else
-    hipLaunchKernelGGL(k_avgvox_write<1>, grid, dim3(256), 0, stream, values, counts, head, link,
-                       C, (int)V, cpw, matrix);
+  // dense part at memset speed, then the sparse part (one wave per occupied voxel)
+  MF_TRY(hipMemsetAsync(matrix, 0, sizeof(float) * B * C * V, stream));
+  if (n > 0)
+    hipLaunchKernelGGL(k_avgvox_scatter, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
+                       values, points, batch_indices, counts, head, link, n, C, B, X, Y, Z, ox,
+                       oy, oz, pitch, matrix);
   return mf::check_launch("mf_average_voxelization_3d_fwd");
 }
 

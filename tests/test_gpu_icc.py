@@ -78,8 +78,8 @@ def test_icc_step_by_step_api_matches_fused_refine(scene8):
     b = mf.contrib.IterativeCollisionCheckLink(scene8["transform_init"][:n], sdf_offset=0.02).to_gpu()
     losses_b, traj = b.refine(*args, n_iter=iters, return_history=True)
     np.testing.assert_allclose(losses_b.cpu().numpy(), losses_a, rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(b.quaternion.detach().cpu().numpy(), a.quaternion.detach().cpu().numpy(), atol=2e-5)
-    np.testing.assert_allclose(b.translation.detach().cpu().numpy(), a.translation.detach().cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(b.quaternion.detach().cpu().numpy(), a.quaternion.detach().cpu().numpy(), atol=2e-4)
+    np.testing.assert_allclose(b.translation.detach().cpu().numpy(), a.translation.detach().cpu().numpy(), atol=2e-4)
 
 
 @pytest.mark.parametrize("n,iters", [(3, 30), (8, 100)])

@@ -11,6 +11,7 @@ from bench import Workload, parse  # noqa: E402
 
 sys.argv = [sys.argv[0]] + sys.argv[1:]
 args = parse()
+if os.environ.get("CUDNN_BENCH"): torch.backends.cudnn.benchmark = True
 wl = Workload(args, 0, torch.device("cuda", 0))
 reps = int(os.environ.get("REPS", "5"))
 what = os.environ.get("WHAT", "icc")
