@@ -66,7 +66,7 @@ struct IccArgs {
   float *bound;           // [O][4]   model-frame bounding sphere
   float *St;              // [S]
   float *part;            // [O][NB][kNumOwn]
-  long long *oth;         // [O][NB][max_ns][12] fixed-point collision moments per block
+  float *oth;             // [O][NB][max_ns][12] collision moments per block
   int max_ns;
   int32_t *step;          // [S] (unused scratch)
   int4 *meta;             // [O] {scene first object, scene end object, point begin, point end}
@@ -201,22 +201,28 @@ __global__ __launch_bounds__(64) void k_icc_pose(IccArgs a, const float *__restr
 }
 
 // ---- launch 1: TDF tiles in LDS -------------------------------------------------
-// Latency design.  A dependent global load costs ~0.3-0.7 us on this part, so the kernel
-// is organised to have O(1) of them: (1) the <= 32 source objects' R|t, bounding spheres
-// and point ranges are fetched by one lane each, in parallel; (2) the flattened source
-// point list streams through in chunks of kTdfThreads with the NEXT chunk's loads issued
-// before the current one is processed; (3) points whose 3^3 neighbourhood touches this
-// tile are compacted into an LDS survivor list and (survivor, offset) work items are
-// then spread evenly over all lanes -- no idle lanes behind a divergent 27-way loop.
+// What measurement taught (profiles/): a dependent global load costs ~0.3-0.7 us, an
+// empty launch ~5 us, ds_min_u64 is ~an order of magnitude slower than 32-bit LDS
+// atomics, and every slab workgroup re-scanning every point is instruction-bound.  So:
+//  (1) the <= 32 source objects' R|t, bounding spheres and point ranges are fetched by
+//      one lane each, in parallel; whole objects are culled by their bounding sphere;
+//  (2) objects are walked wave-uniformly (R|t in scalar registers, ~20 instructions per
+//      rejected point), U loads in flight per lane;
+//  (3) points whose 3^3 neighbourhood touches this tile are appended to an LDS list
+//      (wave-aggregated), then (survivor, offset) work items are spread over all lanes;
+//  (4) (min, arg-min) is resolved with two passes of 32-bit LDS atomics: pass 1
+//      atomicMin(distance bits), pass 2 atomicMin(candidate id) among the candidates
+//      that equal the minimum -- exact, deterministic (lowest id among ties).
 // KS = kernel size of truncated_distance_function.py:36-38 (3 for voxel_threshold 2).
+constexpr int kSurvCap = 4096;  // LDS survivor list (64 KB); drained in place when it fills up
+
 template <int KS>
 __global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, int SX) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn1[];  // dist[nvox], id[nvox]
   __shared__ float s_Rt[kMaxSceneObjects][12];
-  __shared__ int s_start[kMaxSceneObjects + 1];
-  __shared__ int s_pbase[kMaxSceneObjects];
-  __shared__ int s_cnt[kMaxSceneObjects];
-  __shared__ float4 s_surv[kTdfThreads / 64][64];  // per-wave survivor list: fx,fy,fz,bits(id)
+  __shared__ int s_p0[kMaxSceneObjects], s_p1[kMaxSceneObjects];
+  __shared__ float4 s_surv[kSurvCap];  // fx, fy, fz, bits(point id)
+  __shared__ int s_nsurv;
   __shared__ float s_max[kTdfThreads / 64];
   const int ks = KS > 0 ? KS : ks_rt;
   const int h = ks / 2, K = ks * ks * ks;
@@ -228,6 +234,7 @@ __global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, i
   const int x0 = blockIdx.x * SX;
   const int sx = min(SX, D - x0);
   const int nvox = sx * D * D;
+  uint32_t *s_dist = s_dyn1, *s_id = s_dyn1 + SX * D * D;
   const float pitch = a.pitch[o];
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
   const float trunc = a.thr * pitch;
@@ -235,19 +242,19 @@ __global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, i
   // conservative (approximate-arithmetic) rejection bounds, in voxel units
   const float xlo = (float)x0 - fh - 0.51f, xhi = (float)(x0 + sx - 1) + fh + 0.51f;
   const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
-  const unsigned long long init = ((unsigned long long)__float_as_uint(trunc) << 32) | kNoCand;
-  for (int i = threadIdx.x; i < nvox; i += kTdfThreads) s_key[i] = init;
+  const uint32_t tbits = __float_as_uint(trunc);
+  for (int i = threadIdx.x; i < nvox; i += kTdfThreads) { s_dist[i] = tbits; s_id[i] = kNoCand; }
+  if (threadIdx.x == 0) s_nsurv = 0;
   // (1) per-object metadata, one lane per object
   if (threadIdx.x < Ns) {
     const int j = ja + threadIdx.x;
-    int cnt = 0;
+    int p0 = 0, p1 = 0;
     if (other ? (j != o) : (j == o)) {
       const float4 r0 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j);
       const float4 r1 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 4);
       const float4 r2 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 8);
       const float4 b = *reinterpret_cast<const float4 *>(a.bound + 4 * j);
       const int4 mj = a.meta[j];
-      const int p0 = mj.z, p1 = mj.w;
       float *R = s_Rt[threadIdx.x];
       R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y;
       R[6] = r1.z; R[7] = r1.w; R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w;
@@ -258,96 +265,138 @@ __global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, i
       const float r = b.w * inv_pitch + 0.05f + 1e-4f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
       const bool hit = b.w >= 0.0f && !(cx + r < xlo || cx - r > xhi || cy + r < glo ||
                                         cy - r > ghi || cz + r < glo || cz - r > ghi);
-      cnt = hit ? p1 - p0 : 0;
-      s_pbase[threadIdx.x] = p0;
+      if (hit) { p0 = mj.z; p1 = mj.w; }
     }
-    s_cnt[threadIdx.x] = cnt;
+    s_p0[threadIdx.x] = p0;
+    s_p1[threadIdx.x] = p1;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int e = 0; e < Ns; ++e) { s_start[e] = acc; acc += s_cnt[e]; }
-    s_start[Ns] = acc;
-  }
-  __syncthreads();
-  const int total = (a.dbg & 1) ? 0 : s_start[Ns];
-  const uint32_t *s_hi = reinterpret_cast<const uint32_t *>(s_key);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float4 *wl = s_surv[wave];
+  const int lane = threadIdx.x & 63;
 
-  constexpr int U = 8;  // points in flight per lane: total/(1024*8) dependent round trips
-  for (int c0 = 0; c0 < total; c0 += kTdfThreads * U) {
-    int ee[U];
-    uint32_t pp[U];
-    float4 mm[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {  // (2) all loads of this super-chunk issued back to back
-      const int idx = c0 + u * kTdfThreads + threadIdx.x;
-      ee[u] = -1;
-      pp[u] = 0;
-      mm[u] = make_float4(0, 0, 0, 0);
-      if (idx < total) {
-        int e = 0;
-        while (idx >= s_start[e + 1]) ++e;
-        ee[u] = e;
-        pp[u] = (uint32_t)(s_pbase[e] + (idx - s_start[e]));
-        mm[u] = a.pts4[pp[u]];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      bool surv = false;
-      float fx = 0, fy = 0, fz = 0;
-      if (ee[u] >= 0) {
-        const float *R = s_Rt[ee[u]];
-        const float4 m = mm[u];
-        // transform_points: ((R0 x + R1 y) + R2 z) + t, un-fused (oracle order)
-        const float wx = ((R[0] * m.x + R[1] * m.y) + R[2] * m.z) + R[9];
-        const float ax = (wx - ox) * inv_pitch;  // cheap reject before paying IEEE divides
-        const float ex = 0.01f + 1e-5f * fabsf(ax);
-        if (ax >= xlo - ex && ax <= xhi + ex) {
-          const float wy = ((R[3] * m.x + R[4] * m.y) + R[5] * m.z) + R[10];
-          const float wz = ((R[6] * m.x + R[7] * m.y) + R[8] * m.z) + R[11];
-          fx = (wx - ox) / pitch; fy = (wy - oy) / pitch; fz = (wz - oz) / pitch;
-          const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
-          surv = rx + fh >= (float)x0 && rx - fh < (float)(x0 + sx) && ry + fh >= 0.0f &&
-                 ry - fh < (float)D && rz + fh >= 0.0f && rz - fh < (float)D;
-        }
-      }
-      // (3) wave-level compaction: survivors -> this wave's LDS list, then
-      // (survivor, kernel offset) work items over all 64 lanes.  No block barrier.
-      const unsigned long long mask = (a.dbg & 2) ? 0ull : __ballot(surv);
-      if (mask == 0ull) continue;  // wave-uniform
-      const int ns = __popcll(mask);
-      if (surv) {
-        const int slot = __popcll(mask & ((1ull << lane) - 1ull));
-        wl[slot] = make_float4(fx, fy, fz, __uint_as_float(pp[u]));
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (int w = lane; w < ns * K; w += 64) {
-        const int si = w / K, k = w - si * K;
-        const float4 sv = wl[si];
-        const int aa = k / (ks * ks), bb = (k / ks) % ks, cc = k % ks;
-        const int ix = (int)roundf(sv.x) + bb - h;
-        const int iy = (int)roundf(sv.y) + aa - h;
-        const int iz = (int)roundf(sv.z) + cc - h;
-        if (ix < x0 || ix >= x0 + sx || iy < 0 || iy >= D || iz < 0 || iz >= D) continue;
-        const float dx = sv.x - (float)ix, dy = sv.y - (float)iy, dz = sv.z - (float)iz;
-        const float dist = pitch * sqrtf((dx * dx + dy * dy) + dz * dz);
-        if (dist < trunc) {
-          const int li = ((ix - x0) * D + iy) * D + iz;
-          const uint32_t db = __float_as_uint(dist);
-          if (!(a.dbg & 4) && db <= s_hi[2 * li + 1]) {
-            const uint32_t id = __float_as_uint(sv.w) * (uint32_t)K + (uint32_t)k;
-            atomicMin(&s_key[li], ((unsigned long long)db << 32) | id);
+  // Work item = (survivor, a): one y-row of the 3^3 neighbourhood, looping over the z
+  // offsets and the x offsets that fall into this tile; items are spread evenly over all
+  // lanes.  pass 1: 32-bit atomicMin of the distance bits behind a peek; `maybe` collects
+  // (one bit per item of this lane) the items that could still hold a minimum.
+  // pass 2: where the distance equals the final minimum, atomicMin of the candidate id.
+  auto items = [&](const int ns, const int pass, unsigned long long &maybe, const bool marks) {
+    int item_no = 0;
+    for (int w = threadIdx.x; w < ns * ks; w += kTdfThreads, ++item_no) {
+      const int mbit = item_no < 63 ? item_no : 63;  // bit 63 stands for every later item
+      if (pass == 2 && marks && !((maybe >> mbit) & 1ull)) continue;
+      const int si = w / ks, aa = w - si * ks;
+      const float4 sv = s_surv[si];
+      const int iy = (int)roundf(sv.y) + aa - h;
+      if (iy < 0 || iy >= D) continue;
+      const int irx = (int)roundf(sv.x), irz = (int)roundf(sv.z);
+      const float dy = sv.y - (float)iy;
+      const float dy2 = dy * dy;
+      const uint32_t idb = __float_as_uint(sv.w) * (uint32_t)K + (uint32_t)(aa * ks * ks);
+      bool cand = false;
+      for (int bb = 0; bb < ks; ++bb) {
+        const int ix = irx + bb - h;
+        if (ix < x0 || ix >= x0 + sx) continue;
+        const float dx = sv.x - (float)ix;
+        const float dxy = dx * dx + dy2;  // (dx^2 + dy^2) + dz^2: the oracle's order
+        const int lrow = ((ix - x0) * D + iy) * D;
+        for (int cc = 0; cc < ks; ++cc) {
+          const int iz = irz + cc - h;
+          if (iz < 0 || iz >= D) continue;
+          const float dz = sv.z - (float)iz;
+          const float dist = pitch * sqrtf(dxy + dz * dz);
+          if (dist < trunc) {
+            const uint32_t db = __float_as_uint(dist);
+            if (pass == 1) {
+              if (db <= s_dist[lrow + iz]) { atomicMin(&s_dist[lrow + iz], db); cand = true; }
+            } else if (db == s_dist[lrow + iz]) {
+              atomicMin(&s_id[lrow + iz], idb + (uint32_t)(bb * ks + cc));
+            }
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();  // list is reused by the next round
+      if (pass == 1 && cand) maybe |= 1ull << mbit;
     }
+  };
+
+  // Stream every accepted object (wave-uniform R|t), appending tile survivors to the LDS
+  // list; whenever the list could overflow during the next super-chunk it is drained
+  // through items(pass) -- block-uniform decision behind a barrier.  Returns whether it
+  // drained (then pass 2 must re-stream, because the list no longer holds everything).
+  constexpr int U = 2;
+  auto scan = [&](const int pass) -> bool {
+    bool drained = false;
+    unsigned long long unused = 0ull;
+    for (int e = 0; e < Ns; ++e) {
+      const int p0 = s_p0[e], p1 = s_p1[e];  // block-uniform
+      if (p1 <= p0) continue;
+      const float R0 = s_Rt[e][0], R1 = s_Rt[e][1], R2 = s_Rt[e][2], R3 = s_Rt[e][3],
+                  R4 = s_Rt[e][4], R5 = s_Rt[e][5], R6 = s_Rt[e][6], R7 = s_Rt[e][7],
+                  R8 = s_Rt[e][8], T0 = s_Rt[e][9], T1 = s_Rt[e][10], T2 = s_Rt[e][11];
+      for (int c0 = p0; c0 < p1; c0 += kTdfThreads * U) {
+        float4 mm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int p = c0 + u * kTdfThreads + threadIdx.x;
+          mm[u] = p < p1 ? a.pts4[p] : make_float4(0, 0, 0, 0);
+        }
+        __syncthreads();  // s_nsurv below is the value every lane agrees on
+        if (s_nsurv + kTdfThreads * U > kSurvCap) {
+          items(s_nsurv, pass, unused, false);
+          __syncthreads();
+          if (threadIdx.x == 0) s_nsurv = 0;
+          __syncthreads();
+          drained = true;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int p = c0 + u * kTdfThreads + threadIdx.x;
+          bool surv = false;
+          float fx = 0, fy = 0, fz = 0;
+          if (p < p1) {
+            const float4 m = mm[u];
+            // transform_points: ((R0 x + R1 y) + R2 z) + t, un-fused (oracle order)
+            const float wx = ((R0 * m.x + R1 * m.y) + R2 * m.z) + T0;
+            const float ax = (wx - ox) * inv_pitch;  // cheap reject before the IEEE divides
+            const float ex = 0.01f + 1e-5f * fabsf(ax);
+            if (ax >= xlo - ex && ax <= xhi + ex) {
+              const float wy = ((R3 * m.x + R4 * m.y) + R5 * m.z) + T1;
+              const float wz = ((R6 * m.x + R7 * m.y) + R8 * m.z) + T2;
+              fx = (wx - ox) / pitch; fy = (wy - oy) / pitch; fz = (wz - oz) / pitch;
+              const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
+              surv = rx + fh >= (float)x0 && rx - fh < (float)(x0 + sx) && ry + fh >= 0.0f &&
+                     ry - fh < (float)D && rz + fh >= 0.0f && rz - fh < (float)D;
+            }
+          }
+          const unsigned long long mask = (a.dbg & 2) ? 0ull : __ballot(surv);
+          if (mask == 0ull) continue;  // wave-uniform
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&s_nsurv, __popcll(mask));
+          base = __shfl(base, 0, 64);
+          if (surv)
+            s_surv[base + __popcll(mask & ((1ull << lane) - 1ull))] =
+                make_float4(fx, fy, fz, __uint_as_float((uint32_t)p));
+        }
+      }
+    }
+    return drained;
+  };
+
+  unsigned long long maybe = 0ull;
+  bool drained = false;
+  if (!(a.dbg & 1)) drained = scan(1);
+  __syncthreads();
+  if (!drained) {  // the common case: the whole tile's survivors are in LDS
+    const int ns = (a.dbg & 4) ? 0 : s_nsurv;
+    items(ns, 1, maybe, true);
+    __syncthreads();
+    items(ns, 2, maybe, true);
+  } else {  // crowded tile: finish pass 1, then stream everything again for the ids
+    items(s_nsurv, 1, maybe, false);
+    __syncthreads();
+    if (threadIdx.x == 0) s_nsurv = 0;
+    __syncthreads();
+    scan(2);
+    __syncthreads();
+    items(s_nsurv, 2, maybe, false);
   }
   __syncthreads();
   // epilogue: winners out (coalesced 8 B/lane) + max raw inside weight of this tile
@@ -356,9 +405,8 @@ __global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, i
   unsigned long long *Wg = a.W + (int64_t)g * D * D * D + (int64_t)x0 * D * D;
   float wmax = 0.0f;
   for (int i = threadIdx.x; i < nvox; i += kTdfThreads) {
-    const unsigned long long k = s_key[i];
-    Wg[i] = k;
-    const uint32_t lo = (uint32_t)k;
+    const uint32_t lo = s_id[i];
+    Wg[i] = ((unsigned long long)s_dist[i] << 32) | lo;
     float w = (lo != kNoCand ? a.pts4[lo / (uint32_t)K].w : -1.0f) + offset;
     w = w < 0.0f ? 0.0f : w;
     wmax = fmaxf(wmax, w);
@@ -394,7 +442,11 @@ constexpr int kVPT = kVoxPerBlock / kAccThreads;  // voxels per thread
 __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
   __shared__ float s_red[6][kNumOwn];
   __shared__ float s_tr[kAccThreads * (kNumOwn + 1)];
-  __shared__ unsigned long long s_oth[kMaxSceneObjects * 12];
+  // collision moments as 64-bit fixed point split in two 32-bit limbs: a returning
+  // ds_add_u32 on the low limb yields the carry for the high limb.  Integer addition is
+  // associative, so the result is independent of the order of the atomics (bitwise
+  // reproducible) while avoiding the ~10x slower 64-bit LDS atomics.
+  __shared__ uint32_t s_lo[kMaxSceneObjects * 12], s_hi[kMaxSceneObjects * 12];
   __shared__ float s_Rt[kMaxSceneObjects][12];
   __shared__ int s_off[kMaxSceneObjects + 1];
   const int o = blockIdx.y;
@@ -405,7 +457,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
   // all independent loads first: scene tables, scalars, and this thread's voxels
   if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
-  for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) s_oth[i] = 0ull;
+  for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) { s_lo[i] = 0u; s_hi[i] = 0u; }
   const float pitch = a.pitch[o];
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
   const float M_own = __uint_as_float(a.Mbits[2 * o]);
@@ -497,9 +549,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
       }
     }
     if (oth_wins && lo_o != kNoCand && ins != 0.0f) {
-      // collision term: gradient flows to the OTHER object's pose.  Accumulated in LDS as
-      // 2^44 fixed point with integer atomics: associative, hence order-independent and
-      // bitwise reproducible (float atomics would not be)
+      // collision term: gradient flows to the OTHER object's pose
       const uint32_t p = lo_o / (uint32_t)K;
       int e = 0;
       while (e + 1 < Ns && (int)p >= s_off[e + 1]) ++e;
@@ -510,14 +560,20 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
       const float B = wo_in * ins / trunc;
       if (ok && isfinite(B)) {
         const float u[3] = {ux, uy, uz};
-        unsigned long long *dst = s_oth + 12 * e;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-          const float s = u[d] * B;
-          atomicAdd(&dst[4 * d + 0], (unsigned long long)__double2ll_rn((double)(s * m.x) * kFix));
-          atomicAdd(&dst[4 * d + 1], (unsigned long long)__double2ll_rn((double)(s * m.y) * kFix));
-          atomicAdd(&dst[4 * d + 2], (unsigned long long)__double2ll_rn((double)(s * m.z) * kFix));
-          atomicAdd(&dst[4 * d + 3], (unsigned long long)__double2ll_rn((double)s * kFix));
+          const float sB = u[d] * B;
+          const float val[4] = {sB * m.x, sB * m.y, sB * m.z, sB};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const unsigned long long x =
+                (unsigned long long)__double2ll_rn((double)val[c] * kFix);
+            const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+            const int idx = 12 * e + 4 * d + c;
+            const uint32_t old = atomicAdd(&s_lo[idx], xl);
+            const uint32_t carry = (uint32_t)(old + xl < old);
+            if (xh + carry != 0u) atomicAdd(&s_hi[idx], xh + carry);
+          }
         }
       }
     }
@@ -526,7 +582,6 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
   // lane, then kSeg partial sums per component, then the final kSeg-term sum.  ~1.5k
   // cycles instead of 234 dependent cross-lane shuffles per wave.
   constexpr int kRow = kNumOwn + 1, kSeg = 6, kRows = (kAccThreads + kSeg - 1) / kSeg;
-  __syncthreads();  // s_tr aliases nothing live; all lanes are past the voxel loop
 #pragma unroll
   for (int i = 0; i < kNumOwn; ++i) s_tr[threadIdx.x * kRow + i] = acc[i];
   __syncthreads();
@@ -544,9 +599,12 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
     for (int w = 1; w < kSeg; ++w) s += s_red[w][threadIdx.x];
     a.part[((int64_t)o * gridDim.x + blockIdx.x) * kNumOwn + threadIdx.x] = s;
   }
-  // (the barrier above also orders every LDS atomic of this block)
-  long long *po = a.oth + ((int64_t)o * gridDim.x + blockIdx.x) * a.max_ns * 12;
-  for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) po[i] = (long long)s_oth[i];
+  // collision partials of this block (the barriers above order the LDS atomics)
+  float *po = a.oth + ((int64_t)o * gridDim.x + blockIdx.x) * a.max_ns * 12;
+  for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) {
+    const long long x = (long long)(((unsigned long long)s_hi[i] << 32) | s_lo[i]);
+    po[i] = (float)((double)x / kFix);
+  }
 }
 
 // ---- launch 3: reduce, loss, chain rule, chainer-Adam -----------------------------
@@ -563,7 +621,7 @@ __global__ __launch_bounds__(kStepThreads) void k_icc_step(IccArgs a, int NB, in
                                                            float *gq_out, float *gt_out,
                                                            float *traj, int it) {
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-  __shared__ long long s_o[kMaxSceneObjects * 12];
+  __shared__ float s_o[kMaxSceneObjects * 12];
   __shared__ float s_coef[4];
   const int sc = blockIdx.x;
   const int ja = a.scene_off[sc], jb = a.scene_off[sc + 1];
@@ -571,38 +629,40 @@ __global__ __launch_bounds__(kStepThreads) void k_icc_step(IccArgs a, int NB, in
   float *s_part = s_dyn;                      // [Ns*NB][kNumOwn] raw copy
   float *s_tot = s_part + Ns * NB * kNumOwn;  // [Ns][kNumOwn]
   float *s_G = s_tot + Ns * kNumOwn;          // [Ns][12]
+  float *s_orow = s_G + Ns * 12;              // [8][Ns*12] partial collision sums
   const float S_t = a.St[sc];
-  // independent loads: own partials -> LDS, collision partials -> integer LDS atomics
+  // independent, coalesced loads: own partials -> LDS
   const float *src = a.part + (int64_t)ja * NB * kNumOwn;
   const int n_own = Ns * NB * kNumOwn;
   for (int i = threadIdx.x; i < n_own; i += kStepThreads) s_part[i] = src[i];
-  for (int i = threadIdx.x; i < Ns * 12; i += kStepThreads) s_o[i] = 0;
-  __syncthreads();
   {
-    const int row = a.max_ns * 12;  // one (grid, block) row of collision partials
-    const long long *po = a.oth + (int64_t)ja * NB * row;
-    const int n_rows = Ns * NB;
-    // lane -> (row, column); 8 independent loads in flight per lane, then integer adds
-    const int n_el = n_rows * Ns * 12;
-    const int ncol = Ns * 12;
-    for (int i0 = threadIdx.x; i0 < n_el; i0 += kStepThreads * 8) {
-      long long v[8];
-      int cidx[8];
+    // collision partials [Ns*NB rows][max_ns*12]: 8 lane groups x (Ns*12) columns, each
+    // lane sums its rows in increasing order with 8 loads in flight; then the 8 groups
+    // are added in order -> fixed summation order, hence reproducible
+    const int row = a.max_ns * 12, ncol = Ns * 12, n_rows = Ns * NB;
+    const float *po = a.oth + (int64_t)ja * NB * row;
+    if (threadIdx.x < 8 * ncol) {
+      const int grp = threadIdx.x / ncol, c = threadIdx.x - grp * ncol;
+      float sacc = 0.0f;
+      for (int r0 = grp; r0 < n_rows; r0 += 64) {
+        float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * kStepThreads;
-        v[u] = 0;
-        cidx[u] = 0;
-        if (i < n_el) {
-          const int r = i / ncol, c = i - r * ncol;
-          cidx[u] = c;
-          v[u] = po[(int64_t)r * row + c];
+        for (int u = 0; u < 8; ++u) {
+          const int r = r0 + 8 * u;
+          v[u] = r < n_rows ? po[(int64_t)r * row + c] : 0.0f;
         }
-      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (v[u] != 0) atomicAdd((unsigned long long *)&s_o[cidx[u]], (unsigned long long)v[u]);
+        for (int u = 0; u < 8; ++u) sacc += v[u];
+      }
+      s_orow[threadIdx.x] = sacc;
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < Ns * 12) {
+    float sacc = 0.0f;
+#pragma unroll
+    for (int grp = 0; grp < 8; ++grp) sacc += s_orow[grp * Ns * 12 + threadIdx.x];
+    s_o[threadIdx.x] = sacc;
   }
   // fixed-order reduction over blocks: 4 lanes per (object, component), 2 shuffle steps
   for (int i = threadIdx.x; i < Ns * kNumOwn * 4; i += kStepThreads) {
@@ -634,7 +694,7 @@ __global__ __launch_bounds__(kStepThreads) void k_icc_step(IccArgs a, int NB, in
   if (threadIdx.x < Ns * 12) {
     const int jo = threadIdx.x / 12, c = threadIdx.x % 12;
     const float *U = s_tot + jo * kNumOwn + 3;
-    const float oth = (float)((double)s_o[threadIdx.x] / kFix);
+    const float oth = s_o[threadIdx.x];
     s_G[threadIdx.x] = ((s_coef[0] * U[c] - s_coef[1] * U[12 + c]) + s_coef[2] * U[24 + c]) -
                        s_coef[1] * oth;
   }
@@ -724,7 +784,7 @@ WsLayout ws_layout(int O, int S, int D, int max_ns = kMaxSceneObjects) {
   l.bound = off; off = align256(off + O * 4 * 4);
   l.St = off; off = align256(off + S * 4);
   l.part = off; off = align256(off + (int64_t)O * l.NB * kNumOwn * 4);
-  l.oth = off; off = align256(off + (int64_t)O * l.NB * max_ns * 12 * 8);
+  l.oth = off; off = align256(off + (int64_t)O * l.NB * max_ns * 12 * 4);
   l.step = off; off = align256(off + S * 4);
   l.meta = off; off = align256(off + (int64_t)O * 16);
   l.total = off;
@@ -756,7 +816,7 @@ IccArgs make_args(const mfIccBatch *b, void *ws, int max_ns) {
   a.bound = (float *)(p + l.bound);
   a.St = (float *)(p + l.St);
   a.part = (float *)(p + l.part);
-  a.oth = (long long *)(p + l.oth);
+  a.oth = (float *)(p + l.oth);
   a.step = (int32_t *)(p + l.step);
   a.meta = (int4 *)(p + l.meta);
   return a;
@@ -776,7 +836,7 @@ void launch_iteration(const IccArgs &a, int ks, int SX, int NB, int max_ns, int 
                       hipStream_t stream) {
   const int D = a.D;
   const dim3 g1((D + SX - 1) / SX, 2 * a.O);
-  const size_t lds1 = (size_t)SX * D * D * sizeof(unsigned long long);
+  const size_t lds1 = (size_t)SX * D * D * 2 * sizeof(uint32_t);
   if (ks == 3)
     hipLaunchKernelGGL(k_icc_tdf<3>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
   else
@@ -786,7 +846,7 @@ void launch_iteration(const IccArgs &a, int ks, int SX, int NB, int max_ns, int 
   const double fix1 = 1.0 - pow(0.9, (double)adam_step), fix2 = 1.0 - pow(0.999, (double)adam_step);
   const float aq = (float)((double)alpha_q * sqrt(fix2) / fix1);
   const float at = (float)((double)alpha_t * sqrt(fix2) / fix1);
-  const size_t lds3 = (size_t)max_ns * (NB * kNumOwn + kNumOwn + 12) * sizeof(float);
+  const size_t lds3 = (size_t)max_ns * (NB * kNumOwn + kNumOwn + 12 + 8 * 12) * sizeof(float);
   hipLaunchKernelGGL(k_icc_step, dim3(a.S), dim3(kStepThreads), lds3, stream, a, NB, mode, q, t,
                      adam_m, adam_v, aq, at, loss, gq, gt, traj, it);
 }
@@ -831,7 +891,7 @@ static int icc_validate(const mfIccBatch *b) {
   if (int e = icc_prepare_kernels()) return e;
   if (!b || b->n_objects <= 0 || b->n_scenes <= 0 || b->dim <= 0 || b->dim > 64 ||
       b->max_scene_objects <= 0 || b->max_scene_objects > kMaxSceneObjects ||
-      (size_t)b->max_scene_objects * (ws_layout(1, 1, b->dim).NB * kNumOwn + kNumOwn + 12) * 4 >
+      (size_t)b->max_scene_objects * (ws_layout(1, 1, b->dim).NB * kNumOwn + kNumOwn + 12 + 96) * 4 >
           150 * 1024 ||
       (double)b->n_points * 343.0 >= 4294967295.0) {
     mf::set_last_error(hipErrorInvalidValue, "mf_icc: invalid batch descriptor");
@@ -845,7 +905,7 @@ static int slab_planes(int D, int n_grids) {
     const int v = atoi(e);
     if (v >= 1 && v * D * D <= 8192) return std::min(v, D);
   }
-  // tile <= 64 KB of keys; prefer >= 512 workgroups so that 256 CUs stay busy
+  // tile <= 64 KB of (dist, id) words; two 1024-lane workgroups per CU -> aim for >= 512
   int SX = std::max(1, std::min(D, 8192 / (D * D)));
   while (SX > 1 && (int64_t)((D + SX - 1) / SX) * n_grids < 512) SX = (SX + 1) / 2;
   return SX;
