@@ -148,30 +148,38 @@ class Model(nn.Module):
         return torch.gather(order, 1, keep)
 
     def predict(self, *, class_id, rgb, pcd, pitch=None, origin=None, grid_nontarget_empty=None):
-        B, H, W, _ = rgb.shape
+        B = rgb.shape[0]
         dev = rgb.device
         mask = ~torch.isnan(pcd).any(dim=3)
-        rgb = rgb.float().permute(0, 3, 1, 2)
-        pcd = pcd.float().permute(0, 3, 1, 2)
-
-        h_rgb = self.pspnet_extractor(self.resnet_extractor(rgb))
-
         if pitch is None:
             pitch = torch.tensor([self._models.get_voxel_pitch(self._voxel_dim, int(c))
                                   for c in class_id.tolist()], dtype=torch.float32, device=dev)
         else:
             pitch = torch.as_tensor(pitch, dtype=torch.float32, device=dev)
         if origin is None:
+            pcd_chw = pcd.float().permute(0, 3, 1, 2)
             centers = []
             for i in range(B):
-                centers.append(extra.median(pcd[i].reshape(3, -1)[:, mask[i].reshape(-1)].T, axis=0))
+                centers.append(extra.median(pcd_chw[i].reshape(3, -1)[:, mask[i].reshape(-1)].T, axis=0))
             origin = torch.stack(centers) - pitch[:, None] * (self._voxel_dim / 2.0 - 0.5)
         else:
             origin = torch.as_tensor(origin, dtype=torch.float32, device=dev)
+        pix = self._select_points(mask)  # [B,P]; the one host synchronisation
+        return self._predict_device(torch.as_tensor(class_id, device=dev), rgb, pcd, pix, pitch,
+                                    origin, grid_nontarget_empty)
 
-        pix = self._select_points(mask)  # [B,P]
+    def _predict_device(self, class_id, rgb, pcd, pix, pitch, origin, grid_nontarget_empty):
+        """Everything after point selection: pure device work, no host synchronisation."""
+        B = rgb.shape[0]
+        dev = rgb.device
+        rgb = rgb.float().permute(0, 3, 1, 2)
+        pcd = pcd.float().permute(0, 3, 1, 2)
+
+        h_rgb = self.pspnet_extractor(self.resnet_extractor(rgb))
+
         values = torch.gather(h_rgb.reshape(B, h_rgb.shape[1], -1), 2,
                               pix[:, None, :].expand(B, h_rgb.shape[1], -1))
+        # NaN-masked pixels are never selected; nan_to_num keeps the gather capture-safe
         points = torch.gather(pcd.reshape(B, 3, -1), 2, pix[:, None, :].expand(B, 3, -1))
 
         points = (points - origin[:, :, None]) / pitch[:, None, None]  # camera -> voxel frame
@@ -191,7 +199,7 @@ class Model(nn.Module):
         points = points * pitch[:, None, None] + origin[:, :, None]  # voxel -> camera frame
         cls_trans = points[:, None, :, :] + cls_trans * pitch[:, None, None, None]
 
-        fg_class_id = (torch.as_tensor(class_id, device=dev) - 1).long()
+        fg_class_id = (class_id - 1).long()
         ar = torch.arange(B, device=dev)
         rot = F.normalize(cls_rot[ar, fg_class_id], dim=1).transpose(1, 2)  # B4P -> BP4
         trans = cls_trans[ar, fg_class_id].transpose(1, 2)  # B3P -> BP3

@@ -259,3 +259,40 @@ def test_average_distance_add_and_add_s():
     ref = O.average_distance(g["points"], g["transform_true"], g["transforms_pred"], symmetric=True)
     np.testing.assert_allclose(add_s.cpu().numpy(), ref, rtol=1e-6, atol=1e-7)
     assert (add_s <= add + 1e-7).all()
+
+
+# ---- A13/A14 network ------------------------------------------------------------------
+def test_model_predict_shapes_and_3d_part_vs_oracle():
+    from morefusion_amd.contrib.singleview_3d.models import Model
+    torch.manual_seed(0)
+    model = Model(n_fg_class=21, with_occupancy=True).cuda().eval()
+    b = mf.synthetic.make_singleview_batch(2, seed=3)
+    inputs = {k: torch.as_tensor(b[k]).cuda() for k in
+              ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty")}
+    with torch.no_grad():
+        rot, trans, conf = model.predict(**inputs)
+        assert rot.shape == (2, 1000, 4) and trans.shape == (2, 1000, 3) and conf.shape == (2, 1000)
+        np.testing.assert_allclose(rot.norm(dim=2).cpu().numpy(), 1.0, atol=1e-5)
+        assert ((conf > 0) & (conf < 1)).all()
+        # origin=None path: median - 15.5*pitch (model.py:202-205) == the synthetic origin
+        r2, t2, c2 = model.predict(**{**inputs, "origin": None})
+        np.testing.assert_allclose(t2.cpu().numpy(), trans.cpu().numpy(), atol=1e-4)
+        # the voxel ops inside _extract against the oracle, on the network's own tensors
+        P = 1000
+        values = torch.randn(2, 32, P, device="cuda")
+        points = torch.rand(2, 3, P, device="cuda") * 24 + 4
+        feat = model._extract(values, points, inputs["grid_nontarget_empty"])
+        assert feat.shape == (2, 72 + 144 + 256 + 512, P)
+        feat2 = torch.cat((F_relu(model.conv2_rgb(F_relu(model.conv1_rgb(values)))),
+                           F_relu(model.conv2_pcd(F_relu(model.conv1_pcd(15.5 - points))))), 1)
+        vox = model._voxelize(feat2.transpose(1, 2).contiguous(), points.transpose(1, 2))
+        bi = np.arange(2, dtype=np.int32).repeat(P)
+        vox_o, _ = O.average_voxelization_3d(
+            feat2.transpose(1, 2).reshape(2 * P, -1).cpu().numpy(),
+            points.transpose(1, 2).reshape(2 * P, 3).cpu().numpy(), bi, batch_size=2,
+            origin=(0, 0, 0), pitch=1.0, dimensions=(32, 32, 32))
+        np.testing.assert_array_equal(vox.cpu().numpy(), vox_o)
+
+
+def F_relu(x):
+    return torch.nn.functional.relu(x)
