@@ -160,9 +160,17 @@ def roofline_voxelize(wl):
     P, C = values.shape[0] // B, values.shape[1]
     alg = B * (P * (12 + 4 * C + 4) + C * D ** 3 * 4 + D ** 3 * 4)
     achieved = alg / (ms * 1e-3) / 1e9
+    # HBM bytes per call from the PMC passes committed under profiles/ (separate rocprofv3
+    # --pmc FETCH_SIZE / WRITE_SIZE runs of tools/prof_voxelize.py at this exact shape)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_voxelize_pmc.json")
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        if rec["shape"] == dict(B=B, P=P, C=C, D=D):
+            traffic = rec["traffic_bytes"]
     return dict(kernel="mf_average_voxelization_3d_fwd (memset fill + k_avgvox_link + k_avgvox_scatter)",
                 bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                 algorithmic_bytes_per_launch=alg, avg_launch_ms=round(ms, 5),
                 shape=dict(B=B, P=P, C=C, D=D))
 

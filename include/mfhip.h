@@ -177,7 +177,12 @@ typedef struct {
 
 int64_t mf_icc_workspace_bytes(int32_t n_objects, int32_t n_scenes, int32_t dim);
 
-/* One forward+backward: loss [S], gq [O,4], gt [O,3]; q,t not modified. */
+/* Once per batch (and again whenever its point / grid_target arrays change): model-frame
+ * bounding spheres, scene tables and sum(grid_target) per scene into the workspace. */
+int mf_icc_prepare(const mfIccBatch *batch, void *ws, mfStream_t stream);
+
+/* One forward+backward: loss [S], gq [O,4], gt [O,3]; q,t not modified.
+ * Requires mf_icc_prepare on the same (batch, ws). */
 int mf_icc_loss_grad(const mfIccBatch *batch, const float *q, const float *t,
                      float *loss, float *gq, float *gt, void *ws, mfStream_t stream);
 

@@ -75,6 +75,8 @@ class IccScenes:
             self.n_points, voxel_dim,
             max(scene_off[i + 1] - scene_off[i] for i in range(len(scenes))),
             float(voxel_threshold), float(sdf_offset))
+        _lib.check(L.mf_icc_prepare(ctypes.byref(self.desc), self.ws.data_ptr(), _lib.stream_ptr()),
+                   "mf_icc_prepare")
 
     def loss_grad(self, q, t):
         """q [O,4], t [O,3] float32 cuda -> (loss [S], gq [O,4], gt [O,3])."""

@@ -40,8 +40,10 @@
 
 namespace {
 
+__device__ unsigned long long g_dbg_stamps[4096 * 8];  // tuning aid (MF_ICC_DEBUG & 32)
+
 constexpr int kTdfThreads = 1024;
-constexpr int kAccThreads = 256;
+constexpr int kAccThreads = 512;
 constexpr int kVoxPerBlock = 1024;  // k_icc_accum: voxels per workgroup
 constexpr int kNumOwn = 39;         // RN, S_in, PN + 3 x 12 gradient moments
 constexpr uint32_t kNoCand = 0xffffffffu;
@@ -214,14 +216,14 @@ __global__ __launch_bounds__(64) void k_icc_pose(IccArgs a, const float *__restr
 //      atomicMin(distance bits), pass 2 atomicMin(candidate id) among the candidates
 //      that equal the minimum -- exact, deterministic (lowest id among ties).
 // KS = kernel size of truncated_distance_function.py:36-38 (3 for voxel_threshold 2).
-constexpr int kSurvCap = 4096;  // LDS survivor list (64 KB); drained in place when it fills up
+constexpr int kSurvCap = 12288;  // LDS survivor list of packed (object slot, point id): 48 KB
 
 template <int KS>
-__global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, int SX) {
+__global__ __launch_bounds__(kTdfThreads, 8) void k_icc_tdf(IccArgs a, int ks_rt, int SX) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn1[];  // dist[nvox], id[nvox]
   __shared__ float s_Rt[kMaxSceneObjects][12];
   __shared__ int s_p0[kMaxSceneObjects], s_p1[kMaxSceneObjects];
-  __shared__ float4 s_surv[kSurvCap];  // fx, fy, fz, bits(point id)
+  __shared__ uint32_t s_surv[kSurvCap];  // (object slot << 27) | point id
   __shared__ int s_nsurv;
   __shared__ float s_max[kTdfThreads / 64];
   const int ks = KS > 0 ? KS : ks_rt;
@@ -242,8 +244,7 @@ __global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, i
   // conservative (approximate-arithmetic) rejection bounds, in voxel units
   const float xlo = (float)x0 - fh - 0.51f, xhi = (float)(x0 + sx - 1) + fh + 0.51f;
   const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
-  const uint32_t tbits = __float_as_uint(trunc);
-  for (int i = threadIdx.x; i < nvox; i += kTdfThreads) { s_dist[i] = tbits; s_id[i] = kNoCand; }
+  for (int i = threadIdx.x; i < nvox; i += kTdfThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
   if (threadIdx.x == 0) s_nsurv = 0;
   // (1) per-object metadata, one lane per object
   if (threadIdx.x < Ns) {
@@ -273,42 +274,62 @@ __global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, i
   __syncthreads();
   const int lane = threadIdx.x & 63;
 
-  // Work item = (survivor, a): one y-row of the 3^3 neighbourhood, looping over the z
-  // offsets and the x offsets that fall into this tile; items are spread evenly over all
-  // lanes.  pass 1: 32-bit atomicMin of the distance bits behind a peek; `maybe` collects
-  // (one bit per item of this lane) the items that could still hold a minimum.
-  // pass 2: where the distance equals the final minimum, atomicMin of the candidate id.
+  // Work item = one survivor: its ks*ks (y, z) columns times the x offsets inside this
+  // tile.  Instruction count per lane is what bounds this kernel (1024 lanes share 4
+  // SIMDs: ~8 cycles per instruction), so the inner loop is kept lean:
+  //  pass 1 works on SQUARED distances in voxel units -- no sqrt, no pitch: ~15
+  //         instructions per candidate; 32-bit atomicMin of the d2 bits behind a peek.
+  //         dist = pitch*sqrt(d2) is monotone in d2, so the minimum is the same voxel.
+  //  pass 2 re-derives, only for survivors that touched a minimum, the EXACT float
+  //         distance of near-minimal candidates (d2 within a few ulp) and, where it equals
+  //         the exact minimum and is < truncation, takes atomicMin of the candidate id:
+  //         identical winners to the oracle (lowest id among equal ROUNDED distances).
+  const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test later
   auto items = [&](const int ns, const int pass, unsigned long long &maybe, const bool marks) {
     int item_no = 0;
-    for (int w = threadIdx.x; w < ns * ks; w += kTdfThreads, ++item_no) {
-      const int mbit = item_no < 63 ? item_no : 63;  // bit 63 stands for every later item
+    for (int si = threadIdx.x; si < ns; si += kTdfThreads, ++item_no) {
+      const int mbit = item_no < 63 ? item_no : 63;
       if (pass == 2 && marks && !((maybe >> mbit) & 1ull)) continue;
-      const int si = w / ks, aa = w - si * ks;
-      const float4 sv = s_surv[si];
-      const int iy = (int)roundf(sv.y) + aa - h;
-      if (iy < 0 || iy >= D) continue;
-      const int irx = (int)roundf(sv.x), irz = (int)roundf(sv.z);
-      const float dy = sv.y - (float)iy;
-      const float dy2 = dy * dy;
-      const uint32_t idb = __float_as_uint(sv.w) * (uint32_t)K + (uint32_t)(aa * ks * ks);
+      const uint32_t packed = s_surv[si];
+      const uint32_t pid = packed & 0x07ffffffu;
+      const float *R = s_Rt[packed >> 27];
+      const float4 m = a.pts4[pid];
+      // same expressions as the scan -> bit-identical coordinates
+      float4 sv;
+      sv.x = ((((R[0] * m.x + R[1] * m.y) + R[2] * m.z) + R[9]) - ox) / pitch;
+      sv.y = ((((R[3] * m.x + R[4] * m.y) + R[5] * m.z) + R[10]) - oy) / pitch;
+      sv.z = ((((R[6] * m.x + R[7] * m.y) + R[8] * m.z) + R[11]) - oz) / pitch;
+      const int irx = (int)roundf(sv.x), iry = (int)roundf(sv.y), irz = (int)roundf(sv.z);
+      const uint32_t idb = pid * (uint32_t)K;
+      const int bb0 = max(0, x0 - irx + h), bb1 = min(ks - 1, x0 + sx - 1 - irx + h);
       bool cand = false;
-      for (int bb = 0; bb < ks; ++bb) {
+      for (int bb = bb0; bb <= bb1; ++bb) {
         const int ix = irx + bb - h;
-        if (ix < x0 || ix >= x0 + sx) continue;
         const float dx = sv.x - (float)ix;
-        const float dxy = dx * dx + dy2;  // (dx^2 + dy^2) + dz^2: the oracle's order
-        const int lrow = ((ix - x0) * D + iy) * D;
-        for (int cc = 0; cc < ks; ++cc) {
-          const int iz = irz + cc - h;
-          if (iz < 0 || iz >= D) continue;
-          const float dz = sv.z - (float)iz;
-          const float dist = pitch * sqrtf(dxy + dz * dz);
-          if (dist < trunc) {
-            const uint32_t db = __float_as_uint(dist);
+        const float dx2 = dx * dx;
+#pragma unroll
+        for (int aa = 0; aa < ks; ++aa) {
+          const int iy = iry + aa - h;
+          if (iy < 0 || iy >= D) continue;
+          const float dy = sv.y - (float)iy;
+          const float dxy = dx2 + dy * dy;  // (dx^2 + dy^2) + dz^2: the oracle's order
+          const int lrow = ((ix - x0) * D + iy) * D;
+#pragma unroll
+          for (int cc = 0; cc < ks; ++cc) {
+            const int iz = irz + cc - h;
+            if (iz < 0 || iz >= D) continue;
+            const float dz = sv.z - (float)iz;
+            const float d2 = dxy + dz * dz;
+            if (!(d2 < d2_hi)) continue;
+            const uint32_t db = __float_as_uint(d2);
+            const uint32_t cur = s_dist[lrow + iz];
             if (pass == 1) {
-              if (db <= s_dist[lrow + iz]) { atomicMin(&s_dist[lrow + iz], db); cand = true; }
-            } else if (db == s_dist[lrow + iz]) {
-              atomicMin(&s_id[lrow + iz], idb + (uint32_t)(bb * ks + cc));
+              if (db <= cur) { atomicMin(&s_dist[lrow + iz], db); cand = true; }
+            } else if (db <= cur + 8u) {  // within a few ulp of the minimal d2
+              const float dist = pitch * sqrtf(d2);
+              const float dmin = pitch * sqrtf(__uint_as_float(cur));
+              if (dist == dmin && dist < trunc)
+                atomicMin(&s_id[lrow + iz], idb + (uint32_t)((aa * ks + bb) * ks + cc));
             }
           }
         }
@@ -373,21 +394,29 @@ __global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, i
           base = __shfl(base, 0, 64);
           if (surv)
             s_surv[base + __popcll(mask & ((1ull << lane) - 1ull))] =
-                make_float4(fx, fy, fz, __uint_as_float((uint32_t)p));
+                ((uint32_t)e << 27) | (uint32_t)p;
         }
       }
     }
     return drained;
   };
 
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  auto stamp = [&](int i) {
+    if ((a.dbg & 32) && threadIdx.x == 0 && wg < 4096) g_dbg_stamps[wg * 8 + i] = wall_clock64();
+  };
+  stamp(0);
   unsigned long long maybe = 0ull;
   bool drained = false;
   if (!(a.dbg & 1)) drained = scan(1);
   __syncthreads();
+  stamp(1);
+  if ((a.dbg & 32) && threadIdx.x == 0 && wg < 4096) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)s_nsurv | ((unsigned long long)drained << 32);
   if (!drained) {  // the common case: the whole tile's survivors are in LDS
     const int ns = (a.dbg & 4) ? 0 : s_nsurv;
     items(ns, 1, maybe, true);
     __syncthreads();
+    stamp(2);
     items(ns, 2, maybe, true);
   } else {  // crowded tile: finish pass 1, then stream everything again for the ids
     items(s_nsurv, 1, maybe, false);
@@ -399,14 +428,16 @@ __global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, i
     items(s_nsurv, 2, maybe, false);
   }
   __syncthreads();
+  stamp(3);
   // epilogue: winners out (coalesced 8 B/lane) + max raw inside weight of this tile
   // (truncated_distance_function.py:198-204: -1 where no winner, + offset, clamp at 0)
   const float offset = other ? 0.0f : a.sdf_offset;
   unsigned long long *Wg = a.W + (int64_t)g * D * D * D + (int64_t)x0 * D * D;
   float wmax = 0.0f;
   for (int i = threadIdx.x; i < nvox; i += kTdfThreads) {
-    const uint32_t lo = s_id[i];
-    Wg[i] = ((unsigned long long)s_dist[i] << 32) | lo;
+    const uint32_t lo = s_id[i];  // set only where pitch*sqrt(min d2) < trunc
+    const float dist = lo != kNoCand ? pitch * sqrtf(__uint_as_float(s_dist[i])) : trunc;
+    Wg[i] = ((unsigned long long)__float_as_uint(dist) << 32) | lo;
     float w = (lo != kNoCand ? a.pts4[lo / (uint32_t)K].w : -1.0f) + offset;
     w = w < 0.0f ? 0.0f : w;
     wmax = fmaxf(wmax, w);
@@ -420,6 +451,7 @@ __global__ __launch_bounds__(kTdfThreads) void k_icc_tdf(IccArgs a, int ks_rt, i
     for (int i = 1; i < kTdfThreads / 64; ++i) m = fmaxf(m, s_max[i]);
     atomicMax(&a.Mbits[g], __float_as_uint(m));  // m >= 0: uint order == float order
   }
+  stamp(4);
 }
 
 // ---- launch 2: weights, sums, gradient moments ------------------------------------
@@ -440,16 +472,22 @@ __device__ __forceinline__ void world_frac(const float *Rt, const float4 m, floa
 constexpr int kVPT = kVoxPerBlock / kAccThreads;  // voxels per thread
 
 __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
-  __shared__ float s_red[6][kNumOwn];
-  __shared__ float s_tr[kAccThreads * (kNumOwn + 1)];
-  // collision moments as 64-bit fixed point split in two 32-bit limbs: a returning
-  // ds_add_u32 on the low limb yields the carry for the high limb.  Integer addition is
-  // associative, so the result is independent of the order of the atomics (bitwise
-  // reproducible) while avoiding the ~10x slower 64-bit LDS atomics.
-  __shared__ uint32_t s_lo[kMaxSceneObjects * 12], s_hi[kMaxSceneObjects * 12];
+  __shared__ float s_tr[kAccThreads * kNumOwn];
+  // collision moments as 2^44 fixed point split in three 20-bit limbs held in 32-bit LDS
+  // words: <= 1024 adds per block can never overflow a limb, so plain NON-returning
+  // ds_add_u32 suffice (no carries).  Integer addition is associative: the result is
+  // independent of the order of the atomics (bitwise reproducible), and 32-bit LDS atomics
+  // are ~10x cheaper than the 64-bit ones.
+  __shared__ uint32_t s_l0[kMaxSceneObjects * 12], s_l1[kMaxSceneObjects * 12];
+  __shared__ int32_t s_l2[kMaxSceneObjects * 12];
   __shared__ float s_Rt[kMaxSceneObjects][12];
   __shared__ int s_off[kMaxSceneObjects + 1];
   const int o = blockIdx.y;
+  const int wg2 = 2048 + blockIdx.y * gridDim.x + blockIdx.x;
+  auto stamp = [&](int i) {
+    if ((a.dbg & 32) && threadIdx.x == 0 && wg2 < 4096) g_dbg_stamps[wg2 * 8 + i] = wall_clock64();
+  };
+  stamp(0);
   const int D = a.D, V = D * D * D;
   const int4 meta = a.meta[o];
   const int ja = meta.x, jb = meta.y;
@@ -457,7 +495,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
   // all independent loads first: scene tables, scalars, and this thread's voxels
   if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
-  for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) { s_lo[i] = 0u; s_hi[i] = 0u; }
+  for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) { s_l0[i] = 0u; s_l1[i] = 0u; s_l2[i] = 0; }
   const float pitch = a.pitch[o];
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
   const float M_own = __uint_as_float(a.Mbits[2 * o]);
@@ -473,8 +511,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
 
   unsigned long long ko[kVPT], kk[kVPT];
   float ne_[kVPT], tg_[kVPT];
-  float4 m_own[kVPT];
-  float w_oth[kVPT];
+  float4 m_own[kVPT], m_oth[kVPT];
 #pragma unroll
   for (int it = 0; it < kVPT; ++it) {
     const int v = blockIdx.x * kVoxPerBlock + it * kAccThreads + threadIdx.x;
@@ -488,9 +525,10 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
   for (int it = 0; it < kVPT; ++it) {  // second level: winner gathers
     const uint32_t lo = (uint32_t)ko[it], lo_o = (uint32_t)kk[it];
     m_own[it] = lo != kNoCand ? a.pts4[lo / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
-    w_oth[it] = lo_o != kNoCand ? a.pts4[lo_o / (uint32_t)K].w : -1.0f;
+    m_oth[it] = lo_o != kNoCand ? a.pts4[lo_o / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
   }
   __syncthreads();
+  stamp(1);
   const float *Rt_o = s_Rt[o - ja];
 
   float acc[kNumOwn];
@@ -518,7 +556,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
     const uint32_t lo_o = (uint32_t)kk[it];
     if (use_oth) {
       const float go = 1.0f - __uint_as_float((uint32_t)(kk[it] >> 32)) / trunc;
-      float wo = w_oth[it] + 0.0f;
+      float wo = m_oth[it].w + 0.0f;
       if (wo < 0.0f) wo = 0.0f;
       wo_in = wo / M_oth;
       const float oth = go * wo_in;
@@ -553,7 +591,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
       const uint32_t p = lo_o / (uint32_t)K;
       int e = 0;
       while (e + 1 < Ns && (int)p >= s_off[e + 1]) ++e;
-      const float4 m = a.pts4[p];
+      const float4 m = m_oth[it];  // fetched with the second-level gathers above
       float ux, uy, uz;
       bool ok;
       world_frac(s_Rt[e], m, ox, oy, oz, pitch, ix, iy, iz, ux, uy, uz, ok);
@@ -566,43 +604,39 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
           const float val[4] = {sB * m.x, sB * m.y, sB * m.z, sB};
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const unsigned long long x =
-                (unsigned long long)__double2ll_rn((double)val[c] * kFix);
-            const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+            const long long x = __double2ll_rn((double)val[c] * kFix);
             const int idx = 12 * e + 4 * d + c;
-            const uint32_t old = atomicAdd(&s_lo[idx], xl);
-            const uint32_t carry = (uint32_t)(old + xl < old);
-            if (xh + carry != 0u) atomicAdd(&s_hi[idx], xh + carry);
+            atomicAdd(&s_l0[idx], (uint32_t)(x & 0xfffff));
+            atomicAdd(&s_l1[idx], (uint32_t)((x >> 20) & 0xfffff));
+            atomicAdd(&s_l2[idx], (int32_t)(x >> 40));
           }
         }
       }
     }
   }
-  // fixed-order block reduction through LDS (39 x 256 values): one row of 40 floats per
-  // lane, then kSeg partial sums per component, then the final kSeg-term sum.  ~1.5k
-  // cycles instead of 234 dependent cross-lane shuffles per wave.
-  constexpr int kRow = kNumOwn + 1, kSeg = 6, kRows = (kAccThreads + kSeg - 1) / kSeg;
+  // fixed-order block reduction: component-major LDS layout (conflict-free stores), then
+  // each wave owns components {wave, wave+8, ...}: 8 strided LDS reads per lane + one
+  // 6-step wave reduction per component -- ~30 cross-lane steps per wave instead of 234.
+  stamp(2);
+  constexpr int kWaves = kAccThreads / 64;
 #pragma unroll
-  for (int i = 0; i < kNumOwn; ++i) s_tr[threadIdx.x * kRow + i] = acc[i];
+  for (int i = 0; i < kNumOwn; ++i) s_tr[i * kAccThreads + threadIdx.x] = acc[i];
   __syncthreads();
-  if (threadIdx.x < kNumOwn * kSeg) {
-    const int c = threadIdx.x % kNumOwn, seg = threadIdx.x / kNumOwn;
-    const int r1 = min(kAccThreads, (seg + 1) * kRows);
-    float s = 0.0f;
-    for (int r = seg * kRows; r < r1; ++r) s += s_tr[r * kRow + c];
-    s_red[seg][c] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < kNumOwn) {
-    float s = s_red[0][threadIdx.x];
+  {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = wave; c < kNumOwn; c += kWaves) {
+      float sacc = 0.0f;
 #pragma unroll
-    for (int w = 1; w < kSeg; ++w) s += s_red[w][threadIdx.x];
-    a.part[((int64_t)o * gridDim.x + blockIdx.x) * kNumOwn + threadIdx.x] = s;
+      for (int k = 0; k < kWaves; ++k) sacc += s_tr[c * kAccThreads + lane + 64 * k];
+      sacc = mf::wave_sum(sacc);
+      if (lane == 0) a.part[((int64_t)o * gridDim.x + blockIdx.x) * kNumOwn + c] = sacc;
+    }
   }
+  stamp(3);
   // collision partials of this block (the barriers above order the LDS atomics)
   float *po = a.oth + ((int64_t)o * gridDim.x + blockIdx.x) * a.max_ns * 12;
   for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) {
-    const long long x = (long long)(((unsigned long long)s_hi[i] << 32) | s_lo[i]);
+    const long long x = ((long long)s_l2[i] << 40) + ((long long)s_l1[i] << 20) + (long long)s_l0[i];
     po[i] = (float)((double)x / kFix);
   }
 }
@@ -893,7 +927,7 @@ static int icc_validate(const mfIccBatch *b) {
       b->max_scene_objects <= 0 || b->max_scene_objects > kMaxSceneObjects ||
       (size_t)b->max_scene_objects * (ws_layout(1, 1, b->dim).NB * kNumOwn + kNumOwn + 12 + 96) * 4 >
           150 * 1024 ||
-      (double)b->n_points * 343.0 >= 4294967295.0) {
+      (double)b->n_points * 343.0 >= 4294967295.0 || b->n_points >= (1 << 27)) {
     mf::set_last_error(hipErrorInvalidValue, "mf_icc: invalid batch descriptor");
     return -(int)hipErrorInvalidValue;
   }
@@ -911,6 +945,19 @@ static int slab_planes(int D, int n_grids) {
   return SX;
 }
 
+extern "C" int mf_icc_debug_stamps(unsigned long long *host_out, int n) {
+  return -(int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg_stamps), sizeof(unsigned long long) * n);
+}
+
+extern "C" int mf_icc_prepare(const mfIccBatch *batch, void *ws, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int e = icc_validate(batch)) return e;
+  IccArgs a = make_args(batch, ws, batch->max_scene_objects);
+  hipLaunchKernelGGL(k_icc_bound, dim3(a.O), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_icc_scene_setup, dim3(a.S), dim3(256), 0, stream, a, 0);
+  return mf::check_launch("mf_icc_prepare");
+}
+
 extern "C" int mf_icc_loss_grad(const mfIccBatch *batch, const float *q, const float *t,
                                 float *loss, float *gq, float *gt, void *ws,
                                 mfStream_t stream_) {
@@ -921,8 +968,6 @@ extern "C" int mf_icc_loss_grad(const mfIccBatch *batch, const float *q, const f
   const WsLayout l = ws_layout(a.O, a.S, a.D);
   const int ks = ksize_host(a.thr);
   const int SX = slab_planes(a.D, 2 * a.O);
-  hipLaunchKernelGGL(k_icc_bound, dim3(a.O), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(k_icc_scene_setup, dim3(a.S), dim3(256), 0, stream, a, 0);
   hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t);
   launch_iteration(a, ks, SX, l.NB, max_ns, 0, const_cast<float *>(q), const_cast<float *>(t),
                    nullptr, nullptr, 0.0f, 0.0f, 1, loss, gq, gt, nullptr, 0, stream);
@@ -966,8 +1011,6 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
     static hipStream_t cap = nullptr;
     if (!cap) MF_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
     MF_TRY(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-    hipLaunchKernelGGL(k_icc_bound, dim3(a.O), dim3(256), 0, cap, a);
-    hipLaunchKernelGGL(k_icc_scene_setup, dim3(a.S), dim3(256), 0, cap, a, step0);
     hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, cap, a, q, t);
     for (int it = 0; it < n_iter; ++it)
       launch_iteration(a, ks, SX, l.NB, max_ns, 1, q, t, adam_m, adam_v, alpha_q, alpha_t,

@@ -1,0 +1,30 @@
+import os, sys, ctypes
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MF_ICC_DEBUG"] = "32"
+import morefusion_amd as mf
+from bench import Workload, parse
+args = parse(); wl = Workload(args, 0, torch.device("cuda", 0))
+loss, gq, gt = wl.icc.loss_grad(wl.q0, wl.t0)   # one iteration (eager launches)
+torch.cuda.synchronize()
+L = ctypes.CDLL(mf._lib.SO_PATH)
+buf = np.zeros(4096 * 8, np.uint64)
+L.mf_icc_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
+st = buf.reshape(4096, 8)[:512].astype(np.int64)
+t0 = st[:, 0].min()
+d = lambda a, b: (st[:, b] - st[:, a]) / 100.0   # wall_clock64 = 100 MHz -> us
+print("WGs", (st[:, 0] > 0).sum())
+for name, a, b in (("scan", 0, 1), ("pass1", 1, 2), ("pass2", 2, 3), ("epilogue", 3, 4), ("total", 0, 4)):
+    x = d(a, b); print(f"{name:9s} mean {x.mean():7.2f} us  max {x.max():7.2f} us  (argmax wg {x.argmax()})")
+print("start skew (us): max", (st[:, 0] - t0).max() / 100.0, " end max", (st[:, 4] - t0).max() / 100.0)
+ns = st[:, 6] & 0xffffffff; dr = st[:, 6] >> 32
+print("survivors: max", ns.max(), "mean", ns.mean(), "drained WGs", int(dr.sum()))
+worst = np.argsort(-d(0, 4))[:8]
+for w in worst: print("wg", w, "grid", w // 32, "slab", w % 32, "ns", ns[w], "drained", dr[w], "scan", d(0,1)[w], "p1", d(1,2)[w], "p2", d(2,3)[w], "epi", d(3,4)[w])
+
+st2 = buf.reshape(4096, 8)[2048:2048+256].astype(np.int64)
+d2 = lambda a, b: (st2[:, b] - st2[:, a]) / 100.0
+print("K2 WGs", (st2[:, 0] > 0).sum())
+for name, a, b in (("loads", 0, 1), ("voxels", 1, 2), ("reduce", 2, 3), ("total", 0, 3)):
+    x = d2(a, b); print(f"K2 {name:9s} mean {x.mean():7.2f} us  max {x.max():7.2f} us  (argmax wg {x.argmax()})")
+print("K2 start skew max", (st2[:, 0] - st2[:, 0].min()).max() / 100.0, "end max", (st2[:, 3] - st2[:, 0].min()).max() / 100.0)
