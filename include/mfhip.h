@@ -195,6 +195,12 @@ int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float *adam_m,
                   float alpha_t, float *losses, float *traj, void *ws,
                   mfStream_t stream);
 
+/* Measurement hook: launch ONLY the first kernel of an ICC iteration (k_icc_tdf, the
+ * dominant hand-written kernel) so that bench.py can time it with HIP events.  If q and t
+ * are non-NULL the rotation matrices are refreshed from them first (separate tiny launch). */
+int mf_icc_launch_tdf(const mfIccBatch *batch, const float *q, const float *t, void *ws,
+                      mfStream_t stream);
+
 /* small fused helpers of the same path */
 /* pack [Ptot,3] points + [Ptot] sdf into float4 */
 int mf_pack_points_sdf(const float *points, const float *sdf, int64_t n, void *pts4,

@@ -949,6 +949,24 @@ extern "C" int mf_icc_debug_stamps(unsigned long long *host_out, int n) {
   return -(int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg_stamps), sizeof(unsigned long long) * n);
 }
 
+extern "C" int mf_icc_launch_tdf(const mfIccBatch *batch, const float *q, const float *t, void *ws,
+                                 mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int e = icc_validate(batch)) return e;
+  IccArgs a = make_args(batch, ws, batch->max_scene_objects);
+  const int ks = ksize_host(a.thr);
+  const int SX = slab_planes(a.D, 2 * a.O);
+  const int D = a.D;
+  if (q && t) hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t);
+  const dim3 g1((D + SX - 1) / SX, 2 * a.O);
+  const size_t lds1 = (size_t)SX * D * D * 2 * sizeof(uint32_t);
+  if (ks == 3)
+    hipLaunchKernelGGL(k_icc_tdf<3>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
+  else
+    hipLaunchKernelGGL(k_icc_tdf<0>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
+  return mf::check_launch("mf_icc_launch_tdf");
+}
+
 extern "C" int mf_icc_prepare(const mfIccBatch *batch, void *ws, mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = icc_validate(batch)) return e;

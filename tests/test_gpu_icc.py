@@ -199,3 +199,31 @@ def test_icp_link_vs_oracle(fixtures3):
         opt.update()
         first = float(loss) if first is None else first
     assert float(loss) < first
+
+
+def test_icc_single_object_scene_and_far_apart_objects():
+    """N = 1 (no 'other' grid at all, iterative_collision_check_link.py:62-63) and a scene
+    whose objects never overlap (every 'other' grid empty -> NaN guard path, :82)."""
+    sc = mf.synthetic.make_icc_scene(2, seed=5)
+    one = scene_args(sc, 1)
+    link = mf.contrib.IterativeCollisionCheckLink(sc["transform_init"][:1], sdf_offset=0.02).to_gpu()
+    loss = link(*to_dev(one))
+    loss.backward()
+    q0, t0 = link.quaternion.detach().cpu().numpy(), link.translation.detach().cpu().numpy()
+    l_o, gq_o, gt_o, _ = OC.icc_loss_grad(*one, q0, t0, sdf_offset=0.02)
+    np.testing.assert_allclose(float(loss.detach()), l_o, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(link.quaternion.grad.cpu().numpy(), gq_o, rtol=2e-3, atol=2e-5)
+    # two objects 10 m apart
+    T = sc["transform_init"].copy()
+    T[1, :3, 3] += 10.0
+    origin = sc["origin"].copy()
+    origin[1] += 10.0
+    args = (sc["points"], sc["sdf"], sc["pitch"], origin, sc["grid_target"], sc["grid_nontarget_empty"])
+    link = mf.contrib.IterativeCollisionCheckLink(T, sdf_offset=0.02).to_gpu()
+    loss = link(*to_dev(args))
+    loss.backward()
+    q0, t0 = link.quaternion.detach().cpu().numpy(), link.translation.detach().cpu().numpy()
+    l_o, gq_o, gt_o, _ = OC.icc_loss_grad(*args, q0, t0, sdf_offset=0.02)
+    assert np.isfinite(l_o)
+    np.testing.assert_allclose(float(loss.detach()), l_o, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(link.translation.grad.cpu().numpy(), gt_o, rtol=2e-3, atol=2e-4)

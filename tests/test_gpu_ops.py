@@ -296,3 +296,74 @@ def test_model_predict_shapes_and_3d_part_vs_oracle():
 
 def F_relu(x):
     return torch.nn.functional.relu(x)
+
+
+def test_model_training_step_backward_through_hip_ops():
+    """Model.forward (= predict + ADD/ADD-S confidence loss, model.py:277-481) and its
+    backward: gradients flow through average_voxelization_3d / interpolate_voxel_grid
+    (HIP backward kernels) into the 2-D backbone; one SGD step lowers the loss."""
+    from morefusion_amd.contrib.singleview_3d.models import Model, PitchTableModels
+    torch.manual_seed(0)
+    np.random.seed(0)
+    rs = np.random.RandomState(0)
+    pcds = {c: rs.uniform(-0.05, 0.05, (800, 3)).astype(np.float32) for c in mf.synthetic.CLASS_PITCH}
+    model = Model(n_fg_class=21, with_occupancy=True, models=PitchTableModels(pcds)).cuda().train()
+    b = mf.synthetic.make_singleview_batch(2, seed=20)  # classes include a symmetric one -> ADD-S
+    inputs = {k: torch.as_tensor(b[k]).cuda() for k in
+              ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty",
+               "quaternion_true", "translation_true")}
+    opt = torch.optim.SGD(model.parameters(), lr=1e-5)
+    losses = []
+    for _ in range(3):
+        np.random.seed(1)  # same point subsample / CAD subsample every step
+        torch.manual_seed(1)  # same dropout mask
+        opt.zero_grad()
+        loss = model(**inputs)
+        loss.backward()
+        losses.append(float(loss.detach()))
+        opt.step()
+    assert np.isfinite(losses).all()
+    for name in ("conv1_rgb.weight", "conv3.weight", "conv4.weight", "resnet_extractor.conv1.weight",
+                 "conv4_rot.weight", "conv1_occ.weight"):
+        g = dict(model.named_parameters())[name].grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, name
+    assert losses[-1] < losses[0], losses
+    ev = model.evaluate(class_id=inputs["class_id"], quaternion_true=inputs["quaternion_true"],
+                        translation_true=inputs["translation_true"],
+                        quaternion_pred=inputs["quaternion_true"].float(),
+                        translation_pred=inputs["translation_true"].float())
+    assert ev["add"] < 1e-6 and ev["add_s"] < 1e-6  # identical poses -> zero ADD / ADD-S
+
+
+# ---- edge cases: empty / ragged / degenerate inputs ---------------------------------
+def test_empty_and_degenerate_inputs():
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device="cuda")  # noqa: E731
+    # no points at all: dense zero output, zero counts
+    y, c = F.average_voxelization_3d(z(0, 3), z(0, 3), z(0, dt=torch.int32), batch_size=2, origin=(0, 0, 0),
+                                     pitch=1.0, dimensions=(4, 4, 4), return_counts=True)
+    assert y.shape == (2, 3, 4, 4, 4) and float(y.abs().sum()) == 0 and int(c.sum()) == 0
+    # every point outside the grid / invalid batch index
+    pts = torch.tensor([[9.0, 9, 9], [-5, 0, 0], [1, 1, 1]], device="cuda")
+    bi = torch.tensor([0, 0, 7], dtype=torch.int32, device="cuda")
+    y, c = F.average_voxelization_3d(torch.ones(3, 2, device="cuda"), pts, bi, batch_size=1, origin=(0, 0, 0),
+                                     pitch=1.0, dimensions=(4, 4, 4), return_counts=True)
+    assert float(y.abs().sum()) == 0 and int(c.sum()) == 0
+    # interpolation with zero points; TDF with zero points -> all truncation, no winners
+    v = F.interpolate_voxel_grid(torch.rand(1, 2, 4, 4, 4, device="cuda"), z(0, 3), z(0, dt=torch.int32))
+    assert v.shape == (0, 2)
+    tdf, idx = F.truncated_distance_function(z(0, 3), pitch=0.5, origin=(0, 0, 0), dims=(4, 4, 4),
+                                             truncation=1.0, return_indices=True)
+    assert (tdf == 1.0).all() and (idx == -1).all()
+    # a pile-up of > 64 points in one voxel takes the chain fallback path, still exact
+    n = 200
+    pts = torch.full((n, 3), 1.2, device="cuda")
+    vals = torch.arange(n * 2, dtype=torch.float32, device="cuda").reshape(n, 2) * 0.37
+    y, c = F.average_voxelization_3d(vals, pts, z(n, dt=torch.int32), batch_size=1, origin=(0, 0, 0),
+                                     pitch=1.0, dimensions=(4, 4, 4), return_counts=True)
+    y_o, c_o = O.average_voxelization_3d(vals.cpu().numpy(), pts.cpu().numpy(), np.zeros(n, np.int32), batch_size=1,
+                                         origin=(0, 0, 0), pitch=1.0, dimensions=(4, 4, 4))
+    assert int(c[0, 1, 1, 1]) == n
+    np.testing.assert_array_equal(y.cpu().numpy(), y_o)
+    # nn with a single reference point
+    idx = mf.geometry.nn(torch.rand(1, 3, device="cuda"), torch.rand(5, 3, device="cuda"))
+    assert (idx == 0).all()
