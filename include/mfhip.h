@@ -201,6 +201,28 @@ int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float *adam_m,
 int mf_icc_launch_tdf(const mfIccBatch *batch, const float *q, const float *t, void *ws,
                       mfStream_t stream);
 
+/* ---- A13 conv3 of the pose network on sparse voxelized features -----------------
+ * replaces the dense cuDNN Convolution3D(Cs+16 -> Cout, k=4, s=2, pad=1) at
+ *   morefusion/contrib/singleview_3d/models/model.py:73,128
+ * for the Cs voxelized channels, whose input is <= 3 % occupied (counts > 0): 8 parity
+ * classes x one fp32-MFMA GEMM [n x Cs].[Cs x 8*Cout] + an output-stationary reduce.
+ *   x      [B,Cs,D,D,D]  dense voxelized features (zeros where counts == 0)
+ *   counts [B,D,D,D]     from mf_average_voxelization_3d_fwd
+ *   Wp     packed weights from mf_sparse_conv3d_pack_weights (8*Cs*8*Cout floats)
+ *   dense  [B,Cout,D/2..] optional addend (the dense occupancy-channel part), bias [Cout]
+ *   out    [B,Cout,D/2,D/2,D/2] written completely; relu != 0 applies max(.,0)
+ *   max_rows >= number of occupied voxels (e.g. the number of points); ws from
+ *   mf_sparse_conv3d_workspace_bytes.  Deterministic (fixed tap order, no atomics). */
+int64_t mf_sparse_conv3d_workspace_bytes(int32_t B, int32_t Cs, int32_t Cout, int32_t D,
+                                         int32_t max_rows);
+/* W [Cout, w_cin, 4,4,4]; packs input channels [c_off, c_off+Cs). */
+int mf_sparse_conv3d_pack_weights(const float *W, int32_t Cout, int32_t Cs, int32_t w_cin,
+                                  int32_t c_off, float *Wp, mfStream_t stream);
+int mf_sparse_conv3d_k4s2_fwd(const float *x, const int32_t *counts, const float *Wp,
+                              const float *dense, const float *bias, float *out, void *ws,
+                              int32_t B, int32_t Cs, int32_t Cout, int32_t D, int32_t max_rows,
+                              int32_t relu, mfStream_t stream);
+
 /* small fused helpers of the same path */
 /* pack [Ptot,3] points + [Ptot] sdf into float4 */
 int mf_pack_points_sdf(const float *points, const float *sdf, int64_t n, void *pts4,

@@ -8,6 +8,8 @@ Differences that are deliberate:
   * the per-object host loop of ``predict`` (:195-229, one D2H sync per object) is one
     batched gather with a single sync for the point counts (NumPy RNG kept bit-for-bit:
     ``RandomState(1234).permutation(n)[:1000]`` in eval mode);
+  * the last PSPNet level (full-resolution 3x3 conv, 1x1 head, log-softmax) is evaluated
+    only at the 1000 sampled pixels per object (``PSPNetExtractor.forward_sampled``);
   * interpolated features are produced channels-first ([C, B*P]), the layout the heads
     consume, instead of [B*P, C] + transpose;
   * CAD models / voxel pitches come from an injectable ``models`` provider because the
@@ -23,6 +25,7 @@ from .... import functions as functions_module
 from .... import metrics
 from ....models import PSPNetExtractor, ResNet18
 from ....synthetic import CLASS_IDS_SYMMETRIC, CLASS_PITCH
+from .sparse_conv import SparseVoxelConv3d
 
 
 class PitchTableModels:
@@ -60,6 +63,10 @@ class Model(nn.Module):
         assert loss in ["add", "add/add_s"]
         self._loss = loss
         self._models = models or PitchTableModels()
+        # evaluate the last PSPNet level only where the network samples it (model.py:222)
+        self.sparse_pspnet_tail = True
+        # inference: conv3 on fp32 MFMA over the occupied voxels only (csrc/sparseconv.hip)
+        self.sparse_conv3 = True
 
         self.resnet_extractor = ResNet18()
         self.pspnet_extractor = PSPNetExtractor()
@@ -82,14 +89,14 @@ class Model(nn.Module):
             setattr(self, f"conv4_{name}", nn.Conv1d(128, n_fg_class * c_out, 1))
 
     # ---- 3-D feature extraction (model.py:93-164) --------------------------------------
-    def _voxelize(self, values, points):
+    def _voxelize(self, values, points, return_counts=False):
         B, P, _ = values.shape
         assert P == self._n_point
         batch_indices = torch.arange(B, dtype=torch.int32, device=values.device).repeat_interleave(P)
         return functions_module.average_voxelization_3d(
             values.reshape(B * P, -1), points.reshape(B * P, 3).contiguous(), batch_indices,
             batch_size=B, origin=(0, 0, 0), pitch=1.0, dimensions=(self._voxel_dim,) * 3,
-            check_nan=False)
+            return_counts=return_counts, check_nan=False)
 
     def _extract(self, values, points, grid_nontarget_empty):
         B, _, P = values.shape
@@ -103,15 +110,21 @@ class Model(nn.Module):
         h_rgb = F.relu(self.conv2_rgb(h_rgb))
         h_pcd = F.relu(self.conv2_pcd(h_pcd))
         feat2 = torch.cat((h_rgb, h_pcd), dim=1)
-        voxelized = self._voxelize(values=feat2.transpose(1, 2).float().contiguous(),
-                                   points=points.transpose(1, 2))
+        voxelized, counts = self._voxelize(values=feat2.transpose(1, 2).float().contiguous(),
+                                           points=points.transpose(1, 2), return_counts=True)
+        h_occ = None
         if self._with_occupancy:
             g = grid_nontarget_empty.to(values.dtype)[:, None, :, :, :]
             h_occ = F.relu(self.conv1_occ(g))
             h_occ = F.relu(self.conv2_occ(h_occ))
-            voxelized = torch.cat([voxelized.to(h_occ.dtype), h_occ], dim=1)
-
-        h = F.relu(self.conv3(voxelized))
+        if self.sparse_conv3 and not torch.is_grad_enabled() and voxelized.is_cuda:
+            if getattr(self, "_sparse_conv3_op", None) is None:
+                self.__dict__["_sparse_conv3_op"] = SparseVoxelConv3d(self.conv3)
+            h = self._sparse_conv3_op(voxelized, counts, h_occ, max_rows=B * P)
+        else:
+            if h_occ is not None:
+                voxelized = torch.cat([voxelized.to(h_occ.dtype), h_occ], dim=1)
+            h = F.relu(self.conv3(voxelized))
         assert h.shape == (B, 256, 16, 16, 16)
         feat3 = functions_module.interpolate_voxel_grid(h.float(), indices / 2.0, batch_indices,
                                                         channels_first=True)
@@ -175,10 +188,13 @@ class Model(nn.Module):
         rgb = rgb.float().permute(0, 3, 1, 2)
         pcd = pcd.float().permute(0, 3, 1, 2)
 
-        h_rgb = self.pspnet_extractor(self.resnet_extractor(rgb))
-
-        values = torch.gather(h_rgb.reshape(B, h_rgb.shape[1], -1), 2,
-                              pix[:, None, :].expand(B, h_rgb.shape[1], -1))
+        if self.sparse_pspnet_tail:
+            # last PSPNet level evaluated only at the sampled pixels (identical features)
+            values = self.pspnet_extractor.forward_sampled(self.resnet_extractor(rgb), pix)
+        else:
+            h_rgb = self.pspnet_extractor(self.resnet_extractor(rgb))
+            values = torch.gather(h_rgb.reshape(B, h_rgb.shape[1], -1), 2,
+                                  pix[:, None, :].expand(B, h_rgb.shape[1], -1))
         # NaN-masked pixels are never selected; nan_to_num keeps the gather capture-safe
         points = torch.gather(pcd.reshape(B, 3, -1), 2, pix[:, None, :].expand(B, 3, -1))
 

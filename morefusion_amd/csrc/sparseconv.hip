@@ -1,0 +1,300 @@
+// Sparse-input 3-D convolution (kernel 4, stride 2, pad 1) on fp32 MFMA for gfx950.
+//
+// Reference: conv3 of the pose network, `L.Convolution3D(None, 256, 4, 2, pad=1)` applied to
+// the voxelized point features (contrib/singleview_3d/models/model.py:73,128): a dense cuDNN
+// convolution over [B,144,32^3] = 18.9 GFLOP per object -- although average_voxelization_3d
+// leaves at most P = 1000 of the 32768 voxels non-zero (<= 3 %).
+//
+// MI355X design: only occupied voxels do work.
+//   * k4/s2/p1 geometry: input voxel v feeds output o = ((v+1)>>1) - a with kernel tap
+//     k = p + 2a per axis, p = (v+1)&1, a in {0,1}.  So voxels fall into 8 parity classes,
+//     and all voxels of a class use the same 8 kernel taps.
+//   * per class ONE GEMM  C[n_class x (8*Cout)] = A[n_class x Cs] . Wp[Cs x (8*Cout)]
+//     (A = gathered voxel features, Wp = the 8 taps' weight slices side by side) on
+//     v_mfma_f32_16x16x4_f32: exact fp32, k-ordered fma chain.  0.6 GFLOP per object.
+//   * an output-stationary reduce then sums, for every output voxel, its <= 64 contributing
+//     (voxel, tap) rows in fixed tap order (deterministic, no atomics), adds the dense part
+//     (the 16 occupancy channels, computed by a stock dense convolution) and the bias,
+//     applies ReLU, and stores coalesced through an LDS transpose.
+#include <algorithm>
+
+#include "mf_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTM = 64, kTN = 64;  // GEMM tile per 256-lane workgroup
+
+struct ScArgs {
+  const float *x;         // [B,Cs,D,D,D] dense, mostly zero
+  const int32_t *counts;  // [B,D,D,D] occupancy counts of average_voxelization_3d
+  int B, Cs, Cout, D, max_rows;
+  int32_t *rowmap;     // [B*V] compact row of an occupied voxel, else -1
+  int32_t *rowvox;     // [max_rows] b*V+v of a row
+  int32_t *class_cnt;  // [8] rows per parity class
+  int32_t *class_fill; // [8]
+  float *A;            // [max_rows][Cs]
+  float *C;            // [max_rows][8*Cout]
+};
+
+__device__ __forceinline__ int parity_class(int ix, int iy, int iz) {
+  return ((ix + 1) & 1) | (((iy + 1) & 1) << 1) | (((iz + 1) & 1) << 2);
+}
+
+// pass 1: rows per class (wave-aggregated integer atomics)
+__global__ __launch_bounds__(256) void k_sc_count(ScArgs a) {
+  const int V = a.D * a.D * a.D;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int cls = -1;
+  if (i < (int64_t)a.B * V && a.counts[i] > 0) {
+    const int v = (int)(i % V);
+    cls = parity_class(v / (a.D * a.D), (v / a.D) % a.D, v % a.D);
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned long long m = __ballot(cls == c);
+    if (m && lane == __ffsll((long long)m) - 1) atomicAdd(&a.class_cnt[c], __popcll(m));
+  }
+}
+
+// pass 2: compact row ids (class-major), row -> voxel map
+__global__ __launch_bounds__(256) void k_sc_assign(ScArgs a) {
+  const int V = a.D * a.D * a.D;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = i < (int64_t)a.B * V;
+  int cls = -1;
+  if (in && a.counts[i] > 0) {
+    const int v = (int)(i % V);
+    cls = parity_class(v / (a.D * a.D), (v / a.D) % a.D, v % a.D);
+  }
+  const int lane = threadIdx.x & 63;
+  int row = -1;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned long long m = __ballot(cls == c);
+    if (!m) continue;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&a.class_fill[c], __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (cls == c) {
+      int off = 0;
+      for (int k = 0; k < c; ++k) off += a.class_cnt[k];
+      row = off + base + __popcll(m & ((1ull << lane) - 1ull));
+    }
+  }
+  if (in) a.rowmap[i] = row < a.max_rows ? row : -1;
+  if (row >= 0 && row < a.max_rows) a.rowvox[row] = (int32_t)i;
+}
+
+// A[row][c] = x[b][c][v]  (lanes over channels: coalesced stores, strided gathers)
+__global__ __launch_bounds__(256) void k_sc_gather(ScArgs a) {
+  const int V = a.D * a.D * a.D;
+  int n_rows = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) n_rows += a.class_cnt[c];
+  n_rows = min(n_rows, a.max_rows);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = (int)(i / a.Cs), ch = (int)(i % a.Cs);
+  if (row >= n_rows) return;
+  const int bv = a.rowvox[row];
+  const int b = bv / V, v = bv % V;
+  a.A[i] = a.x[((int64_t)b * a.Cs + ch) * V + v];
+}
+
+// C[row][n] = sum_k A[row][k] * Wp[class(row)][k][n],  n in [0, 8*Cout)
+// grid: (row tiles, column tiles, class).  Both operands of a tile sit in LDS
+// ([k][row] and [k][col]: conflict-free fragment reads); K = Cs is small enough to
+// stage completely.  Each wave owns 16 rows x 64 columns = 4 accumulators.
+__global__ __launch_bounds__(256) void k_sc_gemm(ScArgs a, const float *__restrict__ Wp) {
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  const int cls = blockIdx.z;
+  int row0 = 0;
+  for (int k = 0; k < cls; ++k) row0 += a.class_cnt[k];
+  const int n_cls = min(a.class_cnt[cls], max(0, a.max_rows - row0));
+  const int m0 = blockIdx.x * kTM;
+  if (m0 >= n_cls) return;
+  const int K = a.Cs, N = 8 * a.Cout;
+  const int n0 = blockIdx.y * kTN;
+  float *As = s_mem;                    // [K][kTM + 4]
+  float *Bs = s_mem + K * (kTM + 4);    // [K][kTN + 4]
+  // stage A transposed (rows beyond the class are zero) and B
+  for (int i = threadIdx.x; i < kTM * (K / 4); i += 256) {
+    const int r = i / (K / 4), k4 = i % (K / 4);
+    float4 v = make_float4(0, 0, 0, 0);
+    if (m0 + r < n_cls)
+      v = *reinterpret_cast<const float4 *>(a.A + (int64_t)(row0 + m0 + r) * K + 4 * k4);
+    As[(4 * k4 + 0) * (kTM + 4) + r] = v.x;
+    As[(4 * k4 + 1) * (kTM + 4) + r] = v.y;
+    As[(4 * k4 + 2) * (kTM + 4) + r] = v.z;
+    As[(4 * k4 + 3) * (kTM + 4) + r] = v.w;
+  }
+  const float *Wc = Wp + (int64_t)cls * K * N;
+  for (int i = threadIdx.x; i < K * (kTN / 4); i += 256) {
+    const int k = i / (kTN / 4), c4 = i % (kTN / 4);
+    *reinterpret_cast<float4 *>(Bs + k * (kTN + 4) + 4 * c4) =
+        *reinterpret_cast<const float4 *>(Wc + (int64_t)k * N + n0 + 4 * c4);
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    // A fragment: lane l holds A[row = l&15][k = l>>4];  B: B[k = l>>4][col = l&15]
+    const float af = As[(k0 + lk) * (kTM + 4) + wave * 16 + lr];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float bf = Bs[(k0 + lk) * (kTN + 4) + j * 16 + lr];
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[j], 0, 0, 0);
+    }
+  }
+  // C/D fragment: col = lane&15, row = (lane>>4)*4 + i
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = m0 + wave * 16 + lk * 4 + i;
+      if (r < n_cls) a.C[(int64_t)(row0 + r) * N + n0 + j * 16 + lr] = acc[j][i];
+    }
+}
+
+// out[b][co][o] = relu( sum_taps C[row(v)][slot*Cout + co] + dense[b][co][o] + bias[co] )
+// One workgroup = 64 consecutive output voxels x all Cout channels, staged through LDS so
+// that the final stores are coalesced along o.  Each wave walks 16 output voxels; for one
+// voxel the 64 lanes look up its 64 taps at once (one rowmap gather), then every lane
+// accumulates Cout/64 channels over the (few) taps that hit an occupied voxel, in tap order.
+__global__ __launch_bounds__(256) void k_sc_reduce(ScArgs a, const float *__restrict__ dense,
+                                                   const float *__restrict__ bias, int relu,
+                                                   float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float s_tile[];  // [Cout][65]
+  const int D = a.D, Do = D / 2, V = D * D * D, Vo = Do * Do * Do;
+  const int b = blockIdx.y;
+  const int o0 = blockIdx.x * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int N = 8 * a.Cout;
+  const int nj = a.Cout / 64;
+  // this lane's tap: k = (kx,ky,kz) in [0,4)^3, fixed for the whole kernel
+  const int kx = lane >> 4, ky = (lane >> 2) & 3, kz = lane & 3;
+  const int slot = (kx >> 1) | ((ky >> 1) << 1) | ((kz >> 1) << 2);
+  for (int t = 0; t < 16; ++t) {
+    const int ol = wave * 16 + t;
+    const int o = o0 + ol;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    if (o < Vo) {
+      const int oz = o % Do, oy = (o / Do) % Do, oxx = o / (Do * Do);
+      const int vx = 2 * oxx - 1 + kx, vy = 2 * oy - 1 + ky, vz = 2 * oz - 1 + kz;
+      int row = -1;
+      if (vx >= 0 && vx < D && vy >= 0 && vy < D && vz >= 0 && vz < D)
+        row = a.rowmap[(int64_t)b * V + (vx * D + vy) * D + vz];
+      unsigned long long hits = __ballot(row >= 0);
+      while (hits) {  // taps in increasing k: fixed summation order
+        const int src = __ffsll((long long)hits) - 1;
+        hits &= hits - 1;
+        const int r = __shfl(row, src, 64);
+        const int sl = __shfl(slot, src, 64);
+        const float *crow = a.C + (int64_t)r * N + sl * a.Cout;
+        for (int j = 0; j < nj; ++j) acc[j] += crow[lane + 64 * j];
+      }
+    }
+    for (int j = 0; j < nj; ++j) s_tile[(lane + 64 * j) * 65 + ol] = acc[j];
+  }
+  __syncthreads();
+  for (int co = wave; co < a.Cout; co += 4) {
+    const int o = o0 + lane;
+    if (o < Vo) {
+      const int64_t idx = ((int64_t)b * a.Cout + co) * Vo + o;
+      float v = s_tile[co * 65 + lane] + (dense ? dense[idx] : 0.0f) + (bias ? bias[co] : 0.0f);
+      if (relu) v = v > 0.0f ? v : 0.0f;
+      out[idx] = v;
+    }
+  }
+}
+
+// Wp[class][c][slot*Cout + co] = W[co][c][kx][ky][kz],  k = parity + 2*slot bit per axis
+__global__ void k_sc_pack(const float *__restrict__ W, int Cout, int Cs, int w_cin, int c_off,
+                          float *__restrict__ Wp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)8 * Cs * 8 * Cout;
+  if (i >= total) return;
+  const int co = (int)(i % Cout);
+  const int slot = (int)((i / Cout) % 8);
+  const int c = (int)((i / ((int64_t)8 * Cout)) % Cs);
+  const int cls = (int)(i / ((int64_t)8 * Cout * Cs));
+  const int kx = (cls & 1) + 2 * (slot & 1), ky = ((cls >> 1) & 1) + 2 * ((slot >> 1) & 1),
+            kz = ((cls >> 2) & 1) + 2 * ((slot >> 2) & 1);
+  Wp[i] = W[((((int64_t)co * w_cin + c_off + c) * 4 + kx) * 4 + ky) * 4 + kz];
+}
+
+int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+}  // namespace
+
+extern "C" int64_t mf_sparse_conv3d_workspace_bytes(int32_t B, int32_t Cs, int32_t Cout, int32_t D,
+                                                    int32_t max_rows) {
+  const int64_t V = (int64_t)D * D * D;
+  return align256(B * V * 4) + align256((int64_t)max_rows * 4) + align256(64) + align256(64) +
+         align256((int64_t)max_rows * Cs * 4) + align256((int64_t)max_rows * 8 * Cout * 4);
+}
+
+extern "C" int mf_sparse_conv3d_pack_weights(const float *W, int32_t Cout, int32_t Cs,
+                                             int32_t w_cin, int32_t c_off, float *Wp,
+                                             mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t total = (int64_t)8 * Cs * 8 * Cout;
+  hipLaunchKernelGGL(k_sc_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, W,
+                     Cout, Cs, w_cin, c_off, Wp);
+  return mf::check_launch("mf_sparse_conv3d_pack_weights");
+}
+
+extern "C" int mf_sparse_conv3d_k4s2_fwd(const float *x, const int32_t *counts, const float *Wp,
+                                         const float *dense, const float *bias, float *out,
+                                         void *ws, int32_t B, int32_t Cs, int32_t Cout, int32_t D,
+                                         int32_t max_rows, int32_t relu, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || max_rows <= 0) return 0;
+  if (Cs % 4 || Cout % 64 || Cout > 512 || D % 2 || D > 64) {
+    mf::set_last_error(hipErrorInvalidValue, "sparse_conv3d: need Cs%4==0, Cout%64==0 (<=512), even D");
+    return -(int)hipErrorInvalidValue;
+  }
+  const int64_t V = (int64_t)D * D * D;
+  ScArgs a;
+  a.x = x; a.counts = counts; a.B = B; a.Cs = Cs; a.Cout = Cout; a.D = D; a.max_rows = max_rows;
+  char *p = (char *)ws;
+  a.rowmap = (int32_t *)p; p += align256(B * V * 4);
+  a.rowvox = (int32_t *)p; p += align256((int64_t)max_rows * 4);
+  a.class_cnt = (int32_t *)p; p += align256(64);
+  a.class_fill = (int32_t *)p; p += align256(64);
+  a.A = (float *)p; p += align256((int64_t)max_rows * Cs * 4);
+  a.C = (float *)p;
+  MF_TRY(hipMemsetAsync(a.class_cnt, 0, 512, stream));  // class_cnt and class_fill
+  const unsigned nb = (unsigned)((B * V + 255) / 256);
+  hipLaunchKernelGGL(k_sc_count, dim3(nb), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_sc_assign, dim3(nb), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_sc_gather, dim3((unsigned)(((int64_t)max_rows * Cs + 255) / 256)),
+                     dim3(256), 0, stream, a);
+  const size_t lds_g = (size_t)Cs * (kTM + 4 + kTN + 4) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    MF_TRY(hipFuncSetAttribute((const void *)k_sc_gemm, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               150 * 1024));
+    MF_TRY(hipFuncSetAttribute((const void *)k_sc_reduce,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr = true;
+  }
+  if (lds_g > 150 * 1024) {
+    mf::set_last_error(hipErrorInvalidValue, "sparse_conv3d: Cs too large for the LDS-resident K");
+    return -(int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(k_sc_gemm, dim3((max_rows + kTM - 1) / kTM, 8 * Cout / kTN, 8), dim3(256),
+                     lds_g, stream, a, Wp);
+  const int Vo = (D / 2) * (D / 2) * (D / 2);
+  hipLaunchKernelGGL(k_sc_reduce, dim3((Vo + 63) / 64, B), dim3(256),
+                     (size_t)Cout * 65 * sizeof(float), stream, a, dense, bias, relu, out);
+  return mf::check_launch("mf_sparse_conv3d_k4s2_fwd");
+}

@@ -105,3 +105,45 @@ class PSPNetExtractor(nn.Module):
         h = F.dropout(self.up2(h), 0.15, self.training)
         h = self.up3(h)
         return F.log_softmax(self.conv1(h), dim=1)
+
+    def forward_sampled(self, x, pix):
+        """Same features as ``forward(x)`` gathered at the flat pixel indices ``pix`` [B,P]
+        of the full-resolution map -> [B,32,P], WITHOUT materialising the last level.
+
+        The pose network reads only P = 1000 pixels per object of the [B,32,256,256] output
+        (model.py:222); the last PSPUpsample (bilinear x2 + 3x3 conv 64->64 at 256^2, 4.8
+        GFLOP and >400 MB of activations per 8 objects), the 1x1 head and the log-softmax are
+        therefore evaluated at those pixels only: each sampled pixel gathers its 3x3 window
+        of the (virtually) up-sampled map -- 4 bilinear taps per window element, same
+        align_corners=True source-index arithmetic as ``F.interpolate`` -- and applies the
+        same weights.  Mathematically identical; differs only by summation order."""
+        h = F.dropout(self.psp(x), 0.3, self.training)
+        h = F.dropout(self.up1(h), 0.15, self.training)
+        u2 = F.dropout(self.up2(h), 0.15, self.training)  # [B,64,H,W], H = W = 128
+        B, C, H, W = u2.shape
+        Ho, Wo = 2 * H, 2 * W
+        P = pix.shape[1]
+        py, px = pix // Wo, pix % Wo  # [B,P]
+        d = torch.tensor([-1, 0, 1], device=pix.device)
+        yy = (py[:, :, None, None] + d[None, None, :, None]).expand(B, P, 3, 3).reshape(B, P * 9)
+        xx = (px[:, :, None, None] + d[None, None, None, :]).expand(B, P, 3, 3).reshape(B, P * 9)
+        valid = (yy >= 0) & (yy < Ho) & (xx >= 0) & (xx < Wo)  # zero padding of the 3x3 conv
+        yy, xx = yy.clamp(0, Ho - 1), xx.clamp(0, Wo - 1)
+        sy = yy.to(u2.dtype) * ((H - 1) / (Ho - 1))
+        sx = xx.to(u2.dtype) * ((W - 1) / (Wo - 1))
+        y0, x0 = sy.floor().long(), sx.floor().long()
+        y1, x1 = (y0 + 1).clamp(max=H - 1), (x0 + 1).clamp(max=W - 1)
+        ly, lx = (sy - y0)[:, None, :], (sx - x0)[:, None, :]
+        flat = u2.reshape(B, C, H * W)
+
+        def tap(iy, ix):
+            return torch.gather(flat, 2, (iy * W + ix)[:, None, :].expand(B, C, P * 9))
+
+        up = (1 - ly) * ((1 - lx) * tap(y0, x0) + lx * tap(y0, x1)) + \
+            ly * ((1 - lx) * tap(y1, x0) + lx * tap(y1, x1))
+        up = (up * valid[:, None, :]).reshape(B, C, P, 9)
+        w = self.up3.conv.weight.reshape(self.up3.conv.out_channels, C, 9)
+        h = torch.einsum("bcpk,ock->bop", up, w) + self.up3.conv.bias[None, :, None]
+        h = self.up3.prelu(h)
+        h = F.conv1d(h, self.conv1.weight.reshape(self.conv1.out_channels, -1, 1), self.conv1.bias)
+        return F.log_softmax(h, dim=1)

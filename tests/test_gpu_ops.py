@@ -367,3 +367,30 @@ def test_empty_and_degenerate_inputs():
     # nn with a single reference point
     idx = mf.geometry.nn(torch.rand(1, 3, device="cuda"), torch.rand(5, 3, device="cuda"))
     assert (idx == 0).all()
+
+
+# ---- A13 sparse conv3 (fp32 MFMA) --------------------------------------------------------
+@pytest.mark.parametrize("B,Cs,Cd,Cout,n", [(2, 144, 16, 256, 1000), (1, 8, 0, 64, 40), (3, 12, 4, 128, 300)])
+def test_sparse_conv3_matches_dense_conv3d(B, Cs, Cd, Cout, n):
+    from morefusion_amd.contrib.singleview_3d.models.sparse_conv import SparseVoxelConv3d
+    torch.manual_seed(B + Cs)
+    D = 32
+    conv = torch.nn.Conv3d(Cs + Cd, Cout, 4, 2, padding=1).cuda()
+    pts = torch.rand(B * n, 3, device="cuda") * 36 - 2  # some outside, borders included
+    pts[:10] = torch.tensor([0.2, 31.4, 15.0], device="cuda")  # corner/border pile-up
+    vals = torch.randn(B * n, Cs, device="cuda")
+    bi = torch.arange(B, dtype=torch.int32, device="cuda").repeat_interleave(n)
+    vox, counts = F.average_voxelization_3d(vals, pts, bi, batch_size=B, origin=(0, 0, 0), pitch=1.0,
+                                            dimensions=(D, D, D), return_counts=True)
+    h_occ = torch.randn(B, Cd, D, D, D, device="cuda") if Cd else None
+    op = SparseVoxelConv3d(conv)
+    got = op(vox, counts, h_occ, max_rows=B * n)
+    with torch.no_grad():
+        full = torch.cat([vox, h_occ], 1) if Cd else vox
+        ref = torch.relu(conv(full))
+    assert got.shape == ref.shape == (B, Cout, 16, 16, 16)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4)
+    got2 = op(vox, counts, h_occ, max_rows=B * n)  # deterministic: bitwise equal run to run
+    assert torch.equal(got, got2)
+    pre = op(vox, counts, h_occ, max_rows=B * n, relu=False)
+    assert float(pre.min()) < 0  # relu flag honoured

@@ -164,3 +164,19 @@ def test_shard_range_partitions_everything_once():
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_pspnet_sampled_tail_equals_dense_forward():
+    """PSPNetExtractor.forward_sampled == forward + gather (incl. image-border pixels)."""
+    from morefusion_amd.models import PSPNetExtractor
+    torch.manual_seed(0)
+    net = PSPNetExtractor().eval()
+    x = torch.randn(2, 512, 8, 8)  # -> 64x64 output
+    dense = net(x)
+    Ho = Wo = 64
+    pix = torch.randint(0, Ho * Wo, (2, 50))
+    pix[0, :6] = torch.tensor([0, Wo - 1, (Ho - 1) * Wo, Ho * Wo - 1, 5, 7 * Wo])  # corners/edges
+    ref = torch.gather(dense.reshape(2, 32, -1), 2, pix[:, None, :].expand(2, 32, -1))
+    got = net.forward_sampled(x, pix)
+    assert got.shape == (2, 32, 50)
+    np.testing.assert_allclose(got.detach().numpy(), ref.detach().numpy(), rtol=1e-4, atol=2e-5)
