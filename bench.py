@@ -223,10 +223,13 @@ def cpu_baseline(wl, args):
     # route the two HIP ops of predict through the C port for this leg only
     F = mf.functions
 
-    def avg_cpu(values, points, batch_indices, *, batch_size, origin, pitch, dimensions, **kw):
-        m, _ = OC.average_voxelization_3d(values.numpy(), points.numpy(), batch_indices.numpy(),
+    def avg_cpu(values, points, batch_indices, *, batch_size, origin, pitch, dimensions,
+                return_counts=False, **kw):
+        m, c = OC.average_voxelization_3d(values.numpy(), points.numpy(), batch_indices.numpy(),
                                           batch_size=batch_size, origin=origin, pitch=pitch,
                                           dimensions=dimensions)
+        if return_counts:
+            return torch.from_numpy(m), torch.from_numpy(c)
         return torch.from_numpy(m)
 
     def interp_cpu(vox, points, batch_indices, channels_first=False):

@@ -138,26 +138,42 @@ class Model(nn.Module):
         return torch.cat((feat1, feat2, feat3.to(dt), feat4.to(dt)), dim=1)
 
     # ---- point selection (model.py:191-230) ---------------------------------------------
+    _eval_keep_cache = {}
+
+    def _keep_indices(self, n_point):
+        """The reference's subsample / pad of the n valid pixels (model.py:208-219).  In eval
+        mode it seeds a fresh ``RandomState(1234)`` per object, i.e. it is a pure function of
+        n: memoised, so the GPU does not idle behind a host-side MT19937 permutation."""
+        if n_point == 0:
+            raise ValueError("an example has no valid point")
+        if not self.training:
+            hit = Model._eval_keep_cache.get((n_point, self._n_point))
+            if hit is not None:
+                return hit
+        random_state = np.random.mtrand._rand if self.training else np.random.RandomState(1234)
+        if n_point >= self._n_point:
+            keep = random_state.permutation(n_point)[: self._n_point]
+        else:
+            keep = np.r_[np.arange(n_point),
+                         random_state.randint(0, n_point, self._n_point - n_point)]
+        keep = keep.astype(np.int64)
+        if not self.training and len(Model._eval_keep_cache) < 4096:
+            Model._eval_keep_cache[(n_point, self._n_point)] = keep
+        return keep
+
     def _select_points(self, mask):
         """mask [B,H,W] -> flat pixel indices [B,P] (row-major order of ``where``, then the
         reference's NumPy-RNG subsample / pad)."""
         B = mask.shape[0]
-        counts = mask.reshape(B, -1).sum(dim=1).cpu().numpy()  # the one host sync
-        flat = []
-        for i in range(B):
-            n_point = int(counts[i])
-            if n_point == 0:
-                raise ValueError("an example has no valid point")
-            random_state = np.random.mtrand._rand if self.training else np.random.RandomState(1234)
-            if n_point >= self._n_point:
-                keep = random_state.permutation(n_point)[: self._n_point]
-            else:
-                keep = np.r_[np.arange(n_point),
-                             random_state.randint(0, n_point, self._n_point - n_point)]
-            flat.append(keep)
-        keep = torch.from_numpy(np.stack(flat).astype(np.int64)).to(mask.device)
-        # position of the k-th valid pixel of each image
-        order = torch.argsort((~mask).reshape(B, -1).to(torch.uint8), dim=1, stable=True)
+        flat_mask = mask.reshape(B, -1)
+        counts = flat_mask.sum(dim=1).cpu().numpy()  # the one host sync
+        keep = torch.from_numpy(np.stack([self._keep_indices(int(c)) for c in counts])).to(mask.device)
+        # position of the k-th valid pixel of each image (stream compaction by prefix sum)
+        rank = torch.cumsum(flat_mask, dim=1) - 1
+        order = torch.zeros_like(rank)
+        src = torch.arange(flat_mask.shape[1], device=mask.device).expand_as(rank)
+        order.scatter_(1, torch.where(flat_mask, rank, rank.new_full((), flat_mask.shape[1] - 1)),
+                       torch.where(flat_mask, src, src.new_zeros(())))
         return torch.gather(order, 1, keep)
 
     def predict(self, *, class_id, rgb, pcd, pitch=None, origin=None, grid_nontarget_empty=None):

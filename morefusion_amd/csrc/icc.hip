@@ -647,7 +647,6 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
 // mode 0: write loss/gq/gt only.  mode 1: Adam update in place + refresh R|t.
 // aq/at: alpha_t of chainer's Adam for this step (evaluated in double on the host).
 constexpr int kStepThreads = 1024;
-constexpr int kMaxNB = 64;
 
 __global__ __launch_bounds__(kStepThreads) void k_icc_step(IccArgs a, int NB, int mode, float *q,
                                                            float *t, float *adam_m, float *adam_v,
