@@ -42,51 +42,66 @@ __device__ __forceinline__ int parity_class(int ix, int iy, int iz) {
   return ((ix + 1) & 1) | (((iy + 1) & 1) << 1) | (((iz + 1) & 1) << 2);
 }
 
-// pass 1: rows per class (wave-aggregated integer atomics)
-__global__ __launch_bounds__(256) void k_sc_count(ScArgs a) {
+// Index build.  Same-address global atomics cost ~12 ns each, so both passes first count in
+// LDS (32-bit LDS atomics are cheap) and touch the 8 global class counters once per
+// workgroup of 2048 voxels.
+constexpr int kIdxPerThread = 8;
+
+__device__ __forceinline__ int voxel_class(const ScArgs &a, int64_t i, int64_t total) {
+  if (i >= total || a.counts[i] <= 0) return -1;
   const int V = a.D * a.D * a.D;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int cls = -1;
-  if (i < (int64_t)a.B * V && a.counts[i] > 0) {
-    const int v = (int)(i % V);
-    cls = parity_class(v / (a.D * a.D), (v / a.D) % a.D, v % a.D);
-  }
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const unsigned long long m = __ballot(cls == c);
-    if (m && lane == __ffsll((long long)m) - 1) atomicAdd(&a.class_cnt[c], __popcll(m));
-  }
+  const int v = (int)(i % V);
+  return parity_class(v / (a.D * a.D), (v / a.D) % a.D, v % a.D);
 }
 
-// pass 2: compact row ids (class-major), row -> voxel map
-__global__ __launch_bounds__(256) void k_sc_assign(ScArgs a) {
-  const int V = a.D * a.D * a.D;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in = i < (int64_t)a.B * V;
-  int cls = -1;
-  if (in && a.counts[i] > 0) {
-    const int v = (int)(i % V);
-    cls = parity_class(v / (a.D * a.D), (v / a.D) % a.D, v % a.D);
-  }
-  const int lane = threadIdx.x & 63;
-  int row = -1;
+// pass 1: rows per class
+__global__ __launch_bounds__(256) void k_sc_count(ScArgs a) {
+  __shared__ int s_cnt[8];
+  if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t total = (int64_t)a.B * a.D * a.D * a.D;
+  const int64_t base = (int64_t)blockIdx.x * 256 * kIdxPerThread;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const unsigned long long m = __ballot(cls == c);
-    if (!m) continue;
-    const int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&a.class_fill[c], __popcll(m));
-    base = __shfl(base, leader, 64);
-    if (cls == c) {
-      int off = 0;
-      for (int k = 0; k < c; ++k) off += a.class_cnt[k];
-      row = off + base + __popcll(m & ((1ull << lane) - 1ull));
-    }
+  for (int j = 0; j < kIdxPerThread; ++j) {
+    const int cls = voxel_class(a, base + j * 256 + threadIdx.x, total);
+    if (cls >= 0) atomicAdd(&s_cnt[cls], 1);
   }
-  if (in) a.rowmap[i] = row < a.max_rows ? row : -1;
-  if (row >= 0 && row < a.max_rows) a.rowvox[row] = (int32_t)i;
+  __syncthreads();
+  if (threadIdx.x < 8 && s_cnt[threadIdx.x] > 0) atomicAdd(&a.class_cnt[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+// pass 2: compact row ids (class-major), row -> voxel map.  Row order inside a class is
+// arbitrary (it only names rows); every sum that depends on order is taken by tap index.
+__global__ __launch_bounds__(256) void k_sc_assign(ScArgs a) {
+  __shared__ int s_cnt[8], s_base[8], s_fill[8];
+  if (threadIdx.x < 8) { s_cnt[threadIdx.x] = 0; s_fill[threadIdx.x] = 0; }
+  __syncthreads();
+  const int64_t total = (int64_t)a.B * a.D * a.D * a.D;
+  const int64_t base = (int64_t)blockIdx.x * 256 * kIdxPerThread;
+  int cls[kIdxPerThread];
+#pragma unroll
+  for (int j = 0; j < kIdxPerThread; ++j) {
+    cls[j] = voxel_class(a, base + j * 256 + threadIdx.x, total);
+    if (cls[j] >= 0) atomicAdd(&s_cnt[cls[j]], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    int off = 0;
+    for (int k = 0; k < (int)threadIdx.x; ++k) off += a.class_cnt[k];
+    s_base[threadIdx.x] =
+        off + (s_cnt[threadIdx.x] > 0 ? atomicAdd(&a.class_fill[threadIdx.x], s_cnt[threadIdx.x]) : 0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kIdxPerThread; ++j) {
+    const int64_t i = base + j * 256 + threadIdx.x;
+    if (i >= total) continue;
+    int row = -1;
+    if (cls[j] >= 0) row = s_base[cls[j]] + atomicAdd(&s_fill[cls[j]], 1);
+    if (row >= a.max_rows) row = -1;
+    a.rowmap[i] = row;
+    if (row >= 0) a.rowvox[row] = (int32_t)i;
+  }
 }
 
 // A[row][c] = x[b][c][v]  (lanes over channels: coalesced stores, strided gathers)
@@ -105,61 +120,79 @@ __global__ __launch_bounds__(256) void k_sc_gather(ScArgs a) {
 }
 
 // C[row][n] = sum_k A[row][k] * Wp[class(row)][k][n],  n in [0, 8*Cout)
-// grid: (row tiles, column tiles, class).  Both operands of a tile sit in LDS
+// Work list = (class, row tile, column tile).  Both operands of a tile sit in LDS
 // ([k][row] and [k][col]: conflict-free fragment reads); K = Cs is small enough to
 // stage completely.  Each wave owns 16 rows x 64 columns = 4 accumulators.
 __global__ __launch_bounds__(256) void k_sc_gemm(ScArgs a, const float *__restrict__ Wp) {
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  const int cls = blockIdx.z;
-  int row0 = 0;
-  for (int k = 0; k < cls; ++k) row0 += a.class_cnt[k];
-  const int n_cls = min(a.class_cnt[cls], max(0, a.max_rows - row0));
-  const int m0 = blockIdx.x * kTM;
-  if (m0 >= n_cls) return;
   const int K = a.Cs, N = 8 * a.Cout;
-  const int n0 = blockIdx.y * kTN;
-  float *As = s_mem;                    // [K][kTM + 4]
-  float *Bs = s_mem + K * (kTM + 4);    // [K][kTN + 4]
-  // stage A transposed (rows beyond the class are zero) and B
-  for (int i = threadIdx.x; i < kTM * (K / 4); i += 256) {
-    const int r = i / (K / 4), k4 = i % (K / 4);
-    float4 v = make_float4(0, 0, 0, 0);
-    if (m0 + r < n_cls)
-      v = *reinterpret_cast<const float4 *>(a.A + (int64_t)(row0 + m0 + r) * K + 4 * k4);
-    As[(4 * k4 + 0) * (kTM + 4) + r] = v.x;
-    As[(4 * k4 + 1) * (kTM + 4) + r] = v.y;
-    As[(4 * k4 + 2) * (kTM + 4) + r] = v.z;
-    As[(4 * k4 + 3) * (kTM + 4) + r] = v.w;
-  }
-  const float *Wc = Wp + (int64_t)cls * K * N;
-  for (int i = threadIdx.x; i < K * (kTN / 4); i += 256) {
-    const int k = i / (kTN / 4), c4 = i % (kTN / 4);
-    *reinterpret_cast<float4 *>(Bs + k * (kTN + 4) + 4 * c4) =
-        *reinterpret_cast<const float4 *>(Wc + (int64_t)k * N + n0 + 4 * c4);
-  }
-  __syncthreads();
+  const int n_ntiles = N / kTN;
+  float *As = s_mem;                  // [K][kTM + 4]
+  float *Bs = s_mem + K * (kTM + 4);  // [K][kTN + 4]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, lk = lane >> 4;
-  f32x4 acc[4];
+  // class tile tables (8 classes): every workgroup walks the REAL tiles only, grid-strided
+  int cls_rows[8], cls_row0[8], cls_tile0[9];
+  {
+    int r0 = 0, t0 = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  for (int k0 = 0; k0 < K; k0 += 4) {
-    // A fragment: lane l holds A[row = l&15][k = l>>4];  B: B[k = l>>4][col = l&15]
-    const float af = As[(k0 + lk) * (kTM + 4) + wave * 16 + lr];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float bf = Bs[(k0 + lk) * (kTN + 4) + j * 16 + lr];
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[j], 0, 0, 0);
+    for (int c = 0; c < 8; ++c) {
+      const int n = min(a.class_cnt[c], max(0, a.max_rows - r0));
+      cls_rows[c] = n;
+      cls_row0[c] = r0;
+      cls_tile0[c] = t0;
+      r0 += a.class_cnt[c];
+      t0 += ((n + kTM - 1) / kTM) * n_ntiles;
     }
+    cls_tile0[8] = t0;
   }
-  // C/D fragment: col = lane&15, row = (lane>>4)*4 + i
+  for (int tile = blockIdx.x; tile < cls_tile0[8]; tile += gridDim.x) {
+    int cls = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = m0 + wave * 16 + lk * 4 + i;
-      if (r < n_cls) a.C[(int64_t)(row0 + r) * N + n0 + j * 16 + lr] = acc[j][i];
+    for (int c = 1; c < 8; ++c) cls += tile >= cls_tile0[c] ? 1 : 0;
+    const int local = tile - cls_tile0[cls];
+    const int m0 = (local / n_ntiles) * kTM, n0 = (local % n_ntiles) * kTN;
+    const int n_cls = cls_rows[cls], row0 = cls_row0[cls];
+    __syncthreads();  // LDS tiles of the previous iteration are no longer read
+    // stage A transposed (rows beyond the class are zero) and B
+    for (int i = threadIdx.x; i < kTM * (K / 4); i += 256) {
+      const int r = i / (K / 4), k4 = i % (K / 4);
+      float4 v = make_float4(0, 0, 0, 0);
+      if (m0 + r < n_cls)
+        v = *reinterpret_cast<const float4 *>(a.A + (int64_t)(row0 + m0 + r) * K + 4 * k4);
+      As[(4 * k4 + 0) * (kTM + 4) + r] = v.x;
+      As[(4 * k4 + 1) * (kTM + 4) + r] = v.y;
+      As[(4 * k4 + 2) * (kTM + 4) + r] = v.z;
+      As[(4 * k4 + 3) * (kTM + 4) + r] = v.w;
     }
+    const float *Wc = Wp + (int64_t)cls * K * N;
+    for (int i = threadIdx.x; i < K * (kTN / 4); i += 256) {
+      const int k = i / (kTN / 4), c4 = i % (kTN / 4);
+      *reinterpret_cast<float4 *>(Bs + k * (kTN + 4) + 4 * c4) =
+          *reinterpret_cast<const float4 *>(Wc + (int64_t)k * N + n0 + 4 * c4);
+    }
+    __syncthreads();
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      // A fragment: lane l holds A[row = l&15][k = l>>4];  B: B[k = l>>4][col = l&15]
+      const float af = As[(k0 + lk) * (kTM + 4) + wave * 16 + lr];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bf = Bs[(k0 + lk) * (kTN + 4) + j * 16 + lr];
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[j], 0, 0, 0);
+      }
+    }
+    // C/D fragment: col = lane&15, row = (lane>>4)*4 + i
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = m0 + wave * 16 + lk * 4 + i;
+        if (r < n_cls) a.C[(int64_t)(row0 + r) * N + n0 + j * 16 + lr] = acc[j][i];
+      }
+  }
 }
 
 // out[b][co][o] = relu( sum_taps C[row(v)][slot*Cout + co] + dense[b][co][o] + bias[co] )
@@ -273,7 +306,7 @@ extern "C" int mf_sparse_conv3d_k4s2_fwd(const float *x, const int32_t *counts, 
   a.A = (float *)p; p += align256((int64_t)max_rows * Cs * 4);
   a.C = (float *)p;
   MF_TRY(hipMemsetAsync(a.class_cnt, 0, 512, stream));  // class_cnt and class_fill
-  const unsigned nb = (unsigned)((B * V + 255) / 256);
+  const unsigned nb = (unsigned)((B * V + 256 * kIdxPerThread - 1) / (256 * kIdxPerThread));
   hipLaunchKernelGGL(k_sc_count, dim3(nb), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(k_sc_assign, dim3(nb), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(k_sc_gather, dim3((unsigned)(((int64_t)max_rows * Cs + 255) / 256)),
@@ -291,8 +324,8 @@ extern "C" int mf_sparse_conv3d_k4s2_fwd(const float *x, const int32_t *counts, 
     mf::set_last_error(hipErrorInvalidValue, "sparse_conv3d: Cs too large for the LDS-resident K");
     return -(int)hipErrorInvalidValue;
   }
-  hipLaunchKernelGGL(k_sc_gemm, dim3((max_rows + kTM - 1) / kTM, 8 * Cout / kTN, 8), dim3(256),
-                     lds_g, stream, a, Wp);
+  // persistent-style: 2 workgroups per CU walk the (class, row tile, column tile) list
+  hipLaunchKernelGGL(k_sc_gemm, dim3(512), dim3(256), lds_g, stream, a, Wp);
   const int Vo = (D / 2) * (D / 2) * (D / 2);
   hipLaunchKernelGGL(k_sc_reduce, dim3((Vo + 63) / 64, B), dim3(256),
                      (size_t)Cout * 65 * sizeof(float), stream, a, dense, bias, relu, out);
