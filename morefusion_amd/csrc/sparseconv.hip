@@ -197,48 +197,56 @@ __global__ __launch_bounds__(256) void k_sc_gemm(ScArgs a, const float *__restri
 
 // out[b][co][o] = relu( sum_taps C[row(v)][slot*Cout + co] + dense[b][co][o] + bias[co] )
 // One workgroup = 64 consecutive output voxels x all Cout channels, staged through LDS so
-// that the final stores are coalesced along o.  Each wave walks 16 output voxels; for one
+// that the final stores are coalesced along o.  Each wave walks 4 output voxels; for one
 // voxel the 64 lanes look up its 64 taps at once (one rowmap gather), then every lane
 // accumulates Cout/64 channels over the (few) taps that hit an occupied voxel, in tap order.
-__global__ __launch_bounds__(256) void k_sc_reduce(ScArgs a, const float *__restrict__ dense,
-                                                   const float *__restrict__ bias, int relu,
-                                                   float *__restrict__ out) {
+constexpr int kRedThreads = 1024;  // 16 waves x 4 output voxels: short dependent-load chains
+
+__global__ __launch_bounds__(kRedThreads) void k_sc_reduce(ScArgs a, const float *__restrict__ dense,
+                                                          const float *__restrict__ bias, int relu,
+                                                          float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float s_tile[];  // [Cout][65]
   const int D = a.D, Do = D / 2, V = D * D * D, Vo = Do * Do * Do;
   const int b = blockIdx.y;
   const int o0 = blockIdx.x * 64;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int kWaves = kRedThreads / 64, kPerWave = 64 / kWaves;
   const int N = 8 * a.Cout;
   const int nj = a.Cout / 64;
   // this lane's tap: k = (kx,ky,kz) in [0,4)^3, fixed for the whole kernel
   const int kx = lane >> 4, ky = (lane >> 2) & 3, kz = lane & 3;
   const int slot = (kx >> 1) | ((ky >> 1) << 1) | ((kz >> 1) << 2);
-  for (int t = 0; t < 16; ++t) {
-    const int ol = wave * 16 + t;
-    const int o = o0 + ol;
-    float acc[8];
+  int rows[kPerWave];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+  for (int t = 0; t < kPerWave; ++t) {  // all row-map lookups of this wave in flight at once
+    const int o = o0 + wave * kPerWave + t;
+    rows[t] = -1;
     if (o < Vo) {
       const int oz = o % Do, oy = (o / Do) % Do, oxx = o / (Do * Do);
       const int vx = 2 * oxx - 1 + kx, vy = 2 * oy - 1 + ky, vz = 2 * oz - 1 + kz;
-      int row = -1;
       if (vx >= 0 && vx < D && vy >= 0 && vy < D && vz >= 0 && vz < D)
-        row = a.rowmap[(int64_t)b * V + (vx * D + vy) * D + vz];
-      unsigned long long hits = __ballot(row >= 0);
-      while (hits) {  // taps in increasing k: fixed summation order
-        const int src = __ffsll((long long)hits) - 1;
-        hits &= hits - 1;
-        const int r = __shfl(row, src, 64);
-        const int sl = __shfl(slot, src, 64);
-        const float *crow = a.C + (int64_t)r * N + sl * a.Cout;
-        for (int j = 0; j < nj; ++j) acc[j] += crow[lane + 64 * j];
-      }
+        rows[t] = a.rowmap[(int64_t)b * V + (vx * D + vy) * D + vz];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kPerWave; ++t) {
+    const int ol = wave * kPerWave + t;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    unsigned long long hits = __ballot(rows[t] >= 0);
+    while (hits) {  // taps in increasing k: fixed summation order
+      const int src = __ffsll((long long)hits) - 1;
+      hits &= hits - 1;
+      const int r = __shfl(rows[t], src, 64);
+      const int sl = __shfl(slot, src, 64);
+      const float *crow = a.C + (int64_t)r * N + sl * a.Cout;
+      for (int j = 0; j < nj; ++j) acc[j] += crow[lane + 64 * j];
     }
     for (int j = 0; j < nj; ++j) s_tile[(lane + 64 * j) * 65 + ol] = acc[j];
   }
   __syncthreads();
-  for (int co = wave; co < a.Cout; co += 4) {
+  for (int co = wave; co < a.Cout; co += kWaves) {
     const int o = o0 + lane;
     if (o < Vo) {
       const int64_t idx = ((int64_t)b * a.Cout + co) * Vo + o;
@@ -327,7 +335,7 @@ extern "C" int mf_sparse_conv3d_k4s2_fwd(const float *x, const int32_t *counts, 
   // persistent-style: 2 workgroups per CU walk the (class, row tile, column tile) list
   hipLaunchKernelGGL(k_sc_gemm, dim3(512), dim3(256), lds_g, stream, a, Wp);
   const int Vo = (D / 2) * (D / 2) * (D / 2);
-  hipLaunchKernelGGL(k_sc_reduce, dim3((Vo + 63) / 64, B), dim3(256),
+  hipLaunchKernelGGL(k_sc_reduce, dim3((Vo + 63) / 64, B), dim3(kRedThreads),
                      (size_t)Cout * 65 * sizeof(float), stream, a, dense, bias, relu, out);
   return mf::check_launch("mf_sparse_conv3d_k4s2_fwd");
 }
