@@ -198,9 +198,15 @@ def roofline_icc_tdf(wl):
         pts += n_s * (off[so[s + 1]] - off[so[s]])
     alg = pts * 16 + 2 * icc.n_objects * icc.dim ** 3 * 8
     achieved = alg / (ms * 1e-3) / 1e9
+    traffic = None  # PMC passes committed under profiles/ (tools/prof_icc_pmc.sh), same scene
+    pmc = os.path.join(ROOT, "profiles", "r01_icc_pmc.json")
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc))["k_icc_tdf"]
+        if rec["n_objects"] == icc.n_objects and rec["n_points"] == icc.n_points:
+            traffic = rec["traffic_bytes"]
     return dict(kernel="k_icc_tdf (mf_icc_refine, launch 1 of 3 per ICC iteration)", bound="hbm",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                 algorithmic_bytes_per_launch=alg, avg_launch_ms=round(ms, 5),
                 note="L2-resident working set; latency/LDS-atomic bound (DESIGN.md 4)")
 

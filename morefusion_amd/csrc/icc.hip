@@ -11,11 +11,11 @@
 //   (examples/ycb_video/pose_refinement/check_iterative_collision_check_link.py:52-79).
 //
 // Here one iteration is THREE launches and the whole n_iter loop is one hipGraph:
-//   k_icc_tdf    grid (slab, 2*O): pose -> world point -> TDF of the "own" / "other"
-//                point set of object o, tile of the 32^3 grid resident in LDS as packed
-//                u64 keys (distance bits << 32 | global candidate id), ds_min_u64 gives
-//                exact min + deterministic arg-min; epilogue stores the winners and
-//                the per-grid max of the raw inside weight (integer atomicMax).
+//   k_icc_tdf    grid (x-plane tile, 2*O): pose -> world point -> TDF of the "own" / "other"
+//                point set of object o; the tile's (min distance, arg-min id) live in LDS as
+//                two 32-bit words per voxel and are resolved with two passes of 32-bit LDS
+//                atomics (64-bit LDS atomics measured ~10x slower); epilogue stores the
+//                winners and the per-grid max of the raw inside weight (integer atomicMax).
 //   k_icc_accum  grid (block, O): per voxel pseudo-occupancy weights, max() with the
 //                no-entry grid, partial sums of reward / penalty AND the pose-gradient
 //                moments.  The loss gradient is linear in {1/S_t, 1/S_in, PN/S_in^2},
@@ -23,9 +23,9 @@
 //                no second pass over the grids once the global sums are known.
 //   k_icc_step   grid (scene): fixed-order reduction of the partials, loss, chain rule
 //                to (q, t), chainer-Adam update, next iteration's rotation matrices.
-// Every reduction has a fixed order (wave shuffles, ordered partials, integer
-// fixed-point atomics for the rare cross-object collision terms): bitwise
-// reproducible run to run.  No host synchronisation anywhere.
+// Every reduction has a fixed order (ordered partials, wave-sliced block sums, integer
+// fixed-point limbs for the cross-object collision terms): bitwise reproducible run to
+// run.  No host synchronisation anywhere.  MF_ICC_DEBUG / MF_ICC_SX are tuning aids.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>

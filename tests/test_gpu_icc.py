@@ -227,3 +227,23 @@ def test_icc_single_object_scene_and_far_apart_objects():
     assert np.isfinite(l_o)
     np.testing.assert_allclose(float(loss.detach()), l_o, rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(link.translation.grad.cpu().numpy(), gt_o, rtol=2e-3, atol=2e-4)
+
+
+def test_icc_ragged_multi_scene_batch_vs_oracle(fixtures3):
+    """Scenes with 1, 3 and 5 objects in ONE batch: per-scene loss and gradients equal the
+    oracle's for each scene evaluated alone (ragged scene tables, max_scene_objects = 5)."""
+    sizes = [1, 3, 5]
+    scenes = [mf.synthetic.make_icc_scene(n, seed=10 + n, fixtures=fixtures3 if n == 3 else None) for n in sizes]
+    dicts = [dict(points=s["points"], sdf=s["sdf"], pitch=s["pitch"], origin=s["origin"],
+                  grid_target=s["grid_target"], grid_nontarget_empty=s["grid_nontarget_empty"]) for s in scenes]
+    q0 = np.concatenate([np.stack([O.quaternion_from_matrix(T) for T in s["transform_init"]]) for s in scenes]).astype(np.float32)
+    t0 = np.concatenate([s["transform_init"][:, :3, 3] for s in scenes]).astype(np.float32)
+    batch = mf.contrib.IccScenes(dicts, sdf_offset=0.02)
+    loss, gq, gt = batch.loss_grad(dev(q0), dev(t0))
+    lo = 0
+    for k, (n, s) in enumerate(zip(sizes, scenes)):
+        l_o, gq_o, gt_o, _ = OC.icc_loss_grad(*scene_args(s), q0[lo:lo + n], t0[lo:lo + n], sdf_offset=0.02)
+        np.testing.assert_allclose(float(loss[k]), l_o, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(gq[lo:lo + n].cpu().numpy(), gq_o, rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(gt[lo:lo + n].cpu().numpy(), gt_o, rtol=2e-3, atol=2e-4)
+        lo += n
