@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--objects", type=int, default=8)
     ap.add_argument("--icc-iters", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 (default, the reference's precision) or bf16 autocast for the stock "
+                         "convolutions / GEMMs of the network (HIP voxel ops, sparse conv3 and ICC stay f32)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the network pass and the ICC refinement back to back on one stream")
     ap.add_argument("--stage-breakdown", action="store_true", default=True)
@@ -113,7 +116,9 @@ class Workload:
                         alpha_q=0.01, alpha_t=0.001)
 
     def _network(self):
-        rot, trans, conf = self.model.predict(**self.inputs)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.args.dtype == "bf16"):
+            rot, trans, conf = self.model.predict(**self.inputs)
+        rot, trans, conf = rot.float(), trans.float(), conf.float()
         idx = conf.argmax(dim=1)
         ar = torch.arange(self.B, device=self.device)
         return torch.cat([rot[ar, idx], trans[ar, idx]], dim=1)  # [B,7] network poses
@@ -362,7 +367,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {
                 "workload": f"{args.scenes_per_gpu} scene(s) x {args.objects} objects per GPU: "
                             "singleview_3d Model.predict (ResNet18+PSPNet, 32^3 voxelize, occupancy "

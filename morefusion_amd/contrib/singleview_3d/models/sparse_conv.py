@@ -45,12 +45,15 @@ class SparseVoxelConv3d:
             max_rows = B * D ** 3
         dense = None
         if h_dense is not None:
-            dense = F.conv3d(h_dense.float(), self.Wd, None, stride=2, padding=1).contiguous()
+            # (under autocast this convolution may run in bf16; the kernel adds a float32 tensor)
+            dense = F.conv3d(h_dense.float(), self.Wd, None, stride=2, padding=1).float().contiguous()
         lib = _lib.lib()
         nbytes = lib.mf_sparse_conv3d_workspace_bytes(B, Cs, Cout, D, max_rows)
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=voxelized.device)
         x = voxelized.float().contiguous()
+        counts = counts.to(torch.int32)
+        assert x.dtype == torch.float32 and (dense is None or dense.dtype == torch.float32)
         out = torch.empty((B, Cout, D // 2, D // 2, D // 2), dtype=torch.float32, device=x.device)
         bias = self.conv.bias.detach().float().contiguous() if self.conv.bias is not None else None
         _lib.check(lib.mf_sparse_conv3d_k4s2_fwd(

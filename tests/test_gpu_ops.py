@@ -394,3 +394,22 @@ def test_sparse_conv3_matches_dense_conv3d(B, Cs, Cd, Cout, n):
     assert torch.equal(got, got2)
     pre = op(vox, counts, h_occ, max_rows=B * n, relu=False)
     assert float(pre.min()) < 0  # relu flag honoured
+
+
+def test_model_predict_under_bf16_autocast_matches_fp32_roughly():
+    """bf16 autocast for the stock convolutions (BASELINE config 5's precision); the HIP ops
+    keep float32 and must be handed float32 tensors whatever the autocast state."""
+    from morefusion_amd.contrib.singleview_3d.models import Model
+    torch.manual_seed(0)
+    model = Model(n_fg_class=21, with_occupancy=True).cuda().eval()
+    b = mf.synthetic.make_singleview_batch(2, seed=4)
+    inputs = {k: torch.as_tensor(b[k]).cuda() for k in
+              ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty")}
+    with torch.no_grad():
+        rot, trans, conf = model.predict(**inputs)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            rot_b, trans_b, conf_b = model.predict(**inputs)
+    for x in (rot_b, trans_b, conf_b):
+        assert torch.isfinite(x.float()).all()
+    assert float((trans_b.float() - trans).abs().max()) < 0.05  # metres; same pose field
+    assert float((conf_b.float() - conf).abs().max()) < 0.1
