@@ -1,19 +1,20 @@
-"""transformation_matrix(q, t).  morefusion/functions/geometry/transformation_matrix.py:5-18."""
+"""transformation_matrix(quaternion, translation) -> homogeneous 4x4 transform(s).
+
+API of morefusion/functions/geometry/transformation_matrix.py:5-18: a batch ``[N,4]`` /
+``[N,3]`` gives ``[N,4,4]``, a single ``[4]`` / ``[3]`` pair gives ``[4,4]``.
+"""
 from .compose_transform import compose_transform
 from .quaternion_matrix import quaternion_matrix
 
 
 def transformation_matrix(quaternion, translation):
-    if quaternion.ndim == 2:
-        batch_size = quaternion.shape[0]
-        assert quaternion.shape == (batch_size, 4)
-        assert translation.shape == (batch_size, 3)
-        T = quaternion_matrix(quaternion)
-        T = compose_transform(T[:, :3, :3], translation)
-    else:
-        assert quaternion.ndim == 1
-        assert quaternion.shape == (4,)
-        assert translation.shape == (3,)
-        T = quaternion_matrix(quaternion[None])[0]
-        T = compose_transform(T[None, :3, :3], translation[None])[0]
-    return T
+    single = quaternion.ndim == 1
+    q = quaternion[None] if single else quaternion
+    t = translation[None] if single else translation
+    if q.ndim != 2 or q.shape[1] != 4 or t.shape != (q.shape[0], 3):
+        raise ValueError(
+            f"expected quaternion [N,4] and translation [N,3] (or [4] and [3]), got "
+            f"{tuple(quaternion.shape)} and {tuple(translation.shape)}")
+    rotation = quaternion_matrix(q)[:, :3, :3]
+    T = compose_transform(rotation, t)
+    return T[0] if single else T

@@ -1,24 +1,26 @@
-"""masks_to_bboxes -- (y1, x1, y2, x2) of boolean masks.
+"""masks_to_bboxes -- tight (y1, x1, y2, x2) boxes of boolean masks, end-exclusive.
 
-morefusion/geometry/masks_to_bboxes.py:4-38.
+Behaviour of morefusion/geometry/masks_to_bboxes.py:4-38: input ``[N,H,W]`` or ``[H,W]``
+bool, output float64 ``[N,4]`` or ``[4]``; an empty mask gives a zero box.
 """
 import numpy as np
 
 
+def _extent(flags):
+    """First and one-past-last True position of a 1-D bool array, or (0, 0)."""
+    hit = np.flatnonzero(flags)
+    return (hit[0], hit[-1] + 1) if hit.size else (0, 0)
+
+
 def masks_to_bboxes(masks):
     masks = np.asarray(masks)
-    assert masks.dtype == bool
-    ndim = masks.ndim
-    assert ndim in [2, 3], "masks must be 2 or 3 dimensional"
-    if ndim == 2:
-        masks = masks[None]
-    bboxes = np.zeros((len(masks), 4), dtype=np.float64)
-    for i, mask in enumerate(masks):
-        where = np.argwhere(mask)
-        if where.size == 0:
-            continue
-        (y1, x1), (y2, x2) = where.min(0), where.max(0) + 1
-        bboxes[i] = y1, x1, y2, x2
-    if ndim == 2:
-        return bboxes[0]
-    return bboxes
+    if masks.dtype != bool:
+        raise AssertionError("masks must be boolean")
+    if masks.ndim not in (2, 3):
+        raise AssertionError("masks must be 2 or 3 dimensional")
+    stack = masks[None] if masks.ndim == 2 else masks
+    boxes = np.zeros((stack.shape[0], 4), dtype=np.float64)
+    for n, m in enumerate(stack):
+        (y1, y2), (x1, x2) = _extent(m.any(axis=1)), _extent(m.any(axis=0))
+        boxes[n] = (y1, x1, y2, x2)
+    return boxes[0] if masks.ndim == 2 else boxes

@@ -1,37 +1,36 @@
-"""ADD / ADD-S metric (host side, float64).  morefusion/metrics/average_distance.py:6-35."""
+"""ADD and ADD-S between two poses of a model point cloud (host side, float64).
+
+Behaviour of morefusion/metrics/average_distance.py:6-35: ``average_distance(points,
+transform1, transform2)`` takes three equally long lists and returns ``(adds, add_ss)``:
+ADD = mean distance between corresponding transformed points; ADD-S = mean distance from
+each point under transform1 to its nearest neighbour under transform2.
+"""
 import numpy as np
-import sklearn.neighbors
+from scipy.spatial import cKDTree
 
 
-def _transform(points, T, translate=True):
-    out = points @ T[:3, :3].T
-    if translate:
-        out = out + T[:3, 3]
-    return out
+def _apply(points, T, translate):
+    moved = points @ T[:3, :3].T
+    return moved + T[:3, 3] if translate else moved
 
 
-def _average_distance(points, transform1, transform2, translate=True):
-    assert points.shape == (points.shape[0], 3)
-    assert transform1.shape == (4, 4)
-    assert transform2.shape == (4, 4)
+def _pair(points, T1, T2, translate=True):
     points = np.asarray(points, dtype=np.float64)
-    points1 = _transform(points, np.asarray(transform1, dtype=np.float64), translate)
-    points2 = _transform(points, np.asarray(transform2, dtype=np.float64), translate)
-    add = np.linalg.norm(points1 - points2, axis=1).mean()
-    kdtree = sklearn.neighbors.KDTree(points2)
-    indices = kdtree.query(points1, return_distance=False)[:, 0]
-    add_s = np.linalg.norm(points1 - points2[indices], axis=1).mean()
-    return add, add_s
+    T1, T2 = np.asarray(T1, dtype=np.float64), np.asarray(T2, dtype=np.float64)
+    if points.ndim != 2 or points.shape[1] != 3 or T1.shape != (4, 4) or T2.shape != (4, 4):
+        raise ValueError("points must be [n,3] and the transforms 4x4")
+    a, b = _apply(points, T1, translate), _apply(points, T2, translate)
+    add = np.sqrt(((a - b) ** 2).sum(axis=1)).mean()
+    nearest, _ = cKDTree(b).query(a, k=1)
+    return add, nearest.mean()
 
 
 def average_distance(points, transform1, transform2, translate=True):
-    assert isinstance(points, list)
-    batch_size = len(points)
-    assert len(transform1) == batch_size
-    assert len(transform2) == batch_size
-    adds = np.zeros((batch_size,), dtype=float)
-    add_ss = np.zeros((batch_size,), dtype=float)
-    for i in range(batch_size):
-        adds[i], add_ss[i] = _average_distance(
-            points[i], transform1[i], transform2[i], translate=translate)
+    if not isinstance(points, list):
+        raise TypeError("points must be a list of [n,3] arrays (one per instance)")
+    if not (len(points) == len(transform1) == len(transform2)):
+        raise ValueError("points, transform1 and transform2 must have the same length")
+    pairs = [_pair(p, a, b, translate) for p, a, b in zip(points, transform1, transform2)]
+    adds = np.array([p[0] for p in pairs], dtype=float).reshape(len(points))
+    add_ss = np.array([p[1] for p in pairs], dtype=float).reshape(len(points))
     return adds, add_ss

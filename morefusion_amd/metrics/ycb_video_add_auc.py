@@ -1,40 +1,35 @@
-"""YCB-Video ADD(-S) AUC (VOC-style area up to 0.1 m).
+"""YCB-Video ADD(-S) AUC: area under the accuracy-vs-threshold curve up to ``max_value``.
 
-morefusion/metrics/ycb_video_add_auc.py:5-51 (itself a port of the YCB_Video_toolbox
-plot_accuracy_keyframe.m).
+Behaviour of morefusion/metrics/ycb_video_add_auc.py:5-51 (itself following the YCB_Video
+toolbox's plot_accuracy_keyframe.m): errors above ``max_value`` count as misses, the curve
+is made monotone (VOC-style) and integrated over the distinct error values.
 """
 import numpy as np
 
 
+def VOCap(rec, prec, max_value=0.1):
+    """VOC average precision of (rec, prec) extended with (0, 0) and (max_value, prec[-1])."""
+    x = np.concatenate(([0.0], np.asarray(rec, dtype=float), [max_value]))
+    y = np.concatenate(([0.0], np.asarray(prec, dtype=float), [prec[-1]]))
+    y = np.maximum.accumulate(y)
+    step = np.flatnonzero(x[1:] != x[:-1]) + 1
+    return float(((x[step] - x[step - 1]) * y[step]).sum() / max_value)
+
+
 def ycb_video_add_auc(adds, *, max_value=0.1, return_xy=False):
-    adds = np.asarray(adds)
-    assert adds.ndim == 1
-    assert adds.min() >= 0, f"min of adds must be >=0: {adds.min()}"
-    D = adds.astype(float).copy()
-    D[D > max_value] = np.inf
-    d = np.sort(D)
-    n = len(d)
-    accuracy = np.cumsum(np.ones((1, n))) / n
-    keep = np.isfinite(d)
-    if keep.any():
-        d = d[keep]
-        accuracy = accuracy[keep]
-        auc = VOCap(d, accuracy, max_value=max_value)
-        x = np.r_[0, d, max_value]
-        y = np.r_[0, accuracy, accuracy[-1]]
+    adds = np.asarray(adds, dtype=float)
+    if adds.ndim != 1:
+        raise AssertionError("adds must be 1-D")
+    if adds.min() < 0:
+        raise AssertionError(f"min of adds must be >=0: {adds.min()}")
+    n = adds.size
+    hits = np.sort(adds[adds <= max_value])  # misses sort to +inf and are dropped
+    if hits.size:
+        accuracy = np.arange(1, hits.size + 1) / n
+        auc = VOCap(hits, accuracy, max_value=max_value)
+        x = np.concatenate(([0.0], hits, [max_value]))
+        y = np.concatenate(([0.0], accuracy, [accuracy[-1]]))
     else:
         auc = 0
-        x = np.array([0, max_value], dtype=float)
-        y = np.array([0, 0], dtype=float)
-    if return_xy:
-        return auc, x, y
-    return auc
-
-
-def VOCap(rec, prec, max_value=0.1):
-    mrec = np.r_[0, rec, max_value]
-    mpre = np.r_[0, prec, prec[-1]]
-    for i in range(1, len(mpre)):
-        mpre[i] = max(mpre[i], mpre[i - 1])
-    i = np.argwhere(mrec[1:] != mrec[:-1]) + 1
-    return np.sum((mrec[i] - mrec[i - 1]) * mpre[i]) / max_value
+        x, y = np.array([0.0, max_value]), np.zeros(2)
+    return (auc, x, y) if return_xy else auc
