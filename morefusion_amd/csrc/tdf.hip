@@ -4,16 +4,17 @@
 // (K7: one thread per (point, kernel offset); float atomicMin on a global grid, then
 // a racy atomicExch of the candidate id), :105-166 (K8), :181-213 (weights).
 //
-// MI355X design: a workgroup owns a tile of the voxel grid in LDS as packed 64-bit
-// keys (distance bits << 32 | flat candidate id).  Distances are >= 0, so unsigned
-// integer order == float order and ONE ds_min_u64 per candidate yields the exact
-// minimum AND a deterministic arg-min (lowest flat id among equal distances) -- the
-// reference's two-atomic sequence can record a non-minimal writer.  A 32-bit peek at
-// the current minimum skips the atomic for candidates that cannot win (most of
-// them: every voxel sees ~20 candidates).  Tiles are x-slabs (optionally split in
-// y) of <= 64 KB, so two workgroups share a CU's 160 KB LDS; every workgroup streams
-// the whole point list (12 B/point, L2-resident) and keeps only candidates that land
-// in its tile.  No global atomics, no pre-filled global grids, one coalesced write.
+// MI355X design: a workgroup owns a tile of the voxel grid in LDS as two 32-bit words per
+// voxel (distance bits, candidate id).  Distances are >= 0, so unsigned integer order ==
+// float order: pass 0 takes a 32-bit atomicMin of the distance bits, pass 1 a 32-bit
+// atomicMin of the flat id among the candidates that equal the minimum -- exact minimum AND
+// deterministic arg-min (lowest flat id among equal distances); the reference's
+// atomicMin + atomicExch pair can record a non-minimal writer.  (A packed 64-bit key with one
+// ds_min_u64 was the first version: 64-bit LDS atomics measured ~10x slower than 32-bit ones.)
+// Tiles are x-slabs (optionally split in y) of <= 64 KB, so two workgroups share a CU's 160 KB
+// LDS; every workgroup streams the whole point list (12 B/point, L2-resident) and keeps only
+// candidates that land in its tile.  No global atomics, no pre-filled global grids, one
+// coalesced write.
 #include <algorithm>
 
 #include "mf_common.h"
@@ -30,7 +31,6 @@ __device__ __forceinline__ int tdf_ksize(float pitch, float trunc) {
 namespace {
 
 constexpr int kTdfThreads = 256;
-constexpr unsigned long long kNoCand = 0xffffffffull;
 
 // Kernel offsets follow numpy.meshgrid's default 'xy' indexing used at
 // truncated_distance_function.py:39-41: flat k = (a*ks + b)*ks + c  ->  (b, a, c) - ks/2.
@@ -41,63 +41,67 @@ __global__ __launch_bounds__(kTdfThreads) void k_tdf_fwd(const float *__restrict
                                                          float trunc, int ks_rt, int SX, int SY,
                                                          float *__restrict__ tdf,
                                                          int32_t *__restrict__ flat) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_w[];  // dist bits [nvox], id [nvox]
   const int ks = KS > 0 ? KS : ks_rt;
   const int h = ks / 2, K = ks * ks * ks;
   const int x0 = blockIdx.x * SX, y0 = blockIdx.y * SY;
   const int sx = min(SX, X - x0), sy = min(SY, Y - y0);
   const int nvox = sx * sy * Z;
-  const unsigned long long init = ((unsigned long long)__float_as_uint(trunc) << 32) | kNoCand;
-  for (int i = threadIdx.x; i < nvox; i += kTdfThreads) s_key[i] = init;
+  uint32_t *s_dist = s_w, *s_id = s_w + SX * SY * Z;
+  const uint32_t tbits = __float_as_uint(trunc);
+  for (int i = threadIdx.x; i < nvox; i += kTdfThreads) { s_dist[i] = tbits; s_id[i] = 0xffffffffu; }
   __syncthreads();
-  const uint32_t *s_hi = reinterpret_cast<const uint32_t *>(s_key);
   const float fh = (float)h;
-  for (int64_t p = threadIdx.x; p < P; p += kTdfThreads) {
-    float fx = (points[3 * p] - ox) / pitch;
-    float fy = (points[3 * p + 1] - oy) / pitch;
-    float fz = (points[3 * p + 2] - oz) / pitch;
-    float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
-    // neighbourhood vs tile (false for NaN)
-    if (!(rx + fh >= (float)x0 && rx - fh < (float)(x0 + sx) && ry + fh >= (float)y0 &&
-          ry - fh < (float)(y0 + sy) && rz + fh >= 0.0f && rz - fh < (float)Z))
-      continue;
-    const int irx = (int)rx, iry = (int)ry, irz = (int)rz;
+  // pass 0: minimum distance per voxel (32-bit atomicMin on the float bits; distances >= 0);
+  // pass 1: lowest flat id among the candidates whose distance equals that minimum.
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int64_t p = threadIdx.x; p < P; p += kTdfThreads) {
+      const float fx = (points[3 * p] - ox) / pitch;
+      const float fy = (points[3 * p + 1] - oy) / pitch;
+      const float fz = (points[3 * p + 2] - oz) / pitch;
+      const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
+      // neighbourhood vs tile (false for NaN)
+      if (!(rx + fh >= (float)x0 && rx - fh < (float)(x0 + sx) && ry + fh >= (float)y0 &&
+            ry - fh < (float)(y0 + sy) && rz + fh >= 0.0f && rz - fh < (float)Z))
+        continue;
+      const int irx = (int)rx, iry = (int)ry, irz = (int)rz;
 #pragma unroll
-    for (int a = 0; a < ks; ++a) {
-      const int iy = iry + a - h;
-      if (iy < y0 || iy >= y0 + sy) continue;
-      const float dy = fy - (float)iy;
+      for (int a = 0; a < ks; ++a) {
+        const int iy = iry + a - h;
+        if (iy < y0 || iy >= y0 + sy) continue;
+        const float dy = fy - (float)iy;
 #pragma unroll
-      for (int b = 0; b < ks; ++b) {
-        const int ix = irx + b - h;
-        if (ix < x0 || ix >= x0 + sx) continue;
-        const float dx = fx - (float)ix;
-        const float dxy = dx * dx + dy * dy;
+        for (int b = 0; b < ks; ++b) {
+          const int ix = irx + b - h;
+          if (ix < x0 || ix >= x0 + sx) continue;
+          const float dx = fx - (float)ix;
+          const float dxy = dx * dx + dy * dy;
 #pragma unroll
-        for (int c = 0; c < ks; ++c) {
-          const int iz = irz + c - h;
-          if (iz < 0 || iz >= Z) continue;
-          const float dz = fz - (float)iz;
-          const float dist = pitch * sqrtf(dxy + dz * dz);
-          if (dist < trunc) {
-            const int li = ((ix - x0) * sy + (iy - y0)) * Z + iz;
-            const uint32_t db = __float_as_uint(dist);
-            if (db <= s_hi[2 * li + 1]) {
-              const uint32_t id = (uint32_t)(p * K + (a * ks + b) * ks + c);
-              atomicMin(&s_key[li], ((unsigned long long)db << 32) | id);
+          for (int c = 0; c < ks; ++c) {
+            const int iz = irz + c - h;
+            if (iz < 0 || iz >= Z) continue;
+            const float dz = fz - (float)iz;
+            const float dist = pitch * sqrtf(dxy + dz * dz);
+            if (dist < trunc) {
+              const int li = ((ix - x0) * sy + (iy - y0)) * Z + iz;
+              const uint32_t db = __float_as_uint(dist);
+              if (pass == 0) {
+                if (db < s_dist[li]) atomicMin(&s_dist[li], db);
+              } else if (db == s_dist[li]) {
+                atomicMin(&s_id[li], (uint32_t)(p * K + (a * ks + b) * ks + c));
+              }
             }
           }
         }
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
   for (int i = threadIdx.x; i < nvox; i += kTdfThreads) {
-    const unsigned long long k = s_key[i];
     const int iz = i % Z, iy = (i / Z) % sy, ix = i / (Z * sy);
     const int64_t g = ((int64_t)(x0 + ix) * Y + (y0 + iy)) * Z + iz;
-    tdf[g] = __uint_as_float((uint32_t)(k >> 32));
-    const uint32_t lo = (uint32_t)k;
+    tdf[g] = __uint_as_float(s_dist[i]);
+    const uint32_t lo = s_id[i];
     flat[g] = lo == 0xffffffffu ? -1 : (int32_t)lo;
   }
 }
@@ -198,7 +202,7 @@ extern "C" int mf_truncated_distance_function_fwd(const float *points, int64_t P
     SY = std::max(1, cap / Z);
   }
   dim3 grid((X + SX - 1) / SX, (Y + SY - 1) / SY);
-  const size_t lds = (size_t)SX * SY * Z * sizeof(unsigned long long);
+  const size_t lds = (size_t)SX * SY * Z * 2 * sizeof(uint32_t);
   if (ks == 3)
     hipLaunchKernelGGL(k_tdf_fwd<3>, grid, dim3(kTdfThreads), lds, stream, points, P, pitch, ox,
                        oy, oz, X, Y, Z, truncation, ks, SX, SY, tdf, flat);
