@@ -3,4 +3,5 @@
 from .icc_batch import IccScenes
 from .iterative_closest_point_link import IterativeClosestPointLink
 from .iterative_collision_check_link import IterativeCollisionCheckLink
+from .occupancy_registration import OccupancyRegistration, OccupancyRegistrationLink
 from . import singleview_3d

@@ -247,3 +247,42 @@ def test_icc_ragged_multi_scene_batch_vs_oracle(fixtures3):
         np.testing.assert_allclose(gq[lo:lo + n].cpu().numpy(), gq_o, rtol=2e-3, atol=2e-5)
         np.testing.assert_allclose(gt[lo:lo + n].cpu().numpy(), gt_o, rtol=2e-3, atol=2e-4)
         lo += n
+
+
+def test_occupancy_registration_vs_oracle_and_converges():
+    """contrib/occupancy_registration.py:21-60: loss + gradient at the initial pose against the
+    oracle's occupancy_grid_3d forward/backward chained by hand; then the Adam loop lowers it."""
+    rs = np.random.RandomState(0)
+    pitch, dim = 0.01, 16
+    origin = (-0.075, -0.075, -0.075)
+    model = rs.uniform(-0.03, 0.03, (300, 3)).astype(np.float32)
+    T_gt = np.eye(4, dtype=np.float32)
+    T_gt[:3, :3] = mf.synthetic.random_rotation(rs, 0.3)
+    T_gt[:3, 3] = (0.01, -0.005, 0.008)
+    occ = O.occupancy_grid_3d((model @ T_gt[:3, :3].T + T_gt[:3, 3]).astype(np.float32), pitch=pitch,
+                              origin=origin, dims=(dim,) * 3, threshold=1.5)
+    grid_target = np.stack([(occ > 0.3), (occ == 0)]).astype(np.float32)
+    T0 = np.eye(4, dtype=np.float32)
+    reg = mf.contrib.OccupancyRegistration(model, grid_target, pitch=pitch, origin=origin, threshold=1.5,
+                                           transform_init=T0, alpha=0.01)
+    link = reg._optimizer.target
+    loss = link(points_source=reg._points_source, grid_target=reg._grid_target, pitch=pitch, origin=origin, threshold=1.5)
+    loss.backward()
+    # oracle: same composition in NumPy
+    q = np.array([1, 0, 0, 0], np.float32)
+    t = np.zeros(3, np.float32)
+    pw = O.transform_points(model, O.transformation_matrix(q, t))
+    g = O.occupancy_grid_3d(pw, pitch=pitch, origin=origin, dims=(dim,) * 3, threshold=1.5)
+    occd, unocc = grid_target[0], grid_target[1]
+    l_o = (unocc * g).sum() / g.sum() - (occd * g).sum() / occd.sum()
+    np.testing.assert_allclose(float(loss.detach()), l_o, rtol=1e-5, atol=1e-6)
+    gg = unocc / g.sum() - (unocc * g).sum() / g.sum() ** 2 - occd / occd.sum()
+    gp = O.occupancy_grid_3d_backward(gg.astype(np.float32), pw, pitch=pitch, origin=origin, dims=(dim,) * 3, threshold=1.5)
+    np.testing.assert_allclose(link.translation.grad.cpu().numpy(), gp.sum(axis=0), rtol=1e-3, atol=1e-5)
+    link.cleargrads()
+    first = float(loss.detach())
+    T = reg.register(iteration=40)
+    final = float(link(points_source=reg._points_source, grid_target=reg._grid_target, pitch=pitch,
+                       origin=origin, threshold=1.5).detach())
+    assert final < first - 0.05, (first, final)
+    assert T.shape == (4, 4) and np.linalg.norm(T[:3, 3] - T_gt[:3, 3]) < np.linalg.norm(T_gt[:3, 3])
