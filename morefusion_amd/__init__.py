@@ -15,3 +15,4 @@ from . import extra
 from . import optimizers
 from . import contrib
 from . import synthetic
+from . import data_formats

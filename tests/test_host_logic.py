@@ -180,3 +180,46 @@ def test_pspnet_sampled_tail_equals_dense_forward():
     got = net.forward_sampled(x, pix)
     assert got.shape == (2, 32, 50)
     np.testing.assert_allclose(got.detach().numpy(), ref.detach().numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_voxel_grid_wire_format_roundtrip(fixtures3):
+    from morefusion_amd import data_formats as DF
+    g = fixtures3[0]["grid_target"]  # float32 32^3 with 341 occupied voxels
+    idx, val, dims = DF.encode_voxel_grid(g)
+    assert idx.numel() == int((g != 0).sum()) == 341 and dims == (32, 32, 32)
+    # flat index convention i*Y*Z + j*Z + k (collision_based_pose_refinement.py:91-94)
+    i, j, k = np.nonzero(g)
+    np.testing.assert_array_equal(idx.numpy(), i * 32 * 32 + j * 32 + k)
+    np.testing.assert_array_equal(DF.decode_voxel_grid(idx, val, dims).numpy(), g)
+    np.testing.assert_array_equal(DF.decode_voxel_grid(idx, None, dims).numpy(), g != 0)
+    with pytest.raises(ValueError):
+        DF.decode_voxel_grid(torch.tensor([32 ** 3]), None, dims)
+
+
+def test_grid_algebra_eval_and_train_cases():
+    from morefusion_amd import data_formats as DF
+    rs = np.random.RandomState(0)
+    shape = (8, 8, 8)
+    gt, gn, ge = rs.uniform(size=shape), rs.uniform(size=shape), rs.uniform(size=shape)
+    target, nte = DF.grids_for_network(gt, gn, ge)
+    assert target.dtype == bool and nte.dtype == bool
+    np.testing.assert_array_equal(target, gt > 0.5)
+    np.testing.assert_array_equal(nte, ((gn > 0.5) ^ target) | ((ge > 0.5) ^ target))
+    full = (rs.uniform(size=shape) > 0.7).astype(np.int32)
+    ids = rs.randint(0, 4, shape).astype(np.int32)
+    seen = set()
+    for seed in range(40):
+        t2, n2 = DF.grids_for_network(gt, gn, ge, full, ids, train=True, random_state=np.random.RandomState(seed))
+        np.testing.assert_array_equal(t2, target)
+        seen.add(int(n2.sum()))
+    assert len(seen) > 5  # the nine cases really produce different no-entry grids
+    # reference call sequence: choice(ids, size=randint(1, n+1)) then choice(cases)
+    r = np.random.RandomState(3)
+    pick = r.choice(np.array([1, 2, 3]), size=r.randint(1, 4), replace=False)
+    case = r.choice(DF.GRID_CASES)
+    _, n3 = DF.grids_for_network(gt, gn, ge, full, ids, train=True, random_state=np.random.RandomState(3))
+    nf = np.isin(ids, pick) ^ full.astype(bool)
+    if case == "nontarget_full":
+        np.testing.assert_array_equal(n3, nf)
+    _, n4 = DF.grids_for_network(gt, gn, ge, full, ids, train=False)
+    np.testing.assert_array_equal(n4, nte)  # evaluation ignores the *_full grids
