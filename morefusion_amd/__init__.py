@@ -16,3 +16,4 @@ from . import optimizers
 from . import contrib
 from . import synthetic
 from . import data_formats
+from . import serializers
