@@ -17,3 +17,4 @@ from . import contrib
 from . import synthetic
 from . import data_formats
 from . import serializers
+from . import training

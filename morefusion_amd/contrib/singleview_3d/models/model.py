@@ -15,6 +15,8 @@ Differences that are deliberate:
   * CAD models / voxel pitches come from an injectable ``models`` provider because the
     YCB downloads (datasets/ycb_video/models.py:33-42) are unreachable offline.
 """
+import uuid
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -250,17 +252,29 @@ class Model(nn.Module):
 
     @torch.no_grad()
     def evaluate(self, *, class_id, quaternion_true, translation_true, quaternion_pred,
-                 translation_pred):
-        """ADD / ADD-S of the given poses (model.py:325-375), returned as a dict of means."""
+                 translation_pred, per_instance=False):
+        """ADD / ADD-S of the given poses (model.py:325-375), returned as a dict of means.
+
+        ``per_instance=True`` is the reference's evaluation-mode report: one
+        ``{add,add_s,add_or_add_s}/{class_id:04d}/{uuid}`` entry per object, which
+        ``training.PoseEstimationEvaluator`` regroups per class for the AUC."""
         T_true = functions_module.transformation_matrix(
             quaternion_true.float(), translation_true.float()).cpu().numpy()
         T_pred = functions_module.transformation_matrix(quaternion_pred, translation_pred).cpu().numpy()
+        report = {}
         adds, add_ss, mixed = [], [], []
         for i, cid in enumerate(torch.as_tensor(class_id).tolist()):
             add, add_s = metrics.average_distance([self._models.get_pcd(cid)], [T_true[i]], [T_pred[i]])
             adds.append(add[0])
             add_ss.append(add_s[0])
             mixed.append(add_s[0] if cid in CLASS_IDS_SYMMETRIC else add[0])
+            if per_instance:
+                tag = f"{cid:04d}/{uuid.uuid1()}"
+                report[f"add/{tag}"] = float(adds[-1])
+                report[f"add_s/{tag}"] = float(add_ss[-1])
+                report[f"add_or_add_s/{tag}"] = float(mixed[-1])
+        if per_instance:
+            return report
         return dict(add=float(np.mean(adds)), add_s=float(np.mean(add_ss)),
                     add_or_add_s=float(np.mean(mixed)))
 
