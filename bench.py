@@ -53,6 +53,8 @@ def parse():
                          "convolutions / GEMMs of the network (HIP voxel ops, sparse conv3 and ICC stay f32)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the network pass and the ICC refinement back to back on one stream")
+    ap.add_argument("--priority", choices=["none", "net-high", "icc-high", "icc-low"], default="none",
+                    help="HIP stream priorities for the two-stream step (tuning knob)")
     ap.add_argument("--stage-breakdown", action="store_true", default=True)
     return ap.parse_args()
 
@@ -64,6 +66,17 @@ def load_fixtures():
         if os.path.exists(p):
             fx.append(dict(np.load(p)))
     return fx
+
+
+def _low_priority_stream(device):
+    """A HIP stream of the device's least priority (torch only exposes normal/high)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    least, greatest = ctypes.c_int(), ctypes.c_int()
+    assert hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0
+    handle = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithPriority(ctypes.byref(handle), 1, least.value) == 0  # 1 = non-blocking
+    return torch.cuda.ExternalStream(handle.value, device=device)
 
 
 class Workload:
@@ -99,7 +112,10 @@ class Workload:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.gathered = torch.empty((self.world * self.B, 7), device=device)
         self.events = []
-        self.icc_stream = torch.cuda.Stream(device=device)
+        self.icc_stream = torch.cuda.Stream(device=device, priority=-1 if args.priority == "icc-high" else 0)
+        self.net_stream = torch.cuda.Stream(device=device, priority=-1) if args.priority == "net-high" else None
+        if args.priority == "icc-low":
+            self.icc_stream = _low_priority_stream(device)
 
     def _mark(self, name):
         if self._timing:
@@ -138,7 +154,13 @@ class Workload:
             self.icc_stream.wait_stream(main)
             with torch.cuda.stream(self.icc_stream):
                 self._refine()
-            pred = self._network()
+            if self.net_stream is not None:
+                self.net_stream.wait_stream(main)
+                with torch.cuda.stream(self.net_stream):
+                    pred = self._network()
+                main.wait_stream(self.net_stream)
+            else:
+                pred = self._network()
             main.wait_stream(self.icc_stream)
         else:
             pred = self._network()
@@ -379,6 +401,7 @@ def main():
                 "parallelism": f"scene-sharded x{world}, pose all_gather",
                 "streams": "1 (serial)" if args.no_overlap else
                            "2 (ICC refinement overlaps the network pass; stage_ms are the serial stage times)",
+                "stream_priority": args.priority,
             },
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
             "serial_ms_per_step": round(sum(stages.values()), 4),
