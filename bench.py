@@ -269,20 +269,18 @@ def roofline_icc_tdf(wl):
 def cpu_baseline(wl, args):
     """The same workload on the host cores: torch-CPU convolutions/GEMMs + the C port of
     the voxel ops and of the ICC loop (oracle/mf_oracle.c, OpenMP over grids).  Bounded
-    sample: predict on 2 objects (scaled to B), ICC on 10 iterations (scaled to 100)."""
+    sample: one scene's objects through predict and all ICC iterations of one scene on all
+    cores; then 1 object + 10 ICC iterations on ONE thread (scaled) for ``value_1thread``."""
     from oracle import oracle_c as OC
 
     cores = min(os.cpu_count() or 1, 64)  # more threads only add oversubscription noise
-    torch.set_num_threads(cores)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
     torch.backends.cudnn.benchmark = False
     model = Model(n_fg_class=21, with_occupancy=True).eval()
     model.load_state_dict({k: v.cpu() for k, v in wl.model.state_dict().items()})
-    nb = 1
+    nb = min(wl.B, args.objects)  # one whole scene's objects
     inp = {k: v[:nb].cpu() for k, v in wl.inputs.items()}
 
     # route the two HIP ops of predict through the C port for this leg only
-    F = mf.functions
 
     def avg_cpu(values, points, batch_indices, *, batch_size, origin, pitch, dimensions,
                 return_counts=False, **kw):
@@ -302,32 +300,44 @@ def cpu_baseline(wl, args):
              model_mod.functions_module.interpolate_voxel_grid)
     model_mod.functions_module.average_voxelization_3d = avg_cpu
     model_mod.functions_module.interpolate_voxel_grid = interp_cpu
-    try:
+    sc = wl.scenes_np[0]
+    q0 = wl.q0[: len(sc["points"])].cpu().numpy()
+    t0_ = wl.t0[: len(sc["points"])].cpu().numpy()
+    a = (sc["points"], sc["sdf"], sc["pitch"], sc["origin"], sc["grid_target"], sc["grid_nontarget_empty"])
+
+    def timed(threads, iters, n_obj):
+        torch.set_num_threads(threads)
+        OC.set_threads(threads)
+        sub = {k: v[:n_obj] for k, v in inp.items()}
         with torch.no_grad():
-            model.predict(**inp)  # warm-up
+            if threads > 1:
+                model.predict(**{k: v[:1] for k, v in inp.items()})  # warm-up
             t0 = time.perf_counter()
-            model.predict(**inp)
-            t_pred = (time.perf_counter() - t0) * (wl.B / nb)
-    finally:
-        (model_mod.functions_module.average_voxelization_3d,
-         model_mod.functions_module.interpolate_voxel_grid) = saved
-    del F
-    iters = min(10, args.icc_iters)
-    t_icc = 0.0
-    for s, sc in enumerate(wl.scenes_np[:1]):
-        q0 = wl.q0[: len(sc["points"])].cpu().numpy()
-        t0_ = wl.t0[: len(sc["points"])].cpu().numpy()
-        a = (sc["points"], sc["sdf"], sc["pitch"], sc["origin"], sc["grid_target"], sc["grid_nontarget_empty"])
+            model.predict(**sub)
+            t_pred = (time.perf_counter() - t0) * (wl.B / n_obj)
         OC.icc_refine(*a, q0, t0_, n_iter=1, sdf_offset=0.02)
         t0 = time.perf_counter()
         OC.icc_refine(*a, q0, t0_, n_iter=iters, sdf_offset=0.02)
         t_icc = (time.perf_counter() - t0) * (args.icc_iters / iters) * args.scenes_per_gpu
+        return t_pred, t_icc
+
+    iters = args.icc_iters
+    try:
+        t_pred, t_icc = timed(cores, iters, nb)
+        t_pred1, t_icc1 = timed(1, min(10, iters), 1)
+    finally:
+        (model_mod.functions_module.average_voxelization_3d,
+         model_mod.functions_module.interpolate_voxel_grid) = saved
+        torch.set_num_threads(cores)
+        OC.set_threads(cores)
     value = wl.B / (t_pred + t_icc)
     return dict(value=round(value, 3), unit="objects/sec", cores=cores, kind="port",
+                value_1thread=round(wl.B / (t_pred1 + t_icc1), 3),
                 sample=f"predict on {nb} of {wl.B} object(s) (torch-CPU convs + C port of voxelize/"
-                       f"interpolate) scaled x{wl.B / nb:g}; ICC C port (OpenMP) {iters} of "
-                       f"{args.icc_iters} iterations of 1 scene scaled; predict {t_pred:.2f}s + "
-                       f"icc {t_icc:.2f}s per step")
+                       f"interpolate) scaled x{wl.B / nb:g}; ICC C port (OpenMP) all {iters} "
+                       f"iterations of 1 scene; predict {t_pred:.2f}s + icc {t_icc:.2f}s per step. "
+                       f"value_1thread: 1 object + {min(10, iters)} ICC iterations on one thread, scaled "
+                       f"({t_pred1:.2f}s + {t_icc1:.2f}s per step)")
 
 
 def main():

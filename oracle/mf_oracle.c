@@ -28,6 +28,14 @@ static inline float round_away(float x) { return roundf(x); }
 
 int mfo_version(void) { return 1; }
 
+void mfo_set_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
+}
+
 int mfo_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

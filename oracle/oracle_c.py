@@ -38,7 +38,8 @@ def _f(a):
 
 
 def set_threads(n):
-    os.environ["OMP_NUM_THREADS"] = str(n)
+    os.environ["OMP_NUM_THREADS"] = str(n)  # for a not-yet-loaded runtime
+    lib().mfo_set_threads(int(n))
 
 
 def max_threads():
