@@ -228,6 +228,31 @@ int mf_sparse_conv3d_k4s2_fwd(const float *x, const int32_t *counts, const float
 int mf_pack_points_sdf(const float *points, const float *sdf, int64_t n, void *pts4,
                        mfStream_t stream);
 
+/* ---- pre-processing in front of the network ------------------
+ * replaces the per-instance host loop (NumPy + imgviz/cv2) at
+ *   ros/src/morefusion_ros/nodes/singleview_3d_pose_estimation.py:116-176
+ *   morefusion/datasets/rgbd_pose_estimation/base.py:112-137
+ * incl. geometry/pointcloud_from_depth.py:4-26 and geometry/masks_to_bboxes.py:4-38.
+ *   label [H,W] int32 instance image, depth [H,W] float32 metres (NaN = invalid),
+ *   rgb [H,W,3] uint8, instance_ids [n] (n <= 256).
+ * mf_instance_stats: stats [n,6] = {y1, x1, y2, x2 (end-exclusive box of label == id),
+ *   mask pixels, mask pixels with valid depth}; a mask without pixels leaves
+ *   {INT_MAX, INT_MAX, 0, 0, 0, 0}.
+ * mf_instance_crops: per instance the masked crop centerized to S x S:
+ *   rgb_out [n,S,S,3] uint8 (0 outside the mask / padding; 8-bit bilinear resize),
+ *   pcd_out [n,S,S,3] float32 camera-frame points (NaN outside the mask / padding / invalid
+ *   depth; nearest-neighbour resize; back-projection in float64), keep [n] uint8 = mask is
+ *   non-empty and has >= min_valid valid points (the reference skips the others; here
+ *   their outputs are all padding).  Both calls are asynchronous and never synchronise. */
+int mf_instance_stats(const int32_t *label, const float *depth, int H, int W,
+                      const int32_t *instance_ids, int n_inst, int32_t *stats,
+                      mfStream_t stream);
+int mf_instance_crops(const uint8_t *rgb, const float *depth, const int32_t *label, int H,
+                      int W, double fx, double fy, double cx, double cy,
+                      const int32_t *instance_ids, const int32_t *stats, int n_inst, int S,
+                      int min_valid, uint8_t *rgb_out, float *pcd_out, uint8_t *keep,
+                      mfStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

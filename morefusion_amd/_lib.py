@@ -17,6 +17,7 @@ _p = ctypes.c_void_p
 _i = ctypes.c_int
 _i64 = ctypes.c_int64
 _f = ctypes.c_float
+_d = ctypes.c_double
 
 
 class IccBatch(ctypes.Structure):
@@ -57,6 +58,8 @@ _SIGNATURES = {
     "mf_sparse_conv3d_pack_weights": ([_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p], _i),
     "mf_sparse_conv3d_k4s2_fwd": ([_p, _p, _p, _p, _p, _p, _p] + [ctypes.c_int32] * 6 + [_p], _i),
     "mf_pack_points_sdf": ([_p, _p, _i64, _p, _p], _i),
+    "mf_instance_stats": ([_p, _p, _i, _i, _p, _i, _p, _p], _i),
+    "mf_instance_crops": ([_p, _p, _p, _i, _i, _d, _d, _d, _d, _p, _p, _i, _i, _i, _p, _p, _p, _p], _i),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -22,8 +22,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .... import extra
 from .... import functions as functions_module
+from .... import geometry as geometry_module
 from .... import metrics
 from ....models import PSPNetExtractor, ResNet18
 from ....synthetic import CLASS_IDS_SYMMETRIC, CLASS_PITCH
@@ -188,11 +188,8 @@ class Model(nn.Module):
         else:
             pitch = torch.as_tensor(pitch, dtype=torch.float32, device=dev)
         if origin is None:
-            pcd_chw = pcd.float().permute(0, 3, 1, 2)
-            centers = []
-            for i in range(B):
-                centers.append(extra.median(pcd_chw[i].reshape(3, -1)[:, mask[i].reshape(-1)].T, axis=0))
-            origin = torch.stack(centers) - pitch[:, None] * (self._voxel_dim / 2.0 - 0.5)
+            # model.py:202-207 (per-object median of the valid points), batched on device
+            origin = geometry_module.grid_origin(pcd.float(), pitch, dim=self._voxel_dim)
         else:
             origin = torch.as_tensor(origin, dtype=torch.float32, device=dev)
         pix = self._select_points(mask)  # [B,P]; the one host synchronisation

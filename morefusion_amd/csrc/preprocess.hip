@@ -1,0 +1,219 @@
+// Pre-processing in front of the pose network -- gfx950.
+//
+// Reference: a host loop per instance, NumPy + imgviz (cv2 backend) on [H,W] images
+//   ros/src/morefusion_ros/nodes/singleview_3d_pose_estimation.py:116-176
+//   morefusion/datasets/rgbd_pose_estimation/base.py:112-137
+//   geometry/pointcloud_from_depth.py:4-26, geometry/masks_to_bboxes.py:4-38
+// i.e. back-project the whole depth image, then per instance: mask = label == id, skip if
+// fewer than 50 valid points, tight bounding box, crop rgb (masked to 0) and the point
+// cloud (masked to NaN), imgviz.centerize both to S x S (aspect-preserving resize +
+// centred padding; rgb bilinear, points nearest).
+//
+// Here: two launches for ALL instances, nothing on the host.
+//   k_pre_stats  one pass over the label/depth images: per instance bounding box, mask
+//                area and valid-depth count (LDS atomics per workgroup, one global atomic
+//                per touched instance and workgroup).
+//   k_pre_crops  one thread per output pixel and instance: inverts the centerize geometry,
+//                samples rgb with OpenCV's fixed-point bilinear arithmetic and the depth
+//                image with its nearest-neighbour rule, back-projects only the sampled
+//                pixel (float64 like the NumPy expression, stored as float32).
+// HBM-bound and tiny: reads H*W*(4+4+3) bytes once + taps, writes n*S*S*15 bytes.
+#include <limits.h>
+#include <math.h>
+
+#include <algorithm>
+
+#include "mf_common.h"
+
+namespace {
+
+constexpr int kMaxInst = 256;
+constexpr int kStatsThreads = 256;
+
+__global__ void k_pre_init(int32_t *stats, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    stats[6 * i + 0] = INT_MAX;  // y1
+    stats[6 * i + 1] = INT_MAX;  // x1
+    stats[6 * i + 2] = 0;        // y2 (max + 1)
+    stats[6 * i + 3] = 0;        // x2
+    stats[6 * i + 4] = 0;        // mask pixels
+    stats[6 * i + 5] = 0;        // mask pixels with a valid depth
+  }
+}
+
+__global__ __launch_bounds__(kStatsThreads) void k_pre_stats(
+    const int32_t *__restrict__ label, const float *__restrict__ depth, int H, int W,
+    const int32_t *__restrict__ ids, int n, int32_t *__restrict__ stats) {
+  __shared__ int32_t s_id[kMaxInst];
+  __shared__ int32_t s_st[kMaxInst][6];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    s_id[i] = ids[i];
+    s_st[i][0] = INT_MAX; s_st[i][1] = INT_MAX;
+    s_st[i][2] = 0; s_st[i][3] = 0; s_st[i][4] = 0; s_st[i][5] = 0;
+  }
+  __syncthreads();
+  const int64_t npix = (int64_t)H * W;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t l = label[p];
+    const bool valid = !isnan(depth[p]);
+    const int y = (int)(p / W), x = (int)(p % W);
+    for (int i = 0; i < n; ++i) {  // duplicate ids each get their own statistics
+      if (s_id[i] != l) continue;
+      atomicMin(&s_st[i][0], y);
+      atomicMin(&s_st[i][1], x);
+      atomicMax(&s_st[i][2], y + 1);
+      atomicMax(&s_st[i][3], x + 1);
+      atomicAdd(&s_st[i][4], 1);
+      if (valid) atomicAdd(&s_st[i][5], 1);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if (s_st[i][4] == 0) continue;
+    atomicMin(&stats[6 * i + 0], s_st[i][0]);
+    atomicMin(&stats[6 * i + 1], s_st[i][1]);
+    atomicMax(&stats[6 * i + 2], s_st[i][2]);
+    atomicMax(&stats[6 * i + 3], s_st[i][3]);
+    atomicAdd(&stats[6 * i + 4], s_st[i][4]);
+    atomicAdd(&stats[6 * i + 5], s_st[i][5]);
+  }
+}
+
+// cv::resize INTER_LINEAR source index + fixed-point weights for one destination index
+// (modules/imgproc/src/resize.cpp, resizeGeneric_ set-up): f = (float)((d+0.5)*scale-0.5),
+// s = floor(f), f -= s; clamped at both borders; weights = short(rint(w * 2048)).
+__device__ __forceinline__ void linear_tap(int d, double scale, int ssize, int &s0, int &s1,
+                                           int &w0, int &w1, const bool zero_frac_at_border) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (zero_frac_at_border) {  // the x direction resets the fraction, y only clamps the rows
+    if (s < 0) { f = 0.0f; s = 0; }
+    if (s >= ssize - 1) { f = 0.0f; s = ssize - 1; }
+  }
+  w0 = (int)(short)rintf((1.0f - f) * 2048.0f);
+  w1 = (int)(short)rintf(f * 2048.0f);
+  s0 = min(max(s, 0), ssize - 1);
+  s1 = min(max(s + 1, 0), ssize - 1);
+}
+
+__global__ __launch_bounds__(256) void k_pre_crops(
+    const uint8_t *__restrict__ rgb, const float *__restrict__ depth,
+    const int32_t *__restrict__ label, int H, int W, double fx, double fy, double cx, double cy,
+    const int32_t *__restrict__ ids, const int32_t *__restrict__ stats, int S, int min_valid,
+    uint8_t *__restrict__ rgb_out, float *__restrict__ pcd_out, uint8_t *__restrict__ keep) {
+  const int i = blockIdx.y;
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= S * S) return;
+  const int32_t id = ids[i];
+  const int y1 = stats[6 * i + 0], x1 = stats[6 * i + 1];
+  const int sh = stats[6 * i + 2] - y1, sw = stats[6 * i + 3] - x1;
+  const bool ok = stats[6 * i + 4] > 0 && stats[6 * i + 5] >= min_valid;
+  if (o == 0) keep[i] = ok ? 1 : 0;
+  const int oy = o / S, ox = o % S;
+  uint8_t *ro = rgb_out + ((int64_t)i * S * S + o) * 3;
+  float *po = pcd_out + ((int64_t)i * S * S + o) * 3;
+  const float nanv = __builtin_nanf("");
+  ro[0] = 0; ro[1] = 0; ro[2] = 0;
+  po[0] = nanv; po[1] = nanv; po[2] = nanv;
+  if (!ok) return;
+  // imgviz.centerize: scale = min(S/sh, S/sw); resized size = round(size*scale) (half-even)
+  int dh = S, dw = S, ph = 0, pw = 0;
+  const bool identity = (sh == S && sw == S);
+  if (!identity) {
+    const double scale_h = 1.0 * S / sh, scale_w = 1.0 * S / sw;
+    const double scale = scale_h < scale_w ? scale_h : scale_w;
+    dh = (int)rint(sh * scale);
+    dw = (int)rint(sw * scale);
+    if (dh < S) ph = (S - dh) / 2;
+    if (dw < S) pw = (S - dw) / 2;
+  }
+  const int dy = oy - ph, dx = ox - pw;
+  if (dy < 0 || dy >= dh || dx < 0 || dx >= dw || dh <= 0 || dw <= 0) return;  // padding
+  auto masked = [&](int yy, int xx) { return label[(int64_t)(y1 + yy) * W + (x1 + xx)] == id; };
+
+  // ---- points: cv::resize INTER_NEAREST: s = min(floor(d * (1/(dsize/ssize))), ssize-1)
+  {
+    int sy = dy, sx = dx;
+    if (!identity) {
+      const double ify = 1.0 / ((double)dh / sh), ifx = 1.0 / ((double)dw / sw);
+      sy = min((int)floor(dy * ify), sh - 1);
+      sx = min((int)floor(dx * ifx), sw - 1);
+    }
+    if (masked(sy, sx)) {
+      const int r = y1 + sy, c = x1 + sx;
+      const float z = depth[(int64_t)r * W + c];
+      if (!isnan(z)) {  // pointcloud_from_depth.py:17-21, float64 arithmetic
+        po[0] = (float)(((double)z * ((double)c - cx)) / fx);
+        po[1] = (float)(((double)z * ((double)r - cy)) / fy);
+        po[2] = z;
+      }
+    }
+  }
+  // ---- rgb: masked crop, cv::resize INTER_LINEAR for 8-bit (2x2 box for an exact 2:1)
+  auto pix = [&](int yy, int xx, int c) -> int {
+    return masked(yy, xx) ? (int)rgb[((int64_t)(y1 + yy) * W + (x1 + xx)) * 3 + c] : 0;
+  };
+  if (identity) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ro[c] = (uint8_t)pix(dy, dx, c);
+    return;
+  }
+  const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
+  const bool area2 = fabs(scale_x - 2.0) < 2.220446049250313e-16 &&
+                     fabs(scale_y - 2.0) < 2.220446049250313e-16;
+  if (area2) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      ro[c] = (uint8_t)((pix(2 * dy, 2 * dx, c) + pix(2 * dy, 2 * dx + 1, c) +
+                         pix(2 * dy + 1, 2 * dx, c) + pix(2 * dy + 1, 2 * dx + 1, c) + 2) >> 2);
+    return;
+  }
+  int xa, xb, a0, a1, ya, yb, b0, b1;
+  linear_tap(dx, scale_x, sw, xa, xb, a0, a1, true);
+  linear_tap(dy, scale_y, sh, ya, yb, b0, b1, false);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int r0 = pix(ya, xa, c) * a0 + pix(ya, xb, c) * a1;  // horizontal pass, row ya
+    const int r1 = pix(yb, xa, c) * a0 + pix(yb, xb, c) * a1;  // row yb
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    ro[c] = (uint8_t)min(max(v, 0), 255);
+  }
+}
+
+}  // namespace
+
+extern "C" int mf_instance_stats(const int32_t *label, const float *depth, int H, int W,
+                                 const int32_t *instance_ids, int n_inst, int32_t *stats,
+                                 mfStream_t stream) {
+  if (n_inst <= 0) return 0;
+  if (n_inst > kMaxInst || H <= 0 || W <= 0) {
+    mf::set_last_error(hipErrorInvalidValue, "mf_instance_stats: 1..256 instances, H,W > 0");
+    return -(int)hipErrorInvalidValue;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_pre_init, dim3((n_inst + 63) / 64), dim3(64), 0, s, stats, n_inst);
+  const int64_t npix = (int64_t)H * W;
+  const int blocks = (int)std::min<int64_t>((npix + kStatsThreads * 4 - 1) / (kStatsThreads * 4), 1024);
+  hipLaunchKernelGGL(k_pre_stats, dim3(blocks), dim3(kStatsThreads), 0, s, label, depth, H, W,
+                     instance_ids, n_inst, stats);
+  return mf::check_launch("mf_instance_stats");
+}
+
+extern "C" int mf_instance_crops(const uint8_t *rgb, const float *depth, const int32_t *label,
+                                 int H, int W, double fx, double fy, double cx, double cy,
+                                 const int32_t *instance_ids, const int32_t *stats, int n_inst,
+                                 int S, int min_valid, uint8_t *rgb_out, float *pcd_out,
+                                 uint8_t *keep, mfStream_t stream) {
+  if (n_inst <= 0) return 0;
+  if (S <= 0 || H <= 0 || W <= 0) {
+    mf::set_last_error(hipErrorInvalidValue, "mf_instance_crops: S, H, W > 0");
+    return -(int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(k_pre_crops, dim3((S * S + 255) / 256, n_inst), dim3(256), 0,
+                     (hipStream_t)stream, rgb, depth, label, H, W, fx, fy, cx, cy, instance_ids,
+                     stats, S, min_valid, rgb_out, pcd_out, keep);
+  return mf::check_launch("mf_instance_crops");
+}

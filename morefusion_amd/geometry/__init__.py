@@ -5,3 +5,4 @@ from .masks_to_bboxes import masks_to_bboxes
 from .nn import nn
 from .pointcloud_from_depth import pointcloud_from_depth
 from .quaternion_from_matrix import quaternion_from_matrix, translation_from_matrix
+from .instance_crops import grid_origin, instance_crops

@@ -214,3 +214,30 @@ def make_singleview_batch(batch_size=1, seed=0, image_size=256, dim=32):
         quaternion_true=np.stack(out["quaternion_true"]),
         translation_true=np.stack(out["translation_true"]),
     )
+
+
+def make_rgbd_frame(seed=0, height=480, width=640):
+    """A synthetic RGB-D frame + instance image for the pre-processing row: several instances
+    whose bounding boxes exercise every branch of the crop/centerize geometry (wide, tall,
+    small -> up-scaling, exactly 256 x 256, exact 2:1 reduction, too few valid points, absent).
+    Returns dict(rgb u8 [H,W,3], depth f32 [H,W] with NaN holes, K [3,3] float64,
+    label i32 [H,W], instance_ids i32 [n])."""
+    rs = np.random.RandomState(seed)
+    rgb = rs.randint(0, 256, (height, width, 3)).astype(np.uint8)
+    depth = rs.uniform(0.5, 1.5, (height, width)).astype(np.float32)
+    depth[rs.uniform(size=depth.shape) < 0.1] = np.nan
+    label = np.zeros((height, width), np.int32)
+    yy, xx = np.mgrid[:height, :width]
+    label[(yy >= 10) & (yy < 110) & (xx >= 20) & (xx < 330)] = 3                      # wide box
+    label[((yy - 200) / 37.0) ** 2 + ((xx - 60) / 21.0) ** 2 <= 1.0] = 5            # small ellipse
+    label[(yy >= 120) & (yy < 376) & (xx >= 100) & (xx < 356)] = 7                   # 256 x 256
+    label[(yy >= 170) & (yy < 470) & (xx >= 360) & (xx < 400) & ((yy + xx) % 3 > 0)] = 11  # tall, holey
+    label[(yy >= 2) & (yy < 8) & (xx >= 400) & (xx < 406)] = 13                       # 36 px: skipped
+    label[(yy >= 380) & (yy < 470) & (xx >= 410) & (xx < 630)] = 17
+    depth[label == 17] = np.nan                                                       # no valid depth
+    if height >= 480 and width >= 640:
+        label[:] = np.where((yy >= 100) & (yy < 400) & (xx >= 64) & (xx < 576) & (label == 0)
+                            & ((yy // 50 + xx // 64) % 2 == 0), 19, label)           # 512 x 300 -> 2:1
+    K = np.array([[619.4, 0, width / 2 - 0.3], [0, 618.9, height / 2 + 0.7], [0, 0, 1]])
+    ids = np.array([3, 5, 7, 11, 13, 17, 19, 23], np.int32)                            # 23 is absent
+    return dict(rgb=rgb, depth=depth, K=K, label=label, instance_ids=ids)

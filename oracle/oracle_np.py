@@ -761,3 +761,125 @@ def icc_refine(points, sdf, pitch, origin, grid_target, grid_nontarget_empty, tr
         losses.append(loss)
         opt.update([gq, gt])
     return q, t, np.array(losses), np.stack(traj)
+
+
+# --------------------------------------------------------------------------
+# pre-processing in front of the network
+# --------------------------------------------------------------------------
+def pointcloud_from_depth(depth, fx, fy, cx, cy):
+    """geometry/pointcloud_from_depth.py:4-21 (depth_type "z"); float64 result for a
+    float32 depth because ``c - cx`` is float64.  Pinned by tests/golden/ref_preprocess.npz."""
+    rows, cols = depth.shape
+    c, r = np.meshgrid(np.arange(cols), np.arange(rows), sparse=True)
+    valid = ~np.isnan(depth)
+    z = np.where(valid, depth, np.nan)
+    x = np.where(valid, z * (c - cx) / fx, np.nan)
+    y = np.where(valid, z * (r - cy) / fy, np.nan)
+    return np.dstack((x, y, z))
+
+
+def mask_to_bbox(mask):
+    """geometry/masks_to_bboxes.py:28-34 for one mask: (y1, x1, y2, x2), end-exclusive."""
+    where = np.argwhere(mask)
+    if len(where) == 0:
+        return np.zeros(4, dtype=np.int64)
+    (y1, x1), (y2, x2) = where.min(0), where.max(0) + 1
+    return np.array([y1, x1, y2, x2])
+
+
+def cv2_resize_nearest(src, height, width):
+    """OpenCV ``cv::resize(..., INTER_NEAREST)`` (opencv-python, unpinned in
+    requirements.txt:13; absent here -> restated from imgproc/resize.cpp ``resizeNN``:
+    ``sx = min(floor(x * (1 / (dst_w / src_w))), src_w - 1)``).  **parity unpinned**."""
+    sh, sw = src.shape[:2]
+    ify, ifx = 1.0 / (float(height) / sh), 1.0 / (float(width) / sw)
+    sy = np.minimum(np.floor(np.arange(height) * ify).astype(np.int64), sh - 1)
+    sx = np.minimum(np.floor(np.arange(width) * ifx).astype(np.int64), sw - 1)
+    return src[sy][:, sx]
+
+
+def _cv2_linear_taps(n_dst, scale, n_src, zero_frac_at_border):
+    d = np.arange(n_dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    if zero_frac_at_border:
+        lo, hi = s < 0, s >= n_src - 1
+        f = np.where(lo | hi, f32(0), f)
+        s = np.where(lo, 0, np.where(hi, n_src - 1, s))
+    w0 = np.rint((f32(1) - f) * f32(2048)).astype(np.int64)
+    w1 = np.rint(f * f32(2048)).astype(np.int64)
+    return np.clip(s, 0, n_src - 1), np.clip(s + 1, 0, n_src - 1), w0, w1
+
+
+def cv2_resize_linear_u8(src, height, width):
+    """OpenCV ``cv::resize(..., INTER_LINEAR)`` for 8-bit images, native (non-IPP) path of
+    imgproc/resize.cpp: 11-bit fixed-point taps (``resizeGeneric_`` set-up, HResizeLinear,
+    VResizeLinear ``((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2 >> 2``) and the 2x2 box
+    average for an exact 2:1 reduction.  **parity unpinned** (cv2 absent; IPP builds of
+    opencv-python may differ by one grey level)."""
+    sh, sw = src.shape[:2]
+    scale_x, scale_y = 1.0 / (float(width) / sw), 1.0 / (float(height) / sh)
+    img = src.astype(np.int64)
+    eps = np.finfo(np.float64).eps
+    if abs(scale_x - 2.0) < eps and abs(scale_y - 2.0) < eps:
+        out = (img[0::2, 0::2] + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
+        return out[:height, :width].astype(np.uint8)
+    xa, xb, a0, a1 = _cv2_linear_taps(width, scale_x, sw, True)
+    ya, yb, b0, b1 = _cv2_linear_taps(height, scale_y, sh, False)
+    sel = (slice(None), slice(None)) + (None,) * (img.ndim - 2)
+    rows = img[:, xa] * a0[None, :][sel] + img[:, xb] * a1[None, :][sel]   # [sh, width, ...]
+    r0, r1 = rows[ya], rows[yb]
+    b0e, b1e = b0[:, None][sel], b1[:, None][sel]
+    out = (((b0e * (r0 >> 4)) >> 16) + ((b1e * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def centerize(src, shape, cval=None, interpolation="linear"):
+    """imgviz.centerize (imgviz>=0.10, requirements.txt:8; absent here): aspect-preserving
+    resize to fit ``shape`` then centred padding with ``cval``.  **parity unpinned**."""
+    if src.shape[:2] == tuple(shape[:2]):
+        return src
+    dst = np.zeros(tuple(shape[:2]) + src.shape[2:], dtype=src.dtype)
+    if cval is not None:
+        dst[:, :] = cval
+    sh, sw = src.shape[:2]
+    scale = min(1.0 * shape[0] / sh, 1.0 * shape[1] / sw)
+    dh, dw = int(round(sh * scale)), int(round(sw * scale))
+    if interpolation == "nearest":
+        res = cv2_resize_nearest(src, dh, dw)
+    else:
+        res = cv2_resize_linear_u8(src, dh, dw)
+    ph = (shape[0] - dh) // 2 if dh < shape[0] else 0
+    pw = (shape[1] - dw) // 2 if dw < shape[1] else 0
+    dst[ph:ph + dh, pw:pw + dw] = res
+    return dst
+
+
+def instance_crops(rgb, depth, K, label, instance_ids, image_size=256, min_valid=50):
+    """ros/src/morefusion_ros/nodes/singleview_3d_pose_estimation.py:116-126,158-176 (same
+    steps as datasets/rgbd_pose_estimation/base.py:112-137): per instance masked rgb / point
+    cloud crops centerized to ``image_size``.  Instances the reference skips (< ``min_valid``
+    valid points) come back as pure padding with ``keep`` False."""
+    pcd = pointcloud_from_depth(depth, K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+    nanmask = np.isnan(pcd).any(axis=2)
+    S = image_size
+    n = len(instance_ids)
+    rgb_out = np.zeros((n, S, S, 3), np.uint8)
+    pcd_out = np.full((n, S, S, 3), np.nan, np.float64)
+    keep = np.zeros(n, bool)
+    bboxes = np.zeros((n, 4), np.int64)
+    for i, ins_id in enumerate(instance_ids):
+        mask = label == ins_id
+        bboxes[i] = mask_to_bbox(mask)
+        if (~nanmask & mask).sum() < min_valid:
+            continue
+        y1, x1, y2, x2 = bboxes[i]
+        rgb_ins = rgb[y1:y2, x1:x2].copy()
+        rgb_ins[~mask[y1:y2, x1:x2]] = 0
+        rgb_out[i] = centerize(rgb_ins, (S, S), cval=0)
+        pcd_ins = pcd[y1:y2, x1:x2].copy()
+        pcd_ins[~mask[y1:y2, x1:x2]] = np.nan
+        pcd_out[i] = centerize(pcd_ins, (S, S), cval=np.nan, interpolation="nearest")
+        keep[i] = True
+    return rgb_out, pcd_out, keep, bboxes

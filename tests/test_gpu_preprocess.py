@@ -1,0 +1,79 @@
+"""Pre-processing row on the MI355X through the C-ABI: per-instance statistics,
+masked crops and centerize geometry, bit-exact against the oracle (uint8 rgb, float32 points,
+NaN pattern), then frame -> crops -> grid placement -> Model.predict end to end."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+
+import morefusion_amd as mf  # noqa: E402
+from morefusion_amd import geometry, synthetic  # noqa: E402
+
+
+def _run(frame, **kw):
+    return geometry.instance_crops(
+        torch.as_tensor(frame["rgb"]).cuda(), torch.as_tensor(frame["depth"]).cuda(), frame["K"],
+        torch.as_tensor(frame["label"]).cuda(), frame["instance_ids"], **kw)
+
+
+@pytest.mark.parametrize("seed,hw", [(0, (480, 640)), (1, (480, 640)), (2, (300, 420))])
+def test_instance_crops_bit_exact_vs_oracle(seed, hw):
+    f = synthetic.make_rgbd_frame(seed, *hw)
+    out = _run(f)
+    rgb, pcd, keep, bbox = O.instance_crops(f["rgb"], f["depth"], f["K"], f["label"], f["instance_ids"])
+    np.testing.assert_array_equal(out["keep"].cpu().numpy(), keep)
+    np.testing.assert_array_equal(out["bbox"].cpu().numpy(), bbox)
+    valid = ~np.isnan(f["depth"])
+    np.testing.assert_array_equal(out["n_valid"].cpu().numpy(),
+                                  [((f["label"] == i) & valid).sum() for i in f["instance_ids"]])
+    np.testing.assert_array_equal(out["rgb"].cpu().numpy(), rgb)
+    got = out["pcd"].cpu().numpy()
+    assert got.dtype == np.float32
+    np.testing.assert_array_equal(got, pcd.astype(np.float32))  # NaN == NaN positions included
+
+
+def test_instance_crops_other_size_threshold_and_errors():
+    f = synthetic.make_rgbd_frame(3)
+    out = _run(f, image_size=64, min_valid=20)
+    rgb, pcd, keep, _ = O.instance_crops(f["rgb"], f["depth"], f["K"], f["label"], f["instance_ids"],
+                                         image_size=64, min_valid=20)
+    assert keep[4]  # the 36-pixel instance passes a threshold of 20 valid points
+    np.testing.assert_array_equal(out["keep"].cpu().numpy(), keep)
+    np.testing.assert_array_equal(out["rgb"].cpu().numpy(), rgb)
+    np.testing.assert_array_equal(out["pcd"].cpu().numpy(), pcd.astype(np.float32))
+    none = geometry.instance_crops(torch.as_tensor(f["rgb"]).cuda(), torch.as_tensor(f["depth"]).cuda(),
+                                   f["K"], torch.as_tensor(f["label"]).cuda(), np.zeros(0, np.int32))
+    assert none["rgb"].shape == (0, 256, 256, 3) and none["keep"].numel() == 0
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        geometry.instance_crops(torch.as_tensor(f["rgb"]), torch.as_tensor(f["depth"]), f["K"],
+                                torch.as_tensor(f["label"]), f["instance_ids"])
+    with pytest.raises(TypeError):
+        geometry.instance_crops(torch.as_tensor(f["rgb"]).cuda().float(), torch.as_tensor(f["depth"]).cuda(),
+                                f["K"], torch.as_tensor(f["label"]).cuda(), f["instance_ids"])
+
+
+def test_frame_to_poses_end_to_end():
+    from morefusion_amd.contrib.singleview_3d.models import Model
+    f = synthetic.make_rgbd_frame(0)
+    out = _run(f)
+    keep = out["keep"]
+    class_id = torch.tensor([2, 5, 9, 12, 15, 16, 19, 21], dtype=torch.int32)[keep.cpu()]
+    rgb, pcd = out["rgb"][keep], out["pcd"][keep]
+    pitch = torch.tensor([synthetic.CLASS_PITCH[int(c)] for c in class_id], dtype=torch.float32).cuda()
+    origin = geometry.grid_origin(pcd, pitch, dim=32)
+    ref = np.stack([np.nanmedian(p, axis=(0, 1)) for p in pcd.cpu().numpy()]) - 15.5 * pitch.cpu().numpy()[:, None]
+    np.testing.assert_allclose(origin.cpu().numpy(), ref, rtol=0, atol=1e-6)
+    torch.manual_seed(0)
+    model = Model(n_fg_class=21, with_occupancy=True).cuda().eval()
+    grid = torch.zeros((int(keep.sum()), 32, 32, 32), dtype=torch.bool, device="cuda")
+    with torch.no_grad():
+        q, t, c = model.predict(class_id=class_id.cuda(), rgb=rgb, pcd=pcd, pitch=pitch, origin=origin,
+                                grid_nontarget_empty=grid)
+        q2, t2, c2 = model.predict(class_id=class_id.cuda(), rgb=rgb, pcd=pcd, grid_nontarget_empty=grid)
+    assert q.shape[0] == int(keep.sum()) and torch.isfinite(q).all() and torch.isfinite(t).all()
+    # origin=None places the grids with the same batched median
+    for a, b in ((q, q2), (t, t2), (c, c2)):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
