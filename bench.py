@@ -53,6 +53,8 @@ def parse():
                          "convolutions / GEMMs of the network (HIP voxel ops, sparse conv3 and ICC stay f32)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the network pass and the ICC refinement back to back on one stream")
+    ap.add_argument("--channels-last", action="store_true",
+                    help="keep the 2-D backbone (ResNet18 + PSPNet) in NHWC memory format")
     ap.add_argument("--priority", choices=["none", "net-high", "icc-high", "icc-low"], default="none",
                     help="HIP stream priorities for the two-stream step (tuning knob)")
     ap.add_argument("--stage-breakdown", action="store_true", default=True)
@@ -89,6 +91,9 @@ class Workload:
         self.B = S * Nobj
         torch.manual_seed(0)
         self.model = Model(n_fg_class=21, with_occupancy=True).to(device).eval()
+        if args.channels_last:
+            self.model.resnet_extractor.to(memory_format=torch.channels_last)
+            self.model.pspnet_extractor.to(memory_format=torch.channels_last)
         batch = mf.synthetic.make_singleview_batch(self.B, seed=1000 * rank)
         to = lambda x: torch.as_tensor(x).to(device)  # noqa: E731
         self.inputs = dict(class_id=to(batch["class_id"]), rgb=to(batch["rgb"]), pcd=to(batch["pcd"]),
@@ -411,7 +416,8 @@ def main():
                 "parallelism": f"scene-sharded x{world}, pose all_gather",
                 "streams": "1 (serial)" if args.no_overlap else
                            "2 (ICC refinement overlaps the network pass; stage_ms are the serial stage times)",
-                "stream_priority": args.priority,
+                "stream_priority": args.priority, "backbone_memory_format":
+                    "channels_last" if args.channels_last else "contiguous",
             },
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
             "serial_ms_per_step": round(sum(stages.values()), 4),
