@@ -74,6 +74,8 @@ def test_frame_to_poses_end_to_end():
                                 grid_nontarget_empty=grid)
         q2, t2, c2 = model.predict(class_id=class_id.cuda(), rgb=rgb, pcd=pcd, grid_nontarget_empty=grid)
     assert q.shape[0] == int(keep.sum()) and torch.isfinite(q).all() and torch.isfinite(t).all()
-    # origin=None places the grids with the same batched median
+    # origin=None places the grids with the same batched median.  The two calls may run
+    # different MIOpen solutions for the stock 2-D convolutions (first call of a shape vs the
+    # cached choice), so this is a float32-convolution tolerance, not bit equality.
     for a, b in ((q, q2), (t, t2), (c, c2)):
-        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3)
