@@ -201,6 +201,11 @@ int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float *adam_m,
 int mf_icc_launch_tdf(const mfIccBatch *batch, const float *q, const float *t, void *ws,
                       mfStream_t stream);
 
+/* Tuning aid: with MF_ICC_DEBUG=32 in the environment k_icc_tdf / k_icc_accum record
+ * wall_clock64() phase stamps per workgroup; this copies the first n 64-bit words of that
+ * table to host memory (synchronous).  Not used by the product path. */
+int mf_icc_debug_stamps(unsigned long long *host_out, int n);
+
 /* ---- A13 conv3 of the pose network on sparse voxelized features -----------------
  * replaces the dense cuDNN Convolution3D(Cs+16 -> Cout, k=4, s=2, pad=1) at
  *   morefusion/contrib/singleview_3d/models/model.py:73,128

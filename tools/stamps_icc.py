@@ -7,9 +7,8 @@ from bench import Workload, parse
 args = parse(); wl = Workload(args, 0, torch.device("cuda", 0))
 loss, gq, gt = wl.icc.loss_grad(wl.q0, wl.t0)   # one iteration (eager launches)
 torch.cuda.synchronize()
-L = ctypes.CDLL(mf._lib.SO_PATH)
 buf = np.zeros(4096 * 8, np.uint64)
-L.mf_icc_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
+mf._lib.lib().mf_icc_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
 st = buf.reshape(4096, 8)[:512].astype(np.int64)
 t0 = st[:, 0].min()
 d = lambda a, b: (st[:, b] - st[:, a]) / 100.0   # wall_clock64 = 100 MHz -> us
