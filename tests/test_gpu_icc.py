@@ -286,3 +286,39 @@ def test_occupancy_registration_vs_oracle_and_converges():
                        origin=origin, threshold=1.5).detach())
     assert final < first - 0.05, (first, final)
     assert T.shape == (4, 4) and np.linalg.norm(T[:3, 3] - T_gt[:3, 3]) < np.linalg.norm(T_gt[:3, 3])
+
+
+def test_reference_driver_loop_runs_under_the_chainer_facade(scene8):
+    """The loop body of check_iterative_collision_check_link.py:29-79, in its own idiom
+    (cuda.to_gpu, chainer.optimizers.Adam, Variable.array, cuda.to_cpu), over the façade."""
+    import morefusion_amd as morefusion
+    from morefusion_amd import chainer_compat as chainer
+    from morefusion_amd.chainer_compat import cuda
+
+    n = 3
+    data = {k: v[:n] for k, v in scene8.items()}
+    points = [cuda.to_gpu(p).float() for p in data["points"]]
+    sdf = [cuda.to_gpu(s).float() for s in data["sdf"]]
+    pitch = cuda.to_gpu(np.asarray(data["pitch"], np.float32))
+    origin = cuda.to_gpu(np.asarray(data["origin"], np.float32))
+    grid_target = cuda.to_gpu(np.asarray(data["grid_target"], np.float32))
+    grid_nontarget_empty = cuda.to_gpu(np.asarray(data["grid_nontarget_empty"], np.float32))
+
+    link = morefusion.contrib.IterativeCollisionCheckLink(data["transform_init"], sdf_offset=0.02)
+    link.to_gpu()
+    optimizer = chainer.optimizers.Adam(alpha=0.01)
+    optimizer.setup(link)
+    link.translation.update_rule.hyperparam.alpha *= 0.1
+    losses = []
+    for i in range(5):
+        transform = morefusion.functions.transformation_matrix(link.quaternion, link.translation)
+        transform = cuda.to_cpu(transform.array)
+        assert transform.shape == (n, 4, 4) and isinstance(transform, np.ndarray)
+        loss = link(points, sdf, pitch, origin, grid_target, grid_nontarget_empty)
+        loss.backward()
+        optimizer.update()
+        link.zerograds()
+        losses.append(float(cuda.to_cpu(loss.array)))
+    ref = mf.contrib.IterativeCollisionCheckLink(scene8["transform_init"][:n], sdf_offset=0.02).to_gpu()
+    losses_ref, _ = ref.refine(*to_dev(scene_args(scene8, n)), n_iter=5, return_history=True)
+    np.testing.assert_allclose(losses, losses_ref.cpu().numpy(), rtol=1e-4, atol=1e-6)

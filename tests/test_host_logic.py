@@ -261,3 +261,32 @@ def test_chainer_npz_roundtrip_and_key_convention(tmp_path):
     c = Model(n_fg_class=20, with_occupancy=True)
     with pytest.raises(ValueError):
         S.load_npz(f, c)
+
+
+def test_chainer_compat_facade_host_side():
+    from morefusion_amd import chainer_compat as chainer
+    from morefusion_amd.chainer_compat import cuda
+    # concat_examples: dicts / tuples / padding, NumPy out when no device is given
+    ex = [dict(class_id=np.int32(2), pcd=np.zeros((4, 4, 3), np.float32), rgb=np.ones((4, 4, 3), np.uint8)),
+          dict(class_id=np.int32(5), pcd=np.ones((4, 4, 3), np.float32), rgb=np.zeros((4, 4, 3), np.uint8))]
+    out = chainer.dataset.concat_examples(ex, device=-1)
+    assert out["class_id"].tolist() == [2, 5] and out["pcd"].shape == (2, 4, 4, 3) and out["rgb"].dtype == np.uint8
+    a, b = chainer.dataset.concat_examples([(np.arange(3), np.float32(1)), (np.arange(2), np.float32(2))],
+                                           padding=(-1, None))
+    np.testing.assert_array_equal(a, [[0, 1, 2], [0, 1, -1]])
+    np.testing.assert_array_equal(b, [1, 2])
+    # Variable.array, to_cpu, config switches
+    x = torch.ones(3, requires_grad=True) * 2
+    assert not x.array.requires_grad and isinstance(cuda.to_cpu(x), np.ndarray)
+    assert cuda.get_array_module(x) is torch and cuda.get_array_module(np.zeros(1)) is np
+    with chainer.using_config("train", False):
+        assert chainer.config.train is False
+    assert chainer.config.train is True
+    with chainer.using_config("enable_backprop", False), chainer.no_backprop_mode():
+        assert not torch.is_grad_enabled()
+    assert torch.is_grad_enabled()
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            cuda.to_gpu(np.zeros(3))
+    assert chainer.optimizers.Adam(alpha=0.01).hyperparam.alpha == 0.01
+    assert callable(chainer.serializers.load_npz)
