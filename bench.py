@@ -271,6 +271,29 @@ def roofline_icc_tdf(wl):
                 note="L2-resident working set; latency/LDS-atomic bound (DESIGN.md 4)")
 
 
+def accuracy(wl):
+    """The accuracy half of BASELINE's metric, as far as it is measurable offline: ADD of the
+    ICC-refined poses to the known ground truth of the synthetic objects of this rank's first
+    scene (the three recorded fixtures carry no ground truth), before and after refinement,
+    with the YCB-Video AUC (<= 0.1 m).  Un-timed; uses the poses the timed steps produced."""
+    from morefusion_amd.metrics import average_distance, ycb_video_add_auc
+    sc = wl.scenes_np[0]
+    idx = [i for i, T in enumerate(sc["transform_gt"]) if T is not None]
+    if not idx:
+        return None
+    T_ref = mf.functions.transformation_matrix(wl.q, wl.t).cpu().numpy().astype(np.float64)
+    pts = [sc["points"][i].astype(np.float64) for i in idx]
+    gt = [np.asarray(sc["transform_gt"][i], np.float64) for i in idx]
+    add0, _ = average_distance(pts, gt, [sc["transform_init"][i].astype(np.float64) for i in idx])
+    add1, _ = average_distance(pts, gt, [T_ref[i] for i in idx])
+    return dict(objects_with_ground_truth=len(idx),
+                add_init_mm=round(float(add0.mean()) * 1e3, 3), add_refined_mm=round(float(add1.mean()) * 1e3, 3),
+                add_auc_init=round(float(ycb_video_add_auc(add0, max_value=0.1)), 4),
+                add_auc_refined=round(float(ycb_video_add_auc(add1, max_value=0.1)), 4),
+                note="ICC refinement of synthetic perturbed-GT poses; network weights are random, so "
+                     "network-pose accuracy is not measurable offline")
+
+
 def cpu_baseline(wl, args):
     """The same workload on the host cores: torch-CPU convolutions/GEMMs + the C port of
     the voxel ops and of the ICC loop (oracle/mf_oracle.c, OpenMP over grids).  Bounded
@@ -424,6 +447,7 @@ def main():
         }
         out["roofline"] = roofline_icc_tdf(wl)
         out["roofline_voxelize"] = roofline_voxelize(wl)
+        out["accuracy"] = accuracy(wl)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args)
         print(json.dumps(out))
