@@ -322,3 +322,36 @@ def test_reference_driver_loop_runs_under_the_chainer_facade(scene8):
     ref = mf.contrib.IterativeCollisionCheckLink(scene8["transform_init"][:n], sdf_offset=0.02).to_gpu()
     losses_ref, _ = ref.refine(*to_dev(scene_args(scene8, n)), n_iter=5, return_history=True)
     np.testing.assert_allclose(losses, losses_ref.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_icc_refine_teacher_forced_vs_committed_golden(fixtures3):
+    """Same per-iteration pin as above, against the COMMITTED trajectory of the three recorded
+    fixtures (tests/golden/oracle_icc_icp_trajectories.npz, oracle/gen_golden_icc.py) instead of
+    an oracle run at test time."""
+    from conftest import golden
+    g = golden("oracle_icc_icp_trajectories.npz")
+    sc = mf.synthetic.make_icc_scene(3, seed=0, fixtures=fixtures3)
+    args = scene_args(sc)
+    link = mf.contrib.IterativeCollisionCheckLink(sc["transform_init"], sdf_offset=0.02).to_gpu()
+    scenes = link._pack(*to_dev(args))
+    traj, adam, losses = g["icc_traj"], g["icc_adam"], g["icc_losses"]
+    worst = 0.0
+    for k in range(99):
+        q, t = dev(traj[k, :, :4]), dev(traj[k, :, 4:])
+        m, v = dev(adam[k, 0]), dev(adam[k, 1])
+        loss = torch.empty(1, 1).cuda()
+        scenes.refine(q, t, m, v, 1, step0=k, alpha_q=0.01, alpha_t=0.001, losses=loss)
+        np.testing.assert_allclose(float(loss), losses[k], rtol=2e-5, atol=2e-6, err_msg=f"iter {k}")
+        worst = max(worst, np.abs(torch.cat([q, t], 1).cpu().numpy() - traj[k + 1]).max())
+    assert worst < 1e-5, worst
+    # and the ICP driver's committed iterates: loss + gradient of the fused kernel
+    f = fixtures3[2]
+    target = dev((np.argwhere(f["grid_target"] >= 0.5) * f["pitch"] + f["origin"]).astype(np.float32))
+    source = dev(f["pcd_cad"].astype(np.float32))
+    for k in (0, 7, 29):
+        icp = mf.contrib.IterativeClosestPointLink(np.eye(4, dtype=np.float32)).to_gpu()
+        with torch.no_grad():
+            icp.quaternion.copy_(dev(g["icp_traj"][k, :4]))
+            icp.translation.copy_(dev(g["icp_traj"][k, 4:]))
+        loss = icp(source, target)
+        np.testing.assert_allclose(float(loss.detach()), g["icp_losses"][k], rtol=2e-5)

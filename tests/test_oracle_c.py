@@ -144,3 +144,54 @@ def test_icc_refinement_is_chaotic_between_faithful_restatements(scene):
     np.testing.assert_allclose(lc[:4], ln[:4], rtol=1e-5, atol=1e-6)
     assert ln[-1] < ln[0] and lc[-1] < lc[0]
     assert abs(lc[-1] - ln[-1]) < 0.02
+
+
+# ---- A17 / A18: stored trajectories of the restatement (oracle/gen_golden_icc.py) ----------
+def _fixture_scene(fixtures3):
+    from morefusion_amd import synthetic
+    return synthetic.make_icc_scene(3, seed=0, fixtures=fixtures3)
+
+
+def test_icc_golden_trajectory_teacher_forced(fixtures3):
+    """Every stored iterate (pose + Adam state) of the 100-iteration ICC run on the three recorded
+    fixtures: the C restatement re-derives loss and next iterate; the NumPy restatement is
+    sampled.  One step at a time, so the comparison is tight despite the chaotic trajectory."""
+    from conftest import golden
+    g = golden("oracle_icc_icp_trajectories.npz")
+    sc = _fixture_scene(fixtures3)
+    args = (sc["points"], sc["sdf"], sc["pitch"], sc["origin"], sc["grid_target"], sc["grid_nontarget_empty"])
+    traj, adam, losses = g["icc_traj"], g["icc_adam"], g["icc_losses"]
+    assert traj.shape == (100, 3, 7) and adam.shape == (100, 2, 3, 7)
+    np.testing.assert_allclose(traj[0, :, 4:], sc["transform_init"][:, :3, 3], atol=1e-7)
+    for k in range(99):
+        q, t = traj[k, :, :4].copy(), traj[k, :, 4:].copy()
+        loss, gq, gt, _ = OC.icc_loss_grad(*args, q, t, sdf_offset=0.02)
+        np.testing.assert_allclose(loss, losses[k], rtol=2e-6, atol=1e-7)
+        opt = O.ChainerAdam([q, t], [0.01, 0.001])
+        opt.t = k
+        opt.m = [adam[k, 0, :, :4].copy(), adam[k, 0, :, 4:].copy()]
+        opt.v = [adam[k, 1, :, :4].copy(), adam[k, 1, :, 4:].copy()]
+        opt.update([gq, gt])
+        np.testing.assert_allclose(np.concatenate([q, t], axis=1), traj[k + 1], rtol=0, atol=2e-7)
+        if k % 20 == 0:  # the (slow) NumPy restatement on a sample of the iterates
+            loss_np, (gq_np, gt_np, _) = O.icc_loss(*args, traj[k, :, :4], traj[k, :, 4:], sdf_offset=0.02)
+            np.testing.assert_allclose(loss_np, losses[k], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(gq_np, gq, rtol=1e-4, atol=1e-6)
+    assert losses[-1] < losses[0] - 0.1
+
+
+def test_icp_golden_trajectory(fixtures3):
+    from conftest import golden
+    g = golden("oracle_icc_icp_trajectories.npz")
+    f = fixtures3[2]
+    target = (np.argwhere(f["grid_target"] >= 0.5) * f["pitch"] + f["origin"]).astype(np.float32)
+    source = f["pcd_cad"].astype(np.float32)
+    for k in (0, 7, 29):
+        q, t = g["icp_traj"][k, :4], g["icp_traj"][k, 4:]
+        loss_c, gq_c, gt_c = OC.icp_loss_grad(source, target, q, t)
+        loss_n, (gq_n, gt_n) = O.icp_loss(source, target, q, t)
+        np.testing.assert_allclose(loss_c, g["icp_losses"][k], rtol=2e-6)
+        np.testing.assert_allclose(loss_n, g["icp_losses"][k], rtol=1e-5)
+        np.testing.assert_allclose(gq_n, gq_c, rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(gt_n, gt_c, rtol=1e-3, atol=1e-5)
+    assert g["icp_losses"][-1] < g["icp_losses"][0]
