@@ -386,25 +386,7 @@ def main():
 
     wl = Workload(args, rank, device)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        wl.step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = parallel.timed_steps(wl.step, args.steps, args.warmup, device=device)
 
     # un-timed extras: stage breakdown, live kernel timing, CPU baseline (rank 0, N=1)
     wl.events = []

@@ -10,6 +10,8 @@ exchange BASELINE config 4 names: [n_local, 7] float32 per rank (1.8 KB for 8 x 
 -> one latency-bound ``all_gather_into_tensor`` over RCCL/xGMI at the END of the step,
 never per iteration.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -54,3 +56,33 @@ def all_gather_poses_equal(local_poses, out=None, group=None):
         out = local_poses.new_empty((world * local_poses.shape[0], local_poses.shape[1]))
     dist.all_gather_into_tensor(out, local_poses.contiguous(), group=group)
     return out
+
+
+def timed_steps(step, steps, warmup, device=None, group=None):
+    """The benchmark's timing contract: ``warmup`` untimed calls of ``step()``, then exactly
+    ``steps`` calls bracketed by (device sync + barrier) on both sides; returns the elapsed
+    seconds of the SLOWEST rank (all-reduce MAX), identical on every rank."""
+    cuda = device is not None and torch.device(device).type == "cuda"
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def fence():
+        if cuda:
+            torch.cuda.synchronize(device)
+        if multi:
+            dist.barrier(group=group)
+        if cuda:
+            torch.cuda.synchronize(device)
+
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if cuda else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
+        elapsed = float(tt.item())
+    return elapsed

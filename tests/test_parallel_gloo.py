@@ -119,3 +119,39 @@ def test_evaluator_summary_single_and_two_ranks(tmp_path):
     assert r0.keys() == single.keys()
     for k in single:
         np.testing.assert_allclose(r0[k], single[k], rtol=1e-12)
+
+
+# ---- the benchmark's timing contract (bench.py) under two ranks ---------------------------
+def _timed_worker(rank, world, port, out_dir):
+    import json
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+        local = torch.full((2, 7), float(rank))
+
+        def step():  # rank 1 is the slow one; every step ends with the pose all-gather
+            time.sleep(0.01 * (1 + 2 * rank))
+            calls.append(parallel.all_gather_poses_equal(local).shape[0])
+
+        elapsed = parallel.timed_steps(step, steps=5, warmup=2)
+        with open(os.path.join(out_dir, f"timed_{rank}.json"), "w") as f:
+            json.dump(dict(elapsed=elapsed, calls=calls), f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_timed_steps_reports_the_slowest_rank(tmp_path):
+    import json
+    port = _free_port()
+    mp.spawn(_timed_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = json.load(open(tmp_path / "timed_0.json"))
+    r1 = json.load(open(tmp_path / "timed_1.json"))
+    assert r0["calls"] == r1["calls"] == [4] * 7  # 2 warm-up + 5 timed steps, gathered [2*2, 7]
+    assert r0["elapsed"] == r1["elapsed"]          # MAX over ranks, identical everywhere
+    assert 0.15 <= r0["elapsed"] < 1.0             # 5 x 30 ms of the slow rank, not 5 x 10 ms
+    # single process: no collectives, plain wall clock
+    n = []
+    assert parallel.timed_steps(lambda: n.append(1), steps=3, warmup=1) >= 0.0 and len(n) == 4
