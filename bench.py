@@ -426,6 +426,8 @@ def main():
             },
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
             "serial_ms_per_step": round(sum(stages.values()), 4),
+            # the same step with the two stages back to back on one stream (no pipelining credit)
+            "value_serial": round(world * wl.B / (sum(stages.values()) / 1e3), 3) if stages else None,
         }
         out["roofline"] = roofline_icc_tdf(wl)
         out["roofline_voxelize"] = roofline_voxelize(wl)
