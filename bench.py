@@ -343,6 +343,7 @@ def cpu_baseline(wl, args):
             t0 = time.perf_counter()
             model.predict(**sub)
             t_pred = (time.perf_counter() - t0) * (wl.B / n_obj)
+        OC.set_threads(min(threads, 2 * len(sc["points"])))  # the port parallelises over the 2N grids
         OC.icc_refine(*a, q0, t0_, n_iter=1, sdf_offset=0.02)
         t0 = time.perf_counter()
         OC.icc_refine(*a, q0, t0_, n_iter=iters, sdf_offset=0.02)
@@ -363,7 +364,7 @@ def cpu_baseline(wl, args):
                 value_1thread=round(wl.B / (t_pred1 + t_icc1), 3),
                 sample=f"predict on {nb} of {wl.B} object(s) (torch-CPU convs + C port of voxelize/"
                        f"interpolate) scaled x{wl.B / nb:g}; ICC C port (OpenMP) all {iters} "
-                       f"iterations of 1 scene; predict {t_pred:.2f}s + icc {t_icc:.2f}s per step. "
+                       f"iterations of 1 scene on min(cores, 2N) threads; predict {t_pred:.2f}s + icc {t_icc:.2f}s per step. "
                        f"value_1thread: 1 object + {min(10, iters)} ICC iterations on one thread, scaled "
                        f"({t_pred1:.2f}s + {t_icc1:.2f}s per step)")
 
