@@ -84,3 +84,46 @@ def test_grid_origin_matches_numpy_nanmedian_and_nanmean():
         np.testing.assert_allclose(got_med[i], np.nanmedian(p, axis=(0, 1)) - 15.5 * pitch[i], rtol=0, atol=1e-7)
         np.testing.assert_allclose(got_mean[i], np.nanmean(p.astype(np.float64), axis=(0, 1)) - 15.5 * pitch[i],
                                    rtol=0, atol=2e-6)
+
+
+def test_crop_kernel_source_on_the_host_matches_oracle(tmp_path):
+    """csrc/preprocess.hip's k_pre_crops has no barriers: its text is compiled with g++ behind a
+    shim (tests/host_emul/mf_common.h) and run thread by thread -- the kernel source itself is
+    checked against the oracle without a GPU (the -m gpu test repeats this on the device)."""
+    import ctypes
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("g++") is None:
+        import pytest
+        pytest.skip("g++ not available")
+    src = tmp_path / "preprocess.cpp"
+    shutil.copy(os.path.join(root, "morefusion_amd", "csrc", "preprocess.hip"), src)
+    shutil.copy(os.path.join(root, "tests", "host_emul", "mf_common.h"), tmp_path / "mf_common.h")
+    so = tmp_path / "libpre_host.so"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                    "-I", os.path.join(root, "include"), "-o", str(so), str(src)], check=True)
+    L = ctypes.CDLL(str(so))
+    p, i, d = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    L.mf_instance_crops.argtypes = [p, p, p, i, i, d, d, d, d, p, p, i, i, i, p, p, p, p]
+    for seed, (H, W), S in [(0, (480, 640), 256), (2, (300, 420), 256), (3, (480, 640), 64)]:
+        f = synthetic.make_rgbd_frame(seed, H, W)
+        ids = f["instance_ids"]
+        n = len(ids)
+        stats = np.zeros((n, 6), np.int32)  # what mf_instance_stats produces (LDS kernel: device only)
+        for k, a in enumerate(ids):
+            m = f["label"] == a
+            stats[k] = ([*O.mask_to_bbox(m), m.sum(), (m & ~np.isnan(f["depth"])).sum()] if m.any()
+                        else [2 ** 31 - 1, 2 ** 31 - 1, 0, 0, 0, 0])
+        rgb_out = np.full((n, S, S, 3), 77, np.uint8)
+        pcd_out = np.zeros((n, S, S, 3), np.float32)
+        keep = np.zeros(n, np.uint8)
+        K = f["K"]
+        rgb, depth, label = (np.ascontiguousarray(f[k]) for k in ("rgb", "depth", "label"))
+        L.mf_instance_crops(rgb.ctypes.data, depth.ctypes.data, label.ctypes.data, H, W, K[0, 0], K[1, 1],
+                            K[0, 2], K[1, 2], ids.ctypes.data, stats.ctypes.data, n, S, 50,
+                            rgb_out.ctypes.data, pcd_out.ctypes.data, keep.ctypes.data, None)
+        r, pc, kp, _ = O.instance_crops(f["rgb"], f["depth"], K, f["label"], ids, image_size=S)
+        np.testing.assert_array_equal(keep.astype(bool), kp)
+        np.testing.assert_array_equal(rgb_out, r)
+        np.testing.assert_array_equal(pcd_out, pc.astype(np.float32))
