@@ -106,7 +106,7 @@ class PSPNetExtractor(nn.Module):
         h = self.up3(h)
         return F.log_softmax(self.conv1(h), dim=1)
 
-    def forward_sampled(self, x, pix):
+    def forward_sampled(self, x, pix, sparse_decoder=False):
         """Same features as ``forward(x)`` gathered at the flat pixel indices ``pix`` [B,P]
         of the full-resolution map -> [B,32,P], WITHOUT materialising the last level.
 
@@ -116,34 +116,119 @@ class PSPNetExtractor(nn.Module):
         therefore evaluated at those pixels only: each sampled pixel gathers its 3x3 window
         of the (virtually) up-sampled map -- 4 bilinear taps per window element, same
         align_corners=True source-index arithmetic as ``F.interpolate`` -- and applies the
-        same weights.  Mathematically identical; differs only by summation order."""
+        same weights.  Mathematically identical; differs only by summation order.
+
+        ``sparse_decoder=True`` (inference) pushes the same idea through ``up2`` and ``up1``:
+        the decoder is local (bilinear x2 + 3x3 conv per level), so the 128^2 and 64^2 outputs
+        the sampled pixels depend on form a small neighbourhood of the object mask; only those
+        are computed (window gather + one GEMM per level).  Everything below (ResNet, pyramid
+        pooling, bottleneck) has a global receptive field and stays dense."""
         h = F.dropout(self.psp(x), 0.3, self.training)
-        h = F.dropout(self.up1(h), 0.15, self.training)
-        u2 = F.dropout(self.up2(h), 0.15, self.training)  # [B,64,H,W], H = W = 128
-        B, C, H, W = u2.shape
+        taps = self._tail_taps(pix, 4 * h.shape[2], 4 * h.shape[3])
+        if sparse_decoder and not self.training:
+            u2 = self._decode_needed(h, taps)
+        else:
+            h = F.dropout(self.up1(h), 0.15, self.training)
+            u2 = F.dropout(self.up2(h), 0.15, self.training)  # [B,64,H,W], H = W = 128
+        return self._tail(u2, taps)
+
+    @staticmethod
+    def _tail_taps(pix, H, W):
+        """Source taps at the [H,W] level (128^2) of every 3x3 window element of the sampled
+        full-resolution pixels: indices, bilinear fractions and the zero-padding mask."""
+        B, P = pix.shape
         Ho, Wo = 2 * H, 2 * W
-        P = pix.shape[1]
         py, px = pix // Wo, pix % Wo  # [B,P]
         d = torch.tensor([-1, 0, 1], device=pix.device)
         yy = (py[:, :, None, None] + d[None, None, :, None]).expand(B, P, 3, 3).reshape(B, P * 9)
         xx = (px[:, :, None, None] + d[None, None, None, :]).expand(B, P, 3, 3).reshape(B, P * 9)
         valid = (yy >= 0) & (yy < Ho) & (xx >= 0) & (xx < Wo)  # zero padding of the 3x3 conv
         yy, xx = yy.clamp(0, Ho - 1), xx.clamp(0, Wo - 1)
-        sy = yy.to(u2.dtype) * ((H - 1) / (Ho - 1))
-        sx = xx.to(u2.dtype) * ((W - 1) / (Wo - 1))
+        sy = yy.to(torch.float32) * ((H - 1) / (Ho - 1))
+        sx = xx.to(torch.float32) * ((W - 1) / (Wo - 1))
         y0, x0 = sy.floor().long(), sx.floor().long()
         y1, x1 = (y0 + 1).clamp(max=H - 1), (x0 + 1).clamp(max=W - 1)
-        ly, lx = (sy - y0)[:, None, :], (sx - x0)[:, None, :]
+        return dict(P=P, H=H, W=W, valid=valid, y0=y0, x0=x0, y1=y1, x1=x1, ly=sy - y0, lx=sx - x0)
+
+    def _tail(self, u2, taps):
+        """up3 (bilinear x2 + 3x3 conv + PReLU), the 1x1 head and log-softmax at the samples."""
+        B, C, H, W = u2.shape
+        P = taps["P"]
+        ly, lx = taps["ly"].to(u2.dtype)[:, None, :], taps["lx"].to(u2.dtype)[:, None, :]
         flat = u2.reshape(B, C, H * W)
 
         def tap(iy, ix):
             return torch.gather(flat, 2, (iy * W + ix)[:, None, :].expand(B, C, P * 9))
 
+        y0, x0, y1, x1 = taps["y0"], taps["x0"], taps["y1"], taps["x1"]
         up = (1 - ly) * ((1 - lx) * tap(y0, x0) + lx * tap(y0, x1)) + \
             ly * ((1 - lx) * tap(y1, x0) + lx * tap(y1, x1))
-        up = (up * valid[:, None, :]).reshape(B, C, P, 9)
+        up = (up * taps["valid"][:, None, :]).reshape(B, C, P, 9)
         w = self.up3.conv.weight.reshape(self.up3.conv.out_channels, C, 9)
         h = torch.einsum("bcpk,ock->bop", up, w) + self.up3.conv.bias[None, :, None]
         h = self.up3.prelu(h)
         h = F.conv1d(h, self.conv1.weight.reshape(self.conv1.out_channels, -1, 1), self.conv1.bias)
         return F.log_softmax(h, dim=1)
+
+    # ---- needed-set decoder (inference) ---------------------------------------------------
+    @staticmethod
+    def _mark(mask_flat, iy, ix, W, src):
+        mask_flat.scatter_add_(1, iy * W + ix, src)
+
+    @staticmethod
+    def needed_sets(taps):
+        """Boolean maps [B,H2,W2] / [B,H1,W1] of the up2 / up1 outputs the samples depend on.
+        up2's set is exact (the tail gathers with the very same indices); up1's is the source
+        taps of the 3x3-dilated up2 set, widened by one pixel so that it covers whichever
+        neighbour ``F.interpolate`` picks at an exactly-integer source coordinate."""
+        H2, W2 = taps["H"], taps["W"]
+        H1, W1 = H2 // 2, W2 // 2
+        B = taps["valid"].shape[0]
+        dev = taps["valid"].device
+        src = taps["valid"].to(torch.int32)
+        m2 = torch.zeros((B, H2 * W2), dtype=torch.int32, device=dev)
+        for iy, ix in ((taps["y0"], taps["x0"]), (taps["y0"], taps["x1"]),
+                       (taps["y1"], taps["x0"]), (taps["y1"], taps["x1"])):
+            PSPNetExtractor._mark(m2, iy, ix, W2, src)
+        m2 = (m2 > 0).reshape(B, H2, W2)
+        d2 = F.max_pool2d(m2[:, None].float(), 3, 1, 1)[:, 0] > 0  # up-sampled positions up2 reads
+        gy = torch.arange(H2, device=dev, dtype=torch.float32) * ((H1 - 1) / (H2 - 1))
+        gx = torch.arange(W2, device=dev, dtype=torch.float32) * ((W1 - 1) / (W2 - 1))
+        y0, x0 = gy.floor().long(), gx.floor().long()
+        y1, x1 = (y0 + 1).clamp(max=H1 - 1), (x0 + 1).clamp(max=W1 - 1)
+        m1 = torch.zeros((B, H1 * W1), dtype=torch.int32, device=dev)
+        s2 = d2.reshape(B, -1).to(torch.int32)
+        for iy, ix in ((y0, x0), (y0, x1), (y1, x0), (y1, x1)):
+            idx = (iy[:, None] * W1 + ix[None, :]).reshape(1, -1).expand(B, -1)
+            m1.scatter_add_(1, idx, s2)
+        m1 = F.max_pool2d((m1 > 0).reshape(B, 1, H1, W1).float(), 3, 1, 1)[:, 0] > 0
+        return m2, m1
+
+    @staticmethod
+    def _sparse_up(dense_cl, need, up):
+        """One PSPUpsample evaluated only where ``need`` [B,H,W] is set.  ``dense_cl`` is the
+        previous level [B,H/2,W/2,C] (channels last; values outside its own needed set are
+        never read with a non-zero weight).  Returns the output densified to [B,H,W,O]."""
+        B, H, W = need.shape
+        C = dense_cl.shape[3]
+        up2x = F.interpolate(dense_cl.permute(0, 3, 1, 2), (H, W), mode="bilinear", align_corners=True)
+        up2x = up2x.permute(0, 2, 3, 1).contiguous()  # [B,H,W,C]
+        b, y, x = torch.nonzero(need, as_tuple=True)  # host sync on the tiny index computation
+        d = torch.tensor([-1, 0, 1], device=need.device)
+        yy = (y[:, None, None] + d[None, :, None]).expand(-1, 3, 3).reshape(-1, 9)
+        xx = (x[:, None, None] + d[None, None, :]).expand(-1, 3, 3).reshape(-1, 9)
+        inside = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        cols = up2x[b[:, None], yy.clamp(0, H - 1), xx.clamp(0, W - 1)]  # [n,9,C]
+        cols = (cols * inside[:, :, None].to(cols.dtype)).reshape(-1, 9 * C)
+        O = up.conv.out_channels
+        wmat = up.conv.weight.permute(0, 2, 3, 1).reshape(O, 9 * C)  # (ky,kx) major, channel minor
+        rows = up.prelu(torch.addmm(up.conv.bias.to(cols.dtype), cols, wmat.t().to(cols.dtype)))
+        out = rows.new_zeros((B, H, W, O))
+        out[b, y, x] = rows
+        return out
+
+    def _decode_needed(self, h, taps):
+        m2, m1 = self.needed_sets(taps)
+        u1 = self._sparse_up(h.permute(0, 2, 3, 1).contiguous(), m1, self.up1)
+        u2 = self._sparse_up(u1, m2, self.up2)
+        return u2.permute(0, 3, 1, 2)  # [B,64,H2,W2] view; the tail reshapes (copies) it
