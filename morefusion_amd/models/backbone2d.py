@@ -65,15 +65,31 @@ class PSPModule(nn.Module):
             [nn.Conv2d(in_channels, in_channels, 1, bias=False) for _ in sizes])
         self.bottleneck = nn.Conv2d(in_channels * (len(sizes) + 1), out_channels, 1)
 
-    def forward(self, x):
+    def branches(self, x):
+        """The four pooled-context maps, up-sampled back to [H,W] (global receptive field)."""
         H, W = x.shape[2:]
         hs = []
         for size, conv in zip(self.sizes, self.convs):
             k = (H // size, W // size)
             h = conv(F.avg_pool2d(x, k, k))
             hs.append(F.interpolate(h, (H, W), mode="bilinear", align_corners=True))
-        hs.append(x)
-        return F.relu(self.bottleneck(torch.cat(hs, dim=1)))
+        return hs
+
+    def forward(self, x):
+        return F.relu(self.bottleneck(torch.cat(self.branches(x) + [x], dim=1)))
+
+    def forward_needed(self, x, need):
+        """relu(bottleneck(.)) only at the positions ``need`` [B,H,W] (the 1x1 bottleneck is
+        local once the pooled branches exist) -> channels-last [B,H,W,O], zeros elsewhere."""
+        feats = torch.cat(self.branches(x) + [x], dim=1).permute(0, 2, 3, 1).contiguous()  # [B,H,W,5C]
+        b, y, x_ = torch.nonzero(need, as_tuple=True)
+        rows = feats[b, y, x_]  # [n, 5C]
+        O = self.bottleneck.out_channels
+        wmat = self.bottleneck.weight.reshape(O, -1)
+        rows = F.relu(torch.addmm(self.bottleneck.bias.to(rows.dtype), rows, wmat.t().to(rows.dtype)))
+        out = rows.new_zeros(need.shape + (O,))
+        out[b, y, x_] = rows
+        return out
 
 
 class PSPUpsample(nn.Module):
@@ -121,13 +137,14 @@ class PSPNetExtractor(nn.Module):
         ``sparse_decoder=True`` (inference) pushes the same idea through ``up2`` and ``up1``:
         the decoder is local (bilinear x2 + 3x3 conv per level), so the 128^2 and 64^2 outputs
         the sampled pixels depend on form a small neighbourhood of the object mask; only those
-        are computed (window gather + one GEMM per level).  Everything below (ResNet, pyramid
-        pooling, bottleneck) has a global receptive field and stays dense."""
-        h = F.dropout(self.psp(x), 0.3, self.training)
-        taps = self._tail_taps(pix, 4 * h.shape[2], 4 * h.shape[3])
+        are computed (window gather + one GEMM per level), and so is the 1x1 bottleneck of the
+        pyramid module.  The ResNet and the pooled pyramid branches have a global receptive
+        field and stay dense."""
+        taps = self._tail_taps(pix, 4 * x.shape[2], 4 * x.shape[3])
         if sparse_decoder and not self.training:
-            u2 = self._decode_needed(h, taps)
+            u2 = self._decode_needed(x, taps)
         else:
+            h = F.dropout(self.psp(x), 0.3, self.training)
             h = F.dropout(self.up1(h), 0.15, self.training)
             u2 = F.dropout(self.up2(h), 0.15, self.training)  # [B,64,H,W], H = W = 128
         return self._tail(u2, taps)
@@ -177,12 +194,12 @@ class PSPNetExtractor(nn.Module):
 
     @staticmethod
     def needed_sets(taps):
-        """Boolean maps [B,H2,W2] / [B,H1,W1] of the up2 / up1 outputs the samples depend on.
-        up2's set is exact (the tail gathers with the very same indices); up1's is the source
-        taps of the 3x3-dilated up2 set, widened by one pixel so that it covers whichever
-        neighbour ``F.interpolate`` picks at an exactly-integer source coordinate."""
+        """Boolean maps [B,H2,W2], [B,H1,W1], [B,H0,W0] of the up2 / up1 / bottleneck outputs the
+        samples depend on.  up2's set is exact (the tail gathers with the very same indices);
+        each lower set is the bilinear source taps of the 3x3-dilated set above it, widened by
+        one pixel so that it covers whichever neighbour ``F.interpolate`` picks at an
+        exactly-integer source coordinate."""
         H2, W2 = taps["H"], taps["W"]
-        H1, W1 = H2 // 2, W2 // 2
         B = taps["valid"].shape[0]
         dev = taps["valid"].device
         src = taps["valid"].to(torch.int32)
@@ -191,18 +208,26 @@ class PSPNetExtractor(nn.Module):
                        (taps["y1"], taps["x0"]), (taps["y1"], taps["x1"])):
             PSPNetExtractor._mark(m2, iy, ix, W2, src)
         m2 = (m2 > 0).reshape(B, H2, W2)
-        d2 = F.max_pool2d(m2[:, None].float(), 3, 1, 1)[:, 0] > 0  # up-sampled positions up2 reads
-        gy = torch.arange(H2, device=dev, dtype=torch.float32) * ((H1 - 1) / (H2 - 1))
-        gx = torch.arange(W2, device=dev, dtype=torch.float32) * ((W1 - 1) / (W2 - 1))
+        m1 = PSPNetExtractor._source_set(m2)
+        return m2, m1, PSPNetExtractor._source_set(m1)
+
+    @staticmethod
+    def _source_set(need):
+        """Positions of the half-resolution map that a PSPUpsample evaluated on ``need`` reads
+        (bilinear taps of the 3x3-dilated set, widened by one pixel as above)."""
+        B, H, W = need.shape
+        Hs, Ws = H // 2, W // 2
+        dev = need.device
+        dil = F.max_pool2d(need[:, None].float(), 3, 1, 1)[:, 0] > 0
+        gy = torch.arange(H, device=dev, dtype=torch.float32) * ((Hs - 1) / (H - 1))
+        gx = torch.arange(W, device=dev, dtype=torch.float32) * ((Ws - 1) / (W - 1))
         y0, x0 = gy.floor().long(), gx.floor().long()
-        y1, x1 = (y0 + 1).clamp(max=H1 - 1), (x0 + 1).clamp(max=W1 - 1)
-        m1 = torch.zeros((B, H1 * W1), dtype=torch.int32, device=dev)
-        s2 = d2.reshape(B, -1).to(torch.int32)
+        y1, x1 = (y0 + 1).clamp(max=Hs - 1), (x0 + 1).clamp(max=Ws - 1)
+        m = torch.zeros((B, Hs * Ws), dtype=torch.int32, device=dev)
+        src = dil.reshape(B, -1).to(torch.int32)
         for iy, ix in ((y0, x0), (y0, x1), (y1, x0), (y1, x1)):
-            idx = (iy[:, None] * W1 + ix[None, :]).reshape(1, -1).expand(B, -1)
-            m1.scatter_add_(1, idx, s2)
-        m1 = F.max_pool2d((m1 > 0).reshape(B, 1, H1, W1).float(), 3, 1, 1)[:, 0] > 0
-        return m2, m1
+            m.scatter_add_(1, (iy[:, None] * Ws + ix[None, :]).reshape(1, -1).expand(B, -1), src)
+        return F.max_pool2d((m > 0).reshape(B, 1, Hs, Ws).float(), 3, 1, 1)[:, 0] > 0
 
     @staticmethod
     def _sparse_up(dense_cl, need, up):
@@ -227,8 +252,8 @@ class PSPNetExtractor(nn.Module):
         out[b, y, x] = rows
         return out
 
-    def _decode_needed(self, h, taps):
-        m2, m1 = self.needed_sets(taps)
-        u1 = self._sparse_up(h.permute(0, 2, 3, 1).contiguous(), m1, self.up1)
+    def _decode_needed(self, x, taps):
+        m2, m1, m0 = self.needed_sets(taps)
+        u1 = self._sparse_up(self.psp.forward_needed(x, m0), m1, self.up1)
         u2 = self._sparse_up(u1, m2, self.up2)
         return u2.permute(0, 3, 1, 2)  # [B,64,H2,W2] view; the tail reshapes (copies) it
