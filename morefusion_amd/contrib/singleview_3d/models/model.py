@@ -208,8 +208,9 @@ class Model(nn.Module):
 
         if self.sparse_pspnet_tail:
             # last PSPNet level evaluated only at the sampled pixels (identical features)
-            values = self.pspnet_extractor.forward_sampled(
-                self.resnet_extractor(rgb), pix, sparse_decoder=self.sparse_pspnet_decoder)
+            plan = self.pspnet_extractor.plan(pix, rgb.shape[2] // 8, rgb.shape[3] // 8,
+                                              sparse_decoder=self.sparse_pspnet_decoder)
+            values = self.pspnet_extractor.forward_sampled(self.resnet_extractor(rgb), pix, plan=plan)
         else:
             h_rgb = self.pspnet_extractor(self.resnet_extractor(rgb))
             values = torch.gather(h_rgb.reshape(B, h_rgb.shape[1], -1), 2,

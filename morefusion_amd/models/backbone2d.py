@@ -78,16 +78,17 @@ class PSPModule(nn.Module):
     def forward(self, x):
         return F.relu(self.bottleneck(torch.cat(self.branches(x) + [x], dim=1)))
 
-    def forward_needed(self, x, need):
-        """relu(bottleneck(.)) only at the positions ``need`` [B,H,W] (the 1x1 bottleneck is
-        local once the pooled branches exist) -> channels-last [B,H,W,O], zeros elsewhere."""
+    def forward_needed(self, x, where):
+        """relu(bottleneck(.)) only at the positions ``where`` = (b, y, x) index vectors (the 1x1
+        bottleneck is local once the pooled branches exist) -> channels-last [B,H,W,O], zeros
+        elsewhere."""
         feats = torch.cat(self.branches(x) + [x], dim=1).permute(0, 2, 3, 1).contiguous()  # [B,H,W,5C]
-        b, y, x_ = torch.nonzero(need, as_tuple=True)
+        b, y, x_ = where
         rows = feats[b, y, x_]  # [n, 5C]
         O = self.bottleneck.out_channels
         wmat = self.bottleneck.weight.reshape(O, -1)
         rows = F.relu(torch.addmm(self.bottleneck.bias.to(rows.dtype), rows, wmat.t().to(rows.dtype)))
-        out = rows.new_zeros(need.shape + (O,))
+        out = rows.new_zeros(feats.shape[:3] + (O,))
         out[b, y, x_] = rows
         return out
 
@@ -122,7 +123,7 @@ class PSPNetExtractor(nn.Module):
         h = self.up3(h)
         return F.log_softmax(self.conv1(h), dim=1)
 
-    def forward_sampled(self, x, pix, sparse_decoder=False):
+    def forward_sampled(self, x, pix, sparse_decoder=False, plan=None):
         """Same features as ``forward(x)`` gathered at the flat pixel indices ``pix`` [B,P]
         of the full-resolution map -> [B,32,P], WITHOUT materialising the last level.
 
@@ -140,8 +141,8 @@ class PSPNetExtractor(nn.Module):
         are computed (window gather + one GEMM per level), and so is the 1x1 bottleneck of the
         pyramid module.  The ResNet and the pooled pyramid branches have a global receptive
         field and stay dense."""
-        taps = self._tail_taps(pix, 4 * x.shape[2], 4 * x.shape[3])
-        if sparse_decoder and not self.training:
+        taps = plan if plan is not None else self.plan(pix, x.shape[2], x.shape[3], sparse_decoder)
+        if "where" in taps:
             u2 = self._decode_needed(x, taps)
         else:
             h = F.dropout(self.psp(x), 0.3, self.training)
@@ -230,16 +231,17 @@ class PSPNetExtractor(nn.Module):
         return F.max_pool2d((m > 0).reshape(B, 1, Hs, Ws).float(), 3, 1, 1)[:, 0] > 0
 
     @staticmethod
-    def _sparse_up(dense_cl, need, up):
-        """One PSPUpsample evaluated only where ``need`` [B,H,W] is set.  ``dense_cl`` is the
-        previous level [B,H/2,W/2,C] (channels last; values outside its own needed set are
-        never read with a non-zero weight).  Returns the output densified to [B,H,W,O]."""
-        B, H, W = need.shape
-        C = dense_cl.shape[3]
+    def _sparse_up(dense_cl, where, up):
+        """One PSPUpsample evaluated only at ``where`` = (b, y, x) index vectors of its [H,W]
+        output.  ``dense_cl`` is the previous level [B,H/2,W/2,C] (channels last; values outside
+        its own needed set are never read with a non-zero weight).  Returns the output densified
+        to [B,H,W,O]."""
+        B, Hs, Ws, C = dense_cl.shape
+        H, W = 2 * Hs, 2 * Ws
         up2x = F.interpolate(dense_cl.permute(0, 3, 1, 2), (H, W), mode="bilinear", align_corners=True)
         up2x = up2x.permute(0, 2, 3, 1).contiguous()  # [B,H,W,C]
-        b, y, x = torch.nonzero(need, as_tuple=True)  # host sync on the tiny index computation
-        d = torch.tensor([-1, 0, 1], device=need.device)
+        b, y, x = where
+        d = torch.tensor([-1, 0, 1], device=b.device)
         yy = (y[:, None, None] + d[None, :, None]).expand(-1, 3, 3).reshape(-1, 9)
         xx = (x[:, None, None] + d[None, None, :]).expand(-1, 3, 3).reshape(-1, 9)
         inside = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
@@ -252,8 +254,18 @@ class PSPNetExtractor(nn.Module):
         out[b, y, x] = rows
         return out
 
+    def plan(self, pix, H0, W0, sparse_decoder=False):
+        """Everything ``forward_sampled`` derives from the sampled pixels alone: the tail's taps
+        and, for the needed-set decoder, the (b, y, x) index vectors per level.  ``nonzero`` is a
+        host synchronisation -- call this BEFORE queueing the ResNet so that it waits on a few
+        tiny index kernels only ([H0,W0] = size of the ResNet output, 1/8 of the image)."""
+        taps = self._tail_taps(pix, 4 * H0, 4 * W0)
+        if sparse_decoder and not self.training:
+            taps["where"] = tuple(torch.nonzero(m, as_tuple=True) for m in self.needed_sets(taps))
+        return taps
+
     def _decode_needed(self, x, taps):
-        m2, m1, m0 = self.needed_sets(taps)
-        u1 = self._sparse_up(self.psp.forward_needed(x, m0), m1, self.up1)
-        u2 = self._sparse_up(u1, m2, self.up2)
+        w2, w1, w0 = taps["where"]
+        u1 = self._sparse_up(self.psp.forward_needed(x, w0), w1, self.up1)
+        u2 = self._sparse_up(u1, w2, self.up2)
         return u2.permute(0, 3, 1, 2)  # [B,64,H2,W2] view; the tail reshapes (copies) it

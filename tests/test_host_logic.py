@@ -203,6 +203,9 @@ def test_pspnet_needed_set_decoder_equals_dense_forward():
         got = net.forward_sampled(x, pix, sparse_decoder=True)
         m2, m1, m0 = net.needed_sets(net._tail_taps(pix, 4 * hw, 4 * hw))
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+    with torch.no_grad():  # the way Model.predict calls it: index lists planned before the backbone
+        got2 = net.forward_sampled(x, pix, plan=net.plan(pix, hw, hw, sparse_decoder=True))
+    assert torch.equal(got2, got)
     assert m2.shape == (B, 4 * hw, 4 * hw) and m1.shape == (B, 2 * hw, 2 * hw)
     assert 0 < float(m2.float().mean()) < 0.3 and 0 < float(m1.float().mean()) < 0.5
     assert m0.shape == (B, hw, hw) and 0 < float(m0.float().mean()) < 0.8
