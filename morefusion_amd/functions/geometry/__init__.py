@@ -7,6 +7,8 @@ from .compose_transform import compose_transform
 
 from .max_voxelization_3d import max_voxelization_3d
 
+from .occupancy_grid_1d import occupancy_grid_1d
+from .occupancy_grid_2d import occupancy_grid_2d
 from .occupancy_grid_3d import occupancy_grid_3d
 
 from .interpolate_voxel_grid import interpolate_voxel_grid

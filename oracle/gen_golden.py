@@ -147,6 +147,8 @@ def _install_stub():
     F.min = lambda x, axis=None: Variable(np.min(_unwrap(x), axis=axis))
     F.relu = lambda x: Variable(np.maximum(_unwrap(x), 0))
     F.minimum = lambda a, b: Variable(np.minimum(_unwrap(a), _unwrap(b)))
+    F.absolute = lambda x: Variable(np.absolute(_unwrap(x)))
+    F.max = lambda x, axis=None: Variable(np.max(_unwrap(x), axis=axis))
     F.sum = lambda x, axis=None, keepdims=False: Variable(
         np.sum(_unwrap(x), axis=axis, keepdims=keepdims)
     )
@@ -414,6 +416,35 @@ def main():
         median_in=med_in, median_even=xcupy.median(med_in, axis=0),
         median_odd=xcupy.median(med_in[:9], axis=0),
         median_flat=xcupy.median(med_in),
+    )
+    # ---- A5 siblings: occupancy_grid_1d / occupancy_grid_2d (functions/geometry/
+    # occupancy_grid_1d.py:9-60, occupancy_grid_2d.py:10-75; the latter asserts with
+    # collections.Sequence, gone from Python >= 3.10 -> alias it for the import only)
+    import collections
+    import collections.abc
+    if not hasattr(collections, "Sequence"):
+        collections.Sequence = collections.abc.Sequence
+    o1 = _load(g + ".occupancy_grid_1d", "functions/geometry/occupancy_grid_1d.py")
+    o2 = _load(g + ".occupancy_grid_2d", "functions/geometry/occupancy_grid_2d.py")
+    p1 = np.array([0.05, 3.9, 2.5, -0.4], dtype=np.float32)      # incl. the module's own self-check points
+    m1 = o1.occupancy_grid_1d(p1, pitch=1, origin=0, dimension=5).array
+    m1b = o1.occupancy_grid_1d(p1 * 0.1, pitch=0.1, origin=-0.05, dimension=8).array
+    p2 = rs.uniform(-0.5, 4.5, (6, 2)).astype(np.float32)
+    m2 = o2.occupancy_grid_2d(p2, pitch=1, origin=(0, 0), dimension=(5, 6)).array
+    m2b = o2.occupancy_grid_2d(p2, pitch=0.5, origin=(-1.0, 0.5), dimension=(9, 7), threshold=2).array
+    f1 = o1.OccupancyGrid1D(pitch=1, origin=0, dimension=5)
+    g1 = rs.uniform(-1, 1, (p1.shape[0], 5)).astype(np.float32)
+    f1(p1)
+    gp1 = f1.backward((p1,), (g1,))[0]
+    f2 = o2.OccupancyGrid2D(pitch=0.5, origin=(-1.0, 0.5), dimension=(9, 7))
+    g2a = rs.uniform(-1, 1, (7, 9, p2.shape[0])).astype(np.float32)
+    g2b = rs.uniform(-1, 1, (7, 9, p2.shape[0])).astype(np.float32)
+    d_ik, d_jk = f2(p2)
+    gp2 = f2.backward((p2,), (g2a, g2b))[0]
+    np.savez_compressed(
+        os.path.join(OUT, "ref_occupancy_grid_12d.npz"),
+        p1=p1, m1=m1, m1b=m1b, g1=g1, gp1=gp1, p2=p2, m2=m2, m2b=m2b,
+        d_ik=d_ik.array, d_jk=d_jk.array, g2a=g2a, g2b=g2b, gp2=gp2,
     )
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))

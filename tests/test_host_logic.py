@@ -321,3 +321,31 @@ def test_chainer_compat_facade_host_side():
             cuda.to_gpu(np.zeros(3))
     assert chainer.optimizers.Adam(alpha=0.01).hyperparam.alpha == 0.01
     assert callable(chainer.serializers.load_npz)
+
+
+def test_occupancy_grid_1d_2d_vs_reference_golden():
+    """The toy siblings of occupancy_grid_3d against outputs of the
+    reference's own code (oracle/gen_golden.py), values and gradients."""
+    from conftest import golden
+    from morefusion_amd.functions.geometry import occupancy_grid_1d, occupancy_grid_2d
+    g = golden("ref_occupancy_grid_12d.npz")
+    p1 = torch.from_numpy(g["p1"]).requires_grad_(True)
+    m1 = occupancy_grid_1d(p1, pitch=1, origin=0, dimension=5)
+    np.testing.assert_allclose(m1.detach().numpy(), g["m1"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(
+        occupancy_grid_1d(p1.detach() * 0.1, pitch=0.1, origin=-0.05, dimension=8).numpy(), g["m1b"], atol=1e-6)
+    # the Function's backward: d_IJ = i - (x - o)/pitch  =>  dL/dx = sum_i -g/pitch
+    cells = torch.arange(5.0)
+    d = cells[None, :] - (p1[:, None] - 0) / 1
+    (d * torch.from_numpy(g["g1"])).sum().backward()
+    np.testing.assert_allclose(p1.grad.numpy(), g["gp1"], rtol=1e-6, atol=1e-6)
+    p2 = torch.from_numpy(g["p2"]).requires_grad_(True)
+    m2 = occupancy_grid_2d(p2, pitch=1, origin=(0, 0), dimension=(5, 6))
+    assert m2.shape == (6, 5)  # the reference's [dimension[1], dimension[0]] layout
+    np.testing.assert_allclose(m2.detach().numpy(), g["m2"], rtol=0, atol=1e-6)
+    m2b = occupancy_grid_2d(p2, pitch=0.5, origin=(-1.0, 0.5), dimension=(9, 7), threshold=2)
+    np.testing.assert_allclose(m2b.detach().numpy(), g["m2b"], rtol=0, atol=1e-6)
+    m2b.sum().backward()
+    assert torch.isfinite(p2.grad).all() and float(p2.grad.abs().sum()) > 0
+    with pytest.raises(TypeError):
+        occupancy_grid_2d(p2.detach().double(), pitch=1, origin=(0, 0), dimension=(5, 6))
