@@ -349,3 +349,40 @@ def test_occupancy_grid_1d_2d_vs_reference_golden():
     assert torch.isfinite(p2.grad).all() and float(p2.grad.abs().sum()) > 0
     with pytest.raises(TypeError):
         occupancy_grid_2d(p2.detach().double(), pitch=1, origin=(0, 0), dimension=(5, 6))
+
+
+def test_predict_host_logic_decoder_modes_agree(monkeypatch):
+    """Model.predict end to end on the CPU with the two HIP ops replaced by the C oracle (test
+    stand-ins only): the default path (sampled PSPNet tail), the needed-set decoder and the
+    fully dense decoder give the same poses -- the host logic around the kernels is mode-independent."""
+    from oracle import oracle_c as OC
+    import morefusion_amd as mf
+    from morefusion_amd.contrib.singleview_3d.models import Model
+    import morefusion_amd.contrib.singleview_3d.models.model as model_mod
+
+    def avg_cpu(values, points, batch_indices, *, batch_size, origin, pitch, dimensions, return_counts=False, **kw):
+        m, c = OC.average_voxelization_3d(values.numpy(), points.numpy(), batch_indices.numpy(),
+                                          batch_size=batch_size, origin=origin, pitch=pitch, dimensions=dimensions)
+        return (torch.from_numpy(m), torch.from_numpy(c)) if return_counts else torch.from_numpy(m)
+
+    def interp_cpu(vox, points, batch_indices, channels_first=False):
+        out = torch.from_numpy(OC.interpolate_voxel_grid(vox.numpy(), points.numpy(), batch_indices.numpy()))
+        return out.t().contiguous() if channels_first else out
+
+    monkeypatch.setattr(model_mod.functions_module, "average_voxelization_3d", avg_cpu)
+    monkeypatch.setattr(model_mod.functions_module, "interpolate_voxel_grid", interp_cpu)
+    torch.manual_seed(0)
+    model = Model(n_fg_class=21, with_occupancy=True).eval()
+    b = mf.synthetic.make_singleview_batch(1, seed=3)
+    inp = {k: torch.as_tensor(b[k]) for k in ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty")}
+    outs = []
+    with torch.no_grad():
+        for tail, decoder in ((True, False), (True, True), (False, False)):
+            model.sparse_pspnet_tail, model.sparse_pspnet_decoder = tail, decoder
+            outs.append(model.predict(**inp))
+    q, t, c = outs[0]
+    assert q.shape == (1, 1000, 4) and t.shape == (1, 1000, 3) and c.shape == (1, 1000)
+    np.testing.assert_allclose(q.norm(dim=2).numpy(), 1.0, atol=1e-5)
+    for other in outs[1:]:
+        for a, b_ in zip(other, outs[0]):
+            np.testing.assert_allclose(a.numpy(), b_.numpy(), rtol=0, atol=5e-6)
