@@ -69,6 +69,9 @@ def test_frame_to_poses_end_to_end():
     model = Model(n_fg_class=21, with_occupancy=True).cuda().eval()
     grid = torch.zeros((int(keep.sum()), 32, 32, 32), dtype=torch.bool, device="cuda")
     with torch.no_grad():
+        # first call of these shapes: MIOpen settles its solver choice (may differ from later calls)
+        model.predict(class_id=class_id.cuda(), rgb=rgb, pcd=pcd, pitch=pitch, origin=origin,
+                      grid_nontarget_empty=grid)
         q, t, c = model.predict(class_id=class_id.cuda(), rgb=rgb, pcd=pcd, pitch=pitch, origin=origin,
                                 grid_nontarget_empty=grid)
         q2, t2, c2 = model.predict(class_id=class_id.cuda(), rgb=rgb, pcd=pcd, grid_nontarget_empty=grid)

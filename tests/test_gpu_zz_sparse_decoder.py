@@ -18,6 +18,7 @@ def test_sparse_decoder_predict_matches_dense_decoder():
               for k in ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty")}
     with torch.no_grad():
         model.sparse_pspnet_decoder = False
+        model.predict(**inputs)  # first call of these shapes: MIOpen settles its solver choice
         q0, t0, c0 = model.predict(**inputs)
         model.sparse_pspnet_decoder = True
         q1, t1, c1 = model.predict(**inputs)
