@@ -220,7 +220,7 @@ constexpr int kSurvCap = 12288;  // LDS survivor list of packed (object slot, po
 
 template <int KS>
 __global__ __launch_bounds__(kTdfThreads, 8) void k_icc_tdf(IccArgs a, int ks_rt, int SX) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn1[];  // dist[nvox], id[nvox]
+  MF_DYN_LDS(uint32_t, s_dyn1);  // dist[nvox], id[nvox]
   __shared__ float s_Rt[kMaxSceneObjects][12];
   __shared__ int s_p0[kMaxSceneObjects], s_p1[kMaxSceneObjects];
   __shared__ uint32_t s_surv[kSurvCap];  // (object slot << 27) | point id
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(kStepThreads) void k_icc_step(IccArgs a, int NB, in
                                                            float aq, float at, float *loss_out,
                                                            float *gq_out, float *gt_out,
                                                            float *traj, int it) {
-  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  MF_DYN_LDS(float, s_dyn);
   __shared__ float s_o[kMaxSceneObjects * 12];
   __shared__ float s_coef[4];
   const int sc = blockIdx.x;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_lds(
     const float *__restrict__ vox, const float *__restrict__ points,
     const int32_t *__restrict__ batch_indices, int64_t n, int C, int X, int Y, int Z, int cpw,
     float *__restrict__ values, int channels_first) {
-  extern __shared__ __attribute__((aligned(16))) float s_grid[];
+  MF_DYN_LDS(float, s_grid);
   const int b = blockIdx.y;
   const int c0 = blockIdx.x * cpw;
   const int nc = min(cpw, C - c0);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_bwd_lds(
     const float *__restrict__ gvalues, const float *__restrict__ points,
     const int32_t *__restrict__ batch_indices, int64_t n, int C, int X, int Y, int Z, int cpw,
     float *__restrict__ gvox, int channels_first) {
-  extern __shared__ __attribute__((aligned(16))) float s_grid[];
+  MF_DYN_LDS(float, s_grid);
   const int b = blockIdx.y;
   const int c0 = blockIdx.x * cpw;
   const int nc = min(cpw, C - c0);

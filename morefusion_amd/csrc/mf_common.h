@@ -29,6 +29,9 @@ inline int check_launch(const char *where) {
 
 constexpr int kWave = 64;
 
+// dynamic LDS of the workgroup (tests/host_emul/mf_common.h gives the host-emulation form)
+#define MF_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+
 __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // round((p - o) / pitch), CUDA round() == roundf(): half away from zero.

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_sc_gather(ScArgs a) {
 // ([k][row] and [k][col]: conflict-free fragment reads); K = Cs is small enough to
 // stage completely.  Each wave owns 16 rows x 64 columns = 4 accumulators.
 __global__ __launch_bounds__(256) void k_sc_gemm(ScArgs a, const float *__restrict__ Wp) {
-  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  MF_DYN_LDS(float, s_mem);
   const int K = a.Cs, N = 8 * a.Cout;
   const int n_ntiles = N / kTN;
   float *As = s_mem;                  // [K][kTM + 4]
@@ -205,7 +205,7 @@ constexpr int kRedThreads = 1024;  // 16 waves x 4 output voxels: short dependen
 __global__ __launch_bounds__(kRedThreads) void k_sc_reduce(ScArgs a, const float *__restrict__ dense,
                                                           const float *__restrict__ bias, int relu,
                                                           float *__restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float s_tile[];  // [Cout][65]
+  MF_DYN_LDS(float, s_tile);  // [Cout][65]
   const int D = a.D, Do = D / 2, V = D * D * D, Vo = Do * Do * Do;
   const int b = blockIdx.y;
   const int o0 = blockIdx.x * 64;

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kTdfThreads) void k_tdf_fwd(const float *__restrict
                                                          float trunc, int ks_rt, int SX, int SY,
                                                          float *__restrict__ tdf,
                                                          int32_t *__restrict__ flat) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_w[];  // dist bits [nvox], id [nvox]
+  MF_DYN_LDS(uint32_t, s_w);  // dist bits [nvox], id [nvox]
   const int ks = KS > 0 ? KS : ks_rt;
   const int h = ks / 2, K = ks * ks * ks;
   const int x0 = blockIdx.x * SX, y0 = blockIdx.y * SY;

@@ -1,52 +1,335 @@
-/* TEST INFRASTRUCTURE ONLY -- shadows morefusion_amd/csrc/mf_common.h so that a barrier-free HIP
- * kernel source (csrc/preprocess.hip: k_pre_crops) can be compiled with g++ and executed thread by
- * thread on the host: tests/test_preprocess_oracle.py checks the very kernel text against the
- * oracle without a GPU.  Kernels that need __syncthreads()/LDS cooperation are NOT emulated
- * faithfully (threads run one after another) and are not called by the tests. */
+/* TEST INFRASTRUCTURE ONLY -- shadows morefusion_amd/csrc/mf_common.h so that the HIP kernel
+ * SOURCES (csrc/*.hip) can be compiled with g++ and executed on the host without a GPU:
+ * the -m "not gpu" tests then check the very kernel text against the oracle.
+ *
+ * A functional emulator, not a performance model: one workgroup at a time, every GPU thread of
+ * the workgroup is a fiber (ucontext).  __syncthreads() and the wave collectives (__ballot,
+ * __shfl*) park the fiber until every live fiber of the workgroup has arrived / until no lane of
+ * its 64-lane wave can still run (lanes parked elsewhere count as inactive, as on the hardware);
+ * a barrier that can never complete (divergent __syncthreads) aborts with a diagnostic.
+ * Fibers run one after another, so atomics are trivially atomic and results are deterministic.
+ * hipGraph capture records closures and hipGraphLaunch replays them.  "Device" pointers are
+ * host pointers.  Nothing here is ever linked into libmfhip.so. */
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
+#include <vector>
 
 #include "mfhip.h"
 
 typedef int hipError_t;
-typedef void *hipStream_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8, hipStreamNonBlocking = 1,
+       hipStreamCaptureModeThreadLocal = 1 };
+inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+
 struct dim3 {
   unsigned x, y, z;
   dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
 };
-static dim3 blockIdx, threadIdx, blockDim, gridDim;
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(8) int2 { int x, y; };
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+inline float2 make_float2(float x, float y) { return {x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
+inline int2 make_int2(int x, int y) { return {x, y}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+
+inline dim3 blockIdx, threadIdx, blockDim, gridDim;
+constexpr int warpSize = 64;
+
 #define __global__
 #define __device__
+#define __host__
 #define __forceinline__ inline
 #define __shared__ static
 #define __launch_bounds__(...)
 #define __restrict__
-static inline void __syncthreads() {}
+#define HIP_SYMBOL(x) x
+// dynamic LDS of the running workgroup (csrc/mf_common.h defines the device form)
+#define MF_DYN_LDS(type, name) type *name = reinterpret_cast<type *>(::mf_emul::g_dyn_lds)
+
+using std::isfinite;
 using std::isnan;
 using std::max;
 using std::min;
-template <class T> T atomicMin(T *p, T v) { T o = *p; *p = std::min(o, v); return o; }
-template <class T> T atomicMax(T *p, T v) { T o = *p; *p = std::max(o, v); return o; }
-template <class T> T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+
+namespace mf_emul {
+
+enum State { READY = 0, AT_BARRIER = 1, AT_WAVE = 2, DONE = 3 };
+constexpr int kMaxThreads = 1024;
+constexpr size_t kStack = 96 * 1024;
+
+struct Fiber {
+  ucontext_t ctx;
+  State state;
+};
+
+struct Block {
+  int n = 0, cur = 0;
+  ucontext_t sched;
+  Fiber fib[kMaxThreads];
+  char *stacks = nullptr;
+  const std::function<void()> *body = nullptr;
+  uint64_t pending[kMaxThreads / 64][64];  // operands of lanes parked at a wave collective
+  uint64_t result[kMaxThreads / 64][64];   // operands of the collective released last
+  uint64_t active[kMaxThreads / 64];       // lanes that took part in it
+};
+
+inline Block g_block;
+inline unsigned char *g_dyn_lds = nullptr;
+inline size_t g_dyn_cap = 0;
+
+inline void yield_to_scheduler() {
+  Block &b = g_block;
+  swapcontext(&b.fib[b.cur].ctx, &b.sched);
+}
+
+inline void trampoline() {
+  Block &b = g_block;
+  (*b.body)();
+  b.fib[b.cur].state = DONE;
+  swapcontext(&b.fib[b.cur].ctx, &b.sched);
+}
+
+inline void run_block(const std::function<void()> &body, int nthreads) {
+  Block &b = g_block;
+  if (nthreads > kMaxThreads) { fprintf(stderr, "mf_emul: block of %d threads\n", nthreads); abort(); }
+  if (!b.stacks) b.stacks = (char *)malloc(kStack * kMaxThreads);
+  b.n = nthreads;
+  b.body = &body;
+  for (int t = 0; t < nthreads; ++t) {
+    Fiber &f = b.fib[t];
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = b.stacks + kStack * t;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, (void (*)())trampoline, 0);
+    f.state = READY;
+  }
+  const int nw = (nthreads + 63) / 64;
+  for (;;) {
+    bool progress = false, all_done = true;
+    for (int t = 0; t < nthreads; ++t) {
+      if (b.fib[t].state == READY) {
+        b.cur = t;
+        threadIdx = dim3(t % blockDim.x, (t / blockDim.x) % blockDim.y, t / (blockDim.x * blockDim.y));
+        swapcontext(&b.sched, &b.fib[t].ctx);
+        progress = true;
+      }
+      if (b.fib[t].state != DONE) all_done = false;
+    }
+    if (all_done) return;
+    // wave collectives: release a wave once every live lane of it waits at one
+    for (int w = 0; w < nw; ++w) {
+      int waiting = 0;
+      uint64_t mask = 0;
+      for (int l = 0; l < 64 && w * 64 + l < nthreads; ++l)
+        if (b.fib[w * 64 + l].state == AT_WAVE) { ++waiting; mask |= 1ull << l; }
+      // Nothing is READY here: every other live lane of the wave is parked at __syncthreads, so
+      // -- like the hardware -- the collective runs over the lanes that reached it (divergent
+      // lanes are inactive).  Released lanes read `result` before they can park again.
+      if (waiting > 0) {
+        b.active[w] = mask;
+        for (int l = 0; l < 64 && w * 64 + l < nthreads; ++l)
+          if (b.fib[w * 64 + l].state == AT_WAVE) {
+            b.result[w][l] = b.pending[w][l];
+            b.fib[w * 64 + l].state = READY;
+          }
+        progress = true;
+      }
+    }
+    // workgroup barrier
+    {
+      int waiting = 0, live = 0;
+      for (int t = 0; t < nthreads; ++t) {
+        if (b.fib[t].state == DONE) continue;
+        ++live;
+        if (b.fib[t].state == AT_BARRIER) ++waiting;
+      }
+      if (live && waiting == live) {
+        for (int t = 0; t < nthreads; ++t)
+          if (b.fib[t].state == AT_BARRIER) b.fib[t].state = READY;
+        progress = true;
+      }
+    }
+    if (!progress) {
+      int nb = 0, nwv = 0;
+      for (int t = 0; t < nthreads; ++t) { nb += b.fib[t].state == AT_BARRIER; nwv += b.fib[t].state == AT_WAVE; }
+      fprintf(stderr, "mf_emul: DEADLOCK in block (%u,%u): %d fibers at __syncthreads, %d at a wave "
+              "collective -- divergent barrier in the kernel\n", blockIdx.x, blockIdx.y, nb, nwv);
+      abort();
+    }
+  }
+}
+
+// all 64 lanes of the calling fiber's wave exchange one 64-bit word
+inline const uint64_t *wave_exchange(uint64_t v, uint64_t *active_mask) {
+  Block &b = g_block;
+  const int tid = b.cur, w = tid / 64, l = tid % 64;
+  b.pending[w][l] = v;
+  b.fib[tid].state = AT_WAVE;
+  yield_to_scheduler();
+  if (active_mask) *active_mask = b.active[w];
+  return b.result[w];
+}
+
+struct Graph { std::vector<std::function<void()>> nodes; };
+struct Stream { bool capturing = false; Graph *graph = nullptr; };
+
+inline void enqueue(Stream *st, std::function<void()> fn) {
+  if (st && st->capturing) st->graph->nodes.push_back(std::move(fn));
+  else fn();
+}
+
+template <class F>
+inline void launch(Stream *st, dim3 g, dim3 blk, size_t shmem, F kernel_call) {
+  enqueue(st, [=]() {
+    if (shmem > g_dyn_cap) {
+      g_dyn_lds = (unsigned char *)realloc(g_dyn_lds, shmem + 64);
+      g_dyn_cap = shmem;
+    }
+    gridDim = g;
+    blockDim = blk;
+    const std::function<void()> body = kernel_call;
+    for (unsigned bz = 0; bz < g.z; ++bz)
+      for (unsigned by = 0; by < g.y; ++by)
+        for (unsigned bx = 0; bx < g.x; ++bx) {
+          blockIdx = dim3(bx, by, bz);
+          run_block(body, (int)(blk.x * blk.y * blk.z));
+        }
+  });
+}
+
+}  // namespace mf_emul
+
+typedef mf_emul::Stream *hipStream_t;
+typedef mf_emul::Graph *hipGraph_t;
+typedef mf_emul::Graph *hipGraphExec_t;
+
+#define hipLaunchKernelGGL(k, g, b, sh, st, ...) \
+  ::mf_emul::launch((hipStream_t)(st), dim3(g), dim3(b), (size_t)(sh), [=]() { k(__VA_ARGS__); })
+
+inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new mf_emul::Stream(); return hipSuccess; }
+inline hipError_t hipStreamBeginCapture(hipStream_t s, int) {
+  s->capturing = true;
+  s->graph = new mf_emul::Graph();
+  return hipSuccess;
+}
+inline hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t *g) {
+  s->capturing = false;
+  *g = s->graph;
+  s->graph = nullptr;
+  return hipSuccess;
+}
+inline hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t g, void *, void *, unsigned long long) {
+  *e = new mf_emul::Graph(*g);
+  return hipSuccess;
+}
+inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t g) { delete g; return hipSuccess; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t st) {
+  for (auto &n : e->nodes) mf_emul::enqueue(st, n);
+  return hipSuccess;
+}
+inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t st) {
+  mf_emul::enqueue(st, [=]() { memset(p, v, n); });
+  return hipSuccess;
+}
+template <class T>
+inline hipError_t hipMemcpyFromSymbol(void *dst, const T &sym, size_t n) { memcpy(dst, &sym, n); return hipSuccess; }
+
+// ---- device intrinsics ---------------------------------------------------------------
+inline void __syncthreads() {
+  mf_emul::Block &b = mf_emul::g_block;
+  b.fib[b.cur].state = mf_emul::AT_BARRIER;
+  mf_emul::yield_to_scheduler();
+}
+inline void __builtin_amdgcn_wave_barrier() {}
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+inline void __threadfence() {}
+inline unsigned long long wall_clock64() { return 0; }
+
+inline unsigned long long __ballot(int pred) {
+  uint64_t act;
+  const uint64_t *all = mf_emul::wave_exchange(pred ? 1 : 0, &act);
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l)
+    if (((act >> l) & 1) && all[l]) m |= 1ull << l;
+  return m;
+}
+template <class T>
+inline T mf_emul_shfl(T v, int src) {
+  static_assert(sizeof(T) <= 8, "shfl of <= 8 bytes");
+  uint64_t bits = 0;
+  memcpy(&bits, &v, sizeof(T));
+  const int lane = mf_emul::g_block.cur % 64;
+  uint64_t act;
+  const uint64_t *all = mf_emul::wave_exchange(bits, &act);
+  if (src < 0 || src > 63 || !((act >> src) & 1)) src = lane;  // inactive source: own value
+  T out;
+  memcpy(&out, &all[src], sizeof(T));
+  return out;
+}
+template <class T> inline T __shfl(T v, int src, int = 64) { return mf_emul_shfl(v, src & 63); }
+template <class T> inline T __shfl_down(T v, unsigned d, int = 64) {
+  const int lane = mf_emul::g_block.cur % 64;
+  return mf_emul_shfl(v, lane + (int)d < 64 ? lane + (int)d : lane);
+}
+template <class T> inline T __shfl_xor(T v, int m, int = 64) {
+  const int lane = mf_emul::g_block.cur % 64;
+  return mf_emul_shfl(v, lane ^ m);
+}
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+inline long long __double2ll_rn(double x) { return llrint(x); }
+template <class T> inline T atomicMin(T *p, T v) { T o = *p; *p = std::min(o, v); return o; }
+template <class T> inline T atomicMax(T *p, T v) { T o = *p; *p = std::max(o, v); return o; }
+template <class T> inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
+template <class T> inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+
 namespace mf {
 inline void set_last_error(int, const char *) {}
 inline int check_launch(const char *) { return 0; }
+constexpr int kWave = 64;
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline float voxel_coord(float p, float o, float pitch) { return (p - o) / pitch; }
+inline float wave_sum(float v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+inline float wave_max(float v) {
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+  return v;
+}
 }  // namespace mf
-#define hipLaunchKernelGGL(k, g, b, sh, st, ...)                                   \
-  do {                                                                             \
-    dim3 _g = g, _b = b;                                                           \
-    gridDim = _g;                                                                  \
-    blockDim = _b;                                                                 \
-    for (unsigned by = 0; by < _g.y; ++by)                                         \
-      for (unsigned bx = 0; bx < _g.x; ++bx)                                       \
-        for (unsigned tx = 0; tx < _b.x; ++tx) {                                   \
-          blockIdx = dim3(bx, by);                                                 \
-          threadIdx = dim3(tx);                                                    \
-          k(__VA_ARGS__);                                                          \
-        }                                                                          \
+
+#define MF_TRY(expr)                    \
+  do {                                  \
+    hipError_t _e = (expr);             \
+    if (_e != hipSuccess) return -(int)_e; \
   } while (0)
