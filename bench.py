@@ -53,8 +53,6 @@ def parse():
                          "convolutions / GEMMs of the network (HIP voxel ops, sparse conv3 and ICC stay f32)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the network pass and the ICC refinement back to back on one stream")
-    ap.add_argument("--sparse-decoder", action="store_true",
-                    help="evaluate the PSPNet decoder (up1/up2) only where the sampled pixels need it")
     ap.add_argument("--channels-last", action="store_true",
                     help="keep the 2-D backbone (ResNet18 + PSPNet) in NHWC memory format")
     ap.add_argument("--priority", choices=["none", "net-high", "icc-high", "icc-low"], default="none",
@@ -93,7 +91,6 @@ class Workload:
         self.B = S * Nobj
         torch.manual_seed(0)
         self.model = Model(n_fg_class=21, with_occupancy=True).to(device).eval()
-        self.model.sparse_pspnet_decoder = bool(args.sparse_decoder)
         if args.channels_last:
             self.model.resnet_extractor.to(memory_format=torch.channels_last)
             self.model.pspnet_extractor.to(memory_format=torch.channels_last)
@@ -427,7 +424,6 @@ def main():
                            "2 (ICC refinement overlaps the network pass; stage_ms are the serial stage times)",
                 "stream_priority": args.priority, "backbone_memory_format":
                     "channels_last" if args.channels_last else "contiguous",
-                "pspnet_decoder": "needed-set (sparse)" if args.sparse_decoder else "dense",
             },
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
             "serial_ms_per_step": round(sum(stages.values()), 4),

@@ -67,9 +67,6 @@ class Model(nn.Module):
         self._models = models or PitchTableModels()
         # evaluate the last PSPNet level only where the network samples it (model.py:222)
         self.sparse_pspnet_tail = True
-        # also restrict up1/up2 of the PSPNet decoder to the outputs the sampled pixels depend on
-        # (identical features, ~35 % fewer backbone FLOPs; opt-in until measured on the MI355X)
-        self.sparse_pspnet_decoder = False
         # inference: conv3 on fp32 MFMA over the occupied voxels only (csrc/sparseconv.hip)
         self.sparse_conv3 = True
 
@@ -208,8 +205,7 @@ class Model(nn.Module):
 
         if self.sparse_pspnet_tail:
             # last PSPNet level evaluated only at the sampled pixels (identical features)
-            plan = self.pspnet_extractor.plan(pix, rgb.shape[2] // 8, rgb.shape[3] // 8,
-                                              sparse_decoder=self.sparse_pspnet_decoder)
+            plan = self.pspnet_extractor.plan(pix, rgb.shape[2] // 8, rgb.shape[3] // 8)
             values = self.pspnet_extractor.forward_sampled(self.resnet_extractor(rgb), pix, plan=plan)
         else:
             h_rgb = self.pspnet_extractor(self.resnet_extractor(rgb))

@@ -48,7 +48,6 @@ def _cpu_restatement(model_gpu, inputs):
     model = Model(n_fg_class=21, with_occupancy=True).eval()
     model.load_state_dict({k: v.cpu() for k, v in model_gpu.state_dict().items()})
     model.sparse_pspnet_tail = False   # dense decoder + gather (model.py:181-222)
-    model.sparse_pspnet_decoder = False
     model.sparse_conv3 = False         # dense Conv3d (model.py:118-128)
     saved = (model_mod.functions_module.average_voxelization_3d,
              model_mod.functions_module.interpolate_voxel_grid)

@@ -182,37 +182,6 @@ def test_pspnet_sampled_tail_equals_dense_forward():
     np.testing.assert_allclose(got.detach().numpy(), ref.detach().numpy(), rtol=1e-4, atol=2e-5)
 
 
-def test_pspnet_needed_set_decoder_equals_dense_forward():
-    """sparse_decoder=True evaluates up1/up2 only on the outputs the samples depend on: same
-    features as the dense decoder, on clustered samples (an object mask), image corners and
-    an object hugging the border; the needed sets really are a small part of the maps."""
-    from morefusion_amd.models import PSPNetExtractor
-    torch.manual_seed(1)
-    net = PSPNetExtractor().eval()
-    B, hw = 3, 12
-    x = torch.randn(B, 512, hw, hw)  # -> 96 x 96 output
-    S = 8 * hw
-    yy, xx = np.mgrid[:S, :S]
-    rs = np.random.RandomState(0)
-    blobs = [((yy - 50) ** 2 + (xx - 40) ** 2) < 15 ** 2, (yy < 20) & (xx > S - 25), (yy > 30) & (yy < 60) & (xx < 9)]
-    pix = torch.from_numpy(np.stack([rs.choice(np.flatnonzero(m.reshape(-1)), 120, replace=False) for m in blobs]))
-    pix[1, :4] = torch.tensor([0, S - 1, S * (S - 1), S * S - 1])
-    with torch.no_grad():
-        dense = net(x)
-        ref = torch.gather(dense.reshape(B, 32, -1), 2, pix[:, None, :].expand(B, 32, -1))
-        got = net.forward_sampled(x, pix, sparse_decoder=True)
-        m2, m1, m0 = net.needed_sets(net._tail_taps(pix, 4 * hw, 4 * hw))
-    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
-    with torch.no_grad():  # the way Model.predict calls it: index lists planned before the backbone
-        got2 = net.forward_sampled(x, pix, plan=net.plan(pix, hw, hw, sparse_decoder=True))
-    assert torch.equal(got2, got)
-    assert m2.shape == (B, 4 * hw, 4 * hw) and m1.shape == (B, 2 * hw, 2 * hw)
-    assert 0 < float(m2.float().mean()) < 0.3 and 0 < float(m1.float().mean()) < 0.5
-    assert m0.shape == (B, hw, hw) and 0 < float(m0.float().mean()) < 0.8
-    net.train()  # training keeps the dense decoder (dropout); the flag is ignored
-    assert net.forward_sampled(x, pix, sparse_decoder=True).shape == (B, 32, 120)
-
-
 def test_voxel_grid_wire_format_roundtrip(fixtures3):
     from morefusion_amd import data_formats as DF
     g = fixtures3[0]["grid_target"]  # float32 32^3 with 341 occupied voxels
@@ -353,8 +322,8 @@ def test_occupancy_grid_1d_2d_vs_reference_golden():
 
 def test_predict_host_logic_decoder_modes_agree(monkeypatch):
     """Model.predict end to end on the CPU with the two HIP ops replaced by the C oracle (test
-    stand-ins only): the default path (sampled PSPNet tail), the needed-set decoder and the
-    fully dense decoder give the same poses -- the host logic around the kernels is mode-independent."""
+    stand-ins only): the default path (sampled PSPNet tail) and the fully dense decoder give
+    the same poses -- the host logic around the kernels is mode-independent."""
     from oracle import oracle_c as OC
     import morefusion_amd as mf
     from morefusion_amd.contrib.singleview_3d.models import Model
@@ -377,8 +346,8 @@ def test_predict_host_logic_decoder_modes_agree(monkeypatch):
     inp = {k: torch.as_tensor(b[k]) for k in ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty")}
     outs = []
     with torch.no_grad():
-        for tail, decoder in ((True, False), (True, True), (False, False)):
-            model.sparse_pspnet_tail, model.sparse_pspnet_decoder = tail, decoder
+        for tail in (True, False):
+            model.sparse_pspnet_tail = tail
             outs.append(model.predict(**inp))
     q, t, c = outs[0]
     assert q.shape == (1, 1000, 4) and t.shape == (1, 1000, 3) and c.shape == (1, 1000)
