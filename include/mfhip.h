@@ -79,15 +79,20 @@ int mf_max_voxelization_3d_bwd(const float *gmatrix, const int32_t *indices, int
  *   morefusion/functions/geometry/interpolate_voxel_grid.py:159-214, :216-268.
  * points are in voxel-index units; low corner = (int)coord (trunc toward zero).
  * values: [n,C] if channels_first == 0, else [C,n] (coalesced layout the pose
- * network consumes).  gvox [B,C,X,Y,Z] is written completely by _bwd. */
+ * network consumes); every row is written (zeros for rows whose batch index is outside
+ * [0, B)).  gvox [B,C,X,Y,Z] is written completely by _bwd.
+ * batch_start (may be NULL): B+1 row offsets, rows of item b = [batch_start[b],
+ * batch_start[b+1]) -- what a caller with batch-sorted points knows for free (the pose network:
+ * b * P).  With it a workgroup touches only its item's rows; without it every workgroup
+ * filters all n batch_indices. */
 int mf_interpolate_voxel_grid_fwd(const float *vox, const float *points,
-                                  const int32_t *batch_indices, int64_t n, int B, int C,
-                                  int X, int Y, int Z, float *values,
+                                  const int32_t *batch_indices, const int32_t *batch_start,
+                                  int64_t n, int B, int C, int X, int Y, int Z, float *values,
                                   int channels_first, mfStream_t stream);
 int mf_interpolate_voxel_grid_bwd(const float *gvalues, const float *points,
-                                  const int32_t *batch_indices, int64_t n, int B, int C,
-                                  int X, int Y, int Z, float *gvox, int channels_first,
-                                  mfStream_t stream);
+                                  const int32_t *batch_indices, const int32_t *batch_start,
+                                  int64_t n, int B, int C, int X, int Y, int Z, float *gvox,
+                                  int channels_first, mfStream_t stream);
 
 /* ---- A5 occupancy_grid_3d -------------------------------------------------
  * replaces the dense [X,Y,Z,P] composite
@@ -175,10 +180,15 @@ typedef struct {
   float sdf_offset;
 } mfIccBatch;
 
-int64_t mf_icc_workspace_bytes(int32_t n_objects, int32_t n_scenes, int32_t dim);
+/* Bytes of workspace for this batch (negative: invalid descriptor).  Holds the winners of every
+ * grid, partial sums, and the per-iteration x-plane bins of voxel-frame point records:
+ * (dim + 2h) * max_scene_objects * n_points * 16 B of address space, of which one iteration
+ * touches only the points that fall inside a grid. */
+int64_t mf_icc_workspace_bytes(const mfIccBatch *batch);
 
 /* Once per batch (and again whenever its point / grid_target arrays change): model-frame
- * bounding spheres, scene tables and sum(grid_target) per scene into the workspace. */
+ * bounding spheres, scene tables, sum(grid_target) per scene, the (target grid, source object,
+ * point chunk) table and the bin offsets into the workspace. */
 int mf_icc_prepare(const mfIccBatch *batch, void *ws, mfStream_t stream);
 
 /* One forward+backward: loss [S], gq [O,4], gt [O,3]; q,t not modified.
@@ -195,9 +205,10 @@ int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float *adam_m,
                   float alpha_t, float *losses, float *traj, void *ws,
                   mfStream_t stream);
 
-/* Measurement hook: launch ONLY the first kernel of an ICC iteration (k_icc_tdf, the
- * dominant hand-written kernel) so that bench.py can time it with HIP events.  If q and t
- * are non-NULL the rotation matrices are refreshed from them first (separate tiny launch). */
+/* Measurement hook: launch ONLY the TDF front end of an ICC iteration (k_icc_bin + k_icc_tile:
+ * pose -> world points -> x-plane bins -> per-grid (min distance, arg-min) winners) so that
+ * bench.py can time it with HIP events.  If q and t are non-NULL the rotation matrices are
+ * refreshed from them first (separate tiny launch). */
 int mf_icc_launch_tdf(const mfIccBatch *batch, const float *q, const float *t, void *ws,
                       mfStream_t stream);
 

@@ -40,8 +40,8 @@ _SIGNATURES = {
     "mf_average_voxelization_3d_bwd": ([_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p], _i),
     "mf_max_voxelization_3d_fwd": ([_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p], _i),
     "mf_max_voxelization_3d_bwd": ([_p, _p, _i64, _i, _i, _i, _i, _i, _p, _p], _i),
-    "mf_interpolate_voxel_grid_fwd": ([_p, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _i, _p], _i),
-    "mf_interpolate_voxel_grid_bwd": ([_p, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _i, _p], _i),
+    "mf_interpolate_voxel_grid_fwd": ([_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _i, _p], _i),
+    "mf_interpolate_voxel_grid_bwd": ([_p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _i, _p], _i),
     "mf_occupancy_grid_3d_fwd": ([_p, _i64, _f, _f, _f, _f, _i, _i, _i, _f, _p, _p, _p], _i),
     "mf_occupancy_grid_3d_bwd": ([_p, _p, _i64, _f, _f, _f, _f, _i, _i, _i, _f, _p, _p, _p], _i),
     "mf_truncated_distance_function_fwd": ([_p, _i64, _f, _f, _f, _f, _i, _i, _i, _f, _p, _p, _p], _i),
@@ -49,7 +49,7 @@ _SIGNATURES = {
     "mf_pseudo_occupancy_weights": ([_p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p], _i),
     "mf_nn": ([_p, _i64, _p, _i64, _p, _p, _p], _i),
     "mf_icp_loss_grad": ([_p, _i64, _p, _i64, _p, _f, _p, _p], _i),
-    "mf_icc_workspace_bytes": ([ctypes.c_int32, ctypes.c_int32, ctypes.c_int32], _i64),
+    "mf_icc_workspace_bytes": ([ctypes.POINTER(IccBatch)], _i64),
     "mf_icc_launch_tdf": ([ctypes.POINTER(IccBatch), _p, _p, _p, _p], _i),
     "mf_icc_prepare": ([ctypes.POINTER(IccBatch), _p, _p], _i),
     "mf_icc_loss_grad": ([ctypes.POINTER(IccBatch), _p, _p, _p, _p, _p, _p, _p], _i),

@@ -66,8 +66,6 @@ class IccScenes:
         self.origin = torch.cat(origin).contiguous()
         self.grid_target = torch.cat(gt).contiguous()
         self.grid_ne = torch.cat(gne).contiguous()
-        nbytes = L.mf_icc_workspace_bytes(self.n_objects, self.n_scenes, voxel_dim)
-        self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         self.desc = _lib.IccBatch(
             self.pts4.data_ptr(), self.obj_off.data_ptr(), self.scene_off.data_ptr(),
             self.obj_scene.data_ptr(), self.pitch.data_ptr(), self.origin.data_ptr(),
@@ -75,6 +73,10 @@ class IccScenes:
             self.n_points, voxel_dim,
             max(scene_off[i + 1] - scene_off[i] for i in range(len(scenes))),
             float(voxel_threshold), float(sdf_offset))
+        nbytes = L.mf_icc_workspace_bytes(ctypes.byref(self.desc))
+        if nbytes < 0:
+            raise ValueError("mf_icc: invalid batch descriptor (objects per scene <= 32, dim <= 64)")
+        self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         _lib.check(L.mf_icc_prepare(ctypes.byref(self.desc), self.ws.data_ptr(), _lib.stream_ptr()),
                    "mf_icc_prepare")
 

@@ -105,6 +105,7 @@ class Model(nn.Module):
         to_center = (self._voxel_dim / 2.0 - 0.5) - points
         batch_indices = torch.arange(B, dtype=torch.int32, device=values.device).repeat_interleave(P)
         indices = points.transpose(1, 2).reshape(B * P, 3).contiguous()
+        batch_start = torch.arange(B + 1, dtype=torch.int32, device=values.device) * P
 
         h_rgb = F.relu(self.conv1_rgb(values))
         h_pcd = F.relu(self.conv1_pcd(to_center))
@@ -129,12 +130,12 @@ class Model(nn.Module):
             h = F.relu(self.conv3(voxelized))
         assert h.shape == (B, 256, 16, 16, 16)
         feat3 = functions_module.interpolate_voxel_grid(h.float(), indices / 2.0, batch_indices,
-                                                        channels_first=True)
+                                                        channels_first=True, batch_start=batch_start)
         feat3 = feat3.reshape(256, B, P).transpose(0, 1)
         h = F.relu(self.conv4(h))
         assert h.shape == (B, 512, 8, 8, 8)
         feat4 = functions_module.interpolate_voxel_grid(h.float(), indices / 4.0, batch_indices,
-                                                        channels_first=True)
+                                                        channels_first=True, batch_start=batch_start)
         feat4 = feat4.reshape(512, B, P).transpose(0, 1)
         dt = feat1.dtype
         return torch.cat((feat1, feat2, feat3.to(dt), feat4.to(dt)), dim=1)

@@ -72,6 +72,14 @@ struct IccArgs {
   int max_ns;
   int32_t *step;          // [S] (unused scratch)
   int4 *meta;             // [O] {scene first object, scene end object, point begin, point end}
+  // x-plane bins of the per-iteration point binning (k_icc_bin -> k_icc_tile)
+  int4 *tab;              // [n_tab] {target object o, source object j, point begin, point end}; o < 0: unused
+  int n_tab;
+  int nbins;              // D + 2h planes: rounded x in [-h, D-1+h]
+  uint32_t *bin_cnt;      // [2*O][nbins] records in each bin (zero between iterations)
+  int32_t *bin_cap;       // [2*O] capacity of each bin of grid g = number of its source points
+  int64_t *bin_base;      // [2*O] first record of grid g's bins; bin b starts at base + b*cap
+  float4 *rec;            // records {fx, fy, fz, point id bits}: voxel-frame coordinates
   int dbg;                // tuning aid: MF_ICC_DEBUG bit mask (0 in production)
 };
 
@@ -126,6 +134,17 @@ __device__ __forceinline__ void quat_backward(const float *q, const float *gR, f
   const float dot = ((gqs[0] * q[0] + gqs[1] * q[1]) + gqs[2] * q[2]) + gqs[3] * q[3];
 #pragma unroll
   for (int i = 0; i < 4; ++i) gq[i] = s * gqs[i] - (s / n) * dot * q[i];
+}
+
+// Kernel size of one grid: truncated_distance_function.py:36-38 evaluates
+// ceil(truncation / pitch) in float32 with truncation = threshold * pitch
+// (:184), made odd.  For threshold 2 (the link's default) the quotient is exactly 2 -> 3;
+// for other thresholds it depends on the rounding of the two float32 operations, i.e. on the
+// grid's pitch -- so it is evaluated per grid, like the reference does.
+__device__ __forceinline__ int ksize_of(float thr, float pitch) {
+  int ks = (int)ceilf((thr * pitch) / pitch);
+  if (ks % 2 == 0) ks += 1;
+  return ks;
 }
 
 // ---- setup: bounding spheres, sum(grid_target) per scene, R|t from (q,t) -----------
@@ -454,6 +473,369 @@ __global__ __launch_bounds__(kTdfThreads, 8) void k_icc_tdf(IccArgs a, int ks_rt
   stamp(4);
 }
 
+// ---- v2 front end: per-iteration x-plane binning + bin-fed TDF tiles -----------------
+// v1's k_icc_tdf lets every one of the 32 plane workgroups of a grid re-scan all source points of
+// the scene (32x read amplification, a dependent global load per work item).  v2 transforms every
+// (source point, target grid) pair ONCE (k_icc_bin), appends the survivors' voxel-frame
+// coordinates to the bin of their rounded x-plane, and the tile of plane x reads only bins
+// x-h..x+h (k_icc_tile): records arrive as coalesced 16 B loads, both LDS passes run on
+// registers + LDS only.  Coordinates are computed with the oracle's expressions, the candidate
+// set of a tile is exactly v1's survivor set, (min, arg-min) are exact -> bit-identical winners.
+constexpr int kBinThreads = 256;
+constexpr int kBinPPT = 4;                          // points per thread
+constexpr int kBinChunk = kBinThreads * kBinPPT;    // points per workgroup
+constexpr int kMaxBins = 64 + 6;                    // D <= 64, ks <= 7
+
+// Once per batch: bin capacities/offsets per grid and the (target, source, point chunk) table.
+__global__ __launch_bounds__(256) void k_icc_tables(IccArgs a) {
+  __shared__ int s_tab_base[1];
+  if (threadIdx.x == 0) {
+    int64_t rec_off = 0;
+    int tab_off = 0;
+    for (int o = 0; o < a.O; ++o) {
+      const int sc = a.obj_scene[o];
+      const int ja = a.scene_off[sc], jb = a.scene_off[sc + 1];
+      const int p_own = a.obj_off[o + 1] - a.obj_off[o];
+      const int p_all = a.obj_off[jb] - a.obj_off[ja];
+      a.bin_cap[2 * o] = p_own;
+      a.bin_base[2 * o] = rec_off;
+      rec_off += (int64_t)a.nbins * p_own;
+      a.bin_cap[2 * o + 1] = p_all - p_own;
+      a.bin_base[2 * o + 1] = rec_off;
+      rec_off += (int64_t)a.nbins * (p_all - p_own);
+      for (int j = ja; j < jb; ++j) {
+        const int p0 = a.obj_off[j], p1 = a.obj_off[j + 1];
+        for (int c = p0; c < p1; c += kBinChunk)
+          if (tab_off < a.n_tab) a.tab[tab_off++] = make_int4(o, j, c, min(c + kBinChunk, p1));
+      }
+    }
+    s_tab_base[0] = tab_off;
+  }
+  __syncthreads();
+  for (int i = s_tab_base[0] + threadIdx.x; i < a.n_tab; i += blockDim.x) a.tab[i] = make_int4(-1, -1, 0, 0);
+  for (int i = threadIdx.x; i < 2 * a.O * a.nbins; i += blockDim.x) a.bin_cnt[i] = 0u;
+}
+
+// launch 1: one workgroup per (target grid, source object, chunk of <= 1024 points)
+__global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax) {
+  __shared__ int s_cnt[kMaxBins], s_base[kMaxBins];
+  auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
+    if ((a.dbg & 32) && threadIdx.x == 0 && blockIdx.x < 1024)
+      g_dbg_stamps[(3072 + blockIdx.x) * 8 + i] = wall_clock64();
+  };
+  stamp(0);
+  const int4 e = a.tab[blockIdx.x];
+  const int o = e.x, j = e.y;
+  if (o < 0) return;  // block-uniform
+  const int D = a.D, nb = a.nbins;
+  const int g = 2 * o + (j != o ? 1 : 0);
+  // everything below depends on the table entry only: one memory round trip
+  const float4 r0 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j);
+  const float4 r1 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 4);
+  const float4 r2 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 8);
+  const float4 bnd = *reinterpret_cast<const float4 *>(a.bound + 4 * j);
+  const float pitch = a.pitch[o];
+  const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
+  const int cap = a.bin_cap[g];
+  const int64_t base_g = a.bin_base[g];
+  float4 m[kBinPPT];
+#pragma unroll
+  for (int u = 0; u < kBinPPT; ++u) {
+    const int p = e.z + u * kBinThreads + (int)threadIdx.x;
+    m[u] = p < e.w ? a.pts4[p] : make_float4(0, 0, 0, 0);
+  }
+  for (int i = threadIdx.x; i < nb; i += kBinThreads) s_cnt[i] = 0;
+  const float R0 = r0.x, R1 = r0.y, R2 = r0.z, R3 = r0.w, R4 = r1.x, R5 = r1.y, R6 = r1.z,
+              R7 = r1.w, R8 = r2.x, T0 = r2.y, T1 = r2.z, T2 = r2.w;
+  const int h = min(ksize_of(a.thr, pitch) / 2, hmax);
+  const float fh = (float)h, inv_pitch = 1.0f / pitch;
+  {
+    // whole-object rejection with the model's bounding sphere (conservative, block-uniform)
+    const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
+    const float cx = (((R0 * bnd.x + R1 * bnd.y) + R2 * bnd.z) + T0 - ox) * inv_pitch;
+    const float cy = (((R3 * bnd.x + R4 * bnd.y) + R5 * bnd.z) + T1 - oy) * inv_pitch;
+    const float cz = (((R6 * bnd.x + R7 * bnd.y) + R8 * bnd.z) + T2 - oz) * inv_pitch;
+    const float r = bnd.w * inv_pitch + 0.05f + 1e-4f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
+    const bool hit = bnd.w >= 0.0f && !(cx + r < glo || cx - r > ghi || cy + r < glo ||
+                                         cy - r > ghi || cz + r < glo || cz - r > ghi);
+    if (!hit) return;
+  }
+  __syncthreads();
+  float fx[kBinPPT], fy[kBinPPT], fz[kBinPPT];
+  int bin[kBinPPT], slot[kBinPPT];
+#pragma unroll
+  for (int u = 0; u < kBinPPT; ++u) {
+    const int p = e.z + u * kBinThreads + (int)threadIdx.x;
+    bin[u] = -1;
+    slot[u] = 0;
+    if (p < e.w) {
+      // transform_points: ((R0 x + R1 y) + R2 z) + t, un-fused (oracle order), then
+      // (p - origin) / pitch with a correctly rounded divide (voxelization_3d index rule)
+      const float wx = ((R0 * m[u].x + R1 * m[u].y) + R2 * m[u].z) + T0;
+      const float wy = ((R3 * m[u].x + R4 * m[u].y) + R5 * m[u].z) + T1;
+      const float wz = ((R6 * m[u].x + R7 * m[u].y) + R8 * m[u].z) + T2;
+      fx[u] = (wx - ox) / pitch; fy[u] = (wy - oy) / pitch; fz[u] = (wz - oz) / pitch;
+      const float rx = roundf(fx[u]), ry = roundf(fy[u]), rz = roundf(fz[u]);
+      const bool surv = rx + fh >= 0.0f && rx - fh < (float)D && ry + fh >= 0.0f &&
+                        ry - fh < (float)D && rz + fh >= 0.0f && rz - fh < (float)D;
+      if (surv) {
+        bin[u] = (int)rx + hmax;  // in [0, D + 2 hmax)
+        slot[u] = atomicAdd(&s_cnt[bin[u]], 1);
+      }
+    }
+  }
+  __syncthreads();
+  stamp(1);
+  for (int i = threadIdx.x; i < nb; i += kBinThreads) {
+    const int c = s_cnt[i];
+    s_base[i] = c > 0 ? (int)atomicAdd(&a.bin_cnt[(int64_t)g * nb + i], (uint32_t)c) : 0;
+  }
+  __syncthreads();
+  stamp(2);
+#pragma unroll
+  for (int u = 0; u < kBinPPT; ++u) {
+    if (bin[u] < 0) continue;
+    const int idx = s_base[bin[u]] + slot[u];
+    if (idx >= cap) continue;  // cannot happen while bin_cnt starts at zero; never write out of bounds
+    const int p = e.z + u * kBinThreads + (int)threadIdx.x;
+    a.rec[base_g + (int64_t)bin[u] * cap + idx] = make_float4(fx[u], fy[u], fz[u], __uint_as_float((uint32_t)p));
+  }
+  stamp(3);
+}
+
+// launch 2: TDF of one x-plane of one grid, fed from bins x-h..x+h.
+//  pass 1 works on SQUARED distances in voxel units (no sqrt, no pitch): 32-bit atomicMin of
+//         the d2 bits behind a peek.  dist = pitch*sqrt(d2) is monotone in d2.
+//  pass 2 re-derives, only for records that touched a minimum, the EXACT float distance of
+//         near-minimal candidates (d2 within a few ulp) and, where it equals the exact minimum
+//         and is < truncation, takes atomicMin of the candidate id: the same winners as
+//         the oracle (lowest id among equal ROUNDED distances).
+constexpr int kTileThreads = 512;
+constexpr int kTileKeep = 6;  // records per lane kept in registers over both passes
+constexpr int kTileR = 4;     // records in flight per lane beyond those
+
+template <int KS>
+__device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt, const int hmax) {
+  MF_DYN_LDS(uint32_t, s_tile);  // dist[D*D], id[D*D]
+  __shared__ float s_max[kTileThreads / 64];
+  const int ks = KS > 0 ? KS : ks_rt;
+  const int h = ks / 2, K = ks * ks * ks;
+  const int D = a.D, nvox = D * D, nb = a.nbins;
+  const int g = blockIdx.y, o = g >> 1, other = g & 1, x = blockIdx.x;
+  uint32_t *s_dist = s_tile, *s_id = s_tile + nvox;
+  // independent loads: the <= 7 bin counts of this tile, capacity, offset
+  int c[8];
+  c[0] = 0;
+  const int cap = a.bin_cap[g];
+  const int64_t base_g = a.bin_base[g];
+  const float pitch = a.pitch[o];
+  const int bin0 = x + hmax - h;  // bin of plane x - h
+#pragma unroll
+  for (int b = 0; b < 7; ++b) {
+    int n = 0;
+    if (b < ks) n = min((int)a.bin_cnt[(int64_t)g * nb + bin0 + b], cap);
+    c[b + 1] = c[b] + n;
+  }
+  const int T = c[7];
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
+    if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
+  };
+  stamp(0);
+  if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)T;
+  const float trunc = a.thr * pitch;
+  for (int i = threadIdx.x; i < nvox; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
+  __syncthreads();
+  const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test in pass 2
+  const float d2_in = a.thr * a.thr * 0.999f;    // certainly inside the truncation radius
+  const float4 *recs = a.rec + base_g + (int64_t)bin0 * cap;
+  const float fxp = (float)x;
+
+  // record i of this tile's concatenated bins -> (bin b, record); rb < 0: none
+  auto fetch = [&](const int i, float4 &rv, int &rb) {
+    rb = -1;
+    if (i >= T) return;
+    int b = 0;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) b += (k < ks && i >= c[k]) ? 1 : 0;
+    int cb = 0;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) cb = (k == b) ? c[k] : cb;
+    rb = b;
+    rv = recs[(int64_t)b * cap + (i - cb)];
+  };
+  // One record against its ks x ks (y, z) candidates in plane x.  What bounds this kernel is
+  // the LDS round trip, not arithmetic: all peeks of a record are issued together (KS == 3:
+  // nine independent ds_read), then the non-returning atomics.  A peek may be stale (another
+  // lane lowered the voxel meanwhile): values only decrease, so a stale peek only lets MORE
+  // candidates through -- the atomicMin / the exact test of pass 2 decide.
+  // `part` splits pass 1: 0 = the centre candidate only (the voxel the point rounds to -- its
+  // squared distance is <= 0.75, a tight bound), 1 = the other candidates, 2 = all.  Running
+  // the centres of ALL records first lets the peek reject most of the remaining candidates:
+  // a crowded plane otherwise serialises ~9 same-address LDS atomics per record.
+  auto visit = [&](const int pass, const int part, const float4 sv, const int rb) -> bool {
+    const int iry = (int)roundf(sv.y), irz = (int)roundf(sv.z);
+    const uint32_t idb = __float_as_uint(sv.w) * (uint32_t)K;
+    const int bb = ks - 1 - rb;  // x offset of plane x inside this point's neighbourhood
+    const float dx = sv.x - fxp;
+    const float dx2 = dx * dx;
+    bool cand = false;
+    if constexpr (KS == 3) {
+      uint32_t db[9], cur[9];
+      int ad[9];
+#pragma unroll
+      for (int aa = 0; aa < 3; ++aa) {
+        const int iy = iry + aa - 1;
+        const float dy = sv.y - (float)iy;
+        const float dxy = dx2 + dy * dy;  // (dx^2 + dy^2) + dz^2: the oracle's order
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          const int iz = irz + cc - 1;
+          const float dz = sv.z - (float)iz;
+          const float d2 = dxy + dz * dz;
+          const int k = aa * 3 + cc;
+          const bool ok = iy >= 0 && iy < D && iz >= 0 && iz < D && d2 < d2_hi &&
+                          (part == 2 || (part == 0) == (k == 4));
+          db[k] = __float_as_uint(d2);
+          ad[k] = ok ? iy * D + iz : -1;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        if (part != 0 || k == 4) cur[k] = s_dist[ad[k] < 0 ? 0 : ad[k]];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        if (part == 0 && k != 4) continue;
+        if (ad[k] < 0) continue;
+        if (pass == 1) {
+          if (db[k] <= cur[k]) { atomicMin(&s_dist[ad[k]], db[k]); cand = true; }
+        } else if (db[k] <= cur[k] + 8u) {  // within a few ulp of the minimal d2
+          // dist == dmin is certain for equal bits; dist < trunc is certain well inside the
+          // truncation radius (pitch*sqrt(d2) <= 0.9995 thr pitch (1 + 2^-22) < trunc)
+          bool win = db[k] == cur[k] && __uint_as_float(db[k]) < d2_in;
+          if (!win) {
+            const float dist = pitch * sqrtf(__uint_as_float(db[k]));
+            const float dmin = pitch * sqrtf(__uint_as_float(cur[k]));
+            win = dist == dmin && dist < trunc;
+          }
+          if (win) atomicMin(&s_id[ad[k]], idb + (uint32_t)(((k / 3) * 3 + bb) * 3 + (k % 3)));
+        }
+      }
+    } else {
+      if (part == 1) return false;  // generic kernel size: everything in the first part
+      for (int aa = 0; aa < ks; ++aa) {
+        const int iy = iry + aa - h;
+        if (iy < 0 || iy >= D) continue;
+        const float dy = sv.y - (float)iy;
+        const float dxy = dx2 + dy * dy;
+        const int lrow = iy * D;
+        for (int cc = 0; cc < ks; ++cc) {
+          const int iz = irz + cc - h;
+          if (iz < 0 || iz >= D) continue;
+          const float dz = sv.z - (float)iz;
+          const float d2 = dxy + dz * dz;
+          if (!(d2 < d2_hi)) continue;
+          const uint32_t db = __float_as_uint(d2);
+          const uint32_t cur = s_dist[lrow + iz];
+          if (pass == 1) {
+            if (db <= cur) { atomicMin(&s_dist[lrow + iz], db); cand = true; }
+          } else if (db <= cur + 8u) {
+            const float dist = pitch * sqrtf(d2);
+            const float dmin = pitch * sqrtf(__uint_as_float(cur));
+            if (dist == dmin && dist < trunc)
+              atomicMin(&s_id[lrow + iz], idb + (uint32_t)((aa * ks + bb) * ks + cc));
+          }
+        }
+      }
+    }
+    return cand;
+  };
+
+  // The first kTileThreads * kTileKeep records stay in registers over both passes (all loads
+  // in flight at once: ONE memory round trip); a more crowded tile streams the rest again.
+  float4 rv[kTileKeep];
+  int rb[kTileKeep];
+  unsigned keep_cand = 0u;  // bit u: record u touched a minimum in pass 1
+#pragma unroll
+  for (int u = 0; u < kTileKeep; ++u) fetch(u * kTileThreads + (int)threadIdx.x, rv[u], rb[u]);
+  stamp(1);
+#pragma unroll
+  for (int u = 0; u < kTileKeep; ++u)
+    if (rb[u] >= 0 && visit(1, 0, rv[u], rb[u])) keep_cand |= 1u << u;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kTileKeep; ++u)
+    if (rb[u] >= 0 && visit(1, 1, rv[u], rb[u])) keep_cand |= 1u << u;
+  for (int base = kTileThreads * kTileKeep; base < T; base += kTileThreads * kTileR) {
+    float4 xv[kTileR];
+    int xb[kTileR];
+#pragma unroll
+    for (int u = 0; u < kTileR; ++u) fetch(base + u * kTileThreads + (int)threadIdx.x, xv[u], xb[u]);
+#pragma unroll
+    for (int u = 0; u < kTileR; ++u)
+      if (xb[u] >= 0) visit(1, 2, xv[u], xb[u]);
+  }
+  __syncthreads();
+  stamp(2);
+#pragma unroll
+  for (int u = 0; u < kTileKeep; ++u)
+    if ((keep_cand >> u) & 1u) visit(2, 2, rv[u], rb[u]);
+  for (int base = kTileThreads * kTileKeep; base < T; base += kTileThreads * kTileR) {
+    float4 xv[kTileR];
+    int xb[kTileR];
+#pragma unroll
+    for (int u = 0; u < kTileR; ++u) fetch(base + u * kTileThreads + (int)threadIdx.x, xv[u], xb[u]);
+#pragma unroll
+    for (int u = 0; u < kTileR; ++u)
+      if (xb[u] >= 0) visit(2, 2, xv[u], xb[u]);
+  }
+  __syncthreads();
+  stamp(3);
+  // epilogue: winners out (coalesced 8 B/lane) + max raw inside weight of this tile
+  // (truncated_distance_function.py:198-204: -1 where no winner, + offset, clamp at 0)
+  const float offset = other ? 0.0f : a.sdf_offset;
+  unsigned long long *Wg = a.W + (int64_t)g * D * D * D + (int64_t)x * nvox;
+  float wmax = 0.0f;
+  for (int i0 = threadIdx.x; i0 < nvox; i0 += kTileThreads * 4) {
+    uint32_t lo[4];
+    float sd[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kTileThreads;
+      lo[u] = i < nvox ? s_id[i] : kNoCand;  // set only where pitch*sqrt(min d2) < trunc
+      sd[u] = lo[u] != kNoCand ? a.pts4[lo[u] / (uint32_t)K].w : -1.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kTileThreads;
+      if (i >= nvox) continue;
+      const float dist = lo[u] != kNoCand ? pitch * sqrtf(__uint_as_float(s_dist[i])) : trunc;
+      Wg[i] = ((unsigned long long)__float_as_uint(dist) << 32) | lo[u];
+      float w = sd[u] + offset;
+      w = w < 0.0f ? 0.0f : w;
+      wmax = fmaxf(wmax, w);
+    }
+  }
+  wmax = mf::wave_max(wmax);
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = wmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = s_max[0];
+#pragma unroll
+    for (int i = 1; i < kTileThreads / 64; ++i) m = fmaxf(m, s_max[i]);
+    if (m > 0.0f) atomicMax(&a.Mbits[g], __float_as_uint(m));  // m >= 0: uint order == float order
+  }
+  stamp(4);
+}
+
+__global__ __launch_bounds__(kTileThreads) void k_icc_tile(IccArgs a, int hmax) {
+  const int ks = min(ksize_of(a.thr, a.pitch[blockIdx.y >> 1]), 2 * hmax + 1);  // block-uniform
+  if (ks == 3)
+    icc_tile_body<3>(a, 3, hmax);
+  else
+    icc_tile_body<0>(a, ks, hmax);
+}
+
 // ---- launch 2: weights, sums, gradient moments ------------------------------------
 __device__ __forceinline__ void world_frac(const float *Rt, const float4 m, float ox, float oy,
                                            float oz, float pitch, int ix, int iy, int iz,
@@ -471,7 +853,7 @@ __device__ __forceinline__ void world_frac(const float *Rt, const float4 m, floa
 
 constexpr int kVPT = kVoxPerBlock / kAccThreads;  // voxels per thread
 
-__global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
+__global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K_v1) {
   __shared__ float s_tr[kAccThreads * kNumOwn];
   // collision moments as 2^44 fixed point split in three 20-bit limbs held in 32-bit LDS
   // words: <= 1024 adds per block can never overflow a limb, so plain NON-returning
@@ -496,7 +878,13 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K) {
   if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
   for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) { s_l0[i] = 0u; s_l1[i] = 0u; s_l2[i] = 0; }
+  // this object's two grids have been consumed by k_icc_tile: empty their bins for the next k_icc_bin
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < 2 * a.nbins; i += kAccThreads) a.bin_cnt[(int64_t)2 * o * a.nbins + i] = 0u;
   const float pitch = a.pitch[o];
+  // candidate ids are point * K + offset with this grid's own kernel size (K_v1: round-1 front end)
+  const int ks_o = ksize_of(a.thr, pitch);
+  const int K = K_v1 > 0 ? K_v1 : ks_o * ks_o * ks_o;
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
   const float M_own = __uint_as_float(a.Mbits[2 * o]);
   const float M_oth = __uint_as_float(a.Mbits[2 * o + 1]);
@@ -802,14 +1190,27 @@ __global__ void k_pack(const float *__restrict__ points, const float *__restrict
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 struct WsLayout {
-  int64_t W, M, Rt, bound, St, part, oth, step, meta, total;
-  int NB;
+  int64_t W, M, Rt, bound, St, part, oth, step, meta, tab, bin_cnt, bin_cap, bin_base, rec, total;
+  int NB, n_tab, nbins;
 };
 
-WsLayout ws_layout(int O, int S, int D, int max_ns = kMaxSceneObjects) {
+int ksize_host(float thr) {
+  // Upper bound of the per-grid kernel size ksize_of(thr, pitch): the float32 quotient
+  // (thr * pitch) / pitch is within 2 ulp of thr (exactly thr for thr = 2, the link's default).
+  int ks = (int)ceilf(thr * 1.000001f);
+  if (ks % 2 == 0) ks += 1;
+  return ks;
+}
+
+WsLayout ws_layout(const mfIccBatch *b) {
   WsLayout l;
+  const int O = b->n_objects, S = b->n_scenes, D = b->dim, max_ns = b->max_scene_objects;
   const int64_t V = (int64_t)D * D * D;
   l.NB = (int)((V + kVoxPerBlock - 1) / kVoxPerBlock);
+  l.nbins = D + 2 * (ksize_host(b->voxel_threshold) / 2);
+  // every (target, source) pair of a scene in chunks of kBinChunk points:
+  // sum_pairs ceil(P_j / chunk) <= max_ns * n_points / chunk + O * max_ns
+  l.n_tab = (int)(((int64_t)max_ns * b->n_points + kBinChunk - 1) / kBinChunk) + O * max_ns;
   int64_t off = 0;
   l.W = off; off = align256(off + 2 * O * V * 8);
   l.M = off; off = align256(off + 2 * O * 4);
@@ -817,9 +1218,16 @@ WsLayout ws_layout(int O, int S, int D, int max_ns = kMaxSceneObjects) {
   l.bound = off; off = align256(off + O * 4 * 4);
   l.St = off; off = align256(off + S * 4);
   l.part = off; off = align256(off + (int64_t)O * l.NB * kNumOwn * 4);
-  l.oth = off; off = align256(off + (int64_t)O * l.NB * max_ns * 12 * 4);
+  l.oth = off; off = align256(off + (int64_t)O * l.NB * kMaxSceneObjects * 12 * 4);
   l.step = off; off = align256(off + S * 4);
   l.meta = off; off = align256(off + (int64_t)O * 16);
+  l.tab = off; off = align256(off + (int64_t)l.n_tab * 16);
+  l.bin_cnt = off; off = align256(off + (int64_t)2 * O * l.nbins * 4);
+  l.bin_cap = off; off = align256(off + (int64_t)2 * O * 4);
+  l.bin_base = off; off = align256(off + (int64_t)2 * O * 8);
+  // a grid's bins hold <= (its source points) records each: sum over grids of a scene
+  // = Ns * P_scene <= max_ns * n_points, times nbins planes
+  l.rec = off; off = align256(off + (int64_t)l.nbins * max_ns * b->n_points * 16);
   l.total = off;
   return l;
 }
@@ -841,7 +1249,7 @@ IccArgs make_args(const mfIccBatch *b, void *ws, int max_ns) {
   a.sdf_offset = b->sdf_offset;
   a.max_ns = max_ns;
   a.dbg = getenv("MF_ICC_DEBUG") ? atoi(getenv("MF_ICC_DEBUG")) : 0;
-  const WsLayout l = ws_layout(a.O, a.S, a.D);
+  const WsLayout l = ws_layout(b);
   char *p = (char *)ws;
   a.W = (unsigned long long *)(p + l.W);
   a.Mbits = (uint32_t *)(p + l.M);
@@ -852,29 +1260,46 @@ IccArgs make_args(const mfIccBatch *b, void *ws, int max_ns) {
   a.oth = (float *)(p + l.oth);
   a.step = (int32_t *)(p + l.step);
   a.meta = (int4 *)(p + l.meta);
+  a.tab = (int4 *)(p + l.tab);
+  a.n_tab = l.n_tab;
+  a.nbins = l.nbins;
+  a.bin_cnt = (uint32_t *)(p + l.bin_cnt);
+  a.bin_cap = (int32_t *)(p + l.bin_cap);
+  a.bin_base = (int64_t *)(p + l.bin_base);
+  a.rec = (float4 *)(p + l.rec);
   return a;
 }
 
-int ksize_host(float thr) {
-  // truncation / pitch == thr exactly (truncation = thr * pitch in float32 is exact for
-  // thr = 2; for other thresholds the float32 quotient is what the reference evaluates)
-  int ks = (int)ceilf(thr);
-  if (ks % 2 == 0) ks += 1;
-  return ks;
+// MF_ICC_IMPL=1 keeps round 1's scan-everything front end (k_icc_tdf) for A/B measurements
+int icc_impl() {
+  static const int impl = getenv("MF_ICC_IMPL") ? atoi(getenv("MF_ICC_IMPL")) : 2;
+  return impl;
+}
+
+void launch_front(const IccArgs &a, int ks, int SX, hipStream_t stream) {
+  const int D = a.D;
+  if (icc_impl() == 1) {
+    const dim3 g1((D + SX - 1) / SX, 2 * a.O);
+    const size_t lds1 = (size_t)SX * D * D * 2 * sizeof(uint32_t);
+    if (ks == 3)
+      hipLaunchKernelGGL(k_icc_tdf<3>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
+    else
+      hipLaunchKernelGGL(k_icc_tdf<0>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
+    return;
+  }
+  const int hmax = (a.nbins - D) / 2;
+  hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, hmax);
+  const size_t lds = (size_t)D * D * 2 * sizeof(uint32_t);
+  hipLaunchKernelGGL(k_icc_tile, dim3(D, 2 * a.O), dim3(kTileThreads), lds, stream, a, hmax);
 }
 
 void launch_iteration(const IccArgs &a, int ks, int SX, int NB, int max_ns, int mode, float *q,
                       float *t, float *adam_m, float *adam_v, float alpha_q, float alpha_t,
                       int adam_step, float *loss, float *gq, float *gt, float *traj, int it,
                       hipStream_t stream) {
-  const int D = a.D;
-  const dim3 g1((D + SX - 1) / SX, 2 * a.O);
-  const size_t lds1 = (size_t)SX * D * D * 2 * sizeof(uint32_t);
-  if (ks == 3)
-    hipLaunchKernelGGL(k_icc_tdf<3>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
-  else
-    hipLaunchKernelGGL(k_icc_tdf<0>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
-  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), 0, stream, a, ks * ks * ks);
+  launch_front(a, ks, SX, stream);
+  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), 0, stream, a,
+                     icc_impl() == 1 ? ks * ks * ks : 0);
   // chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once
   const double fix1 = 1.0 - pow(0.9, (double)adam_step), fix2 = 1.0 - pow(0.999, (double)adam_step);
   const float aq = (float)((double)alpha_q * sqrt(fix2) / fix1);
@@ -893,8 +1318,16 @@ std::mutex g_graph_mu;
 
 }  // namespace
 
-extern "C" int64_t mf_icc_workspace_bytes(int32_t n_objects, int32_t n_scenes, int32_t dim) {
-  return ws_layout(n_objects, n_scenes, dim).total;
+static bool icc_batch_ok(const mfIccBatch *b) {
+  return b && b->n_objects > 0 && b->n_scenes > 0 && b->dim > 0 && b->dim <= 64 &&
+         b->n_points >= 0 && b->max_scene_objects > 0 && b->max_scene_objects <= kMaxSceneObjects &&
+         b->voxel_threshold > 0.0f && ksize_host(b->voxel_threshold) <= 7 &&
+         (double)b->n_points * 343.0 < 4294967295.0 && b->n_points < (1 << 27);
+}
+
+extern "C" int64_t mf_icc_workspace_bytes(const mfIccBatch *batch) {
+  if (!icc_batch_ok(batch)) return -1;
+  return ws_layout(batch).total;
 }
 
 extern "C" int mf_pack_points_sdf(const float *points, const float *sdf, int64_t n, void *pts4,
@@ -907,26 +1340,16 @@ extern "C" int mf_pack_points_sdf(const float *points, const float *sdf, int64_t
 }
 
 static int icc_prepare_kernels() {
-  static bool done = false;
-  if (done) return 0;
-  // static + dynamic LDS above 64 KB is opt-in
-  MF_TRY(hipFuncSetAttribute((const void *)k_icc_tdf<3>,
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  MF_TRY(hipFuncSetAttribute((const void *)k_icc_tdf<0>,
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  MF_TRY(hipFuncSetAttribute((const void *)k_icc_step,
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-  done = true;
-  return 0;
+  // static + dynamic LDS above 64 KB is opt-in (per device, thread-safe: mf::allow_big_lds)
+  if (int e = mf::allow_big_lds((const void *)k_icc_tdf<3>, 64 * 1024)) return e;
+  if (int e = mf::allow_big_lds((const void *)k_icc_tdf<0>, 64 * 1024)) return e;
+  return mf::allow_big_lds((const void *)k_icc_step, 150 * 1024);
 }
 
 static int icc_validate(const mfIccBatch *b) {
   if (int e = icc_prepare_kernels()) return e;
-  if (!b || b->n_objects <= 0 || b->n_scenes <= 0 || b->dim <= 0 || b->dim > 64 ||
-      b->max_scene_objects <= 0 || b->max_scene_objects > kMaxSceneObjects ||
-      (size_t)b->max_scene_objects * (ws_layout(1, 1, b->dim).NB * kNumOwn + kNumOwn + 12 + 96) * 4 >
-          150 * 1024 ||
-      (double)b->n_points * 343.0 >= 4294967295.0 || b->n_points >= (1 << 27)) {
+  if (!icc_batch_ok(b) ||
+      (size_t)b->max_scene_objects * (ws_layout(b).NB * kNumOwn + kNumOwn + 12 + 96) * 4 > 150 * 1024) {
     mf::set_last_error(hipErrorInvalidValue, "mf_icc: invalid batch descriptor");
     return -(int)hipErrorInvalidValue;
   }
@@ -955,14 +1378,10 @@ extern "C" int mf_icc_launch_tdf(const mfIccBatch *batch, const float *q, const 
   IccArgs a = make_args(batch, ws, batch->max_scene_objects);
   const int ks = ksize_host(a.thr);
   const int SX = slab_planes(a.D, 2 * a.O);
-  const int D = a.D;
   if (q && t) hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t);
-  const dim3 g1((D + SX - 1) / SX, 2 * a.O);
-  const size_t lds1 = (size_t)SX * D * D * 2 * sizeof(uint32_t);
-  if (ks == 3)
-    hipLaunchKernelGGL(k_icc_tdf<3>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
-  else
-    hipLaunchKernelGGL(k_icc_tdf<0>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
+  // inside an iteration k_icc_accum empties the bins; this hook has no accum launch
+  MF_TRY(hipMemsetAsync(a.bin_cnt, 0, sizeof(uint32_t) * 2 * a.O * a.nbins, stream));
+  launch_front(a, ks, SX, stream);
   return mf::check_launch("mf_icc_launch_tdf");
 }
 
@@ -972,6 +1391,7 @@ extern "C" int mf_icc_prepare(const mfIccBatch *batch, void *ws, mfStream_t stre
   IccArgs a = make_args(batch, ws, batch->max_scene_objects);
   hipLaunchKernelGGL(k_icc_bound, dim3(a.O), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(k_icc_scene_setup, dim3(a.S), dim3(256), 0, stream, a, 0);
+  hipLaunchKernelGGL(k_icc_tables, dim3(1), dim3(256), 0, stream, a);
   return mf::check_launch("mf_icc_prepare");
 }
 
@@ -982,7 +1402,7 @@ extern "C" int mf_icc_loss_grad(const mfIccBatch *batch, const float *q, const f
   if (int e = icc_validate(batch)) return e;
   const int max_ns = batch->max_scene_objects;
   IccArgs a = make_args(batch, ws, max_ns);
-  const WsLayout l = ws_layout(a.O, a.S, a.D);
+  const WsLayout l = ws_layout(batch);
   const int ks = ksize_host(a.thr);
   const int SX = slab_planes(a.D, 2 * a.O);
   hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t);
@@ -1000,7 +1420,7 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
   if (n_iter <= 0) return 0;
   const int max_ns = batch->max_scene_objects;
   IccArgs a = make_args(batch, ws, max_ns);
-  const WsLayout l = ws_layout(a.O, a.S, a.D);
+  const WsLayout l = ws_layout(batch);
   const int ks = ksize_host(a.thr);
   const int SX = slab_planes(a.D, 2 * a.O);
 
@@ -1017,7 +1437,9 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
   key.v.push_back(((uint64_t)(uint32_t)a.O << 32) | (uint32_t)a.S);
   key.v.push_back(((uint64_t)(uint32_t)a.D << 32) | (uint32_t)batch->n_points);
   key.v.push_back(((uint64_t)(uint32_t)n_iter << 32) | (uint32_t)step0);
-  key.v.push_back((uint64_t)max_ns);
+  int dev = 0;
+  MF_TRY(hipGetDevice(&dev));
+  key.v.push_back(((uint64_t)(uint32_t)dev << 32) | (uint32_t)max_ns);
 
   std::lock_guard<std::mutex> lock(g_graph_mu);
   auto itg = g_graphs.find(key);
@@ -1025,7 +1447,8 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
     hipGraph_t graph = nullptr;
     // The caller's stream may be the legacy NULL stream (torch's default), which cannot be
     // captured: record the graph on a private stream, replay it on the caller's.
-    static hipStream_t cap = nullptr;
+    static std::map<int, hipStream_t> caps;  // one capture stream per device (under g_graph_mu)
+    hipStream_t &cap = caps[dev];
     if (!cap) MF_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
     MF_TRY(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, cap, a, q, t);

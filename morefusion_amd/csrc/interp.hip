@@ -51,33 +51,95 @@ __device__ __forceinline__ bool plausible(float px, float py, float pz) {
   return fabsf(px) < L && fabsf(py) < L && fabsf(pz) < L;  // false for NaN too
 }
 
+// Candidate rows of batch item b.  With ``batch_start`` (B+1 row offsets: the rows of item b
+// are [batch_start[b], batch_start[b+1]), what the pose network passes) a workgroup visits
+// only its own rows; without it every workgroup filters all n rows by batch_indices, with
+// kScanU index loads in flight per lane (round 1 walked them one dependent load at a time:
+// 15 us of the 31 us kernel at B = 8).  Rows that belong to no item (index outside [0, B) /
+// outside every range) are owned by the workgroups of item 0, which write zeros for them.
+constexpr int kScanU = 8;
+
+template <class F>
+__device__ __forceinline__ void for_rows_of_item(const int32_t *__restrict__ batch_indices,
+                                                 const int32_t *__restrict__ batch_start,
+                                                 int64_t n, int b, int B, F &&visit) {
+  if (batch_start) {
+    const int64_t p0 = batch_start[b], p1 = batch_start[b + 1];
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += kInterpThreads) visit(p, true);
+    if (b == 0) {
+      const int64_t lo = batch_start[0], hi = batch_start[B];
+      for (int64_t p = threadIdx.x; p < n; p += kInterpThreads)
+        if (p < lo || p >= hi) visit(p, false);
+    }
+    return;
+  }
+  for (int64_t base = 0; base < n; base += (int64_t)kInterpThreads * kScanU) {
+    int bi[kScanU];
+#pragma unroll
+    for (int u = 0; u < kScanU; ++u) {
+      const int64_t p = base + (int64_t)u * kInterpThreads + threadIdx.x;
+      bi[u] = p < n ? batch_indices[p] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < kScanU; ++u) {
+      const int64_t p = base + (int64_t)u * kInterpThreads + threadIdx.x;
+      if (p >= n) continue;
+      if (bi[u] == b)
+        visit(p, true);
+      else if (b == 0 && (bi[u] < 0 || bi[u] >= B))
+        visit(p, false);
+    }
+  }
+}
+
+// coalesced copy global -> LDS (or back), kStageU 16 B loads in flight per lane
+constexpr int kStageU = 8;
+
+__device__ __forceinline__ void stage_copy(float *__restrict__ dst, const float *__restrict__ src,
+                                           int total) {
+  if ((total & 3) == 0) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    const int n4 = total / 4;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += kInterpThreads * kStageU) {
+      float4 v[kStageU];
+#pragma unroll
+      for (int u = 0; u < kStageU; ++u) {
+        const int i = i0 + u * kInterpThreads;
+        if (i < n4) v[u] = s4[i];
+      }
+#pragma unroll
+      for (int u = 0; u < kStageU; ++u) {
+        const int i = i0 + u * kInterpThreads;
+        if (i < n4) d4[i] = v[u];
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < total; i += kInterpThreads) dst[i] = src[i];
+  }
+}
+
 // grid: x = channel chunk, y = batch item.  LDS: cpw * V floats.
 __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_lds(
     const float *__restrict__ vox, const float *__restrict__ points,
-    const int32_t *__restrict__ batch_indices, int64_t n, int C, int X, int Y, int Z, int cpw,
-    float *__restrict__ values, int channels_first) {
+    const int32_t *__restrict__ batch_indices, const int32_t *__restrict__ batch_start, int64_t n,
+    int B, int C, int X, int Y, int Z, int cpw, float *__restrict__ values, int channels_first) {
   MF_DYN_LDS(float, s_grid);
   const int b = blockIdx.y;
   const int c0 = blockIdx.x * cpw;
   const int nc = min(cpw, C - c0);
   const int V = X * Y * Z;
-  const float *src = vox + ((int64_t)b * C + c0) * V;
-  const int total = nc * V;
-  if ((V & 3) == 0) {
-    const float4 *s4 = reinterpret_cast<const float4 *>(src);
-    float4 *d4 = reinterpret_cast<float4 *>(s_grid);
-    for (int i = threadIdx.x; i < total / 4; i += kInterpThreads) d4[i] = s4[i];
-  } else {
-    for (int i = threadIdx.x; i < total; i += kInterpThreads) s_grid[i] = src[i];
-  }
+  stage_copy(s_grid, vox + ((int64_t)b * C + c0) * V, nc * V);
   __syncthreads();
-  for (int64_t p = threadIdx.x; p < n; p += kInterpThreads) {
-    if (batch_indices[p] != b) continue;
-    float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+  for_rows_of_item(batch_indices, batch_start, n, b, B, [&](int64_t p, bool mine) {
     Corner k;
-    if (plausible(px, py, pz)) {
-      corners(px, py, pz, X, Y, Z, k);
-    } else {
+    bool ok = false;
+    if (mine) {
+      const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+      ok = plausible(px, py, pz);
+      if (ok) corners(px, py, pz, X, Y, Z, k);
+    }
+    if (!ok) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { k.off[j] = -1; k.w[j] = 0.0f; }
     }
@@ -92,7 +154,7 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_lds(
       else
         values[p * C + c0 + c] = acc;
     }
-  }
+  });
 }
 
 // Fallback for grids too large for LDS: direct gathers (thread per point x channel chunk).
@@ -125,8 +187,8 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_direct(
 
 __global__ __launch_bounds__(kInterpThreads) void k_interp_bwd_lds(
     const float *__restrict__ gvalues, const float *__restrict__ points,
-    const int32_t *__restrict__ batch_indices, int64_t n, int C, int X, int Y, int Z, int cpw,
-    float *__restrict__ gvox, int channels_first) {
+    const int32_t *__restrict__ batch_indices, const int32_t *__restrict__ batch_start, int64_t n,
+    int B, int C, int X, int Y, int Z, int cpw, float *__restrict__ gvox, int channels_first) {
   MF_DYN_LDS(float, s_grid);
   const int b = blockIdx.y;
   const int c0 = blockIdx.x * cpw;
@@ -135,29 +197,22 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_bwd_lds(
   const int total = nc * V;
   for (int i = threadIdx.x; i < total; i += kInterpThreads) s_grid[i] = 0.0f;
   __syncthreads();
-  for (int64_t p = threadIdx.x; p < n; p += kInterpThreads) {
-    if (batch_indices[p] != b) continue;
-    float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
-    if (!plausible(px, py, pz)) continue;
+  for_rows_of_item(batch_indices, batch_start, n, b, B, [&](int64_t p, bool mine) {
+    if (!mine) return;
+    const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+    if (!plausible(px, py, pz)) return;
     Corner k;
     corners(px, py, pz, X, Y, Z, k);
     for (int c = 0; c < nc; ++c) {
-      float g = channels_first ? gvalues[(int64_t)(c0 + c) * n + p] : gvalues[p * C + c0 + c];
+      const float g = channels_first ? gvalues[(int64_t)(c0 + c) * n + p] : gvalues[p * C + c0 + c];
       float *dst = s_grid + c * V;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (k.off[j] >= 0) atomicAdd(&dst[k.off[j]], k.w[j] * g);
     }
-  }
+  });
   __syncthreads();
-  float *out = gvox + ((int64_t)b * C + c0) * V;
-  if ((V & 3) == 0) {
-    float4 *o4 = reinterpret_cast<float4 *>(out);
-    const float4 *s4 = reinterpret_cast<const float4 *>(s_grid);
-    for (int i = threadIdx.x; i < total / 4; i += kInterpThreads) o4[i] = s4[i];
-  } else {
-    for (int i = threadIdx.x; i < total; i += kInterpThreads) out[i] = s_grid[i];
-  }
+  stage_copy(gvox + ((int64_t)b * C + c0) * V, s_grid, total);
 }
 
 __global__ __launch_bounds__(kInterpThreads) void k_interp_bwd_direct(
@@ -195,7 +250,8 @@ int pick_cpw(int C, int B, int64_t V) {
 }  // namespace
 
 extern "C" int mf_interpolate_voxel_grid_fwd(const float *vox, const float *points,
-                                             const int32_t *batch_indices, int64_t n, int B,
+                                             const int32_t *batch_indices,
+                                             const int32_t *batch_start, int64_t n, int B,
                                              int C, int X, int Y, int Z, float *values,
                                              int channels_first, mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -204,15 +260,10 @@ extern "C" int mf_interpolate_voxel_grid_fwd(const float *vox, const float *poin
   if (V * 4 <= kMaxLds) {
     const int cpw = pick_cpw(C, B, V);
     const size_t lds = (size_t)cpw * V * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-      MF_TRY(hipFuncSetAttribute((const void *)k_interp_fwd_lds,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-      attr_set = true;
-    }
+    if (int e = mf::allow_big_lds((const void *)k_interp_fwd_lds, kMaxLds)) return e;
     hipLaunchKernelGGL(k_interp_fwd_lds, dim3((C + cpw - 1) / cpw, B), dim3(kInterpThreads), lds,
-                       stream, vox, points, batch_indices, n, C, X, Y, Z, cpw, values,
-                       channels_first);
+                       stream, vox, points, batch_indices, batch_start, n, B, C, X, Y, Z, cpw,
+                       values, channels_first);
   } else {
     hipLaunchKernelGGL(k_interp_fwd_direct,
                        dim3((unsigned)((n + kInterpThreads - 1) / kInterpThreads),
@@ -224,7 +275,8 @@ extern "C" int mf_interpolate_voxel_grid_fwd(const float *vox, const float *poin
 }
 
 extern "C" int mf_interpolate_voxel_grid_bwd(const float *gvalues, const float *points,
-                                             const int32_t *batch_indices, int64_t n, int B,
+                                             const int32_t *batch_indices,
+                                             const int32_t *batch_start, int64_t n, int B,
                                              int C, int X, int Y, int Z, float *gvox,
                                              int channels_first, mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -233,15 +285,10 @@ extern "C" int mf_interpolate_voxel_grid_bwd(const float *gvalues, const float *
   if (V * 4 <= kMaxLds) {
     const int cpw = pick_cpw(C, B, V);
     const size_t lds = (size_t)cpw * V * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-      MF_TRY(hipFuncSetAttribute((const void *)k_interp_bwd_lds,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-      attr_set = true;
-    }
+    if (int e = mf::allow_big_lds((const void *)k_interp_bwd_lds, kMaxLds)) return e;
     hipLaunchKernelGGL(k_interp_bwd_lds, dim3((C + cpw - 1) / cpw, B), dim3(kInterpThreads), lds,
-                       stream, gvalues, points, batch_indices, n, C, X, Y, Z, cpw, gvox,
-                       channels_first);
+                       stream, gvalues, points, batch_indices, batch_start, n, B, C, X, Y, Z, cpw,
+                       gvox, channels_first);
   } else {
     MF_TRY(hipMemsetAsync(gvox, 0, sizeof(float) * B * C * V, stream));
     if (n > 0)

@@ -27,6 +27,11 @@ inline int check_launch(const char *where) {
     }                                                 \
   } while (0)
 
+// Opt a kernel in to more than 64 KB of dynamic LDS.  The attribute is per DEVICE (one process
+// may drive several GPUs) and this may be called from any thread: api.hip keeps a mutex-guarded
+// (device, function) set.
+int allow_big_lds(const void *kernel, int bytes);
+
 constexpr int kWave = 64;
 
 // dynamic LDS of the workgroup (tests/host_emul/mf_common.h gives the host-emulation form)

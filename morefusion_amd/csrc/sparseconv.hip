@@ -320,14 +320,8 @@ extern "C" int mf_sparse_conv3d_k4s2_fwd(const float *x, const int32_t *counts, 
   hipLaunchKernelGGL(k_sc_gather, dim3((unsigned)(((int64_t)max_rows * Cs + 255) / 256)),
                      dim3(256), 0, stream, a);
   const size_t lds_g = (size_t)Cs * (kTM + 4 + kTN + 4) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    MF_TRY(hipFuncSetAttribute((const void *)k_sc_gemm, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               150 * 1024));
-    MF_TRY(hipFuncSetAttribute((const void *)k_sc_reduce,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr = true;
-  }
+  if (int e = mf::allow_big_lds((const void *)k_sc_gemm, 150 * 1024)) return e;
+  if (int e = mf::allow_big_lds((const void *)k_sc_reduce, 150 * 1024)) return e;
   if (lds_g > 150 * 1024) {
     mf::set_last_error(hipErrorInvalidValue, "sparse_conv3d: Cs too large for the LDS-resident K");
     return -(int)hipErrorInvalidValue;

@@ -11,7 +11,7 @@ from ... import _lib
 
 class InterpolateVoxelGrid(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, voxelized, points, batch_indices, channels_first):
+    def forward(ctx, voxelized, points, batch_indices, channels_first, batch_start=None):
         _lib.require_gpu(voxelized, points, batch_indices)
         if voxelized.dtype != torch.float32 or voxelized.ndim != 5:
             raise TypeError("voxelized must be float32 [B, C, X, Y, Z]")
@@ -22,15 +22,21 @@ class InterpolateVoxelGrid(torch.autograd.Function):
             raise TypeError("batch_indices must be int32 [P]")
         vox, pts, bi = voxelized.contiguous(), points.contiguous(), batch_indices.contiguous()
         B, C, X, Y, Z = vox.shape
+        if batch_start is not None:
+            _lib.require_gpu(batch_start)
+            if batch_start.dtype != torch.int32 or batch_start.shape != (B + 1,):
+                raise TypeError("batch_start must be int32 [B + 1]")
+            batch_start = batch_start.contiguous()
         n = pts.shape[0]
         shape = (C, n) if channels_first else (n, C)
         values = torch.empty(shape, dtype=torch.float32, device=vox.device)
         _lib.check(
             _lib.lib().mf_interpolate_voxel_grid_fwd(
-                vox.data_ptr(), pts.data_ptr(), bi.data_ptr(), n, B, C, X, Y, Z,
+                vox.data_ptr(), pts.data_ptr(), bi.data_ptr(), _lib.ptr(batch_start), n, B, C, X, Y, Z,
                 values.data_ptr(), int(channels_first), _lib.stream_ptr()),
             "mf_interpolate_voxel_grid_fwd")
         ctx.save_for_backward(pts, bi)
+        ctx.batch_start = batch_start
         ctx.meta = (B, C, X, Y, Z, bool(channels_first))
         return values
 
@@ -42,13 +48,16 @@ class InterpolateVoxelGrid(torch.autograd.Function):
         gvox = torch.empty((B, C, X, Y, Z), dtype=torch.float32, device=gvalues.device)
         _lib.check(
             _lib.lib().mf_interpolate_voxel_grid_bwd(
-                gvalues.data_ptr(), pts.data_ptr(), bi.data_ptr(), pts.shape[0], B, C, X, Y, Z,
-                gvox.data_ptr(), int(channels_first), _lib.stream_ptr()),
+                gvalues.data_ptr(), pts.data_ptr(), bi.data_ptr(), _lib.ptr(ctx.batch_start),
+                pts.shape[0], B, C, X, Y, Z, gvox.data_ptr(), int(channels_first), _lib.stream_ptr()),
             "mf_interpolate_voxel_grid_bwd")
-        return gvox, None, None, None
+        return gvox, None, None, None, None
 
 
-def interpolate_voxel_grid(voxelized, points, batch_indices, channels_first=False):
+def interpolate_voxel_grid(voxelized, points, batch_indices, channels_first=False, batch_start=None):
     """Returns [P, C] like the reference; ``channels_first=True`` returns [C, P]
-    (the coalesced layout the pose network consumes, saving a transpose)."""
-    return InterpolateVoxelGrid.apply(voxelized, points, batch_indices, channels_first)
+    (the coalesced layout the pose network consumes, saving a transpose).  ``batch_start``
+    (int32 [B+1] row offsets, optional) tells the kernel that the rows of item b are
+    ``batch_start[b]:batch_start[b+1]`` (points sorted by batch index, as the pose network's
+    are): each workgroup then visits only its own rows."""
+    return InterpolateVoxelGrid.apply(voxelized, points, batch_indices, channels_first, batch_start)

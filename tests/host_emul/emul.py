@@ -70,8 +70,8 @@ class EmulIccScenes:
     def __init__(self, lib, scenes, voxel_dim=32, voxel_threshold=2, sdf_offset=0.0):
         self.lib = lib
         lib.mf_icc_workspace_bytes.restype = _i64
-        lib.mf_icc_workspace_bytes.argtypes = [ctypes.c_int32] * 3
         P = ctypes.POINTER(IccBatch)
+        lib.mf_icc_workspace_bytes.argtypes = [P]
         lib.mf_icc_prepare.argtypes = [P, _p, _p]
         lib.mf_icc_loss_grad.argtypes = [P, _p, _p, _p, _p, _p, _p, _p]
         lib.mf_icc_refine.argtypes = [P, _p, _p, _p, _p, ctypes.c_int32, ctypes.c_int32, _f, _f, _p, _p, _p, _p]
@@ -99,14 +99,15 @@ class EmulIccScenes:
         self.origin = np.ascontiguousarray(np.concatenate(origin))
         self.grid_target = np.ascontiguousarray(np.concatenate(gt))
         self.grid_ne = np.ascontiguousarray(np.concatenate(gne))
-        nbytes = lib.mf_icc_workspace_bytes(self.n_objects, self.n_scenes, voxel_dim)
-        self.ws = np.zeros(nbytes + 256, np.uint8)
-        self.ws_ptr = (self.ws.ctypes.data + 255) & ~255
         self.desc = IccBatch(
             ptr(self.pts4), ptr(self.obj_off), ptr(self.scene_off), ptr(self.obj_scene), ptr(self.pitch),
             ptr(self.origin), ptr(self.grid_target), ptr(self.grid_ne), self.n_objects, self.n_scenes,
             self.n_points, voxel_dim, max(scene_off[i + 1] - scene_off[i] for i in range(len(scenes))),
             float(voxel_threshold), float(sdf_offset))
+        nbytes = lib.mf_icc_workspace_bytes(ctypes.byref(self.desc))
+        assert nbytes > 0
+        self.ws = np.zeros(nbytes + 256, np.uint8)
+        self.ws_ptr = (self.ws.ctypes.data + 255) & ~255
         rc = lib.mf_icc_prepare(ctypes.byref(self.desc), self.ws_ptr, None)
         assert rc == 0, rc
 

@@ -315,6 +315,7 @@ template <class T> inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o == cmp
 namespace mf {
 inline void set_last_error(int, const char *) {}
 inline int check_launch(const char *) { return 0; }
+inline int allow_big_lds(const void *, int) { return 0; }
 constexpr int kWave = 64;
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline float voxel_coord(float p, float o, float pitch) { return (p - o) / pitch; }

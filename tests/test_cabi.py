@@ -37,9 +37,17 @@ def test_icc_batch_struct_matches_header():
 
 
 def test_workspace_size_is_host_only_arithmetic():
-    n = mf._lib.lib().mf_icc_workspace_bytes(8, 1, 32)
-    assert n >= 2 * 8 * 32 ** 3 * 8
-    assert mf._lib.lib().mf_icc_workspace_bytes(64, 8, 32) > n
+    def desc(n_objects, n_scenes, n_points, max_ns, thr=2.0):
+        return mf._lib.IccBatch(None, None, None, None, None, None, None, None, n_objects, n_scenes,
+                                n_points, 32, max_ns, thr, 0.0)
+    ws = mf._lib.lib().mf_icc_workspace_bytes
+    n = ws(ctypes.byref(desc(8, 1, 28000, 8)))
+    # winners of 16 grids + the x-plane bins (34 planes x 8 grids' worth of point records)
+    assert n >= 2 * 8 * 32 ** 3 * 8 + 34 * 8 * 28000 * 16
+    assert ws(ctypes.byref(desc(64, 8, 8 * 28000, 8))) > n
+    assert ws(ctypes.byref(desc(8, 1, 28000, 8, thr=4.0))) > n       # kernel size 5: two more planes
+    assert ws(ctypes.byref(desc(40, 1, 28000, 40))) < 0              # > 32 objects in a scene
+    assert ws(ctypes.byref(desc(8, 1, 28000, 8, thr=9.0))) < 0       # kernel size > 7
 
 
 def test_ops_refuse_cpu_tensors_loudly():

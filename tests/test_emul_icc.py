@@ -1,0 +1,102 @@
+"""The ICC kernel SOURCE (csrc/icc.hip: k_icc_bin, k_icc_tile, k_icc_accum, k_icc_step and the
+hipGraph loop of mf_icc_refine) compiled for the host behind tests/host_emul (fiber emulator)
+and checked against the oracle WITHOUT a GPU.  The -m gpu tests (tests/test_gpu_icc.py) repeat
+these comparisons on the MI355X at full size; here scenes are kept small enough for the
+emulator (one workgroup at a time, every GPU thread a fiber)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c as OC
+from oracle import oracle_np as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_emul"))
+import emul  # noqa: E402
+
+import morefusion_amd.synthetic as synthetic  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not emul.available(), reason="g++ not available")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emul.build(["icc.hip"])
+
+
+def _dict(sc):
+    return dict(points=sc["points"], sdf=sc["sdf"], pitch=sc["pitch"], origin=sc["origin"],
+                grid_target=sc["grid_target"], grid_nontarget_empty=sc["grid_nontarget_empty"])
+
+
+def _args(sc):
+    return (sc["points"], sc["sdf"], sc["pitch"], sc["origin"], sc["grid_target"], sc["grid_nontarget_empty"])
+
+
+def _pose0(sc):
+    q = np.stack([O.quaternion_from_matrix(T) for T in sc["transform_init"]]).astype(np.float32)
+    t = sc["transform_init"][:, :3, 3].astype(np.float32).copy()
+    return q, t
+
+
+def test_icc_kernel_source_loss_and_grad_vs_oracle(lib, fixtures3):
+    sc = synthetic.make_icc_scene(4, seed=0, fixtures=fixtures3)
+    S = emul.EmulIccScenes(lib, [_dict(sc)], sdf_offset=0.02)
+    q0, t0 = _pose0(sc)
+    loss, gq, gt = S.loss_grad(q0, t0)
+    l_o, gq_o, gt_o, _ = OC.icc_loss_grad(*_args(sc), q0, t0, sdf_offset=0.02)
+    np.testing.assert_allclose(loss[0], l_o, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(gq, gq_o, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(gt, gt_o, rtol=2e-3, atol=2e-4)
+    # the bins are left empty for the next iteration: a second call gives the same bits
+    loss2, gq2, gt2 = S.loss_grad(q0, t0)
+    np.testing.assert_array_equal(loss, loss2)
+    np.testing.assert_array_equal(gq, gq2)
+    np.testing.assert_array_equal(gt, gt2)
+
+
+def test_icc_kernel_source_refine_teacher_forced_vs_oracle(lib, fixtures3):
+    """One fused step (bin -> tile -> accum -> step, captured in a graph) from the oracle's state
+    at iteration k lands on the oracle's iterate k+1 (same pin as the GPU test)."""
+    n, iters = 3, 4
+    sc = synthetic.make_icc_scene(n, seed=0, fixtures=fixtures3)
+    q0, t0 = _pose0(sc)
+    _, _, losses_o, traj_o, hist_o = OC.icc_refine(*_args(sc), q0, t0, n_iter=iters, sdf_offset=0.02,
+                                                  return_adam=True)
+    S = emul.EmulIccScenes(lib, [_dict(sc)], sdf_offset=0.02)
+    for k in range(iters - 1):
+        q, t = traj_o[k, :, :4].copy(), traj_o[k, :, 4:].copy()
+        m, v = hist_o[k, 0].copy(), hist_o[k, 1].copy()
+        loss = np.zeros((1, 1), np.float32)
+        S.refine(q, t, m, v, 1, step0=k, losses=loss)
+        np.testing.assert_allclose(loss[0, 0], losses_o[k], rtol=2e-5, atol=2e-6)
+        assert np.abs(np.concatenate([q, t], 1) - traj_o[k + 1]).max() < 1e-5
+    # free-running graph replay: same first losses
+    q, t = q0.copy(), t0.copy()
+    m, v = np.zeros((n, 7), np.float32), np.zeros((n, 7), np.float32)
+    losses = np.zeros((3, 1), np.float32)
+    S.refine(q, t, m, v, 3, losses=losses)
+    np.testing.assert_allclose(losses[:, 0], losses_o[:3], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("thr", [3, 4])
+def test_icc_kernel_source_ragged_scenes_and_wider_kernel(lib, thr):
+    """Scenes of 1 and 3 objects in one batch (ragged tables, a scene without any 'other' grid)
+    and wider TDF kernels (truncated_distance_function.py:36-38, ceil(truncation / pitch) in
+    float32 made odd): threshold 4 -> kernel size 5 for every grid; threshold 3 -> 3 or 5
+    depending on how 3 * pitch / pitch rounds for each grid's pitch, as in the reference."""
+    scenes = [synthetic.make_icc_scene(n, seed=20 + n) for n in (1, 3)]
+    S = emul.EmulIccScenes(lib, [_dict(s) for s in scenes], voxel_threshold=thr, sdf_offset=0.02)
+    q0 = np.concatenate([_pose0(s)[0] for s in scenes])
+    t0 = np.concatenate([_pose0(s)[1] for s in scenes])
+    loss, gq, gt = S.loss_grad(q0, t0)
+    lo = 0
+    for k, s in enumerate(scenes):
+        n = len(s["points"])
+        l_o, gq_o, gt_o, _ = OC.icc_loss_grad(*_args(s), q0[lo:lo + n], t0[lo:lo + n], voxel_threshold=thr,
+                                              sdf_offset=0.02)
+        np.testing.assert_allclose(loss[k], l_o, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(gq[lo:lo + n], gq_o, rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(gt[lo:lo + n], gt_o, rtol=2e-3, atol=2e-4)
+        lo += n

@@ -1,0 +1,7 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r02
+timeout 600 python -m pytest tests/test_gpu_icc.py -x -q > gpurun_out/r02/c3_tests.log 2>&1; echo "icc tests rc $?"; tail -2 gpurun_out/r02/c3_tests.log
+bash tools/prof_k.sh r02v2b MF_ICC_IMPL=2 2>&1 | tail -4
+grep -E "k_icc" gpurun_out/prof_r02v2b/icc_kernel_stats.csv | cut -c1-150 | head -5
+timeout 120 python tools/stamps_icc.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r02/c3_stamps.log

@@ -12,14 +12,21 @@ mf._lib.lib().mf_icc_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
 st = buf.reshape(4096, 8)[:512].astype(np.int64)
 t0 = st[:, 0].min()
 d = lambda a, b: (st[:, b] - st[:, a]) / 100.0   # wall_clock64 = 100 MHz -> us
-print("WGs", (st[:, 0] > 0).sum())
-for name, a, b in (("scan", 0, 1), ("pass1", 1, 2), ("pass2", 2, 3), ("epilogue", 3, 4), ("total", 0, 4)):
-    x = d(a, b); print(f"{name:9s} mean {x.mean():7.2f} us  max {x.max():7.2f} us  (argmax wg {x.argmax()})")
-print("start skew (us): max", (st[:, 0] - t0).max() / 100.0, " end max", (st[:, 4] - t0).max() / 100.0)
-ns = st[:, 6] & 0xffffffff; dr = st[:, 6] >> 32
-print("survivors: max", ns.max(), "mean", ns.mean(), "drained WGs", int(dr.sum()))
-worst = np.argsort(-d(0, 4))[:8]
-for w in worst: print("wg", w, "grid", w // 32, "slab", w % 32, "ns", ns[w], "drained", dr[w], "scan", d(0,1)[w], "p1", d(1,2)[w], "p2", d(2,3)[w], "epi", d(3,4)[w])
+print("tile WGs", (st[:, 0] > 0).sum())
+for name, a, b in (("init+load", 0, 1), ("pass1", 1, 2), ("pass2", 2, 3), ("epilogue", 3, 4), ("total", 0, 4)):
+    x = d(a, b); print(f"tile {name:9s} mean {x.mean():7.2f} us  max {x.max():7.2f} us  (argmax wg {x.argmax()})")
+print("tile start skew (us): max", (st[:, 0] - t0).max() / 100.0, " end max", (st[:, 4] - t0).max() / 100.0)
+ns = st[:, 6]
+print("records per tile: max", ns.max(), "mean", ns.mean())
+worst = np.argsort(-d(0, 4))[:6]
+for w in worst: print("wg", w, "grid", w // 32, "plane", w % 32, "T", ns[w], "load", d(0,1)[w], "p1", d(1,2)[w], "p2", d(2,3)[w], "epi", d(3,4)[w])
+sb = buf.reshape(4096, 8)[3072:3072+512].astype(np.int64)
+live = sb[:, 3] > 0
+db = lambda a, b: (sb[live, b] - sb[live, a]) / 100.0
+print("bin WGs", (sb[:, 0] > 0).sum(), "live", live.sum())
+for name, a, b in (("loads+count", 0, 1), ("global atomic", 1, 2), ("stores", 2, 3), ("total", 0, 3)):
+    x = db(a, b); print(f"bin {name:13s} mean {x.mean():7.2f} us  max {x.max():7.2f} us")
+print("bin start skew max", (sb[sb[:,0]>0, 0] - sb[sb[:,0]>0, 0].min()).max() / 100.0, "end max", (sb[live, 3] - sb[sb[:,0]>0, 0].min()).max() / 100.0)
 
 st2 = buf.reshape(4096, 8)[2048:2048+256].astype(np.int64)
 d2 = lambda a, b: (st2[:, b] - st2[:, a]) / 100.0
