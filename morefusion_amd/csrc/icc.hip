@@ -852,16 +852,21 @@ __device__ __forceinline__ void world_frac(const float *Rt, const float4 m, floa
 }
 
 constexpr int kVPT = kVoxPerBlock / kAccThreads;  // voxels per thread
+constexpr int kAccRep = 16;                       // replicas of the collision-limb accumulators
 
 __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K_v1) {
-  __shared__ float s_tr[kAccThreads * kNumOwn];
+  __shared__ float s_rows[kAccThreads / 16][kNumOwn + 1];  // 16-lane row sums (+1: bank spread)
   // collision moments as 2^44 fixed point split in three 20-bit limbs held in 32-bit LDS
   // words: <= 1024 adds per block can never overflow a limb, so plain NON-returning
   // ds_add_u32 suffice (no carries).  Integer addition is associative: the result is
   // independent of the order of the atomics (bitwise reproducible), and 32-bit LDS atomics
-  // are ~10x cheaper than the 64-bit ones.
-  __shared__ uint32_t s_l0[kMaxSceneObjects * 12], s_l1[kMaxSceneObjects * 12];
-  __shared__ int32_t s_l2[kMaxSceneObjects * 12];
+  // are ~10x cheaper than the 64-bit ones.  All colliding voxels of a block add into the same
+  // 36 words per other object, and same-address LDS atomics serialise (measured: the crowded
+  // blocks spent 3-5 us here) -> kAccRep replicas selected by lane, in different banks (odd
+  // stride), summed at the end: integer sums, still order-independent.
+  MF_DYN_LDS(uint32_t, s_lim);  // [3 limbs][kAccRep][lim_stride]
+  const int lim_stride = a.max_ns * 12 + 1;
+  const int lim_words = kAccRep * lim_stride;
   __shared__ float s_Rt[kMaxSceneObjects][12];
   __shared__ int s_off[kMaxSceneObjects + 1];
   const int o = blockIdx.y;
@@ -877,7 +882,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K_v1) 
   // all independent loads first: scene tables, scalars, and this thread's voxels
   if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
-  for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) { s_l0[i] = 0u; s_l1[i] = 0u; s_l2[i] = 0; }
+  for (int i = threadIdx.x; i < 3 * lim_words; i += kAccThreads) s_lim[i] = 0u;
   // this object's two grids have been consumed by k_icc_tile: empty their bins for the next k_icc_bin
   if (blockIdx.x == 0)
     for (int i = threadIdx.x; i < 2 * a.nbins; i += kAccThreads) a.bin_cnt[(int64_t)2 * o * a.nbins + i] = 0u;
@@ -993,38 +998,42 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K_v1) 
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const long long x = __double2ll_rn((double)val[c] * kFix);
-            const int idx = 12 * e + 4 * d + c;
-            atomicAdd(&s_l0[idx], (uint32_t)(x & 0xfffff));
-            atomicAdd(&s_l1[idx], (uint32_t)((x >> 20) & 0xfffff));
-            atomicAdd(&s_l2[idx], (int32_t)(x >> 40));
+            const int idx = (int)(threadIdx.x & (kAccRep - 1)) * lim_stride + 12 * e + 4 * d + c;
+            atomicAdd(&s_lim[idx], (uint32_t)(x & 0xfffff));
+            atomicAdd(&s_lim[lim_words + idx], (uint32_t)((x >> 20) & 0xfffff));
+            atomicAdd(&s_lim[2 * lim_words + idx], (uint32_t)(int32_t)(x >> 40));  // two's complement
           }
         }
       }
     }
   }
-  // fixed-order block reduction: component-major LDS layout (conflict-free stores), then
-  // each wave owns components {wave, wave+8, ...}: 8 strided LDS reads per lane + one
-  // 6-step wave reduction per component -- ~30 cross-lane steps per wave instead of 234.
+  // fixed-order block reduction: every component is summed over each 16-lane row on DPP (4 VALU
+  // steps, no LDS), the 32 row sums go through LDS, one lane per component adds them in order.
   stamp(2);
-  constexpr int kWaves = kAccThreads / 64;
 #pragma unroll
-  for (int i = 0; i < kNumOwn; ++i) s_tr[i * kAccThreads + threadIdx.x] = acc[i];
+  for (int i = 0; i < kNumOwn; ++i) {
+    const float r = mf::row16_sum(acc[i]);
+    if ((threadIdx.x & 15) == 0) s_rows[threadIdx.x >> 4][i] = r;
+  }
   __syncthreads();
-  {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int c = wave; c < kNumOwn; c += kWaves) {
-      float sacc = 0.0f;
+  if (threadIdx.x < kNumOwn) {
+    float sacc = 0.0f;
 #pragma unroll
-      for (int k = 0; k < kWaves; ++k) sacc += s_tr[c * kAccThreads + lane + 64 * k];
-      sacc = mf::wave_sum(sacc);
-      if (lane == 0) a.part[((int64_t)o * gridDim.x + blockIdx.x) * kNumOwn + c] = sacc;
-    }
+    for (int r = 0; r < kAccThreads / 16; ++r) sacc += s_rows[r][threadIdx.x];
+    a.part[((int64_t)o * gridDim.x + blockIdx.x) * kNumOwn + threadIdx.x] = sacc;
   }
   stamp(3);
-  // collision partials of this block (the barriers above order the LDS atomics)
+  // collision partials of this block (the barrier above orders the LDS atomics)
   float *po = a.oth + ((int64_t)o * gridDim.x + blockIdx.x) * a.max_ns * 12;
   for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) {
-    const long long x = ((long long)s_l2[i] << 40) + ((long long)s_l1[i] << 20) + (long long)s_l0[i];
+    long long l0 = 0, l1 = 0, l2 = 0;
+#pragma unroll
+    for (int r = 0; r < kAccRep; ++r) {
+      l0 += (long long)s_lim[r * lim_stride + i];
+      l1 += (long long)s_lim[lim_words + r * lim_stride + i];
+      l2 += (long long)(int32_t)s_lim[2 * lim_words + r * lim_stride + i];
+    }
+    const long long x = (l2 << 40) + (l1 << 20) + l0;
     po[i] = (float)((double)x / kFix);
   }
 }
@@ -1298,7 +1307,8 @@ void launch_iteration(const IccArgs &a, int ks, int SX, int NB, int max_ns, int 
                       int adam_step, float *loss, float *gq, float *gt, float *traj, int it,
                       hipStream_t stream) {
   launch_front(a, ks, SX, stream);
-  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), 0, stream, a,
+  const size_t lds2 = (size_t)3 * kAccRep * (max_ns * 12 + 1) * sizeof(uint32_t);  // <= 74 KB
+  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), lds2, stream, a,
                      icc_impl() == 1 ? ks * ks * ks : 0);
   // chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once
   const double fix1 = 1.0 - pow(0.9, (double)adam_step), fix2 = 1.0 - pow(0.999, (double)adam_step);
@@ -1343,6 +1353,7 @@ static int icc_prepare_kernels() {
   // static + dynamic LDS above 64 KB is opt-in (per device, thread-safe: mf::allow_big_lds)
   if (int e = mf::allow_big_lds((const void *)k_icc_tdf<3>, 64 * 1024)) return e;
   if (int e = mf::allow_big_lds((const void *)k_icc_tdf<0>, 64 * 1024)) return e;
+  if (int e = mf::allow_big_lds((const void *)k_icc_accum, 80 * 1024)) return e;
   return mf::allow_big_lds((const void *)k_icc_step, 150 * 1024);
 }
 

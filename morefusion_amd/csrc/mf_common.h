@@ -46,16 +46,51 @@ __device__ __forceinline__ float voxel_coord(float p, float o, float pitch) {
   return (p - o) / pitch;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+// ---- cross-lane reductions on DPP (one VALU op per step; __shfl_* compile to ds_bpermute,
+// an LDS-crossbar round trip per step).  All lanes of the wave must be active.
+// DPP controls: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140 -- a butterfly over each aligned group of 16 lanes (a DPP "row").
+template <int CTRL>
+__device__ __forceinline__ float dpp_zero(float v) {  // inactive / invalid source lanes read 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_self(float v) {  // inactive / invalid source lanes read v
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// Sum over each 16-lane row; every lane of the row receives the same bits
+// (((v + v^1) + (..)^2) + half-mirror) + mirror: a fixed association).
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_zero<0xB1>(v);
+  v += dpp_zero<0x4E>(v);
+  v += dpp_zero<0x141>(v);
+  v += dpp_zero<0x140>(v);
   return v;
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_self<0xB1>(v));
+  v = fmaxf(v, dpp_self<0x4E>(v));
+  v = fmaxf(v, dpp_self<0x141>(v));
+  v = fmaxf(v, dpp_self<0x140>(v));
   return v;
+}
+
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// Wave-wide sum / max, result in EVERY lane: (row0 + row1) + (row2 + row3).
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
 }  // namespace mf

@@ -319,13 +319,37 @@ inline int allow_big_lds(const void *, int) { return 0; }
 constexpr int kWave = 64;
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline float voxel_coord(float p, float o, float pitch) { return (p - o) / pitch; }
+// same association as the DPP butterflies of csrc/mf_common.h
+inline float row16_reduce(float v, bool is_max) {
+  uint64_t bits = 0, act;
+  memcpy(&bits, &v, 4);
+  const uint64_t *all = mf_emul::wave_exchange(bits, &act);
+  const int lane = mf_emul::g_block.cur % 64, row = lane & ~15;
+  float x[16], y[16];
+  for (int i = 0; i < 16; ++i) {
+    uint64_t b = all[row + i];
+    memcpy(&x[i], &b, 4);
+    if (!((act >> (row + i)) & 1)) x[i] = is_max ? v : 0.0f;
+  }
+  auto op = [&](float a, float b) { return is_max ? fmaxf(a, b) : a + b; };
+  for (int i = 0; i < 16; ++i) y[i] = op(x[i], x[i ^ 1]);
+  for (int i = 0; i < 16; ++i) x[i] = op(y[i], y[i ^ 2]);
+  for (int i = 0; i < 16; ++i) y[i] = op(x[i], x[(i & 8) | (7 - (i & 7))]);
+  for (int i = 0; i < 16; ++i) x[i] = op(y[i], y[15 - i]);
+  return x[lane & 15];
+}
+inline float row16_sum(float v) { return row16_reduce(v, false); }
+inline float row16_max(float v) { return row16_reduce(v, true); }
+inline float lane_value(float v, int lane) { return mf_emul_shfl(v, lane); }
 inline float wave_sum(float v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v = row16_sum(v);
+  const float a = lane_value(v, 0), b = lane_value(v, 16), c = lane_value(v, 32), d = lane_value(v, 48);
+  return (a + b) + (c + d);
 }
 inline float wave_max(float v) {
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
-  return v;
+  v = row16_max(v);
+  const float a = lane_value(v, 0), b = lane_value(v, 16), c = lane_value(v, 32), d = lane_value(v, 48);
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 }  // namespace mf
 
