@@ -319,7 +319,7 @@ def cpu_baseline(wl, args):
             return torch.from_numpy(m), torch.from_numpy(c)
         return torch.from_numpy(m)
 
-    def interp_cpu(vox, points, batch_indices, channels_first=False):
+    def interp_cpu(vox, points, batch_indices, channels_first=False, batch_start=None):
         out = torch.from_numpy(OC.interpolate_voxel_grid(vox.numpy(), points.numpy(), batch_indices.numpy()))
         return out.t().contiguous() if channels_first else out
 

@@ -610,19 +610,29 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax) {
 //         near-minimal candidates (d2 within a few ulp) and, where it equals the exact minimum
 //         and is < truncation, takes atomicMin of the candidate id: the same winners as
 //         the oracle (lowest id among equal ROUNDED distances).
-constexpr int kTileThreads = 512;
-constexpr int kTileKeep = 6;  // records per lane kept in registers over both passes
-constexpr int kTileR = 4;     // records in flight per lane beyond those
+constexpr int kTileThreads = 256;
+constexpr int kTileStripes = 4;  // y-stripes per plane: a workgroup owns D/4 rows of one x-plane
+constexpr int kTileKeep = 10;    // records per lane kept in registers over both passes
+constexpr int kTileR = 4;        // records in flight per lane beyond those
 
+// A crowded plane (2400 records at 8 objects) is bound by instruction issue and same-address LDS
+// atomics of ONE workgroup while the other 500 idle: each plane is split in kTileStripes
+// y-stripes.  Every stripe workgroup streams all records of the plane's bins (16 B each, L2
+// hits) and keeps those whose ks rows touch its stripe; the (min, arg-min) of a voxel only
+// depends on the set of candidates, so the winners do not change.
 template <int KS>
 __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt, const int hmax) {
-  MF_DYN_LDS(uint32_t, s_tile);  // dist[D*D], id[D*D]
+  MF_DYN_LDS(uint32_t, s_tile);  // dist[rows*D], id[rows*D]
   __shared__ float s_max[kTileThreads / 64];
   const int ks = KS > 0 ? KS : ks_rt;
   const int h = ks / 2, K = ks * ks * ks;
-  const int D = a.D, nvox = D * D, nb = a.nbins;
-  const int g = blockIdx.y, o = g >> 1, other = g & 1, x = blockIdx.x;
-  uint32_t *s_dist = s_tile, *s_id = s_tile + nvox;
+  const int D = a.D, nb = a.nbins;
+  const int g = blockIdx.y, o = g >> 1, other = g & 1;
+  const int x = blockIdx.x / kTileStripes, stripe = blockIdx.x % kTileStripes;
+  const int rows_max = (D + kTileStripes - 1) / kTileStripes;
+  const int y0 = stripe * rows_max, y1 = min(D, y0 + rows_max);
+  const int nvox = max(0, y1 - y0) * D;
+  uint32_t *s_dist = s_tile, *s_id = s_tile + rows_max * D;
   // independent loads: the <= 7 bin counts of this tile, capacity, offset
   int c[8];
   c[0] = 0;
@@ -651,7 +661,7 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
   const float4 *recs = a.rec + base_g + (int64_t)bin0 * cap;
   const float fxp = (float)x;
 
-  // record i of this tile's concatenated bins -> (bin b, record); rb < 0: none
+  // record i of this tile's concatenated bins -> (bin b, record); rb < 0: none / not in my stripe
   auto fetch = [&](const int i, float4 &rv, int &rb) {
     rb = -1;
     if (i >= T) return;
@@ -664,16 +674,16 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
     rb = b;
     rv = recs[(int64_t)b * cap + (i - cb)];
   };
-  // One record against its ks x ks (y, z) candidates in plane x.  What bounds this kernel is
-  // the LDS round trip, not arithmetic: all peeks of a record are issued together (KS == 3:
-  // nine independent ds_read), then the non-returning atomics.  A peek may be stale (another
-  // lane lowered the voxel meanwhile): values only decrease, so a stale peek only lets MORE
-  // candidates through -- the atomicMin / the exact test of pass 2 decide.
-  // `part` splits pass 1: 0 = the centre candidate only (the voxel the point rounds to -- its
-  // squared distance is <= 0.75, a tight bound), 1 = the other candidates, 2 = all.  Running
-  // the centres of ALL records first lets the peek reject most of the remaining candidates:
-  // a crowded plane otherwise serialises ~9 same-address LDS atomics per record.
-  auto visit = [&](const int pass, const int part, const float4 sv, const int rb) -> bool {
+  auto mine = [&](const float4 &rv) {  // do the ks rows around round(y) touch rows [y0, y1)?
+    const int iry = (int)roundf(rv.y);
+    return iry + h >= y0 && iry - h < y1;
+  };
+  // One record against its ks x ks (y, z) candidates in plane x.  All peeks of a record are
+  // issued together (KS == 3: nine independent ds_read), then the non-returning atomics.  A
+  // peek may be stale (another lane lowered the voxel meanwhile): values only decrease, so a
+  // stale peek only lets MORE candidates through -- the atomicMin / the exact test of pass 2
+  // decide.
+  auto visit = [&](const int pass, const float4 sv, const int rb) -> bool {
     const int iry = (int)roundf(sv.y), irz = (int)roundf(sv.z);
     const uint32_t idb = __float_as_uint(sv.w) * (uint32_t)K;
     const int bb = ks - 1 - rb;  // x offset of plane x inside this point's neighbourhood
@@ -693,19 +703,15 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
           const int iz = irz + cc - 1;
           const float dz = sv.z - (float)iz;
           const float d2 = dxy + dz * dz;
-          const int k = aa * 3 + cc;
-          const bool ok = iy >= 0 && iy < D && iz >= 0 && iz < D && d2 < d2_hi &&
-                          (part == 2 || (part == 0) == (k == 4));
-          db[k] = __float_as_uint(d2);
-          ad[k] = ok ? iy * D + iz : -1;
+          const bool ok = iy >= y0 && iy < y1 && iz >= 0 && iz < D && d2 < d2_hi;
+          db[aa * 3 + cc] = __float_as_uint(d2);
+          ad[aa * 3 + cc] = ok ? (iy - y0) * D + iz : -1;
         }
       }
 #pragma unroll
-      for (int k = 0; k < 9; ++k)
-        if (part != 0 || k == 4) cur[k] = s_dist[ad[k] < 0 ? 0 : ad[k]];
+      for (int k = 0; k < 9; ++k) cur[k] = s_dist[ad[k] < 0 ? 0 : ad[k]];
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        if (part == 0 && k != 4) continue;
         if (ad[k] < 0) continue;
         if (pass == 1) {
           if (db[k] <= cur[k]) { atomicMin(&s_dist[ad[k]], db[k]); cand = true; }
@@ -722,13 +728,12 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
         }
       }
     } else {
-      if (part == 1) return false;  // generic kernel size: everything in the first part
       for (int aa = 0; aa < ks; ++aa) {
         const int iy = iry + aa - h;
-        if (iy < 0 || iy >= D) continue;
+        if (iy < y0 || iy >= y1) continue;
         const float dy = sv.y - (float)iy;
         const float dxy = dx2 + dy * dy;
-        const int lrow = iy * D;
+        const int lrow = (iy - y0) * D;
         for (int cc = 0; cc < ks; ++cc) {
           const int iz = irz + cc - h;
           if (iz < 0 || iz >= D) continue;
@@ -760,12 +765,10 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
   for (int u = 0; u < kTileKeep; ++u) fetch(u * kTileThreads + (int)threadIdx.x, rv[u], rb[u]);
   stamp(1);
 #pragma unroll
-  for (int u = 0; u < kTileKeep; ++u)
-    if (rb[u] >= 0 && visit(1, 0, rv[u], rb[u])) keep_cand |= 1u << u;
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < kTileKeep; ++u)
-    if (rb[u] >= 0 && visit(1, 1, rv[u], rb[u])) keep_cand |= 1u << u;
+  for (int u = 0; u < kTileKeep; ++u) {
+    if (rb[u] >= 0 && !mine(rv[u])) rb[u] = -1;
+    if (rb[u] >= 0 && visit(1, rv[u], rb[u])) keep_cand |= 1u << u;
+  }
   for (int base = kTileThreads * kTileKeep; base < T; base += kTileThreads * kTileR) {
     float4 xv[kTileR];
     int xb[kTileR];
@@ -773,13 +776,13 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
     for (int u = 0; u < kTileR; ++u) fetch(base + u * kTileThreads + (int)threadIdx.x, xv[u], xb[u]);
 #pragma unroll
     for (int u = 0; u < kTileR; ++u)
-      if (xb[u] >= 0) visit(1, 2, xv[u], xb[u]);
+      if (xb[u] >= 0 && mine(xv[u])) visit(1, xv[u], xb[u]);
   }
   __syncthreads();
   stamp(2);
 #pragma unroll
   for (int u = 0; u < kTileKeep; ++u)
-    if ((keep_cand >> u) & 1u) visit(2, 2, rv[u], rb[u]);
+    if ((keep_cand >> u) & 1u) visit(2, rv[u], rb[u]);
   for (int base = kTileThreads * kTileKeep; base < T; base += kTileThreads * kTileR) {
     float4 xv[kTileR];
     int xb[kTileR];
@@ -787,14 +790,14 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
     for (int u = 0; u < kTileR; ++u) fetch(base + u * kTileThreads + (int)threadIdx.x, xv[u], xb[u]);
 #pragma unroll
     for (int u = 0; u < kTileR; ++u)
-      if (xb[u] >= 0) visit(2, 2, xv[u], xb[u]);
+      if (xb[u] >= 0 && mine(xv[u])) visit(2, xv[u], xb[u]);
   }
   __syncthreads();
   stamp(3);
   // epilogue: winners out (coalesced 8 B/lane) + max raw inside weight of this tile
   // (truncated_distance_function.py:198-204: -1 where no winner, + offset, clamp at 0)
   const float offset = other ? 0.0f : a.sdf_offset;
-  unsigned long long *Wg = a.W + (int64_t)g * D * D * D + (int64_t)x * nvox;
+  unsigned long long *Wg = a.W + (int64_t)g * D * D * D + ((int64_t)x * D + y0) * D;
   float wmax = 0.0f;
   for (int i0 = threadIdx.x; i0 < nvox; i0 += kTileThreads * 4) {
     uint32_t lo[4];
@@ -1298,8 +1301,9 @@ void launch_front(const IccArgs &a, int ks, int SX, hipStream_t stream) {
   }
   const int hmax = (a.nbins - D) / 2;
   hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, hmax);
-  const size_t lds = (size_t)D * D * 2 * sizeof(uint32_t);
-  hipLaunchKernelGGL(k_icc_tile, dim3(D, 2 * a.O), dim3(kTileThreads), lds, stream, a, hmax);
+  const size_t lds = (size_t)((D + kTileStripes - 1) / kTileStripes) * D * 2 * sizeof(uint32_t);
+  hipLaunchKernelGGL(k_icc_tile, dim3(D * kTileStripes, 2 * a.O), dim3(kTileThreads), lds, stream, a,
+                     hmax);
 }
 
 void launch_iteration(const IccArgs &a, int ks, int SX, int NB, int max_ns, int mode, float *q,

@@ -154,6 +154,41 @@ def test_interpolate_voxel_grid_fwd_bwd_vs_oracle(shape, n, channels_first):
     np.testing.assert_allclose(vt.grad.cpu().numpy(), gref, rtol=1e-5, atol=1e-5)  # float atomics order
 
 
+@pytest.mark.parametrize("channels_first", [False, True])
+def test_interpolate_voxel_grid_row_ranges_and_orphan_rows(channels_first):
+    """``batch_start`` (rows of item b = [start[b], start[b+1])): same bits as the batch_indices
+    scan, forward and backward, with ragged items and one empty item; rows whose batch index is
+    outside [0, B) -- or outside every range -- come back as zeros on both paths."""
+    rs = np.random.RandomState(5)
+    shape = (4, 256, 16, 16, 16)
+    counts = [700, 0, 1300, 500]
+    n_orphan = 37
+    n = sum(counts) + n_orphan
+    bi = np.concatenate([np.full(c, b, np.int32) for b, c in enumerate(counts)] + [np.full(n_orphan, 9, np.int32)])
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    vox = rs.uniform(-1, 1, shape).astype(np.float32)
+    pts = (rs.uniform(-0.1, 1.1, (n, 3)) * 16).astype(np.float32)
+    gy = rs.uniform(-1, 1, (n, shape[1])).astype(np.float32)
+    outs, grads = [], []
+    for bs in (None, dev(start)):
+        vt = dev(vox).requires_grad_(True)
+        out = F.interpolate_voxel_grid(vt, dev(pts), dev(bi), channels_first=channels_first, batch_start=bs)
+        out.backward(dev(gy.T.copy() if channels_first else gy))
+        got = out.detach().cpu().numpy()
+        outs.append(got.T if channels_first else got)
+        grads.append(vt.grad.cpu().numpy())
+    valid = bi < 4
+    ref = O.interpolate_voxel_grid(vox, pts[valid], bi[valid], mode="gpu")
+    for got in outs:
+        np.testing.assert_array_equal(got[valid], ref)
+        np.testing.assert_array_equal(got[~valid], 0.0)
+    gref = O.interpolate_voxel_grid_backward(gy[valid], pts[valid], bi[valid], shape, mode="gpu")
+    for g in grads:
+        np.testing.assert_allclose(g, gref, rtol=1e-5, atol=1e-5)
+    with pytest.raises(TypeError):
+        F.interpolate_voxel_grid(dev(vox), dev(pts), dev(bi), batch_start=dev(start[:-1]))
+
+
 # ---- A5 ------------------------------------------------------------------------------
 def test_occupancy_grid_3d_known_answer_and_config1():
     g = golden("ref_occupancy_grid_3d.npz")

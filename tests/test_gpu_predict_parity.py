@@ -38,7 +38,7 @@ def _avg_cpu(values, points, batch_indices, *, batch_size, origin, pitch, dimens
     return (torch.from_numpy(m), torch.from_numpy(c)) if return_counts else torch.from_numpy(m)
 
 
-def _interp_cpu(vox, points, batch_indices, channels_first=False):
+def _interp_cpu(vox, points, batch_indices, channels_first=False, batch_start=None):
     out = torch.from_numpy(OC.interpolate_voxel_grid(vox.numpy(), points.numpy(), batch_indices.numpy()))
     return out.t().contiguous() if channels_first else out
 

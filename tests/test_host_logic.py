@@ -334,7 +334,7 @@ def test_predict_host_logic_decoder_modes_agree(monkeypatch):
                                           batch_size=batch_size, origin=origin, pitch=pitch, dimensions=dimensions)
         return (torch.from_numpy(m), torch.from_numpy(c)) if return_counts else torch.from_numpy(m)
 
-    def interp_cpu(vox, points, batch_indices, channels_first=False):
+    def interp_cpu(vox, points, batch_indices, channels_first=False, batch_start=None):
         out = torch.from_numpy(OC.interpolate_voxel_grid(vox.numpy(), points.numpy(), batch_indices.numpy()))
         return out.t().contiguous() if channels_first else out
 
