@@ -11,21 +11,27 @@
 //   (examples/ycb_video/pose_refinement/check_iterative_collision_check_link.py:52-79).
 //
 // Here one iteration is THREE launches and the whole n_iter loop is one hipGraph:
-//   k_icc_tdf    grid (x-plane tile, 2*O): pose -> world point -> TDF of the "own" / "other"
-//                point set of object o; the tile's (min distance, arg-min id) live in LDS as
-//                two 32-bit words per voxel and are resolved with two passes of 32-bit LDS
-//                atomics (64-bit LDS atomics measured ~10x slower); epilogue stores the
-//                winners and the per-grid max of the raw inside weight (integer atomicMax).
+//   k_icc_bin    one workgroup per (target grid, source object, chunk of 1024 points).  Inside
+//                the loop it first applies the PREVIOUS iteration's optimiser step for its source
+//                object (the reduced gradient is ~200 fixed-point words: every workgroup
+//                recomputes the same bits, one designated workgroup per object stores them),
+//                then transforms its points once and appends the survivors' voxel-frame
+//                coordinates to the bin of their rounded x-plane.
+//   k_icc_tile   grid (x-plane * y-stripe, 2*O): TDF of the "own" / "other" point set of object
+//                o from bins x-h..x+h; (min distance, arg-min id) live in LDS as two 32-bit words
+//                per voxel, resolved with two passes of 32-bit LDS atomics (64-bit LDS atomics
+//                measured ~10x slower); epilogue stores the winners and the per-grid max of
+//                the raw inside weight (integer atomicMax).
 //   k_icc_accum  grid (block, O): per voxel pseudo-occupancy weights, max() with the
-//                no-entry grid, partial sums of reward / penalty AND the pose-gradient
-//                moments.  The loss gradient is linear in {1/S_t, 1/S_in, PN/S_in^2},
-//                so moments are accumulated per coefficient and combined later --
-//                no second pass over the grids once the global sums are known.
-//   k_icc_step   grid (scene): fixed-order reduction of the partials, loss, chain rule
-//                to (q, t), chainer-Adam update, next iteration's rotation matrices.
-// Every reduction has a fixed order (ordered partials, wave-sliced block sums, integer
-// fixed-point limbs for the cross-object collision terms): bitwise reproducible run to
-// run.  No host synchronisation anywhere.  MF_ICC_DEBUG / MF_ICC_SX are tuning aids.
+//                no-entry grid, sums of reward / penalty AND the pose-gradient moments.  The
+//                loss gradient is linear in {1/S_t, 1/S_in, PN/S_in^2}, so moments are
+//                accumulated per coefficient and combined later -- no second pass over the
+//                grids once the global sums are known.  Block sums are added as 64-bit fixed
+//                point with global integer atomics: exact, order-independent.
+//   k_icc_step   (once, after the last iteration; and for mf_icc_loss_grad) the same per-object
+//                step as a kernel of its own: loss, chain rule to (q, t), chainer-Adam.
+// Every reduction has a fixed order or is an integer sum: bitwise reproducible run to run.
+// No host synchronisation anywhere.  MF_ICC_DEBUG is a tuning aid.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -42,12 +48,15 @@ namespace {
 
 __device__ unsigned long long g_dbg_stamps[4096 * 8];  // tuning aid (MF_ICC_DEBUG & 32)
 
-constexpr int kTdfThreads = 1024;
 constexpr int kAccThreads = 512;
 constexpr int kVoxPerBlock = 1024;  // k_icc_accum: voxels per workgroup
 constexpr int kNumOwn = 39;         // RN, S_in, PN + 3 x 12 gradient moments
 constexpr uint32_t kNoCand = 0xffffffffu;
-constexpr double kFix = 17592186044416.0;  // 2^44 fixed point for the collision moments
+constexpr double kFix = 17592186044416.0;  // 2^44 fixed point for the collision moments (per block)
+constexpr double kFixOth = 1099511627776.0;  // 2^40: collision moments summed over blocks
+constexpr double kFixOwn = 4294967296.0;     // 2^32: reward / penalty sums and own-gradient moments
+constexpr int kOwnSlots = kNumOwn + 1;       // + count of non-finite block sums (-> NaN loss)
+constexpr int kStateFloats = 21;             // q[4] t[3] m[7] v[7] of one object
 constexpr int kMaxSceneObjects = 32;
 
 struct IccArgs {
@@ -67,13 +76,16 @@ struct IccArgs {
   float *Rt;              // [O][12]  R row-major, then t
   float *bound;           // [O][4]   model-frame bounding sphere
   float *St;              // [S]
-  float *part;            // [O][NB][kNumOwn]
-  float *oth;             // [O][NB][max_ns][12] collision moments per block
+  // reduced sums of one iteration, 64-bit fixed point, two parities (iteration k adds into
+  // k & 1 while the step folded into k_icc_bin still reads (k - 1) & 1)
+  long long *acc_own;     // [2][O][kOwnSlots]
+  long long *acc_oth;     // [2][O][max_ns][12]  collision moments of grid o onto scene object e
+  float *state_alt;       // [O][kStateFloats] second copy of (q, t, m, v): odd iterates
   int max_ns;
-  int32_t *step;          // [S] (unused scratch)
   int4 *meta;             // [O] {scene first object, scene end object, point begin, point end}
   // x-plane bins of the per-iteration point binning (k_icc_bin -> k_icc_tile)
   int4 *tab;              // [n_tab] {target object o, source object j, point begin, point end}; o < 0: unused
+  int4 *tab2;             // [n_tab] {scene first object, objects in scene, scene, 1 = designated entry of j}
   int n_tab;
   int nbins;              // D + 2h planes: rounded x in [-h, D-1+h]
   uint32_t *bin_cnt;      // [2*O][nbins] records in each bin (zero between iterations)
@@ -196,7 +208,6 @@ __global__ __launch_bounds__(256) void k_icc_bound(IccArgs a) {
 __global__ __launch_bounds__(256) void k_icc_scene_setup(IccArgs a, int32_t step0) {
   __shared__ float s_red[4];
   const int s = blockIdx.x;
-  if (threadIdx.x == 0) a.step[s] = step0;
   const int V = a.D * a.D * a.D;
   const int64_t b0 = (int64_t)a.scene_off[s] * V, b1 = (int64_t)a.scene_off[s + 1] * V;
   float acc = 0.0f;
@@ -207,8 +218,10 @@ __global__ __launch_bounds__(256) void k_icc_scene_setup(IccArgs a, int32_t step
   if (threadIdx.x == 0) a.St[s] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
+// Start of a loss evaluation / refinement: R|t from (q, t); empty accumulators of parity 0 and
+// the per-grid maxima; traj[0] = the initial pose.
 __global__ __launch_bounds__(64) void k_icc_pose(IccArgs a, const float *__restrict__ q,
-                                                 const float *__restrict__ t) {
+                                                 const float *__restrict__ t, float *traj) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= a.O) return;
   float R[9];
@@ -219,268 +232,24 @@ __global__ __launch_bounds__(64) void k_icc_pose(IccArgs a, const float *__restr
   for (int i = 0; i < 3; ++i) a.Rt[12 * o + 9 + i] = t[3 * o + i];
   a.Mbits[2 * o] = 0;
   a.Mbits[2 * o + 1] = 0;
+  for (int i = 0; i < kOwnSlots; ++i) a.acc_own[(int64_t)o * kOwnSlots + i] = 0;
+  for (int i = 0; i < a.max_ns * 12; ++i) a.acc_oth[(int64_t)o * a.max_ns * 12 + i] = 0;
+  if (traj) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) traj[7 * o + i] = q[4 * o + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) traj[7 * o + 4 + i] = t[3 * o + i];
+  }
 }
 
-// ---- launch 1: TDF tiles in LDS -------------------------------------------------
-// What measurement taught (profiles/): a dependent global load costs ~0.3-0.7 us, an
-// empty launch ~5 us, ds_min_u64 is ~an order of magnitude slower than 32-bit LDS
-// atomics, and every slab workgroup re-scanning every point is instruction-bound.  So:
-//  (1) the <= 32 source objects' R|t, bounding spheres and point ranges are fetched by
-//      one lane each, in parallel; whole objects are culled by their bounding sphere;
-//  (2) objects are walked wave-uniformly (R|t in scalar registers, ~20 instructions per
-//      rejected point), U loads in flight per lane;
-//  (3) points whose 3^3 neighbourhood touches this tile are appended to an LDS list
-//      (wave-aggregated), then (survivor, offset) work items are spread over all lanes;
-//  (4) (min, arg-min) is resolved with two passes of 32-bit LDS atomics: pass 1
-//      atomicMin(distance bits), pass 2 atomicMin(candidate id) among the candidates
-//      that equal the minimum -- exact, deterministic (lowest id among ties).
-// KS = kernel size of truncated_distance_function.py:36-38 (3 for voxel_threshold 2).
-constexpr int kSurvCap = 12288;  // LDS survivor list of packed (object slot, point id): 48 KB
-
-template <int KS>
-__global__ __launch_bounds__(kTdfThreads, 8) void k_icc_tdf(IccArgs a, int ks_rt, int SX) {
-  MF_DYN_LDS(uint32_t, s_dyn1);  // dist[nvox], id[nvox]
-  __shared__ float s_Rt[kMaxSceneObjects][12];
-  __shared__ int s_p0[kMaxSceneObjects], s_p1[kMaxSceneObjects];
-  __shared__ uint32_t s_surv[kSurvCap];  // (object slot << 27) | point id
-  __shared__ int s_nsurv;
-  __shared__ float s_max[kTdfThreads / 64];
-  const int ks = KS > 0 ? KS : ks_rt;
-  const int h = ks / 2, K = ks * ks * ks;
-  const int D = a.D;
-  const int g = blockIdx.y, o = g >> 1, other = g & 1;
-  const int4 meta = a.meta[o];  // {ja, jb, p0, p1}
-  const int ja = meta.x, jb = meta.y;
-  const int Ns = jb - ja;
-  const int x0 = blockIdx.x * SX;
-  const int sx = min(SX, D - x0);
-  const int nvox = sx * D * D;
-  uint32_t *s_dist = s_dyn1, *s_id = s_dyn1 + SX * D * D;
-  const float pitch = a.pitch[o];
-  const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
-  const float trunc = a.thr * pitch;
-  const float fh = (float)h, inv_pitch = 1.0f / pitch;
-  // conservative (approximate-arithmetic) rejection bounds, in voxel units
-  const float xlo = (float)x0 - fh - 0.51f, xhi = (float)(x0 + sx - 1) + fh + 0.51f;
-  const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
-  for (int i = threadIdx.x; i < nvox; i += kTdfThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
-  if (threadIdx.x == 0) s_nsurv = 0;
-  // (1) per-object metadata, one lane per object
-  if (threadIdx.x < Ns) {
-    const int j = ja + threadIdx.x;
-    int p0 = 0, p1 = 0;
-    if (other ? (j != o) : (j == o)) {
-      const float4 r0 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j);
-      const float4 r1 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 4);
-      const float4 r2 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 8);
-      const float4 b = *reinterpret_cast<const float4 *>(a.bound + 4 * j);
-      const int4 mj = a.meta[j];
-      float *R = s_Rt[threadIdx.x];
-      R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y;
-      R[6] = r1.z; R[7] = r1.w; R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w;
-      // whole-object rejection with the model's bounding sphere
-      const float cx = (((R[0] * b.x + R[1] * b.y) + R[2] * b.z) + R[9] - ox) * inv_pitch;
-      const float cy = (((R[3] * b.x + R[4] * b.y) + R[5] * b.z) + R[10] - oy) * inv_pitch;
-      const float cz = (((R[6] * b.x + R[7] * b.y) + R[8] * b.z) + R[11] - oz) * inv_pitch;
-      const float r = b.w * inv_pitch + 0.05f + 1e-4f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
-      const bool hit = b.w >= 0.0f && !(cx + r < xlo || cx - r > xhi || cy + r < glo ||
-                                        cy - r > ghi || cz + r < glo || cz - r > ghi);
-      if (hit) { p0 = mj.z; p1 = mj.w; }
-    }
-    s_p0[threadIdx.x] = p0;
-    s_p1[threadIdx.x] = p1;
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-
-  // Work item = one survivor: its ks*ks (y, z) columns times the x offsets inside this
-  // tile.  Instruction count per lane is what bounds this kernel (1024 lanes share 4
-  // SIMDs: ~8 cycles per instruction), so the inner loop is kept lean:
-  //  pass 1 works on SQUARED distances in voxel units -- no sqrt, no pitch: ~15
-  //         instructions per candidate; 32-bit atomicMin of the d2 bits behind a peek.
-  //         dist = pitch*sqrt(d2) is monotone in d2, so the minimum is the same voxel.
-  //  pass 2 re-derives, only for survivors that touched a minimum, the EXACT float
-  //         distance of near-minimal candidates (d2 within a few ulp) and, where it equals
-  //         the exact minimum and is < truncation, takes atomicMin of the candidate id:
-  //         identical winners to the oracle (lowest id among equal ROUNDED distances).
-  const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test later
-  auto items = [&](const int ns, const int pass, unsigned long long &maybe, const bool marks) {
-    int item_no = 0;
-    for (int si = threadIdx.x; si < ns; si += kTdfThreads, ++item_no) {
-      const int mbit = item_no < 63 ? item_no : 63;
-      if (pass == 2 && marks && !((maybe >> mbit) & 1ull)) continue;
-      const uint32_t packed = s_surv[si];
-      const uint32_t pid = packed & 0x07ffffffu;
-      const float *R = s_Rt[packed >> 27];
-      const float4 m = a.pts4[pid];
-      // same expressions as the scan -> bit-identical coordinates
-      float4 sv;
-      sv.x = ((((R[0] * m.x + R[1] * m.y) + R[2] * m.z) + R[9]) - ox) / pitch;
-      sv.y = ((((R[3] * m.x + R[4] * m.y) + R[5] * m.z) + R[10]) - oy) / pitch;
-      sv.z = ((((R[6] * m.x + R[7] * m.y) + R[8] * m.z) + R[11]) - oz) / pitch;
-      const int irx = (int)roundf(sv.x), iry = (int)roundf(sv.y), irz = (int)roundf(sv.z);
-      const uint32_t idb = pid * (uint32_t)K;
-      const int bb0 = max(0, x0 - irx + h), bb1 = min(ks - 1, x0 + sx - 1 - irx + h);
-      bool cand = false;
-      for (int bb = bb0; bb <= bb1; ++bb) {
-        const int ix = irx + bb - h;
-        const float dx = sv.x - (float)ix;
-        const float dx2 = dx * dx;
-#pragma unroll
-        for (int aa = 0; aa < ks; ++aa) {
-          const int iy = iry + aa - h;
-          if (iy < 0 || iy >= D) continue;
-          const float dy = sv.y - (float)iy;
-          const float dxy = dx2 + dy * dy;  // (dx^2 + dy^2) + dz^2: the oracle's order
-          const int lrow = ((ix - x0) * D + iy) * D;
-#pragma unroll
-          for (int cc = 0; cc < ks; ++cc) {
-            const int iz = irz + cc - h;
-            if (iz < 0 || iz >= D) continue;
-            const float dz = sv.z - (float)iz;
-            const float d2 = dxy + dz * dz;
-            if (!(d2 < d2_hi)) continue;
-            const uint32_t db = __float_as_uint(d2);
-            const uint32_t cur = s_dist[lrow + iz];
-            if (pass == 1) {
-              if (db <= cur) { atomicMin(&s_dist[lrow + iz], db); cand = true; }
-            } else if (db <= cur + 8u) {  // within a few ulp of the minimal d2
-              const float dist = pitch * sqrtf(d2);
-              const float dmin = pitch * sqrtf(__uint_as_float(cur));
-              if (dist == dmin && dist < trunc)
-                atomicMin(&s_id[lrow + iz], idb + (uint32_t)((aa * ks + bb) * ks + cc));
-            }
-          }
-        }
-      }
-      if (pass == 1 && cand) maybe |= 1ull << mbit;
-    }
-  };
-
-  // Stream every accepted object (wave-uniform R|t), appending tile survivors to the LDS
-  // list; whenever the list could overflow during the next super-chunk it is drained
-  // through items(pass) -- block-uniform decision behind a barrier.  Returns whether it
-  // drained (then pass 2 must re-stream, because the list no longer holds everything).
-  constexpr int U = 2;
-  auto scan = [&](const int pass) -> bool {
-    bool drained = false;
-    unsigned long long unused = 0ull;
-    for (int e = 0; e < Ns; ++e) {
-      const int p0 = s_p0[e], p1 = s_p1[e];  // block-uniform
-      if (p1 <= p0) continue;
-      const float R0 = s_Rt[e][0], R1 = s_Rt[e][1], R2 = s_Rt[e][2], R3 = s_Rt[e][3],
-                  R4 = s_Rt[e][4], R5 = s_Rt[e][5], R6 = s_Rt[e][6], R7 = s_Rt[e][7],
-                  R8 = s_Rt[e][8], T0 = s_Rt[e][9], T1 = s_Rt[e][10], T2 = s_Rt[e][11];
-      for (int c0 = p0; c0 < p1; c0 += kTdfThreads * U) {
-        float4 mm[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int p = c0 + u * kTdfThreads + threadIdx.x;
-          mm[u] = p < p1 ? a.pts4[p] : make_float4(0, 0, 0, 0);
-        }
-        __syncthreads();  // s_nsurv below is the value every lane agrees on
-        if (s_nsurv + kTdfThreads * U > kSurvCap) {
-          items(s_nsurv, pass, unused, false);
-          __syncthreads();
-          if (threadIdx.x == 0) s_nsurv = 0;
-          __syncthreads();
-          drained = true;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int p = c0 + u * kTdfThreads + threadIdx.x;
-          bool surv = false;
-          float fx = 0, fy = 0, fz = 0;
-          if (p < p1) {
-            const float4 m = mm[u];
-            // transform_points: ((R0 x + R1 y) + R2 z) + t, un-fused (oracle order)
-            const float wx = ((R0 * m.x + R1 * m.y) + R2 * m.z) + T0;
-            const float ax = (wx - ox) * inv_pitch;  // cheap reject before the IEEE divides
-            const float ex = 0.01f + 1e-5f * fabsf(ax);
-            if (ax >= xlo - ex && ax <= xhi + ex) {
-              const float wy = ((R3 * m.x + R4 * m.y) + R5 * m.z) + T1;
-              const float wz = ((R6 * m.x + R7 * m.y) + R8 * m.z) + T2;
-              fx = (wx - ox) / pitch; fy = (wy - oy) / pitch; fz = (wz - oz) / pitch;
-              const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
-              surv = rx + fh >= (float)x0 && rx - fh < (float)(x0 + sx) && ry + fh >= 0.0f &&
-                     ry - fh < (float)D && rz + fh >= 0.0f && rz - fh < (float)D;
-            }
-          }
-          const unsigned long long mask = (a.dbg & 2) ? 0ull : __ballot(surv);
-          if (mask == 0ull) continue;  // wave-uniform
-          int base = 0;
-          if (lane == 0) base = atomicAdd(&s_nsurv, __popcll(mask));
-          base = __shfl(base, 0, 64);
-          if (surv)
-            s_surv[base + __popcll(mask & ((1ull << lane) - 1ull))] =
-                ((uint32_t)e << 27) | (uint32_t)p;
-        }
-      }
-    }
-    return drained;
-  };
-
-  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-  auto stamp = [&](int i) {
-    if ((a.dbg & 32) && threadIdx.x == 0 && wg < 4096) g_dbg_stamps[wg * 8 + i] = wall_clock64();
-  };
-  stamp(0);
-  unsigned long long maybe = 0ull;
-  bool drained = false;
-  if (!(a.dbg & 1)) drained = scan(1);
-  __syncthreads();
-  stamp(1);
-  if ((a.dbg & 32) && threadIdx.x == 0 && wg < 4096) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)s_nsurv | ((unsigned long long)drained << 32);
-  if (!drained) {  // the common case: the whole tile's survivors are in LDS
-    const int ns = (a.dbg & 4) ? 0 : s_nsurv;
-    items(ns, 1, maybe, true);
-    __syncthreads();
-    stamp(2);
-    items(ns, 2, maybe, true);
-  } else {  // crowded tile: finish pass 1, then stream everything again for the ids
-    items(s_nsurv, 1, maybe, false);
-    __syncthreads();
-    if (threadIdx.x == 0) s_nsurv = 0;
-    __syncthreads();
-    scan(2);
-    __syncthreads();
-    items(s_nsurv, 2, maybe, false);
-  }
-  __syncthreads();
-  stamp(3);
-  // epilogue: winners out (coalesced 8 B/lane) + max raw inside weight of this tile
-  // (truncated_distance_function.py:198-204: -1 where no winner, + offset, clamp at 0)
-  const float offset = other ? 0.0f : a.sdf_offset;
-  unsigned long long *Wg = a.W + (int64_t)g * D * D * D + (int64_t)x0 * D * D;
-  float wmax = 0.0f;
-  for (int i = threadIdx.x; i < nvox; i += kTdfThreads) {
-    const uint32_t lo = s_id[i];  // set only where pitch*sqrt(min d2) < trunc
-    const float dist = lo != kNoCand ? pitch * sqrtf(__uint_as_float(s_dist[i])) : trunc;
-    Wg[i] = ((unsigned long long)__float_as_uint(dist) << 32) | lo;
-    float w = (lo != kNoCand ? a.pts4[lo / (uint32_t)K].w : -1.0f) + offset;
-    w = w < 0.0f ? 0.0f : w;
-    wmax = fmaxf(wmax, w);
-  }
-  wmax = mf::wave_max(wmax);
-  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = wmax;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float m = s_max[0];
-#pragma unroll
-    for (int i = 1; i < kTdfThreads / 64; ++i) m = fmaxf(m, s_max[i]);
-    atomicMax(&a.Mbits[g], __float_as_uint(m));  // m >= 0: uint order == float order
-  }
-  stamp(4);
-}
-
-// ---- v2 front end: per-iteration x-plane binning + bin-fed TDF tiles -----------------
-// v1's k_icc_tdf lets every one of the 32 plane workgroups of a grid re-scan all source points of
-// the scene (32x read amplification, a dependent global load per work item).  v2 transforms every
-// (source point, target grid) pair ONCE (k_icc_bin), appends the survivors' voxel-frame
-// coordinates to the bin of their rounded x-plane, and the tile of plane x reads only bins
-// x-h..x+h (k_icc_tile): records arrive as coalesced 16 B loads, both LDS passes run on
-// registers + LDS only.  Coordinates are computed with the oracle's expressions, the candidate
-// set of a tile is exactly v1's survivor set, (min, arg-min) are exact -> bit-identical winners.
+// ---- front end: per-iteration x-plane binning + bin-fed TDF tiles ----------------------
+// Round 1 let every one of the 32 plane workgroups of a grid re-scan all source points of the
+// scene (32x read amplification, a dependent global load per work item).  Now every (source
+// point, target grid) pair is transformed ONCE (k_icc_bin), the survivors' voxel-frame
+// coordinates are appended to the bin of their rounded x-plane, and the tile of plane x reads
+// only bins x-h..x+h (k_icc_tile): records arrive as coalesced 16 B loads, both LDS passes run
+// on registers + LDS only.  Coordinates are computed with the oracle's expressions and (min,
+// arg-min) are exact -> the same winners (verified bit-identical against round 1 on the GPU).
 constexpr int kBinThreads = 256;
 constexpr int kBinPPT = 4;                          // points per thread
 constexpr int kBinChunk = kBinThreads * kBinPPT;    // points per workgroup
@@ -505,8 +274,14 @@ __global__ __launch_bounds__(256) void k_icc_tables(IccArgs a) {
       rec_off += (int64_t)a.nbins * (p_all - p_own);
       for (int j = ja; j < jb; ++j) {
         const int p0 = a.obj_off[j], p1 = a.obj_off[j + 1];
-        for (int c = p0; c < p1; c += kBinChunk)
-          if (tab_off < a.n_tab) a.tab[tab_off++] = make_int4(o, j, c, min(c + kBinChunk, p1));
+        // the first chunk of the pair (j, j) is the designated entry of object j: it stores the
+        // optimiser step folded into k_icc_bin (exists even for an object without points)
+        for (int c = p0; c < p1 || (c == p0 && j == o); c += kBinChunk)
+          if (tab_off < a.n_tab) {
+            a.tab[tab_off] = make_int4(o, j, c, min(c + kBinChunk, p1));
+            a.tab2[tab_off] = make_int4(ja, jb - ja, sc, (j == o && c == p0) ? 1 : 0);
+            ++tab_off;
+          }
       }
     }
     s_tab_base[0] = tab_off;
@@ -516,9 +291,105 @@ __global__ __launch_bounds__(256) void k_icc_tables(IccArgs a) {
   for (int i = threadIdx.x; i < 2 * a.O * a.nbins; i += blockDim.x) a.bin_cnt[i] = 0u;
 }
 
+// ---- the optimiser step of ONE object from the reduced sums of an iteration ------------
+// (iterative_collision_check_link.py:91-98 loss; chain rule through transformation_matrix /
+// quaternion_matrix.py:36-78; chainer.optimizers.Adam v7 in float32).  A pure function of global
+// memory: every workgroup that needs object j's next pose evaluates it and gets the same bits.
+// `sv` = 52 sums gathered by the caller (LDS or registers): [0..2] RN, S_in, PN of the scene,
+// [3..38] the 3 x 12 own-gradient moments of j, [39..50] collision moments onto j, [51] != 0 if
+// any block sum of the scene was not finite.
+constexpr int kStepSums = 52;
+
+struct IccStepArgs {
+  int mode;        // 0: none (bin reads a.Rt), 1: Adam step + outputs, 2: gradients only (k_icc_step)
+  int par;         // parity of the accumulators to read
+  int it;          // iteration whose pose is produced (traj row; its loss goes to losses[it - 1])
+  float aq, at;    // alpha_t of chainer's Adam for this step (evaluated in double on the host)
+  const float *q_in, *t_in, *m_in, *v_in;  // state before the step
+  float *q_out, *t_out, *m_out, *v_out;    // state after it (may alias the inputs)
+  float *loss_out;                         // [S] or NULL
+  float *gq_out, *gt_out;                  // mode 2
+  float *traj;                             // [n_iter][O][7] or NULL
+};
+
+// Lane `l` of the calling workgroup gathers sum number l (l < kStepSums) of object j.
+__device__ __forceinline__ float icc_step_gather(const IccArgs &a, int par, int j, int ja, int Ns, int l) {
+  const long long *own = a.acc_own + (int64_t)par * a.O * kOwnSlots;
+  const long long *oth = a.acc_oth + (int64_t)par * a.O * a.max_ns * 12;
+  if (l < 3) {  // scene sums, objects in order
+    float s = 0.0f;
+    for (int jo = 0; jo < Ns; ++jo) s += (float)((double)own[(int64_t)(ja + jo) * kOwnSlots + l] / kFixOwn);
+    return s;
+  }
+  if (l < kNumOwn) return (float)((double)own[(int64_t)j * kOwnSlots + l] / kFixOwn);
+  if (l < kNumOwn + 12) {  // collision moments of every grid of the scene onto j: exact integer sum
+    long long x = 0;
+    for (int jo = 0; jo < Ns; ++jo) x += oth[((int64_t)(ja + jo) * a.max_ns + (j - ja)) * 12 + (l - kNumOwn)];
+    return (float)((double)x / kFixOth);
+  }
+  long long bad = 0;
+  for (int jo = 0; jo < Ns; ++jo) bad |= own[(int64_t)(ja + jo) * kOwnSlots + kNumOwn];
+  return bad != 0 ? 1.0f : 0.0f;
+}
+
+// sv: the gathered sums; st: (q, t, m, v) before the step.  Returns the pose to use next
+// (R|t, 12 floats) and, for mode 1, the state after the step.
+__device__ __forceinline__ void icc_step_apply(const float *sv, float S_t, const float *st,
+                                               const IccStepArgs &sp, float *Rt_out, float *st_out,
+                                               float &loss, float *gq, float *gt) {
+  const float RN = sv[0], S_in = sv[1], PN = sv[2];
+  const float reward = RN / S_t, penalty = PN / S_in;
+  loss = sv[51] != 0.0f ? __builtin_nanf("") : penalty - reward;
+  const float c0 = 1.0f / S_t, c1 = 1.0f / S_in, c2 = PN / (S_in * S_in);
+  float gR[9];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = 4 * d + c;
+      const float G = ((c0 * sv[3 + i] - c1 * sv[15 + i]) + c2 * sv[27 + i]) - c1 * sv[39 + i];
+      if (c < 3) gR[3 * d + c] = G; else gt[d] = G;
+    }
+  float qq[4], tt[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qq[i] = st[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tt[i] = st[4 + i];
+  quat_backward(qq, gR, gq);
+  if (sv[51] != 0.0f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gq[i] = loss;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gt[i] = loss;
+  }
+  if (sp.mode == 1) {
+    // chainer.optimizers.Adam (v7) update rule in float32
+    const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-8f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const float gi = i < 4 ? gq[i] : gt[i - 4];
+      float mm = st[7 + i], vv = st[14 + i];
+      mm += omb1 * (gi - mm);
+      vv += omb2 * (gi * gi - vv);
+      st_out[7 + i] = mm;
+      st_out[14 + i] = vv;
+      const float upd = (i < 4 ? sp.aq : sp.at) * mm / (sqrtf(vv) + eps);
+      if (i < 4) qq[i] -= upd; else tt[i - 4] -= upd;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) st_out[i] = qq[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) st_out[4 + i] = tt[i];
+  quat_to_R(qq, Rt_out);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Rt_out[9 + i] = tt[i];
+}
+
 // launch 1: one workgroup per (target grid, source object, chunk of <= 1024 points)
-__global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax) {
+__global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax, IccStepArgs sp) {
   __shared__ int s_cnt[kMaxBins], s_base[kMaxBins];
+  __shared__ float s_sum[kStepSums], s_state[kStateFloats];
   auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
     if ((a.dbg & 32) && threadIdx.x == 0 && blockIdx.x < 1024)
       g_dbg_stamps[(3072 + blockIdx.x) * 8 + i] = wall_clock64();
@@ -529,10 +400,24 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax) {
   if (o < 0) return;  // block-uniform
   const int D = a.D, nb = a.nbins;
   const int g = 2 * o + (j != o ? 1 : 0);
-  // everything below depends on the table entry only: one memory round trip
-  const float4 r0 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j);
-  const float4 r1 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 4);
-  const float4 r2 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 8);
+  // everything below depends on the table entries only: one memory round trip
+  const int4 e2 = a.tab2[blockIdx.x];  // {scene first object, objects in scene, scene, designated}
+  float4 r0, r1, r2;
+  float S_t = 1.0f;
+  if (sp.mode == 0) {
+    r0 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j);
+    r1 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 4);
+    r2 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 8);
+  } else {
+    // the previous iteration's reduced sums of object j (fixed point) and its optimiser state
+    if (threadIdx.x < kStepSums) s_sum[threadIdx.x] = icc_step_gather(a, sp.par, j, e2.x, e2.y, threadIdx.x);
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + kStateFloats) {
+      const int i = threadIdx.x - 64;
+      s_state[i] = i < 4 ? sp.q_in[4 * j + i] : i < 7 ? sp.t_in[3 * j + i - 4]
+                   : i < 14 ? sp.m_in[7 * j + i - 7] : sp.v_in[7 * j + i - 14];
+    }
+    S_t = a.St[e2.z];
+  }
   const float4 bnd = *reinterpret_cast<const float4 *>(a.bound + 4 * j);
   const float pitch = a.pitch[o];
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
@@ -545,6 +430,38 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax) {
     m[u] = p < e.w ? a.pts4[p] : make_float4(0, 0, 0, 0);
   }
   for (int i = threadIdx.x; i < nb; i += kBinThreads) s_cnt[i] = 0;
+  if (sp.mode != 0) {
+    __syncthreads();
+    // every lane evaluates the same step from LDS (broadcast reads): no second barrier
+    float Rt[12], st_new[kStateFloats], loss, gq[4], gt[3];
+    icc_step_apply(s_sum, S_t, s_state, sp, Rt, st_new, loss, gq, gt);
+    r0 = make_float4(Rt[0], Rt[1], Rt[2], Rt[3]);
+    r1 = make_float4(Rt[4], Rt[5], Rt[6], Rt[7]);
+    r2 = make_float4(Rt[8], Rt[9], Rt[10], Rt[11]);
+    if (e2.w != 0 && threadIdx.x == 0) {  // the designated workgroup of object j stores the step
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sp.q_out[4 * j + i] = st_new[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sp.t_out[3 * j + i] = st_new[4 + i];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) { sp.m_out[7 * j + i] = st_new[7 + i]; sp.v_out[7 * j + i] = st_new[14 + i]; }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) a.Rt[12 * j + i] = Rt[i];
+      if (sp.traj) {
+        float *tr = sp.traj + ((int64_t)sp.it * a.O + j) * 7;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tr[i] = st_new[i];
+      }
+      if (sp.loss_out && j == e2.x) sp.loss_out[e2.z] = loss;
+      // empty this object's accumulators of the parity the coming k_icc_accum adds into
+      a.Mbits[2 * j] = 0;
+      a.Mbits[2 * j + 1] = 0;
+      long long *own = a.acc_own + ((int64_t)(sp.par ^ 1) * a.O + j) * kOwnSlots;
+      for (int i = 0; i < kOwnSlots; ++i) own[i] = 0;
+      long long *oth = a.acc_oth + ((int64_t)(sp.par ^ 1) * a.O + j) * a.max_ns * 12;
+      for (int i = 0; i < a.max_ns * 12; ++i) oth[i] = 0;
+    }
+  }
   const float R0 = r0.x, R1 = r0.y, R2 = r0.z, R3 = r0.w, R4 = r1.x, R5 = r1.y, R6 = r1.z,
               R7 = r1.w, R8 = r2.x, T0 = r2.y, T1 = r2.z, T2 = r2.w;
   const int h = min(ksize_of(a.thr, pitch) / 2, hmax);
@@ -610,16 +527,15 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax) {
 //         near-minimal candidates (d2 within a few ulp) and, where it equals the exact minimum
 //         and is < truncation, takes atomicMin of the candidate id: the same winners as
 //         the oracle (lowest id among equal ROUNDED distances).
-constexpr int kTileThreads = 256;
-constexpr int kTileStripes = 4;  // y-stripes per plane: a workgroup owns D/4 rows of one x-plane
-constexpr int kTileKeep = 10;    // records per lane kept in registers over both passes
+constexpr int kTileThreads = 512;
+constexpr int kTileStripes = 1;  // y-stripes per plane (measured: 4 stripes x 256 lanes 26.8 us vs 14.9 us)
+constexpr int kTileKeep = 6;     // records per lane kept in registers over both passes
 constexpr int kTileR = 4;        // records in flight per lane beyond those
 
-// A crowded plane (2400 records at 8 objects) is bound by instruction issue and same-address LDS
-// atomics of ONE workgroup while the other 500 idle: each plane is split in kTileStripes
-// y-stripes.  Every stripe workgroup streams all records of the plane's bins (16 B each, L2
-// hits) and keeps those whose ks rows touch its stripe; the (min, arg-min) of a voxel only
-// depends on the set of candidates, so the winners do not change.
+// A plane may be split in kTileStripes y-stripes (a workgroup then keeps only the records whose
+// ks rows touch its stripe; the (min, arg-min) of a voxel only depends on the set of candidates).
+// Measured on the 8-object scene: wave-level divergence makes every stripe pay for all records
+// of the plane -- one 512-lane workgroup per plane is faster.
 template <int KS>
 __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt, const int hmax) {
   MF_DYN_LDS(uint32_t, s_tile);  // dist[rows*D], id[rows*D]
@@ -857,7 +773,7 @@ __device__ __forceinline__ void world_frac(const float *Rt, const float4 m, floa
 constexpr int kVPT = kVoxPerBlock / kAccThreads;  // voxels per thread
 constexpr int kAccRep = 16;                       // replicas of the collision-limb accumulators
 
-__global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K_v1) {
+__global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   __shared__ float s_rows[kAccThreads / 16][kNumOwn + 1];  // 16-lane row sums (+1: bank spread)
   // collision moments as 2^44 fixed point split in three 20-bit limbs held in 32-bit LDS
   // words: <= 1024 adds per block can never overflow a limb, so plain NON-returning
@@ -890,9 +806,9 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K_v1) 
   if (blockIdx.x == 0)
     for (int i = threadIdx.x; i < 2 * a.nbins; i += kAccThreads) a.bin_cnt[(int64_t)2 * o * a.nbins + i] = 0u;
   const float pitch = a.pitch[o];
-  // candidate ids are point * K + offset with this grid's own kernel size (K_v1: round-1 front end)
+  // candidate ids are point * K + offset with this grid's own kernel size
   const int ks_o = ksize_of(a.thr, pitch);
-  const int K = K_v1 > 0 ? K_v1 : ks_o * ks_o * ks_o;
+  const int K = ks_o * ks_o * ks_o;
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
   const float M_own = __uint_as_float(a.Mbits[2 * o]);
   const float M_oth = __uint_as_float(a.Mbits[2 * o + 1]);
@@ -1019,15 +935,24 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K_v1) 
     if ((threadIdx.x & 15) == 0) s_rows[threadIdx.x >> 4][i] = r;
   }
   __syncthreads();
+  // The block sums join the object's accumulators as 64-bit fixed point: integer atomics are
+  // exact and order-independent, so the iteration's reduced sums (~200 words per scene) are
+  // bitwise reproducible and the optimiser step needs no reduction pass of its own.
+  long long *own = a.acc_own + ((int64_t)par * a.O + o) * kOwnSlots;
   if (threadIdx.x < kNumOwn) {
     float sacc = 0.0f;
 #pragma unroll
     for (int r = 0; r < kAccThreads / 16; ++r) sacc += s_rows[r][threadIdx.x];
-    a.part[((int64_t)o * gridDim.x + blockIdx.x) * kNumOwn + threadIdx.x] = sacc;
+    if (isfinite(sacc)) {
+      const long long x = __double2ll_rn((double)sacc * kFixOwn);
+      if (x != 0) atomicAdd(reinterpret_cast<unsigned long long *>(own + threadIdx.x), (unsigned long long)x);
+    } else {
+      atomicAdd(reinterpret_cast<unsigned long long *>(own + kNumOwn), 1ull);  // -> NaN loss
+    }
   }
   stamp(3);
-  // collision partials of this block (the barrier above orders the LDS atomics)
-  float *po = a.oth + ((int64_t)o * gridDim.x + blockIdx.x) * a.max_ns * 12;
+  // collision moments of this block (the barrier above orders the LDS atomics): 2^44 -> 2^40
+  long long *po = a.acc_oth + ((int64_t)par * a.O + o) * a.max_ns * 12;
   for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) {
     long long l0 = 0, l1 = 0, l2 = 0;
 #pragma unroll
@@ -1036,159 +961,45 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int K_v1) 
       l1 += (long long)s_lim[lim_words + r * lim_stride + i];
       l2 += (long long)(int32_t)s_lim[2 * lim_words + r * lim_stride + i];
     }
-    const long long x = (l2 << 40) + (l1 << 20) + l0;
-    po[i] = (float)((double)x / kFix);
+    const long long x = ((l2 << 40) + (l1 << 20) + l0) >> 4;
+    if (x != 0) atomicAdd(reinterpret_cast<unsigned long long *>(po + i), (unsigned long long)x);
   }
 }
 
-// ---- launch 3: reduce, loss, chain rule, chainer-Adam -----------------------------
-// One 1024-lane workgroup per scene.  Every partial is fetched with independent,
-// coalesced loads (one memory latency), reduced in LDS in a fixed order.
-// mode 0: write loss/gq/gt only.  mode 1: Adam update in place + refresh R|t.
-// aq/at: alpha_t of chainer's Adam for this step (evaluated in double on the host).
-constexpr int kStepThreads = 1024;
-
-__global__ __launch_bounds__(kStepThreads) void k_icc_step(IccArgs a, int NB, int mode, float *q,
-                                                           float *t, float *adam_m, float *adam_v,
-                                                           float aq, float at, float *loss_out,
-                                                           float *gq_out, float *gt_out,
-                                                           float *traj, int it) {
-  MF_DYN_LDS(float, s_dyn);
-  __shared__ float s_o[kMaxSceneObjects * 12];
-  __shared__ float s_coef[4];
-  const int sc = blockIdx.x;
-  const int ja = a.scene_off[sc], jb = a.scene_off[sc + 1];
-  const int Ns = jb - ja;
-  float *s_part = s_dyn;                      // [Ns*NB][kNumOwn] raw copy
-  float *s_tot = s_part + Ns * NB * kNumOwn;  // [Ns][kNumOwn]
-  float *s_G = s_tot + Ns * kNumOwn;          // [Ns][12]
-  float *s_orow = s_G + Ns * 12;              // [8][Ns*12] partial collision sums
+// ---- the step as a kernel of its own: one 64-lane workgroup per object ----------------
+// mode 1: after the last iteration of mf_icc_refine.  mode 2: mf_icc_loss_grad (loss, gq, gt).
+__global__ __launch_bounds__(64) void k_icc_step(IccArgs a, IccStepArgs sp) {
+  __shared__ float s_sum[kStepSums], s_state[kStateFloats];
+  const int j = blockIdx.x;
+  const int4 meta = a.meta[j];
+  const int ja = meta.x, Ns = meta.y - meta.x;
+  const int sc = a.obj_scene[j];
+  if (threadIdx.x < kStepSums) s_sum[threadIdx.x] = icc_step_gather(a, sp.par, j, ja, Ns, threadIdx.x);
+  if (threadIdx.x < kStateFloats) {
+    const int i = threadIdx.x;
+    s_state[i] = i < 4 ? sp.q_in[4 * j + i] : i < 7 ? sp.t_in[3 * j + i - 4]
+                 : (sp.mode == 1 ? (i < 14 ? sp.m_in[7 * j + i - 7] : sp.v_in[7 * j + i - 14]) : 0.0f);
+  }
   const float S_t = a.St[sc];
-  // independent, coalesced loads: own partials -> LDS
-  const float *src = a.part + (int64_t)ja * NB * kNumOwn;
-  const int n_own = Ns * NB * kNumOwn;
-  for (int i = threadIdx.x; i < n_own; i += kStepThreads) s_part[i] = src[i];
-  {
-    // collision partials [Ns*NB rows][max_ns*12]: 8 lane groups x (Ns*12) columns, each
-    // lane sums its rows in increasing order with 8 loads in flight; then the 8 groups
-    // are added in order -> fixed summation order, hence reproducible
-    const int row = a.max_ns * 12, ncol = Ns * 12, n_rows = Ns * NB;
-    const float *po = a.oth + (int64_t)ja * NB * row;
-    if (threadIdx.x < 8 * ncol) {
-      const int grp = threadIdx.x / ncol, c = threadIdx.x - grp * ncol;
-      float sacc = 0.0f;
-      for (int r0 = grp; r0 < n_rows; r0 += 64) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int r = r0 + 8 * u;
-          v[u] = r < n_rows ? po[(int64_t)r * row + c] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) sacc += v[u];
-      }
-      s_orow[threadIdx.x] = sacc;
-    }
-  }
   __syncthreads();
-  if (threadIdx.x < Ns * 12) {
-    float sacc = 0.0f;
+  if (threadIdx.x != 0) return;
+  float Rt[12], st_new[kStateFloats], loss, gq[4], gt[3];
+  icc_step_apply(s_sum, S_t, s_state, sp, Rt, st_new, loss, gq, gt);
+  if (sp.loss_out && j == ja) sp.loss_out[sc] = loss;
+  if (sp.mode == 1) {
 #pragma unroll
-    for (int grp = 0; grp < 8; ++grp) sacc += s_orow[grp * Ns * 12 + threadIdx.x];
-    s_o[threadIdx.x] = sacc;
-  }
-  // fixed-order reduction over blocks: 4 lanes per (object, component), 2 shuffle steps
-  for (int i = threadIdx.x; i < Ns * kNumOwn * 4; i += kStepThreads) {
-    const int oc = i >> 2, sub = i & 3;
-    const int jo = oc / kNumOwn, c = oc - jo * kNumOwn;
-    const float *p = s_part + (int64_t)jo * NB * kNumOwn + c;
-    float s = 0.0f;
-    for (int b = sub; b < NB; b += 4) s += p[b * kNumOwn];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (sub == 0) s_tot[oc] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float RN = 0.0f, S_in = 0.0f, PN = 0.0f;
-    for (int jo = 0; jo < Ns; ++jo) {
-      RN += s_tot[jo * kNumOwn + 0];
-      S_in += s_tot[jo * kNumOwn + 1];
-      PN += s_tot[jo * kNumOwn + 2];
-    }
-    // iterative_collision_check_link.py:91-98
-    const float reward = RN / S_t, penalty = PN / S_in;
-    if (loss_out) loss_out[sc] = penalty - reward;
-    s_coef[0] = 1.0f / S_t;
-    s_coef[1] = 1.0f / S_in;
-    s_coef[2] = PN / (S_in * S_in);
-  }
-  __syncthreads();
-  if (threadIdx.x < Ns * 12) {
-    const int jo = threadIdx.x / 12, c = threadIdx.x % 12;
-    const float *U = s_tot + jo * kNumOwn + 3;
-    const float oth = s_o[threadIdx.x];
-    s_G[threadIdx.x] = ((s_coef[0] * U[c] - s_coef[1] * U[12 + c]) + s_coef[2] * U[24 + c]) -
-                       s_coef[1] * oth;
-  }
-  __syncthreads();
-  if (threadIdx.x < Ns) {
-    const int o = ja + threadIdx.x;
-    const float *G = s_G + threadIdx.x * 12;
-    float gR[9], gt[3], gq[4], qq[4], tt[3];
+    for (int i = 0; i < 4; ++i) sp.q_out[4 * j + i] = st_new[i];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      gR[3 * d + 0] = G[4 * d + 0];
-      gR[3 * d + 1] = G[4 * d + 1];
-      gR[3 * d + 2] = G[4 * d + 2];
-      gt[d] = G[4 * d + 3];
-    }
+    for (int i = 0; i < 3; ++i) sp.t_out[3 * j + i] = st_new[4 + i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qq[i] = q[4 * o + i];
+    for (int i = 0; i < 7; ++i) { sp.m_out[7 * j + i] = st_new[7 + i]; sp.v_out[7 * j + i] = st_new[14 + i]; }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) tt[i] = t[3 * o + i];
-    quat_backward(qq, gR, gq);
-    if (gq_out) {
+    for (int i = 0; i < 12; ++i) a.Rt[12 * j + i] = Rt[i];
+  } else if (sp.gq_out) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) gq_out[4 * o + i] = gq[i];
+    for (int i = 0; i < 4; ++i) sp.gq_out[4 * j + i] = gq[i];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) gt_out[3 * o + i] = gt[i];
-    }
-    if (mode == 1) {
-      if (traj) {
-        float *tr = traj + ((int64_t)it * a.O + o) * 7;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tr[i] = qq[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) tr[4 + i] = tt[i];
-      }
-      // chainer.optimizers.Adam (v7) update rule in float32
-      const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-8f;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const float gi = i < 4 ? gq[i] : gt[i - 4];
-        float mm = adam_m[7 * o + i], vv = adam_v[7 * o + i];
-        mm += omb1 * (gi - mm);
-        vv += omb2 * (gi * gi - vv);
-        adam_m[7 * o + i] = mm;
-        adam_v[7 * o + i] = vv;
-        const float upd = (i < 4 ? aq : at) * mm / (sqrtf(vv) + eps);
-        if (i < 4) qq[i] -= upd; else tt[i - 4] -= upd;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) q[4 * o + i] = qq[i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) t[3 * o + i] = tt[i];
-      float R[9];
-      quat_to_R(qq, R);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) a.Rt[12 * o + i] = R[i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) a.Rt[12 * o + 9 + i] = tt[i];
-    }
-    // reset the per-iteration accumulators for the next launch 1
-    a.Mbits[2 * o] = 0;
-    a.Mbits[2 * o + 1] = 0;
+    for (int i = 0; i < 3; ++i) sp.gt_out[3 * j + i] = gt[i];
   }
 }
 
@@ -1202,7 +1013,8 @@ __global__ void k_pack(const float *__restrict__ points, const float *__restrict
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 struct WsLayout {
-  int64_t W, M, Rt, bound, St, part, oth, step, meta, tab, bin_cnt, bin_cap, bin_base, rec, total;
+  int64_t W, M, Rt, bound, St, acc_own, acc_oth, state_alt, meta, tab, tab2, bin_cnt, bin_cap, bin_base,
+      rec, total;
   int NB, n_tab, nbins;
 };
 
@@ -1221,19 +1033,20 @@ WsLayout ws_layout(const mfIccBatch *b) {
   l.NB = (int)((V + kVoxPerBlock - 1) / kVoxPerBlock);
   l.nbins = D + 2 * (ksize_host(b->voxel_threshold) / 2);
   // every (target, source) pair of a scene in chunks of kBinChunk points:
-  // sum_pairs ceil(P_j / chunk) <= max_ns * n_points / chunk + O * max_ns
-  l.n_tab = (int)(((int64_t)max_ns * b->n_points + kBinChunk - 1) / kBinChunk) + O * max_ns;
+  // sum_pairs ceil(P_j / chunk) <= max_ns * n_points / chunk + O * max_ns (+ O designated entries)
+  l.n_tab = (int)(((int64_t)max_ns * b->n_points + kBinChunk - 1) / kBinChunk) + O * max_ns + O;
   int64_t off = 0;
   l.W = off; off = align256(off + 2 * O * V * 8);
   l.M = off; off = align256(off + 2 * O * 4);
   l.Rt = off; off = align256(off + O * 12 * 4);
   l.bound = off; off = align256(off + O * 4 * 4);
   l.St = off; off = align256(off + S * 4);
-  l.part = off; off = align256(off + (int64_t)O * l.NB * kNumOwn * 4);
-  l.oth = off; off = align256(off + (int64_t)O * l.NB * kMaxSceneObjects * 12 * 4);
-  l.step = off; off = align256(off + S * 4);
+  l.acc_own = off; off = align256(off + (int64_t)2 * O * kOwnSlots * 8);
+  l.acc_oth = off; off = align256(off + (int64_t)2 * O * max_ns * 12 * 8);
+  l.state_alt = off; off = align256(off + (int64_t)O * kStateFloats * 4);
   l.meta = off; off = align256(off + (int64_t)O * 16);
   l.tab = off; off = align256(off + (int64_t)l.n_tab * 16);
+  l.tab2 = off; off = align256(off + (int64_t)l.n_tab * 16);
   l.bin_cnt = off; off = align256(off + (int64_t)2 * O * l.nbins * 4);
   l.bin_cap = off; off = align256(off + (int64_t)2 * O * 4);
   l.bin_base = off; off = align256(off + (int64_t)2 * O * 8);
@@ -1244,7 +1057,7 @@ WsLayout ws_layout(const mfIccBatch *b) {
   return l;
 }
 
-IccArgs make_args(const mfIccBatch *b, void *ws, int max_ns) {
+IccArgs make_args(const mfIccBatch *b, void *ws) {
   IccArgs a;
   a.pts4 = (const float4 *)b->pts4;
   a.obj_off = b->obj_off;
@@ -1259,7 +1072,7 @@ IccArgs make_args(const mfIccBatch *b, void *ws, int max_ns) {
   a.D = b->dim;
   a.thr = b->voxel_threshold;
   a.sdf_offset = b->sdf_offset;
-  a.max_ns = max_ns;
+  a.max_ns = b->max_scene_objects;
   a.dbg = getenv("MF_ICC_DEBUG") ? atoi(getenv("MF_ICC_DEBUG")) : 0;
   const WsLayout l = ws_layout(b);
   char *p = (char *)ws;
@@ -1268,11 +1081,12 @@ IccArgs make_args(const mfIccBatch *b, void *ws, int max_ns) {
   a.Rt = (float *)(p + l.Rt);
   a.bound = (float *)(p + l.bound);
   a.St = (float *)(p + l.St);
-  a.part = (float *)(p + l.part);
-  a.oth = (float *)(p + l.oth);
-  a.step = (int32_t *)(p + l.step);
+  a.acc_own = (long long *)(p + l.acc_own);
+  a.acc_oth = (long long *)(p + l.acc_oth);
+  a.state_alt = (float *)(p + l.state_alt);
   a.meta = (int4 *)(p + l.meta);
   a.tab = (int4 *)(p + l.tab);
+  a.tab2 = (int4 *)(p + l.tab2);
   a.n_tab = l.n_tab;
   a.nbins = l.nbins;
   a.bin_cnt = (uint32_t *)(p + l.bin_cnt);
@@ -1282,45 +1096,25 @@ IccArgs make_args(const mfIccBatch *b, void *ws, int max_ns) {
   return a;
 }
 
-// MF_ICC_IMPL=1 keeps round 1's scan-everything front end (k_icc_tdf) for A/B measurements
-int icc_impl() {
-  static const int impl = getenv("MF_ICC_IMPL") ? atoi(getenv("MF_ICC_IMPL")) : 2;
-  return impl;
-}
-
-void launch_front(const IccArgs &a, int ks, int SX, hipStream_t stream) {
+// bin (+ the previous iteration's step when sp.mode == 1) -> tile
+void launch_front(const IccArgs &a, const IccStepArgs &sp, hipStream_t stream) {
   const int D = a.D;
-  if (icc_impl() == 1) {
-    const dim3 g1((D + SX - 1) / SX, 2 * a.O);
-    const size_t lds1 = (size_t)SX * D * D * 2 * sizeof(uint32_t);
-    if (ks == 3)
-      hipLaunchKernelGGL(k_icc_tdf<3>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
-    else
-      hipLaunchKernelGGL(k_icc_tdf<0>, g1, dim3(kTdfThreads), lds1, stream, a, ks, SX);
-    return;
-  }
   const int hmax = (a.nbins - D) / 2;
-  hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, hmax);
+  hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, hmax, sp);
   const size_t lds = (size_t)((D + kTileStripes - 1) / kTileStripes) * D * 2 * sizeof(uint32_t);
   hipLaunchKernelGGL(k_icc_tile, dim3(D * kTileStripes, 2 * a.O), dim3(kTileThreads), lds, stream, a,
                      hmax);
 }
 
-void launch_iteration(const IccArgs &a, int ks, int SX, int NB, int max_ns, int mode, float *q,
-                      float *t, float *adam_m, float *adam_v, float alpha_q, float alpha_t,
-                      int adam_step, float *loss, float *gq, float *gt, float *traj, int it,
-                      hipStream_t stream) {
-  launch_front(a, ks, SX, stream);
-  const size_t lds2 = (size_t)3 * kAccRep * (max_ns * 12 + 1) * sizeof(uint32_t);  // <= 74 KB
-  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), lds2, stream, a,
-                     icc_impl() == 1 ? ks * ks * ks : 0);
-  // chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once
-  const double fix1 = 1.0 - pow(0.9, (double)adam_step), fix2 = 1.0 - pow(0.999, (double)adam_step);
-  const float aq = (float)((double)alpha_q * sqrt(fix2) / fix1);
-  const float at = (float)((double)alpha_t * sqrt(fix2) / fix1);
-  const size_t lds3 = (size_t)max_ns * (NB * kNumOwn + kNumOwn + 12 + 8 * 12) * sizeof(float);
-  hipLaunchKernelGGL(k_icc_step, dim3(a.S), dim3(kStepThreads), lds3, stream, a, NB, mode, q, t,
-                     adam_m, adam_v, aq, at, loss, gq, gt, traj, it);
+void launch_accum(const IccArgs &a, int NB, int par, hipStream_t stream) {
+  const size_t lds2 = (size_t)3 * kAccRep * (a.max_ns * 12 + 1) * sizeof(uint32_t);  // <= 74 KB
+  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), lds2, stream, a, par);
+}
+
+// chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once
+float adam_alpha_t(float alpha, int step) {
+  const double fix1 = 1.0 - pow(0.9, (double)step), fix2 = 1.0 - pow(0.999, (double)step);
+  return (float)((double)alpha * sqrt(fix2) / fix1);
 }
 
 struct GraphKey {
@@ -1353,33 +1147,14 @@ extern "C" int mf_pack_points_sdf(const float *points, const float *sdf, int64_t
   return mf::check_launch("mf_pack_points_sdf");
 }
 
-static int icc_prepare_kernels() {
-  // static + dynamic LDS above 64 KB is opt-in (per device, thread-safe: mf::allow_big_lds)
-  if (int e = mf::allow_big_lds((const void *)k_icc_tdf<3>, 64 * 1024)) return e;
-  if (int e = mf::allow_big_lds((const void *)k_icc_tdf<0>, 64 * 1024)) return e;
-  if (int e = mf::allow_big_lds((const void *)k_icc_accum, 80 * 1024)) return e;
-  return mf::allow_big_lds((const void *)k_icc_step, 150 * 1024);
-}
-
 static int icc_validate(const mfIccBatch *b) {
-  if (int e = icc_prepare_kernels()) return e;
-  if (!icc_batch_ok(b) ||
-      (size_t)b->max_scene_objects * (ws_layout(b).NB * kNumOwn + kNumOwn + 12 + 96) * 4 > 150 * 1024) {
+  // dynamic LDS above 64 KB is opt-in (per device, thread-safe: mf::allow_big_lds)
+  if (int e = mf::allow_big_lds((const void *)k_icc_accum, 80 * 1024)) return e;
+  if (!icc_batch_ok(b)) {
     mf::set_last_error(hipErrorInvalidValue, "mf_icc: invalid batch descriptor");
     return -(int)hipErrorInvalidValue;
   }
   return 0;
-}
-
-static int slab_planes(int D, int n_grids) {
-  if (const char *e = getenv("MF_ICC_SX")) {
-    const int v = atoi(e);
-    if (v >= 1 && v * D * D <= 8192) return std::min(v, D);
-  }
-  // tile <= 64 KB of (dist, id) words; two 1024-lane workgroups per CU -> aim for >= 512
-  int SX = std::max(1, std::min(D, 8192 / (D * D)));
-  while (SX > 1 && (int64_t)((D + SX - 1) / SX) * n_grids < 512) SX = (SX + 1) / 2;
-  return SX;
 }
 
 extern "C" int mf_icc_debug_stamps(unsigned long long *host_out, int n) {
@@ -1390,20 +1165,19 @@ extern "C" int mf_icc_launch_tdf(const mfIccBatch *batch, const float *q, const 
                                  mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = icc_validate(batch)) return e;
-  IccArgs a = make_args(batch, ws, batch->max_scene_objects);
-  const int ks = ksize_host(a.thr);
-  const int SX = slab_planes(a.D, 2 * a.O);
-  if (q && t) hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t);
+  IccArgs a = make_args(batch, ws);
+  if (q && t) hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t, (float *)nullptr);
   // inside an iteration k_icc_accum empties the bins; this hook has no accum launch
   MF_TRY(hipMemsetAsync(a.bin_cnt, 0, sizeof(uint32_t) * 2 * a.O * a.nbins, stream));
-  launch_front(a, ks, SX, stream);
+  IccStepArgs sp = {};
+  launch_front(a, sp, stream);
   return mf::check_launch("mf_icc_launch_tdf");
 }
 
 extern "C" int mf_icc_prepare(const mfIccBatch *batch, void *ws, mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = icc_validate(batch)) return e;
-  IccArgs a = make_args(batch, ws, batch->max_scene_objects);
+  IccArgs a = make_args(batch, ws);
   hipLaunchKernelGGL(k_icc_bound, dim3(a.O), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(k_icc_scene_setup, dim3(a.S), dim3(256), 0, stream, a, 0);
   hipLaunchKernelGGL(k_icc_tables, dim3(1), dim3(256), 0, stream, a);
@@ -1415,14 +1189,21 @@ extern "C" int mf_icc_loss_grad(const mfIccBatch *batch, const float *q, const f
                                 mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = icc_validate(batch)) return e;
-  const int max_ns = batch->max_scene_objects;
-  IccArgs a = make_args(batch, ws, max_ns);
+  IccArgs a = make_args(batch, ws);
   const WsLayout l = ws_layout(batch);
-  const int ks = ksize_host(a.thr);
-  const int SX = slab_planes(a.D, 2 * a.O);
-  hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t);
-  launch_iteration(a, ks, SX, l.NB, max_ns, 0, const_cast<float *>(q), const_cast<float *>(t),
-                   nullptr, nullptr, 0.0f, 0.0f, 1, loss, gq, gt, nullptr, 0, stream);
+  hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t, (float *)nullptr);
+  IccStepArgs none = {};
+  launch_front(a, none, stream);
+  launch_accum(a, l.NB, 0, stream);
+  IccStepArgs sp = {};
+  sp.mode = 2;
+  sp.par = 0;
+  sp.q_in = q;
+  sp.t_in = t;
+  sp.loss_out = loss;
+  sp.gq_out = gq;
+  sp.gt_out = gt;
+  hipLaunchKernelGGL(k_icc_step, dim3(a.O), dim3(64), 0, stream, a, sp);
   return mf::check_launch("mf_icc_loss_grad");
 }
 
@@ -1434,10 +1215,8 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
   if (int e = icc_validate(batch)) return e;
   if (n_iter <= 0) return 0;
   const int max_ns = batch->max_scene_objects;
-  IccArgs a = make_args(batch, ws, max_ns);
+  IccArgs a = make_args(batch, ws);
   const WsLayout l = ws_layout(batch);
-  const int ks = ksize_host(a.thr);
-  const int SX = slab_planes(a.D, 2 * a.O);
 
   GraphKey key;
   auto push = [&](const void *p) { key.v.push_back((uint64_t)(uintptr_t)p); };
@@ -1466,11 +1245,35 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
     hipStream_t &cap = caps[dev];
     if (!cap) MF_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
     MF_TRY(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-    hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, cap, a, q, t);
-    for (int it = 0; it < n_iter; ++it)
-      launch_iteration(a, ks, SX, l.NB, max_ns, 1, q, t, adam_m, adam_v, alpha_q, alpha_t,
-                       step0 + it + 1, losses ? losses + (int64_t)it * a.S : nullptr, nullptr,
-                       nullptr, traj, it, cap);
+    // State after i steps lives in the caller's arrays for even i and in the workspace copy for
+    // odd i: the step folded into k_icc_bin reads one while its designated workgroups write the
+    // other.  Iteration k: [bin: step k-1 (k > 0), binning] -> tile -> accum; then one last step.
+    float *alt = a.state_alt;
+    float *sq[2] = {q, alt}, *st[2] = {t, alt + 4 * a.O}, *sm[2] = {adam_m, alt + 7 * a.O},
+          *sv[2] = {adam_v, alt + 14 * a.O};
+    hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, cap, a, (const float *)q,
+                       (const float *)t, traj);
+    for (int k = 0; k <= n_iter; ++k) {
+      IccStepArgs sp = {};
+      if (k > 0) {
+        const int in = (k - 1) & 1, out = k == n_iter ? 0 : (k & 1);
+        sp.mode = 1;
+        sp.par = (k - 1) & 1;
+        sp.it = k;
+        sp.aq = adam_alpha_t(alpha_q, step0 + k);
+        sp.at = adam_alpha_t(alpha_t, step0 + k);
+        sp.q_in = sq[in]; sp.t_in = st[in]; sp.m_in = sm[in]; sp.v_in = sv[in];
+        sp.q_out = sq[out]; sp.t_out = st[out]; sp.m_out = sm[out]; sp.v_out = sv[out];
+        sp.loss_out = losses ? losses + (int64_t)(k - 1) * a.S : nullptr;
+        sp.traj = k < n_iter ? traj : nullptr;
+      }
+      if (k == n_iter) {  // the step of the last iteration, as a kernel of its own
+        hipLaunchKernelGGL(k_icc_step, dim3(a.O), dim3(64), 0, cap, a, sp);
+        break;
+      }
+      launch_front(a, sp, cap);
+      launch_accum(a, l.NB, k & 1, cap);
+    }
     hipError_t ce = hipStreamEndCapture(cap, &graph);
     if (ce != hipSuccess) {
       mf::set_last_error(ce, "hipStreamEndCapture(icc)");

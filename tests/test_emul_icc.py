@@ -100,3 +100,30 @@ def test_icc_kernel_source_ragged_scenes_and_wider_kernel(lib, thr):
         np.testing.assert_allclose(gq[lo:lo + n], gq_o, rtol=2e-3, atol=2e-5)
         np.testing.assert_allclose(gt[lo:lo + n], gt_o, rtol=2e-3, atol=2e-4)
         lo += n
+
+
+@pytest.mark.parametrize("n_iter", [2, 3])
+def test_icc_kernel_source_loop_equals_single_steps(lib, n_iter):
+    """The n_iter loop (optimiser step folded into the next iteration's binning kernel, state
+    ping-ponging between the caller's arrays and the workspace copy, last step as its own
+    kernel) walks exactly the iterates of n_iter one-iteration calls, for even and odd n_iter;
+    losses[k] and traj[k] (pose BEFORE step k) land in the right rows."""
+    scenes = [synthetic.make_icc_scene(n, seed=30 + n) for n in (2, 1)]
+    S = emul.EmulIccScenes(lib, [_dict(s) for s in scenes], sdf_offset=0.02)
+    q0 = np.concatenate([_pose0(s)[0] for s in scenes])
+    t0 = np.concatenate([_pose0(s)[1] for s in scenes])
+    q, t = q0.copy(), t0.copy()
+    m, v = np.zeros((3, 7), np.float32), np.zeros((3, 7), np.float32)
+    losses = np.zeros((n_iter, 2), np.float32)
+    traj = np.zeros((n_iter, 3, 7), np.float32)
+    S.refine(q, t, m, v, n_iter, losses=losses, traj=traj)
+    q1, t1 = q0.copy(), t0.copy()
+    m1, v1 = np.zeros((3, 7), np.float32), np.zeros((3, 7), np.float32)
+    for k in range(n_iter):
+        np.testing.assert_array_equal(traj[k], np.concatenate([q1, t1], 1))
+        l1 = np.zeros((1, 2), np.float32)
+        S.refine(q1, t1, m1, v1, 1, step0=k, losses=l1)
+        np.testing.assert_array_equal(losses[k], l1[0])
+    for a, b in ((q, q1), (t, t1), (m, m1), (v, v1)):
+        np.testing.assert_array_equal(a, b)
+    assert np.abs(q - q0).max() > 1e-4  # it did move
