@@ -312,24 +312,56 @@ struct IccStepArgs {
   float *traj;                             // [n_iter][O][7] or NULL
 };
 
-// Lane `l` of the calling workgroup gathers sum number l (l < kStepSums) of object j.
-__device__ __forceinline__ float icc_step_gather(const IccArgs &a, int par, int j, int ja, int Ns, int l) {
+// The calling workgroup (NT lanes) gathers the kStepSums sums of object j into s_sum.  Every
+// accumulator word is fetched by its own lane -- ONE memory round trip (a lane walking the
+// scene's objects serially costs a dependent load per object: measured 9 us at 8 objects) --
+// staged in LDS, then summed in object order.  s_raw: >= (16 * max_ns + kNumOwn) 64-bit words.
+// Contains two barriers: call it from uniform control flow.
+constexpr int kStepRawWords = 16 * kMaxSceneObjects + kNumOwn;
+
+template <int NT>
+__device__ __forceinline__ void icc_step_gather(const IccArgs &a, int par, int j, int ja, int Ns,
+                                                long long *s_raw, float *s_sum) {
   const long long *own = a.acc_own + (int64_t)par * a.O * kOwnSlots;
   const long long *oth = a.acc_oth + (int64_t)par * a.O * a.max_ns * 12;
-  if (l < 3) {  // scene sums, objects in order
-    float s = 0.0f;
-    for (int jo = 0; jo < Ns; ++jo) s += (float)((double)own[(int64_t)(ja + jo) * kOwnSlots + l] / kFixOwn);
-    return s;
+  // items: [0, 4 Ns): own slots {RN, S_in, PN, non-finite count} of every scene object;
+  // [4 Ns, 16 Ns): the 12 collision moments onto j from every scene object's grid;
+  // [16 Ns, 16 Ns + 36): the own-gradient moments of j
+  const int n_items = 16 * Ns + (kNumOwn - 3);
+  for (int i = threadIdx.x; i < n_items; i += NT) {
+    long long x;
+    if (i < 4 * Ns) {
+      const int jo = i >> 2, l = i & 3;
+      x = own[(int64_t)(ja + jo) * kOwnSlots + (l < 3 ? l : kNumOwn)];
+    } else if (i < 16 * Ns) {
+      const int k = i - 4 * Ns, jo = k / 12, c = k - 12 * jo;
+      x = oth[((int64_t)(ja + jo) * a.max_ns + (j - ja)) * 12 + c];
+    } else {
+      x = own[(int64_t)j * kOwnSlots + 3 + (i - 16 * Ns)];
+    }
+    s_raw[i] = x;
   }
-  if (l < kNumOwn) return (float)((double)own[(int64_t)j * kOwnSlots + l] / kFixOwn);
-  if (l < kNumOwn + 12) {  // collision moments of every grid of the scene onto j: exact integer sum
-    long long x = 0;
-    for (int jo = 0; jo < Ns; ++jo) x += oth[((int64_t)(ja + jo) * a.max_ns + (j - ja)) * 12 + (l - kNumOwn)];
-    return (float)((double)x / kFixOth);
+  __syncthreads();
+  if (threadIdx.x < kStepSums) {
+    const int l = threadIdx.x;
+    float r;
+    if (l < 3) {  // scene sums, objects in order
+      r = 0.0f;
+      for (int jo = 0; jo < Ns; ++jo) r += (float)((double)s_raw[4 * jo + l] * (1.0 / kFixOwn));
+    } else if (l < kNumOwn) {
+      r = (float)((double)s_raw[16 * Ns + (l - 3)] * (1.0 / kFixOwn));
+    } else if (l < kNumOwn + 12) {  // exact integer sum over the scene's grids
+      long long x = 0;
+      for (int jo = 0; jo < Ns; ++jo) x += s_raw[4 * Ns + 12 * jo + (l - kNumOwn)];
+      r = (float)((double)x * (1.0 / kFixOth));
+    } else {
+      long long bad = 0;
+      for (int jo = 0; jo < Ns; ++jo) bad |= s_raw[4 * jo + 3];
+      r = bad != 0 ? 1.0f : 0.0f;
+    }
+    s_sum[l] = r;
   }
-  long long bad = 0;
-  for (int jo = 0; jo < Ns; ++jo) bad |= own[(int64_t)(ja + jo) * kOwnSlots + kNumOwn];
-  return bad != 0 ? 1.0f : 0.0f;
+  __syncthreads();
 }
 
 // sv: the gathered sums; st: (q, t, m, v) before the step.  Returns the pose to use next
@@ -390,6 +422,7 @@ __device__ __forceinline__ void icc_step_apply(const float *sv, float S_t, const
 __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax, IccStepArgs sp) {
   __shared__ int s_cnt[kMaxBins], s_base[kMaxBins];
   __shared__ float s_sum[kStepSums], s_state[kStateFloats];
+  __shared__ long long s_raw[kStepRawWords];
   auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
     if ((a.dbg & 32) && threadIdx.x == 0 && blockIdx.x < 1024)
       g_dbg_stamps[(3072 + blockIdx.x) * 8 + i] = wall_clock64();
@@ -409,10 +442,9 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax, Ic
     r1 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 4);
     r2 = *reinterpret_cast<const float4 *>(a.Rt + 12 * j + 8);
   } else {
-    // the previous iteration's reduced sums of object j (fixed point) and its optimiser state
-    if (threadIdx.x < kStepSums) s_sum[threadIdx.x] = icc_step_gather(a, sp.par, j, e2.x, e2.y, threadIdx.x);
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + kStateFloats) {
-      const int i = threadIdx.x - 64;
+    // its optimiser state; the reduced sums are gathered below, in the same round trip
+    if (threadIdx.x >= 224 && threadIdx.x < 224 + kStateFloats) {
+      const int i = threadIdx.x - 224;
       s_state[i] = i < 4 ? sp.q_in[4 * j + i] : i < 7 ? sp.t_in[3 * j + i - 4]
                    : i < 14 ? sp.m_in[7 * j + i - 7] : sp.v_in[7 * j + i - 14];
     }
@@ -431,8 +463,9 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax, Ic
   }
   for (int i = threadIdx.x; i < nb; i += kBinThreads) s_cnt[i] = 0;
   if (sp.mode != 0) {
-    __syncthreads();
-    // every lane evaluates the same step from LDS (broadcast reads): no second barrier
+    // the previous iteration's reduced sums of object j (fixed point)
+    icc_step_gather<kBinThreads>(a, sp.par, j, e2.x, e2.y, s_raw, s_sum);
+    // every lane evaluates the same step from LDS (broadcast reads): no further barrier
     float Rt[12], st_new[kStateFloats], loss, gq[4], gt[3];
     icc_step_apply(s_sum, S_t, s_state, sp, Rt, st_new, loss, gq, gt);
     r0 = make_float4(Rt[0], Rt[1], Rt[2], Rt[3]);
@@ -970,18 +1003,18 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
 // mode 1: after the last iteration of mf_icc_refine.  mode 2: mf_icc_loss_grad (loss, gq, gt).
 __global__ __launch_bounds__(64) void k_icc_step(IccArgs a, IccStepArgs sp) {
   __shared__ float s_sum[kStepSums], s_state[kStateFloats];
+  __shared__ long long s_raw[kStepRawWords];
   const int j = blockIdx.x;
   const int4 meta = a.meta[j];
   const int ja = meta.x, Ns = meta.y - meta.x;
   const int sc = a.obj_scene[j];
-  if (threadIdx.x < kStepSums) s_sum[threadIdx.x] = icc_step_gather(a, sp.par, j, ja, Ns, threadIdx.x);
   if (threadIdx.x < kStateFloats) {
     const int i = threadIdx.x;
     s_state[i] = i < 4 ? sp.q_in[4 * j + i] : i < 7 ? sp.t_in[3 * j + i - 4]
                  : (sp.mode == 1 ? (i < 14 ? sp.m_in[7 * j + i - 7] : sp.v_in[7 * j + i - 14]) : 0.0f);
   }
   const float S_t = a.St[sc];
-  __syncthreads();
+  icc_step_gather<64>(a, sp.par, j, ja, Ns, s_raw, s_sum);
   if (threadIdx.x != 0) return;
   float Rt[12], st_new[kStateFloats], loss, gq[4], gt[3];
   icc_step_apply(s_sum, S_t, s_state, sp, Rt, st_new, loss, gq, gt);
