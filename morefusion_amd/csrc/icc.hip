@@ -52,8 +52,7 @@ constexpr int kAccThreads = 512;
 constexpr int kVoxPerBlock = 1024;  // k_icc_accum: voxels per workgroup
 constexpr int kNumOwn = 39;         // RN, S_in, PN + 3 x 12 gradient moments
 constexpr uint32_t kNoCand = 0xffffffffu;
-constexpr double kFix = 17592186044416.0;  // 2^44 fixed point for the collision moments (per block)
-constexpr double kFixOth = 1099511627776.0;  // 2^40: collision moments summed over blocks
+constexpr double kFixOth = 1099511627776.0;  // 2^40 fixed point: collision moments summed over blocks
 constexpr double kFixOwn = 4294967296.0;     // 2^32: reward / penalty sums and own-gradient moments
 constexpr int kOwnSlots = kNumOwn + 1;       // + count of non-finite block sums (-> NaN loss)
 constexpr int kStateFloats = 21;             // q[4] t[3] m[7] v[7] of one object
@@ -804,21 +803,17 @@ __device__ __forceinline__ void world_frac(const float *Rt, const float4 m, floa
 }
 
 constexpr int kVPT = kVoxPerBlock / kAccThreads;  // voxels per thread
-constexpr int kAccRep = 16;                       // replicas of the collision-limb accumulators
 
 __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   __shared__ float s_rows[kAccThreads / 16][kNumOwn + 1];  // 16-lane row sums (+1: bank spread)
-  // collision moments as 2^44 fixed point split in three 20-bit limbs held in 32-bit LDS
-  // words: <= 1024 adds per block can never overflow a limb, so plain NON-returning
-  // ds_add_u32 suffice (no carries).  Integer addition is associative: the result is
-  // independent of the order of the atomics (bitwise reproducible), and 32-bit LDS atomics
-  // are ~10x cheaper than the 64-bit ones.  All colliding voxels of a block add into the same
-  // 36 words per other object, and same-address LDS atomics serialise (measured: the crowded
-  // blocks spent 3-5 us here) -> kAccRep replicas selected by lane, in different banks (odd
-  // stride), summed at the end: integer sums, still order-independent.
-  MF_DYN_LDS(uint32_t, s_lim);  // [3 limbs][kAccRep][lim_stride]
-  const int lim_stride = a.max_ns * 12 + 1;
-  const int lim_words = kAccRep * lim_stride;
+  // Collision moments (gradient of this grid's penalty onto ANOTHER object's pose): each lane
+  // keeps the 12 moments of its colliding voxels in registers; after the voxel loop the block
+  // reduces them per other object in a fixed order (DPP row sums + ordered row adds), exactly
+  // like its own moments.  (Round 1 / early round 2 pushed every colliding voxel through 36
+  // fixed-point LDS atomics behind float64 conversions: ~600 instructions per colliding voxel,
+  // 3-5 us in the crowded blocks.)
+  __shared__ float s_rows2[2][kAccThreads / 16][12 + 1];
+  __shared__ uint32_t s_emask;  // scene objects some voxel of this block collides with
   __shared__ float s_Rt[kMaxSceneObjects][12];
   __shared__ int s_off[kMaxSceneObjects + 1];
   const int o = blockIdx.y;
@@ -834,7 +829,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   // all independent loads first: scene tables, scalars, and this thread's voxels
   if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
-  for (int i = threadIdx.x; i < 3 * lim_words; i += kAccThreads) s_lim[i] = 0u;
+  if (threadIdx.x == 0) s_emask = 0u;
   // this object's two grids have been consumed by k_icc_tile: empty their bins for the next k_icc_bin
   if (blockIdx.x == 0)
     for (int i = threadIdx.x; i < 2 * a.nbins; i += kAccThreads) a.bin_cnt[(int64_t)2 * o * a.nbins + i] = 0u;
@@ -879,6 +874,10 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   float acc[kNumOwn];
 #pragma unroll
   for (int i = 0; i < kNumOwn; ++i) acc[i] = 0.0f;
+  int ecol[kVPT];
+  float cv[kVPT][12];
+#pragma unroll
+  for (int it = 0; it < kVPT; ++it) ecol[it] = -1;
 
 #pragma unroll
   for (int it = 0; it < kVPT; ++it) {
@@ -943,22 +942,21 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
       const float B = wo_in * ins / trunc;
       if (ok && isfinite(B)) {
         const float u[3] = {ux, uy, uz};
+        ecol[it] = e;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
           const float sB = u[d] * B;
-          const float val[4] = {sB * m.x, sB * m.y, sB * m.z, sB};
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const long long x = __double2ll_rn((double)val[c] * kFix);
-            const int idx = (int)(threadIdx.x & (kAccRep - 1)) * lim_stride + 12 * e + 4 * d + c;
-            atomicAdd(&s_lim[idx], (uint32_t)(x & 0xfffff));
-            atomicAdd(&s_lim[lim_words + idx], (uint32_t)((x >> 20) & 0xfffff));
-            atomicAdd(&s_lim[2 * lim_words + idx], (uint32_t)(int32_t)(x >> 40));  // two's complement
-          }
+          cv[it][4 * d + 0] = sB * m.x;
+          cv[it][4 * d + 1] = sB * m.y;
+          cv[it][4 * d + 2] = sB * m.z;
+          cv[it][4 * d + 3] = sB;
         }
       }
     }
   }
+#pragma unroll
+  for (int it = 0; it < kVPT; ++it)
+    if (ecol[it] >= 0) atomicOr(&s_emask, 1u << ecol[it]);
   // fixed-order block reduction: every component is summed over each 16-lane row on DPP (4 VALU
   // steps, no LDS), the 32 row sums go through LDS, one lane per component adds them in order.
   stamp(2);
@@ -984,18 +982,30 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
     }
   }
   stamp(3);
-  // collision moments of this block (the barrier above orders the LDS atomics): 2^44 -> 2^40
+  // collision moments, one other object at a time (block-uniform loop over the set bits)
   long long *po = a.acc_oth + ((int64_t)par * a.O + o) * a.max_ns * 12;
-  for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) {
-    long long l0 = 0, l1 = 0, l2 = 0;
+  uint32_t em = s_emask;  // complete: every atomicOr precedes the barrier above
+  int buf = 0;
+  while (em != 0u) {
+    const int e = __ffs((int)em) - 1;
+    em &= em - 1u;
 #pragma unroll
-    for (int r = 0; r < kAccRep; ++r) {
-      l0 += (long long)s_lim[r * lim_stride + i];
-      l1 += (long long)s_lim[lim_words + r * lim_stride + i];
-      l2 += (long long)(int32_t)s_lim[2 * lim_words + r * lim_stride + i];
+    for (int c = 0; c < 12; ++c) {
+      float v = 0.0f;
+#pragma unroll
+      for (int it = 0; it < kVPT; ++it) v += ecol[it] == e ? cv[it][c] : 0.0f;
+      const float r = mf::row16_sum(v);
+      if ((threadIdx.x & 15) == 0) s_rows2[buf][threadIdx.x >> 4][c] = r;
     }
-    const long long x = ((l2 << 40) + (l1 << 20) + l0) >> 4;
-    if (x != 0) atomicAdd(reinterpret_cast<unsigned long long *>(po + i), (unsigned long long)x);
+    __syncthreads();  // two buffers: the next object's writes cannot overtake these reads
+    if (threadIdx.x < 12) {
+      float sacc = 0.0f;
+#pragma unroll
+      for (int r = 0; r < kAccThreads / 16; ++r) sacc += s_rows2[buf][r][threadIdx.x];
+      const long long x = isfinite(sacc) ? __double2ll_rn((double)sacc * kFixOth) : 0;
+      if (x != 0) atomicAdd(reinterpret_cast<unsigned long long *>(po + 12 * e + threadIdx.x), (unsigned long long)x);
+    }
+    buf ^= 1;
   }
 }
 
@@ -1140,8 +1150,7 @@ void launch_front(const IccArgs &a, const IccStepArgs &sp, hipStream_t stream) {
 }
 
 void launch_accum(const IccArgs &a, int NB, int par, hipStream_t stream) {
-  const size_t lds2 = (size_t)3 * kAccRep * (a.max_ns * 12 + 1) * sizeof(uint32_t);  // <= 74 KB
-  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), lds2, stream, a, par);
+  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), 0, stream, a, par);
 }
 
 // chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once
@@ -1181,8 +1190,6 @@ extern "C" int mf_pack_points_sdf(const float *points, const float *sdf, int64_t
 }
 
 static int icc_validate(const mfIccBatch *b) {
-  // dynamic LDS above 64 KB is opt-in (per device, thread-safe: mf::allow_big_lds)
-  if (int e = mf::allow_big_lds((const void *)k_icc_accum, 80 * 1024)) return e;
   if (!icc_batch_ok(b)) {
     mf::set_last_error(hipErrorInvalidValue, "mf_icc: invalid batch descriptor");
     return -(int)hipErrorInvalidValue;

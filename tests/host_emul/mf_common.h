@@ -299,6 +299,7 @@ template <class T> inline T __shfl_xor(T v, int m, int = 64) {
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline int __ffs(int x) { return __builtin_ffs(x); }
 inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
