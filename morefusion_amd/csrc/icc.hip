@@ -552,35 +552,47 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax, Ic
   stamp(3);
 }
 
-// launch 2: TDF of one x-plane of one grid, fed from bins x-h..x+h.
-//  pass 1 works on SQUARED distances in voxel units (no sqrt, no pitch): 32-bit atomicMin of
-//         the d2 bits behind a peek.  dist = pitch*sqrt(d2) is monotone in d2.
-//  pass 2 re-derives, only for records that touched a minimum, the EXACT float distance of
-//         near-minimal candidates (d2 within a few ulp) and, where it equals the exact minimum
-//         and is < truncation, takes atomicMin of the candidate id: the same winners as
-//         the oracle (lowest id among equal ROUNDED distances).
+// launch 2: TDF of one x-plane of one grid, fed from bins x-h..x+h -- ONE pass over the records.
+//  * squared distances in voxel units (no sqrt, no pitch; dist = pitch*sqrt(d2) is monotone in
+//    d2): 32-bit RETURNING atomicMin of the d2 bits behind a batched peek;
+//  * a candidate that lowered the minimum ("setter", ~ln(n) of the n candidates of a voxel)
+//    also takes a 64-bit atomicMin of (d2 bits << 32 | candidate id): when the records are
+//    done the word holds the minimum and the id of the candidate that achieved it;
+//  * the reference's winner is the lowest id among equal ROUNDED distances, which can differ
+//    from the above only if two candidates of a voxel lie within a few ulp of each other in d2.
+//    The value returned by the 32-bit atomic is the exact history of the voxel, so any such
+//    pair is seen (|d2 - previous minimum| <= 8 ulp) and raises the tile's tie flag; a flagged
+//    tile (rare: generic poses have no ties) re-streams its records through the exact
+//    tie-break (the two-pass scheme every tile ran before).  Winners are therefore identical.
+// A crowded plane (T records > kTileSplit: up to 2400 at 8 objects, mean 300) is bound by the
+// instruction issue of ONE CU while the rest idle: its kTileStripes workgroups each own D/4 rows,
+// compact the records whose rows touch their stripe into LDS (dense lanes: a lane-masked stripe
+// pays for every record of the plane) and process only those; a light plane is handled by
+// stripe 0 alone and the other stripes exit at once.
 constexpr int kTileThreads = 512;
-constexpr int kTileStripes = 1;  // y-stripes per plane (measured: 4 stripes x 256 lanes 26.8 us vs 14.9 us)
-constexpr int kTileKeep = 6;     // records per lane kept in registers over both passes
-constexpr int kTileR = 4;        // records in flight per lane beyond those
+constexpr int kTileStripes = 4;
+#ifndef MF_ICC_TILE_SPLIT
+#define MF_ICC_TILE_SPLIT 640  // (tests build with a small value to force the split path)
+#endif
+constexpr int kTileSplit = MF_ICC_TILE_SPLIT;  // records per plane above which the stripes share the work
+constexpr int kTileR = 2;         // records per lane per round
+constexpr int kTileList = kTileThreads * kTileR;  // LDS record list of a stripe (one round's worth)
+constexpr unsigned long long kNoWin = 0xffffffffffffffffull;
 
-// A plane may be split in kTileStripes y-stripes (a workgroup then keeps only the records whose
-// ks rows touch its stripe; the (min, arg-min) of a voxel only depends on the set of candidates).
-// Measured on the 8-object scene: wave-level divergence makes every stripe pay for all records
-// of the plane -- one 512-lane workgroup per plane is faster.
 template <int KS>
 __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt, const int hmax) {
-  MF_DYN_LDS(uint32_t, s_tile);  // dist[rows*D], id[rows*D]
+  MF_DYN_LDS(uint32_t, s_tile);  // dist[D*D] u32 | id[D*D] u32 | win[D*D] u64 | list[kTileList] float4
   __shared__ float s_max[kTileThreads / 64];
+  __shared__ int s_n;
+  __shared__ uint32_t s_tie;
   const int ks = KS > 0 ? KS : ks_rt;
   const int h = ks / 2, K = ks * ks * ks;
-  const int D = a.D, nb = a.nbins;
+  const int D = a.D, nb = a.nbins, plane = D * D;
   const int g = blockIdx.y, o = g >> 1, other = g & 1;
   const int x = blockIdx.x / kTileStripes, stripe = blockIdx.x % kTileStripes;
-  const int rows_max = (D + kTileStripes - 1) / kTileStripes;
-  const int y0 = stripe * rows_max, y1 = min(D, y0 + rows_max);
-  const int nvox = max(0, y1 - y0) * D;
-  uint32_t *s_dist = s_tile, *s_id = s_tile + rows_max * D;
+  uint32_t *s_dist = s_tile, *s_id = s_tile + plane;
+  unsigned long long *s_win = reinterpret_cast<unsigned long long *>(s_tile + 2 * plane);
+  float4 *s_list = reinterpret_cast<float4 *>(s_tile + 4 * plane);
   // independent loads: the <= 7 bin counts of this tile, capacity, offset
   int c[8];
   c[0] = 0;
@@ -595,51 +607,81 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
     c[b + 1] = c[b] + n;
   }
   const int T = c[7];
-  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-  auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
-    if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
+  const bool split = T > kTileSplit;
+  if (!split && stripe != 0) return;  // block-uniform
+  const int rows = (D + kTileStripes - 1) / kTileStripes;
+  const int y0 = split ? stripe * rows : 0, y1 = split ? min(D, y0 + rows) : D;
+  const int nvox = max(0, y1 - y0) * D;
+  const int wg = blockIdx.y * (gridDim.x / kTileStripes) + x;
+  auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32), stripe 0 of every plane
+    if ((a.dbg & 32) && threadIdx.x == 0 && stripe == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
   };
   stamp(0);
-  if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)T;
+  if ((a.dbg & 32) && threadIdx.x == 0 && stripe == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)T;
   const float trunc = a.thr * pitch;
-  for (int i = threadIdx.x; i < nvox; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
+  for (int i = threadIdx.x; i < nvox; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_win[i] = kNoWin; }
+  if (threadIdx.x == 0) { s_n = 0; s_tie = 0u; }
   __syncthreads();
-  const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test in pass 2
+  const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test at the end
   const float d2_in = a.thr * a.thr * 0.999f;    // certainly inside the truncation radius
   const float4 *recs = a.rec + base_g + (int64_t)bin0 * cap;
   const float fxp = (float)x;
+  const int lane = threadIdx.x & 63;
 
-  // record i of this tile's concatenated bins -> (bin b, record); rb < 0: none / not in my stripe
-  auto fetch = [&](const int i, float4 &rv, int &rb) {
-    rb = -1;
-    if (i >= T) return;
+  // record i of this tile's concatenated bins; its bin offset b rides in bits 28..30 of the id
+  // word (point ids are < 2^27).  ok = false: none.
+  auto fetch = [&](const int i, float4 &rv, bool &ok) {
+    ok = i < T;
+    if (!ok) return;
     int b = 0;
 #pragma unroll
     for (int k = 1; k < 7; ++k) b += (k < ks && i >= c[k]) ? 1 : 0;
     int cb = 0;
 #pragma unroll
     for (int k = 1; k < 7; ++k) cb = (k == b) ? c[k] : cb;
-    rb = b;
     rv = recs[(int64_t)b * cap + (i - cb)];
+    rv.w = __uint_as_float(__float_as_uint(rv.w) | ((uint32_t)b << 28));
   };
   auto mine = [&](const float4 &rv) {  // do the ks rows around round(y) touch rows [y0, y1)?
     const int iry = (int)roundf(rv.y);
     return iry + h >= y0 && iry - h < y1;
   };
-  // One record against its ks x ks (y, z) candidates in plane x.  All peeks of a record are
-  // issued together (KS == 3: nine independent ds_read), then the non-returning atomics.  A
-  // peek may be stale (another lane lowered the voxel meanwhile): values only decrease, so a
-  // stale peek only lets MORE candidates through -- the atomicMin / the exact test of pass 2
-  // decide.
-  auto visit = [&](const int pass, const float4 sv, const int rb) -> bool {
+  // One record against its ks x ks (y, z) candidates in plane x.  exact == false: the single
+  // pass described above.  exact == true (flagged tiles only): s_dist holds the final minima;
+  // candidates whose exact float distance equals the minimal one (and is < truncation) take
+  // atomicMin of their id into s_id.
+  auto visit = [&](const bool exact, const float4 sv) {
     const int iry = (int)roundf(sv.y), irz = (int)roundf(sv.z);
-    const uint32_t idb = __float_as_uint(sv.w) * (uint32_t)K;
-    const int bb = ks - 1 - rb;  // x offset of plane x inside this point's neighbourhood
+    const uint32_t wbits = __float_as_uint(sv.w);
+    const uint32_t idb = (wbits & 0x07ffffffu) * (uint32_t)K;
+    const int bb = ks - 1 - (int)(wbits >> 28);  // x offset of plane x inside this point's neighbourhood
     const float dx = sv.x - fxp;
     const float dx2 = dx * dx;
-    bool cand = false;
+    auto one = [&](const int ad, const uint32_t db, const uint32_t cur, const uint32_t cid, uint32_t &old) {
+      // (only the non-exact path returns through `old`)
+      if (exact) {
+        if (db <= cur + 8u) {  // within a few ulp of the minimal d2
+          bool win = db == cur && __uint_as_float(db) < d2_in;
+          if (!win) {
+            const float dist = pitch * sqrtf(__uint_as_float(db));
+            const float dmin = pitch * sqrtf(__uint_as_float(cur));
+            win = dist == dmin && dist < trunc;
+          }
+          if (win) atomicMin(&s_id[ad], cid);
+        }
+      } else {
+        old = 0u;  // "not issued"
+        if (db <= cur + 8u) old = atomicMin(&s_dist[ad], db);
+      }
+    };
+    auto settle = [&](const int ad, const uint32_t db, const uint32_t cid, const uint32_t old) {
+      if (old == 0u) return;  // d2 == 0 exactly never reads back as 0 here: see below
+      if (db < old) atomicMin(&s_win[ad], ((unsigned long long)db << 32) | cid);
+      const uint32_t diff = db > old ? db - old : old - db;
+      if (diff <= 8u) s_tie = 1u;  // incl. an exact tie (db == old)
+    };
     if constexpr (KS == 3) {
-      uint32_t db[9], cur[9];
+      uint32_t db[9], cur[9], old[9];
       int ad[9];
 #pragma unroll
       for (int aa = 0; aa < 3; ++aa) {
@@ -652,7 +694,8 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
           const float dz = sv.z - (float)iz;
           const float d2 = dxy + dz * dz;
           const bool ok = iy >= y0 && iy < y1 && iz >= 0 && iz < D && d2 < d2_hi;
-          db[aa * 3 + cc] = __float_as_uint(d2);
+          // +1: keeps the bits of d2 == 0 apart from the "not issued" marker; order-preserving
+          db[aa * 3 + cc] = __float_as_uint(d2) + 1u;
           ad[aa * 3 + cc] = ok ? (iy - y0) * D + iz : -1;
         }
       }
@@ -660,20 +703,13 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
       for (int k = 0; k < 9; ++k) cur[k] = s_dist[ad[k] < 0 ? 0 : ad[k]];
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        if (ad[k] < 0) continue;
-        if (pass == 1) {
-          if (db[k] <= cur[k]) { atomicMin(&s_dist[ad[k]], db[k]); cand = true; }
-        } else if (db[k] <= cur[k] + 8u) {  // within a few ulp of the minimal d2
-          // dist == dmin is certain for equal bits; dist < trunc is certain well inside the
-          // truncation radius (pitch*sqrt(d2) <= 0.9995 thr pitch (1 + 2^-22) < trunc)
-          bool win = db[k] == cur[k] && __uint_as_float(db[k]) < d2_in;
-          if (!win) {
-            const float dist = pitch * sqrtf(__uint_as_float(db[k]));
-            const float dmin = pitch * sqrtf(__uint_as_float(cur[k]));
-            win = dist == dmin && dist < trunc;
-          }
-          if (win) atomicMin(&s_id[ad[k]], idb + (uint32_t)(((k / 3) * 3 + bb) * 3 + (k % 3)));
-        }
+        old[k] = 0u;
+        if (ad[k] >= 0) one(ad[k], db[k], cur[k], idb + (uint32_t)(((k / 3) * 3 + bb) * 3 + (k % 3)), old[k]);
+      }
+      if (!exact) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          if (ad[k] >= 0) settle(ad[k], db[k], idb + (uint32_t)(((k / 3) * 3 + bb) * 3 + (k % 3)), old[k]);
       }
     } else {
       for (int aa = 0; aa < ks; ++aa) {
@@ -688,87 +724,117 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
           const float dz = sv.z - (float)iz;
           const float d2 = dxy + dz * dz;
           if (!(d2 < d2_hi)) continue;
-          const uint32_t db = __float_as_uint(d2);
-          const uint32_t cur = s_dist[lrow + iz];
-          if (pass == 1) {
-            if (db <= cur) { atomicMin(&s_dist[lrow + iz], db); cand = true; }
-          } else if (db <= cur + 8u) {
-            const float dist = pitch * sqrtf(d2);
-            const float dmin = pitch * sqrtf(__uint_as_float(cur));
-            if (dist == dmin && dist < trunc)
-              atomicMin(&s_id[lrow + iz], idb + (uint32_t)((aa * ks + bb) * ks + cc));
-          }
+          const uint32_t db = __float_as_uint(d2) + 1u;
+          const uint32_t cid = idb + (uint32_t)((aa * ks + bb) * ks + cc);
+          uint32_t old = 0u;
+          one(lrow + iz, db, s_dist[lrow + iz], cid, old);
+          if (!exact) settle(lrow + iz, db, cid, old);
         }
       }
     }
-    return cand;
   };
 
-  // The first kTileThreads * kTileKeep records stay in registers over both passes (all loads
-  // in flight at once: ONE memory round trip); a more crowded tile streams the rest again.
-  float4 rv[kTileKeep];
-  int rb[kTileKeep];
-  unsigned keep_cand = 0u;  // bit u: record u touched a minimum in pass 1
+  // Stream the tile's records through visit(): kTileR records per lane per round, the next
+  // round's loads in flight while this one is processed.  A split tile first compacts the
+  // records of its stripe into LDS (wave-aggregated append) and walks the dense list.
+  auto stream = [&](const bool exact) {
+    float4 nv[kTileR];
+    bool nok[kTileR];
 #pragma unroll
-  for (int u = 0; u < kTileKeep; ++u) fetch(u * kTileThreads + (int)threadIdx.x, rv[u], rb[u]);
+    for (int u = 0; u < kTileR; ++u) fetch(u * kTileThreads + (int)threadIdx.x, nv[u], nok[u]);
+    for (int base = 0; base < T; base += kTileList) {
+      float4 rv[kTileR];
+      bool ok[kTileR];
+#pragma unroll
+      for (int u = 0; u < kTileR; ++u) { rv[u] = nv[u]; ok[u] = nok[u]; }
+#pragma unroll
+      for (int u = 0; u < kTileR; ++u)
+        fetch(base + kTileList + u * kTileThreads + (int)threadIdx.x, nv[u], nok[u]);
+      if (!split) {
+#pragma unroll
+        for (int u = 0; u < kTileR; ++u)
+          if (ok[u]) visit(exact, rv[u]);
+        continue;
+      }
+#pragma unroll
+      for (int u = 0; u < kTileR; ++u) {
+        const bool rel = ok[u] && mine(rv[u]);
+        const unsigned long long mask = __ballot(rel);
+        if (mask != 0ull) {  // wave-uniform
+          const int leader = __ffsll(mask) - 1;
+          int slot = 0;
+          if (lane == leader) slot = atomicAdd(&s_n, __popcll(mask));
+          slot = __shfl(slot, leader, 64);
+          if (rel) s_list[slot + __popcll(mask & ((1ull << lane) - 1ull))] = rv[u];
+        }
+      }
+      __syncthreads();
+      const int n = s_n;
+      for (int i = threadIdx.x; i < n; i += kTileThreads) visit(exact, s_list[i]);
+      __syncthreads();
+      if (threadIdx.x == 0) s_n = 0;
+      // (the next append is behind the barrier of the next round's end or uses s_n after it:
+      //  thread 0 resets before it can reach the next ballot's atomicAdd of any wave? no --
+      //  another wave may already be appending: order it)
+      __syncthreads();
+    }
+  };
+
   stamp(1);
-#pragma unroll
-  for (int u = 0; u < kTileKeep; ++u) {
-    if (rb[u] >= 0 && !mine(rv[u])) rb[u] = -1;
-    if (rb[u] >= 0 && visit(1, rv[u], rb[u])) keep_cand |= 1u << u;
-  }
-  for (int base = kTileThreads * kTileKeep; base < T; base += kTileThreads * kTileR) {
-    float4 xv[kTileR];
-    int xb[kTileR];
-#pragma unroll
-    for (int u = 0; u < kTileR; ++u) fetch(base + u * kTileThreads + (int)threadIdx.x, xv[u], xb[u]);
-#pragma unroll
-    for (int u = 0; u < kTileR; ++u)
-      if (xb[u] >= 0 && mine(xv[u])) visit(1, xv[u], xb[u]);
-  }
+  stream(false);
   __syncthreads();
   stamp(2);
-#pragma unroll
-  for (int u = 0; u < kTileKeep; ++u)
-    if ((keep_cand >> u) & 1u) visit(2, rv[u], rb[u]);
-  for (int base = kTileThreads * kTileKeep; base < T; base += kTileThreads * kTileR) {
-    float4 xv[kTileR];
-    int xb[kTileR];
-#pragma unroll
-    for (int u = 0; u < kTileR; ++u) fetch(base + u * kTileThreads + (int)threadIdx.x, xv[u], xb[u]);
-#pragma unroll
-    for (int u = 0; u < kTileR; ++u)
-      if (xb[u] >= 0 && mine(xv[u])) visit(2, xv[u], xb[u]);
+  const bool tie = s_tie != 0u;  // block-uniform
+  if ((a.dbg & 64) && threadIdx.x == 0) {  // test hook: how many tiles took which path
+    if (tie) atomicAdd(&g_dbg_stamps[4095 * 8], 1ull);
+    if (split) atomicAdd(&g_dbg_stamps[4095 * 8 + 1], 1ull);
   }
-  __syncthreads();
+  if (tie) {
+    for (int i = threadIdx.x; i < nvox; i += kTileThreads) s_id[i] = kNoCand;
+    __syncthreads();
+    stream(true);
+    __syncthreads();
+  }
   stamp(3);
   // epilogue: winners out (coalesced 8 B/lane) + max raw inside weight of this tile
   // (truncated_distance_function.py:198-204: -1 where no winner, + offset, clamp at 0)
   const float offset = other ? 0.0f : a.sdf_offset;
   unsigned long long *Wg = a.W + (int64_t)g * D * D * D + ((int64_t)x * D + y0) * D;
   float wmax = 0.0f;
-  for (int i0 = threadIdx.x; i0 < nvox; i0 += kTileThreads * 4) {
-    uint32_t lo[4];
-    float sd[4];
+  for (int i0 = threadIdx.x; i0 < nvox; i0 += kTileThreads * 2) {
+    uint32_t lo[2];
+    float sd[2], dist[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const int i = i0 + u * kTileThreads;
-      lo[u] = i < nvox ? s_id[i] : kNoCand;  // set only where pitch*sqrt(min d2) < trunc
+      lo[u] = kNoCand;
+      dist[u] = trunc;
+      if (i < nvox) {
+        const uint32_t dmin = s_dist[i];
+        if (dmin != 0x7f800000u) {
+          const float d = pitch * sqrtf(__uint_as_float(dmin - 1u));
+          if (tie) {
+            lo[u] = s_id[i];  // set only where the exact distance is < truncation
+          } else if (d < trunc) {
+            lo[u] = (uint32_t)s_win[i];
+          }
+          if (lo[u] != kNoCand) dist[u] = d;
+        }
+      }
       sd[u] = lo[u] != kNoCand ? a.pts4[lo[u] / (uint32_t)K].w : -1.0f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const int i = i0 + u * kTileThreads;
       if (i >= nvox) continue;
-      const float dist = lo[u] != kNoCand ? pitch * sqrtf(__uint_as_float(s_dist[i])) : trunc;
-      Wg[i] = ((unsigned long long)__float_as_uint(dist) << 32) | lo[u];
+      Wg[i] = ((unsigned long long)__float_as_uint(dist[u]) << 32) | lo[u];
       float w = sd[u] + offset;
       w = w < 0.0f ? 0.0f : w;
       wmax = fmaxf(wmax, w);
     }
   }
   wmax = mf::wave_max(wmax);
-  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = wmax;
+  if (lane == 0) s_max[threadIdx.x >> 6] = wmax;
   __syncthreads();
   if (threadIdx.x == 0) {
     float m = s_max[0];
@@ -1144,7 +1210,7 @@ void launch_front(const IccArgs &a, const IccStepArgs &sp, hipStream_t stream) {
   const int D = a.D;
   const int hmax = (a.nbins - D) / 2;
   hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, hmax, sp);
-  const size_t lds = (size_t)((D + kTileStripes - 1) / kTileStripes) * D * 2 * sizeof(uint32_t);
+  const size_t lds = (size_t)D * D * 4 * sizeof(uint32_t) + (size_t)kTileList * sizeof(float4);  // 32 KB at D = 32
   hipLaunchKernelGGL(k_icc_tile, dim3(D * kTileStripes, 2 * a.O), dim3(kTileThreads), lds, stream, a,
                      hmax);
 }

@@ -127,3 +127,57 @@ def test_icc_kernel_source_loop_equals_single_steps(lib, n_iter):
     for a, b in ((q, q1), (t, t1), (m, m1), (v, v1)):
         np.testing.assert_array_equal(a, b)
     assert np.abs(q - q0).max() > 1e-4  # it did move
+
+
+def _lattice_tie_scene():
+    """Two objects whose points sit on a half-voxel lattice exactly symmetric about the voxel
+    centres of a power-of-two grid, identity poses: every voxel sees many candidates at EXACTLY
+    the same distance -> the winner is decided by the lowest-candidate-id rule alone (random sdf
+    makes the loss depend on it)."""
+    rs = np.random.RandomState(3)
+    pitch = np.float32(1.0 / 128)
+    dim = 32
+    objs = []
+    for k, lo in enumerate([(6, 6, 6), (11, 9, 8)]):
+        ax = [(np.arange(2 * 9) * 0.5 + 0.25 + l) for l in lo]
+        g = np.stack(np.meshgrid(*ax, indexing="ij"), -1).reshape(-1, 3) * float(pitch)
+        rs.shuffle(g)
+        objs.append(g.astype(np.float32))
+    n = len(objs)
+    T = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+    return dict(points=objs, sdf=[rs.uniform(-0.01, 0.03, len(p)).astype(np.float32) for p in objs],
+                pitch=np.full(n, pitch, np.float32), origin=np.zeros((n, 3), np.float32),
+                grid_target=(rs.uniform(size=(n, dim, dim, dim)) < 0.3).astype(np.float32),
+                grid_nontarget_empty=(rs.uniform(size=(n, dim, dim, dim)) < 0.5).astype(np.float32),
+                transform_init=T)
+
+
+@pytest.mark.parametrize("split", [640, 24])
+def test_icc_kernel_source_exact_ties_and_split_planes(split, fixtures3):
+    """(a) exact distance ties -> the tile's tie flag -> the exact lowest-id tie-break pass;
+    (b) MF_ICC_TILE_SPLIT=24 forces every non-trivial plane through the stripe split + LDS
+    compaction path.  Both against the oracle, on the tie scene and on an ordinary scene."""
+    import ctypes
+    os.environ["MF_ICC_DEBUG"] = "64"  # count the tiles that took the tie / split paths
+    try:
+        lib = emul.build(["icc.hip"], extra_flags=(f"-DMF_ICC_TILE_SPLIT={split}",))
+        runs = []
+        for sc in (_lattice_tie_scene(), synthetic.make_icc_scene(3, seed=0, fixtures=fixtures3)):
+            S = emul.EmulIccScenes(lib, [_dict(sc)], sdf_offset=0.02)
+            q0, t0 = _pose0(sc)
+            before = np.zeros(4096 * 8, np.uint64)
+            lib.mf_icc_debug_stamps(ctypes.c_void_p(before.ctypes.data), before.size)
+            out = S.loss_grad(q0, t0)
+            after = np.zeros(4096 * 8, np.uint64)
+            lib.mf_icc_debug_stamps(ctypes.c_void_p(after.ctypes.data), after.size)
+            runs.append((sc, q0, t0, out, (after - before)[4095 * 8:4095 * 8 + 2]))
+    finally:
+        del os.environ["MF_ICC_DEBUG"]
+    assert runs[0][4][0] > 0          # the lattice scene really has tied tiles
+    if split < 640:
+        assert runs[1][4][1] > 0      # and the small threshold really splits planes
+    for sc, q0, t0, (loss, gq, gt), _ in runs:
+        l_o, gq_o, gt_o, _ = OC.icc_loss_grad(*_args(sc), q0, t0, sdf_offset=0.02)
+        np.testing.assert_allclose(loss[0], l_o, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(gq, gq_o, rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(gt, gt_o, rtol=2e-3, atol=2e-4)
