@@ -205,14 +205,14 @@ int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float *adam_m,
                   float alpha_t, float *losses, float *traj, void *ws,
                   mfStream_t stream);
 
-/* Measurement hook: launch ONLY the TDF front end of an ICC iteration (k_icc_bin + k_icc_tile:
- * pose -> world points -> x-plane bins -> per-grid (min distance, arg-min) winners) so that
- * bench.py can time it with HIP events.  If q and t are non-NULL the rotation matrices are
- * refreshed from them first (separate tiny launch). */
-int mf_icc_launch_tdf(const mfIccBatch *batch, const float *q, const float *t, void *ws,
-                      mfStream_t stream);
+/* Measurement hook so that bench.py can time ONE kernel of an ICC iteration with HIP events:
+ * stage 0 = (optional pose refresh from q, t if non-NULL) + empty the bins + k_icc_bin (pose ->
+ * world points -> x-plane bins of voxel-frame records); stage 1 = k_icc_tile alone (bins ->
+ * per-grid (min distance, arg-min) winners; repeatable: it does not consume the bins). */
+int mf_icc_launch_stage(const mfIccBatch *batch, const float *q, const float *t, void *ws,
+                        int32_t stage, mfStream_t stream);
 
-/* Tuning aid: with MF_ICC_DEBUG=32 in the environment k_icc_tdf / k_icc_accum record
+/* Tuning aid: with MF_ICC_DEBUG=32 in the environment k_icc_bin / k_icc_tile / k_icc_accum record
  * wall_clock64() phase stamps per workgroup; this copies the first n 64-bit words of that
  * table to host memory (synchronous).  Not used by the product path. */
 int mf_icc_debug_stamps(unsigned long long *host_out, int n);

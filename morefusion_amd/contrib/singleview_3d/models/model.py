@@ -199,11 +199,15 @@ class Model(nn.Module):
 
     def _predict_device(self, class_id, rgb, pcd, pix, pitch, origin, grid_nontarget_empty):
         """Everything after point selection: pure device work, no host synchronisation."""
+        values, points = self._backbone_features(rgb, pcd, pix)
+        return self._pose_from_features(class_id, values, points, pitch, origin, grid_nontarget_empty)
+
+    def _backbone_features(self, rgb, pcd, pix):
+        """The stock 2-D part (ResNet18 + PSPNet on MIOpen) and the gathers at the sampled pixels:
+        -> per-point image features [B,32,P] and camera-frame points [B,3,P]."""
         B = rgb.shape[0]
-        dev = rgb.device
         rgb = rgb.float().permute(0, 3, 1, 2)
         pcd = pcd.float().permute(0, 3, 1, 2)
-
         if self.sparse_pspnet_tail:
             # last PSPNet level evaluated only at the sampled pixels (identical features)
             plan = self.pspnet_extractor.plan(pix, rgb.shape[2] // 8, rgb.shape[3] // 8)
@@ -214,7 +218,13 @@ class Model(nn.Module):
                                   pix[:, None, :].expand(B, h_rgb.shape[1], -1))
         # NaN-masked pixels are never selected; nan_to_num keeps the gather capture-safe
         points = torch.gather(pcd.reshape(B, 3, -1), 2, pix[:, None, :].expand(B, 3, -1))
+        return values, points
 
+    def _pose_from_features(self, class_id, values, points, pitch, origin, grid_nontarget_empty):
+        """The volumetric part (the hand-written path of the network): voxelize -> occupancy
+        branch + conv3/conv4 -> trilinear sampling -> the three per-point heads."""
+        B = values.shape[0]
+        dev = values.device
         points = (points - origin[:, :, None]) / pitch[:, None, None]  # camera -> voxel frame
         h = self._extract(values, points, grid_nontarget_empty)
 

@@ -86,7 +86,8 @@ struct IccArgs {
   int4 *tab;              // [n_tab] {target object o, source object j, point begin, point end}; o < 0: unused
   int4 *tab2;             // [n_tab] {scene first object, objects in scene, scene, 1 = designated entry of j}
   int n_tab;
-  int nbins;              // D + 2h planes: rounded x in [-h, D-1+h]
+  int hmax;               // largest TDF half-kernel of the batch
+  int nbins;              // kHalves * (D + 2 hmax): (x-plane of the rounded x in [-hmax, D-1+hmax], y-half)
   uint32_t *bin_cnt;      // [2*O][nbins] records in each bin (zero between iterations)
   int32_t *bin_cap;       // [2*O] capacity of each bin of grid g = number of its source points
   int64_t *bin_base;      // [2*O] first record of grid g's bins; bin b starts at base + b*cap
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(64) void k_icc_pose(IccArgs a, const float *__restr
 constexpr int kBinThreads = 256;
 constexpr int kBinPPT = 4;                          // points per thread
 constexpr int kBinChunk = kBinThreads * kBinPPT;    // points per workgroup
-constexpr int kMaxBins = 64 + 6;                    // D <= 64, ks <= 7
+constexpr int kHalves = 2;                          // y-halves of a plane: rows [0, D/2), [D/2, D)
+constexpr int kMaxBins = kHalves * (64 + 6);        // D <= 64, ks <= 7
 
 // Once per batch: bin capacities/offsets per grid and the (target, source, point chunk) table.
 __global__ __launch_bounds__(256) void k_icc_tables(IccArgs a) {
@@ -418,7 +420,7 @@ __device__ __forceinline__ void icc_step_apply(const float *sv, float S_t, const
 }
 
 // launch 1: one workgroup per (target grid, source object, chunk of <= 1024 points)
-__global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax, IccStepArgs sp) {
+__global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs sp) {
   __shared__ int s_cnt[kMaxBins], s_base[kMaxBins];
   __shared__ float s_sum[kStepSums], s_state[kStateFloats];
   __shared__ long long s_raw[kStepRawWords];
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax, Ic
   const int4 e = a.tab[blockIdx.x];
   const int o = e.x, j = e.y;
   if (o < 0) return;  // block-uniform
-  const int D = a.D, nb = a.nbins;
+  const int D = a.D, nb = a.nbins, hmax = a.hmax;
   const int g = 2 * o + (j != o ? 1 : 0);
   // everything below depends on the table entries only: one memory round trip
   const int4 e2 = a.tab2[blockIdx.x];  // {scene first object, objects in scene, scene, designated}
@@ -510,13 +512,16 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax, Ic
     if (!hit) return;
   }
   __syncthreads();
+  // A survivor goes to the bin of its rounded x-plane, in the y-half (or both halves) its
+  // ks rows touch: the tile of a half then finds exactly its own records, dense.
   float fx[kBinPPT], fy[kBinPPT], fz[kBinPPT];
-  int bin[kBinPPT], slot[kBinPPT];
+  int bin[kBinPPT][kHalves], slot[kBinPPT][kHalves];
+  const int Dh = (D + 1) / 2;
 #pragma unroll
   for (int u = 0; u < kBinPPT; ++u) {
     const int p = e.z + u * kBinThreads + (int)threadIdx.x;
-    bin[u] = -1;
-    slot[u] = 0;
+#pragma unroll
+    for (int hf = 0; hf < kHalves; ++hf) { bin[u][hf] = -1; slot[u][hf] = 0; }
     if (p < e.w) {
       // transform_points: ((R0 x + R1 y) + R2 z) + t, un-fused (oracle order), then
       // (p - origin) / pitch with a correctly rounded divide (voxelization_3d index rule)
@@ -528,8 +533,16 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax, Ic
       const bool surv = rx + fh >= 0.0f && rx - fh < (float)D && ry + fh >= 0.0f &&
                         ry - fh < (float)D && rz + fh >= 0.0f && rz - fh < (float)D;
       if (surv) {
-        bin[u] = (int)rx + hmax;  // in [0, D + 2 hmax)
-        slot[u] = atomicAdd(&s_cnt[bin[u]], 1);
+        const int plane = (int)rx + hmax;  // in [0, D + 2 hmax)
+        const int iry = (int)ry;
+        if (iry - h < Dh) {
+          bin[u][0] = plane * kHalves;
+          slot[u][0] = atomicAdd(&s_cnt[bin[u][0]], 1);
+        }
+        if (iry + h >= Dh) {
+          bin[u][1] = plane * kHalves + 1;
+          slot[u][1] = atomicAdd(&s_cnt[bin[u][1]], 1);
+        }
       }
     }
   }
@@ -543,173 +556,156 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, int hmax, Ic
   stamp(2);
 #pragma unroll
   for (int u = 0; u < kBinPPT; ++u) {
-    if (bin[u] < 0) continue;
-    const int idx = s_base[bin[u]] + slot[u];
-    if (idx >= cap) continue;  // cannot happen while bin_cnt starts at zero; never write out of bounds
     const int p = e.z + u * kBinThreads + (int)threadIdx.x;
-    a.rec[base_g + (int64_t)bin[u] * cap + idx] = make_float4(fx[u], fy[u], fz[u], __uint_as_float((uint32_t)p));
+#pragma unroll
+    for (int hf = 0; hf < kHalves; ++hf) {
+      if (bin[u][hf] < 0) continue;
+      const int idx = s_base[bin[u][hf]] + slot[u][hf];
+      if (idx >= cap) continue;  // cannot happen while bin_cnt starts at zero; never write out of bounds
+      a.rec[base_g + (int64_t)bin[u][hf] * cap + idx] =
+          make_float4(fx[u], fy[u], fz[u], __uint_as_float((uint32_t)p));
+    }
   }
   stamp(3);
 }
 
-// launch 2: TDF of one x-plane of one grid, fed from bins x-h..x+h -- ONE pass over the records.
-//  * squared distances in voxel units (no sqrt, no pitch; dist = pitch*sqrt(d2) is monotone in
-//    d2): 32-bit RETURNING atomicMin of the d2 bits behind a batched peek;
-//  * a candidate that lowered the minimum ("setter", ~ln(n) of the n candidates of a voxel)
-//    also takes a 64-bit atomicMin of (d2 bits << 32 | candidate id): when the records are
-//    done the word holds the minimum and the id of the candidate that achieved it;
-//  * the reference's winner is the lowest id among equal ROUNDED distances, which can differ
-//    from the above only if two candidates of a voxel lie within a few ulp of each other in d2.
-//    The value returned by the 32-bit atomic is the exact history of the voxel, so any such
-//    pair is seen (|d2 - previous minimum| <= 8 ulp) and raises the tile's tie flag; a flagged
-//    tile (rare: generic poses have no ties) re-streams its records through the exact
-//    tie-break (the two-pass scheme every tile ran before).  Winners are therefore identical.
-// A crowded plane (T records > kTileSplit: up to 2400 at 8 objects, mean 300) is bound by the
-// instruction issue of ONE CU while the rest idle: its kTileStripes workgroups each own D/4 rows,
-// compact the records whose rows touch their stripe into LDS (dense lanes: a lane-masked stripe
-// pays for every record of the plane) and process only those; a light plane is handled by
-// stripe 0 alone and the other stripes exit at once.
+// launch 2: TDF of one half of an x-plane (rows [y0, y1)) of one grid, fed from the bins of
+// planes x-h..x+h of that half.
+//  pass 1 works on SQUARED distances in voxel units (no sqrt, no pitch): 32-bit atomicMin of
+//         the d2 bits behind a batched peek.  dist = pitch*sqrt(d2) is monotone in d2.  A lane
+//         remembers, per record, WHICH of its candidates were within a few ulp of the minimum
+//         it saw (9-bit mask): minima only decrease, so no other candidate can end up minimal.
+//  pass 2 re-derives, only for those candidates (~ln n of the n candidates of a voxel), the EXACT
+//         float distance and, where it equals the exact minimum and is < truncation, takes
+//         atomicMin of the candidate id: the same winners as the oracle (lowest id among
+//         equal ROUNDED distances).
+// Measured alternatives (profiles/): a single pass with a 64-bit (d2, id) LDS
+// atomicMin per improving candidate is slower (ds_min_u64 processes lanes serially); splitting
+// a crowded plane over 4 workgroups that each scan all its records is slower (every stripe
+// pays for every record, and 2048 workgroups no longer fit the chip at once) -- hence the
+// halves are made by the binning kernel, where it costs one extra append for 1 point in 8.
 constexpr int kTileThreads = 512;
-constexpr int kTileStripes = 4;
-#ifndef MF_ICC_TILE_SPLIT
-#define MF_ICC_TILE_SPLIT 640  // (tests build with a small value to force the split path)
-#endif
-constexpr int kTileSplit = MF_ICC_TILE_SPLIT;  // records per plane above which the stripes share the work
-constexpr int kTileR = 2;         // records per lane per round
-constexpr int kTileList = kTileThreads * kTileR;  // LDS record list of a stripe (one round's worth)
-constexpr unsigned long long kNoWin = 0xffffffffffffffffull;
+constexpr int kTileKeep = 4;  // records per lane kept in registers over both passes
+constexpr int kTileR = 4;     // records in flight per lane beyond those
 
 template <int KS>
-__device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt, const int hmax) {
-  MF_DYN_LDS(uint32_t, s_tile);  // dist[D*D] u32 | id[D*D] u32 | win[D*D] u64 | list[kTileList] float4
+__device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt) {
+  MF_DYN_LDS(uint32_t, s_tile);  // dist[rows*D], id[rows*D]
   __shared__ float s_max[kTileThreads / 64];
-  __shared__ int s_n;
-  __shared__ uint32_t s_tie;
   const int ks = KS > 0 ? KS : ks_rt;
   const int h = ks / 2, K = ks * ks * ks;
-  const int D = a.D, nb = a.nbins, plane = D * D;
+  const int D = a.D, nb = a.nbins, hmax = a.hmax;
   const int g = blockIdx.y, o = g >> 1, other = g & 1;
-  const int x = blockIdx.x / kTileStripes, stripe = blockIdx.x % kTileStripes;
-  uint32_t *s_dist = s_tile, *s_id = s_tile + plane;
-  unsigned long long *s_win = reinterpret_cast<unsigned long long *>(s_tile + 2 * plane);
-  float4 *s_list = reinterpret_cast<float4 *>(s_tile + 4 * plane);
+  const int x = blockIdx.x / kHalves, half = blockIdx.x % kHalves;
+  const int Dh = (D + 1) / 2;
+  const int y0 = half * Dh, y1 = half == 0 ? Dh : D;
+  const int nvox = (y1 - y0) * D;
+  uint32_t *s_dist = s_tile, *s_id = s_tile + Dh * D;
   // independent loads: the <= 7 bin counts of this tile, capacity, offset
   int c[8];
   c[0] = 0;
   const int cap = a.bin_cap[g];
   const int64_t base_g = a.bin_base[g];
   const float pitch = a.pitch[o];
-  const int bin0 = x + hmax - h;  // bin of plane x - h
+  const int bin0 = x + hmax - h;  // plane x - h
 #pragma unroll
   for (int b = 0; b < 7; ++b) {
     int n = 0;
-    if (b < ks) n = min((int)a.bin_cnt[(int64_t)g * nb + bin0 + b], cap);
+    if (b < ks) n = min((int)a.bin_cnt[(int64_t)g * nb + (bin0 + b) * kHalves + half], cap);
     c[b + 1] = c[b] + n;
   }
   const int T = c[7];
-  const bool split = T > kTileSplit;
-  if (!split && stripe != 0) return;  // block-uniform
-  const int rows = (D + kTileStripes - 1) / kTileStripes;
-  const int y0 = split ? stripe * rows : 0, y1 = split ? min(D, y0 + rows) : D;
-  const int nvox = max(0, y1 - y0) * D;
-  const int wg = blockIdx.y * (gridDim.x / kTileStripes) + x;
-  auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32), stripe 0 of every plane
-    if ((a.dbg & 32) && threadIdx.x == 0 && stripe == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
+    if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
   };
   stamp(0);
-  if ((a.dbg & 32) && threadIdx.x == 0 && stripe == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)T;
+  if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)T;
   const float trunc = a.thr * pitch;
-  for (int i = threadIdx.x; i < nvox; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_win[i] = kNoWin; }
-  if (threadIdx.x == 0) { s_n = 0; s_tie = 0u; }
+  for (int i = threadIdx.x; i < nvox; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
   __syncthreads();
-  const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test at the end
+  const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test in pass 2
   const float d2_in = a.thr * a.thr * 0.999f;    // certainly inside the truncation radius
-  const float4 *recs = a.rec + base_g + (int64_t)bin0 * cap;
+  const float4 *recs = a.rec + base_g;
   const float fxp = (float)x;
-  const int lane = threadIdx.x & 63;
 
-  // record i of this tile's concatenated bins; its bin offset b rides in bits 28..30 of the id
-  // word (point ids are < 2^27).  ok = false: none.
-  auto fetch = [&](const int i, float4 &rv, bool &ok) {
-    ok = i < T;
-    if (!ok) return;
+  // record i of this tile's concatenated bins -> (plane offset b, record); rb < 0: none
+  auto fetch = [&](const int i, float4 &rv, int &rb) {
+    rb = -1;
+    if (i >= T) return;
     int b = 0;
 #pragma unroll
     for (int k = 1; k < 7; ++k) b += (k < ks && i >= c[k]) ? 1 : 0;
     int cb = 0;
 #pragma unroll
     for (int k = 1; k < 7; ++k) cb = (k == b) ? c[k] : cb;
-    rv = recs[(int64_t)b * cap + (i - cb)];
-    rv.w = __uint_as_float(__float_as_uint(rv.w) | ((uint32_t)b << 28));
+    rb = b;
+    rv = recs[(int64_t)((bin0 + b) * kHalves + half) * cap + (i - cb)];
   };
-  auto mine = [&](const float4 &rv) {  // do the ks rows around round(y) touch rows [y0, y1)?
-    const int iry = (int)roundf(rv.y);
-    return iry + h >= y0 && iry - h < y1;
+  // exact tie-break of ONE candidate against the final minimum of its voxel
+  auto settle = [&](const int ad, const uint32_t db, const uint32_t cid) {
+    const uint32_t cur = s_dist[ad];
+    if (db <= cur + 8u) {  // within a few ulp of the minimal d2
+      // dist == dmin is certain for equal bits; dist < trunc is certain well inside the
+      // truncation radius (pitch*sqrt(d2) <= 0.9995 thr pitch (1 + 2^-22) < trunc)
+      bool win = db == cur && __uint_as_float(db) < d2_in;
+      if (!win) {
+        const float dist = pitch * sqrtf(__uint_as_float(db));
+        const float dmin = pitch * sqrtf(__uint_as_float(cur));
+        win = dist == dmin && dist < trunc;
+      }
+      if (win) atomicMin(&s_id[ad], cid);
+    }
   };
-  // One record against its ks x ks (y, z) candidates in plane x.  exact == false: the single
-  // pass described above.  exact == true (flagged tiles only): s_dist holds the final minima;
-  // candidates whose exact float distance equals the minimal one (and is < truncation) take
-  // atomicMin of their id into s_id.
-  auto visit = [&](const bool exact, const float4 sv) {
+  // One record against its ks x ks (y, z) candidates in plane x.  pass 1 returns the mask of
+  // candidates that may still win (KS == 3: one bit per candidate; else bit 0 = "any"); pass 2
+  // visits the candidates of `mask`.  All peeks of a record are issued together, then the
+  // non-returning atomics.  A peek may be stale (another lane lowered the voxel meanwhile):
+  // values only decrease, so a stale peek only lets MORE candidates through.
+  auto visit = [&](const int pass, const float4 sv, const int rb, const unsigned mask) -> unsigned {
     const int iry = (int)roundf(sv.y), irz = (int)roundf(sv.z);
-    const uint32_t wbits = __float_as_uint(sv.w);
-    const uint32_t idb = (wbits & 0x07ffffffu) * (uint32_t)K;
-    const int bb = ks - 1 - (int)(wbits >> 28);  // x offset of plane x inside this point's neighbourhood
+    const uint32_t idb = __float_as_uint(sv.w) * (uint32_t)K;
+    const int bb = ks - 1 - rb;  // x offset of plane x inside this point's neighbourhood
     const float dx = sv.x - fxp;
     const float dx2 = dx * dx;
-    auto one = [&](const int ad, const uint32_t db, const uint32_t cur, const uint32_t cid, uint32_t &old) {
-      // (only the non-exact path returns through `old`)
-      if (exact) {
-        if (db <= cur + 8u) {  // within a few ulp of the minimal d2
-          bool win = db == cur && __uint_as_float(db) < d2_in;
-          if (!win) {
-            const float dist = pitch * sqrtf(__uint_as_float(db));
-            const float dmin = pitch * sqrtf(__uint_as_float(cur));
-            win = dist == dmin && dist < trunc;
+    unsigned out = 0u;
+    if constexpr (KS == 3) {
+      if (pass == 1) {
+        uint32_t db[9], cur[9];
+        int ad[9];
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) {
+          const int iy = iry + aa - 1;
+          const float dy = sv.y - (float)iy;
+          const float dxy = dx2 + dy * dy;  // (dx^2 + dy^2) + dz^2: the oracle's order
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            const int iz = irz + cc - 1;
+            const float dz = sv.z - (float)iz;
+            const float d2 = dxy + dz * dz;
+            const bool ok = iy >= y0 && iy < y1 && iz >= 0 && iz < D && d2 < d2_hi;
+            db[aa * 3 + cc] = __float_as_uint(d2);
+            ad[aa * 3 + cc] = ok ? (iy - y0) * D + iz : -1;
           }
-          if (win) atomicMin(&s_id[ad], cid);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cur[k] = s_dist[ad[k] < 0 ? 0 : ad[k]];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          if (ad[k] < 0) continue;
+          if (db[k] <= cur[k]) atomicMin(&s_dist[ad[k]], db[k]);
+          if (db[k] <= cur[k] + 8u) out |= 1u << k;
         }
       } else {
-        old = 0u;  // "not issued"
-        if (db <= cur + 8u) old = atomicMin(&s_dist[ad], db);
-      }
-    };
-    auto settle = [&](const int ad, const uint32_t db, const uint32_t cid, const uint32_t old) {
-      if (old == 0u) return;  // d2 == 0 exactly never reads back as 0 here: see below
-      if (db < old) atomicMin(&s_win[ad], ((unsigned long long)db << 32) | cid);
-      const uint32_t diff = db > old ? db - old : old - db;
-      if (diff <= 8u) s_tie = 1u;  // incl. an exact tie (db == old)
-    };
-    if constexpr (KS == 3) {
-      uint32_t db[9], cur[9], old[9];
-      int ad[9];
 #pragma unroll
-      for (int aa = 0; aa < 3; ++aa) {
-        const int iy = iry + aa - 1;
-        const float dy = sv.y - (float)iy;
-        const float dxy = dx2 + dy * dy;  // (dx^2 + dy^2) + dz^2: the oracle's order
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-          const int iz = irz + cc - 1;
-          const float dz = sv.z - (float)iz;
-          const float d2 = dxy + dz * dz;
-          const bool ok = iy >= y0 && iy < y1 && iz >= 0 && iz < D && d2 < d2_hi;
-          // +1: keeps the bits of d2 == 0 apart from the "not issued" marker; order-preserving
-          db[aa * 3 + cc] = __float_as_uint(d2) + 1u;
-          ad[aa * 3 + cc] = ok ? (iy - y0) * D + iz : -1;
+        for (int k = 0; k < 9; ++k) {
+          if (!((mask >> k) & 1u)) continue;  // in range and near-minimal when pass 1 saw it
+          const int aa = k / 3, cc = k % 3;
+          const int iy = iry + aa - 1, iz = irz + cc - 1;
+          const float dy = sv.y - (float)iy, dz = sv.z - (float)iz;
+          const float d2 = (dx2 + dy * dy) + dz * dz;
+          settle((iy - y0) * D + iz, __float_as_uint(d2), idb + (uint32_t)((aa * 3 + bb) * 3 + cc));
         }
-      }
-#pragma unroll
-      for (int k = 0; k < 9; ++k) cur[k] = s_dist[ad[k] < 0 ? 0 : ad[k]];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        old[k] = 0u;
-        if (ad[k] >= 0) one(ad[k], db[k], cur[k], idb + (uint32_t)(((k / 3) * 3 + bb) * 3 + (k % 3)), old[k]);
-      }
-      if (!exact) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-          if (ad[k] >= 0) settle(ad[k], db[k], idb + (uint32_t)(((k / 3) * 3 + bb) * 3 + (k % 3)), old[k]);
       }
     } else {
       for (int aa = 0; aa < ks; ++aa) {
@@ -724,77 +720,73 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
           const float dz = sv.z - (float)iz;
           const float d2 = dxy + dz * dz;
           if (!(d2 < d2_hi)) continue;
-          const uint32_t db = __float_as_uint(d2) + 1u;
-          const uint32_t cid = idb + (uint32_t)((aa * ks + bb) * ks + cc);
-          uint32_t old = 0u;
-          one(lrow + iz, db, s_dist[lrow + iz], cid, old);
-          if (!exact) settle(lrow + iz, db, cid, old);
+          const uint32_t db = __float_as_uint(d2);
+          if (pass == 1) {
+            const uint32_t cur = s_dist[lrow + iz];
+            if (db <= cur) atomicMin(&s_dist[lrow + iz], db);
+            if (db <= cur + 8u) out = 1u;
+          } else {
+            settle(lrow + iz, db, idb + (uint32_t)((aa * ks + bb) * ks + cc));
+          }
         }
       }
     }
+    return out;
   };
 
-  // Stream the tile's records through visit(): kTileR records per lane per round, the next
-  // round's loads in flight while this one is processed.  A split tile first compacts the
-  // records of its stripe into LDS (wave-aggregated append) and walks the dense list.
-  auto stream = [&](const bool exact) {
-    float4 nv[kTileR];
-    bool nok[kTileR];
+  // The first kTileThreads * kTileKeep records stay in registers over both passes (all loads
+  // in flight at once: ONE memory round trip); a more crowded tile streams the rest again.
+  float4 rv[kTileKeep];
+  int rb[kTileKeep];
+  unsigned long long keep = 0ull;  // 9 bits per kept record: candidates that may still win
 #pragma unroll
-    for (int u = 0; u < kTileR; ++u) fetch(u * kTileThreads + (int)threadIdx.x, nv[u], nok[u]);
-    for (int base = 0; base < T; base += kTileList) {
-      float4 rv[kTileR];
-      bool ok[kTileR];
-#pragma unroll
-      for (int u = 0; u < kTileR; ++u) { rv[u] = nv[u]; ok[u] = nok[u]; }
-#pragma unroll
-      for (int u = 0; u < kTileR; ++u)
-        fetch(base + kTileList + u * kTileThreads + (int)threadIdx.x, nv[u], nok[u]);
-      if (!split) {
-#pragma unroll
-        for (int u = 0; u < kTileR; ++u)
-          if (ok[u]) visit(exact, rv[u]);
-        continue;
-      }
-#pragma unroll
-      for (int u = 0; u < kTileR; ++u) {
-        const bool rel = ok[u] && mine(rv[u]);
-        const unsigned long long mask = __ballot(rel);
-        if (mask != 0ull) {  // wave-uniform
-          const int leader = __ffsll(mask) - 1;
-          int slot = 0;
-          if (lane == leader) slot = atomicAdd(&s_n, __popcll(mask));
-          slot = __shfl(slot, leader, 64);
-          if (rel) s_list[slot + __popcll(mask & ((1ull << lane) - 1ull))] = rv[u];
-        }
-      }
-      __syncthreads();
-      const int n = s_n;
-      for (int i = threadIdx.x; i < n; i += kTileThreads) visit(exact, s_list[i]);
-      __syncthreads();
-      if (threadIdx.x == 0) s_n = 0;
-      // (the next append is behind the barrier of the next round's end or uses s_n after it:
-      //  thread 0 resets before it can reach the next ballot's atomicAdd of any wave? no --
-      //  another wave may already be appending: order it)
-      __syncthreads();
-    }
-  };
-
+  for (int u = 0; u < kTileKeep; ++u) fetch(u * kTileThreads + (int)threadIdx.x, rv[u], rb[u]);
   stamp(1);
-  stream(false);
+#pragma unroll
+  for (int u = 0; u < kTileKeep; ++u)
+    if (rb[u] >= 0) keep |= (unsigned long long)visit(1, rv[u], rb[u], 0u) << (9 * u);
+  for (int base = kTileThreads * kTileKeep; base < T; base += kTileThreads * kTileR) {
+    float4 xv[kTileR];
+    int xb[kTileR];
+#pragma unroll
+    for (int u = 0; u < kTileR; ++u) fetch(base + u * kTileThreads + (int)threadIdx.x, xv[u], xb[u]);
+#pragma unroll
+    for (int u = 0; u < kTileR; ++u)
+      if (xb[u] >= 0) visit(1, xv[u], xb[u], 0u);
+  }
   __syncthreads();
   stamp(2);
-  const bool tie = s_tie != 0u;  // block-uniform
-  if ((a.dbg & 64) && threadIdx.x == 0) {  // test hook: how many tiles took which path
-    if (tie) atomicAdd(&g_dbg_stamps[4095 * 8], 1ull);
-    if (split) atomicAdd(&g_dbg_stamps[4095 * 8 + 1], 1ull);
+#pragma unroll
+  for (int u = 0; u < kTileKeep; ++u) {
+    const unsigned m9 = (unsigned)(keep >> (9 * u)) & 0x1ffu;
+    if (m9 != 0u) visit(2, rv[u], rb[u], m9);
   }
-  if (tie) {
-    for (int i = threadIdx.x; i < nvox; i += kTileThreads) s_id[i] = kNoCand;
-    __syncthreads();
-    stream(true);
-    __syncthreads();
+  for (int base = kTileThreads * kTileKeep; base < T; base += kTileThreads * kTileR) {
+    float4 xv[kTileR];
+    int xb[kTileR];
+#pragma unroll
+    for (int u = 0; u < kTileR; ++u) fetch(base + u * kTileThreads + (int)threadIdx.x, xv[u], xb[u]);
+#pragma unroll
+    for (int u = 0; u < kTileR; ++u) {
+      if (xb[u] < 0) continue;
+      // streamed records carry no mask: every in-range candidate within the window is examined
+      if constexpr (KS == 3) {
+        const int iry = (int)roundf(xv[u].y), irz = (int)roundf(xv[u].z);
+        unsigned m9 = 0u;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const int iy = iry + k / 3 - 1, iz = irz + k % 3 - 1;
+          const float dxs = xv[u].x - fxp, dy = xv[u].y - (float)iy, dz = xv[u].z - (float)iz;
+          const float d2 = (dxs * dxs + dy * dy) + dz * dz;
+          if (iy >= y0 && iy < y1 && iz >= 0 && iz < D && d2 < d2_hi) m9 |= 1u << k;
+        }
+        if (m9 != 0u) visit(2, xv[u], xb[u], m9);
+      } else {
+        visit(2, xv[u], xb[u], 1u);
+      }
+    }
   }
+  __syncthreads();
   stamp(3);
   // epilogue: winners out (coalesced 8 B/lane) + max raw inside weight of this tile
   // (truncated_distance_function.py:198-204: -1 where no winner, + offset, clamp at 0)
@@ -803,38 +795,26 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
   float wmax = 0.0f;
   for (int i0 = threadIdx.x; i0 < nvox; i0 += kTileThreads * 2) {
     uint32_t lo[2];
-    float sd[2], dist[2];
+    float sd[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int i = i0 + u * kTileThreads;
-      lo[u] = kNoCand;
-      dist[u] = trunc;
-      if (i < nvox) {
-        const uint32_t dmin = s_dist[i];
-        if (dmin != 0x7f800000u) {
-          const float d = pitch * sqrtf(__uint_as_float(dmin - 1u));
-          if (tie) {
-            lo[u] = s_id[i];  // set only where the exact distance is < truncation
-          } else if (d < trunc) {
-            lo[u] = (uint32_t)s_win[i];
-          }
-          if (lo[u] != kNoCand) dist[u] = d;
-        }
-      }
+      lo[u] = i < nvox ? s_id[i] : kNoCand;  // set only where pitch*sqrt(min d2) < trunc
       sd[u] = lo[u] != kNoCand ? a.pts4[lo[u] / (uint32_t)K].w : -1.0f;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int i = i0 + u * kTileThreads;
       if (i >= nvox) continue;
-      Wg[i] = ((unsigned long long)__float_as_uint(dist[u]) << 32) | lo[u];
+      const float dist = lo[u] != kNoCand ? pitch * sqrtf(__uint_as_float(s_dist[i])) : trunc;
+      Wg[i] = ((unsigned long long)__float_as_uint(dist) << 32) | lo[u];
       float w = sd[u] + offset;
       w = w < 0.0f ? 0.0f : w;
       wmax = fmaxf(wmax, w);
     }
   }
   wmax = mf::wave_max(wmax);
-  if (lane == 0) s_max[threadIdx.x >> 6] = wmax;
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = wmax;
   __syncthreads();
   if (threadIdx.x == 0) {
     float m = s_max[0];
@@ -845,12 +825,12 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
   stamp(4);
 }
 
-__global__ __launch_bounds__(kTileThreads) void k_icc_tile(IccArgs a, int hmax) {
-  const int ks = min(ksize_of(a.thr, a.pitch[blockIdx.y >> 1]), 2 * hmax + 1);  // block-uniform
+__global__ __launch_bounds__(kTileThreads) void k_icc_tile(IccArgs a) {
+  const int ks = min(ksize_of(a.thr, a.pitch[blockIdx.y >> 1]), 2 * a.hmax + 1);  // block-uniform
   if (ks == 3)
-    icc_tile_body<3>(a, 3, hmax);
+    icc_tile_body<3>(a, 3);
   else
-    icc_tile_body<0>(a, ks, hmax);
+    icc_tile_body<0>(a, ks);
 }
 
 // ---- launch 2: weights, sums, gradient moments ------------------------------------
@@ -1140,7 +1120,7 @@ WsLayout ws_layout(const mfIccBatch *b) {
   const int O = b->n_objects, S = b->n_scenes, D = b->dim, max_ns = b->max_scene_objects;
   const int64_t V = (int64_t)D * D * D;
   l.NB = (int)((V + kVoxPerBlock - 1) / kVoxPerBlock);
-  l.nbins = D + 2 * (ksize_host(b->voxel_threshold) / 2);
+  l.nbins = kHalves * (D + 2 * (ksize_host(b->voxel_threshold) / 2));
   // every (target, source) pair of a scene in chunks of kBinChunk points:
   // sum_pairs ceil(P_j / chunk) <= max_ns * n_points / chunk + O * max_ns (+ O designated entries)
   l.n_tab = (int)(((int64_t)max_ns * b->n_points + kBinChunk - 1) / kBinChunk) + O * max_ns + O;
@@ -1160,7 +1140,7 @@ WsLayout ws_layout(const mfIccBatch *b) {
   l.bin_cap = off; off = align256(off + (int64_t)2 * O * 4);
   l.bin_base = off; off = align256(off + (int64_t)2 * O * 8);
   // a grid's bins hold <= (its source points) records each: sum over grids of a scene
-  // = Ns * P_scene <= max_ns * n_points, times nbins planes
+  // = Ns * P_scene <= max_ns * n_points, times nbins (plane, half) bins
   l.rec = off; off = align256(off + (int64_t)l.nbins * max_ns * b->n_points * 16);
   l.total = off;
   return l;
@@ -1198,6 +1178,7 @@ IccArgs make_args(const mfIccBatch *b, void *ws) {
   a.tab2 = (int4 *)(p + l.tab2);
   a.n_tab = l.n_tab;
   a.nbins = l.nbins;
+  a.hmax = ksize_host(b->voxel_threshold) / 2;
   a.bin_cnt = (uint32_t *)(p + l.bin_cnt);
   a.bin_cap = (int32_t *)(p + l.bin_cap);
   a.bin_base = (int64_t *)(p + l.bin_base);
@@ -1208,11 +1189,9 @@ IccArgs make_args(const mfIccBatch *b, void *ws) {
 // bin (+ the previous iteration's step when sp.mode == 1) -> tile
 void launch_front(const IccArgs &a, const IccStepArgs &sp, hipStream_t stream) {
   const int D = a.D;
-  const int hmax = (a.nbins - D) / 2;
-  hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, hmax, sp);
-  const size_t lds = (size_t)D * D * 4 * sizeof(uint32_t) + (size_t)kTileList * sizeof(float4);  // 32 KB at D = 32
-  hipLaunchKernelGGL(k_icc_tile, dim3(D * kTileStripes, 2 * a.O), dim3(kTileThreads), lds, stream, a,
-                     hmax);
+  hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, sp);
+  const size_t lds = (size_t)((D + 1) / 2) * D * 2 * sizeof(uint32_t);  // 4 KB at D = 32
+  hipLaunchKernelGGL(k_icc_tile, dim3(D * kHalves, 2 * a.O), dim3(kTileThreads), lds, stream, a);
 }
 
 void launch_accum(const IccArgs &a, int NB, int par, hipStream_t stream) {
@@ -1267,17 +1246,26 @@ extern "C" int mf_icc_debug_stamps(unsigned long long *host_out, int n) {
   return -(int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg_stamps), sizeof(unsigned long long) * n);
 }
 
-extern "C" int mf_icc_launch_tdf(const mfIccBatch *batch, const float *q, const float *t, void *ws,
-                                 mfStream_t stream_) {
+extern "C" int mf_icc_launch_stage(const mfIccBatch *batch, const float *q, const float *t, void *ws,
+                                   int32_t stage, mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = icc_validate(batch)) return e;
   IccArgs a = make_args(batch, ws);
-  if (q && t) hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t, (float *)nullptr);
-  // inside an iteration k_icc_accum empties the bins; this hook has no accum launch
-  MF_TRY(hipMemsetAsync(a.bin_cnt, 0, sizeof(uint32_t) * 2 * a.O * a.nbins, stream));
-  IccStepArgs sp = {};
-  launch_front(a, sp, stream);
-  return mf::check_launch("mf_icc_launch_tdf");
+  const int D = a.D;
+  if (stage == 0) {
+    if (q && t) hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t, (float *)nullptr);
+    // inside an iteration k_icc_accum empties the bins; this hook has no accum launch
+    MF_TRY(hipMemsetAsync(a.bin_cnt, 0, sizeof(uint32_t) * 2 * a.O * a.nbins, stream));
+    IccStepArgs sp = {};
+    hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, sp);
+  } else if (stage == 1) {
+    const size_t lds = (size_t)((D + 1) / 2) * D * 2 * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_icc_tile, dim3(D * kHalves, 2 * a.O), dim3(kTileThreads), lds, stream, a);
+  } else {
+    mf::set_last_error(hipErrorInvalidValue, "mf_icc_launch_stage: stage must be 0 or 1");
+    return -(int)hipErrorInvalidValue;
+  }
+  return mf::check_launch("mf_icc_launch_stage");
 }
 
 extern "C" int mf_icc_prepare(const mfIccBatch *batch, void *ws, mfStream_t stream_) {
