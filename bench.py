@@ -8,14 +8,18 @@ One "step" = one pass of the whole path over one batch of synthetic input, per G
     arg-max confidence -> per-object pose
     ICC joint refinement of every scene, 100 x {forward, backward, chainer-Adam} on device
     (N > 1) RCCL all-gather of the refined [n,7] poses
-By default the ICC refinement is issued on a second HIP stream and overlaps the network pass
-(software pipelining: in deployment ICC of scene k runs beside the network of scene k+1; the
-synthetic stages of one step are independent, so they overlap inside the step); every step
-still executes both stages completely.  ``--no-overlap`` runs them back to back; the JSON
-always carries the serial stage times (``stage_ms``, ``serial_ms_per_step``).
-Inputs are resident in HBM before the timed region.  Weights are random (no pretrained
-file is reachable offline), so the network's poses are meaningless: the ICC stage starts
-from the scene's synthetic perturbed-ground-truth poses instead -- same work, real grids.
+Pipelining (the default, ``value``): step k issues network(k) on the main stream, records an
+event, and issues ICC(k) + the pose all-gather on a second stream that WAITS on that event --
+ICC(k) is ordered after the network pass that produces its poses and overlaps network(k+1),
+the way a deployment refines frame k while the network runs on frame k+1.  Every step executes
+both stages completely.  ``--no-overlap`` runs them back to back on one stream; the JSON always
+carries the serial stage times (``stage_ms``, ``value_serial``), the rate of the hand-written
+volumetric path alone (``value_handwritten_path``: voxelize + 3-D CNN + heads + ICC, stock 2-D
+backbone excluded) and the batch-1 latency of BASELINE configs[1] (``latency_batch1_ms``).
+Inputs are resident in HBM before the timed region.  Weights are random (no pretrained file is
+reachable offline), so the network's poses carry no information: the ICC stage consumes the
+network's pose tensor only as its ordering dependency and starts from the scene's synthetic
+perturbed-ground-truth poses -- same work, real grids.
 
 Contract: python bench.py --gpus N --steps K --warmup W  -> ONE JSON line on rank 0.
 """
@@ -128,7 +132,8 @@ class Workload:
             e.record()
             self.events.append((name, e))
 
-    def _refine(self):
+    def _refine(self, network_poses=None):
+        # network_poses [B,7]: the stream-ordered dependency of this refinement (see module doc)
         self.q.copy_(self.q0)
         self.t.copy_(self.t0)
         self.m.zero_()
@@ -146,32 +151,33 @@ class Workload:
 
     @torch.no_grad()
     def step(self, timing=False):
-        """One pass of the path over this rank's batch.  Default: two HIP streams -- the ICC
-        refinement (latency-bound, few CUs) runs on its own stream beside the network pass
-        (MFMA-bound), the way a deployment pipelines ICC of scene k with the network of scene
-        k+1; both stages are executed completely for the batch inside every step.
-        ``timing=True`` (stage breakdown, un-timed) runs them back to back instead."""
+        """One pass of the path over this rank's batch.  Default: network(k) on the main stream,
+        then ICC(k) + pose all-gather on a second stream behind an event recorded after
+        network(k); the next call's network(k+1) does not wait for ICC(k).  ``timing=True``
+        (stage breakdown, un-timed) and ``--no-overlap`` run the stages back to back."""
         self._timing = timing
         overlap = not (timing or self.args.no_overlap)
         self._mark("start")
         if overlap:
             main = torch.cuda.current_stream()
-            self.icc_stream.wait_stream(main)
-            with torch.cuda.stream(self.icc_stream):
-                self._refine()
-            if self.net_stream is not None:
-                self.net_stream.wait_stream(main)
-                with torch.cuda.stream(self.net_stream):
-                    pred = self._network()
-                main.wait_stream(self.net_stream)
-            else:
+            net = self.net_stream if self.net_stream is not None else main
+            if net is not main:
+                net.wait_stream(main)
+            with torch.cuda.stream(net):
                 pred = self._network()
-            main.wait_stream(self.icc_stream)
-        else:
-            pred = self._network()
-            self._mark("predict")
-            self._refine()
-            self._mark("icc")
+                done = torch.cuda.Event()
+                done.record(net)
+            pred.record_stream(self.icc_stream)
+            with torch.cuda.stream(self.icc_stream):
+                self.icc_stream.wait_event(done)  # ICC(k) after network(k) ...
+                self._refine(pred)                # ... beside network(k+1) of the next call
+                poses = torch.cat([self.q, self.t], dim=1)
+                out = parallel.all_gather_poses_equal(poses, out=self.gathered if self.world > 1 else None)
+            return out, pred
+        pred = self._network()
+        self._mark("predict")
+        self._refine(pred)
+        self._mark("icc")
         poses = torch.cat([self.q, self.t], dim=1)
         out = parallel.all_gather_poses_equal(poses, out=self.gathered if self.world > 1 else None)
         self._mark("gather")
@@ -235,40 +241,86 @@ def roofline_voxelize(wl):
                 shape=dict(B=B, P=P, C=C, D=D))
 
 
-def roofline_icc_tdf(wl):
-    """k_icc_tdf -- the hand-written kernel with the largest share of the step (100 launches
-    per refinement).  Algorithmic HBM bytes per launch (forward half): every
-    grid reads its source points once, 16 B each (own: sum P_i; other: (N-1) sum P per
-    scene) and stores its 32^3 winners, 8 B each.  The working set is L2/MALL resident and
-    the kernel is bound by dependent-load latency and LDS atomics, not by HBM bandwidth --
-    the fraction below is what the contract asks for, not a claim that HBM is the limiter."""
+def _icc_algorithmic_bytes(icc):
+    """SURVEY.md 8d, ICC: per iteration and scene of N objects, forward reads
+    sum_i (P_i + sum_{j != i} P_j) * 16 B (points + sdf, own + others) + N * 2 * D^3 * 4 B
+    (target and no-entry grids), no grid bytes written (winners are an implementation buffer);
+    the backward re-reads the same.  Returns (point bytes, grid bytes) of one forward."""
+    so = icc.scene_off_host
+    off = icc.obj_off.cpu().tolist()
+    pairs = 0
+    for s in range(icc.n_scenes):
+        pairs += (so[s + 1] - so[s]) * (off[so[s + 1]] - off[so[s]])
+    return pairs * 16, icc.n_objects * 2 * icc.dim ** 3 * 4
+
+
+def roofline_icc(wl, us_per_iter):
+    """k_icc_tile -- the hand-written kernel with the largest share of the step (100 launches per
+    refinement), timed live with HIP events through mf_icc_launch_stage on torch's current stream.
+    Its algorithmic HBM bytes per launch (8d, forward half of the TDF): every grid reads its source
+    points once, 16 B each.  ``iteration`` is the same accounting for one whole ICC iteration
+    (bin + tile + accum incl. the folded optimiser step): forward + backward re-read, 8d's
+    12.4 MB per 8-object scene.  The working set is L2/MALL resident and the kernels are bound by
+    dependent-load latency and instruction issue, not by HBM bandwidth -- the fractions below are
+    what the contract asks for, not a claim that HBM is the limiter."""
     import ctypes
     icc = wl.icc
     lib = mf._lib.lib()
     stream = mf._lib.stream_ptr()
-    lib.mf_icc_launch_tdf(ctypes.byref(icc.desc), wl.q0.data_ptr(), wl.t0.data_ptr(),
-                          icc.ws.data_ptr(), stream)
-    ms = time_kernel_live(lambda: lib.mf_icc_launch_tdf(ctypes.byref(icc.desc), None, None,
-                                                        icc.ws.data_ptr(), stream), 200)
-    so = icc.scene_off_host
-    off = icc.obj_off.cpu().tolist()
-    pts = 0
-    for s in range(icc.n_scenes):
-        n_s = so[s + 1] - so[s]
-        pts += n_s * (off[so[s + 1]] - off[so[s]])
-    alg = pts * 16 + 2 * icc.n_objects * icc.dim ** 3 * 8
-    achieved = alg / (ms * 1e-3) / 1e9
+    mf._lib.check(lib.mf_icc_launch_stage(ctypes.byref(icc.desc), wl.q0.data_ptr(), wl.t0.data_ptr(),
+                                          icc.ws.data_ptr(), 0, stream), "mf_icc_launch_stage")
+    ms = time_kernel_live(lambda: lib.mf_icc_launch_stage(ctypes.byref(icc.desc), None, None,
+                                                          icc.ws.data_ptr(), 1, stream), 200)
+    pts_bytes, grid_bytes = _icc_algorithmic_bytes(icc)
+    achieved = pts_bytes / (ms * 1e-3) / 1e9
     traffic = None  # PMC passes committed under profiles/ (tools/prof_icc_pmc.sh), same scene
-    pmc = os.path.join(ROOT, "profiles", "r01_icc_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_icc_pmc.json")
     if os.path.exists(pmc):
-        rec = json.load(open(pmc))["k_icc_tdf"]
-        if rec["n_objects"] == icc.n_objects and rec["n_points"] == icc.n_points:
+        rec = json.load(open(pmc)).get("k_icc_tile")
+        if rec and rec["n_objects"] == icc.n_objects and rec["n_points"] == icc.n_points:
             traffic = rec["traffic_bytes"]
-    return dict(kernel="k_icc_tdf (mf_icc_refine, launch 1 of 3 per ICC iteration)", bound="hbm",
+    it_bytes = 2 * (pts_bytes + grid_bytes)
+    it_achieved = it_bytes / (us_per_iter * 1e-6) / 1e9
+    return dict(kernel="k_icc_tile (launch 2 of 3 per ICC iteration; mf_icc_refine)", bound="hbm",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                algorithmic_bytes_per_launch=alg, avg_launch_ms=round(ms, 5),
-                note="L2-resident working set; latency/LDS-atomic bound (DESIGN.md 4)")
+                algorithmic_bytes_per_launch=pts_bytes, avg_launch_ms=round(ms, 5),
+                iteration=dict(kernels="k_icc_bin (+ folded optimiser step) + k_icc_tile + k_icc_accum",
+                               algorithmic_bytes=it_bytes, us=round(us_per_iter, 3),
+                               achieved=round(it_achieved, 1), frac=round(it_achieved / HBM_PEAK_GBS, 4)),
+                note="L2-resident working set; latency / instruction-issue bound (DESIGN.md 4)")
+
+
+def handwritten_path(wl, reps=10):
+    """Stage times (ms) of the hand-written volumetric path alone: Model._pose_from_features
+    (voxelize, occupancy convs, sparse conv3, conv4, trilinear sampling, heads) on the features
+    one predict() hands it, and the ICC refinement; the stock 2-D backbone is excluded."""
+    m = wl.model
+    inp = wl.inputs
+    with torch.no_grad():
+        mask = ~torch.isnan(inp["pcd"]).any(dim=3)
+        pix = m._select_points(mask)
+        values, points = m._backbone_features(inp["rgb"], inp["pcd"], pix)
+        args = (torch.as_tensor(inp["class_id"], device=wl.device), values, points, inp["pitch"].float(),
+                inp["origin"].float(), inp["grid_nontarget_empty"])
+        t_vol = time_kernel_live(lambda: m._pose_from_features(*args), reps)
+        t_icc = time_kernel_live(wl._refine, reps)
+    return t_vol, t_icc
+
+
+def latency_batch1(wl, reps=20):
+    """BASELINE configs[1]: singleview_3d inference at batch = 1 -- latency of one
+    Model.predict call (ms, incl. its one host synchronisation for the point counts)."""
+    one = {k: v[:1].contiguous() for k, v in wl.inputs.items()}
+    with torch.no_grad():
+        for _ in range(3):
+            wl.model.predict(**one)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            wl.model.predict(**one)
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
 
 
 def accuracy(wl):
@@ -417,11 +469,13 @@ def main():
                             f"3D-CNN, heads; B={wl.B}) -> ICC joint refine {args.icc_iters} iters "
                             "(BASELINE configs[1]+configs[2]); random weights, ICC starts from "
                             "synthetic perturbed-GT poses"
-                            + ("" if args.no_overlap else "; ICC on a second HIP stream beside the network pass"),
+                            + ("" if args.no_overlap else "; ICC(k) on a second HIP stream, event-ordered "
+                               "after network(k), beside network(k+1)"),
                 "objects_per_gpu": wl.B, "icc_iters": args.icc_iters,
                 "parallelism": f"scene-sharded x{world}, pose all_gather",
                 "streams": "1 (serial)" if args.no_overlap else
-                           "2 (ICC refinement overlaps the network pass; stage_ms are the serial stage times)",
+                           "2 (pipelined: ICC(k) waits on network(k)'s event and overlaps network(k+1); "
+                           "stage_ms are the serial stage times)",
                 "stream_priority": args.priority, "backbone_memory_format":
                     "channels_last" if args.channels_last else "contiguous",
             },
@@ -430,7 +484,11 @@ def main():
             # the same step with the two stages back to back on one stream (no pipelining credit)
             "value_serial": round(world * wl.B / (sum(stages.values()) / 1e3), 3) if stages else None,
         }
-        out["roofline"] = roofline_icc_tdf(wl)
+        t_vol, t_icc = handwritten_path(wl)
+        out["value_handwritten_path"] = round(world * wl.B / ((t_vol + t_icc) / 1e3), 3)
+        out["handwritten_path_ms"] = {"volumetric_network_part": round(t_vol, 4), "icc": round(t_icc, 4)}
+        out["latency_batch1_ms"] = {"predict": round(latency_batch1(wl), 4)}
+        out["roofline"] = roofline_icc(wl, t_icc * 1e3 / args.icc_iters)  # all scenes share the launches
         out["roofline_voxelize"] = roofline_voxelize(wl)
         out["accuracy"] = accuracy(wl)
         if world == 1 and not args.no_cpu_baseline:

@@ -858,7 +858,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   // like its own moments.  (Round 1 / early round 2 pushed every colliding voxel through 36
   // fixed-point LDS atomics behind float64 conversions: ~600 instructions per colliding voxel,
   // 3-5 us in the crowded blocks.)
-  __shared__ float s_rows2[2][kAccThreads / 16][12 + 1];
+  MF_DYN_LDS(float, s_rows2);   // [max_ns][kAccThreads / 16][12 + 1] row sums per other object
   __shared__ uint32_t s_emask;  // scene objects some voxel of this block collides with
   __shared__ float s_Rt[kMaxSceneObjects][12];
   __shared__ int s_off[kMaxSceneObjects + 1];
@@ -1028,30 +1028,33 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
     }
   }
   stamp(3);
-  // collision moments, one other object at a time (block-uniform loop over the set bits)
+  // collision moments: row sums of every other object this block collides with (block-uniform
+  // loop over the set bits, no barrier inside), ONE barrier, then 12 lanes per object add the
+  // rows in order
   long long *po = a.acc_oth + ((int64_t)par * a.O + o) * a.max_ns * 12;
-  uint32_t em = s_emask;  // complete: every atomicOr precedes the barrier above
-  int buf = 0;
-  while (em != 0u) {
+  const uint32_t em0 = s_emask;  // complete: every atomicOr precedes the barrier above
+  constexpr int kRows = kAccThreads / 16;
+  for (uint32_t em = em0; em != 0u; em &= em - 1u) {
     const int e = __ffs((int)em) - 1;
-    em &= em - 1u;
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
       float v = 0.0f;
 #pragma unroll
       for (int it = 0; it < kVPT; ++it) v += ecol[it] == e ? cv[it][c] : 0.0f;
       const float r = mf::row16_sum(v);
-      if ((threadIdx.x & 15) == 0) s_rows2[buf][threadIdx.x >> 4][c] = r;
+      if ((threadIdx.x & 15) == 0) s_rows2[(e * kRows + (threadIdx.x >> 4)) * 13 + c] = r;
     }
-    __syncthreads();  // two buffers: the next object's writes cannot overtake these reads
-    if (threadIdx.x < 12) {
-      float sacc = 0.0f;
+  }
+  if (em0 == 0u) return;  // block-uniform
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) {
+    const int e = i / 12, c = i - 12 * e;
+    if (!((em0 >> e) & 1u)) continue;
+    float sacc = 0.0f;
 #pragma unroll
-      for (int r = 0; r < kAccThreads / 16; ++r) sacc += s_rows2[buf][r][threadIdx.x];
-      const long long x = isfinite(sacc) ? __double2ll_rn((double)sacc * kFixOth) : 0;
-      if (x != 0) atomicAdd(reinterpret_cast<unsigned long long *>(po + 12 * e + threadIdx.x), (unsigned long long)x);
-    }
-    buf ^= 1;
+    for (int r = 0; r < kRows; ++r) sacc += s_rows2[(e * kRows + r) * 13 + c];
+    const long long x = isfinite(sacc) ? __double2ll_rn((double)sacc * kFixOth) : 0;
+    if (x != 0) atomicAdd(reinterpret_cast<unsigned long long *>(po + i), (unsigned long long)x);
   }
 }
 
@@ -1195,7 +1198,8 @@ void launch_front(const IccArgs &a, const IccStepArgs &sp, hipStream_t stream) {
 }
 
 void launch_accum(const IccArgs &a, int NB, int par, hipStream_t stream) {
-  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), 0, stream, a, par);
+  const size_t lds = (size_t)a.max_ns * (kAccThreads / 16) * 13 * sizeof(float);  // <= 53 KB
+  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), lds, stream, a, par);
 }
 
 // chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once

@@ -9,7 +9,7 @@ loss, gq, gt = wl.icc.loss_grad(wl.q0, wl.t0)   # one iteration (eager launches)
 torch.cuda.synchronize()
 buf = np.zeros(4096 * 8, np.uint64)
 mf._lib.lib().mf_icc_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
-st = buf.reshape(4096, 8)[:512].astype(np.int64)
+st = buf.reshape(4096, 8)[:1024].astype(np.int64)
 t0 = st[:, 0].min()
 d = lambda a, b: (st[:, b] - st[:, a]) / 100.0   # wall_clock64 = 100 MHz -> us
 print("tile WGs", (st[:, 0] > 0).sum())
@@ -19,7 +19,7 @@ print("tile start skew (us): max", (st[:, 0] - t0).max() / 100.0, " end max", (s
 ns = st[:, 6]
 print("records per tile: max", ns.max(), "mean", ns.mean())
 worst = np.argsort(-d(0, 4))[:6]
-for w in worst: print("wg", w, "grid", w // 32, "plane", w % 32, "T", ns[w], "load", d(0,1)[w], "p1", d(1,2)[w], "p2", d(2,3)[w], "epi", d(3,4)[w])
+for w in worst: print("wg", w, "grid", w // 64, "plane", (w % 64) // 2, "half", w % 2, "T", ns[w], "load", d(0,1)[w], "p1", d(1,2)[w], "p2", d(2,3)[w], "epi", d(3,4)[w])
 sb = buf.reshape(4096, 8)[3072:3072+512].astype(np.int64)
 live = sb[:, 3] > 0
 db = lambda a, b: (sb[live, b] - sb[live, a]) / 100.0
