@@ -239,6 +239,24 @@ int mf_sparse_conv3d_k4s2_fwd(const float *x, const int32_t *counts, const float
                               int32_t B, int32_t Cs, int32_t Cout, int32_t D, int32_t max_rows,
                               int32_t relu, mfStream_t stream);
 
+/* ---- A12 functions.average_distance (ADD / ADD-S pose loss), batched ----------------
+ * replaces the transform_points x2 + geometry.nn + gather + sub/square/sum/sqrt/mean composite
+ *   morefusion/functions/loss/average_distance.py:64-85
+ * and the per-object Python loop around it, contrib/singleview_3d/models/model.py:406-434.
+ *   points [B,M,3] model points, T_true [B,4,4], T_pred [B,P,4,4] row-major, symmetric [B]
+ *   uint8 (NULL = none): 0 -> ADD, else ADD-S (nearest true point, lowest index among equal
+ *   squared distances).  out [B,P] = mean_m || true'_m - pred_m ||.
+ *   nn_idx [B,P,M] int32 (may be NULL): arg-min indices of the ADD-S rows, written by _fwd and
+ *   read by _bwd (NULL: _bwd searches again).
+ * _bwd: gT_pred [B,P,4,4] = d(sum gout * out) / d T_pred (rows 0..2; row 3 = 0).  The true
+ * pose and the model points receive no gradient (they are data in the reference's callers). */
+int mf_average_distance_fwd(const float *points, const float *T_true, const float *T_pred,
+                            const uint8_t *symmetric, int32_t B, int32_t M, int32_t P,
+                            float *out, int32_t *nn_idx, mfStream_t stream);
+int mf_average_distance_bwd(const float *points, const float *T_true, const float *T_pred,
+                            const uint8_t *symmetric, const float *gout, int32_t B, int32_t M,
+                            int32_t P, const int32_t *nn_idx, float *gT_pred, mfStream_t stream);
+
 /* small fused helpers of the same path */
 /* pack [Ptot,3] points + [Ptot] sdf into float4 */
 int mf_pack_points_sdf(const float *points, const float *sdf, int64_t n, void *pts4,

@@ -289,19 +289,32 @@ class Model(nn.Module):
 
     def loss(self, *, class_id, quaternion_true, translation_true, quaternion_pred,
              translation_pred, confidence_pred):
-        B = quaternion_pred.shape[0]
+        """DenseFusion pose loss (model.py:377-434): per object mean over the confident points
+        of ``ADD(-S) * conf - lambda * log(conf)``, averaged over the batch.  All B objects go
+        through ONE fused ADD / ADD-S kernel (functions.average_distance_batch) instead of the
+        reference's per-object loop of transform / nn / gather launches."""
+        B, P = quaternion_pred.shape[0], quaternion_pred.shape[1]
         dev = quaternion_pred.device
-        loss = 0
-        for i, cid in enumerate(torch.as_tensor(class_id).tolist()):
-            T_pred = functions_module.transformation_matrix(quaternion_pred[i], translation_pred[i])
-            T_true = functions_module.transformation_matrix(
-                quaternion_true[i].float(), translation_true[i].float())
+        cids = [int(c) for c in torch.as_tensor(class_id).tolist()]
+        T_pred = functions_module.transformation_matrix(
+            quaternion_pred.reshape(B * P, 4), translation_pred.reshape(B * P, 3)).reshape(B, P, 4, 4)
+        T_true = functions_module.transformation_matrix(quaternion_true.float(), translation_true.float())
+        cads = []
+        for cid in cids:  # model.py:411-414: 500 random CAD points per object (host RNG, like the reference)
             cad_pcd = self._models.get_pcd(cid)
-            cad_pcd = cad_pcd[np.random.permutation(cad_pcd.shape[0])[:500]]
-            cad_pcd = torch.as_tensor(cad_pcd, dtype=torch.float32, device=dev)
-            is_symmetric = cid in CLASS_IDS_SYMMETRIC and self._loss != "add"
-            add = functions_module.average_distance(cad_pcd, T_true, T_pred, symmetric=is_symmetric)
-            keep = confidence_pred[i].detach() > 0
-            conf = confidence_pred[i][keep]
-            loss = loss + (add[keep] * conf - self._lambda_confidence * torch.log(conf)).mean()
-        return loss / B
+            cads.append(np.asarray(cad_pcd[np.random.permutation(cad_pcd.shape[0])[:500]], dtype=np.float32))
+        symmetric = [cid in CLASS_IDS_SYMMETRIC and self._loss != "add" for cid in cids]
+        if len({c.shape[0] for c in cads}) == 1:
+            cad = torch.as_tensor(np.stack(cads), device=dev)
+            sym = torch.tensor(symmetric, dtype=torch.bool, device=dev) if any(symmetric) else None
+            add = functions_module.average_distance_batch(cad, T_true, T_pred, sym)  # [B,P]
+        else:  # CAD clouds of different sizes (< 500 points): one call per object
+            add = torch.stack([functions_module.average_distance(
+                torch.as_tensor(cads[i], device=dev), T_true[i], T_pred[i], symmetric=symmetric[i])
+                for i in range(B)])
+        keep = confidence_pred.detach() > 0
+        conf = torch.where(keep, confidence_pred, torch.ones_like(confidence_pred))
+        per_point = torch.where(keep, add * conf - self._lambda_confidence * torch.log(conf),
+                                torch.zeros_like(add))
+        per_object = per_point.sum(dim=1) / keep.sum(dim=1)  # an object without a confident point -> nan, as .mean() of nothing
+        return per_object.sum() / B

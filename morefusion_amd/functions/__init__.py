@@ -14,3 +14,4 @@ from .geometry import translation_matrix
 from .geometry import truncated_distance_function
 
 from .loss import average_distance
+from .loss import average_distance_batch  # the same op over B objects (one fused launch)

@@ -1,2 +1,2 @@
 # flake8: noqa
-from .average_distance import average_distance
+from .average_distance import average_distance, average_distance_batch  # noqa: F401

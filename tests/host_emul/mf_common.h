@@ -37,12 +37,14 @@ struct dim3 {
   dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
 };
 struct float2 { float x, y; };
+struct float3 { float x, y, z; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(16) int4 { int x, y, z, w; };
 struct alignas(8) int2 { int x, y; };
 struct alignas(8) uint2 { unsigned x, y; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 inline float2 make_float2(float x, float y) { return {x, y}; }
+inline float3 make_float3(float x, float y, float z) { return {x, y, z}; }
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
 inline int2 make_int2(int x, int y) { return {x, y}; }

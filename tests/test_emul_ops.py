@@ -1,0 +1,95 @@
+"""Kernel SOURCES other than the ICC compiled for the host behind tests/host_emul (fiber emulator)
+and checked against the oracle without a GPU: the fused ADD / ADD-S loss (csrc/loss.hip) and
+interpolate_voxel_grid with per-item row ranges (csrc/interp.hip)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_emul"))
+import emul  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not emul.available(), reason="g++ not available")
+_p, _i32 = ctypes.c_void_p, ctypes.c_int32
+
+
+def _pose(rs):
+    from morefusion_amd.synthetic import random_rotation
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = random_rotation(rs, 1.0)
+    T[:3, 3] = rs.uniform(-0.05, 0.05, 3)
+    return T
+
+
+def test_add_loss_kernel_source_vs_oracle():
+    lib = emul.build(["loss.hip"])
+    lib.mf_average_distance_fwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]
+    lib.mf_average_distance_bwd.argtypes = [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]
+    rs = np.random.RandomState(0)
+    B, M, P = 3, 300, 5
+    pts = rs.uniform(-0.05, 0.05, (B, M, 3)).astype(np.float32)
+    Tt = np.stack([_pose(rs) for _ in range(B)])
+    Tp = np.stack([[(_pose(rs) @ np.eye(4)).astype(np.float32) for _ in range(P)] for _ in range(B)])
+    for b in range(B):  # predictions near the truth: ADD-S then really picks other points
+        for p in range(P):
+            Tp[b, p] = Tt[b]
+            Tp[b, p, :3, 3] += rs.uniform(-0.01, 0.01, 3).astype(np.float32)
+    sym = np.array([0, 1, 1], np.uint8)
+    out = np.zeros((B, P), np.float32)
+    idx = np.zeros((B, P, M), np.int32)
+    assert lib.mf_average_distance_fwd(pts.ctypes.data, Tt.ctypes.data, Tp.ctypes.data, sym.ctypes.data, B, M, P,
+                                       out.ctypes.data, idx.ctypes.data, None) == 0
+    for b in range(B):
+        ref = O.average_distance(pts[b], Tt[b], Tp[b], symmetric=bool(sym[b]))
+        np.testing.assert_allclose(out[b], ref, rtol=2e-6, atol=1e-8)
+    # backward: against central differences of the forward (float64 restatement of the same formula)
+    gout = rs.uniform(0.5, 1.5, (B, P)).astype(np.float32)
+    for use_idx in (True, False):
+        gT = np.full((B, P, 4, 4), 7.0, np.float32)
+        assert lib.mf_average_distance_bwd(pts.ctypes.data, Tt.ctypes.data, Tp.ctypes.data, sym.ctypes.data,
+                                           gout.ctypes.data, B, M, P, idx.ctypes.data if use_idx else None,
+                                           gT.ctypes.data, None) == 0
+        assert (gT[:, :, 3] == 0).all()
+        for b, p in ((0, 1), (1, 0), (2, 4)):
+            num = np.zeros((3, 4))
+            for i in range(3):
+                for j in range(4):
+                    vals = []
+                    for sgn in (+1, -1):
+                        T = Tp[b, p].astype(np.float64).copy()
+                        T[i, j] += sgn * 1e-6
+                        true = pts[b].astype(np.float64) @ Tt[b, :3, :3].T.astype(np.float64) + Tt[b, :3, 3]
+                        pred = pts[b].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+                        tr = true[idx[b, p]] if sym[b] else true  # arg-min frozen, like the reference
+                        vals.append(np.linalg.norm(tr - pred, axis=1).mean())
+                    num[i, j] = (vals[0] - vals[1]) / 2e-6 * gout[b, p]
+            np.testing.assert_allclose(gT[b, p, :3], num, rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("channels_first", [0, 1])
+def test_interpolate_kernel_source_row_ranges_vs_oracle(channels_first):
+    lib = emul.build(["interp.hip"])
+    lib.mf_interpolate_voxel_grid_fwd.argtypes = [_p, _p, _p, _p, ctypes.c_int64] + [ctypes.c_int] * 5 + [_p, ctypes.c_int, _p]
+    rs = np.random.RandomState(1)
+    B, C, X = 3, 6, 8
+    counts = [120, 0, 77]
+    orphan = 9
+    n = sum(counts) + orphan
+    bi = np.concatenate([np.full(c, b, np.int32) for b, c in enumerate(counts)] + [np.full(orphan, -2, np.int32)])
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    vox = rs.uniform(-1, 1, (B, C, X, X, X)).astype(np.float32)
+    pts = (rs.uniform(-0.15, 1.1, (n, 3)) * X).astype(np.float32)
+    valid = bi >= 0
+    ref = O.interpolate_voxel_grid(vox, pts[valid], bi[valid], mode="gpu")
+    for bs in (None, start):
+        out = np.full((C, n) if channels_first else (n, C), 5.0, np.float32)
+        assert lib.mf_interpolate_voxel_grid_fwd(vox.ctypes.data, pts.ctypes.data, bi.ctypes.data,
+                                                 None if bs is None else bs.ctypes.data, n, B, C, X, X, X,
+                                                 out.ctypes.data, channels_first, None) == 0
+        got = out.T if channels_first else out
+        np.testing.assert_array_equal(got[valid], ref)
+        np.testing.assert_array_equal(got[~valid], 0.0)
