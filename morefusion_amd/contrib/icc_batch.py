@@ -77,7 +77,12 @@ class IccScenes:
         if nbytes < 0:
             raise ValueError("mf_icc: invalid batch descriptor (objects per scene <= 32, dim <= 64)")
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        _lib.check(L.mf_icc_prepare(ctypes.byref(self.desc), self.ws.data_ptr(), _lib.stream_ptr()),
+        self.prepare()
+
+    def prepare(self):
+        """(Re-)derive what depends on the point / grid arrays: bounding spheres, sum(grid_target),
+        tables.  Call again after updating ``pts4`` / ``grid_target`` / ``pitch`` / ``origin`` in place."""
+        _lib.check(_lib.lib().mf_icc_prepare(ctypes.byref(self.desc), self.ws.data_ptr(), _lib.stream_ptr()),
                    "mf_icc_prepare")
 
     def loss_grad(self, q, t):

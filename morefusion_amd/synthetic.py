@@ -216,6 +216,68 @@ def make_singleview_batch(batch_size=1, seed=0, image_size=256, dim=32):
     )
 
 
+def make_singleview_examples(n_examples=1, seed=0, image_size=256, dim=32):
+    """Raw per-object example dicts in the dataset's schema (SURVEY A0:
+    datasets/rgbd_pose_estimation/base.py:164-175 plus the ``*_full`` grids of the training
+    set): class_id i32, rgb u8 [H,W,3], pcd f64 [H,W,3] (NaN outside the mask -- the dataset
+    hands out float64, ``Transform`` casts), quaternion_true / translation_true f64, pitch,
+    origin f64, grid_target / grid_nontarget / grid_empty f32 OctoMap PROBABILITIES in [0,1],
+    grid_target_full {0,1}, grid_nontarget_full i32 instance ids.
+    ``transform_example`` (examples/ycb_video/singleview_3d/train.py:27-140) turns one into the
+    network's inputs."""
+    batch = make_singleview_batch(n_examples, seed=seed, image_size=image_size, dim=dim)
+    rs = np.random.RandomState(seed + 7919)
+    zz = np.stack(np.mgrid[0:dim, 0:dim, 0:dim], -1) - (dim / 2 - 0.5)
+    r = np.linalg.norm(zz, axis=-1)
+    examples = []
+    for b in range(n_examples):
+        noise = lambda lo, hi: rs.uniform(lo, hi, (dim,) * 3).astype(np.float32)  # noqa: E731
+        full = r < 0.30 * dim                                # the whole object
+        seen = full & (zz[..., 2] < 0)                       # its camera-facing half, as fused so far
+        other = (np.linalg.norm(zz - np.array([0.55 * dim, 0, 0]), axis=-1) < 0.25 * dim)
+        other2 = (np.linalg.norm(zz + np.array([0, 0.6 * dim, 0]), axis=-1) < 0.2 * dim)
+        ne = batch["grid_nontarget_empty"][b]
+        ids = np.zeros((dim,) * 3, np.int32)
+        ids[other] = 4
+        ids[other2 & ~other] = 9
+        examples.append(dict(
+            class_id=np.int32(batch["class_id"][b]), rgb=batch["rgb"][b],
+            pcd=batch["pcd"][b].astype(np.float64),
+            quaternion_true=batch["quaternion_true"][b].astype(np.float64),
+            translation_true=batch["translation_true"][b].astype(np.float64),
+            pitch=np.float64(batch["pitch"][b]), origin=batch["origin"][b].astype(np.float64),
+            grid_target=np.where(seen, noise(0.55, 0.97), noise(0.0, 0.45)),
+            # (the mapping's non-target / empty grids are > 0.5 on the target's own voxels too:
+            #  Transform removes them again with ``^ grid_target``, train.py:50-54)
+            grid_nontarget=np.where((other & ~full) | seen, noise(0.6, 0.95), noise(0.0, 0.4)),
+            grid_empty=np.where((ne & ~full & ~other) | seen, noise(0.55, 0.99), noise(0.0, 0.45)),
+            grid_target_full=full.astype(np.uint8), grid_nontarget_full=ids))
+    return examples
+
+
+def transform_example(example, train=False, with_occupancy=True, random_state=None):
+    """The reference's per-example ``Transform`` (train.py:27-140): dtype casts and the boolean
+    grid algebra (data_formats.grids_for_network) -> the keys ``Model.predict`` / ``forward`` take."""
+    from .data_formats import grids_for_network
+
+    d = dict(example)
+    assert d["class_id"].dtype == np.int32 and d["rgb"].dtype == np.uint8
+    for k in ("pcd", "quaternion_true", "translation_true"):
+        d[k] = np.asarray(d[k], np.float32)
+    raw = {k: d.pop(k) for k in ("grid_target", "grid_nontarget", "grid_empty", "grid_target_full",
+                                 "grid_nontarget_full")}
+    if not with_occupancy:
+        d.pop("pitch")
+        d.pop("origin")
+        return d
+    d["origin"] = np.asarray(d["origin"], np.float32)
+    d["pitch"] = np.asarray(d["pitch"], np.float32)
+    d["grid_target"], d["grid_nontarget_empty"] = grids_for_network(
+        raw["grid_target"], raw["grid_nontarget"], raw["grid_empty"], raw["grid_target_full"],
+        raw["grid_nontarget_full"], train=train, random_state=random_state)
+    return d
+
+
 def make_rgbd_frame(seed=0, height=480, width=640):
     """A synthetic RGB-D frame + instance image for the pre-processing row: several instances
     whose bounding boxes exercise every branch of the crop/centerize geometry (wide, tall,

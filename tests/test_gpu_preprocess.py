@@ -81,3 +81,58 @@ def test_frame_to_poses_end_to_end():
     # cached choice), so this is a float32-convolution tolerance, not bit equality.
     for a, b in ((q, q2), (t, t2), (c, c2)):
         torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3)
+
+
+def test_wire_format_grids_decode_on_device_and_feed_icc(fixtures3):
+    """the three recorded instances as the ROS pipeline ships them -- sparse
+    VoxelGrid.msg (flat indices + values), decoded ON THE DEVICE (data_formats.decode_voxel_grid)
+    -- go straight into the ICC refinement; same loss / gradients as the dense fixtures, and the
+    oracle's."""
+    from morefusion_amd import data_formats as DF
+    from oracle import oracle_c as OC
+    sc = mf.synthetic.make_icc_scene(3, seed=0, fixtures=fixtures3)
+    grids = {}
+    for key in ("grid_target", "grid_nontarget_empty"):
+        dec = []
+        for g in sc[key]:
+            idx, val, dims = DF.encode_voxel_grid(g)            # what the mapping node publishes
+            d = DF.decode_voxel_grid(idx.cuda(), val.cuda(), dims)  # collision_based_pose_refinement.py:86-98
+            assert d.is_cuda and d.shape == (32, 32, 32)
+            np.testing.assert_array_equal(d.cpu().numpy(), g)
+            dec.append(d)
+        grids[key] = torch.stack(dec)
+    dev = lambda x: torch.as_tensor(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    link = mf.contrib.IterativeCollisionCheckLink(sc["transform_init"], sdf_offset=0.02).to_gpu()
+    loss = link([dev(p) for p in sc["points"]], [dev(s) for s in sc["sdf"]], dev(sc["pitch"]), dev(sc["origin"]),
+                grids["grid_target"], grids["grid_nontarget_empty"])
+    loss.backward()
+    q0, t0 = link.quaternion.detach().cpu().numpy(), link.translation.detach().cpu().numpy()
+    l_o, gq_o, gt_o, _ = OC.icc_loss_grad(sc["points"], sc["sdf"], sc["pitch"], sc["origin"], sc["grid_target"],
+                                          sc["grid_nontarget_empty"], q0, t0, sdf_offset=0.02)
+    np.testing.assert_allclose(float(loss.detach()), l_o, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(link.quaternion.grad.cpu().numpy(), gq_o, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(link.translation.grad.cpu().numpy(), gt_o, rtol=2e-3, atol=2e-4)
+
+
+def test_raw_examples_through_transform_into_predict():
+    """dataset-schema examples -> Transform -> concat_examples -> to_gpu ->
+    Model.predict with the caller's keyword interface (demo.py:80-100); same poses as feeding the
+    pre-transformed batch."""
+    from morefusion_amd.chainer_compat import cuda, dataset
+    from morefusion_amd.contrib.singleview_3d.models import Model
+    torch.manual_seed(0)
+    model = Model(n_fg_class=21, with_occupancy=True).cuda().eval()
+    examples = [mf.synthetic.transform_example(e) for e in mf.synthetic.make_singleview_examples(2, seed=5)]
+    batch = dataset.concat_examples(examples)
+    inputs = {k: cuda.to_gpu(batch[k]) for k in ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty")}
+    with torch.no_grad():
+        model.predict(**inputs)
+        q, t, c = model.predict(**inputs)
+    assert q.shape == (2, 1000, 4) and torch.isfinite(q).all() and torch.isfinite(t).all()
+    idx = c.argmax(dim=1)
+    pose = torch.cat([q[torch.arange(2), idx], t[torch.arange(2), idx]], 1)
+    assert pose.shape == (2, 7)
+    # the no-entry grid matters: a different grid changes the prediction
+    with torch.no_grad():
+        q2, _, _ = model.predict(**{**inputs, "grid_nontarget_empty": torch.zeros_like(inputs["grid_nontarget_empty"])})
+    assert float((q2 - q).abs().max()) > 0

@@ -1,6 +1,8 @@
 """Host-side logic of the path on CPU: rigid-transform ops (device-agnostic torch),
 chainer-style Adam, quaternion_from_matrix, metrics, pre-processing helpers, synthetic
 inputs, point selection of Model.predict, shard arithmetic."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -225,6 +227,24 @@ def test_grid_algebra_eval_and_train_cases():
     np.testing.assert_array_equal(n4, nte)  # evaluation ignores the *_full grids
 
 
+def test_chainer_key_convention_matches_the_reference_link_tree():
+    """tests/golden/ref_chainer_param_paths.json lists every parameter path + shape of the
+    reference network, obtained by EXECUTING its link definitions (oracle/gen_golden_params.py:
+    models/dense_fusion/resnet.py, pspnet.py, contrib/singleview_3d/models/model.py:48-91).
+    serializers.chainer_key must map the torch model onto exactly that set."""
+    import json
+    from morefusion_amd import serializers as S
+    from morefusion_amd.contrib.singleview_3d.models import Model
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_chainer_param_paths.json")))["params"]
+    model = Model(n_fg_class=21, with_occupancy=True)
+    mine = {}
+    for name, key, tensor in S._entries(model):
+        mine[key] = [] if name.endswith("prelu.weight") else list(tensor.shape)  # PReLU slope: shape ()
+    assert set(mine) == set(ref), (sorted(set(mine) - set(ref)), sorted(set(ref) - set(mine)))
+    assert mine == ref
+    assert len(ref) == 77
+
+
 def test_chainer_npz_roundtrip_and_key_convention(tmp_path):
     from morefusion_amd import serializers as S
     from morefusion_amd.contrib.singleview_3d.models import Model
@@ -355,3 +375,36 @@ def test_predict_host_logic_decoder_modes_agree(monkeypatch):
     for other in outs[1:]:
         for a, b_ in zip(other, outs[0]):
             np.testing.assert_allclose(a.numpy(), b_.numpy(), rtol=0, atol=5e-6)
+
+
+def test_raw_example_schema_and_transform():
+    """raw dataset-schema examples (probability grids, *_full grids) -> the reference's
+    Transform (train.py:27-140) -> concat_examples -> exactly the keys / dtypes the caller passes
+    to Model.predict (demo.py:80-93); the training variant draws its grid case from the RNG."""
+    from morefusion_amd import synthetic
+    from morefusion_amd.chainer_compat import dataset
+    ex = synthetic.make_singleview_examples(2, seed=3)
+    assert sorted(ex[0]) == ["class_id", "grid_empty", "grid_nontarget", "grid_nontarget_full", "grid_target",
+                             "grid_target_full", "origin", "pcd", "pitch", "quaternion_true", "rgb",
+                             "translation_true"]
+    for k in ("grid_target", "grid_nontarget", "grid_empty"):
+        g = ex[0][k]
+        assert g.dtype == np.float32 and g.shape == (32, 32, 32) and 0 <= g.min() and g.max() <= 1
+        assert 0.01 < (g > 0.5).mean() < 0.9  # probabilities, on both sides of the 0.5 threshold
+    assert set(np.unique(ex[0]["grid_target_full"])) == {0, 1} and ex[0]["grid_nontarget_full"].dtype == np.int32
+    t = [synthetic.transform_example(e) for e in ex]
+    assert "grid_empty" not in t[0] and "grid_target_full" not in t[0]
+    tgt, ne = t[0]["grid_target"], t[0]["grid_nontarget_empty"]
+    assert tgt.dtype == bool and ne.dtype == bool and not (tgt & ne).any()
+    # evaluation = the "empty+nontarget" case of the grid algebra on the thresholded grids
+    target = ex[0]["grid_target"] > 0.5
+    want = ((ex[0]["grid_nontarget"] > 0.5) ^ target) | ((ex[0]["grid_empty"] > 0.5) ^ target)
+    np.testing.assert_array_equal(ne, want)
+    batch = dataset.concat_examples(t)
+    assert batch["rgb"].shape == (2, 256, 256, 3) and batch["pcd"].dtype == np.float32
+    assert batch["grid_nontarget_empty"].shape == (2, 32, 32, 32)
+    cases = {synthetic.transform_example(ex[0], train=True, random_state=np.random.RandomState(s))
+             ["grid_nontarget_empty"].sum() for s in range(12)}
+    assert len(cases) > 3  # different GRID_CASES / instance subsets are drawn
+    no_occ = synthetic.transform_example(ex[0], with_occupancy=False)
+    assert "pitch" not in no_occ and "origin" not in no_occ and "grid_target" not in no_occ
