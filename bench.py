@@ -199,31 +199,24 @@ def time_kernel_live(fn, reps):
 
 
 def roofline_voxelize(wl):
-    """Dominant hand-written HBM-bound op of Model.predict: mf_average_voxelization_3d_fwd
-    (dense fill + link + scatter launches), timed on the EXACT arguments one predict() passes it
-    (B objects, P=1000 clustered surface points, C=144 features, 32^3 grid).
+    """The dense HBM-bound op of the volumetric API: mf_average_voxelization_3d_fwd (memset fill +
+    link + scatter launches), timed on the arguments the pose network has for it (B objects,
+    P = 1000 clustered surface points each, C = 144 features, 32^3 grid).  The training path
+    calls it; inference feeds the same chains straight into conv3's GEMM rows
+    (mf_sparse_conv3d_k4s2_points_fwd) and never builds the dense tensor.
     Algorithmic bytes / object: read P*(12+4C+4) + write C*D^3*4 + D^3*4."""
-    import morefusion_amd.contrib.singleview_3d.models.model as model_mod
-
-    captured = {}
-    real = model_mod.functions_module.average_voxelization_3d
-
-    def spy(values, points, batch_indices, **kw):
-        captured["args"] = (values.clone(), points.clone(), batch_indices.clone())
-        captured["kw"] = kw
-        return real(values, points, batch_indices, **kw)
-
-    model_mod.functions_module.average_voxelization_3d = spy
-    try:
-        with torch.no_grad():
-            wl.model.predict(**wl.inputs)
-    finally:
-        model_mod.functions_module.average_voxelization_3d = real
-    values, points, bi = captured["args"]
-    kw = captured["kw"]
-    ms = time_kernel_live(lambda: real(values, points, bi, **kw), 50)
-    B, D = kw["batch_size"], kw["dimensions"][0]
-    P, C = values.shape[0] // B, values.shape[1]
+    m, inp = wl.model, wl.inputs
+    with torch.no_grad():
+        pix = m._select_points(~torch.isnan(inp["pcd"]).any(dim=3))
+        _, points = m._backbone_features(inp["rgb"], inp["pcd"], pix)
+        points = (points - inp["origin"].float()[:, :, None]) / inp["pitch"].float()[:, None, None]
+    B, D = points.shape[0], m._voxel_dim
+    P, C = points.shape[2], 144
+    pts = points.transpose(1, 2).reshape(B * P, 3).contiguous()
+    values = torch.randn(B * P, C, device=wl.device)
+    bi = torch.arange(B, dtype=torch.int32, device=wl.device).repeat_interleave(P)
+    kw = dict(batch_size=B, origin=(0, 0, 0), pitch=1.0, dimensions=(D, D, D), check_nan=False)
+    ms = time_kernel_live(lambda: mf.functions.average_voxelization_3d(values, pts, bi, **kw), 50)
     alg = B * (P * (12 + 4 * C + 4) + C * D ** 3 * 4 + D ** 3 * 4)
     achieved = alg / (ms * 1e-3) / 1e9
     # HBM bytes per call from the PMC passes committed under profiles/ (separate rocprofv3

@@ -228,9 +228,9 @@ int mf_icc_debug_stamps(unsigned long long *host_out, int n);
  *   dense  [B,Cout,D/2..] optional addend (the dense occupancy-channel part), bias [Cout]
  *   out    [B,Cout,D/2,D/2,D/2] written completely; relu != 0 applies max(.,0)
  *   max_rows >= number of occupied voxels (e.g. the number of points); ws from
- *   mf_sparse_conv3d_workspace_bytes.  Deterministic (fixed tap order, no atomics). */
+ *   mf_sparse_conv3d_workspace_bytes (n_points = 0 for this entry).  Deterministic (fixed tap order, no atomics). */
 int64_t mf_sparse_conv3d_workspace_bytes(int32_t B, int32_t Cs, int32_t Cout, int32_t D,
-                                         int32_t max_rows);
+                                         int32_t max_rows, int64_t n_points);
 /* W [Cout, w_cin, 4,4,4]; packs input channels [c_off, c_off+Cs). */
 int mf_sparse_conv3d_pack_weights(const float *W, int32_t Cout, int32_t Cs, int32_t w_cin,
                                   int32_t c_off, float *Wp, mfStream_t stream);
@@ -256,6 +256,19 @@ int mf_average_distance_fwd(const float *points, const float *T_true, const floa
 int mf_average_distance_bwd(const float *points, const float *T_true, const float *T_pred,
                             const uint8_t *symmetric, const float *gout, int32_t B, int32_t M,
                             int32_t P, const int32_t *nn_idx, float *gT_pred, mfStream_t stream);
+
+/* The same convolution fed by the POINTS (inference): average_voxelization_3d's per-voxel chains
+ * write the compact rows the GEMM consumes -- the dense [B,Cs,D,D,D] tensor of
+ *   morefusion/contrib/singleview_3d/models/model.py:114-128 (151 MB at B = 8) is never
+ * materialised.  values [n,Cs], points [n,3] voxel-frame (origin o, pitch), batch_indices [n];
+ * same means (increasing point index), same output bits as voxelize + mf_sparse_conv3d_k4s2_fwd.
+ * ws from mf_sparse_conv3d_workspace_bytes(..., n_points = n). */
+int mf_sparse_conv3d_k4s2_points_fwd(const float *values, const float *points,
+                                     const int32_t *batch_indices, int64_t n, float ox, float oy,
+                                     float oz, float pitch, const float *Wp, const float *dense,
+                                     const float *bias, float *out, void *ws, int32_t B,
+                                     int32_t Cs, int32_t Cout, int32_t D, int32_t max_rows,
+                                     int32_t relu, mfStream_t stream);
 
 /* small fused helpers of the same path */
 /* pack [Ptot,3] points + [Ptot] sdf into float4 */

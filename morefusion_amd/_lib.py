@@ -55,7 +55,9 @@ _SIGNATURES = {
     "mf_icc_loss_grad": ([ctypes.POINTER(IccBatch), _p, _p, _p, _p, _p, _p, _p], _i),
     "mf_icc_refine": ([ctypes.POINTER(IccBatch), _p, _p, _p, _p, ctypes.c_int32, ctypes.c_int32, _f, _f, _p, _p, _p, _p], _i),
     "mf_icc_debug_stamps": ([_p, _i], _i),
-    "mf_sparse_conv3d_workspace_bytes": ([ctypes.c_int32] * 5, _i64),
+    "mf_sparse_conv3d_workspace_bytes": ([ctypes.c_int32] * 5 + [_i64], _i64),
+    "mf_sparse_conv3d_k4s2_points_fwd": ([_p, _p, _p, _i64, _f, _f, _f, _f, _p, _p, _p, _p, _p]
+                                         + [ctypes.c_int32] * 6 + [_p], _i),
     "mf_sparse_conv3d_pack_weights": ([_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p], _i),
     "mf_sparse_conv3d_k4s2_fwd": ([_p, _p, _p, _p, _p, _p, _p] + [ctypes.c_int32] * 6 + [_p], _i),
     "mf_pack_points_sdf": ([_p, _p, _i64, _p, _p], _i),

@@ -48,7 +48,7 @@ class SparseVoxelConv3d:
             # (under autocast this convolution may run in bf16; the kernel adds a float32 tensor)
             dense = F.conv3d(h_dense.float(), self.Wd, None, stride=2, padding=1).float().contiguous()
         lib = _lib.lib()
-        nbytes = lib.mf_sparse_conv3d_workspace_bytes(B, Cs, Cout, D, max_rows)
+        nbytes = lib.mf_sparse_conv3d_workspace_bytes(B, Cs, Cout, D, max_rows, 0)
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=voxelized.device)
         x = voxelized.float().contiguous()
@@ -60,4 +60,34 @@ class SparseVoxelConv3d:
             x.data_ptr(), counts.contiguous().data_ptr(), self.Wp.data_ptr(), _lib.ptr(dense),
             _lib.ptr(bias), out.data_ptr(), self._ws.data_ptr(), B, Cs, Cout, D, int(max_rows),
             int(relu), _lib.stream_ptr()), "mf_sparse_conv3d_k4s2_fwd")
+        return out
+
+    @torch.no_grad()
+    def from_points(self, values, points, batch_indices, batch_size, h_dense=None, dim=32, origin=(0, 0, 0),
+                    pitch=1.0, relu=True):
+        """``relu(conv(cat[average_voxelization_3d(values, points), h_dense]))`` WITHOUT the dense
+        voxelized tensor: values [n,Cs], points [n,3], batch_indices [n] int32 -> [B,Cout,D/2,...].
+        The per-voxel chains of the voxelization write the GEMM's compact rows directly
+        (``mf_sparse_conv3d_k4s2_points_fwd``); same output bits as ``__call__`` on the dense op."""
+        _lib.require_gpu(values, points, batch_indices)
+        n, Cs = values.shape
+        B, D = int(batch_size), int(dim)
+        Cout = self.conv.out_channels
+        self._prepare(Cs)
+        dense = None
+        if h_dense is not None:
+            dense = F.conv3d(h_dense.float(), self.Wd, None, stride=2, padding=1).float().contiguous()
+        lib = _lib.lib()
+        max_rows = max(int(n), 1)
+        nbytes = lib.mf_sparse_conv3d_workspace_bytes(B, Cs, Cout, D, max_rows, n)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=values.device)
+        vals, pts, bi = _lib.f32c(values), _lib.f32c(points), _lib.i32c(batch_indices)
+        out = torch.empty((B, Cout, D // 2, D // 2, D // 2), dtype=torch.float32, device=values.device)
+        bias = self.conv.bias.detach().float().contiguous() if self.conv.bias is not None else None
+        o = _lib.as_float3(origin)
+        _lib.check(lib.mf_sparse_conv3d_k4s2_points_fwd(
+            vals.data_ptr(), pts.data_ptr(), bi.data_ptr(), n, o[0], o[1], o[2], float(pitch),
+            self.Wp.data_ptr(), _lib.ptr(dense), _lib.ptr(bias), out.data_ptr(), self._ws.data_ptr(),
+            B, Cs, Cout, D, max_rows, int(relu), _lib.stream_ptr()), "mf_sparse_conv3d_k4s2_points_fwd")
         return out

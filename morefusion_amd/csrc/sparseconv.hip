@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include "mf_common.h"
+#include "voxel_chain.h"
 
 namespace {
 
@@ -117,6 +118,45 @@ __global__ __launch_bounds__(256) void k_sc_gather(ScArgs a) {
   const int bv = a.rowvox[row];
   const int b = bv / V, v = bv % V;
   a.A[i] = a.x[((int64_t)b * a.Cs + ch) * V + v];
+}
+
+// ---- front end WITHOUT the dense tensor (inference) ------------------------------------
+// average_voxelization_3d leaves <= 3 % of the voxels occupied; handing that through a dense
+// [B,Cs,D,D,D] tensor costs a 151 MB zero-fill (B = 8) and a strided re-gather.  Here the
+// per-voxel point chains (voxel_chain.h) feed the compact A rows directly: link -> count/assign
+// -> one wave per occupied voxel writes its mean row into A[rowmap[voxel]].
+__global__ __launch_bounds__(256) void k_sc_link(const float *__restrict__ points,
+                                                 const int32_t *__restrict__ batch_indices, int64_t n,
+                                                 int B, int D, float ox, float oy, float oz, float pitch,
+                                                 int32_t *__restrict__ counts, int32_t *__restrict__ head,
+                                                 int32_t *__restrict__ link) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  mf::chain_link(points, batch_indices, i, B, D, D, D, ox, oy, oz, pitch, counts, head, link, nullptr);
+}
+
+__global__ __launch_bounds__(256) void k_sc_rows_from_chains(ScArgs a, const float *__restrict__ values,
+                                                            const float *__restrict__ points,
+                                                            const int32_t *__restrict__ batch_indices,
+                                                            int64_t n, float ox, float oy, float oz,
+                                                            float pitch, const int32_t *__restrict__ head,
+                                                            const int32_t *__restrict__ link) {
+  __shared__ int s_ids[4][64];
+  __shared__ int s_sorted[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  // the row of this point's voxel (only used by the chain-head wave)
+  int v;
+  bool has_nan;
+  const bool ok = mf::voxel_of(points, i, ox, oy, oz, pitch, a.D, a.D, a.D, v, has_nan);
+  const int b = batch_indices[i];
+  int row = -1;
+  if (ok && b >= 0 && b < a.B) row = a.rowmap[(int64_t)b * a.D * a.D * a.D + v];
+  if (row < 0) return;  // outside the grid, or beyond max_rows (wave-uniform)
+  float *dst = a.A + (int64_t)row * a.Cs;
+  mf::chain_mean(values, points, batch_indices, a.counts, head, link, i, a.Cs, a.B, a.D, a.D, a.D, ox, oy, oz,
+                 pitch, s_ids[wave], s_sorted[wave], lane, [&](int ch, float mean) { dst[ch] = mean; });
 }
 
 // C[row][n] = sum_k A[row][k] * Wp[class(row)][k][n],  n in [0, 8*Cout)
@@ -277,10 +317,11 @@ int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 }  // namespace
 
 extern "C" int64_t mf_sparse_conv3d_workspace_bytes(int32_t B, int32_t Cs, int32_t Cout, int32_t D,
-                                                    int32_t max_rows) {
+                                                    int32_t max_rows, int64_t n_points) {
   const int64_t V = (int64_t)D * D * D;
   return align256(B * V * 4) + align256((int64_t)max_rows * 4) + align256(64) + align256(64) +
-         align256((int64_t)max_rows * Cs * 4) + align256((int64_t)max_rows * 8 * Cout * 4);
+         align256((int64_t)max_rows * Cs * 4) + align256((int64_t)max_rows * 8 * Cout * 4) +
+         2 * align256(B * V * 4) + align256(n_points * 4);  // counts, chain heads, chain links
 }
 
 extern "C" int mf_sparse_conv3d_pack_weights(const float *W, int32_t Cout, int32_t Cs,
@@ -293,43 +334,108 @@ extern "C" int mf_sparse_conv3d_pack_weights(const float *W, int32_t Cout, int32
   return mf::check_launch("mf_sparse_conv3d_pack_weights");
 }
 
+namespace {
+
+struct ScWs {
+  ScArgs a;
+  int32_t *head, *link, *counts_own;
+};
+
+// workspace carve-up shared by both entry points (n_points == 0: no chain arrays)
+ScWs sc_carve(void *ws, int B, int Cs, int Cout, int D, int max_rows, int64_t n_points) {
+  const int64_t V = (int64_t)D * D * D;
+  ScWs w;
+  w.a.B = B; w.a.Cs = Cs; w.a.Cout = Cout; w.a.D = D; w.a.max_rows = max_rows;
+  w.a.x = nullptr; w.a.counts = nullptr;
+  char *p = (char *)ws;
+  w.a.rowmap = (int32_t *)p; p += align256(B * V * 4);
+  w.a.rowvox = (int32_t *)p; p += align256((int64_t)max_rows * 4);
+  w.a.class_cnt = (int32_t *)p; p += align256(64);
+  w.a.class_fill = (int32_t *)p; p += align256(64);
+  w.a.A = (float *)p; p += align256((int64_t)max_rows * Cs * 4);
+  w.a.C = (float *)p; p += align256((int64_t)max_rows * 8 * Cout * 4);
+  w.counts_own = (int32_t *)p; p += align256(B * V * 4);
+  w.head = (int32_t *)p; p += align256(B * V * 4);
+  w.link = (int32_t *)p;
+  return w;
+}
+
+int sc_check(int B, int Cs, int Cout, int D) {
+  if (Cs % 4 || Cout % 64 || Cout > 512 || D % 2 || D > 64) {
+    mf::set_last_error(hipErrorInvalidValue, "sparse_conv3d: need Cs%4==0, Cout%64==0 (<=512), even D");
+    return -(int)hipErrorInvalidValue;
+  }
+  const size_t lds_g = (size_t)Cs * (kTM + 4 + kTN + 4) * sizeof(float);
+  if (lds_g > 150 * 1024) {
+    mf::set_last_error(hipErrorInvalidValue, "sparse_conv3d: Cs too large for the LDS-resident K");
+    return -(int)hipErrorInvalidValue;
+  }
+  if (int e = mf::allow_big_lds((const void *)k_sc_gemm, 150 * 1024)) return e;
+  return mf::allow_big_lds((const void *)k_sc_reduce, 150 * 1024);
+}
+
+// rows per class + compact row ids from a.counts
+void sc_index(const ScArgs &a, hipStream_t stream) {
+  const int64_t V = (int64_t)a.D * a.D * a.D;
+  const unsigned nb = (unsigned)((a.B * V + 256 * kIdxPerThread - 1) / (256 * kIdxPerThread));
+  hipLaunchKernelGGL(k_sc_count, dim3(nb), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_sc_assign, dim3(nb), dim3(256), 0, stream, a);
+}
+
+// 8 parity-class GEMMs + output-stationary reduce
+void sc_gemm_reduce(const ScArgs &a, const float *Wp, const float *dense, const float *bias, int relu,
+                    float *out, hipStream_t stream) {
+  const size_t lds_g = (size_t)a.Cs * (kTM + 4 + kTN + 4) * sizeof(float);
+  // persistent-style: 2 workgroups per CU walk the (class, row tile, column tile) list
+  hipLaunchKernelGGL(k_sc_gemm, dim3(512), dim3(256), lds_g, stream, a, Wp);
+  const int Vo = (a.D / 2) * (a.D / 2) * (a.D / 2);
+  hipLaunchKernelGGL(k_sc_reduce, dim3((Vo + 63) / 64, a.B), dim3(kRedThreads),
+                     (size_t)a.Cout * 65 * sizeof(float), stream, a, dense, bias, relu, out);
+}
+
+}  // namespace
+
 extern "C" int mf_sparse_conv3d_k4s2_fwd(const float *x, const int32_t *counts, const float *Wp,
                                          const float *dense, const float *bias, float *out,
                                          void *ws, int32_t B, int32_t Cs, int32_t Cout, int32_t D,
                                          int32_t max_rows, int32_t relu, mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || max_rows <= 0) return 0;
-  if (Cs % 4 || Cout % 64 || Cout > 512 || D % 2 || D > 64) {
-    mf::set_last_error(hipErrorInvalidValue, "sparse_conv3d: need Cs%4==0, Cout%64==0 (<=512), even D");
-    return -(int)hipErrorInvalidValue;
-  }
-  const int64_t V = (int64_t)D * D * D;
-  ScArgs a;
-  a.x = x; a.counts = counts; a.B = B; a.Cs = Cs; a.Cout = Cout; a.D = D; a.max_rows = max_rows;
-  char *p = (char *)ws;
-  a.rowmap = (int32_t *)p; p += align256(B * V * 4);
-  a.rowvox = (int32_t *)p; p += align256((int64_t)max_rows * 4);
-  a.class_cnt = (int32_t *)p; p += align256(64);
-  a.class_fill = (int32_t *)p; p += align256(64);
-  a.A = (float *)p; p += align256((int64_t)max_rows * Cs * 4);
-  a.C = (float *)p;
-  MF_TRY(hipMemsetAsync(a.class_cnt, 0, 512, stream));  // class_cnt and class_fill
-  const unsigned nb = (unsigned)((B * V + 256 * kIdxPerThread - 1) / (256 * kIdxPerThread));
-  hipLaunchKernelGGL(k_sc_count, dim3(nb), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(k_sc_assign, dim3(nb), dim3(256), 0, stream, a);
+  if (int e = sc_check(B, Cs, Cout, D)) return e;
+  ScWs w = sc_carve(ws, B, Cs, Cout, D, max_rows, 0);
+  w.a.x = x;
+  w.a.counts = counts;
+  MF_TRY(hipMemsetAsync(w.a.class_cnt, 0, 512, stream));  // class_cnt and class_fill
+  sc_index(w.a, stream);
   hipLaunchKernelGGL(k_sc_gather, dim3((unsigned)(((int64_t)max_rows * Cs + 255) / 256)),
-                     dim3(256), 0, stream, a);
-  const size_t lds_g = (size_t)Cs * (kTM + 4 + kTN + 4) * sizeof(float);
-  if (int e = mf::allow_big_lds((const void *)k_sc_gemm, 150 * 1024)) return e;
-  if (int e = mf::allow_big_lds((const void *)k_sc_reduce, 150 * 1024)) return e;
-  if (lds_g > 150 * 1024) {
-    mf::set_last_error(hipErrorInvalidValue, "sparse_conv3d: Cs too large for the LDS-resident K");
-    return -(int)hipErrorInvalidValue;
-  }
-  // persistent-style: 2 workgroups per CU walk the (class, row tile, column tile) list
-  hipLaunchKernelGGL(k_sc_gemm, dim3(512), dim3(256), lds_g, stream, a, Wp);
-  const int Vo = (D / 2) * (D / 2) * (D / 2);
-  hipLaunchKernelGGL(k_sc_reduce, dim3((Vo + 63) / 64, B), dim3(kRedThreads),
-                     (size_t)Cout * 65 * sizeof(float), stream, a, dense, bias, relu, out);
+                     dim3(256), 0, stream, w.a);
+  sc_gemm_reduce(w.a, Wp, dense, bias, relu, out, stream);
   return mf::check_launch("mf_sparse_conv3d_k4s2_fwd");
+}
+
+extern "C" int mf_sparse_conv3d_k4s2_points_fwd(const float *values, const float *points,
+                                                const int32_t *batch_indices, int64_t n, float ox,
+                                                float oy, float oz, float pitch, const float *Wp,
+                                                const float *dense, const float *bias, float *out,
+                                                void *ws, int32_t B, int32_t Cs, int32_t Cout,
+                                                int32_t D, int32_t max_rows, int32_t relu,
+                                                mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || max_rows <= 0) return 0;
+  if (int e = sc_check(B, Cs, Cout, D)) return e;
+  const int64_t V = (int64_t)D * D * D;
+  ScWs w = sc_carve(ws, B, Cs, Cout, D, max_rows, n);
+  w.a.counts = w.counts_own;
+  MF_TRY(hipMemsetAsync(w.a.class_cnt, 0, 512, stream));
+  MF_TRY(hipMemsetAsync(w.counts_own, 0, sizeof(int32_t) * B * V, stream));
+  MF_TRY(hipMemsetAsync(w.head, 0xff, sizeof(int32_t) * B * V, stream));
+  if (n > 0)
+    hipLaunchKernelGGL(k_sc_link, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, points,
+                       batch_indices, n, B, D, ox, oy, oz, pitch, w.counts_own, w.head, w.link);
+  sc_index(w.a, stream);
+  if (n > 0)
+    hipLaunchKernelGGL(k_sc_rows_from_chains, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, w.a,
+                       values, points, batch_indices, n, ox, oy, oz, pitch, w.head, w.link);
+  sc_gemm_reduce(w.a, Wp, dense, bias, relu, out, stream);
+  return mf::check_launch("mf_sparse_conv3d_k4s2_points_fwd");
 }

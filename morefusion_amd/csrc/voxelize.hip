@@ -18,22 +18,11 @@
 #include <algorithm>
 
 #include "mf_common.h"
+#include "voxel_chain.h"
 
 namespace {
 
-__device__ __forceinline__ bool voxel_of(const float *__restrict__ points, int64_t i, float ox,
-                                         float oy, float oz, float pitch, int X, int Y, int Z,
-                                         int &v, bool &has_nan) {
-  float x = points[3 * i], y = points[3 * i + 1], z = points[3 * i + 2];
-  has_nan = (x != x) || (y != y) || (z != z);
-  float rx = roundf(mf::voxel_coord(x, ox, pitch));
-  float ry = roundf(mf::voxel_coord(y, oy, pitch));
-  float rz = roundf(mf::voxel_coord(z, oz, pitch));
-  bool ok = rx >= 0.0f && rx < (float)X && ry >= 0.0f && ry < (float)Y && rz >= 0.0f &&
-            rz < (float)Z;
-  v = ok ? ((int)rx * Y + (int)ry) * Z + (int)rz : -1;
-  return ok;
-}
+using mf::voxel_of;
 
 __global__ __launch_bounds__(256) void k_avgvox_link(const float *__restrict__ points,
                                                      const int32_t *__restrict__ batch_indices,
@@ -45,26 +34,13 @@ __global__ __launch_bounds__(256) void k_avgvox_link(const float *__restrict__ p
                                                      int32_t *__restrict__ nan_flag) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  int v;
-  bool has_nan;
-  bool ok = voxel_of(points, i, ox, oy, oz, pitch, X, Y, Z, v, has_nan);
-  if (has_nan && nan_flag) atomicOr(nan_flag, 1);
-  int b = batch_indices[i];
-  ok = ok && b >= 0 && b < B;
-  int32_t l = -2;
-  if (ok) {
-    int64_t key = (int64_t)b * X * Y * Z + v;
-    atomicAdd(&counts[key], 1);
-    l = atomicExch(&head[key], (int32_t)i);
-  }
-  link[i] = l;
+  mf::chain_link(points, batch_indices, i, B, X, Y, Z, ox, oy, oz, pitch, counts, head, link, nan_flag);
 }
 
 // Sparse half of the forward: one WAVE per point; only the wave of a voxel's chain head
-// (exactly one per occupied voxel) continues.  Lane 0 walks the chain once, the ids are
-// rank-sorted by the lanes, then lanes run over channels: coalesced reads of the value
-// rows, sum in increasing point index, divide, store.  The dense [B,C,X,Y,Z] tensor was
-// zero-filled beforehand at memset speed, so only ~3 % of its lines are touched twice.
+// (exactly one per occupied voxel) continues (mf::chain_mean, voxel_chain.h).  The dense
+// [B,C,X,Y,Z] tensor was zero-filled beforehand at memset speed, so only ~3 % of its lines
+// are touched twice.
 __global__ __launch_bounds__(256) void k_avgvox_scatter(const float *__restrict__ values,
                                                         const float *__restrict__ points,
                                                         const int32_t *__restrict__ batch_indices,
@@ -79,52 +55,15 @@ __global__ __launch_bounds__(256) void k_avgvox_scatter(const float *__restrict_
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + wave;
   if (i >= n) return;
+  const int64_t V = (int64_t)X * Y * Z;
+  // the destination depends on the voxel: recompute its key for the store
   int v;
   bool has_nan;
-  const bool ok = voxel_of(points, i, ox, oy, oz, pitch, X, Y, Z, v, has_nan);
+  voxel_of(points, i, ox, oy, oz, pitch, X, Y, Z, v, has_nan);
   const int b = batch_indices[i];
-  if (!(ok && b >= 0 && b < B)) return;
-  const int64_t V = (int64_t)X * Y * Z;
-  const int64_t key = (int64_t)b * V + v;
-  if (head[key] != (int32_t)i) return;  // not this voxel's chain head (wave-uniform)
-  const int cnt = counts[key];
   float *out = matrix + (int64_t)b * C * V + v;
-  if (cnt <= 64) {
-    if (lane == 0) {
-      int m = (int)i;
-      for (int k = 0; k < cnt; ++k) { s_ids[wave][k] = m; m = link[m]; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < cnt) {
-      const int mine = s_ids[wave][lane];
-      int rank = 0;
-      for (int k = 0; k < cnt; ++k) rank += s_ids[wave][k] < mine ? 1 : 0;
-      s_sorted[wave][rank] = mine;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int ch = lane; ch < C; ch += 64) {
-      float s = 0.0f;
-      for (int k = 0; k < cnt; ++k) s += values[(int64_t)s_sorted[wave][k] * C + ch];
-      out[(int64_t)ch * V] = s / (float)cnt;
-    }
-  } else {  // pathological pile-up in one voxel: repeated selection, still in index order
-    for (int ch = lane; ch < C; ch += 64) {
-      float s = 0.0f;
-      int last = -1;
-      for (int k = 0; k < cnt; ++k) {
-        int best = 0x7fffffff;
-        for (int m = (int)i; m >= 0; m = link[m])
-          if (m > last && m < best) best = m;
-        s += values[(int64_t)best * C + ch];
-        last = best;
-      }
-      out[(int64_t)ch * V] = s / (float)cnt;
-    }
-  }
+  mf::chain_mean(values, points, batch_indices, counts, head, link, i, C, B, X, Y, Z, ox, oy, oz, pitch,
+                 s_ids[wave], s_sorted[wave], lane, [&](int ch, float mean) { out[(int64_t)ch * V] = mean; });
 }
 
 __global__ __launch_bounds__(256) void k_avgvox_bwd(const float *__restrict__ gmatrix,

@@ -429,6 +429,10 @@ def test_sparse_conv3_matches_dense_conv3d(B, Cs, Cd, Cout, n):
     assert torch.equal(got, got2)
     pre = op(vox, counts, h_occ, max_rows=B * n, relu=False)
     assert float(pre.min()) < 0  # relu flag honoured
+    # fed by the points (no dense voxelized tensor): the same bits
+    got3 = op.from_points(vals, pts, bi, batch_size=B, h_dense=h_occ, dim=D)
+    assert torch.equal(got3, got)
+    assert torch.equal(op.from_points(vals, pts, bi, batch_size=B, h_dense=h_occ, dim=D, relu=False), pre)
 
 
 def test_model_predict_under_bf16_autocast_matches_fp32_roughly():
