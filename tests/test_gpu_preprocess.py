@@ -9,6 +9,7 @@ from oracle import oracle_np as O
 
 pytestmark = pytest.mark.gpu
 
+import morefusion_amd as mf  # noqa: E402
 from morefusion_amd import geometry, synthetic  # noqa: E402
 
 

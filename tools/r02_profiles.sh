@@ -13,4 +13,7 @@ WHAT=predict REPS=6 CUDNN_BENCH=1 timeout 300 rocprofv3 --kernel-trace --pmc WRI
 # 3. MFMA pipe utilisation of the network's convolutions / GEMMs (stock MIOpen + rocBLAS + k_sc_gemm)
 WHAT=predict REPS=6 CUDNN_BENCH=1 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/pred_mfma -o p -- python tools/prof_icc.py > $P/pred_mfma.log 2>&1
 python tools/r02_profiles_summarise.py $P
-ls $P; tail -2 $P/bench.log | cut -c1-300
+cp $P/bench/bench_kernel_stats.csv $P/summary/r02_bench_full_run_kernel_stats.csv 2>/dev/null
+# only the summaries travel back (gpurun merges <= 64 MiB)
+for d in bench icc_fetch icc_write pred_fetch pred_write pred_mfma; do rm -rf $P/$d; done
+ls $P $P/summary; tail -1 $P/bench.log | cut -c1-300
