@@ -56,8 +56,15 @@ class IterativeCollisionCheckLink(torch.nn.Module):
             p.grad = None
 
     def _pack(self, points, sdf, pitch, origin, grid_target, grid_nontarget_empty):
-        key = tuple(id(x) for x in (points, sdf, pitch, origin, grid_target, grid_nontarget_empty))
-        key += tuple(int(p.data_ptr()) if isinstance(p, torch.Tensor) else id(p) for p in points)
+        # identity AND in-place version of every tensor argument: per-frame buffers updated in
+        # place between calls must not hit a stale packed copy
+        def ident(x):
+            if isinstance(x, torch.Tensor):
+                return (int(x.data_ptr()), int(x._version), tuple(x.shape))
+            if isinstance(x, (list, tuple)):
+                return tuple(ident(v) for v in x)
+            return id(x)
+        key = tuple(ident(x) for x in (points, sdf, pitch, origin, grid_target, grid_nontarget_empty))
         if self._scenes is None or self._scenes_key != key:
             self._scenes = IccScenes(
                 [dict(points=points, sdf=sdf, pitch=pitch, origin=origin, grid_target=grid_target,

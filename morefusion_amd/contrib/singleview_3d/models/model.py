@@ -62,7 +62,14 @@ class Model(nn.Module):
         self._with_occupancy = with_occupancy
         if loss is None:
             loss = "add/add_s"
-        assert loss in ["add", "add/add_s"]
+        if loss in ("add+occupancy", "add/add_s+occupancy"):
+            # model.py:437-470: that branch calls pseudo_occupancy_voxelization without its ``sdf``
+            # argument (truncated_distance_function.py:181) and raises TypeError in the reference
+            raise NotImplementedError(
+                f"loss={loss!r}: the occupancy term of the reference cannot run (it omits the required "
+                "sdf argument of pseudo_occupancy_voxelization); use 'add' or 'add/add_s'")
+        if loss not in ("add", "add/add_s"):
+            raise ValueError(f"unknown loss {loss!r}")
         self._loss = loss
         self._models = models or PitchTableModels()
         # evaluate the last PSPNet level only where the network samples it (model.py:222)
