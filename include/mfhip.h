@@ -178,6 +178,10 @@ typedef struct {
   int32_t max_scene_objects; /* max objects in one scene (<= 32) */
   float voxel_threshold;
   float sdf_offset;
+  int32_t grid_ne_binary; /* != 0: the caller guarantees that every grid_ne value is exactly 0 or 1
+                             (what the reference's callers pass: bool grids cast to float32) ->
+                             single-pass iteration (TDF tiles and weights/sums in one kernel, two
+                             launches per iteration); 0: any values, two-kernel path */
 } mfIccBatch;
 
 /* Bytes of workspace for this batch (negative: invalid descriptor).  Holds the winners of every
@@ -208,7 +212,9 @@ int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float *adam_m,
 /* Measurement hook so that bench.py can time ONE kernel of an ICC iteration with HIP events:
  * stage 0 = (optional pose refresh from q, t if non-NULL) + empty the bins + k_icc_bin (pose ->
  * world points -> x-plane bins of voxel-frame records); stage 1 = k_icc_tile alone (bins ->
- * per-grid (min distance, arg-min) winners; repeatable: it does not consume the bins). */
+ * per-grid (min distance, arg-min) winners); stage 2 = k_icc_fused alone (bins -> winners ->
+ * weights / sums / moments; needs grid_ne_binary).  Stages 1, 2 are repeatable: they do not
+ * consume the bins (their sums simply keep adding up). */
 int mf_icc_launch_stage(const mfIccBatch *batch, const float *q, const float *t, void *ws,
                         int32_t stage, mfStream_t stream);
 

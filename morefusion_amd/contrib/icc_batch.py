@@ -72,7 +72,10 @@ class IccScenes:
             self.grid_target.data_ptr(), self.grid_ne.data_ptr(), self.n_objects, self.n_scenes,
             self.n_points, voxel_dim,
             max(scene_off[i + 1] - scene_off[i] for i in range(len(scenes))),
-            float(voxel_threshold), float(sdf_offset))
+            float(voxel_threshold), float(sdf_offset),
+            # {0,1} no-entry grids (bool cast to float32, what every caller of the reference passes)
+            # take the single-pass kernel; checked once here (pack time, not in the loop)
+            int(bool(((self.grid_ne == 0) | (self.grid_ne == 1)).all())))
         nbytes = L.mf_icc_workspace_bytes(ctypes.byref(self.desc))
         if nbytes < 0:
             raise ValueError("mf_icc: invalid batch descriptor (objects per scene <= 32, dim <= 64)")

@@ -54,7 +54,9 @@ constexpr int kNumOwn = 39;         // RN, S_in, PN + 3 x 12 gradient moments
 constexpr uint32_t kNoCand = 0xffffffffu;
 constexpr double kFixOth = 1099511627776.0;  // 2^40 fixed point: collision moments summed over blocks
 constexpr double kFixOwn = 4294967296.0;     // 2^32: reward / penalty sums and own-gradient moments
-constexpr int kOwnSlots = kNumOwn + 1;       // + count of non-finite block sums (-> NaN loss)
+constexpr int kNumF = 65;                    // single-pass path: 5 scene sums + 5 x 12 moments (below)
+constexpr int kOwnSlots = kNumF + 1;         // accumulator words per object; the slot after the sums
+                                             // counts non-finite block sums (-> NaN loss)
 constexpr int kStateFloats = 21;             // q[4] t[3] m[7] v[7] of one object
 constexpr int kMaxSceneObjects = 32;
 
@@ -71,7 +73,8 @@ struct IccArgs {
   float thr, sdf_offset;
   // workspace
   unsigned long long *W;  // [2*O][V]
-  uint32_t *Mbits;        // [2*O]
+  uint32_t *Mbits;        // [2 parities][2*O] per-grid max of the raw inside weight (float bits)
+  int ne_binary;          // every grid_ne value is exactly 0 or 1 -> single-pass path (see k_icc_fused)
   float *Rt;              // [O][12]  R row-major, then t
   float *bound;           // [O][4]   model-frame bounding sphere
   float *St;              // [S]
@@ -88,7 +91,8 @@ struct IccArgs {
   int n_tab;
   int hmax;               // largest TDF half-kernel of the batch
   int nbins;              // kHalves * (D + 2 hmax): (x-plane of the rounded x in [-hmax, D-1+hmax], y-half)
-  uint32_t *bin_cnt;      // [2*O][nbins] records in each bin (zero between iterations)
+  uint32_t *bin_cnt;      // [2 parities][2*O][nbins] records in each bin: iteration k fills parity k & 1,
+                          // the step side of k_icc_bin empties the other one for iteration k + 1
   int32_t *bin_cap;       // [2*O] capacity of each bin of grid g = number of its source points
   int64_t *bin_base;      // [2*O] first record of grid g's bins; bin b starts at base + b*cap
   float4 *rec;            // records {fx, fy, fz, point id bits}: voxel-frame coordinates
@@ -230,8 +234,12 @@ __global__ __launch_bounds__(64) void k_icc_pose(IccArgs a, const float *__restr
   for (int i = 0; i < 9; ++i) a.Rt[12 * o + i] = R[i];
 #pragma unroll
   for (int i = 0; i < 3; ++i) a.Rt[12 * o + 9 + i] = t[3 * o + i];
-  a.Mbits[2 * o] = 0;
-  a.Mbits[2 * o + 1] = 0;
+  for (int par = 0; par < 2; ++par) {
+    a.Mbits[(int64_t)par * 2 * a.O + 2 * o] = 0;
+    a.Mbits[(int64_t)par * 2 * a.O + 2 * o + 1] = 0;
+  }
+  for (int par = 0; par < 2; ++par)
+    for (int i = 0; i < 2 * a.nbins; ++i) a.bin_cnt[((int64_t)par * 2 * a.O + 2 * o) * a.nbins + i] = 0u;
   for (int i = 0; i < kOwnSlots; ++i) a.acc_own[(int64_t)o * kOwnSlots + i] = 0;
   for (int i = 0; i < a.max_ns * 12; ++i) a.acc_oth[(int64_t)o * a.max_ns * 12 + i] = 0;
   if (traj) {
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) void k_icc_tables(IccArgs a) {
   }
   __syncthreads();
   for (int i = s_tab_base[0] + threadIdx.x; i < a.n_tab; i += blockDim.x) a.tab[i] = make_int4(-1, -1, 0, 0);
-  for (int i = threadIdx.x; i < 2 * a.O * a.nbins; i += blockDim.x) a.bin_cnt[i] = 0u;
+  for (int i = threadIdx.x; i < 4 * a.O * a.nbins; i += blockDim.x) a.bin_cnt[i] = 0u;
 }
 
 // ---- the optimiser step of ONE object from the reduced sums of an iteration ------------
@@ -303,7 +311,9 @@ constexpr int kStepSums = 52;
 
 struct IccStepArgs {
   int mode;        // 0: none (bin reads a.Rt), 1: Adam step + outputs, 2: gradients only (k_icc_step)
-  int par;         // parity of the accumulators to read
+  int fused;       // the sums come from k_icc_fused (monomials in 1/M_own, 1/M_oth) instead of k_icc_accum
+  int par;         // parity of the accumulators / per-grid maxima to read
+  int cpar;        // parity of the bin counters this launch fills
   int it;          // iteration whose pose is produced (traj row; its loss goes to losses[it - 1])
   float aq, at;    // alpha_t of chainer's Adam for this step (evaluated in double on the host)
   const float *q_in, *t_in, *m_in, *v_in;  // state before the step
@@ -318,7 +328,7 @@ struct IccStepArgs {
 // scene's objects serially costs a dependent load per object: measured 9 us at 8 objects) --
 // staged in LDS, then summed in object order.  s_raw: >= (16 * max_ns + kNumOwn) 64-bit words.
 // Contains two barriers: call it from uniform control flow.
-constexpr int kStepRawWords = 16 * kMaxSceneObjects + kNumOwn;
+constexpr int kStepRawWords = 20 * kMaxSceneObjects + 60;  // (the single-pass path stages more words)
 
 template <int NT>
 __device__ __forceinline__ void icc_step_gather(const IccArgs &a, int par, int j, int ja, int Ns,
@@ -358,6 +368,74 @@ __device__ __forceinline__ void icc_step_gather(const IccArgs &a, int par, int j
     } else {
       long long bad = 0;
       for (int jo = 0; jo < Ns; ++jo) bad |= s_raw[4 * jo + 3];
+      r = bad != 0 ? 1.0f : 0.0f;
+    }
+    s_sum[l] = r;
+  }
+  __syncthreads();
+}
+
+// The same for the single-pass path (k_icc_fused): the accumulators hold the monomial sums, the
+// per-grid maxima M_own / M_oth give a = 1/M_own, b = 1/M_oth (b = 0 where the "other" grid is
+// empty or absent: iterative_collision_check_link.py:62-63,82), and the lanes form the sums the
+// step expects (see the table above k_icc_fused).
+template <int NT>
+__device__ __forceinline__ void icc_step_gather_fused(const IccArgs &a, int par, int j, int ja, int Ns,
+                                                      long long *s_raw, float *s_sum) {
+  const long long *own = a.acc_own + (int64_t)par * a.O * kOwnSlots;
+  const long long *oth = a.acc_oth + (int64_t)par * a.O * a.max_ns * 12;
+  const uint32_t *Mb = a.Mbits + (int64_t)par * 2 * a.O;
+  // items: [0, 8 Ns): per scene object {5 scene sums, non-finite count, M_own bits, M_oth bits};
+  // [8 Ns, 20 Ns): the 12 collision moments onto j from every scene object's grid;
+  // [20 Ns, 20 Ns + 60): the 5 x 12 own-gradient moments of j
+  const int n_items = 20 * Ns + 60;
+  for (int i = threadIdx.x; i < n_items; i += NT) {
+    long long x;
+    if (i < 8 * Ns) {
+      const int jo = i >> 3, l = i & 7;
+      if (l < 5) x = own[(int64_t)(ja + jo) * kOwnSlots + l];
+      else if (l == 5) x = own[(int64_t)(ja + jo) * kOwnSlots + kNumF];
+      else x = (long long)Mb[2 * (ja + jo) + (l - 6)];
+    } else if (i < 20 * Ns) {
+      const int k = i - 8 * Ns, jo = k / 12, c = k - 12 * jo;
+      x = oth[((int64_t)(ja + jo) * a.max_ns + (j - ja)) * 12 + c];
+    } else {
+      x = own[(int64_t)j * kOwnSlots + 5 + (i - 20 * Ns)];
+    }
+    s_raw[i] = x;
+  }
+  __syncthreads();
+  auto f_own = [&](long long x) { return (float)((double)x * (1.0 / kFixOwn)); };
+  auto a_of = [&](int jo) { return 1.0f / __uint_as_float((uint32_t)s_raw[8 * jo + 6]); };
+  auto b_of = [&](int jo) {
+    const float M = __uint_as_float((uint32_t)s_raw[8 * jo + 7]);
+    return (Ns > 1 && M != 0.0f) ? 1.0f / M : 0.0f;
+  };
+  if (threadIdx.x < kStepSums) {
+    const int l = threadIdx.x;
+    const int jj = j - ja;
+    float r = 0.0f;
+    if (l == 0) {  // RN
+      for (int jo = 0; jo < Ns; ++jo) r += f_own(s_raw[8 * jo + 0]) - a_of(jo) * f_own(s_raw[8 * jo + 1]);
+    } else if (l == 1) {  // S_in
+      for (int jo = 0; jo < Ns; ++jo) r += a_of(jo) * f_own(s_raw[8 * jo + 2]);
+    } else if (l == 2) {  // PN
+      for (int jo = 0; jo < Ns; ++jo)
+        r += a_of(jo) * (f_own(s_raw[8 * jo + 3]) + b_of(jo) * f_own(s_raw[8 * jo + 4]));
+    } else if (l < 15) {  // reward moments
+      const int c = l - 3;
+      r = f_own(s_raw[20 * Ns + c]) - a_of(jj) * f_own(s_raw[20 * Ns + 12 + c]);
+    } else if (l < 27) {  // penalty numerator moments
+      const int c = l - 15;
+      r = a_of(jj) * (f_own(s_raw[20 * Ns + 24 + c]) + b_of(jj) * f_own(s_raw[20 * Ns + 36 + c]));
+    } else if (l < 39) {  // penalty denominator moments
+      r = a_of(jj) * f_own(s_raw[20 * Ns + 48 + (l - 27)]);
+    } else if (l < 51) {  // collision moments of every grid of the scene onto j
+      for (int jo = 0; jo < Ns; ++jo)
+        r += (a_of(jo) * b_of(jo)) * (float)((double)s_raw[8 * Ns + 12 * jo + (l - 39)] * (1.0 / kFixOth));
+    } else {
+      long long bad = 0;
+      for (int jo = 0; jo < Ns; ++jo) bad |= s_raw[8 * jo + 5];
       r = bad != 0 ? 1.0f : 0.0f;
     }
     s_sum[l] = r;
@@ -465,7 +543,10 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
   for (int i = threadIdx.x; i < nb; i += kBinThreads) s_cnt[i] = 0;
   if (sp.mode != 0) {
     // the previous iteration's reduced sums of object j (fixed point)
-    icc_step_gather<kBinThreads>(a, sp.par, j, e2.x, e2.y, s_raw, s_sum);
+    if (sp.fused)
+      icc_step_gather_fused<kBinThreads>(a, sp.par, j, e2.x, e2.y, s_raw, s_sum);
+    else
+      icc_step_gather<kBinThreads>(a, sp.par, j, e2.x, e2.y, s_raw, s_sum);
     // every lane evaluates the same step from LDS (broadcast reads): no further barrier
     float Rt[12], st_new[kStateFloats], loss, gq[4], gt[3];
     icc_step_apply(s_sum, S_t, s_state, sp, Rt, st_new, loss, gq, gt);
@@ -488,13 +569,16 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
       }
       if (sp.loss_out && j == e2.x) sp.loss_out[e2.z] = loss;
       // empty this object's accumulators of the parity the coming k_icc_accum adds into
-      a.Mbits[2 * j] = 0;
-      a.Mbits[2 * j + 1] = 0;
+      a.Mbits[(int64_t)(sp.par ^ 1) * 2 * a.O + 2 * j] = 0;
+      a.Mbits[(int64_t)(sp.par ^ 1) * 2 * a.O + 2 * j + 1] = 0;
       long long *own = a.acc_own + ((int64_t)(sp.par ^ 1) * a.O + j) * kOwnSlots;
       for (int i = 0; i < kOwnSlots; ++i) own[i] = 0;
       long long *oth = a.acc_oth + ((int64_t)(sp.par ^ 1) * a.O + j) * a.max_ns * 12;
       for (int i = 0; i < a.max_ns * 12; ++i) oth[i] = 0;
     }
+    if (e2.w != 0)  // ... and the bins of its two grids that the NEXT iteration fills
+      for (int i = threadIdx.x; i < 2 * nb; i += kBinThreads)
+        a.bin_cnt[((int64_t)(sp.cpar ^ 1) * 2 * a.O + 2 * j) * nb + i] = 0u;
   }
   const float R0 = r0.x, R1 = r0.y, R2 = r0.z, R3 = r0.w, R4 = r1.x, R5 = r1.y, R6 = r1.z,
               R7 = r1.w, R8 = r2.x, T0 = r2.y, T1 = r2.z, T2 = r2.w;
@@ -550,7 +634,7 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
   stamp(1);
   for (int i = threadIdx.x; i < nb; i += kBinThreads) {
     const int c = s_cnt[i];
-    s_base[i] = c > 0 ? (int)atomicAdd(&a.bin_cnt[(int64_t)g * nb + i], (uint32_t)c) : 0;
+    s_base[i] = c > 0 ? (int)atomicAdd(&a.bin_cnt[((int64_t)sp.cpar * 2 * a.O + g) * nb + i], (uint32_t)c) : 0;
   }
   __syncthreads();
   stamp(2);
@@ -587,9 +671,10 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
 constexpr int kTileThreads = 512;
 constexpr int kTileKeep = 4;  // records per lane kept in registers over both passes
 constexpr int kTileR = 4;     // records in flight per lane beyond those
+constexpr int kFusedKeepOwn = 2, kFusedKeepOth = 4;  // k_icc_fused: kept records per lane and grid
 
 template <int KS>
-__device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt) {
+__device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt, const int par) {
   MF_DYN_LDS(uint32_t, s_tile);  // dist[rows*D], id[rows*D]
   __shared__ float s_max[kTileThreads / 64];
   const int ks = KS > 0 ? KS : ks_rt;
@@ -611,7 +696,7 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt)
 #pragma unroll
   for (int b = 0; b < 7; ++b) {
     int n = 0;
-    if (b < ks) n = min((int)a.bin_cnt[(int64_t)g * nb + (bin0 + b) * kHalves + half], cap);
+    if (b < ks) n = min((int)a.bin_cnt[((int64_t)par * 2 * a.O + g) * nb + (bin0 + b) * kHalves + half], cap);
     c[b + 1] = c[b] + n;
   }
   const int T = c[7];
@@ -820,17 +905,17 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt)
     float m = s_max[0];
 #pragma unroll
     for (int i = 1; i < kTileThreads / 64; ++i) m = fmaxf(m, s_max[i]);
-    if (m > 0.0f) atomicMax(&a.Mbits[g], __float_as_uint(m));  // m >= 0: uint order == float order
+    if (m > 0.0f) atomicMax(&a.Mbits[(int64_t)par * 2 * a.O + g], __float_as_uint(m));  // m >= 0: uint order == float order
   }
   stamp(4);
 }
 
-__global__ __launch_bounds__(kTileThreads) void k_icc_tile(IccArgs a) {
+__global__ __launch_bounds__(kTileThreads) void k_icc_tile(IccArgs a, int par) {
   const int ks = min(ksize_of(a.thr, a.pitch[blockIdx.y >> 1]), 2 * a.hmax + 1);  // block-uniform
   if (ks == 3)
-    icc_tile_body<3>(a, 3);
+    icc_tile_body<3>(a, 3, par);
   else
-    icc_tile_body<0>(a, ks);
+    icc_tile_body<0>(a, ks, par);
 }
 
 // ---- launch 2: weights, sums, gradient moments ------------------------------------
@@ -876,16 +961,13 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
   if (threadIdx.x == 0) s_emask = 0u;
-  // this object's two grids have been consumed by k_icc_tile: empty their bins for the next k_icc_bin
-  if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < 2 * a.nbins; i += kAccThreads) a.bin_cnt[(int64_t)2 * o * a.nbins + i] = 0u;
   const float pitch = a.pitch[o];
   // candidate ids are point * K + offset with this grid's own kernel size
   const int ks_o = ksize_of(a.thr, pitch);
   const int K = ks_o * ks_o * ks_o;
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
-  const float M_own = __uint_as_float(a.Mbits[2 * o]);
-  const float M_oth = __uint_as_float(a.Mbits[2 * o + 1]);
+  const float M_own = __uint_as_float(a.Mbits[(int64_t)par * 2 * a.O + 2 * o]);
+  const float M_oth = __uint_as_float(a.Mbits[(int64_t)par * 2 * a.O + 2 * o + 1]);
   const float trunc = a.thr * pitch;
   // iterative_collision_check_link.py:82: skip the max() when grid_other has NaN,
   // which happens iff its normaliser max(weight) is 0 (0/0 everywhere).
@@ -1058,6 +1140,410 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   }
 }
 
+// ---- single-pass path: TDF tiles + weights / sums / moments in ONE kernel -------------
+// k_icc_tile -> W -> k_icc_accum exists only because the weights are normalised by the per-grid
+// maximum M = max(inside weight), known once every tile of the grid is done.  Every caller of
+// the reference passes {0,1} no-entry grids (bool cast to float32:
+// check_iterative_collision_check_link.py:36-38, collision_based_pose_refinement.py:162), and
+// for those maximum(no-entry, other) is a selection, so the loss and its gradient are POLYNOMIAL
+// in a = 1/M_own and b = 1/M_oth.  With gw = g*w (g = 1 - tdf/trunc, w = clamped inside weight),
+// go, wo the same of the "other" grid, nb = [sdf + offset >= 0], ne in {0,1}:
+//   RN   = sum nb*g*tg          - a   sum gw*tg                  (sums 0, 1)
+//   S_in =                        a   sum gw                      (sum 2)
+//   PN   =                        a   sum gw*ne + a b sum gw*(1-ne)*go*wo        (sums 3, 4)
+//   own gradient moments (u = unit residual of the winner, m its model point; 12 each):
+//     U0a: nb*tg/trunc, U0b: w*tg/trunc (coeff -a), U1a: w*ne/trunc (a), U1b: w*(1-ne)*go*wo/trunc
+//     (a b), U2: w/trunc (a)
+//   collision moments onto the other object e: u_o (x) {m_o,1} * wo*gw/trunc     (coeff a b)
+// A workgroup = (object, x-plane, y-half) runs both TDFs of its voxels in LDS (own + other
+// records), then one lane per voxel accumulates the 65 monomial sums; the step (icc_step_gather)
+// applies a, b from the per-grid maxima.  The winners never leave LDS: no W round trip, no
+// second launch, no dependent re-load of what the tile just computed.  Same arithmetic per
+// voxel as k_icc_accum up to the association of the normaliser (tests: loss within 2e-5,
+// step within 1e-5 of the oracle's).  Grids with other values take the two-kernel path.
+template <int KS>
+__device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt, const int par) {
+  MF_DYN_LDS(uint32_t, s_tile);  // dist[2][nvh] | id[2][nvh] | rows2[max_ns][32][13] floats
+  __shared__ float s_rows[kTileThreads / 16][kNumF + 1];
+  __shared__ float s_max[2][kTileThreads / 64];
+  __shared__ float s_Rt[kMaxSceneObjects][12];
+  __shared__ int s_off[kMaxSceneObjects + 1];
+  __shared__ uint32_t s_emask;
+  const int ks = KS > 0 ? KS : ks_rt;
+  const int h = ks / 2, K = ks * ks * ks;
+  const int D = a.D, nb = a.nbins, hmax = a.hmax, V = D * D * D;
+  const int o = blockIdx.y;
+  const int x = blockIdx.x / kHalves, half = blockIdx.x % kHalves;
+  const int Dh = (D + 1) / 2;
+  const int y0 = half * Dh, y1 = half == 0 ? Dh : D;
+  const int nvh = Dh * D;               // LDS stride of one (dist | id) array
+  const int nvox = (y1 - y0) * D;
+  uint32_t *s_dist = s_tile, *s_id = s_tile + 2 * nvh;
+  float *s_rows2 = reinterpret_cast<float *>(s_tile + 4 * nvh);
+  const int4 meta = a.meta[o];
+  const int ja = meta.x, Ns = meta.y - meta.x;
+  // independent loads: bin counts of both grids, capacities, offsets, scalars, scene tables
+  int c[2][8];
+  int cap[2];
+  int64_t base_g[2];
+  const float pitch = a.pitch[o];
+  const int bin0 = x + hmax - h;  // plane x - h
+#pragma unroll
+  for (int kd = 0; kd < 2; ++kd) {
+    const int g = 2 * o + kd;
+    cap[kd] = a.bin_cap[g];
+    base_g[kd] = a.bin_base[g];
+    c[kd][0] = 0;
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+      int n = 0;
+      if (b < ks && (kd == 0 || Ns > 1))
+        n = min((int)a.bin_cnt[((int64_t)par * 2 * a.O + g) * nb + (bin0 + b) * kHalves + half], cap[kd]);
+      c[kd][b + 1] = c[kd][b] + n;
+    }
+  }
+  const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
+  if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
+  if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
+  if (threadIdx.x == 0) s_emask = 0u;
+  const float trunc = a.thr * pitch;
+  for (int i = threadIdx.x; i < 2 * nvh; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
+    if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
+  };
+  stamp(0);
+  if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)(c[0][7] + c[1][7]);
+  // the voxel phase's first-level loads, issued now: this lane's voxel of the two input grids
+  const int vloc = threadIdx.x;  // (D = 32: one voxel per lane; larger grids loop below)
+  float ne0 = 0.0f, tg0 = 0.0f;
+  if (vloc < nvox) {
+    const int64_t gv = (int64_t)o * V + ((int64_t)x * D + y0) * D + vloc;
+    ne0 = a.grid_ne[gv];
+    tg0 = a.grid_target[gv];
+  }
+  __syncthreads();
+  const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test in pass 2
+  const float d2_in = a.thr * a.thr * 0.999f;    // certainly inside the truncation radius
+  const float fxp = (float)x;
+
+  // record i of grid kd's concatenated bins -> (plane offset b, record); rb < 0: none
+  auto fetch = [&](const int kd, const int i, float4 &rv, int &rb) {
+    rb = -1;
+    if (i >= c[kd][7]) return;
+    int b = 0;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) b += (k < ks && i >= c[kd][k]) ? 1 : 0;
+    int cb = 0;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) cb = (k == b) ? c[kd][k] : cb;
+    rb = b;
+    rv = a.rec[base_g[kd] + (int64_t)((bin0 + b) * kHalves + half) * cap[kd] + (i - cb)];
+  };
+  auto settle = [&](uint32_t *dist, uint32_t *id, const int ad, const uint32_t db, const uint32_t cid) {
+    const uint32_t cur = dist[ad];
+    if (db <= cur + 8u) {  // within a few ulp of the minimal d2
+      bool win = db == cur && __uint_as_float(db) < d2_in;
+      if (!win) {
+        const float dd = pitch * sqrtf(__uint_as_float(db));
+        const float dmin = pitch * sqrtf(__uint_as_float(cur));
+        win = dd == dmin && dd < trunc;
+      }
+      if (win) atomicMin(&id[ad], cid);
+    }
+  };
+  // the two-pass (min, arg-min) of k_icc_tile, on the LDS arrays of grid kd
+  auto visit = [&](const int pass, const int kd, const float4 sv, const int rb, const unsigned mask) -> unsigned {
+    uint32_t *dist = s_dist + kd * nvh, *id = s_id + kd * nvh;
+    const int iry = (int)roundf(sv.y), irz = (int)roundf(sv.z);
+    const uint32_t idb = __float_as_uint(sv.w) * (uint32_t)K;
+    const int bb = ks - 1 - rb;
+    const float dx = sv.x - fxp;
+    const float dx2 = dx * dx;
+    unsigned out = 0u;
+    if constexpr (KS == 3) {
+      if (pass == 1) {
+        uint32_t db[9], cur[9];
+        int ad[9];
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) {
+          const int iy = iry + aa - 1;
+          const float dy = sv.y - (float)iy;
+          const float dxy = dx2 + dy * dy;
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            const int iz = irz + cc - 1;
+            const float dz = sv.z - (float)iz;
+            const float d2 = dxy + dz * dz;
+            const bool ok = iy >= y0 && iy < y1 && iz >= 0 && iz < D && d2 < d2_hi;
+            db[aa * 3 + cc] = __float_as_uint(d2);
+            ad[aa * 3 + cc] = ok ? (iy - y0) * D + iz : -1;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cur[k] = dist[ad[k] < 0 ? 0 : ad[k]];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          if (ad[k] < 0) continue;
+          if (db[k] <= cur[k]) atomicMin(&dist[ad[k]], db[k]);
+          if (db[k] <= cur[k] + 8u) out |= 1u << k;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          if (!((mask >> k) & 1u)) continue;
+          const int aa = k / 3, cc = k % 3;
+          const int iy = iry + aa - 1, iz = irz + cc - 1;
+          const float dy = sv.y - (float)iy, dz = sv.z - (float)iz;
+          const float d2 = (dx2 + dy * dy) + dz * dz;
+          settle(dist, id, (iy - y0) * D + iz, __float_as_uint(d2), idb + (uint32_t)((aa * 3 + bb) * 3 + cc));
+        }
+      }
+    } else {
+      for (int aa = 0; aa < ks; ++aa) {
+        const int iy = iry + aa - h;
+        if (iy < y0 || iy >= y1) continue;
+        const float dy = sv.y - (float)iy;
+        const float dxy = dx2 + dy * dy;
+        const int lrow = (iy - y0) * D;
+        for (int cc = 0; cc < ks; ++cc) {
+          const int iz = irz + cc - h;
+          if (iz < 0 || iz >= D) continue;
+          const float dz = sv.z - (float)iz;
+          const float d2 = dxy + dz * dz;
+          if (!(d2 < d2_hi)) continue;
+          const uint32_t db = __float_as_uint(d2);
+          if (pass == 1) {
+            const uint32_t cur = dist[lrow + iz];
+            if (db <= cur) atomicMin(&dist[lrow + iz], db);
+            if (db <= cur + 8u) out = 1u;
+          } else {
+            settle(dist, id, lrow + iz, db, idb + (uint32_t)((aa * ks + bb) * ks + cc));
+          }
+        }
+      }
+    }
+    return out;
+  };
+  auto full_mask = [&](const float4 &sv) -> unsigned {  // streamed records carry no pass-1 mask
+    if constexpr (KS == 3) {
+      const int iry = (int)roundf(sv.y), irz = (int)roundf(sv.z);
+      unsigned m9 = 0u;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int iy = iry + k / 3 - 1, iz = irz + k % 3 - 1;
+        const float dxs = sv.x - fxp, dy = sv.y - (float)iy, dz = sv.z - (float)iz;
+        const float d2 = (dxs * dxs + dy * dy) + dz * dz;
+        if (iy >= y0 && iy < y1 && iz >= 0 && iz < D && d2 < d2_hi) m9 |= 1u << k;
+      }
+      return m9;
+    } else {
+      return 1u;
+    }
+  };
+
+  // kept records: kFusedKeepOwn per lane of the own grid, kFusedKeepOth of the other grid, all
+  // loads in flight at once (ONE memory round trip); more crowded tiles stream the rest twice
+  float4 rvo[kFusedKeepOwn], rvk[kFusedKeepOth];
+  int rbo[kFusedKeepOwn], rbk[kFusedKeepOth];
+  unsigned long long keep = 0ull;  // 9 bits per kept record
+#pragma unroll
+  for (int u = 0; u < kFusedKeepOwn; ++u) fetch(0, u * kTileThreads + (int)threadIdx.x, rvo[u], rbo[u]);
+#pragma unroll
+  for (int u = 0; u < kFusedKeepOth; ++u) fetch(1, u * kTileThreads + (int)threadIdx.x, rvk[u], rbk[u]);
+  stamp(1);
+#pragma unroll
+  for (int u = 0; u < kFusedKeepOwn; ++u)
+    if (rbo[u] >= 0) keep |= (unsigned long long)visit(1, 0, rvo[u], rbo[u], 0u) << (9 * u);
+#pragma unroll
+  for (int u = 0; u < kFusedKeepOth; ++u)
+    if (rbk[u] >= 0) keep |= (unsigned long long)visit(1, 1, rvk[u], rbk[u], 0u) << (9 * (kFusedKeepOwn + u));
+  auto stream_rest = [&](const int pass) {
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd) {
+      const int first = kTileThreads * (kd == 0 ? kFusedKeepOwn : kFusedKeepOth);
+      for (int base = first; base < c[kd][7]; base += kTileThreads * kTileR) {
+        float4 xv[kTileR];
+        int xb[kTileR];
+#pragma unroll
+        for (int u = 0; u < kTileR; ++u) fetch(kd, base + u * kTileThreads + (int)threadIdx.x, xv[u], xb[u]);
+#pragma unroll
+        for (int u = 0; u < kTileR; ++u) {
+          if (xb[u] < 0) continue;
+          if (pass == 1) {
+            visit(1, kd, xv[u], xb[u], 0u);
+          } else {
+            const unsigned m9 = full_mask(xv[u]);
+            if (m9 != 0u) visit(2, kd, xv[u], xb[u], m9);
+          }
+        }
+      }
+    }
+  };
+  stream_rest(1);
+  __syncthreads();
+  stamp(2);
+#pragma unroll
+  for (int u = 0; u < kFusedKeepOwn; ++u) {
+    const unsigned m9 = (unsigned)(keep >> (9 * u)) & 0x1ffu;
+    if (m9 != 0u) visit(2, 0, rvo[u], rbo[u], m9);
+  }
+#pragma unroll
+  for (int u = 0; u < kFusedKeepOth; ++u) {
+    const unsigned m9 = (unsigned)(keep >> (9 * (kFusedKeepOwn + u))) & 0x1ffu;
+    if (m9 != 0u) visit(2, 1, rvk[u], rbk[u], m9);
+  }
+  stream_rest(2);
+  __syncthreads();
+  stamp(3);
+
+  // ---- voxel phase: one lane per voxel of the half-plane (loop for grids larger than 32^3)
+  const float *Rt_o = s_Rt[o - ja];
+  float wmax_own = 0.0f, wmax_oth = 0.0f;
+  constexpr int kRows = kTileThreads / 16;
+  for (int i = threadIdx.x; i < kRows * (kNumF + 1); i += kTileThreads) (&s_rows[0][0])[i] = 0.0f;
+  __syncthreads();
+  int ecol = -1;       // (one voxel per lane per round; rounds > 1 only for D > 32)
+  float cv[12];
+  for (int v0 = 0; v0 < nvox; v0 += kTileThreads) {
+    const int vi = v0 + (int)threadIdx.x;
+    const bool live = vi < nvox;
+    float ne = ne0, tg = tg0;
+    if (v0 > 0 && live) {
+      const int64_t gv = (int64_t)o * V + ((int64_t)x * D + y0) * D + vi;
+      ne = a.grid_ne[gv];
+      tg = a.grid_target[gv];
+    }
+    const uint32_t lo = live ? s_id[vi] : kNoCand, lo_o = live ? s_id[nvh + vi] : kNoCand;
+    const bool has = lo != kNoCand, has_o = lo_o != kNoCand;
+    const float4 m_own = has ? a.pts4[lo / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
+    const float4 m_oth = has_o ? a.pts4[lo_o / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
+    const float dist_o = has ? pitch * sqrtf(__uint_as_float(s_dist[vi])) : trunc;
+    const float dist_k = has_o ? pitch * sqrtf(__uint_as_float(s_dist[nvh + vi])) : trunc;
+    const int iy = y0 + vi / D, iz = vi % D;
+    const float g = 1.0f - dist_o / trunc;  // 1 - tdf/trunc
+    float w = m_own.w + a.sdf_offset;
+    const bool neg = w < 0.0f;
+    if (neg) w = 0.0f;
+    const float go = 1.0f - dist_k / trunc;
+    float wo = m_oth.w + 0.0f;
+    if (wo < 0.0f) wo = 0.0f;
+    if (live) { wmax_own = fmaxf(wmax_own, w); wmax_oth = fmaxf(wmax_oth, wo); }
+    const float gw = g * w;
+    const float gwo = (1.0f - ne) * (go * wo);  // (1 - ne) * go * wo: the part that needs b
+    float val[kNumF];
+    val[0] = (live && !neg) ? g * tg : 0.0f;
+    val[1] = live ? gw * tg : 0.0f;
+    val[2] = live ? gw : 0.0f;
+    val[3] = live ? gw * ne : 0.0f;
+    val[4] = live ? gw * gwo : 0.0f;
+#pragma unroll
+    for (int k = 5; k < kNumF; ++k) val[k] = 0.0f;
+    if (live && has) {
+      float ux, uy, uz;
+      bool ok;
+      world_frac(Rt_o, m_own, ox, oy, oz, pitch, x, iy, iz, ux, uy, uz, ok);
+      if (ok) {
+        const float kk[5] = {neg ? 0.0f : tg / trunc, w * tg / trunc, w * ne / trunc, w * gwo / trunc, w / trunc};
+        const float u[3] = {ux, uy, uz};
+#pragma unroll
+        for (int sset = 0; sset < 5; ++sset)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const float sc = u[d] * kk[sset];
+            val[5 + 12 * sset + 4 * d + 0] = sc * m_own.x;
+            val[5 + 12 * sset + 4 * d + 1] = sc * m_own.y;
+            val[5 + 12 * sset + 4 * d + 2] = sc * m_own.z;
+            val[5 + 12 * sset + 4 * d + 3] = sc;
+          }
+      }
+    }
+    // row sums straight into LDS (one lane per 16-lane row adds; rounds accumulate)
+#pragma unroll
+    for (int k = 0; k < kNumF; ++k) {
+      const float r = mf::row16_sum(val[k]);
+      if ((threadIdx.x & 15) == 0) s_rows[threadIdx.x >> 4][k] += r;
+    }
+    // collision term: gradient flows to the OTHER object's pose (kept for the reduction below;
+    // with more than one round per lane only the last colliding voxel is kept -> D <= 32 only)
+    if (live && ne == 0.0f && has_o && go * wo > 0.0f && gw != 0.0f) {
+      const uint32_t p = lo_o / (uint32_t)K;
+      int e = 0;
+      while (e + 1 < Ns && (int)p >= s_off[e + 1]) ++e;
+      float ux, uy, uz;
+      bool ok;
+      world_frac(s_Rt[e], m_oth, ox, oy, oz, pitch, x, iy, iz, ux, uy, uz, ok);
+      const float B = wo * gw / trunc;
+      if (ok && isfinite(B)) {
+        const float u[3] = {ux, uy, uz};
+        ecol = e;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const float sB = u[d] * B;
+          cv[4 * d + 0] = sB * m_oth.x;
+          cv[4 * d + 1] = sB * m_oth.y;
+          cv[4 * d + 2] = sB * m_oth.z;
+          cv[4 * d + 3] = sB;
+        }
+      }
+    }
+  }
+  if (ecol >= 0) atomicOr(&s_emask, 1u << ecol);
+  // per-grid maxima of the raw inside weights (the normalisers a, b of the step)
+  wmax_own = mf::wave_max(wmax_own);
+  wmax_oth = mf::wave_max(wmax_oth);
+  if ((threadIdx.x & 63) == 0) { s_max[0][threadIdx.x >> 6] = wmax_own; s_max[1][threadIdx.x >> 6] = wmax_oth; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    float m = s_max[threadIdx.x][0];
+#pragma unroll
+    for (int i = 1; i < kTileThreads / 64; ++i) m = fmaxf(m, s_max[threadIdx.x][i]);
+    if (m > 0.0f) atomicMax(&a.Mbits[(int64_t)par * 2 * a.O + 2 * o + threadIdx.x], __float_as_uint(m));
+  }
+  long long *own = a.acc_own + ((int64_t)par * a.O + o) * kOwnSlots;
+  if (threadIdx.x < kNumF) {
+    float sacc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) sacc += s_rows[r][threadIdx.x];
+    if (isfinite(sacc)) {
+      const long long xq = __double2ll_rn((double)sacc * kFixOwn);
+      if (xq != 0) atomicAdd(reinterpret_cast<unsigned long long *>(own + threadIdx.x), (unsigned long long)xq);
+    } else {
+      atomicAdd(reinterpret_cast<unsigned long long *>(own + kNumF), 1ull);  // -> NaN loss
+    }
+  }
+  stamp(4);
+  long long *po = a.acc_oth + ((int64_t)par * a.O + o) * a.max_ns * 12;
+  const uint32_t em0 = s_emask;
+  for (uint32_t em = em0; em != 0u; em &= em - 1u) {
+    const int e = __ffs((int)em) - 1;
+#pragma unroll
+    for (int cc = 0; cc < 12; ++cc) {
+      const float r = mf::row16_sum(ecol == e ? cv[cc] : 0.0f);
+      if ((threadIdx.x & 15) == 0) s_rows2[(e * kRows + (threadIdx.x >> 4)) * 13 + cc] = r;
+    }
+  }
+  if (em0 == 0u) return;  // block-uniform
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.max_ns * 12; i += kTileThreads) {
+    const int e = i / 12, cc = i - 12 * e;
+    if (!((em0 >> e) & 1u)) continue;
+    float sacc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) sacc += s_rows2[(e * kRows + r) * 13 + cc];
+    const long long xq = isfinite(sacc) ? __double2ll_rn((double)sacc * kFixOth) : 0;
+    if (xq != 0) atomicAdd(reinterpret_cast<unsigned long long *>(po + i), (unsigned long long)xq);
+  }
+}
+
+__global__ __launch_bounds__(kTileThreads, 4) void k_icc_fused(IccArgs a, int par) {  // 2 workgroups per CU
+  const int ks = min(ksize_of(a.thr, a.pitch[blockIdx.y]), 2 * a.hmax + 1);  // block-uniform
+  if (ks == 3)
+    icc_fused_body<3>(a, 3, par);
+  else
+    icc_fused_body<0>(a, ks, par);
+}
+
 // ---- the step as a kernel of its own: one 64-lane workgroup per object ----------------
 // mode 1: after the last iteration of mf_icc_refine.  mode 2: mf_icc_loss_grad (loss, gq, gt).
 __global__ __launch_bounds__(64) void k_icc_step(IccArgs a, IccStepArgs sp) {
@@ -1073,7 +1559,10 @@ __global__ __launch_bounds__(64) void k_icc_step(IccArgs a, IccStepArgs sp) {
                  : (sp.mode == 1 ? (i < 14 ? sp.m_in[7 * j + i - 7] : sp.v_in[7 * j + i - 14]) : 0.0f);
   }
   const float S_t = a.St[sc];
-  icc_step_gather<64>(a, sp.par, j, ja, Ns, s_raw, s_sum);
+  if (sp.fused)
+    icc_step_gather_fused<64>(a, sp.par, j, ja, Ns, s_raw, s_sum);
+  else
+    icc_step_gather<64>(a, sp.par, j, ja, Ns, s_raw, s_sum);
   if (threadIdx.x != 0) return;
   float Rt[12], st_new[kStateFloats], loss, gq[4], gt[3];
   icc_step_apply(s_sum, S_t, s_state, sp, Rt, st_new, loss, gq, gt);
@@ -1129,7 +1618,7 @@ WsLayout ws_layout(const mfIccBatch *b) {
   l.n_tab = (int)(((int64_t)max_ns * b->n_points + kBinChunk - 1) / kBinChunk) + O * max_ns + O;
   int64_t off = 0;
   l.W = off; off = align256(off + 2 * O * V * 8);
-  l.M = off; off = align256(off + 2 * O * 4);
+  l.M = off; off = align256(off + 2 * 2 * O * 4);
   l.Rt = off; off = align256(off + O * 12 * 4);
   l.bound = off; off = align256(off + O * 4 * 4);
   l.St = off; off = align256(off + S * 4);
@@ -1139,7 +1628,7 @@ WsLayout ws_layout(const mfIccBatch *b) {
   l.meta = off; off = align256(off + (int64_t)O * 16);
   l.tab = off; off = align256(off + (int64_t)l.n_tab * 16);
   l.tab2 = off; off = align256(off + (int64_t)l.n_tab * 16);
-  l.bin_cnt = off; off = align256(off + (int64_t)2 * O * l.nbins * 4);
+  l.bin_cnt = off; off = align256(off + (int64_t)2 * 2 * O * l.nbins * 4);
   l.bin_cap = off; off = align256(off + (int64_t)2 * O * 4);
   l.bin_base = off; off = align256(off + (int64_t)2 * O * 8);
   // a grid's bins hold <= (its source points) records each: sum over grids of a scene
@@ -1165,6 +1654,10 @@ IccArgs make_args(const mfIccBatch *b, void *ws) {
   a.thr = b->voxel_threshold;
   a.sdf_offset = b->sdf_offset;
   a.max_ns = b->max_scene_objects;
+  // single pass only for {0,1} no-entry grids, one voxel of a half-plane per lane, and unless
+  // MF_ICC_GENERAL=1 asks for the two-kernel path (A/B measurements)
+  a.ne_binary = b->grid_ne_binary != 0 && ((b->dim + 1) / 2) * b->dim <= kTileThreads &&
+                !(getenv("MF_ICC_GENERAL") && atoi(getenv("MF_ICC_GENERAL")) != 0);
   a.dbg = getenv("MF_ICC_DEBUG") ? atoi(getenv("MF_ICC_DEBUG")) : 0;
   const WsLayout l = ws_layout(b);
   char *p = (char *)ws;
@@ -1189,17 +1682,22 @@ IccArgs make_args(const mfIccBatch *b, void *ws) {
   return a;
 }
 
-// bin (+ the previous iteration's step when sp.mode == 1) -> tile
-void launch_front(const IccArgs &a, const IccStepArgs &sp, hipStream_t stream) {
-  const int D = a.D;
+// One iteration k (counters / accumulators / maxima of parity k & 1): bin (+ the previous
+// iteration's step when sp.mode == 1), then either the single-pass kernel or tile -> accum.
+void launch_iteration(const IccArgs &a, IccStepArgs sp, int NB, int k, hipStream_t stream) {
+  const int D = a.D, par = k & 1;
+  sp.cpar = par;
+  sp.fused = a.ne_binary;
   hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, sp);
-  const size_t lds = (size_t)((D + 1) / 2) * D * 2 * sizeof(uint32_t);  // 4 KB at D = 32
-  hipLaunchKernelGGL(k_icc_tile, dim3(D * kHalves, 2 * a.O), dim3(kTileThreads), lds, stream, a);
-}
-
-void launch_accum(const IccArgs &a, int NB, int par, hipStream_t stream) {
-  const size_t lds = (size_t)a.max_ns * (kAccThreads / 16) * 13 * sizeof(float);  // <= 53 KB
-  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), lds, stream, a, par);
+  const size_t lds_tile = (size_t)((D + 1) / 2) * D * 2 * sizeof(uint32_t);  // 4 KB at D = 32
+  const size_t lds_rows2 = (size_t)a.max_ns * (kAccThreads / 16) * 13 * sizeof(float);  // <= 53 KB
+  if (a.ne_binary) {
+    hipLaunchKernelGGL(k_icc_fused, dim3(D * kHalves, a.O), dim3(kTileThreads), 2 * lds_tile + lds_rows2, stream,
+                       a, par);
+    return;
+  }
+  hipLaunchKernelGGL(k_icc_tile, dim3(D * kHalves, 2 * a.O), dim3(kTileThreads), lds_tile, stream, a, par);
+  hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), lds_rows2, stream, a, par);
 }
 
 // chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once
@@ -1239,6 +1737,7 @@ extern "C" int mf_pack_points_sdf(const float *points, const float *sdf, int64_t
 }
 
 static int icc_validate(const mfIccBatch *b) {
+  if (int e = mf::allow_big_lds((const void *)k_icc_fused, 80 * 1024)) return e;
   if (!icc_batch_ok(b)) {
     mf::set_last_error(hipErrorInvalidValue, "mf_icc: invalid batch descriptor");
     return -(int)hipErrorInvalidValue;
@@ -1264,9 +1763,17 @@ extern "C" int mf_icc_launch_stage(const mfIccBatch *batch, const float *q, cons
     hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, sp);
   } else if (stage == 1) {
     const size_t lds = (size_t)((D + 1) / 2) * D * 2 * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_icc_tile, dim3(D * kHalves, 2 * a.O), dim3(kTileThreads), lds, stream, a);
+    hipLaunchKernelGGL(k_icc_tile, dim3(D * kHalves, 2 * a.O), dim3(kTileThreads), lds, stream, a, 0);
+  } else if (stage == 2) {
+    if (!a.ne_binary) {
+      mf::set_last_error(hipErrorInvalidValue, "mf_icc_launch_stage: stage 2 needs {0,1} no-entry grids");
+      return -(int)hipErrorInvalidValue;
+    }
+    const size_t lds = (size_t)((D + 1) / 2) * D * 4 * sizeof(uint32_t) +
+                       (size_t)a.max_ns * (kAccThreads / 16) * 13 * sizeof(float);
+    hipLaunchKernelGGL(k_icc_fused, dim3(D * kHalves, a.O), dim3(kTileThreads), lds, stream, a, 0);
   } else {
-    mf::set_last_error(hipErrorInvalidValue, "mf_icc_launch_stage: stage must be 0 or 1");
+    mf::set_last_error(hipErrorInvalidValue, "mf_icc_launch_stage: stage must be 0, 1 or 2");
     return -(int)hipErrorInvalidValue;
   }
   return mf::check_launch("mf_icc_launch_stage");
@@ -1291,10 +1798,10 @@ extern "C" int mf_icc_loss_grad(const mfIccBatch *batch, const float *q, const f
   const WsLayout l = ws_layout(batch);
   hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t, (float *)nullptr);
   IccStepArgs none = {};
-  launch_front(a, none, stream);
-  launch_accum(a, l.NB, 0, stream);
+  launch_iteration(a, none, l.NB, 0, stream);
   IccStepArgs sp = {};
   sp.mode = 2;
+  sp.fused = a.ne_binary;
   sp.par = 0;
   sp.q_in = q;
   sp.t_in = t;
@@ -1331,7 +1838,7 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
   key.v.push_back(((uint64_t)(uint32_t)n_iter << 32) | (uint32_t)step0);
   int dev = 0;
   MF_TRY(hipGetDevice(&dev));
-  key.v.push_back(((uint64_t)(uint32_t)dev << 32) | (uint32_t)max_ns);
+  key.v.push_back(((uint64_t)(uint32_t)dev << 32) | ((uint32_t)max_ns << 1) | (uint32_t)a.ne_binary);
 
   std::lock_guard<std::mutex> lock(g_graph_mu);
   auto itg = g_graphs.find(key);
@@ -1366,11 +1873,11 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
         sp.traj = k < n_iter ? traj : nullptr;
       }
       if (k == n_iter) {  // the step of the last iteration, as a kernel of its own
+        sp.fused = a.ne_binary;
         hipLaunchKernelGGL(k_icc_step, dim3(a.O), dim3(64), 0, cap, a, sp);
         break;
       }
-      launch_front(a, sp, cap);
-      launch_accum(a, l.NB, k & 1, cap);
+      launch_iteration(a, sp, l.NB, k, cap);
     }
     hipError_t ce = hipStreamEndCapture(cap, &graph);
     if (ce != hipSuccess) {

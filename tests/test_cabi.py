@@ -33,13 +33,13 @@ def test_icc_batch_struct_matches_header():
     body = text[text.index("typedef struct {"):text.index("} mfIccBatch;")]
     fields = re.findall(r"\b(\w+);", body)
     assert fields == [f[0] for f in mf._lib.IccBatch._fields_]
-    assert ctypes.sizeof(mf._lib.IccBatch) == 8 * 8 + 5 * 4 + 2 * 4 + 4  # incl. tail padding
+    assert ctypes.sizeof(mf._lib.IccBatch) == 8 * 8 + 5 * 4 + 2 * 4 + 4
 
 
 def test_workspace_size_is_host_only_arithmetic():
     def desc(n_objects, n_scenes, n_points, max_ns, thr=2.0):
         return mf._lib.IccBatch(None, None, None, None, None, None, None, None, n_objects, n_scenes,
-                                n_points, 32, max_ns, thr, 0.0)
+                                n_points, 32, max_ns, thr, 0.0, 1)
     ws = mf._lib.lib().mf_icc_workspace_bytes
     n = ws(ctypes.byref(desc(8, 1, 28000, 8)))
     # winners of 16 grids + the x-plane bins (34 planes x 8 grids' worth of point records)

@@ -25,6 +25,13 @@ def lib():
     return emul.build(["icc.hip"])
 
 
+@pytest.fixture(params=[1, 0], ids=["single_pass", "two_kernel"])
+def sp(request):
+    """Both iteration layouts: k_icc_bin -> k_icc_fused (the {0,1} no-entry grids every caller
+    passes) and k_icc_bin -> k_icc_tile -> k_icc_accum (any grid values)."""
+    return request.param
+
+
 def _dict(sc):
     return dict(points=sc["points"], sdf=sc["sdf"], pitch=sc["pitch"], origin=sc["origin"],
                 grid_target=sc["grid_target"], grid_nontarget_empty=sc["grid_nontarget_empty"])
@@ -40,9 +47,9 @@ def _pose0(sc):
     return q, t
 
 
-def test_icc_kernel_source_loss_and_grad_vs_oracle(lib, fixtures3):
+def test_icc_kernel_source_loss_and_grad_vs_oracle(lib, fixtures3, sp):
     sc = synthetic.make_icc_scene(4, seed=0, fixtures=fixtures3)
-    S = emul.EmulIccScenes(lib, [_dict(sc)], sdf_offset=0.02)
+    S = emul.EmulIccScenes(lib, [_dict(sc)], sdf_offset=0.02, single_pass=sp)
     q0, t0 = _pose0(sc)
     loss, gq, gt = S.loss_grad(q0, t0)
     l_o, gq_o, gt_o, _ = OC.icc_loss_grad(*_args(sc), q0, t0, sdf_offset=0.02)
@@ -56,7 +63,7 @@ def test_icc_kernel_source_loss_and_grad_vs_oracle(lib, fixtures3):
     np.testing.assert_array_equal(gt, gt2)
 
 
-def test_icc_kernel_source_refine_teacher_forced_vs_oracle(lib, fixtures3):
+def test_icc_kernel_source_refine_teacher_forced_vs_oracle(lib, fixtures3, sp=1):
     """One fused step (bin -> tile -> accum -> step, captured in a graph) from the oracle's state
     at iteration k lands on the oracle's iterate k+1 (same pin as the GPU test)."""
     n, iters = 3, 4
@@ -64,7 +71,7 @@ def test_icc_kernel_source_refine_teacher_forced_vs_oracle(lib, fixtures3):
     q0, t0 = _pose0(sc)
     _, _, losses_o, traj_o, hist_o = OC.icc_refine(*_args(sc), q0, t0, n_iter=iters, sdf_offset=0.02,
                                                   return_adam=True)
-    S = emul.EmulIccScenes(lib, [_dict(sc)], sdf_offset=0.02)
+    S = emul.EmulIccScenes(lib, [_dict(sc)], sdf_offset=0.02, single_pass=sp)
     for k in range(iters - 1):
         q, t = traj_o[k, :, :4].copy(), traj_o[k, :, 4:].copy()
         m, v = hist_o[k, 0].copy(), hist_o[k, 1].copy()
@@ -80,14 +87,14 @@ def test_icc_kernel_source_refine_teacher_forced_vs_oracle(lib, fixtures3):
     np.testing.assert_allclose(losses[:, 0], losses_o[:3], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("thr", [3, 4])
-def test_icc_kernel_source_ragged_scenes_and_wider_kernel(lib, thr):
+@pytest.mark.parametrize("thr,sp", [(3, 0), (4, 1)])
+def test_icc_kernel_source_ragged_scenes_and_wider_kernel(lib, thr, sp):
     """Scenes of 1 and 3 objects in one batch (ragged tables, a scene without any 'other' grid)
     and wider TDF kernels (truncated_distance_function.py:36-38, ceil(truncation / pitch) in
     float32 made odd): threshold 4 -> kernel size 5 for every grid; threshold 3 -> 3 or 5
     depending on how 3 * pitch / pitch rounds for each grid's pitch, as in the reference."""
     scenes = [synthetic.make_icc_scene(n, seed=20 + n) for n in (1, 3)]
-    S = emul.EmulIccScenes(lib, [_dict(s) for s in scenes], voxel_threshold=thr, sdf_offset=0.02)
+    S = emul.EmulIccScenes(lib, [_dict(s) for s in scenes], voxel_threshold=thr, sdf_offset=0.02, single_pass=sp)
     q0 = np.concatenate([_pose0(s)[0] for s in scenes])
     t0 = np.concatenate([_pose0(s)[1] for s in scenes])
     loss, gq, gt = S.loss_grad(q0, t0)
@@ -102,14 +109,14 @@ def test_icc_kernel_source_ragged_scenes_and_wider_kernel(lib, thr):
         lo += n
 
 
-@pytest.mark.parametrize("n_iter", [2, 3])
-def test_icc_kernel_source_loop_equals_single_steps(lib, n_iter):
+@pytest.mark.parametrize("n_iter,sp", [(2, 0), (3, 1)])
+def test_icc_kernel_source_loop_equals_single_steps(lib, n_iter, sp):
     """The n_iter loop (optimiser step folded into the next iteration's binning kernel, state
     ping-ponging between the caller's arrays and the workspace copy, last step as its own
     kernel) walks exactly the iterates of n_iter one-iteration calls, for even and odd n_iter;
     losses[k] and traj[k] (pose BEFORE step k) land in the right rows."""
     scenes = [synthetic.make_icc_scene(n, seed=30 + n) for n in (2, 1)]
-    S = emul.EmulIccScenes(lib, [_dict(s) for s in scenes], sdf_offset=0.02)
+    S = emul.EmulIccScenes(lib, [_dict(s) for s in scenes], sdf_offset=0.02, single_pass=sp)
     q0 = np.concatenate([_pose0(s)[0] for s in scenes])
     t0 = np.concatenate([_pose0(s)[1] for s in scenes])
     q, t = q0.copy(), t0.copy()
@@ -152,11 +159,29 @@ def _lattice_tie_scene():
                 transform_init=T)
 
 
-def test_icc_kernel_source_exact_distance_ties(lib, fixtures3):
+def test_icc_kernel_source_exact_distance_ties(lib, fixtures3, sp):
     """Exact distance ties in (almost) every voxel: the winner is decided by the lowest-candidate-id
     rule of pass 2 alone; loss and gradients depend on it through the random sdf."""
     sc = _lattice_tie_scene()
+    S = emul.EmulIccScenes(lib, [_dict(sc)], sdf_offset=0.02, single_pass=sp)
+    q0, t0 = _pose0(sc)
+    loss, gq, gt = S.loss_grad(q0, t0)
+    l_o, gq_o, gt_o, _ = OC.icc_loss_grad(*_args(sc), q0, t0, sdf_offset=0.02)
+    np.testing.assert_allclose(loss[0], l_o, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(gq, gq_o, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(gt, gt_o, rtol=2e-3, atol=2e-4)
+
+
+def test_icc_kernel_source_fractional_no_entry_grid_takes_the_two_kernel_path(lib, fixtures3):
+    """A no-entry grid with values strictly between 0 and 1 (maximum(no-entry, other) is then a
+    genuine comparison against the normalised other-grid, iterative_collision_check_link.py:83-85):
+    the wrapper detects it and the two-kernel path reproduces the oracle."""
+    sc = synthetic.make_icc_scene(3, seed=0, fixtures=fixtures3)
+    rs = np.random.RandomState(0)
+    sc = dict(sc)
+    sc["grid_nontarget_empty"] = (sc["grid_nontarget_empty"] * rs.uniform(0.05, 1.0, sc["grid_nontarget_empty"].shape)).astype(np.float32)
     S = emul.EmulIccScenes(lib, [_dict(sc)], sdf_offset=0.02)
+    assert S.desc.grid_ne_binary == 0
     q0, t0 = _pose0(sc)
     loss, gq, gt = S.loss_grad(q0, t0)
     l_o, gq_o, gt_o, _ = OC.icc_loss_grad(*_args(sc), q0, t0, sdf_offset=0.02)
