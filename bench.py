@@ -262,23 +262,33 @@ def roofline_icc(wl, us_per_iter):
     stream = mf._lib.stream_ptr()
     mf._lib.check(lib.mf_icc_launch_stage(ctypes.byref(icc.desc), wl.q0.data_ptr(), wl.t0.data_ptr(),
                                           icc.ws.data_ptr(), 0, stream), "mf_icc_launch_stage")
+    single_pass = bool(icc.desc.grid_ne_binary) and not os.environ.get("MF_ICC_GENERAL")
+    stage = 2 if single_pass else 1
+    mf._lib.check(lib.mf_icc_launch_stage(ctypes.byref(icc.desc), None, None, icc.ws.data_ptr(), stage, stream),
+                  "mf_icc_launch_stage")
     ms = time_kernel_live(lambda: lib.mf_icc_launch_stage(ctypes.byref(icc.desc), None, None,
-                                                          icc.ws.data_ptr(), 1, stream), 200)
+                                                          icc.ws.data_ptr(), stage, stream), 200)
     pts_bytes, grid_bytes = _icc_algorithmic_bytes(icc)
-    achieved = pts_bytes / (ms * 1e-3) / 1e9
-    traffic = None  # PMC passes committed under profiles/ (tools/prof_icc_pmc.sh), same scene
+    # k_icc_fused reads the points of every (grid, source) pair once and the two input grids;
+    # k_icc_tile (two-kernel path) only the points
+    alg = pts_bytes + grid_bytes if single_pass else pts_bytes
+    kname = "k_icc_fused" if single_pass else "k_icc_tile"
+    achieved = alg / (ms * 1e-3) / 1e9
+    traffic = None  # PMC passes committed under profiles/ (tools/r02_profiles.sh), same scene
     pmc = os.path.join(ROOT, "profiles", "r02_icc_pmc.json")
     if os.path.exists(pmc):
-        rec = json.load(open(pmc)).get("k_icc_tile")
+        rec = json.load(open(pmc)).get(kname)
         if rec and rec["n_objects"] == icc.n_objects and rec["n_points"] == icc.n_points:
             traffic = rec["traffic_bytes"]
     it_bytes = 2 * (pts_bytes + grid_bytes)
     it_achieved = it_bytes / (us_per_iter * 1e-6) / 1e9
-    return dict(kernel="k_icc_tile (launch 2 of 3 per ICC iteration; mf_icc_refine)", bound="hbm",
+    return dict(kernel=(f"{kname} (launch 2 of 2 per ICC iteration; mf_icc_refine)" if single_pass else
+                        f"{kname} (launch 2 of 3 per ICC iteration; mf_icc_refine)"), bound="hbm",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                algorithmic_bytes_per_launch=pts_bytes, avg_launch_ms=round(ms, 5),
-                iteration=dict(kernels="k_icc_bin (+ folded optimiser step) + k_icc_tile + k_icc_accum",
+                algorithmic_bytes_per_launch=alg, avg_launch_ms=round(ms, 5),
+                iteration=dict(kernels="k_icc_bin (+ folded optimiser step) + " +
+                                       ("k_icc_fused" if single_pass else "k_icc_tile + k_icc_accum"),
                                algorithmic_bytes=it_bytes, us=round(us_per_iter, 3),
                                achieved=round(it_achieved, 1), frac=round(it_achieved / HBM_PEAK_GBS, 4)),
                 note="L2-resident working set; latency / instruction-issue bound (DESIGN.md 4)")
