@@ -406,11 +406,20 @@ __device__ __forceinline__ void icc_step_gather_fused(const IccArgs &a, int par,
   }
   __syncthreads();
   auto f_own = [&](long long x) { return (float)((double)x * (1.0 / kFixOwn)); };
-  auto a_of = [&](int jo) { return 1.0f / __uint_as_float((uint32_t)s_raw[8 * jo + 6]); };
-  auto b_of = [&](int jo) {
-    const float M = __uint_as_float((uint32_t)s_raw[8 * jo + 7]);
-    return (Ns > 1 && M != 0.0f) ? 1.0f / M : 0.0f;
-  };
+  // a, b of every scene object once (IEEE divides off the summing lanes' critical path); they
+  // overwrite the raw M words (slots 6, 7 of the object) as float bits
+  if (threadIdx.x < Ns) {
+    const int jo = threadIdx.x;
+    const float Mo = __uint_as_float((uint32_t)s_raw[8 * jo + 6]);
+    const float Mk = __uint_as_float((uint32_t)s_raw[8 * jo + 7]);
+    const float av = 1.0f / Mo;
+    const float bv = (Ns > 1 && Mk != 0.0f) ? 1.0f / Mk : 0.0f;
+    s_raw[8 * jo + 6] = (long long)__float_as_uint(av);
+    s_raw[8 * jo + 7] = (long long)__float_as_uint(bv);
+  }
+  __syncthreads();
+  auto a_of = [&](int jo) { return __uint_as_float((uint32_t)s_raw[8 * jo + 6]); };
+  auto b_of = [&](int jo) { return __uint_as_float((uint32_t)s_raw[8 * jo + 7]); };
   if (threadIdx.x < kStepSums) {
     const int l = threadIdx.x;
     const int jj = j - ja;
@@ -1401,19 +1410,12 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   const float *Rt_o = s_Rt[o - ja];
   float wmax_own = 0.0f, wmax_oth = 0.0f;
   constexpr int kRows = kTileThreads / 16;
-  for (int i = threadIdx.x; i < kRows * (kNumF + 1); i += kTileThreads) (&s_rows[0][0])[i] = 0.0f;
-  __syncthreads();
-  int ecol = -1;       // (one voxel per lane per round; rounds > 1 only for D > 32)
+  int ecol = -1;
   float cv[12];
-  for (int v0 = 0; v0 < nvox; v0 += kTileThreads) {
-    const int vi = v0 + (int)threadIdx.x;
+  {  // the host selects this kernel only if a half-plane has <= kTileThreads voxels: one per lane
+    const int vi = (int)threadIdx.x;
     const bool live = vi < nvox;
-    float ne = ne0, tg = tg0;
-    if (v0 > 0 && live) {
-      const int64_t gv = (int64_t)o * V + ((int64_t)x * D + y0) * D + vi;
-      ne = a.grid_ne[gv];
-      tg = a.grid_target[gv];
-    }
+    const float ne = ne0, tg = tg0;
     const uint32_t lo = live ? s_id[vi] : kNoCand, lo_o = live ? s_id[nvh + vi] : kNoCand;
     const bool has = lo != kNoCand, has_o = lo_o != kNoCand;
     const float4 m_own = has ? a.pts4[lo / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
@@ -1458,14 +1460,13 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
           }
       }
     }
-    // row sums straight into LDS (one lane per 16-lane row adds; rounds accumulate)
+    // row sums (DPP, 4 VALU steps each) straight into LDS
 #pragma unroll
     for (int k = 0; k < kNumF; ++k) {
       const float r = mf::row16_sum(val[k]);
-      if ((threadIdx.x & 15) == 0) s_rows[threadIdx.x >> 4][k] += r;
+      if ((threadIdx.x & 15) == 0) s_rows[threadIdx.x >> 4][k] = r;
     }
-    // collision term: gradient flows to the OTHER object's pose (kept for the reduction below;
-    // with more than one round per lane only the last colliding voxel is kept -> D <= 32 only)
+    // collision term: gradient flows to the OTHER object's pose (kept for the reduction below)
     if (live && ne == 0.0f && has_o && go * wo > 0.0f && gw != 0.0f) {
       const uint32_t p = lo_o / (uint32_t)K;
       int e = 0;

@@ -355,3 +355,31 @@ def test_icc_refine_teacher_forced_vs_committed_golden(fixtures3):
             icp.translation.copy_(dev(g["icp_traj"][k, 4:]))
         loss = icp(source, target)
         np.testing.assert_allclose(float(loss.detach()), g["icp_losses"][k], rtol=2e-5)
+
+
+def test_icc_fractional_no_entry_grid_two_kernel_path_vs_oracle(scene8):
+    """No-entry grids with values strictly between 0 and 1: maximum(no-entry, other-occupancy) is a
+    genuine comparison against the NORMALISED other grid (iterative_collision_check_link.py:83-85),
+    the single-pass kernel's polynomial form does not apply; the wrapper detects it at pack time
+    and the tile -> accum path reproduces the oracle.  The {0,1} grids of every other test take the
+    single-pass path (asserted)."""
+    n = 4
+    args = list(scene_args(scene8, n))
+    rs = np.random.RandomState(0)
+    args[5] = (args[5] * rs.uniform(0.05, 1.0, args[5].shape)).astype(np.float32)
+    link = mf.contrib.IterativeCollisionCheckLink(scene8["transform_init"][:n], sdf_offset=0.02).to_gpu()
+    loss = link(*to_dev(args))
+    assert link._scenes.desc.grid_ne_binary == 0
+    loss.backward()
+    q0 = link.quaternion.detach().cpu().numpy()
+    t0 = link.translation.detach().cpu().numpy()
+    l_o, gq_o, gt_o, _ = OC.icc_loss_grad(*args, q0, t0, sdf_offset=0.02)
+    np.testing.assert_allclose(float(loss.detach()), l_o, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(link.quaternion.grad.cpu().numpy(), gq_o, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(link.translation.grad.cpu().numpy(), gt_o, rtol=2e-3, atol=2e-4)
+    losses, _ = link.refine(*to_dev(args), n_iter=5, return_history=True)
+    _, _, losses_o, _ = OC.icc_refine(*args, q0, t0, n_iter=5, sdf_offset=0.02)
+    np.testing.assert_allclose(losses.cpu().numpy()[:3], losses_o[:3], rtol=1e-4, atol=1e-6)
+    binary = mf.contrib.IterativeCollisionCheckLink(scene8["transform_init"][:n], sdf_offset=0.02).to_gpu()
+    binary(*to_dev(scene_args(scene8, n)))
+    assert binary._scenes.desc.grid_ne_binary == 1
