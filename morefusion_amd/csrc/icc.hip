@@ -681,6 +681,7 @@ constexpr int kTileThreads = 512;
 constexpr int kTileKeep = 4;  // records per lane kept in registers over both passes
 constexpr int kTileR = 4;     // records in flight per lane beyond those
 constexpr int kFusedKeepOwn = 2, kFusedKeepOth = 4;  // k_icc_fused: kept records per lane and grid
+constexpr int kFusedVox = 2;                         // voxels per active lane of its voxel phase
 
 template <int KS>
 __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt, const int par) {
@@ -1224,12 +1225,20 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   stamp(0);
   if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)(c[0][7] + c[1][7]);
   // the voxel phase's first-level loads, issued now: this lane's voxel of the two input grids
-  const int vloc = threadIdx.x;  // (D = 32: one voxel per lane; larger grids loop below)
-  float ne0 = 0.0f, tg0 = 0.0f;
-  if (vloc < nvox) {
-    const int64_t gv = (int64_t)o * V + ((int64_t)x * D + y0) * D + vloc;
-    ne0 = a.grid_ne[gv];
-    tg0 = a.grid_target[gv];
+  float ne0[kFusedVox], tg0[kFusedVox];
+  {
+    const int n_act0 = (nvox + kFusedVox - 1) / kFusedVox;
+#pragma unroll
+    for (int u = 0; u < kFusedVox; ++u) {
+      const int vi = (int)threadIdx.x + u * n_act0;
+      ne0[u] = 0.0f;
+      tg0[u] = 0.0f;
+      if ((int)threadIdx.x < n_act0 && vi < nvox) {
+        const int64_t gv = (int64_t)o * V + ((int64_t)x * D + y0) * D + vi;
+        ne0[u] = a.grid_ne[gv];
+        tg0[u] = a.grid_target[gv];
+      }
+    }
   }
   __syncthreads();
   const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test in pass 2
@@ -1406,90 +1415,117 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   __syncthreads();
   stamp(3);
 
-  // ---- voxel phase: one lane per voxel of the half-plane (loop for grids larger than 32^3)
+  // ---- voxel phase.  Its cost is instruction issue (per wave: ~300 instructions of per-voxel
+  // arithmetic + 65 row reductions of ~8), so HALF the lanes take two voxels each: the
+  // reductions are paid once per two voxels (measured: 8 us with one voxel per lane), the
+  // other waves fall through to the barrier.  Waves without any own winner skip the 60 moment
+  // reductions.
   const float *Rt_o = s_Rt[o - ja];
   float wmax_own = 0.0f, wmax_oth = 0.0f;
   constexpr int kRows = kTileThreads / 16;
-  int ecol = -1;
-  float cv[12];
-  {  // the host selects this kernel only if a half-plane has <= kTileThreads voxels: one per lane
-    const int vi = (int)threadIdx.x;
-    const bool live = vi < nvox;
-    const float ne = ne0, tg = tg0;
-    const uint32_t lo = live ? s_id[vi] : kNoCand, lo_o = live ? s_id[nvh + vi] : kNoCand;
-    const bool has = lo != kNoCand, has_o = lo_o != kNoCand;
-    const float4 m_own = has ? a.pts4[lo / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
-    const float4 m_oth = has_o ? a.pts4[lo_o / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
-    const float dist_o = has ? pitch * sqrtf(__uint_as_float(s_dist[vi])) : trunc;
-    const float dist_k = has_o ? pitch * sqrtf(__uint_as_float(s_dist[nvh + vi])) : trunc;
-    const int iy = y0 + vi / D, iz = vi % D;
-    const float g = 1.0f - dist_o / trunc;  // 1 - tdf/trunc
-    float w = m_own.w + a.sdf_offset;
-    const bool neg = w < 0.0f;
-    if (neg) w = 0.0f;
-    const float go = 1.0f - dist_k / trunc;
-    float wo = m_oth.w + 0.0f;
-    if (wo < 0.0f) wo = 0.0f;
-    if (live) { wmax_own = fmaxf(wmax_own, w); wmax_oth = fmaxf(wmax_oth, wo); }
-    const float gw = g * w;
-    const float gwo = (1.0f - ne) * (go * wo);  // (1 - ne) * go * wo: the part that needs b
+  const int n_act = (nvox + kFusedVox - 1) / kFusedVox;  // active lanes (256 at D = 32)
+  const int n_rows = (n_act + 15) / 16;
+  int ecol[kFusedVox];
+  float cv[kFusedVox][12];
+#pragma unroll
+  for (int u = 0; u < kFusedVox; ++u) ecol[u] = -1;
+  if ((int)(threadIdx.x & ~63u) < n_act) {  // wave-uniform
     float val[kNumF];
-    val[0] = (live && !neg) ? g * tg : 0.0f;
-    val[1] = live ? gw * tg : 0.0f;
-    val[2] = live ? gw : 0.0f;
-    val[3] = live ? gw * ne : 0.0f;
-    val[4] = live ? gw * gwo : 0.0f;
 #pragma unroll
-    for (int k = 5; k < kNumF; ++k) val[k] = 0.0f;
-    if (live && has) {
-      float ux, uy, uz;
-      bool ok;
-      world_frac(Rt_o, m_own, ox, oy, oz, pitch, x, iy, iz, ux, uy, uz, ok);
-      if (ok) {
-        const float kk[5] = {neg ? 0.0f : tg / trunc, w * tg / trunc, w * ne / trunc, w * gwo / trunc, w / trunc};
-        const float u[3] = {ux, uy, uz};
+    for (int k = 0; k < kNumF; ++k) val[k] = 0.0f;
+    bool any_mom = false;
+    uint32_t lo[kFusedVox], lo_o[kFusedVox];
+    float4 m_own[kFusedVox], m_oth[kFusedVox];
 #pragma unroll
-        for (int sset = 0; sset < 5; ++sset)
+    for (int u = 0; u < kFusedVox; ++u) {  // all winner gathers in flight together
+      const int vi = (int)threadIdx.x + u * n_act;
+      const bool live = (int)threadIdx.x < n_act && vi < nvox;
+      lo[u] = live ? s_id[vi] : kNoCand;
+      lo_o[u] = live ? s_id[nvh + vi] : kNoCand;
+      m_own[u] = lo[u] != kNoCand ? a.pts4[lo[u] / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
+      m_oth[u] = lo_o[u] != kNoCand ? a.pts4[lo_o[u] / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
+    }
+#pragma unroll
+    for (int u = 0; u < kFusedVox; ++u) {
+      const int vi = (int)threadIdx.x + u * n_act;
+      const bool live = (int)threadIdx.x < n_act && vi < nvox;
+      const float ne = ne0[u], tg = tg0[u];
+      const bool has = lo[u] != kNoCand, has_o = lo_o[u] != kNoCand;
+      const float dist_o = has ? pitch * sqrtf(__uint_as_float(s_dist[vi])) : trunc;
+      const float dist_k = has_o ? pitch * sqrtf(__uint_as_float(s_dist[nvh + vi])) : trunc;
+      const int iy = y0 + vi / D, iz = vi % D;
+      const float g = 1.0f - dist_o / trunc;  // 1 - tdf/trunc
+      float w = m_own[u].w + a.sdf_offset;
+      const bool neg = w < 0.0f;
+      if (neg) w = 0.0f;
+      const float go = 1.0f - dist_k / trunc;
+      float wo = m_oth[u].w + 0.0f;
+      if (wo < 0.0f) wo = 0.0f;
+      if (live) { wmax_own = fmaxf(wmax_own, w); wmax_oth = fmaxf(wmax_oth, wo); }
+      const float gw = g * w;
+      const float gwo = (1.0f - ne) * (go * wo);  // (1 - ne) * go * wo: the part that needs b
+      if (live) {
+        val[0] += neg ? 0.0f : g * tg;
+        val[1] += gw * tg;
+        val[2] += gw;
+        val[3] += gw * ne;
+        val[4] += gw * gwo;
+      }
+      if (live && has) {
+        float ux, uy, uz;
+        bool ok;
+        world_frac(Rt_o, m_own[u], ox, oy, oz, pitch, x, iy, iz, ux, uy, uz, ok);
+        if (ok) {
+          any_mom = true;
+          const float kk[5] = {neg ? 0.0f : tg / trunc, w * tg / trunc, w * ne / trunc, w * gwo / trunc, w / trunc};
+          const float uu[3] = {ux, uy, uz};
+#pragma unroll
+          for (int sset = 0; sset < 5; ++sset)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              const float sc = uu[d] * kk[sset];
+              val[5 + 12 * sset + 4 * d + 0] += sc * m_own[u].x;
+              val[5 + 12 * sset + 4 * d + 1] += sc * m_own[u].y;
+              val[5 + 12 * sset + 4 * d + 2] += sc * m_own[u].z;
+              val[5 + 12 * sset + 4 * d + 3] += sc;
+            }
+        }
+      }
+      // collision term: gradient flows to the OTHER object's pose (kept for the reduction below)
+      if (live && ne == 0.0f && has_o && go * wo > 0.0f && gw != 0.0f) {
+        const uint32_t p = lo_o[u] / (uint32_t)K;
+        int e = 0;
+        while (e + 1 < Ns && (int)p >= s_off[e + 1]) ++e;
+        float ux, uy, uz;
+        bool ok;
+        world_frac(s_Rt[e], m_oth[u], ox, oy, oz, pitch, x, iy, iz, ux, uy, uz, ok);
+        const float B = wo * gw / trunc;
+        if (ok && isfinite(B)) {
+          const float uu[3] = {ux, uy, uz};
+          ecol[u] = e;
 #pragma unroll
           for (int d = 0; d < 3; ++d) {
-            const float sc = u[d] * kk[sset];
-            val[5 + 12 * sset + 4 * d + 0] = sc * m_own.x;
-            val[5 + 12 * sset + 4 * d + 1] = sc * m_own.y;
-            val[5 + 12 * sset + 4 * d + 2] = sc * m_own.z;
-            val[5 + 12 * sset + 4 * d + 3] = sc;
+            const float sB = uu[d] * B;
+            cv[u][4 * d + 0] = sB * m_oth[u].x;
+            cv[u][4 * d + 1] = sB * m_oth[u].y;
+            cv[u][4 * d + 2] = sB * m_oth[u].z;
+            cv[u][4 * d + 3] = sB;
           }
-      }
-    }
-    // row sums (DPP, 4 VALU steps each) straight into LDS
-#pragma unroll
-    for (int k = 0; k < kNumF; ++k) {
-      const float r = mf::row16_sum(val[k]);
-      if ((threadIdx.x & 15) == 0) s_rows[threadIdx.x >> 4][k] = r;
-    }
-    // collision term: gradient flows to the OTHER object's pose (kept for the reduction below)
-    if (live && ne == 0.0f && has_o && go * wo > 0.0f && gw != 0.0f) {
-      const uint32_t p = lo_o / (uint32_t)K;
-      int e = 0;
-      while (e + 1 < Ns && (int)p >= s_off[e + 1]) ++e;
-      float ux, uy, uz;
-      bool ok;
-      world_frac(s_Rt[e], m_oth, ox, oy, oz, pitch, x, iy, iz, ux, uy, uz, ok);
-      const float B = wo * gw / trunc;
-      if (ok && isfinite(B)) {
-        const float u[3] = {ux, uy, uz};
-        ecol = e;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          const float sB = u[d] * B;
-          cv[4 * d + 0] = sB * m_oth.x;
-          cv[4 * d + 1] = sB * m_oth.y;
-          cv[4 * d + 2] = sB * m_oth.z;
-          cv[4 * d + 3] = sB;
         }
       }
     }
+    // row sums (DPP, 4 VALU steps each) straight into LDS
+    const bool wave_mom = __ballot(any_mom) != 0ull;
+#pragma unroll
+    for (int k = 0; k < kNumF; ++k) {
+      float r = 0.0f;
+      if (k < 5 || wave_mom) r = mf::row16_sum(val[k]);
+      if ((threadIdx.x & 15) == 0) s_rows[threadIdx.x >> 4][k] = r;
+    }
   }
-  if (ecol >= 0) atomicOr(&s_emask, 1u << ecol);
+#pragma unroll
+  for (int u = 0; u < kFusedVox; ++u)
+    if (ecol[u] >= 0) atomicOr(&s_emask, 1u << ecol[u]);
   // per-grid maxima of the raw inside weights (the normalisers a, b of the step)
   wmax_own = mf::wave_max(wmax_own);
   wmax_oth = mf::wave_max(wmax_oth);
@@ -1504,8 +1540,7 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   long long *own = a.acc_own + ((int64_t)par * a.O + o) * kOwnSlots;
   if (threadIdx.x < kNumF) {
     float sacc = 0.0f;
-#pragma unroll
-    for (int r = 0; r < kRows; ++r) sacc += s_rows[r][threadIdx.x];
+    for (int r = 0; r < n_rows; ++r) sacc += s_rows[r][threadIdx.x];
     if (isfinite(sacc)) {
       const long long xq = __double2ll_rn((double)sacc * kFixOwn);
       if (xq != 0) atomicAdd(reinterpret_cast<unsigned long long *>(own + threadIdx.x), (unsigned long long)xq);
@@ -1520,7 +1555,10 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
     const int e = __ffs((int)em) - 1;
 #pragma unroll
     for (int cc = 0; cc < 12; ++cc) {
-      const float r = mf::row16_sum(ecol == e ? cv[cc] : 0.0f);
+      float v = 0.0f;
+#pragma unroll
+      for (int u = 0; u < kFusedVox; ++u) v += ecol[u] == e ? cv[u][cc] : 0.0f;
+      const float r = mf::row16_sum(v);
       if ((threadIdx.x & 15) == 0) s_rows2[(e * kRows + (threadIdx.x >> 4)) * 13 + cc] = r;
     }
   }
