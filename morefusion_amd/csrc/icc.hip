@@ -556,9 +556,11 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
       icc_step_gather_fused<kBinThreads>(a, sp.par, j, e2.x, e2.y, s_raw, s_sum);
     else
       icc_step_gather<kBinThreads>(a, sp.par, j, e2.x, e2.y, s_raw, s_sum);
+    stamp(4);
     // every lane evaluates the same step from LDS (broadcast reads): no further barrier
     float Rt[12], st_new[kStateFloats], loss, gq[4], gt[3];
     icc_step_apply(s_sum, S_t, s_state, sp, Rt, st_new, loss, gq, gt);
+    stamp(5);
     r0 = make_float4(Rt[0], Rt[1], Rt[2], Rt[3]);
     r1 = make_float4(Rt[4], Rt[5], Rt[6], Rt[7]);
     r2 = make_float4(Rt[8], Rt[9], Rt[10], Rt[11]);
@@ -681,7 +683,7 @@ constexpr int kTileThreads = 512;
 constexpr int kTileKeep = 4;  // records per lane kept in registers over both passes
 constexpr int kTileR = 4;     // records in flight per lane beyond those
 constexpr int kFusedKeepOwn = 2, kFusedKeepOth = 4;  // k_icc_fused: kept records per lane and grid
-constexpr int kFusedVox = 2;                         // voxels per active lane of its voxel phase
+constexpr int kFusedVox = 1;  // voxels per active lane of its voxel phase (2: measured slower, 21.5 vs 20.3 us)
 
 template <int KS>
 __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt, const int par) {
@@ -1415,11 +1417,9 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   __syncthreads();
   stamp(3);
 
-  // ---- voxel phase.  Its cost is instruction issue (per wave: ~300 instructions of per-voxel
-  // arithmetic + 65 row reductions of ~8), so HALF the lanes take two voxels each: the
-  // reductions are paid once per two voxels (measured: 8 us with one voxel per lane), the
-  // other waves fall through to the barrier.  Waves without any own winner skip the 60 moment
-  // reductions.
+  // ---- voxel phase: kFusedVox voxels per active lane (one at D = 32; with two, half the waves
+  // pay the 65 row reductions once per two voxels but the per-lane dependent chain doubles --
+  // measured slower).  Waves without any own winner skip the 60 moment reductions.
   const float *Rt_o = s_Rt[o - ja];
   float wmax_own = 0.0f, wmax_oth = 0.0f;
   constexpr int kRows = kTileThreads / 16;

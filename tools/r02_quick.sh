@@ -7,3 +7,4 @@ timeout 900 python -m pytest tests/test_gpu_icc.py tests/test_gpu_accuracy_popul
 bash tools/prof_k.sh $TAG 2>&1 | tail -5
 python tools/time_icc_quick.py 2>&1 | grep -v amdgpu | tail -3
 timeout 120 python tools/stamps_icc.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r02/${TAG}_stamps.log; grep -E "total|pass|load|reduce|voxels" gpurun_out/r02/${TAG}_stamps.log
+STAMP_REFINE=1 timeout 120 python tools/stamps_icc.py 2>&1 | grep -E "^bin " 

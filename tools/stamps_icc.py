@@ -5,7 +5,11 @@ os.environ["MF_ICC_DEBUG"] = "32"
 import morefusion_amd as mf
 from bench import Workload, parse
 args = parse(); wl = Workload(args, 0, torch.device("cuda", 0))
-loss, gq, gt = wl.icc.loss_grad(wl.q0, wl.t0)   # one iteration (eager launches)
+if os.environ.get("STAMP_REFINE"):   # two loop iterations: the second k_icc_bin carries the folded step
+    wl.q.copy_(wl.q0); wl.t.copy_(wl.t0); wl.m.zero_(); wl.v.zero_()
+    wl.icc.refine(wl.q, wl.t, wl.m, wl.v, 2)
+else:
+    loss, gq, gt = wl.icc.loss_grad(wl.q0, wl.t0)   # one iteration (eager launches)
 torch.cuda.synchronize()
 buf = np.zeros(4096 * 8, np.uint64)
 mf._lib.lib().mf_icc_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
@@ -24,7 +28,8 @@ sb = buf.reshape(4096, 8)[3072:3072+512].astype(np.int64)
 live = sb[:, 3] > 0
 db = lambda a, b: (sb[live, b] - sb[live, a]) / 100.0
 print("bin WGs", (sb[:, 0] > 0).sum(), "live", live.sum())
-for name, a, b in (("loads+count", 0, 1), ("global atomic", 1, 2), ("stores", 2, 3), ("total", 0, 3)):
+steps = (("loads+gather", 0, 4), ("step math", 4, 5), ("count", 5, 1)) if os.environ.get("STAMP_REFINE") else (("loads+count", 0, 1),)
+for name, a, b in steps + (("global atomic", 1, 2), ("stores", 2, 3), ("total", 0, 3)):
     x = db(a, b); print(f"bin {name:13s} mean {x.mean():7.2f} us  max {x.max():7.2f} us")
 print("bin start skew max", (sb[sb[:,0]>0, 0] - sb[sb[:,0]>0, 0].min()).max() / 100.0, "end max", (sb[live, 3] - sb[sb[:,0]>0, 0].min()).max() / 100.0)
 
