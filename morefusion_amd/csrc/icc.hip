@@ -579,17 +579,19 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
         for (int i = 0; i < 7; ++i) tr[i] = st_new[i];
       }
       if (sp.loss_out && j == e2.x) sp.loss_out[e2.z] = loss;
-      // empty this object's accumulators of the parity the coming k_icc_accum adds into
-      a.Mbits[(int64_t)(sp.par ^ 1) * 2 * a.O + 2 * j] = 0;
-      a.Mbits[(int64_t)(sp.par ^ 1) * 2 * a.O + 2 * j + 1] = 0;
-      long long *own = a.acc_own + ((int64_t)(sp.par ^ 1) * a.O + j) * kOwnSlots;
-      for (int i = 0; i < kOwnSlots; ++i) own[i] = 0;
-      long long *oth = a.acc_oth + ((int64_t)(sp.par ^ 1) * a.O + j) * a.max_ns * 12;
-      for (int i = 0; i < a.max_ns * 12; ++i) oth[i] = 0;
     }
-    if (e2.w != 0)  // ... and the bins of its two grids that the NEXT iteration fills
+    if (e2.w != 0) {
+      // ... and empties, all lanes together (one lane storing ~300 words in a row measured 4 us):
+      // this object's accumulators and maxima of the parity the coming iteration adds into, and
+      // the bins of its two grids that the NEXT iteration fills
+      if (threadIdx.x < 2) a.Mbits[(int64_t)(sp.par ^ 1) * 2 * a.O + 2 * j + threadIdx.x] = 0;
+      long long *own = a.acc_own + ((int64_t)(sp.par ^ 1) * a.O + j) * kOwnSlots;
+      for (int i = threadIdx.x; i < kOwnSlots; i += kBinThreads) own[i] = 0;
+      long long *oth = a.acc_oth + ((int64_t)(sp.par ^ 1) * a.O + j) * a.max_ns * 12;
+      for (int i = threadIdx.x; i < a.max_ns * 12; i += kBinThreads) oth[i] = 0;
       for (int i = threadIdx.x; i < 2 * nb; i += kBinThreads)
         a.bin_cnt[((int64_t)(sp.cpar ^ 1) * 2 * a.O + 2 * j) * nb + i] = 0u;
+    }
   }
   const float R0 = r0.x, R1 = r0.y, R2 = r0.z, R3 = r0.w, R4 = r1.x, R5 = r1.y, R6 = r1.z,
               R7 = r1.w, R8 = r2.x, T0 = r2.y, T1 = r2.z, T2 = r2.w;
