@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from .... import functions as functions_module
 from .... import geometry as geometry_module
 from .... import metrics
-from ....models import PSPNetExtractor, ResNet18
+from ....models import PSPNetExtractor, ResNet18, ResNet18Extractor
 from ....synthetic import CLASS_IDS_SYMMETRIC, CLASS_PITCH
 from .sparse_conv import SparseVoxelConv3d
 
@@ -56,8 +56,6 @@ class Model(nn.Module):
     def __init__(self, *, n_fg_class, pretrained_resnet18=False, with_occupancy=False, loss=None,
                  loss_scale=None, models=None):
         super().__init__()
-        if pretrained_resnet18:
-            raise NotImplementedError("pretrained chainercv2 weights are not reachable offline")
         self._n_fg_class = n_fg_class
         self._with_occupancy = with_occupancy
         if loss is None:
@@ -77,7 +75,10 @@ class Model(nn.Module):
         # inference: conv3 on fp32 MFMA over the occupied voxels only (csrc/sparseconv.hip)
         self.sparse_conv3 = True
 
-        self.resnet_extractor = ResNet18()
+        # model.py:50-56: the ImageNet-pretrained chainercv2 ResNet-18 (frozen BatchNorm, no
+        # gradient below res2) or the DenseFusion ResNet18.  The pretrained weights are a
+        # download: the architecture is built with random init and filled by serializers.load_npz
+        self.resnet_extractor = ResNet18Extractor() if pretrained_resnet18 else ResNet18()
         self.pspnet_extractor = PSPNetExtractor()
         self.conv1_rgb = nn.Conv1d(32, 64, 1)
         self.conv1_pcd = nn.Conv1d(3, 8, 1)

@@ -1,2 +1,2 @@
 # flake8: noqa
-from .backbone2d import PSPNetExtractor, ResNet18
+from .backbone2d import PSPNetExtractor, ResNet18, ResNet18Extractor

@@ -57,6 +57,95 @@ class ResNet18(nn.Module):
         return self.res5(self.res4(self.res3(self.res2(h))))
 
 
+class _ConvBlock(nn.Module):
+    """chainercv2 ``ConvBlock``: conv (no bias) + BatchNorm (+ ReLU); children ``conv``, ``bn``."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, dilate=1, activate=True):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride, padding=pad, dilation=dilate, bias=False)
+        self.bn = nn.BatchNorm2d(cout, eps=1e-5)
+        self.activate = activate
+
+    def forward(self, x):
+        h = self.bn(self.conv(x))
+        return F.relu(h) if self.activate else h
+
+
+class _ResBody(nn.Module):
+    def __init__(self, cin, cout, stride, dilate):
+        super().__init__()
+        self.conv1 = _ConvBlock(cin, cout, 3, stride, pad=dilate, dilate=dilate)
+        self.conv2 = _ConvBlock(cout, cout, 3, 1, pad=dilate, dilate=dilate, activate=False)
+
+    def forward(self, x):
+        return self.conv2(self.conv1(x))
+
+
+class _ResUnit(nn.Module):
+    """chainercv2 ``ResUnit`` (basic block): ``body`` + optional ``identity_conv`` + ReLU."""
+
+    def __init__(self, cin, cout, stride, dilate, resize):
+        super().__init__()
+        self.body = _ResBody(cin, cout, stride, dilate)
+        self.identity_conv = _ConvBlock(cin, cout, 1, stride, activate=False) if resize else None
+
+    def forward(self, x):
+        identity = x if self.identity_conv is None else self.identity_conv(x)
+        return F.relu(self.body(x) + identity)
+
+
+class _InitBlock(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = _ConvBlock(3, 64, 7, 2, pad=3)
+
+    def forward(self, x):
+        return F.max_pool2d(self.conv(x), 3, 2, 1)
+
+
+class ResNet18Extractor(nn.Module):
+    """``morefusion.models.ResNet18Extractor`` (models/resnet.py:7-52): the chainercv2 ImageNet
+    ResNet-18 with the strides of stages 3 / 4 removed and their second units dilated by 2 / 4, so
+    that [B,3,H,W] -> [B,512,H/8,W/8] like the DenseFusion ResNet18.  BatchNorm always runs in
+    inference mode (``using_config('train', False)``, :44) and no gradient flows below ``res2``
+    (``h.unchain()``, :47-48).  Child names follow chainercv2 (``init_block/conv/{conv,bn}``,
+    ``resN/unitM/body/convK/{conv,bn}``, ``identity_conv``) so that ``serializers`` maps a
+    ``pretrained_resnet18=True`` checkpoint onto it; the ImageNet weights themselves are a
+    chainercv2 download and not reachable offline (random init here; parity unpinned)."""
+
+    mean_rgb = (0.485, 0.456, 0.406)
+    std_rgb = (0.229, 0.224, 0.225)
+
+    def __init__(self):
+        super().__init__()
+        self.init_block = _InitBlock()
+        spec = ((64, 64, 1, 1, False), (64, 128, 2, 1, True), (128, 256, 1, 2, True), (256, 512, 1, 4, True))
+        for n, (cin, cout, stride, dilate, resize) in zip((2, 3, 4, 5), spec):
+            stage = nn.Module()
+            stage.unit1 = _ResUnit(cin, cout, stride, 1, resize)
+            stage.unit2 = _ResUnit(cout, cout, 1, dilate, False)
+            setattr(self, f"res{n}", stage)
+        self.register_buffer("mean", torch.tensor(self.mean_rgb).view(1, 3, 1, 1))
+        self.register_buffer("std", torch.tensor(self.std_rgb).view(1, 3, 1, 1))
+
+    def train(self, mode=True):  # BatchNorm statistics are never updated (resnet.py:44)
+        super().train(mode)
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+        return self
+
+    def forward(self, x):
+        h = (x / 255.0 - self.mean) / self.std
+        h = self.init_block(h)
+        h = self.res2.unit2(self.res2.unit1(h))
+        h = h.detach()  # unchain_at="res2"
+        for n in (3, 4, 5):
+            stage = getattr(self, f"res{n}")
+            h = stage.unit2(stage.unit1(h))
+        return h
+
+
 class PSPModule(nn.Module):
     def __init__(self, in_channels, out_channels, sizes):
         super().__init__()

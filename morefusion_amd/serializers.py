@@ -17,6 +17,9 @@ import numpy as np
 import torch
 
 _PARAM = {"weight": "W", "bias": "b"}
+# chainer.links.BatchNormalization: gamma, beta and the persistents avg_mean, avg_var, N
+_BN_PARAM = {"weight": "gamma", "bias": "beta", "running_mean": "avg_mean", "running_var": "avg_var",
+             "num_batches_tracked": "N"}
 _NON_SERIALISED = re.compile(r"(^|\.)(mean|std)$")  # plain attributes in the reference, not persistents
 
 
@@ -32,7 +35,10 @@ def chainer_key(torch_name):
         else:
             out.append(part)
     leaf = parts[-1]
-    out.append(_PARAM.get(leaf, leaf))
+    if len(parts) > 1 and parts[-2] == "bn":  # chainercv2 ConvBlock.bn (ResNet18Extractor)
+        out.append(_BN_PARAM.get(leaf, leaf))
+    else:
+        out.append(_PARAM.get(leaf, leaf))
     return "/".join(out)
 
 

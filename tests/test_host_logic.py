@@ -408,3 +408,33 @@ def test_raw_example_schema_and_transform():
     assert len(cases) > 3  # different GRID_CASES / instance subsets are drawn
     no_occ = synthetic.transform_example(ex[0], with_occupancy=False)
     assert "pitch" not in no_occ and "origin" not in no_occ and "grid_target" not in no_occ
+
+
+def test_resnet18_extractor_architecture_and_checkpoint_keys(tmp_path):
+    """pretrained_resnet18=True (models/resnet.py:7-52): stride-8 output like the DenseFusion
+    ResNet18, BatchNorm frozen even in train(), no gradient below res2, chainercv2 child names
+    in the checkpoint keys, npz round trip."""
+    from morefusion_amd import serializers as S
+    from morefusion_amd.contrib.singleview_3d.models import Model
+    from morefusion_amd.models import ResNet18Extractor
+    torch.manual_seed(0)
+    net = ResNet18Extractor().train()
+    x = torch.randint(0, 256, (2, 3, 64, 64)).float()
+    before = net.res3.unit1.body.conv1.bn.running_mean.clone()
+    y = net(x)
+    assert y.shape == (2, 512, 8, 8)
+    y.sum().backward()
+    assert torch.equal(net.res3.unit1.body.conv1.bn.running_mean, before)          # statistics frozen
+    assert net.init_block.conv.conv.weight.grad is None and net.res2.unit2.body.conv2.conv.weight.grad is None
+    assert net.res3.unit1.body.conv1.conv.weight.grad is not None
+    assert S.chainer_key("resnet_extractor.res4.unit1.identity_conv.conv.weight") == "resnet_extractor/res4/unit1/identity_conv/conv/W"
+    assert S.chainer_key("resnet_extractor.init_block.conv.bn.running_var") == "resnet_extractor/init_block/conv/bn/avg_var"
+    assert S.chainer_key("resnet_extractor.res5.unit2.body.conv2.bn.weight") == "resnet_extractor/res5/unit2/body/conv2/bn/gamma"
+    a = Model(n_fg_class=21, pretrained_resnet18=True, with_occupancy=True)
+    b = Model(n_fg_class=21, pretrained_resnet18=True, with_occupancy=True)
+    S.save_npz(str(tmp_path / "m.npz"), a)
+    assert S.load_npz(str(tmp_path / "m.npz"), b) == []
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    with pytest.raises(NotImplementedError, match="occupancy term"):
+        Model(n_fg_class=21, loss="add+occupancy")
