@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int kInterpThreads = 256;
+constexpr int kInterpPre = 4;  // points per lane loaded ahead of the grid staging (row-range mode)
 
 struct Corner {
   int off[8];
@@ -129,16 +130,11 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_lds(
   const int c0 = blockIdx.x * cpw;
   const int nc = min(cpw, C - c0);
   const int V = X * Y * Z;
-  stage_copy(s_grid, vox + ((int64_t)b * C + c0) * V, nc * V);
-  __syncthreads();
-  for_rows_of_item(batch_indices, batch_start, n, b, B, [&](int64_t p, bool mine) {
+  // one point: corners once, then nc channels of 8 LDS gathers each
+  auto sample = [&](int64_t p, bool mine, float px, float py, float pz) {
     Corner k;
-    bool ok = false;
-    if (mine) {
-      const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
-      ok = plausible(px, py, pz);
-      if (ok) corners(px, py, pz, X, Y, Z, k);
-    }
+    bool ok = mine && plausible(px, py, pz);
+    if (ok) corners(px, py, pz, X, Y, Z, k);
     if (!ok) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { k.off[j] = -1; k.w[j] = 0.0f; }
@@ -154,6 +150,41 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_lds(
       else
         values[p * C + c0 + c] = acc;
     }
+  };
+  // Row ranges known and the item's rows fit kInterpPre per lane (the pose network: 1000 rows,
+  // 4 per lane): the point loads are issued BEFORE the grid chunk is staged, so their latency
+  // hides behind the 64 KB copy instead of costing one dependent round trip per loop iteration.
+  if (batch_start) {
+    const int64_t p0 = batch_start[b], p1 = batch_start[b + 1];
+    if (p1 - p0 <= (int64_t)kInterpThreads * kInterpPre) {
+      float px[kInterpPre], py[kInterpPre], pz[kInterpPre];
+#pragma unroll
+      for (int u = 0; u < kInterpPre; ++u) {
+        const int64_t p = p0 + (int64_t)u * kInterpThreads + threadIdx.x;
+        px[u] = py[u] = pz[u] = 0.0f;
+        if (p < p1) { px[u] = points[3 * p]; py[u] = points[3 * p + 1]; pz[u] = points[3 * p + 2]; }
+      }
+      stage_copy(s_grid, vox + ((int64_t)b * C + c0) * V, nc * V);
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < kInterpPre; ++u) {
+        const int64_t p = p0 + (int64_t)u * kInterpThreads + threadIdx.x;
+        if (p < p1) sample(p, true, px[u], py[u], pz[u]);
+      }
+      if (b == 0) {  // rows outside every item: zeros (same contract as the scan path)
+        const int64_t lo = batch_start[0], hi = batch_start[B];
+        for (int64_t p = threadIdx.x; p < n; p += kInterpThreads)
+          if (p < lo || p >= hi) sample(p, false, 0.0f, 0.0f, 0.0f);
+      }
+      return;
+    }
+  }
+  stage_copy(s_grid, vox + ((int64_t)b * C + c0) * V, nc * V);
+  __syncthreads();
+  for_rows_of_item(batch_indices, batch_start, n, b, B, [&](int64_t p, bool mine) {
+    float px = 0.0f, py = 0.0f, pz = 0.0f;
+    if (mine) { px = points[3 * p]; py = points[3 * p + 1]; pz = points[3 * p + 2]; }
+    sample(p, mine, px, py, pz);
   });
 }
 
