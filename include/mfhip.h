@@ -147,6 +147,19 @@ int mf_nn(const float *ref, int64_t R, const float *query, int64_t Q, int64_t *o
 int mf_icp_loss_grad(const float *source, int64_t S, const float *target, int64_t T,
                      const float *Rt, float thresh, float *out, mfStream_t stream);
 
+/* The ICP driver's whole loop on the device
+ *   examples/ycb_video/pose_refinement/check_iterative_closest_point_link.py:40-70
+ * (one link per instance, loss = sum of the links' losses, chainer Adam with the translations'
+ * alpha scaled): n_iter x {k_icp over every link, quaternion chain rule + Adam step}, 2 launches
+ * per iteration, no host synchronisation and no autograd round trip.
+ *   source [sum S_l,3], src_off [L+1]; target [sum T_l,3], tgt_off [L+1]; max_T >= max_l T_l;
+ *   q [L,4], t [L,3], adam_m / adam_v [L,7] updated in place; losses [n_iter,L] may be NULL;
+ *   ws: 28 * L floats. */
+int mf_icp_refine(const float *source, const int32_t *src_off, const float *target,
+                  const int32_t *tgt_off, int32_t L, int32_t max_T, float thresh, float *q, float *t,
+                  float *adam_m, float *adam_v, int32_t n_iter, int32_t step0, float alpha_q,
+                  float alpha_t, float *losses, float *ws, mfStream_t stream);
+
 /* ---- A9 IterativeCollisionCheckLink (fused) --------------------------------
  *   morefusion/contrib/iterative_collision_check_link.py:31-99 (forward),
  *   truncated_distance_function.py:105-166 (backward), driver loop

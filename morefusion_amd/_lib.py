@@ -49,6 +49,8 @@ _SIGNATURES = {
     "mf_pseudo_occupancy_weights": ([_p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p], _i),
     "mf_nn": ([_p, _i64, _p, _i64, _p, _p, _p], _i),
     "mf_icp_loss_grad": ([_p, _i64, _p, _i64, _p, _f, _p, _p], _i),
+    "mf_icp_refine": ([_p, _p, _p, _p, ctypes.c_int32, ctypes.c_int32, _f, _p, _p, _p, _p, ctypes.c_int32,
+                       ctypes.c_int32, _f, _f, _p, _p, _p], _i),
     "mf_icc_workspace_bytes": ([ctypes.POINTER(IccBatch)], _i64),
     "mf_icc_launch_stage": ([ctypes.POINTER(IccBatch), _p, _p, _p, ctypes.c_int32, _p], _i),
     "mf_icc_prepare": ([ctypes.POINTER(IccBatch), _p, _p], _i),

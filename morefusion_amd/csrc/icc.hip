@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "mf_common.h"
+#include "quat.h"
 
 namespace {
 
@@ -99,58 +100,8 @@ struct IccArgs {
   int dbg;                // tuning aid: MF_ICC_DEBUG bit mask (0 in production)
 };
 
-__device__ __forceinline__ void quat_to_R(const float *q, float *R) {
-  // morefusion/functions/geometry/quaternion_matrix.py:65-78, :14-34
-  const float n = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
-  const float s = sqrtf(2.0f / n);
-  const float qs[4] = {q[0] * s, q[1] * s, q[2] * s, q[3] * s};
-  float Q[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Q[i][j] = qs[i] * qs[j];
-  R[0] = 1.0f - Q[2][2] - Q[3][3];
-  R[1] = Q[1][2] - Q[3][0];
-  R[2] = Q[1][3] + Q[2][0];
-  R[3] = Q[1][2] + Q[3][0];
-  R[4] = 1.0f - Q[1][1] - Q[3][3];
-  R[5] = Q[2][3] - Q[1][0];
-  R[6] = Q[1][3] - Q[2][0];
-  R[7] = Q[2][3] + Q[1][0];
-  R[8] = 1.0f - Q[1][1] - Q[2][2];
-}
-
-__device__ __forceinline__ void quat_backward(const float *q, const float *gR, float *gq) {
-  // quaternion_matrix.py:36-51 (dR/dQ), outer product :54-62, scaling :71-72
-  float gQ[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) gQ[i][j] = 0.0f;
-  gQ[1][0] = -gR[5] + gR[7];
-  gQ[1][1] = -gR[4] - gR[8];
-  gQ[1][2] = gR[1] + gR[3];
-  gQ[1][3] = gR[2] + gR[6];
-  gQ[2][0] = gR[2] - gR[6];
-  gQ[2][2] = -gR[0] - gR[8];
-  gQ[2][3] = gR[5] + gR[7];
-  gQ[3][0] = -gR[1] + gR[3];
-  gQ[3][3] = -gR[0] - gR[4];
-  const float n = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
-  const float s = sqrtf(2.0f / n);
-  const float qs[4] = {q[0] * s, q[1] * s, q[2] * s, q[3] * s};
-  float gqs[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float a = 0.0f, b = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { a += gQ[i][j] * qs[j]; b += gQ[j][i] * qs[j]; }
-    gqs[i] = a + b;
-  }
-  const float dot = ((gqs[0] * q[0] + gqs[1] * q[1]) + gqs[2] * q[2]) + gqs[3] * q[3];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) gq[i] = s * gqs[i] - (s / n) * dot * q[i];
-}
+using mf::quat_backward;
+using mf::quat_to_R;
 
 // Kernel size of one grid: truncated_distance_function.py:36-38 evaluates
 // ceil(truncation / pitch) in float32 with truncation = threshold * pitch

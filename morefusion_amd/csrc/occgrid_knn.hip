@@ -10,7 +10,10 @@
 // Here each output element keeps a running (min, arg-min) in registers while the
 // point set streams through LDS in tiles that every lane reads at the same address
 // (LDS broadcast, conflict-free): HBM traffic drops to the compulsory (R+Q)*12 B.
+#include <math.h>
+
 #include "mf_common.h"
+#include "quat.h"
 
 namespace {
 
@@ -139,10 +142,23 @@ __global__ __launch_bounds__(256) void k_nn(const float *__restrict__ ref, int R
 // ---- A10 ICP link ---------------------------------------------------------------
 // One thread per target point; transformed source streamed through LDS.
 // out[0] += loss, out[1] += matches, out[4..15] += d loss / d [R|t] (row-major 3x4).
-__global__ __launch_bounds__(256) void k_icp(const float *__restrict__ source, int S,
-                                             const float *__restrict__ target, int T,
-                                             const float *__restrict__ Rt, float thresh,
-                                             float *__restrict__ out) {
+// Link l = blockIdx.y of a batch (src_off / tgt_off: [L+1] row offsets, NULL for a single link
+// whose arrays are S / T rows long); Rt [L][12], out [L][16].
+__global__ __launch_bounds__(256) void k_icp(const float *__restrict__ source_all, int S_single,
+                                             const float *__restrict__ target_all, int T_single,
+                                             const int32_t *__restrict__ src_off,
+                                             const int32_t *__restrict__ tgt_off,
+                                             const float *__restrict__ Rt_all, float thresh,
+                                             float *__restrict__ out_all) {
+  const int l = blockIdx.y;
+  const int s0 = src_off ? src_off[l] : 0, t0 = tgt_off ? tgt_off[l] : 0;
+  const int S = src_off ? src_off[l + 1] - s0 : S_single;
+  const int T = tgt_off ? tgt_off[l + 1] - t0 : T_single;
+  if ((int)(blockIdx.x * blockDim.x) >= T) return;  // block-uniform: grid.x covers the longest link
+  const float *source = source_all + 3 * (int64_t)s0;
+  const float *target = target_all + 3 * (int64_t)t0;
+  const float *Rt = Rt_all + 12 * l;
+  float *out = out_all + 16 * l;
   __shared__ float4 s_s[kTile];
   __shared__ float s_red[4][16];
   const int ti = blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,6 +220,50 @@ __global__ __launch_bounds__(256) void k_icp(const float *__restrict__ source, i
   }
 }
 
+
+// The optimiser step of the fused ICP loop: one lane per link.  out[l] = {loss, matches, -, -,
+// d loss / d R (9), d loss / d t (3)} of k_icp -> chain rule through the quaternion -> chainer-Adam
+// -> next R|t; out[l] is cleared for the next iteration.
+__global__ __launch_bounds__(64) void k_icp_step(int L, float *__restrict__ q, float *__restrict__ t,
+                                                 float *__restrict__ adam_m, float *__restrict__ adam_v,
+                                                 float aq, float at, float *__restrict__ Rt,
+                                                 float *__restrict__ out, float *__restrict__ losses,
+                                                 int apply) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  float qq[4], tt[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qq[i] = q[4 * l + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tt[i] = t[3 * l + i];
+  if (apply) {
+    float gR[9], gt[3], gq[4], mm[7], vv[7];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gR[i] = out[16 * l + 4 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gt[i] = out[16 * l + 13 + i];
+    if (losses) losses[l] = out[16 * l];
+    mf::quat_backward(qq, gR, gq);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { mm[i] = adam_m[7 * l + i]; vv[i] = adam_v[7 * l + i]; }
+    mf::adam_pose_step(gq, gt, aq, at, qq, tt, mm, vv);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { adam_m[7 * l + i] = mm[i]; adam_v[7 * l + i] = vv[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[4 * l + i] = qq[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[3 * l + i] = tt[i];
+  }
+  float R[9];
+  mf::quat_to_R(qq, R);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rt[12 * l + i] = R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Rt[12 * l + 9 + i] = tt[i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) out[16 * l + i] = 0.0f;
+}
+
 }  // namespace
 
 extern "C" int mf_occupancy_grid_3d_fwd(const float *points, int64_t P, float pitch, float ox,
@@ -243,6 +303,32 @@ extern "C" int mf_icp_loss_grad(const float *source, int64_t S, const float *tar
   hipStream_t stream = (hipStream_t)stream_;
   if (T == 0 || S == 0) return 0;
   hipLaunchKernelGGL(k_icp, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, stream, source,
-                     (int)S, target, (int)T, Rt, thresh, out);
+                     (int)S, target, (int)T, (const int32_t *)nullptr, (const int32_t *)nullptr, Rt, thresh, out);
   return mf::check_launch("mf_icp_loss_grad");
+}
+
+extern "C" int mf_icp_refine(const float *source, const int32_t *src_off, const float *target,
+                             const int32_t *tgt_off, int32_t L, int32_t max_T, float thresh, float *q,
+                             float *t, float *adam_m, float *adam_v, int32_t n_iter, int32_t step0,
+                             float alpha_q, float alpha_t, float *losses, float *ws,
+                             mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (L <= 0 || n_iter <= 0) return 0;
+  float *Rt = ws, *out = ws + 12 * (int64_t)L;  // ws: 28 floats per link
+  const dim3 gs((L + 63) / 64), gk((unsigned)((max_T + 255) / 256), L);
+  // R|t of the initial poses, cleared sums; then n_iter x {loss + gradient, step}
+  hipLaunchKernelGGL(k_icp_step, gs, dim3(64), 0, stream, (int)L, q, t, adam_m, adam_v, 0.0f, 0.0f, Rt, out,
+                     (float *)nullptr, 0);
+  for (int k = 0; k < n_iter; ++k) {
+    if (max_T > 0)
+      hipLaunchKernelGGL(k_icp, gk, dim3(256), 0, stream, source, 0, target, 0, src_off, tgt_off,
+                         (const float *)Rt, thresh, out);
+    // chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once
+    const int st = step0 + k + 1;
+    const double fix1 = 1.0 - pow(0.9, (double)st), fix2 = 1.0 - pow(0.999, (double)st);
+    hipLaunchKernelGGL(k_icp_step, gs, dim3(64), 0, stream, (int)L, q, t, adam_m, adam_v,
+                       (float)((double)alpha_q * sqrt(fix2) / fix1), (float)((double)alpha_t * sqrt(fix2) / fix1),
+                       Rt, out, losses ? losses + (int64_t)k * L : (float *)nullptr, 1);
+  }
+  return mf::check_launch("mf_icp_refine");
 }

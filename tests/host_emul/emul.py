@@ -41,6 +41,9 @@ def build(sources, extra_flags=()):
     for name in list(sources) + ["mf_common.h"]:
         path = os.path.join(HERE if name == "mf_common.h" else CSRC, name)
         h.update(open(path, "rb").read())
+    for hname in sorted(os.listdir(CSRC)):
+        if hname.endswith(".h"):
+            h.update(open(os.path.join(CSRC, hname), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "mfhip.h"), "rb").read())
     h.update(" ".join(extra_flags).encode())
     tag = h.hexdigest()[:16]
@@ -48,6 +51,9 @@ def build(sources, extra_flags=()):
     if not os.path.exists(so):
         work = os.path.join(BUILD, tag)
         os.makedirs(work, exist_ok=True)
+        for hname in os.listdir(CSRC):  # shared device headers (the emulator's mf_common.h shadows csrc's)
+            if hname.endswith(".h") and hname != "mf_common.h":
+                shutil.copy(os.path.join(CSRC, hname), os.path.join(work, hname))
         shutil.copy(os.path.join(HERE, "mf_common.h"), os.path.join(work, "mf_common.h"))
         cpps = []
         for name in sources:

@@ -93,3 +93,46 @@ def test_interpolate_kernel_source_row_ranges_vs_oracle(channels_first):
         got = out.T if channels_first else out
         np.testing.assert_array_equal(got[valid], ref)
         np.testing.assert_array_equal(got[~valid], 0.0)
+
+
+def test_fused_icp_loop_kernel_source_vs_oracle(fixtures3):
+    """mf_icp_refine (k_icp over a batch of links + k_icp_step: chain rule, chainer-Adam, next R|t;
+    the driver loop of check_iterative_closest_point_link.py:40-70) against the oracle's loop: the
+    committed 30-iterate trajectory of fixture 2 and a second link refined in the same batch."""
+    from conftest import golden
+    from oracle import oracle_c as OC
+    lib = emul.build(["occgrid_knn.hip"])
+    lib.mf_icp_refine.argtypes = [_p, _p, _p, _p, _i32, _i32, ctypes.c_float, _p, _p, _p, _p, _i32, _i32,
+                                  ctypes.c_float, ctypes.c_float, _p, _p, _p]
+    g = golden("oracle_icc_icp_trajectories.npz")
+    links = []
+    for f in (fixtures3[2], fixtures3[0]):
+        # argwhere hands back a transposed view: force row-major [T,3]
+        target = np.ascontiguousarray((np.argwhere(f["grid_target"] >= 0.5) * f["pitch"] + f["origin"]).astype(np.float32))
+        source = np.ascontiguousarray(f["pcd_cad"].astype(np.float32)[:: 4 if f is fixtures3[0] else 1])
+        links.append((source, target, O.quaternion_from_matrix(f["transform_init"]).astype(np.float32),
+                      f["transform_init"][:3, 3].astype(np.float32)))
+    n_iter = 6
+    src = np.ascontiguousarray(np.concatenate([k[0] for k in links]))
+    tgt = np.ascontiguousarray(np.concatenate([k[1] for k in links]))
+    src_off = np.r_[0, np.cumsum([len(k[0]) for k in links])].astype(np.int32)
+    tgt_off = np.r_[0, np.cumsum([len(k[1]) for k in links])].astype(np.int32)
+    q = np.stack([k[2] for k in links]).copy()
+    t = np.stack([k[3] for k in links]).copy()
+    m, v = np.zeros((2, 7), np.float32), np.zeros((2, 7), np.float32)
+    losses = np.zeros((n_iter, 2), np.float32)
+    ws = np.zeros(28 * 2, np.float32)
+    rc = lib.mf_icp_refine(src.ctypes.data, src_off.ctypes.data, tgt.ctypes.data, tgt_off.ctypes.data, 2,
+                           int(max(len(k[1]) for k in links)), 0.02, q.ctypes.data, t.ctypes.data, m.ctypes.data,
+                           v.ctypes.data, n_iter, 0, 0.01, 0.001, losses.ctypes.data, ws.ctypes.data, None)
+    assert rc == 0
+    np.testing.assert_allclose(losses[:, 0], g["icp_losses"][:n_iter], rtol=1e-4)   # committed golden
+    np.testing.assert_allclose(np.r_[q[0], t[0]], g["icp_traj"][n_iter], atol=2e-5)
+    # link 1: the oracle's loop at test time
+    qi, ti = links[1][2].copy(), links[1][3].copy()
+    opt = O.ChainerAdam([qi, ti], [0.01, 0.001])
+    for k in range(n_iter):
+        loss, gq, gt = OC.icp_loss_grad(links[1][0], links[1][1], qi, ti)
+        np.testing.assert_allclose(losses[k, 1], loss, rtol=1e-4)
+        opt.update([gq, gt])
+    np.testing.assert_allclose(np.r_[q[1], t[1]], np.r_[qi, ti], atol=2e-5)
