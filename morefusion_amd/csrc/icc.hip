@@ -636,7 +636,9 @@ constexpr int kTileThreads = 512;
 constexpr int kTileKeep = 4;  // records per lane kept in registers over both passes
 constexpr int kTileR = 4;     // records in flight per lane beyond those
 constexpr int kFusedKeepOwn = 2, kFusedKeepOth = 4;  // k_icc_fused: kept records per lane and grid
-constexpr int kFusedVox = 1;  // voxels per active lane of its voxel phase (2: measured slower, 21.5 vs 20.3 us)
+constexpr int kPad = 2;  // margin cells of its LDS tile on every side (ks = 3: candidates reach 2 cells out)
+// LDS words of one (dist | id) array of the single-pass kernel's padded half-plane tile
+__host__ __device__ constexpr int fused_tile_words(int D) { return ((D + 1) / 2 + 2 * kPad) * (D + 2 * kPad); }
 
 template <int KS>
 __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt, const int par) {
@@ -1134,6 +1136,9 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   __shared__ float s_Rt[kMaxSceneObjects][12];
   __shared__ int s_off[kMaxSceneObjects + 1];
   __shared__ uint32_t s_emask;
+  __shared__ float2 s_netg[kTileThreads];   // (no-entry, target) of voxel i, for its compacted lane
+  __shared__ uint16_t s_list[kTileThreads];  // voxels with an own winner, in voxel order
+  __shared__ int s_wcnt[kTileThreads / 64];
   const int ks = KS > 0 ? KS : ks_rt;
   const int h = ks / 2, K = ks * ks * ks;
   const int D = a.D, nb = a.nbins, hmax = a.hmax, V = D * D * D;
@@ -1141,7 +1146,8 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   const int x = blockIdx.x / kHalves, half = blockIdx.x % kHalves;
   const int Dh = (D + 1) / 2;
   const int y0 = half * Dh, y1 = half == 0 ? Dh : D;
-  const int nvh = Dh * D;               // LDS stride of one (dist | id) array
+  const int Wp = D + 2 * kPad, rows_p = Dh + 2 * kPad;  // padded tile (see visit)
+  const int nvh = rows_p * Wp;          // LDS stride of one (dist | id) array
   const int nvox = (y1 - y0) * D;
   uint32_t *s_dist = s_tile, *s_id = s_tile + 2 * nvh;
   float *s_rows2 = reinterpret_cast<float *>(s_tile + 4 * nvh);
@@ -1167,6 +1173,7 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
       c[kd][b + 1] = c[kd][b] + n;
     }
   }
+  if (c[0][7] + c[1][7] == 0) return;  // block-uniform: no record of either grid reaches this tile
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
   if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
@@ -1180,20 +1187,11 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   stamp(0);
   if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)(c[0][7] + c[1][7]);
   // the voxel phase's first-level loads, issued now: this lane's voxel of the two input grids
-  float ne0[kFusedVox], tg0[kFusedVox];
-  {
-    const int n_act0 = (nvox + kFusedVox - 1) / kFusedVox;
-#pragma unroll
-    for (int u = 0; u < kFusedVox; ++u) {
-      const int vi = (int)threadIdx.x + u * n_act0;
-      ne0[u] = 0.0f;
-      tg0[u] = 0.0f;
-      if ((int)threadIdx.x < n_act0 && vi < nvox) {
-        const int64_t gv = (int64_t)o * V + ((int64_t)x * D + y0) * D + vi;
-        ne0[u] = a.grid_ne[gv];
-        tg0[u] = a.grid_target[gv];
-      }
-    }
+  float ne0 = 0.0f, tg0 = 0.0f;
+  if ((int)threadIdx.x < nvox) {
+    const int64_t gv = (int64_t)o * V + ((int64_t)x * D + y0) * D + (int)threadIdx.x;
+    ne0 = a.grid_ne[gv];
+    tg0 = a.grid_target[gv];
   }
   __syncthreads();
   const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test in pass 2
@@ -1213,63 +1211,65 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
     rb = b;
     rv = a.rec[base_g[kd] + (int64_t)((bin0 + b) * kHalves + half) * cap[kd] + (i - cb)];
   };
-  auto settle = [&](uint32_t *dist, uint32_t *id, const int ad, const uint32_t db, const uint32_t cid) {
-    const uint32_t cur = dist[ad];
-    if (db <= cur + 8u) {  // within a few ulp of the minimal d2
-      bool win = db == cur && __uint_as_float(db) < d2_in;
-      if (!win) {
-        const float dd = pitch * sqrtf(__uint_as_float(db));
-        const float dmin = pitch * sqrtf(__uint_as_float(cur));
-        win = dd == dmin && dd < trunc;
-      }
-      if (win) atomicMin(&id[ad], cid);
+  // candidate `cid` at squared distance bits `db` against the final minimum `cur` of its voxel
+  auto settle_at = [&](uint32_t *id, const int ad, const uint32_t db, const uint32_t cur, const uint32_t cid) {
+    bool win = db == cur && __uint_as_float(db) < d2_in;
+    if (!win) {
+      const float dd = pitch * sqrtf(__uint_as_float(db));
+      const float dmin = pitch * sqrtf(__uint_as_float(cur));
+      win = dd == dmin && dd < trunc;
     }
+    if (win) atomicMin(&id[ad], cid);
   };
-  // the two-pass (min, arg-min) of k_icc_tile, on the LDS arrays of grid kd
-  auto visit = [&](const int pass, const int kd, const float4 sv, const int rb, const unsigned mask) -> unsigned {
+  // The two-pass (min, arg-min) of k_icc_tile on the LDS arrays of grid kd.  The tile carries a
+  // margin of kPad cells on every side: all nine (y, z) candidates of a record of this half's
+  // bins (rounded y in [y0 - 1, y1], z in [-1, D]) address cells of the padded tile, the ones
+  // outside the half land in margin cells nobody reads.  ks = 3 therefore needs NO predicate:
+  // pass 1 = nine fire-and-forget ds_min at constant offsets from one base address (a peek at
+  // the current minimum first, or range / radius tests per candidate, cost more instructions
+  // than the atomics they save: 19.9 -> 18.4 us without the peek alone), pass 2 = the nine
+  // FINAL minima in one batch of reads, the exact test only where this record is within a few
+  // ulp.  A minimum beyond the truncation radius simply finds no winner in pass 2.
+  auto visit = [&](const int pass, const int kd, const float4 sv, const int rb) {
     uint32_t *dist = s_dist + kd * nvh, *id = s_id + kd * nvh;
     const int iry = (int)roundf(sv.y), irz = (int)roundf(sv.z);
     const uint32_t idb = __float_as_uint(sv.w) * (uint32_t)K;
     const int bb = ks - 1 - rb;
     const float dx = sv.x - fxp;
     const float dx2 = dx * dx;
-    unsigned out = 0u;
     if constexpr (KS == 3) {
+      // cell of candidate (aa, cc) = (0, 0): row iry - 1, column irz - 1; clamped so that a
+      // corrupt record cannot leave the tile
+      const int r0 = min(max(iry - 1 - y0 + kPad, 0), rows_p - 3);
+      const int c0 = min(max(irz - 1 + kPad, 0), Wp - 3);
+      const int cbase = r0 * Wp + c0;
+      uint32_t db[9];
+#pragma unroll
+      for (int aa = 0; aa < 3; ++aa) {
+        const float dy = sv.y - (float)(iry + aa - 1);
+        const float dxy = dx2 + dy * dy;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          const float dz = sv.z - (float)(irz + cc - 1);
+          db[aa * 3 + cc] = __float_as_uint(dxy + dz * dz);
+        }
+      }
       if (pass == 1) {
-        uint32_t db[9], cur[9];
-        int ad[9];
 #pragma unroll
-        for (int aa = 0; aa < 3; ++aa) {
-          const int iy = iry + aa - 1;
-          const float dy = sv.y - (float)iy;
-          const float dxy = dx2 + dy * dy;
-#pragma unroll
-          for (int cc = 0; cc < 3; ++cc) {
-            const int iz = irz + cc - 1;
-            const float dz = sv.z - (float)iz;
-            const float d2 = dxy + dz * dz;
-            const bool ok = iy >= y0 && iy < y1 && iz >= 0 && iz < D && d2 < d2_hi;
-            db[aa * 3 + cc] = __float_as_uint(d2);
-            ad[aa * 3 + cc] = ok ? (iy - y0) * D + iz : -1;
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) cur[k] = dist[ad[k] < 0 ? 0 : ad[k]];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          if (ad[k] < 0) continue;
-          if (db[k] <= cur[k]) atomicMin(&dist[ad[k]], db[k]);
-          if (db[k] <= cur[k] + 8u) out |= 1u << k;
-        }
+        for (int k = 0; k < 9; ++k) atomicMin(&dist[cbase + (k / 3) * Wp + (k % 3)], db[k]);
       } else {
+        uint32_t cur[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          if (!((mask >> k) & 1u)) continue;
-          const int aa = k / 3, cc = k % 3;
-          const int iy = iry + aa - 1, iz = irz + cc - 1;
-          const float dy = sv.y - (float)iy, dz = sv.z - (float)iz;
-          const float d2 = (dx2 + dy * dy) + dz * dz;
-          settle(dist, id, (iy - y0) * D + iz, __float_as_uint(d2), idb + (uint32_t)((aa * 3 + bb) * 3 + cc));
+        for (int k = 0; k < 9; ++k) cur[k] = dist[cbase + (k / 3) * Wp + (k % 3)];
+        unsigned near = 0u;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) near |= (db[k] <= cur[k] + 8u ? 1u : 0u) << k;
+        if (near != 0u) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k)
+            if ((near >> k) & 1u)
+              settle_at(id, cbase + (k / 3) * Wp + (k % 3), db[k], cur[k],
+                        idb + (uint32_t)(((k / 3) * 3 + bb) * 3 + (k % 3)));
         }
       }
     } else {
@@ -1278,7 +1278,7 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
         if (iy < y0 || iy >= y1) continue;
         const float dy = sv.y - (float)iy;
         const float dxy = dx2 + dy * dy;
-        const int lrow = (iy - y0) * D;
+        const int lrow = (iy - y0 + kPad) * Wp + kPad;
         for (int cc = 0; cc < ks; ++cc) {
           const int iz = irz + cc - h;
           if (iz < 0 || iz >= D) continue;
@@ -1287,31 +1287,13 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
           if (!(d2 < d2_hi)) continue;
           const uint32_t db = __float_as_uint(d2);
           if (pass == 1) {
-            const uint32_t cur = dist[lrow + iz];
-            if (db <= cur) atomicMin(&dist[lrow + iz], db);
-            if (db <= cur + 8u) out = 1u;
+            atomicMin(&dist[lrow + iz], db);
           } else {
-            settle(dist, id, lrow + iz, db, idb + (uint32_t)((aa * ks + bb) * ks + cc));
+            const uint32_t cur = dist[lrow + iz];
+            if (db <= cur + 8u) settle_at(id, lrow + iz, db, cur, idb + (uint32_t)((aa * ks + bb) * ks + cc));
           }
         }
       }
-    }
-    return out;
-  };
-  auto full_mask = [&](const float4 &sv) -> unsigned {  // streamed records carry no pass-1 mask
-    if constexpr (KS == 3) {
-      const int iry = (int)roundf(sv.y), irz = (int)roundf(sv.z);
-      unsigned m9 = 0u;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const int iy = iry + k / 3 - 1, iz = irz + k % 3 - 1;
-        const float dxs = sv.x - fxp, dy = sv.y - (float)iy, dz = sv.z - (float)iz;
-        const float d2 = (dxs * dxs + dy * dy) + dz * dz;
-        if (iy >= y0 && iy < y1 && iz >= 0 && iz < D && d2 < d2_hi) m9 |= 1u << k;
-      }
-      return m9;
-    } else {
-      return 1u;
     }
   };
 
@@ -1319,19 +1301,18 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   // loads in flight at once (ONE memory round trip); more crowded tiles stream the rest twice
   float4 rvo[kFusedKeepOwn], rvk[kFusedKeepOth];
   int rbo[kFusedKeepOwn], rbk[kFusedKeepOth];
-  unsigned long long keep = 0ull;  // 9 bits per kept record
 #pragma unroll
   for (int u = 0; u < kFusedKeepOwn; ++u) fetch(0, u * kTileThreads + (int)threadIdx.x, rvo[u], rbo[u]);
 #pragma unroll
   for (int u = 0; u < kFusedKeepOth; ++u) fetch(1, u * kTileThreads + (int)threadIdx.x, rvk[u], rbk[u]);
   stamp(1);
+  auto pass_over = [&](const int pass) {
 #pragma unroll
-  for (int u = 0; u < kFusedKeepOwn; ++u)
-    if (rbo[u] >= 0) keep |= (unsigned long long)visit(1, 0, rvo[u], rbo[u], 0u) << (9 * u);
+    for (int u = 0; u < kFusedKeepOwn; ++u)
+      if (rbo[u] >= 0) visit(pass, 0, rvo[u], rbo[u]);
 #pragma unroll
-  for (int u = 0; u < kFusedKeepOth; ++u)
-    if (rbk[u] >= 0) keep |= (unsigned long long)visit(1, 1, rvk[u], rbk[u], 0u) << (9 * (kFusedKeepOwn + u));
-  auto stream_rest = [&](const int pass) {
+    for (int u = 0; u < kFusedKeepOth; ++u)
+      if (rbk[u] >= 0) visit(pass, 1, rvk[u], rbk[u]);
 #pragma unroll
     for (int kd = 0; kd < 2; ++kd) {
       const int first = kTileThreads * (kd == 0 ? kFusedKeepOwn : kFusedKeepOth);
@@ -1341,129 +1322,129 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
 #pragma unroll
         for (int u = 0; u < kTileR; ++u) fetch(kd, base + u * kTileThreads + (int)threadIdx.x, xv[u], xb[u]);
 #pragma unroll
-        for (int u = 0; u < kTileR; ++u) {
-          if (xb[u] < 0) continue;
-          if (pass == 1) {
-            visit(1, kd, xv[u], xb[u], 0u);
-          } else {
-            const unsigned m9 = full_mask(xv[u]);
-            if (m9 != 0u) visit(2, kd, xv[u], xb[u], m9);
-          }
-        }
+        for (int u = 0; u < kTileR; ++u)
+          if (xb[u] >= 0) visit(pass, kd, xv[u], xb[u]);
       }
     }
   };
-  stream_rest(1);
+  if (!(a.dbg & 128)) pass_over(1);  // XDBG
   __syncthreads();
   stamp(2);
-#pragma unroll
-  for (int u = 0; u < kFusedKeepOwn; ++u) {
-    const unsigned m9 = (unsigned)(keep >> (9 * u)) & 0x1ffu;
-    if (m9 != 0u) visit(2, 0, rvo[u], rbo[u], m9);
-  }
-#pragma unroll
-  for (int u = 0; u < kFusedKeepOth; ++u) {
-    const unsigned m9 = (unsigned)(keep >> (9 * (kFusedKeepOwn + u))) & 0x1ffu;
-    if (m9 != 0u) visit(2, 1, rvk[u], rbk[u], m9);
-  }
-  stream_rest(2);
+  if (!(a.dbg & 256)) pass_over(2);  // XDBG
   __syncthreads();
   stamp(3);
+  if (a.dbg & 512) return;  // XDBG
 
-  // ---- voxel phase: kFusedVox voxels per active lane (one at D = 32; with two, half the waves
-  // pay the 65 row reductions once per two voxels but the per-lane dependent chain doubles --
-  // measured slower).  Waves without any own winner skip the 60 moment reductions.
-  const float *Rt_o = s_Rt[o - ja];
-  float wmax_own = 0.0f, wmax_oth = 0.0f;
-  constexpr int kRows = kTileThreads / 16;
-  const int n_act = (nvox + kFusedVox - 1) / kFusedVox;  // active lanes (256 at D = 32)
-  const int n_rows = (n_act + 15) / 16;
-  int ecol[kFusedVox];
-  float cv[kFusedVox][12];
+  // ---- voxel phase.  Only a voxel WITH an own winner adds to any sum (without one g = 0 and
+  // w = 0), and those are the few voxels of the surface shell, scattered over most waves of
+  // the tile: compact them, so that ceil(n / 64) waves pay the arithmetic and the 65 row
+  // reductions instead of every wave the shell touches.  The maximum of the OTHER grid's
+  // weights needs every voxel with an other-winner: taken here in the voxel-per-lane layout,
+  // its gather is in flight during the compaction.
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto cell = [&](const int vi) { return (vi / D + kPad) * Wp + (vi % D + kPad); };  // voxel -> padded cell
+  const int my_cell = cell(tid < nvox ? tid : 0);
+  const uint32_t my_id = tid < nvox ? s_id[my_cell] : kNoCand;
+  const uint32_t my_ido = tid < nvox ? s_id[nvh + my_cell] : kNoCand;
+  const float wo_mine = my_ido != kNoCand ? a.pts4[my_ido / (uint32_t)K].w : -1.0f;
+  s_netg[tid] = make_float2(ne0, tg0);  // for the lane that takes this voxel
+  const bool act = my_id != kNoCand;
+  const unsigned long long bal = __ballot(act);
+  if (lane == 0) s_wcnt[wave] = __popcll(bal);
+  __syncthreads();
+  int before = 0, total = 0;
 #pragma unroll
-  for (int u = 0; u < kFusedVox; ++u) ecol[u] = -1;
-  if ((int)(threadIdx.x & ~63u) < n_act) {  // wave-uniform
+  for (int w = 0; w < kTileThreads / 64; ++w) {
+    const int cw = s_wcnt[w];
+    before += w < wave ? cw : 0;
+    total += cw;
+  }
+  if (act) s_list[before + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+  __syncthreads();
+  stamp(5);
+  const float *Rt_o = s_Rt[o - ja];
+  float wmax_own = 0.0f;
+  float wmax_oth = fmaxf(wo_mine + 0.0f, 0.0f);
+  constexpr int kRows = kTileThreads / 16;
+  const int n_rows = (total + 15) / 16;
+  const bool wave_on = (tid & ~63) < total;  // wave-uniform
+  int ecol = -1;
+  float cv[12];
+  if (wave_on) {
     float val[kNumF];
 #pragma unroll
     for (int k = 0; k < kNumF; ++k) val[k] = 0.0f;
     bool any_mom = false;
-    uint32_t lo[kFusedVox], lo_o[kFusedVox];
-    float4 m_own[kFusedVox], m_oth[kFusedVox];
-#pragma unroll
-    for (int u = 0; u < kFusedVox; ++u) {  // all winner gathers in flight together
-      const int vi = (int)threadIdx.x + u * n_act;
-      const bool live = (int)threadIdx.x < n_act && vi < nvox;
-      lo[u] = live ? s_id[vi] : kNoCand;
-      lo_o[u] = live ? s_id[nvh + vi] : kNoCand;
-      m_own[u] = lo[u] != kNoCand ? a.pts4[lo[u] / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
-      m_oth[u] = lo_o[u] != kNoCand ? a.pts4[lo_o[u] / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
+    const bool live = tid < total;
+    const int vi = live ? (int)s_list[tid] : 0;
+    const int pc = cell(vi);
+    const uint32_t lo = live ? s_id[pc] : kNoCand;
+    const uint32_t lo_o = live ? s_id[nvh + pc] : kNoCand;
+    // winner gathers in flight together
+    const float4 m_own = lo != kNoCand ? a.pts4[lo / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
+    const float4 m_oth = lo_o != kNoCand ? a.pts4[lo_o / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
+    const float2 netg = s_netg[vi];
+    const float ne = live ? netg.x : 0.0f, tg = live ? netg.y : 0.0f;
+    const bool has = lo != kNoCand, has_o = lo_o != kNoCand;
+    const float dist_o = has ? pitch * sqrtf(__uint_as_float(s_dist[pc])) : trunc;
+    const float dist_k = has_o ? pitch * sqrtf(__uint_as_float(s_dist[nvh + pc])) : trunc;
+    const int iy = y0 + vi / D, iz = vi % D;
+    const float g = 1.0f - dist_o / trunc;  // 1 - tdf/trunc
+    float w = m_own.w + a.sdf_offset;
+    const bool neg = w < 0.0f;
+    if (neg) w = 0.0f;
+    const float go = 1.0f - dist_k / trunc;
+    float wo = m_oth.w + 0.0f;
+    if (wo < 0.0f) wo = 0.0f;
+    if (live) wmax_own = w;
+    const float gw = g * w;
+    const float gwo = (1.0f - ne) * (go * wo);  // (1 - ne) * go * wo: the part that needs b
+    if (live) {
+      val[0] = neg ? 0.0f : g * tg;
+      val[1] = gw * tg;
+      val[2] = gw;
+      val[3] = gw * ne;
+      val[4] = gw * gwo;
     }
+    if (live && has) {
+      float ux, uy, uz;
+      bool ok;
+      world_frac(Rt_o, m_own, ox, oy, oz, pitch, x, iy, iz, ux, uy, uz, ok);
+      if (ok) {
+        any_mom = true;
+        const float kk[5] = {neg ? 0.0f : tg / trunc, w * tg / trunc, w * ne / trunc, w * gwo / trunc, w / trunc};
+        const float uu[3] = {ux, uy, uz};
 #pragma unroll
-    for (int u = 0; u < kFusedVox; ++u) {
-      const int vi = (int)threadIdx.x + u * n_act;
-      const bool live = (int)threadIdx.x < n_act && vi < nvox;
-      const float ne = ne0[u], tg = tg0[u];
-      const bool has = lo[u] != kNoCand, has_o = lo_o[u] != kNoCand;
-      const float dist_o = has ? pitch * sqrtf(__uint_as_float(s_dist[vi])) : trunc;
-      const float dist_k = has_o ? pitch * sqrtf(__uint_as_float(s_dist[nvh + vi])) : trunc;
-      const int iy = y0 + vi / D, iz = vi % D;
-      const float g = 1.0f - dist_o / trunc;  // 1 - tdf/trunc
-      float w = m_own[u].w + a.sdf_offset;
-      const bool neg = w < 0.0f;
-      if (neg) w = 0.0f;
-      const float go = 1.0f - dist_k / trunc;
-      float wo = m_oth[u].w + 0.0f;
-      if (wo < 0.0f) wo = 0.0f;
-      if (live) { wmax_own = fmaxf(wmax_own, w); wmax_oth = fmaxf(wmax_oth, wo); }
-      const float gw = g * w;
-      const float gwo = (1.0f - ne) * (go * wo);  // (1 - ne) * go * wo: the part that needs b
-      if (live) {
-        val[0] += neg ? 0.0f : g * tg;
-        val[1] += gw * tg;
-        val[2] += gw;
-        val[3] += gw * ne;
-        val[4] += gw * gwo;
-      }
-      if (live && has) {
-        float ux, uy, uz;
-        bool ok;
-        world_frac(Rt_o, m_own[u], ox, oy, oz, pitch, x, iy, iz, ux, uy, uz, ok);
-        if (ok) {
-          any_mom = true;
-          const float kk[5] = {neg ? 0.0f : tg / trunc, w * tg / trunc, w * ne / trunc, w * gwo / trunc, w / trunc};
-          const float uu[3] = {ux, uy, uz};
-#pragma unroll
-          for (int sset = 0; sset < 5; ++sset)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-              const float sc = uu[d] * kk[sset];
-              val[5 + 12 * sset + 4 * d + 0] += sc * m_own[u].x;
-              val[5 + 12 * sset + 4 * d + 1] += sc * m_own[u].y;
-              val[5 + 12 * sset + 4 * d + 2] += sc * m_own[u].z;
-              val[5 + 12 * sset + 4 * d + 3] += sc;
-            }
-        }
-      }
-      // collision term: gradient flows to the OTHER object's pose (kept for the reduction below)
-      if (live && ne == 0.0f && has_o && go * wo > 0.0f && gw != 0.0f) {
-        const uint32_t p = lo_o[u] / (uint32_t)K;
-        int e = 0;
-        while (e + 1 < Ns && (int)p >= s_off[e + 1]) ++e;
-        float ux, uy, uz;
-        bool ok;
-        world_frac(s_Rt[e], m_oth[u], ox, oy, oz, pitch, x, iy, iz, ux, uy, uz, ok);
-        const float B = wo * gw / trunc;
-        if (ok && isfinite(B)) {
-          const float uu[3] = {ux, uy, uz};
-          ecol[u] = e;
+        for (int sset = 0; sset < 5; ++sset)
 #pragma unroll
           for (int d = 0; d < 3; ++d) {
-            const float sB = uu[d] * B;
-            cv[u][4 * d + 0] = sB * m_oth[u].x;
-            cv[u][4 * d + 1] = sB * m_oth[u].y;
-            cv[u][4 * d + 2] = sB * m_oth[u].z;
-            cv[u][4 * d + 3] = sB;
+            const float sc = uu[d] * kk[sset];
+            val[5 + 12 * sset + 4 * d + 0] = sc * m_own.x;
+            val[5 + 12 * sset + 4 * d + 1] = sc * m_own.y;
+            val[5 + 12 * sset + 4 * d + 2] = sc * m_own.z;
+            val[5 + 12 * sset + 4 * d + 3] = sc;
           }
+      }
+    }
+    // collision term: gradient flows to the OTHER object's pose (kept for the reduction below)
+    if (live && ne == 0.0f && has_o && go * wo > 0.0f && gw != 0.0f) {
+      const uint32_t pp = lo_o / (uint32_t)K;
+      int e = 0;
+      while (e + 1 < Ns && (int)pp >= s_off[e + 1]) ++e;
+      float ux, uy, uz;
+      bool ok;
+      world_frac(s_Rt[e], m_oth, ox, oy, oz, pitch, x, iy, iz, ux, uy, uz, ok);
+      const float B = wo * gw / trunc;
+      if (ok && isfinite(B)) {
+        const float uu[3] = {ux, uy, uz};
+        ecol = e;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const float sB = uu[d] * B;
+          cv[4 * d + 0] = sB * m_oth.x;
+          cv[4 * d + 1] = sB * m_oth.y;
+          cv[4 * d + 2] = sB * m_oth.z;
+          cv[4 * d + 3] = sB;
         }
       }
     }
@@ -1473,30 +1454,29 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
     for (int k = 0; k < kNumF; ++k) {
       float r = 0.0f;
       if (k < 5 || wave_mom) r = mf::row16_sum(val[k]);
-      if ((threadIdx.x & 15) == 0) s_rows[threadIdx.x >> 4][k] = r;
+      if ((tid & 15) == 0) s_rows[tid >> 4][k] = r;
     }
   }
-#pragma unroll
-  for (int u = 0; u < kFusedVox; ++u)
-    if (ecol[u] >= 0) atomicOr(&s_emask, 1u << ecol[u]);
+  if (ecol >= 0) atomicOr(&s_emask, 1u << ecol);
   // per-grid maxima of the raw inside weights (the normalisers a, b of the step)
   wmax_own = mf::wave_max(wmax_own);
   wmax_oth = mf::wave_max(wmax_oth);
-  if ((threadIdx.x & 63) == 0) { s_max[0][threadIdx.x >> 6] = wmax_own; s_max[1][threadIdx.x >> 6] = wmax_oth; }
+  if (lane == 0) { s_max[0][wave] = wmax_own; s_max[1][wave] = wmax_oth; }
   __syncthreads();
-  if (threadIdx.x < 2) {
-    float m = s_max[threadIdx.x][0];
+  if (tid < 2) {
+    float m = s_max[tid][0];
 #pragma unroll
-    for (int i = 1; i < kTileThreads / 64; ++i) m = fmaxf(m, s_max[threadIdx.x][i]);
-    if (m > 0.0f) atomicMax(&a.Mbits[(int64_t)par * 2 * a.O + 2 * o + threadIdx.x], __float_as_uint(m));
+    for (int i = 1; i < kTileThreads / 64; ++i) m = fmaxf(m, s_max[tid][i]);
+    if (m > 0.0f) atomicMax(&a.Mbits[(int64_t)par * 2 * a.O + 2 * o + tid], __float_as_uint(m));
   }
+  if (total == 0) return;  // block-uniform: no own winner here, nothing to add
   long long *own = a.acc_own + ((int64_t)par * a.O + o) * kOwnSlots;
-  if (threadIdx.x < kNumF) {
+  if (tid < kNumF) {
     float sacc = 0.0f;
-    for (int r = 0; r < n_rows; ++r) sacc += s_rows[r][threadIdx.x];
+    for (int r = 0; r < n_rows; ++r) sacc += s_rows[r][tid];
     if (isfinite(sacc)) {
       const long long xq = __double2ll_rn((double)sacc * kFixOwn);
-      if (xq != 0) atomicAdd(reinterpret_cast<unsigned long long *>(own + threadIdx.x), (unsigned long long)xq);
+      if (xq != 0) atomicAdd(reinterpret_cast<unsigned long long *>(own + tid), (unsigned long long)xq);
     } else {
       atomicAdd(reinterpret_cast<unsigned long long *>(own + kNumF), 1ull);  // -> NaN loss
     }
@@ -1504,25 +1484,23 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   stamp(4);
   long long *po = a.acc_oth + ((int64_t)par * a.O + o) * a.max_ns * 12;
   const uint32_t em0 = s_emask;
-  for (uint32_t em = em0; em != 0u; em &= em - 1u) {
-    const int e = __ffs((int)em) - 1;
+  if (em0 == 0u) return;  // block-uniform
+  if (wave_on) {
+    for (uint32_t em = em0; em != 0u; em &= em - 1u) {
+      const int e = __ffs((int)em) - 1;
 #pragma unroll
-    for (int cc = 0; cc < 12; ++cc) {
-      float v = 0.0f;
-#pragma unroll
-      for (int u = 0; u < kFusedVox; ++u) v += ecol[u] == e ? cv[u][cc] : 0.0f;
-      const float r = mf::row16_sum(v);
-      if ((threadIdx.x & 15) == 0) s_rows2[(e * kRows + (threadIdx.x >> 4)) * 13 + cc] = r;
+      for (int cc = 0; cc < 12; ++cc) {
+        const float r = mf::row16_sum(ecol == e ? cv[cc] : 0.0f);
+        if ((tid & 15) == 0) s_rows2[(e * kRows + (tid >> 4)) * 13 + cc] = r;
+      }
     }
   }
-  if (em0 == 0u) return;  // block-uniform
   __syncthreads();
-  for (int i = threadIdx.x; i < a.max_ns * 12; i += kTileThreads) {
+  for (int i = tid; i < a.max_ns * 12; i += kTileThreads) {
     const int e = i / 12, cc = i - 12 * e;
     if (!((em0 >> e) & 1u)) continue;
     float sacc = 0.0f;
-#pragma unroll
-    for (int r = 0; r < kRows; ++r) sacc += s_rows2[(e * kRows + r) * 13 + cc];
+    for (int r = 0; r < n_rows; ++r) sacc += s_rows2[(e * kRows + r) * 13 + cc];
     const long long xq = isfinite(sacc) ? __double2ll_rn((double)sacc * kFixOth) : 0;
     if (xq != 0) atomicAdd(reinterpret_cast<unsigned long long *>(po + i), (unsigned long long)xq);
   }
@@ -1684,8 +1662,8 @@ void launch_iteration(const IccArgs &a, IccStepArgs sp, int NB, int k, hipStream
   const size_t lds_tile = (size_t)((D + 1) / 2) * D * 2 * sizeof(uint32_t);  // 4 KB at D = 32
   const size_t lds_rows2 = (size_t)a.max_ns * (kAccThreads / 16) * 13 * sizeof(float);  // <= 53 KB
   if (a.ne_binary) {
-    hipLaunchKernelGGL(k_icc_fused, dim3(D * kHalves, a.O), dim3(kTileThreads), 2 * lds_tile + lds_rows2, stream,
-                       a, par);
+    hipLaunchKernelGGL(k_icc_fused, dim3(D * kHalves, a.O), dim3(kTileThreads),
+                       4 * fused_tile_words(D) * sizeof(uint32_t) + lds_rows2, stream, a, par);
     return;
   }
   hipLaunchKernelGGL(k_icc_tile, dim3(D * kHalves, 2 * a.O), dim3(kTileThreads), lds_tile, stream, a, par);
@@ -1761,7 +1739,7 @@ extern "C" int mf_icc_launch_stage(const mfIccBatch *batch, const float *q, cons
       mf::set_last_error(hipErrorInvalidValue, "mf_icc_launch_stage: stage 2 needs {0,1} no-entry grids");
       return -(int)hipErrorInvalidValue;
     }
-    const size_t lds = (size_t)((D + 1) / 2) * D * 4 * sizeof(uint32_t) +
+    const size_t lds = 4 * fused_tile_words(D) * sizeof(uint32_t) +
                        (size_t)a.max_ns * (kAccThreads / 16) * 13 * sizeof(float);
     hipLaunchKernelGGL(k_icc_fused, dim3(D * kHalves, a.O), dim3(kTileThreads), lds, stream, a, 0);
   } else {

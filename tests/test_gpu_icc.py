@@ -359,8 +359,9 @@ def test_icc_refine_teacher_forced_vs_committed_golden(fixtures3):
 
 def test_icp_fused_loop_vs_committed_golden_and_autograd_loop(fixtures3):
     """icp_refine (mf_icp_refine: the driver loop of check_iterative_closest_point_link.py:40-70 on the
-    device, every link of the ChainList in one batch) against (a) the committed 30-iterate oracle
-    trajectory of fixture 2 and (b) the same loop driven through autograd + optimizers.Adam, per link."""
+    device, every link of the ChainList in one batch) against (a) the same loop driven through
+    autograd + optimizers.Adam per link for the first steps, and (b) the committed 30-iterate oracle
+    trajectory of fixture 2, reached by a second call that continues the optimiser state."""
     from conftest import golden
     g = golden("oracle_icc_icp_trajectories.npz")
     sets = []
@@ -368,28 +369,43 @@ def test_icp_fused_loop_vs_committed_golden_and_autograd_loop(fixtures3):
         tgt = np.ascontiguousarray((np.argwhere(f["grid_target"] >= 0.5) * f["pitch"] + f["origin"]).astype(np.float32))
         src = np.ascontiguousarray(f["pcd_cad"].astype(np.float32)[:: (1, 3, 2)[i]])
         sets.append((f["transform_init"], dev(src), dev(tgt)))
-    n_iter = 30
+    n0, n1 = 6, 24
     links = [mf.contrib.IterativeClosestPointLink(T).to_gpu() for T, _, _ in sets]
-    losses = mf.contrib.icp_refine(links, [s for _, s, _ in sets], [t for _, _, t in sets], n_iter=n_iter,
-                                   return_history=True).cpu().numpy()
-    np.testing.assert_allclose(losses[:, 0], g["icp_losses"][:n_iter], rtol=1e-4)
+    srcs, tgts = [s for _, s, _ in sets], [t for _, _, t in sets]
+    losses = mf.contrib.icp_refine(links, srcs, tgts, n_iter=n0, return_history=True).cpu().numpy()
+    np.testing.assert_allclose(losses[:, 0], g["icp_losses"][:n0], rtol=1e-4)
     got = np.r_[links[0].quaternion.detach().cpu().numpy(), links[0].translation.detach().cpu().numpy()]
-    np.testing.assert_allclose(got, g["icp_final"], atol=2e-4)  # 30 free-running float32 steps
+    np.testing.assert_allclose(got, g["icp_traj"][n0], atol=2e-5)
     for i, (T, src, tgt) in enumerate(sets):
+        # (a1) the oracle's loop on this link
+        qi = O.quaternion_from_matrix(T).astype(np.float32)
+        ti = np.asarray(T)[:3, 3].astype(np.float32).copy()
+        opt_o = O.ChainerAdam([qi, ti], [0.01, 0.001])
+        for k in range(n0):
+            l_o, gq, gt = OC.icp_loss_grad(src.cpu().numpy(), tgt.cpu().numpy(), qi, ti)
+            np.testing.assert_allclose(losses[k, i], l_o, rtol=2e-4, err_msg=f"link {i} iter {k}")
+            opt_o.update([gq, gt])
+        got_i = np.r_[links[i].quaternion.detach().cpu().numpy(), links[i].translation.detach().cpu().numpy()]
+        np.testing.assert_allclose(got_i, np.r_[qi, ti], atol=1e-4)
+        # (a2) autograd + optimizers.Adam: the same losses; the poses only loosely (a component
+        # whose gradient is rounding noise takes an Adam step of full size in either direction)
         ref = mf.contrib.IterativeClosestPointLink(T).to_gpu()
         opt = mf.optimizers.Adam(alpha=0.01).setup(ref)
         ref.translation.update_rule.hyperparam.alpha *= 0.1
-        for k in range(n_iter):
+        for k in range(n0):
             ref.zerograds()
             loss = ref(src, tgt)
             loss.backward()
             opt.update()
-            np.testing.assert_allclose(losses[k, i], float(loss), rtol=2e-4, err_msg=f"link {i} iter {k}")
-        np.testing.assert_allclose(links[i].quaternion.detach().cpu().numpy(), ref.quaternion.detach().cpu().numpy(), atol=2e-4)
-        np.testing.assert_allclose(links[i].translation.detach().cpu().numpy(), ref.translation.detach().cpu().numpy(), atol=2e-4)
-    # a second call continues the same optimiser (moments and step count live on the link)
-    more = mf.contrib.icp_refine(links[:1], [sets[0][1]], [sets[0][2]], n_iter=2, return_history=True)
-    assert links[0]._adam_t == n_iter + 2 and float(more[0, 0]) <= losses[0, 0]
+            np.testing.assert_allclose(losses[k, i], float(loss), rtol=2e-3, err_msg=f"link {i} iter {k}")
+        np.testing.assert_allclose(links[i].quaternion.detach().cpu().numpy(), ref.quaternion.detach().cpu().numpy(), atol=5e-3)
+        np.testing.assert_allclose(links[i].translation.detach().cpu().numpy(), ref.translation.detach().cpu().numpy(), atol=5e-4)
+    # the second call continues the same optimiser (moments and step count live on the links)
+    more = mf.contrib.icp_refine(links, srcs, tgts, n_iter=n1, return_history=True).cpu().numpy()
+    assert links[0]._adam_t == n0 + n1
+    np.testing.assert_allclose(more[:, 0], g["icp_losses"][n0:n0 + n1], rtol=1e-3)
+    got = np.r_[links[0].quaternion.detach().cpu().numpy(), links[0].translation.detach().cpu().numpy()]
+    np.testing.assert_allclose(got, g["icp_final"], atol=2e-4)  # 30 free-running float32 steps
 
 
 def test_icc_fractional_no_entry_grid_two_kernel_path_vs_oracle(scene8):
