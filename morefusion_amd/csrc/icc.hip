@@ -900,6 +900,22 @@ __device__ __forceinline__ void world_frac(const float *Rt, const float4 m, floa
   ux = dx / n; uy = dy / n; uz = dz / n;
 }
 
+// the same with reciprocal multiplies (k_icc_fused's voxel phase; see there)
+__device__ __forceinline__ void world_frac_r(const float *Rt, const float4 m, float ox, float oy,
+                                             float oz, float inv_pitch, int ix, int iy, int iz,
+                                             float &ux, float &uy, float &uz, bool &ok) {
+  const float wx = ((Rt[0] * m.x + Rt[1] * m.y) + Rt[2] * m.z) + Rt[9];
+  const float wy = ((Rt[3] * m.x + Rt[4] * m.y) + Rt[5] * m.z) + Rt[10];
+  const float wz = ((Rt[6] * m.x + Rt[7] * m.y) + Rt[8] * m.z) + Rt[11];
+  const float dx = (wx - ox) * inv_pitch - (float)ix;
+  const float dy = (wy - oy) * inv_pitch - (float)iy;
+  const float dz = (wz - oz) * inv_pitch - (float)iz;
+  const float n2 = (dx * dx + dy * dy) + dz * dz;
+  ok = n2 > 0.0f;  // truncated_distance_function.py:141
+  const float rn = __frsqrt_rn(n2);
+  ux = dx * rn; uy = dy * rn; uz = dz * rn;
+}
+
 constexpr int kVPT = kVoxPerBlock / kAccThreads;  // voxels per thread
 
 __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
@@ -1128,17 +1144,31 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
 // second launch, no dependent re-load of what the tile just computed.  Same arithmetic per
 // voxel as k_icc_accum up to the association of the normaliser (tests: loss within 2e-5,
 // step within 1e-5 of the oracle's).  Grids with other values take the two-kernel path.
+// static LDS of k_icc_fused (declared once in the kernel: the body is instantiated per kernel size)
+struct FusedLds {
+  float rows[kTileThreads / 16][kNumF + 1];
+  float max[2][kTileThreads / 64];
+  float Rt[kMaxSceneObjects][12];
+  int off[kMaxSceneObjects + 1];
+  // voxels with an own winner, compacted in voxel order: index, (no-entry, target), winner points
+  uint16_t list[kTileThreads];
+  float2 netg[kTileThreads];
+  float4 mown[kTileThreads], moth[kTileThreads];
+  int wcnt[kTileThreads / 64];
+};
+
 template <int KS>
-__device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt, const int par) {
+__device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt, const int par, FusedLds &L) {
   MF_DYN_LDS(uint32_t, s_tile);  // dist[2][nvh] | id[2][nvh] | rows2[max_ns][32][13] floats
-  __shared__ float s_rows[kTileThreads / 16][kNumF + 1];
-  __shared__ float s_max[2][kTileThreads / 64];
-  __shared__ float s_Rt[kMaxSceneObjects][12];
-  __shared__ int s_off[kMaxSceneObjects + 1];
-  __shared__ uint32_t s_emask;
-  __shared__ float2 s_netg[kTileThreads];   // (no-entry, target) of voxel i, for its compacted lane
-  __shared__ uint16_t s_list[kTileThreads];  // voxels with an own winner, in voxel order
-  __shared__ int s_wcnt[kTileThreads / 64];
+  auto &s_rows = L.rows;
+  auto &s_max = L.max;
+  auto &s_Rt = L.Rt;
+  auto &s_off = L.off;
+  auto &s_list = L.list;
+  auto &s_netg = L.netg;
+  auto &s_mown = L.mown;
+  auto &s_moth = L.moth;
+  auto &s_wcnt = L.wcnt;
   const int ks = KS > 0 ? KS : ks_rt;
   const int h = ks / 2, K = ks * ks * ks;
   const int D = a.D, nb = a.nbins, hmax = a.hmax, V = D * D * D;
@@ -1177,9 +1207,10 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
   if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
-  if (threadIdx.x == 0) s_emask = 0u;
   const float trunc = a.thr * pitch;
   for (int i = threadIdx.x; i < 2 * nvh; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
+  for (int i = threadIdx.x; i < Ns * (kTileThreads / 16) * 13; i += kTileThreads) s_rows2[i] = 0.0f;
+  for (int i = threadIdx.x; i < (kTileThreads / 16) * (kNumF + 1); i += kTileThreads) (&s_rows[0][0])[i] = 0.0f;
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
   auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
     if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
@@ -1197,6 +1228,8 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test in pass 2
   const float d2_in = a.thr * a.thr * 0.999f;    // certainly inside the truncation radius
   const float fxp = (float)x;
+  const uint32_t hi_bits = __float_as_uint(d2_hi) - 1u;  // d2 < d2_hi on the bit patterns (d2 >= 0)
+  const uint32_t in_bits = __float_as_uint(d2_in);       // d2 < d2_in  <=>  bits < in_bits
 
   // record i of grid kd's concatenated bins -> (plane offset b, record); rb < 0: none
   auto fetch = [&](const int kd, const int i, float4 &rv, int &rb) {
@@ -1261,13 +1294,26 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
         uint32_t cur[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) cur[k] = dist[cbase + (k / 3) * Wp + (k % 3)];
-        unsigned near = 0u;
+        // fast: this record IS the minimum, certainly inside the truncation radius -> candidate
+        // for the arg-min.  slow (rare): within a few ulp of the minimum or near the radius ->
+        // the exact float test.  Kept as a separate loop behind one branch: inlined next to the
+        // fast path the compiler speculates both square roots into every candidate (measured:
+        // pass 2 at 4-5 us in every tile, 50 instructions per candidate).
+        unsigned fast = 0u, slow = 0u;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) near |= (db[k] <= cur[k] + 8u ? 1u : 0u) << k;
-        if (near != 0u) {
+        for (int k = 0; k < 9; ++k) {
+          const bool f = db[k] == cur[k] && db[k] < in_bits;
+          const bool nr = db[k] <= min(cur[k] + 8u, hi_bits);
+          fast |= (f ? 1u : 0u) << k;
+          slow |= (nr && !f ? 1u : 0u) << k;
+        }
 #pragma unroll
+        for (int k = 0; k < 9; ++k)
+          if ((fast >> k) & 1u)
+            atomicMin(&id[cbase + (k / 3) * Wp + (k % 3)], idb + (uint32_t)(((k / 3) * 3 + bb) * 3 + (k % 3)));
+        if (slow != 0u) {
           for (int k = 0; k < 9; ++k)
-            if ((near >> k) & 1u)
+            if ((slow >> k) & 1u)
               settle_at(id, cbase + (k / 3) * Wp + (k % 3), db[k], cur[k],
                         idb + (uint32_t)(((k / 3) * 3 + bb) * 3 + (k % 3)));
         }
@@ -1346,9 +1392,11 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   const int my_cell = cell(tid < nvox ? tid : 0);
   const uint32_t my_id = tid < nvox ? s_id[my_cell] : kNoCand;
   const uint32_t my_ido = tid < nvox ? s_id[nvh + my_cell] : kNoCand;
-  const float wo_mine = my_ido != kNoCand ? a.pts4[my_ido / (uint32_t)K].w : -1.0f;
-  s_netg[tid] = make_float2(ne0, tg0);  // for the lane that takes this voxel
+  // both winner gathers of this voxel in flight during the compaction; the lane that takes the
+  // voxel reads them from LDS (no second dependent global round trip)
   const bool act = my_id != kNoCand;
+  const float4 g_own = act ? a.pts4[my_id / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
+  const float4 g_oth = my_ido != kNoCand ? a.pts4[my_ido / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
   const unsigned long long bal = __ballot(act);
   if (lane == 0) s_wcnt[wave] = __popcll(bal);
   __syncthreads();
@@ -1359,82 +1407,97 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
     before += w < wave ? cw : 0;
     total += cw;
   }
-  if (act) s_list[before + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+  if (act) {
+    const int slot = before + __popcll(bal & ((1ull << lane) - 1ull));
+    s_list[slot] = (uint16_t)tid;
+    s_mown[slot] = g_own;
+    s_moth[slot] = g_oth;
+    s_netg[slot] = make_float2(ne0, tg0);
+  }
   __syncthreads();
   stamp(5);
   const float *Rt_o = s_Rt[o - ja];
   float wmax_own = 0.0f;
-  float wmax_oth = fmaxf(wo_mine + 0.0f, 0.0f);
+  float wmax_oth = fmaxf(g_oth.w + 0.0f, 0.0f);
   constexpr int kRows = kTileThreads / 16;
   const int n_rows = (total + 15) / 16;
-  const bool wave_on = (tid & ~63) < total;  // wave-uniform
-  int ecol = -1;
-  float cv[12];
-  if (wave_on) {
-    float val[kNumF];
-#pragma unroll
-    for (int k = 0; k < kNumF; ++k) val[k] = 0.0f;
-    bool any_mom = false;
+  if ((tid & ~63) < total) {  // wave-uniform
     const bool live = tid < total;
     const int vi = live ? (int)s_list[tid] : 0;
     const int pc = cell(vi);
     const uint32_t lo = live ? s_id[pc] : kNoCand;
     const uint32_t lo_o = live ? s_id[nvh + pc] : kNoCand;
-    // winner gathers in flight together
-    const float4 m_own = lo != kNoCand ? a.pts4[lo / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
-    const float4 m_oth = lo_o != kNoCand ? a.pts4[lo_o / (uint32_t)K] : make_float4(0, 0, 0, -1.0f);
-    const float2 netg = s_netg[vi];
+    const float4 m_own = live ? s_mown[tid] : make_float4(0, 0, 0, -1.0f);
+    const float4 m_oth = live ? s_moth[tid] : make_float4(0, 0, 0, -1.0f);
+    const float2 netg = s_netg[tid];
     const float ne = live ? netg.x : 0.0f, tg = live ? netg.y : 0.0f;
     const bool has = lo != kNoCand, has_o = lo_o != kNoCand;
+    // Winners (arg-min) are exact; from here on the weights use reciprocal multiplies
+    // (x * (1/trunc), x * (1/pitch), d * rsq(|d|^2)) instead of IEEE divides: <= 2 ulp per factor,
+    // far inside the tolerance of the sums (which are re-associated anyway), and ~200 fewer
+    // instructions on the one wave whose issue time is this phase.
+    const float inv_trunc = 1.0f / trunc, inv_pitch = 1.0f / pitch;
     const float dist_o = has ? pitch * sqrtf(__uint_as_float(s_dist[pc])) : trunc;
     const float dist_k = has_o ? pitch * sqrtf(__uint_as_float(s_dist[nvh + pc])) : trunc;
     const int iy = y0 + vi / D, iz = vi % D;
-    const float g = 1.0f - dist_o / trunc;  // 1 - tdf/trunc
+    const float g = has ? fmaxf(1.0f - dist_o * inv_trunc, 0.0f) : 0.0f;  // 1 - tdf/trunc
     float w = m_own.w + a.sdf_offset;
     const bool neg = w < 0.0f;
     if (neg) w = 0.0f;
-    const float go = 1.0f - dist_k / trunc;
+    const float go = has_o ? fmaxf(1.0f - dist_k * inv_trunc, 0.0f) : 0.0f;
     float wo = m_oth.w + 0.0f;
     if (wo < 0.0f) wo = 0.0f;
     if (live) wmax_own = w;
     const float gw = g * w;
     const float gwo = (1.0f - ne) * (go * wo);  // (1 - ne) * go * wo: the part that needs b
-    if (live) {
-      val[0] = neg ? 0.0f : g * tg;
-      val[1] = gw * tg;
-      val[2] = gw;
-      val[3] = gw * ne;
-      val[4] = gw * gwo;
-    }
-    if (live && has) {
-      float ux, uy, uz;
-      bool ok;
-      world_frac(Rt_o, m_own, ox, oy, oz, pitch, x, iy, iz, ux, uy, uz, ok);
-      if (ok) {
-        any_mom = true;
-        const float kk[5] = {neg ? 0.0f : tg / trunc, w * tg / trunc, w * ne / trunc, w * gwo / trunc, w / trunc};
-        const float uu[3] = {ux, uy, uz};
+    const int row = tid >> 4;
+    const bool row_lead = (tid & 15) == 0;
+    {
+      const float v5[5] = {live && !neg ? g * tg : 0.0f, live ? gw * tg : 0.0f, live ? gw : 0.0f,
+                           live ? gw * ne : 0.0f, live ? gw * gwo : 0.0f};
 #pragma unroll
-        for (int sset = 0; sset < 5; ++sset)
-#pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const float sc = uu[d] * kk[sset];
-            val[5 + 12 * sset + 4 * d + 0] = sc * m_own.x;
-            val[5 + 12 * sset + 4 * d + 1] = sc * m_own.y;
-            val[5 + 12 * sset + 4 * d + 2] = sc * m_own.z;
-            val[5 + 12 * sset + 4 * d + 3] = sc;
-          }
+      for (int k = 0; k < 5; ++k) {
+        const float r = mf::row16_sum(v5[k]);
+        if (row_lead) s_rows[row][k] = r;
       }
     }
-    // collision term: gradient flows to the OTHER object's pose (kept for the reduction below)
+    // own-gradient moments, set by set; a set no lane of the wave contributes to is skipped
+    // (s_rows starts zeroed): target-free or no-entry-free regions drop 24 of the 60 reductions
+    {
+      float uu[3] = {0.0f, 0.0f, 0.0f};
+      bool ok = false;
+      if (live && has) {
+        world_frac_r(Rt_o, m_own, ox, oy, oz, inv_pitch, x, iy, iz, uu[0], uu[1], uu[2], ok);
+        if (!ok) uu[0] = uu[1] = uu[2] = 0.0f;
+      }
+      const float wt = ok ? w * inv_trunc : 0.0f;
+      const float kk[5] = {ok && !neg ? tg * inv_trunc : 0.0f, wt * tg, wt * ne, wt * gwo, wt};
+      const float mc[4] = {m_own.x, m_own.y, m_own.z, 1.0f};
+#pragma unroll
+      for (int sset = 0; sset < 5; ++sset) {
+        if (__ballot(kk[sset] != 0.0f) == 0ull) continue;  // wave-uniform
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const float sc = uu[d] * kk[sset];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const float r = mf::row16_sum(sc * mc[cc]);
+            if (row_lead) s_rows[row][5 + 12 * sset + 4 * d + cc] = r;
+          }
+        }
+      }
+    }
+    // collision term: gradient flows to the OTHER object's pose
+    int ecol = -1;
+    float cv[12];
     if (live && ne == 0.0f && has_o && go * wo > 0.0f && gw != 0.0f) {
       const uint32_t pp = lo_o / (uint32_t)K;
       int e = 0;
       while (e + 1 < Ns && (int)pp >= s_off[e + 1]) ++e;
       float ux, uy, uz;
       bool ok;
-      world_frac(s_Rt[e], m_oth, ox, oy, oz, pitch, x, iy, iz, ux, uy, uz, ok);
-      const float B = wo * gw / trunc;
+      world_frac_r(s_Rt[e], m_oth, ox, oy, oz, inv_pitch, x, iy, iz, ux, uy, uz, ok);
+      const float B = wo * gw * inv_trunc;
       if (ok && isfinite(B)) {
         const float uu[3] = {ux, uy, uz};
         ecol = e;
@@ -1448,30 +1511,37 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
         }
       }
     }
-    // row sums (DPP, 4 VALU steps each) straight into LDS
-    const bool wave_mom = __ballot(any_mom) != 0ull;
+    // the 12 collision moments per other object some lane of this wave collides with (rows2
+    // starts zeroed: a wave writes only the objects it meets)
+    if (__ballot(ecol >= 0) != 0ull) {
+      for (int e = 0; e < Ns; ++e) {
+        if (__ballot(ecol == e) == 0ull) continue;  // wave-uniform
 #pragma unroll
-    for (int k = 0; k < kNumF; ++k) {
-      float r = 0.0f;
-      if (k < 5 || wave_mom) r = mf::row16_sum(val[k]);
-      if ((tid & 15) == 0) s_rows[tid >> 4][k] = r;
+        for (int cc = 0; cc < 12; ++cc) {
+          const float r = mf::row16_sum(ecol == e ? cv[cc] : 0.0f);
+          if (row_lead) s_rows2[(e * kRows + row) * 13 + cc] = r;
+        }
+      }
     }
   }
-  if (ecol >= 0) atomicOr(&s_emask, 1u << ecol);
+  stamp(7);
   // per-grid maxima of the raw inside weights (the normalisers a, b of the step)
   wmax_own = mf::wave_max(wmax_own);
   wmax_oth = mf::wave_max(wmax_oth);
   if (lane == 0) { s_max[0][wave] = wmax_own; s_max[1][wave] = wmax_oth; }
   __syncthreads();
-  if (tid < 2) {
-    float m = s_max[tid][0];
+  if (tid >= kTileThreads - 2) {  // (lanes away from the ones that reduce the sums below)
+    const int kd = tid - (kTileThreads - 2);
+    float m = s_max[kd][0];
 #pragma unroll
-    for (int i = 1; i < kTileThreads / 64; ++i) m = fmaxf(m, s_max[tid][i]);
-    if (m > 0.0f) atomicMax(&a.Mbits[(int64_t)par * 2 * a.O + 2 * o + tid], __float_as_uint(m));
+    for (int i = 1; i < kTileThreads / 64; ++i) m = fmaxf(m, s_max[kd][i]);
+    if (m > 0.0f) atomicMax(&a.Mbits[(int64_t)par * 2 * a.O + 2 * o + kd], __float_as_uint(m));
   }
   if (total == 0) return;  // block-uniform: no own winner here, nothing to add
-  long long *own = a.acc_own + ((int64_t)par * a.O + o) * kOwnSlots;
+  // ONE reduction phase: lane k < 65 adds the rows of own sum k, the next 12 Ns lanes the rows of
+  // a collision moment (zero rows where no wave met that object); fixed order, fixed point
   if (tid < kNumF) {
+    long long *own = a.acc_own + ((int64_t)par * a.O + o) * kOwnSlots;
     float sacc = 0.0f;
     for (int r = 0; r < n_rows; ++r) sacc += s_rows[r][tid];
     if (isfinite(sacc)) {
@@ -1480,38 +1550,24 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
     } else {
       atomicAdd(reinterpret_cast<unsigned long long *>(own + kNumF), 1ull);  // -> NaN loss
     }
-  }
-  stamp(4);
-  long long *po = a.acc_oth + ((int64_t)par * a.O + o) * a.max_ns * 12;
-  const uint32_t em0 = s_emask;
-  if (em0 == 0u) return;  // block-uniform
-  if (wave_on) {
-    for (uint32_t em = em0; em != 0u; em &= em - 1u) {
-      const int e = __ffs((int)em) - 1;
-#pragma unroll
-      for (int cc = 0; cc < 12; ++cc) {
-        const float r = mf::row16_sum(ecol == e ? cv[cc] : 0.0f);
-        if ((tid & 15) == 0) s_rows2[(e * kRows + (tid >> 4)) * 13 + cc] = r;
-      }
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < a.max_ns * 12; i += kTileThreads) {
-    const int e = i / 12, cc = i - 12 * e;
-    if (!((em0 >> e) & 1u)) continue;
+  } else if (tid < kNumF + 12 * Ns) {
+    long long *po = a.acc_oth + ((int64_t)par * a.O + o) * a.max_ns * 12;
+    const int i = tid - kNumF, e = i / 12, cc = i - 12 * e;
     float sacc = 0.0f;
     for (int r = 0; r < n_rows; ++r) sacc += s_rows2[(e * kRows + r) * 13 + cc];
     const long long xq = isfinite(sacc) ? __double2ll_rn((double)sacc * kFixOth) : 0;
     if (xq != 0) atomicAdd(reinterpret_cast<unsigned long long *>(po + i), (unsigned long long)xq);
   }
+  stamp(4);
 }
 
 __global__ __launch_bounds__(kTileThreads, 4) void k_icc_fused(IccArgs a, int par) {  // 2 workgroups per CU
+  __shared__ FusedLds L;
   const int ks = min(ksize_of(a.thr, a.pitch[blockIdx.y]), 2 * a.hmax + 1);  // block-uniform
   if (ks == 3)
-    icc_fused_body<3>(a, 3, par);
+    icc_fused_body<3>(a, 3, par, L);
   else
-    icc_fused_body<0>(a, ks, par);
+    icc_fused_body<0>(a, ks, par, L);
 }
 
 // ---- the step as a kernel of its own: one 64-lane workgroup per object ----------------

@@ -298,6 +298,7 @@ template <class T> inline T __shfl_xor(T v, int m, int = 64) {
   const int lane = mf_emul::g_block.cur % 64;
   return mf_emul_shfl(v, lane ^ m);
 }
+inline float __frsqrt_rn(float x) { return 1.0f / sqrtf(x); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
