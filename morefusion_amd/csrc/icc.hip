@@ -340,63 +340,58 @@ __device__ __forceinline__ void icc_step_gather_fused(const IccArgs &a, int par,
   // [8 Ns, 20 Ns): the 12 collision moments onto j from every scene object's grid;
   // [20 Ns, 20 Ns + 60): the 5 x 12 own-gradient moments of j
   const int n_items = 20 * Ns + 60;
-  for (int i = threadIdx.x; i < n_items; i += NT) {
-    long long x;
-    if (i < 8 * Ns) {
-      const int jo = i >> 3, l = i & 7;
-      if (l < 5) x = own[(int64_t)(ja + jo) * kOwnSlots + l];
-      else if (l == 5) x = own[(int64_t)(ja + jo) * kOwnSlots + kNumF];
-      else x = (long long)Mb[2 * (ja + jo) + (l - 6)];
-    } else if (i < 20 * Ns) {
-      const int k = i - 8 * Ns, jo = k / 12, c = k - 12 * jo;
-      x = oth[((int64_t)(ja + jo) * a.max_ns + (j - ja)) * 12 + c];
-    } else {
-      x = own[(int64_t)j * kOwnSlots + 5 + (i - 20 * Ns)];
+  // every lane converts the word it fetched (fixed point -> float, M -> 1/M) before the first
+  // barrier: the conversions and the IEEE reciprocals run in parallel instead of on the summing
+  // lanes (one barrier and ~Ns serial int64 -> double -> float conversions per sum less)
+  float *s_f = reinterpret_cast<float *>(s_raw);
+  for (int i0 = 0; i0 < n_items; i0 += NT) {
+    const int i = i0 + (int)threadIdx.x;
+    float fv = 0.0f;
+    if (i < n_items) {
+      if (i < 8 * Ns) {
+        const int jo = i >> 3, l = i & 7;
+        if (l < 5) {
+          fv = (float)((double)own[(int64_t)(ja + jo) * kOwnSlots + l] * (1.0 / kFixOwn));
+        } else if (l == 5) {
+          fv = own[(int64_t)(ja + jo) * kOwnSlots + kNumF] != 0 ? 1.0f : 0.0f;
+        } else {  // a = 1/M_own, b = 1/M_oth (b = 0 where the "other" grid is empty)
+          const float M = __uint_as_float(Mb[2 * (ja + jo) + (l - 6)]);
+          fv = l == 6 ? 1.0f / M : ((Ns > 1 && M != 0.0f) ? 1.0f / M : 0.0f);
+        }
+      } else if (i < 20 * Ns) {
+        const int k = i - 8 * Ns, jo = k / 12, c = k - 12 * jo;
+        fv = (float)((double)oth[((int64_t)(ja + jo) * a.max_ns + (j - ja)) * 12 + c] * (1.0 / kFixOth));
+      } else {
+        fv = (float)((double)own[(int64_t)j * kOwnSlots + 5 + (i - 20 * Ns)] * (1.0 / kFixOwn));
+      }
     }
-    s_raw[i] = x;
+    if (i < n_items) s_f[i] = fv;
   }
   __syncthreads();
-  auto f_own = [&](long long x) { return (float)((double)x * (1.0 / kFixOwn)); };
-  // a, b of every scene object once (IEEE divides off the summing lanes' critical path); they
-  // overwrite the raw M words (slots 6, 7 of the object) as float bits
-  if (threadIdx.x < Ns) {
-    const int jo = threadIdx.x;
-    const float Mo = __uint_as_float((uint32_t)s_raw[8 * jo + 6]);
-    const float Mk = __uint_as_float((uint32_t)s_raw[8 * jo + 7]);
-    const float av = 1.0f / Mo;
-    const float bv = (Ns > 1 && Mk != 0.0f) ? 1.0f / Mk : 0.0f;
-    s_raw[8 * jo + 6] = (long long)__float_as_uint(av);
-    s_raw[8 * jo + 7] = (long long)__float_as_uint(bv);
-  }
-  __syncthreads();
-  auto a_of = [&](int jo) { return __uint_as_float((uint32_t)s_raw[8 * jo + 6]); };
-  auto b_of = [&](int jo) { return __uint_as_float((uint32_t)s_raw[8 * jo + 7]); };
+  auto a_of = [&](int jo) { return s_f[8 * jo + 6]; };
+  auto b_of = [&](int jo) { return s_f[8 * jo + 7]; };
   if (threadIdx.x < kStepSums) {
     const int l = threadIdx.x;
     const int jj = j - ja;
     float r = 0.0f;
     if (l == 0) {  // RN
-      for (int jo = 0; jo < Ns; ++jo) r += f_own(s_raw[8 * jo + 0]) - a_of(jo) * f_own(s_raw[8 * jo + 1]);
+      for (int jo = 0; jo < Ns; ++jo) r += s_f[8 * jo + 0] - a_of(jo) * s_f[8 * jo + 1];
     } else if (l == 1) {  // S_in
-      for (int jo = 0; jo < Ns; ++jo) r += a_of(jo) * f_own(s_raw[8 * jo + 2]);
+      for (int jo = 0; jo < Ns; ++jo) r += a_of(jo) * s_f[8 * jo + 2];
     } else if (l == 2) {  // PN
-      for (int jo = 0; jo < Ns; ++jo)
-        r += a_of(jo) * (f_own(s_raw[8 * jo + 3]) + b_of(jo) * f_own(s_raw[8 * jo + 4]));
+      for (int jo = 0; jo < Ns; ++jo) r += a_of(jo) * (s_f[8 * jo + 3] + b_of(jo) * s_f[8 * jo + 4]);
     } else if (l < 15) {  // reward moments
       const int c = l - 3;
-      r = f_own(s_raw[20 * Ns + c]) - a_of(jj) * f_own(s_raw[20 * Ns + 12 + c]);
+      r = s_f[20 * Ns + c] - a_of(jj) * s_f[20 * Ns + 12 + c];
     } else if (l < 27) {  // penalty numerator moments
       const int c = l - 15;
-      r = a_of(jj) * (f_own(s_raw[20 * Ns + 24 + c]) + b_of(jj) * f_own(s_raw[20 * Ns + 36 + c]));
+      r = a_of(jj) * (s_f[20 * Ns + 24 + c] + b_of(jj) * s_f[20 * Ns + 36 + c]);
     } else if (l < 39) {  // penalty denominator moments
-      r = a_of(jj) * f_own(s_raw[20 * Ns + 48 + (l - 27)]);
+      r = a_of(jj) * s_f[20 * Ns + 48 + (l - 27)];
     } else if (l < 51) {  // collision moments of every grid of the scene onto j
-      for (int jo = 0; jo < Ns; ++jo)
-        r += (a_of(jo) * b_of(jo)) * (float)((double)s_raw[8 * Ns + 12 * jo + (l - 39)] * (1.0 / kFixOth));
+      for (int jo = 0; jo < Ns; ++jo) r += (a_of(jo) * b_of(jo)) * s_f[8 * Ns + 12 * jo + (l - 39)];
     } else {
-      long long bad = 0;
-      for (int jo = 0; jo < Ns; ++jo) bad |= s_raw[8 * jo + 5];
-      r = bad != 0 ? 1.0f : 0.0f;
+      for (int jo = 0; jo < Ns; ++jo) r = s_f[8 * jo + 5] != 0.0f ? 1.0f : r;
     }
     s_sum[l] = r;
   }
@@ -1296,26 +1291,30 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
         for (int k = 0; k < 9; ++k) cur[k] = dist[cbase + (k / 3) * Wp + (k % 3)];
         // fast: this record IS the minimum, certainly inside the truncation radius -> candidate
         // for the arg-min.  slow (rare): within a few ulp of the minimum or near the radius ->
-        // the exact float test.  Kept as a separate loop behind one branch: inlined next to the
-        // fast path the compiler speculates both square roots into every candidate (measured:
-        // pass 2 at 4-5 us in every tile, 50 instructions per candidate).
-        unsigned fast = 0u, slow = 0u;
+        // the exact float test, in a ROLLED loop behind one branch that recomputes what it
+        // needs.  (Inlined next to the fast path the compiler speculated both square roots into
+        // every candidate: pass 2 took 4-5 us in every tile; unrolled behind the branch it was
+        // still 900 instructions of code per record.)
+        const uint32_t cid0 = idb + (uint32_t)(bb * 3);
+        bool any_slow = false;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           const bool f = db[k] == cur[k] && db[k] < in_bits;
-          const bool nr = db[k] <= min(cur[k] + 8u, hi_bits);
-          fast |= (f ? 1u : 0u) << k;
-          slow |= (nr && !f ? 1u : 0u) << k;
+          // (issuing it unconditionally with a neutral value instead: measured slower, 2.3 vs 1.6 us)
+          if (f) atomicMin(&id[cbase + (k / 3) * Wp + (k % 3)], cid0 + (uint32_t)((k / 3) * 9 + (k % 3)));
+          any_slow |= !f && db[k] <= min(cur[k] + 8u, hi_bits);
         }
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-          if ((fast >> k) & 1u)
-            atomicMin(&id[cbase + (k / 3) * Wp + (k % 3)], idb + (uint32_t)(((k / 3) * 3 + bb) * 3 + (k % 3)));
-        if (slow != 0u) {
-          for (int k = 0; k < 9; ++k)
-            if ((slow >> k) & 1u)
-              settle_at(id, cbase + (k / 3) * Wp + (k % 3), db[k], cur[k],
-                        idb + (uint32_t)(((k / 3) * 3 + bb) * 3 + (k % 3)));
+        if (any_slow) {
+#pragma nounroll
+          for (int k = 0; k < 9; ++k) {
+            const int aa = k / 3, cc = k - 3 * aa;
+            const float dy = sv.y - (float)(iry + aa - 1), dz = sv.z - (float)(irz + cc - 1);
+            const uint32_t dbk = __float_as_uint((dx2 + dy * dy) + dz * dz);
+            const int ad = cbase + aa * Wp + cc;
+            const uint32_t curk = dist[ad];
+            const bool f = dbk == curk && dbk < in_bits;
+            if (!f && dbk <= min(curk + 8u, hi_bits)) settle_at(id, ad, dbk, curk, cid0 + (uint32_t)(aa * 9 + cc));
+          }
         }
       }
     } else {
@@ -1388,8 +1387,10 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   // weights needs every voxel with an other-winner: taken here in the voxel-per-lane layout,
   // its gather is in flight during the compaction.
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  auto cell = [&](const int vi) { return (vi / D + kPad) * Wp + (vi % D + kPad); };  // voxel -> padded cell
-  const int my_cell = cell(tid < nvox ? tid : 0);
+  // voxel -> (row, column) without an integer divide: exact for vi < 1024, D <= 64
+  const uint32_t rcpD = (65536u + (uint32_t)D - 1u) / (uint32_t)D;  // (scalar)
+  const int my_r = (int)(((uint32_t)tid * rcpD) >> 16), my_c = tid - my_r * D;
+  const int my_cell = tid < nvox ? (my_r + kPad) * Wp + (my_c + kPad) : 0;
   const uint32_t my_id = tid < nvox ? s_id[my_cell] : kNoCand;
   const uint32_t my_ido = tid < nvox ? s_id[nvh + my_cell] : kNoCand;
   // both winner gathers of this voxel in flight during the compaction; the lane that takes the
@@ -1409,7 +1410,7 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   }
   if (act) {
     const int slot = before + __popcll(bal & ((1ull << lane) - 1ull));
-    s_list[slot] = (uint16_t)tid;
+    s_list[slot] = (uint16_t)((my_r << 8) | my_c);
     s_mown[slot] = g_own;
     s_moth[slot] = g_oth;
     s_netg[slot] = make_float2(ne0, tg0);
@@ -1423,8 +1424,9 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   const int n_rows = (total + 15) / 16;
   if ((tid & ~63) < total) {  // wave-uniform
     const bool live = tid < total;
-    const int vi = live ? (int)s_list[tid] : 0;
-    const int pc = cell(vi);
+    const int rc = live ? (int)s_list[tid] : 0;
+    const int vr = rc >> 8, vc = rc & 255;
+    const int pc = (vr + kPad) * Wp + (vc + kPad);
     const uint32_t lo = live ? s_id[pc] : kNoCand;
     const uint32_t lo_o = live ? s_id[nvh + pc] : kNoCand;
     const float4 m_own = live ? s_mown[tid] : make_float4(0, 0, 0, -1.0f);
@@ -1439,7 +1441,7 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
     const float inv_trunc = 1.0f / trunc, inv_pitch = 1.0f / pitch;
     const float dist_o = has ? pitch * sqrtf(__uint_as_float(s_dist[pc])) : trunc;
     const float dist_k = has_o ? pitch * sqrtf(__uint_as_float(s_dist[nvh + pc])) : trunc;
-    const int iy = y0 + vi / D, iz = vi % D;
+    const int iy = y0 + vr, iz = vc;
     const float g = has ? fmaxf(1.0f - dist_o * inv_trunc, 0.0f) : 0.0f;  // 1 - tdf/trunc
     float w = m_own.w + a.sdf_offset;
     const bool neg = w < 0.0f;
@@ -1455,10 +1457,12 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
     {
       const float v5[5] = {live && !neg ? g * tg : 0.0f, live ? gw * tg : 0.0f, live ? gw : 0.0f,
                            live ? gw * ne : 0.0f, live ? gw * gwo : 0.0f};
+      float r5[5];
 #pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const float r = mf::row16_sum(v5[k]);
-        if (row_lead) s_rows[row][k] = r;
+      for (int k = 0; k < 5; ++k) r5[k] = mf::row16_sum(v5[k]);
+      if (row_lead) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s_rows[row][k] = r5[k];
       }
     }
     // own-gradient moments, set by set; a set no lane of the wave contributes to is skipped
@@ -1476,14 +1480,18 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
 #pragma unroll
       for (int sset = 0; sset < 5; ++sset) {
         if (__ballot(kk[sset] != 0.0f) == 0ull) continue;  // wave-uniform
+        // the 12 chains in one block (independent DPP chains interleave: no wait-state nops),
+        // one predicated burst of stores
+        float r12[12];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
           const float sc = uu[d] * kk[sset];
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const float r = mf::row16_sum(sc * mc[cc]);
-            if (row_lead) s_rows[row][5 + 12 * sset + 4 * d + cc] = r;
-          }
+          for (int cc = 0; cc < 4; ++cc) r12[4 * d + cc] = mf::row16_sum(sc * mc[cc]);
+        }
+        if (row_lead) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) s_rows[row][5 + 12 * sset + i] = r12[i];
         }
       }
     }
@@ -1491,9 +1499,9 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
     int ecol = -1;
     float cv[12];
     if (live && ne == 0.0f && has_o && go * wo > 0.0f && gw != 0.0f) {
-      const uint32_t pp = lo_o / (uint32_t)K;
-      int e = 0;
-      while (e + 1 < Ns && (int)pp >= s_off[e + 1]) ++e;
+      const int pp = (int)(lo_o / (uint32_t)K);
+      int e = 0;  // scene object of the point: independent LDS reads, no dependent search loop
+      for (int k = 1; k < Ns; ++k) e += pp >= s_off[k] ? 1 : 0;
       float ux, uy, uz;
       bool ok;
       world_frac_r(s_Rt[e], m_oth, ox, oy, oz, inv_pitch, x, iy, iz, ux, uy, uz, ok);
@@ -1516,10 +1524,12 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
     if (__ballot(ecol >= 0) != 0ull) {
       for (int e = 0; e < Ns; ++e) {
         if (__ballot(ecol == e) == 0ull) continue;  // wave-uniform
+        float r12[12];
 #pragma unroll
-        for (int cc = 0; cc < 12; ++cc) {
-          const float r = mf::row16_sum(ecol == e ? cv[cc] : 0.0f);
-          if (row_lead) s_rows2[(e * kRows + row) * 13 + cc] = r;
+        for (int cc = 0; cc < 12; ++cc) r12[cc] = mf::row16_sum(ecol == e ? cv[cc] : 0.0f);
+        if (row_lead) {
+#pragma unroll
+          for (int cc = 0; cc < 12; ++cc) s_rows2[(e * kRows + row) * 13 + cc] = r12[cc];
         }
       }
     }

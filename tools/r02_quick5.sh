@@ -1,0 +1,3 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python tools/stamps_bin.py 2>&1 | grep -v amdgpu | tail -8
