@@ -207,7 +207,7 @@ def roofline_voxelize(wl):
     Algorithmic bytes / object: read P*(12+4C+4) + write C*D^3*4 + D^3*4."""
     m, inp = wl.model, wl.inputs
     with torch.no_grad():
-        pix = m._select_points(~torch.isnan(inp["pcd"]).any(dim=3))
+        pix = m._select_points(inp["pcd"])
         _, points = m._backbone_features(inp["rgb"], inp["pcd"], pix)
         points = (points - inp["origin"].float()[:, :, None]) / inp["pitch"].float()[:, None, None]
     B, D = points.shape[0], m._voxel_dim
@@ -301,8 +301,7 @@ def handwritten_path(wl, reps=10):
     m = wl.model
     inp = wl.inputs
     with torch.no_grad():
-        mask = ~torch.isnan(inp["pcd"]).any(dim=3)
-        pix = m._select_points(mask)
+        pix = m._select_points(inp["pcd"])
         values, points = m._backbone_features(inp["rgb"], inp["pcd"], pix)
         args = (torch.as_tensor(inp["class_id"], device=wl.device), values, points, inp["pitch"].float(),
                 inp["origin"].float(), inp["grid_nontarget_empty"])

@@ -319,6 +319,16 @@ int mf_instance_crops(const uint8_t *rgb, const float *depth, const int32_t *lab
                       int min_valid, uint8_t *rgb_out, float *pcd_out, uint8_t *keep,
                       mfStream_t stream);
 
+/* valid-pixel list in front of Model.predict's point selection: replaces, per object,
+ *   contrib/singleview_3d/models/model.py:195-196 `iy, ix = xp.where(mask[i])` and :206
+ *   `n_point = int(mask[i].sum())` with mask = ~isnan(pcd).any(channel).
+ * pcd [B,HW,3] float32 -> order [B,HW] int32: the row-major
+ * pixel indices h*W+w of the pixels without a NaN coordinate, in increasing order (entries beyond
+ * counts[b] are left untouched), counts [B] int32.  The reference's NumPy-RNG subsample
+ * (`keep`, :207-219) then indexes this list.  Asynchronous, never synchronises. */
+int mf_valid_pixel_order(const float *pcd, int32_t B, int32_t HW, int32_t *order, int32_t *counts,
+                         mfStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "mf_pack_points_sdf": ([_p, _p, _i64, _p, _p], _i),
     "mf_average_distance_fwd": ([_p, _p, _p, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p, _p], _i),
     "mf_average_distance_bwd": ([_p, _p, _p, _p, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p, _p], _i),
+    "mf_valid_pixel_order": ([_p, ctypes.c_int32, ctypes.c_int32, _p, _p, _p], _i),
     "mf_instance_stats": ([_p, _p, _i, _i, _p, _i, _p, _p], _i),
     "mf_instance_crops": ([_p, _p, _p, _i, _i, _d, _d, _d, _d, _p, _p, _i, _i, _i, _p, _p, _p, _p], _i),
 }

@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .... import _lib
 from .... import functions as functions_module
 from .... import geometry as geometry_module
 from .... import metrics
@@ -176,25 +177,28 @@ class Model(nn.Module):
             Model._eval_keep_cache[(n_point, self._n_point)] = keep
         return keep
 
-    def _select_points(self, mask):
-        """mask [B,H,W] -> flat pixel indices [B,P] (row-major order of ``where``, then the
-        reference's NumPy-RNG subsample / pad)."""
-        B = mask.shape[0]
-        flat_mask = mask.reshape(B, -1)
-        counts = flat_mask.sum(dim=1).cpu().numpy()  # the one host sync
-        keep = torch.from_numpy(np.stack([self._keep_indices(int(c)) for c in counts])).to(mask.device)
-        # position of the k-th valid pixel of each image (stream compaction by prefix sum)
-        rank = torch.cumsum(flat_mask, dim=1) - 1
-        order = torch.zeros_like(rank)
-        src = torch.arange(flat_mask.shape[1], device=mask.device).expand_as(rank)
-        order.scatter_(1, torch.where(flat_mask, rank, rank.new_full((), flat_mask.shape[1] - 1)),
-                       torch.where(flat_mask, src, src.new_zeros(())))
-        return torch.gather(order, 1, keep)
+    def _select_points(self, pcd):
+        """pcd [B,H,W,3] -> flat pixel indices [B,P]: the row-major list of the pixels without a
+        NaN coordinate (``where(mask)``, model.py:195) from one launch of ``mf_valid_pixel_order``,
+        then the reference's NumPy-RNG subsample / pad of it."""
+        B, HW = pcd.shape[0], pcd.shape[1] * pcd.shape[2]
+        _lib.require_gpu(pcd)
+        pcd = _lib.f32c(pcd)
+        order = torch.empty((B, HW), dtype=torch.int32, device=pcd.device)
+        counts = torch.empty((B,), dtype=torch.int32, device=pcd.device)
+        _lib.check(_lib.lib().mf_valid_pixel_order(pcd.data_ptr(), B, HW, order.data_ptr(), counts.data_ptr(),
+                                                   _lib.stream_ptr()), "mf_valid_pixel_order")
+        return self._subsample(order, counts.cpu().numpy())  # the one host sync (the RNG needs n_point)
+
+    def _subsample(self, order, counts):
+        """order [B,HW] (valid pixels first, row-major), counts [B] on the host -> [B,P] int64:
+        ``iy[keep], ix[keep]`` of model.py:207-220 as flat indices."""
+        keep = torch.from_numpy(np.stack([self._keep_indices(int(c)) for c in counts])).to(order.device)
+        return torch.gather(order, 1, keep).long()
 
     def predict(self, *, class_id, rgb, pcd, pitch=None, origin=None, grid_nontarget_empty=None):
         B = rgb.shape[0]
         dev = rgb.device
-        mask = ~torch.isnan(pcd).any(dim=3)
         if pitch is None:
             pitch = torch.tensor([self._models.get_voxel_pitch(self._voxel_dim, int(c))
                                   for c in class_id.tolist()], dtype=torch.float32, device=dev)
@@ -205,7 +209,7 @@ class Model(nn.Module):
             origin = geometry_module.grid_origin(pcd.float(), pitch, dim=self._voxel_dim)
         else:
             origin = torch.as_tensor(origin, dtype=torch.float32, device=dev)
-        pix = self._select_points(mask)  # [B,P]; the one host synchronisation
+        pix = self._select_points(pcd)  # [B,P]; the one host synchronisation
         return self._predict_device(torch.as_tensor(class_id, device=dev), rgb, pcd, pix, pitch,
                                     origin, grid_nontarget_empty)
 

@@ -294,6 +294,10 @@ template <class T> inline T __shfl_down(T v, unsigned d, int = 64) {
   const int lane = mf_emul::g_block.cur % 64;
   return mf_emul_shfl(v, lane + (int)d < 64 ? lane + (int)d : lane);
 }
+template <class T> inline T __shfl_up(T v, unsigned d, int = 64) {
+  const int lane = mf_emul::g_block.cur % 64;
+  return mf_emul_shfl(v, lane - (int)d >= 0 ? lane - (int)d : lane);
+}
 template <class T> inline T __shfl_xor(T v, int m, int = 64) {
   const int lane = mf_emul::g_block.cur % 64;
   return mf_emul_shfl(v, lane ^ m);

@@ -136,3 +136,29 @@ def test_fused_icp_loop_kernel_source_vs_oracle(fixtures3):
         np.testing.assert_allclose(losses[k, 1], loss, rtol=1e-4)
         opt.update([gq, gt])
     np.testing.assert_allclose(np.r_[q[1], t[1]], np.r_[qi, ti], atol=2e-5)
+
+
+def test_valid_pixel_order_kernel_source_vs_numpy_where():
+    """mf_valid_pixel_order (k_valid_order: shuffle prefix + wave totals + running base) against
+    np.where(~isnan(pcd).any(-1)) (model.py:195-196,206): vector-load and scalar paths, a ragged
+    tail, an image without valid pixels, +-inf coordinates (valid: only NaN masks a pixel)."""
+    lib = emul.build(["preprocess.hip"])
+    lib.mf_valid_pixel_order.argtypes = [_p, _i32, _i32, _p, _p, _p]
+    rs = np.random.RandomState(3)
+    for HW, off in ((4096 + 2048, 0), (5003, 0), (4096, 1)):
+        B = 3
+        buf = np.zeros(B * HW * 3 + 4, np.float32)
+        pcd = buf[off:off + B * HW * 3].reshape(B, HW, 3)   # off = 1: not 16-byte aligned
+        pcd[:] = rs.randn(B, HW, 3)
+        pcd[0][rs.rand(HW) < 0.6] = np.nan
+        pcd[1][:, 1][rs.rand(HW) < 0.3] = np.nan
+        pcd[1][5, 2] = np.inf
+        pcd[2] = np.nan
+        order = np.full((B, HW), -7, np.int32)
+        counts = np.full(B, -1, np.int32)
+        assert lib.mf_valid_pixel_order(pcd.ctypes.data, B, HW, order.ctypes.data, counts.ctypes.data, None) == 0
+        for b in range(B):
+            want = np.flatnonzero(~np.isnan(pcd[b]).any(axis=1))
+            assert counts[b] == len(want)
+            np.testing.assert_array_equal(order[b, :len(want)], want)
+            assert (order[b, len(want):] == -7).all()

@@ -137,3 +137,43 @@ def test_raw_examples_through_transform_into_predict():
     with torch.no_grad():
         q2, _, _ = model.predict(**{**inputs, "grid_nontarget_empty": torch.zeros_like(inputs["grid_nontarget_empty"])})
     assert float((q2 - q).abs().max()) > 0
+
+
+def test_point_selection_kernel_and_reference_rng():
+    """Model._select_points = mf_valid_pixel_order + the reference's NumPy-RNG subsample
+    (contrib/singleview_3d/models/model.py:195-220): bit-exact against np.where + RandomState(1234)
+    on the synthetic batch (float32 and float64 input), a crafted ragged case, and the raw kernel
+    on an unaligned view."""
+    import ctypes
+    from morefusion_amd.contrib.singleview_3d.models import Model
+    m = Model(n_fg_class=21, with_occupancy=True).eval()
+    b = synthetic.make_singleview_batch(3, seed=4)
+    pcd = b["pcd"].copy()
+    pcd[2] = np.nan                     # third crop: 400 valid pixels < n_point (arange + randint padding)
+    pcd[2, 100:110, 90:130] = 1.0
+    for dtype in (np.float32, np.float64):
+        pix = m._select_points(torch.as_tensor(pcd.astype(dtype)).cuda()).cpu().numpy()
+        for i in range(3):
+            iy, ix = np.where(~np.isnan(pcd[i]).any(axis=2))
+            n = len(iy)
+            rs = np.random.RandomState(1234)
+            keep = rs.permutation(n)[:1000] if n >= 1000 else np.r_[np.arange(n), rs.randint(0, n, 1000 - n)]
+            np.testing.assert_array_equal(pix[i], iy[keep] * pcd.shape[2] + ix[keep])
+    # raw kernel, image rows not 16-byte aligned and H*W not a multiple of 4
+    HW = 70 * 71
+    buf = torch.full((2 * HW * 3 + 1,), float("nan")).cuda()
+    view = buf[1:].reshape(2, HW, 3)
+    g = torch.Generator().manual_seed(0)
+    vals = torch.randn(2, HW, 3, generator=g)
+    vals[torch.rand(2, HW, generator=g) < 0.4] = float("nan")
+    view.copy_(vals)
+    order = torch.full((2, HW), -1, dtype=torch.int32).cuda()
+    counts = torch.zeros(2, dtype=torch.int32).cuda()
+    mf._lib.check(mf._lib.lib().mf_valid_pixel_order(view.data_ptr(), 2, HW, order.data_ptr(), counts.data_ptr(),
+                                                     mf._lib.stream_ptr()), "mf_valid_pixel_order")
+    for i in range(2):
+        want = np.flatnonzero(~np.isnan(vals[i].numpy()).any(axis=1))
+        assert int(counts[i]) == len(want)
+        np.testing.assert_array_equal(order[i, :len(want)].cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        m._select_points(torch.full((1, 8, 8, 3), float("nan")).cuda())  # "an example has no valid point"

@@ -147,7 +147,13 @@ def test_model_point_selection_follows_reference_rng():
     mask = torch.zeros(2, 64, 64, dtype=torch.bool)
     mask[0, 10:50, 5:60] = True  # 2200 > 1000 points: permutation[:1000]
     mask[1, 3:13, 4:24] = True  # 200 < 1000 points: arange + randint padding
-    pix = m._select_points(mask).numpy()
+    # the valid-pixel list comes from mf_valid_pixel_order on the GPU (tests/test_gpu_preprocess.py);
+    # here: the host half, on a list built by NumPy
+    order = torch.zeros(2, 64 * 64, dtype=torch.int32)
+    for b in range(2):
+        idx = np.flatnonzero(mask[b].numpy().ravel())
+        order[b, :len(idx)] = torch.from_numpy(idx.astype(np.int32))
+    pix = m._subsample(order, mask.reshape(2, -1).sum(1).numpy()).numpy()
     iy, ix = np.where(mask[0].numpy())
     keep = np.random.RandomState(1234).permutation(len(iy))[:1000]  # model.py:211-213
     np.testing.assert_array_equal(pix[0], iy[keep] * 64 + ix[keep])
@@ -358,8 +364,17 @@ def test_predict_host_logic_decoder_modes_agree(monkeypatch):
         out = torch.from_numpy(OC.interpolate_voxel_grid(vox.numpy(), points.numpy(), batch_indices.numpy()))
         return out.t().contiguous() if channels_first else out
 
+    def select_cpu(self, pcd):  # stand-in for mf_valid_pixel_order: np.where, then the product's host half
+        valid = ~np.isnan(pcd.numpy()).any(axis=3).reshape(pcd.shape[0], -1)
+        order = torch.zeros(valid.shape, dtype=torch.int32)
+        for i, v in enumerate(valid):
+            idx = np.flatnonzero(v)
+            order[i, :len(idx)] = torch.from_numpy(idx.astype(np.int32))
+        return self._subsample(order, valid.sum(1))
+
     monkeypatch.setattr(model_mod.functions_module, "average_voxelization_3d", avg_cpu)
     monkeypatch.setattr(model_mod.functions_module, "interpolate_voxel_grid", interp_cpu)
+    monkeypatch.setattr(Model, "_select_points", select_cpu)
     torch.manual_seed(0)
     model = Model(n_fg_class=21, with_occupancy=True).eval()
     b = mf.synthetic.make_singleview_batch(1, seed=3)
