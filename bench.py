@@ -378,10 +378,16 @@ def cpu_baseline(wl, args):
         return out.t().contiguous() if channels_first else out
 
     import morefusion_amd.contrib.singleview_3d.models.model as model_mod
+    def select_cpu(self, pcd):
+        from oracle import oracle_np as O
+        order, counts = O.valid_pixel_order(pcd.numpy())
+        return self._subsample(torch.from_numpy(order), counts)
+
     saved = (model_mod.functions_module.average_voxelization_3d,
-             model_mod.functions_module.interpolate_voxel_grid)
+             model_mod.functions_module.interpolate_voxel_grid, Model._select_points)
     model_mod.functions_module.average_voxelization_3d = avg_cpu
     model_mod.functions_module.interpolate_voxel_grid = interp_cpu
+    Model._select_points = select_cpu
     sc = wl.scenes_np[0]
     q0 = wl.q0[: len(sc["points"])].cpu().numpy()
     t0_ = wl.t0[: len(sc["points"])].cpu().numpy()
@@ -410,7 +416,7 @@ def cpu_baseline(wl, args):
         t_pred1, t_icc1 = timed(1, min(10, iters), 1)
     finally:
         (model_mod.functions_module.average_voxelization_3d,
-         model_mod.functions_module.interpolate_voxel_grid) = saved
+         model_mod.functions_module.interpolate_voxel_grid, Model._select_points) = saved
         torch.set_num_threads(cores)
         OC.set_threads(cores)
     value = wl.B / (t_pred + t_icc)

@@ -188,6 +188,113 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_lds(
   });
 }
 
+// The same workgroup shape with the chunk stored VOXEL-major in LDS, channels innermost
+// ([V][cpw], cpw a multiple of 4): a corner gather is one 16-byte LDS read per 4 channels instead
+// of 4 scalar reads at 4 addresses, and the corner offset is computed once for all of them --
+// the gather phase (8 x cpw random LDS reads per point, the part that made the kernel LDS-issue
+// bound at 0.2 of the HBM roofline) shrinks 4x.  Staging transposes on the way in: a lane takes a
+// voxel, loads its cpw channels from the cpw channel planes (each load coalesced across the
+// wave) and stores them as 16-byte rows (consecutive lanes -> consecutive rows).
+// Same sums in the same order per channel as k_interp_fwd_lds: identical bits.
+template <int CPW>
+__global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_vm(
+    const float *__restrict__ vox, const float *__restrict__ points,
+    const int32_t *__restrict__ batch_indices, const int32_t *__restrict__ batch_start, int64_t n,
+    int B, int C, int X, int Y, int Z, float *__restrict__ values, int channels_first) {
+  MF_DYN_LDS(float, s_grid);
+  constexpr int Q = CPW / 4;
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CPW;
+  const int V = X * Y * Z;
+  float4 *s4 = reinterpret_cast<float4 *>(s_grid);
+  auto sample = [&](int64_t p, bool mine, float px, float py, float pz) {
+    Corner k;
+    bool ok = mine && plausible(px, py, pz);
+    if (ok) corners(px, py, pz, X, Y, Z, k);
+    float acc[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) acc[c] = 0.0f;
+    if (ok) {
+      float4 g[8][Q];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) g[j][q] = s4[(k.off[j] < 0 ? 0 : k.off[j]) * Q + q];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (k.off[j] < 0) continue;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          acc[4 * q + 0] += k.w[j] * g[j][q].x;
+          acc[4 * q + 1] += k.w[j] * g[j][q].y;
+          acc[4 * q + 2] += k.w[j] * g[j][q].z;
+          acc[4 * q + 3] += k.w[j] * g[j][q].w;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      if (channels_first)
+        values[(int64_t)(c0 + c) * n + p] = acc[c];
+      else
+        values[p * C + c0 + c] = acc[c];
+    }
+  };
+  auto stage = [&]() {
+    const float *src = vox + ((int64_t)b * C + c0) * V;
+    constexpr int kVox = 16 / CPW > 0 ? 16 / CPW : 1;  // voxels per lane and round: 16 loads in flight
+    for (int v0 = threadIdx.x; v0 < V; v0 += kInterpThreads * kVox) {
+      float r[kVox][CPW];
+#pragma unroll
+      for (int u = 0; u < kVox; ++u) {
+        const int v = v0 + u * kInterpThreads;
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) r[u][c] = v < V ? src[(int64_t)c * V + v] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < kVox; ++u) {
+        const int v = v0 + u * kInterpThreads;
+        if (v >= V) continue;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          s4[v * Q + q] = make_float4(r[u][4 * q], r[u][4 * q + 1], r[u][4 * q + 2], r[u][4 * q + 3]);
+      }
+    }
+  };
+  if (batch_start) {
+    const int64_t p0 = batch_start[b], p1 = batch_start[b + 1];
+    if (p1 - p0 <= (int64_t)kInterpThreads * kInterpPre) {
+      float px[kInterpPre], py[kInterpPre], pz[kInterpPre];
+#pragma unroll
+      for (int u = 0; u < kInterpPre; ++u) {
+        const int64_t p = p0 + (int64_t)u * kInterpThreads + threadIdx.x;
+        px[u] = py[u] = pz[u] = 0.0f;
+        if (p < p1) { px[u] = points[3 * p]; py[u] = points[3 * p + 1]; pz[u] = points[3 * p + 2]; }
+      }
+      stage();
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < kInterpPre; ++u) {
+        const int64_t p = p0 + (int64_t)u * kInterpThreads + threadIdx.x;
+        if (p < p1) sample(p, true, px[u], py[u], pz[u]);
+      }
+      if (b == 0) {  // rows outside every item: zeros (same contract as the scan path)
+        const int64_t lo = batch_start[0], hi = batch_start[B];
+        for (int64_t p = threadIdx.x; p < n; p += kInterpThreads)
+          if (p < lo || p >= hi) sample(p, false, 0.0f, 0.0f, 0.0f);
+      }
+      return;
+    }
+  }
+  stage();
+  __syncthreads();
+  for_rows_of_item(batch_indices, batch_start, n, b, B, [&](int64_t p, bool mine) {
+    float px = 0.0f, py = 0.0f, pz = 0.0f;
+    if (mine) { px = points[3 * p]; py = points[3 * p + 1]; pz = points[3 * p + 2]; }
+    sample(p, mine, px, py, pz);
+  });
+}
+
 // Fallback for grids too large for LDS: direct gathers (thread per point x channel chunk).
 __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_direct(
     const float *__restrict__ vox, const float *__restrict__ points,
@@ -291,6 +398,15 @@ extern "C" int mf_interpolate_voxel_grid_fwd(const float *vox, const float *poin
   if (V * 4 <= kMaxLds) {
     const int cpw = pick_cpw(C, B, V);
     const size_t lds = (size_t)cpw * V * 4;
+    if ((cpw == 4 || cpw == 8) && C % cpw == 0 && lds <= 64 * 1024) {  // voxel-major chunk, 16 B gathers
+      if (cpw == 4)
+        hipLaunchKernelGGL(k_interp_fwd_vm<4>, dim3(C / cpw, B), dim3(kInterpThreads), lds, stream, vox, points,
+                           batch_indices, batch_start, n, B, C, X, Y, Z, values, channels_first);
+      else
+        hipLaunchKernelGGL(k_interp_fwd_vm<8>, dim3(C / cpw, B), dim3(kInterpThreads), lds, stream, vox, points,
+                           batch_indices, batch_start, n, B, C, X, Y, Z, values, channels_first);
+      return mf::check_launch("mf_interpolate_voxel_grid_fwd");
+    }
     if (int e = mf::allow_big_lds((const void *)k_interp_fwd_lds, kMaxLds)) return e;
     hipLaunchKernelGGL(k_interp_fwd_lds, dim3((C + cpw - 1) / cpw, B), dim3(kInterpThreads), lds,
                        stream, vox, points, batch_indices, batch_start, n, B, C, X, Y, Z, cpw,

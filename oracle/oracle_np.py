@@ -883,3 +883,17 @@ def instance_crops(rgb, depth, K, label, instance_ids, image_size=256, min_valid
         pcd_out[i] = centerize(pcd_ins, (S, S), cval=np.nan, interpolation="nearest")
         keep[i] = True
     return rgb_out, pcd_out, keep, bboxes
+
+
+def valid_pixel_order(pcd):
+    """Row-major list of the pixels without a NaN coordinate, per image, and their counts:
+    ``iy, ix = xp.where(mask[i])`` / ``int(mask[i].sum())`` with ``mask = ~isnan(pcd).any(axis)``
+    (contrib/singleview_3d/models/model.py:195-196,206) as flat indices iy * W + ix.
+    pcd [B,H,W,3] or [B,HW,3] -> (order [B,HW] int32, valid entries first; counts [B] int64)."""
+    pcd = np.asarray(pcd)
+    valid = ~np.isnan(pcd).any(axis=-1).reshape(pcd.shape[0], -1)
+    order = np.zeros(valid.shape, np.int32)
+    for i, v in enumerate(valid):
+        idx = np.flatnonzero(v)
+        order[i, :len(idx)] = idx
+    return order, valid.sum(axis=1)

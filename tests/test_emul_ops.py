@@ -95,6 +95,33 @@ def test_interpolate_kernel_source_row_ranges_vs_oracle(channels_first):
         np.testing.assert_array_equal(got[~valid], 0.0)
 
 
+@pytest.mark.parametrize("C", [1024, 2048])
+def test_interpolate_voxel_major_kernel_source_vs_oracle(C):
+    """The shapes that select k_interp_fwd_vm<4> / <8> (chunk stored voxel-major in LDS, one 16-byte
+    gather per 4 channels): bit-identical to the oracle's GPU-order sums, both output layouts,
+    with and without row ranges."""
+    lib = emul.build(["interp.hip"])
+    lib.mf_interpolate_voxel_grid_fwd.argtypes = [_p, _p, _p, _p, ctypes.c_int64] + [ctypes.c_int] * 5 + [_p, ctypes.c_int, _p]
+    rs = np.random.RandomState(2)
+    B, X = 2, 8
+    counts = [37, 21]
+    n = sum(counts) + 3
+    bi = np.concatenate([np.full(c, b, np.int32) for b, c in enumerate(counts)] + [np.full(3, 7, np.int32)])
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    vox = rs.uniform(-1, 1, (B, C, X, X, X)).astype(np.float32)
+    pts = (rs.uniform(-0.15, 1.1, (n, 3)) * X).astype(np.float32)
+    valid = bi < B
+    ref = O.interpolate_voxel_grid(vox, pts[valid], bi[valid], mode="gpu")
+    for channels_first, bs in ((1, start), (0, None)):
+        out = np.full((C, n) if channels_first else (n, C), 5.0, np.float32)
+        assert lib.mf_interpolate_voxel_grid_fwd(vox.ctypes.data, pts.ctypes.data, bi.ctypes.data,
+                                                 None if bs is None else bs.ctypes.data, n, B, C, X, X, X,
+                                                 out.ctypes.data, channels_first, None) == 0
+        got = out.T if channels_first else out
+        np.testing.assert_array_equal(got[valid], ref)
+        np.testing.assert_array_equal(got[~valid], 0.0)
+
+
 def test_fused_icp_loop_kernel_source_vs_oracle(fixtures3):
     """mf_icp_refine (k_icp over a batch of links + k_icp_step: chain rule, chainer-Adam, next R|t;
     the driver loop of check_iterative_closest_point_link.py:40-70) against the oracle's loop: the

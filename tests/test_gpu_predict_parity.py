@@ -20,6 +20,7 @@ import pytest
 import torch
 
 from oracle import oracle_c as OC
+from oracle import oracle_np as O
 
 pytestmark = pytest.mark.gpu
 
@@ -43,6 +44,11 @@ def _interp_cpu(vox, points, batch_indices, channels_first=False, batch_start=No
     return out.t().contiguous() if channels_first else out
 
 
+def _select_cpu(self, pcd):  # np.where(mask) (model.py:195) + the product's host-side subsample
+    order, counts = O.valid_pixel_order(pcd.numpy())
+    return self._subsample(torch.from_numpy(order), counts)
+
+
 def _cpu_restatement(model_gpu, inputs):
     """Dense reference data flow on the CPU with the oracle's voxel ops."""
     model = Model(n_fg_class=21, with_occupancy=True).eval()
@@ -50,15 +56,16 @@ def _cpu_restatement(model_gpu, inputs):
     model.sparse_pspnet_tail = False   # dense decoder + gather (model.py:181-222)
     model.sparse_conv3 = False         # dense Conv3d (model.py:118-128)
     saved = (model_mod.functions_module.average_voxelization_3d,
-             model_mod.functions_module.interpolate_voxel_grid)
+             model_mod.functions_module.interpolate_voxel_grid, Model._select_points)
     model_mod.functions_module.average_voxelization_3d = _avg_cpu
     model_mod.functions_module.interpolate_voxel_grid = _interp_cpu
+    Model._select_points = _select_cpu
     try:
         with torch.no_grad():
             return model.predict(**{k: v.cpu() for k, v in inputs.items()})
     finally:
         (model_mod.functions_module.average_voxelization_3d,
-         model_mod.functions_module.interpolate_voxel_grid) = saved
+         model_mod.functions_module.interpolate_voxel_grid, Model._select_points) = saved
 
 
 def _argmax_pose(rot, trans, conf):

@@ -365,12 +365,9 @@ def test_predict_host_logic_decoder_modes_agree(monkeypatch):
         return out.t().contiguous() if channels_first else out
 
     def select_cpu(self, pcd):  # stand-in for mf_valid_pixel_order: np.where, then the product's host half
-        valid = ~np.isnan(pcd.numpy()).any(axis=3).reshape(pcd.shape[0], -1)
-        order = torch.zeros(valid.shape, dtype=torch.int32)
-        for i, v in enumerate(valid):
-            idx = np.flatnonzero(v)
-            order[i, :len(idx)] = torch.from_numpy(idx.astype(np.int32))
-        return self._subsample(order, valid.sum(1))
+        from oracle import oracle_np as O_
+        order, counts = O_.valid_pixel_order(pcd.numpy())
+        return self._subsample(torch.from_numpy(order), counts)
 
     monkeypatch.setattr(model_mod.functions_module, "average_voxelization_3d", avg_cpu)
     monkeypatch.setattr(model_mod.functions_module, "interpolate_voxel_grid", interp_cpu)
