@@ -188,65 +188,93 @@ __global__ __launch_bounds__(256) void k_pre_crops(
 // contrib/singleview_3d/models/model.py:195-196,206 -- `iy, ix = xp.where(mask[i])`,
 // `n_point = int(mask[i].sum())` per object, with mask = ~isnan(pcd).any(axis): row-major list
 // of the pixels whose three coordinates are all finite-or-inf (not NaN), and their count.
-// One 1024-lane workgroup per image walks it in chunks of 4096 pixels: 4 consecutive pixels per
-// lane (three 16-byte loads), wave prefix by shuffles, wave totals through LDS, running base.
+// A workgroup = (chunk of 4096 pixels, image): 4 consecutive pixels per lane (three 16-byte
+// loads).  It first counts the valid pixels of the chunks BEFORE its own (all loads in flight, no
+// barrier: the prefix is re-read from L2 rather than handed over between workgroups -- 16 chunks
+// per 256 x 256 image, so no second launch and no inter-workgroup protocol), then scans its own
+// chunk (wave prefix by shuffles, wave totals through LDS) and writes the indices.
 // (As torch ops this was isnan / any / sum / cumsum / where x2 / scatter: the int64 cumsum over
-// 8 x 65536 alone measured 149 us per predict.)
+// 8 x 65536 alone measured 149 us per predict; one workgroup per image walking all 16 chunks
+// behind barriers measured 42 us.)
 constexpr int kCompactThreads = 1024;
+constexpr int kCompactChunk = 4 * kCompactThreads;
+
+__device__ __forceinline__ unsigned valid4(const float *__restrict__ src, int p, int HW, int vec) {
+  unsigned v = 0u;
+  if (vec && p + 3 < HW) {
+    const float4 *q = reinterpret_cast<const float4 *>(src + 3 * (int64_t)p);
+    const float4 a = q[0], c = q[1], d = q[2];
+    v = ((a.x == a.x && a.y == a.y && a.z == a.z) ? 1u : 0u) |
+        ((a.w == a.w && c.x == c.x && c.y == c.y) ? 2u : 0u) |
+        ((c.z == c.z && c.w == c.w && d.x == d.x) ? 4u : 0u) |
+        ((d.y == d.y && d.z == d.z && d.w == d.w) ? 8u : 0u);
+  } else {
+    for (int k = 0; k < 4; ++k)
+      if (p + k < HW) {
+        const float x = src[3 * (int64_t)(p + k)], y = src[3 * (int64_t)(p + k) + 1], z = src[3 * (int64_t)(p + k) + 2];
+        if (x == x && y == y && z == z) v |= 1u << k;
+      }
+  }
+  return v;
+}
 
 __global__ __launch_bounds__(kCompactThreads) void k_valid_order(const float *__restrict__ pcd, int HW,
                                                                   int vec, int32_t *__restrict__ order,
                                                                   int32_t *__restrict__ counts) {
-  __shared__ int s_wave[kCompactThreads / 64];
-  __shared__ int s_base;
-  const int b = blockIdx.x;
+  __shared__ int s_wave[kCompactThreads / 64], s_pre[kCompactThreads / 64];
+  const int b = blockIdx.y, chunk = blockIdx.x;
   const float *src = pcd + (int64_t)b * HW * 3;
   int32_t *dst = order + (int64_t)b * HW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) s_base = 0;
-  __syncthreads();
-  for (int p0 = 0; p0 < HW; p0 += 4 * kCompactThreads) {
-    const int p = p0 + 4 * (int)threadIdx.x;
-    unsigned v = 0u;
-    if (vec && p + 3 < HW) {
-      const float4 *q = reinterpret_cast<const float4 *>(src + 3 * (int64_t)p);
-      const float4 a = q[0], c = q[1], d = q[2];
-      v = ((a.x == a.x && a.y == a.y && a.z == a.z) ? 1u : 0u) |
-          ((a.w == a.w && c.x == c.x && c.y == c.y) ? 2u : 0u) |
-          ((c.z == c.z && c.w == c.w && d.x == d.x) ? 4u : 0u) |
-          ((d.y == d.y && d.z == d.z && d.w == d.w) ? 8u : 0u);
-    } else {
-      for (int k = 0; k < 4; ++k)
-        if (p + k < HW) {
-          const float x = src[3 * (int64_t)(p + k)], y = src[3 * (int64_t)(p + k) + 1], z = src[3 * (int64_t)(p + k) + 2];
-          if (x == x && y == y && z == z) v |= 1u << k;
-        }
-    }
-    const int n = __popc(v);
-    int incl = n;  // inclusive prefix over the wave
+  // valid pixels of the chunks before this one
+  int pre = 0;
+  if (vec) {  // earlier chunks are full: no bounds test, 4 chunks (12 loads) in flight per lane
+    constexpr int kU = 4;
+    for (int c0 = 0; c0 < chunk; c0 += kU) {
+      float4 r[kU][3];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(incl, off);
-      if (lane >= off) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    int before = s_base, chunk = 0;
+      for (int u = 0; u < kU; ++u) {
+        const int c = min(c0 + u, chunk - 1);
+        const float4 *q = reinterpret_cast<const float4 *>(src + 3 * ((int64_t)c * kCompactChunk + 4 * (int)threadIdx.x));
+        r[u][0] = q[0]; r[u][1] = q[1]; r[u][2] = q[2];
+      }
 #pragma unroll
-    for (int w = 0; w < kCompactThreads / 64; ++w) {
-      const int cw = s_wave[w];
-      before += w < wave ? cw : 0;
-      chunk += cw;
+      for (int u = 0; u < kU; ++u) {
+        if (c0 + u >= chunk) continue;
+        const float4 a = r[u][0], c = r[u][1], d = r[u][2];
+        pre += ((a.x == a.x && a.y == a.y && a.z == a.z) ? 1 : 0) + ((a.w == a.w && c.x == c.x && c.y == c.y) ? 1 : 0) +
+               ((c.z == c.z && c.w == c.w && d.x == d.x) ? 1 : 0) + ((d.y == d.y && d.z == d.z && d.w == d.w) ? 1 : 0);
+      }
     }
-    int at = before + incl - n;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if ((v >> k) & 1u) dst[at++] = p + k;
-    __syncthreads();
-    if (threadIdx.x == 0) s_base += chunk;
-    __syncthreads();
+  } else {
+    for (int c = 0; c < chunk; ++c) pre += __popc(valid4(src, c * kCompactChunk + 4 * (int)threadIdx.x, HW, 0));
   }
-  if (threadIdx.x == 0) counts[b] = s_base;
+  const int p = chunk * kCompactChunk + 4 * (int)threadIdx.x;
+  const unsigned v = valid4(src, p, HW, vec);
+  const int n = __popc(v);
+  int incl = n;  // inclusive prefix over the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off);
+  if (lane == 63) s_wave[wave] = incl;
+  if (lane == 0) s_pre[wave] = pre;
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kCompactThreads / 64; ++w) {
+    const int cw = s_wave[w];
+    before += s_pre[w] + (w < wave ? cw : 0);
+    total += s_pre[w] + cw;
+  }
+  int at = before + incl - n;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if ((v >> k) & 1u) dst[at++] = p + k;
+  if (threadIdx.x == 0 && chunk == (int)gridDim.x - 1) counts[b] = total;
 }
 
 }  // namespace
@@ -294,6 +322,8 @@ extern "C" int mf_valid_pixel_order(const float *pcd, int32_t B, int32_t HW, int
   }
   // 16-byte loads need every image to start 16-byte aligned: HW * 3 floats per image
   const int vec = (reinterpret_cast<uintptr_t>(pcd) & 15u) == 0 && HW % 4 == 0;
-  hipLaunchKernelGGL(k_valid_order, dim3(B), dim3(kCompactThreads), 0, stream, pcd, (int)HW, vec, order, counts);
+  if (HW == 0) return -(int)hipMemsetAsync(counts, 0, sizeof(int32_t) * B, stream);
+  hipLaunchKernelGGL(k_valid_order, dim3((HW + kCompactChunk - 1) / kCompactChunk, B), dim3(kCompactThreads), 0, stream,
+                     pcd, (int)HW, vec, order, counts);
   return mf::check_launch("mf_valid_pixel_order");
 }

@@ -172,7 +172,7 @@ def test_valid_pixel_order_kernel_source_vs_numpy_where():
     lib = emul.build(["preprocess.hip"])
     lib.mf_valid_pixel_order.argtypes = [_p, _i32, _i32, _p, _p, _p]
     rs = np.random.RandomState(3)
-    for HW, off in ((4096 + 2048, 0), (5003, 0), (4096, 1)):
+    for HW, off in ((4096 + 2048, 0), (5003, 0), (4096, 1), (4096 * 6 + 8, 0), (4096 * 2 + 5, 1)):
         B = 3
         buf = np.zeros(B * HW * 3 + 4, np.float32)
         pcd = buf[off:off + B * HW * 3].reshape(B, HW, 3)   # off = 1: not 16-byte aligned
