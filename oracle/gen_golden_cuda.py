@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""Golden vectors for the GPU-ONLY half of the path, produced by executing the REFERENCE's own
+CUDA kernel text and Python bodies on the CPU.  TEST INFRASTRUCTURE ONLY (build container).
+
+``oracle/gen_golden.py`` pins what the reference can run on NumPy (its ``forward_cpu`` bodies).
+The rest of the path -- truncated_distance_function (K7/K8), pseudo_occupancy_voxelization (F2),
+the GPU forms of interpolate_voxel_grid (K5/K6, incl. the only backward), geometry.nn (K9), the
+ICC and ICP links' forward -- exists in the reference only as CUDA text inside
+``cuda.elementwise(...)`` strings, one ``.cu`` file, and xp-generic Python around them.  This
+script runs exactly that code: the reference modules are loaded by path from /root/reference
+under the stand-in ``chainer`` of gen_golden.py, extended by a ``cupy`` namespace that is NumPy
+plus ``oracle/cuda_text.py`` (ElementwiseKernel / RawKernel: the kernel text compiled by g++ and
+executed sequentially, IEEE float32, no FMA contraction).  Every number written below comes out
+of reference source files; nothing of them is copied into the repository.
+
+Reference files executed (under /root/reference/morefusion):
+  functions/geometry/truncated_distance_function.py (forward_gpu, backward_gpu,
+      truncated_distance_function, pseudo_occupancy_voxelization)
+  functions/geometry/interpolate_voxel_grid.py (forward_gpu, backward_gpu)
+  geometry/knn/nn.py (nn_gpu) + geometry/knn/cuComputeDistanceGlobal.cu
+  contrib/iterative_collision_check_link.py (forward), contrib/iterative_closest_point_link.py
+      (forward, T), with functions/geometry/{transformation_matrix, quaternion_matrix,
+      translation_matrix, compose_transform, transform_points}.py underneath
+
+Not pinned by this (third party, absent): chainer's autograd through the links (their gradients),
+chainer.optimizers.Adam, trimesh.quaternion_from_matrix (the links are built around their
+``__init__``: quaternion / translation are set directly).
+
+Usage:  python oracle/gen_golden_cuda.py   (writes tests/golden/ref_cuda_*.npz)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import cuda_text  # noqa: E402
+from oracle import gen_golden as G  # noqa: E402
+
+OUT = G.OUT
+
+
+def install():
+    G._install_stub()
+    chainer = sys.modules["chainer"]
+    cuda = sys.modules["chainer.backends.cuda"]
+    cupy = types.ModuleType("cupy")
+    cupy.__dict__.update({k: getattr(np, k) for k in dir(np) if not k.startswith("_")})
+    cupy.ElementwiseKernel = cuda_text.ElementwiseKernel
+    cupy.RawKernel = cuda_text.RawKernel
+    sys.modules["cupy"] = cupy
+    cuda.cupy = cupy
+    cuda.elementwise = cuda_text.elementwise
+
+    # chainer.Function.__call__: arrays here are NumPy, but the code under test is the GPU branch
+    def call(self, *inputs):
+        arrays = tuple(G._unwrap(x) for x in inputs)
+        self._inputs = arrays
+        fwd = self.forward_gpu if G._overridden(self, "forward_gpu") else (
+            self.forward_cpu if G._overridden(self, "forward_cpu") else self.forward)
+        outs = tuple(G.Variable(o) for o in fwd(arrays))
+        return outs[0] if len(outs) == 1 else outs
+
+    G.Function.__call__ = call
+
+    F = sys.modules["chainer.functions"]
+    U, V = G._unwrap, G.Variable
+    F.stack = lambda xs, axis=0: V(np.stack([U(x) for x in xs], axis=axis))
+    F.maximum = lambda a, b: V(np.maximum(U(a), U(b)))
+    F.argmin = lambda x, axis=None: V(np.argmin(U(x), axis=axis))
+    F.concat = lambda xs, axis=1: V(np.concatenate([U(x) for x in xs], axis=axis))
+
+    class Link:
+        xp = np
+
+        def __init__(self):
+            pass
+
+        def __call__(self, *a, **k):
+            return self.forward(*a, **k)
+
+    chainer.Link = Link
+    chainer.Parameter = lambda initializer=None, *a, **k: V(initializer)
+    for name in ("trimesh", "trimesh.transformations", "path", "sklearn", "sklearn.neighbors"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["trimesh"].transformations = sys.modules["trimesh.transformations"]
+    sys.modules["sklearn"].neighbors = sys.modules["sklearn.neighbors"]
+
+    class _Path(str):  # path.Path(__file__).abspath().parent / "x.cu"
+        def abspath(self):
+            return _Path(os.path.abspath(self))
+
+        parent = property(lambda self: _Path(os.path.dirname(self)))
+
+        def __truediv__(self, other):
+            return _Path(os.path.join(self, other))
+
+    sys.modules["path"].Path = _Path
+    for pkg, sub in [("morefusion.contrib", "contrib"), ("morefusion.geometry.knn", "geometry/knn")]:
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(G.REF, sub)]
+        sys.modules[pkg] = m
+
+
+def main():
+    install()
+    g = "morefusion.functions.geometry"
+    L = G._load
+    tdf = L(g + ".truncated_distance_function", "functions/geometry/truncated_distance_function.py")
+    itp = L(g + ".interpolate_voxel_grid", "functions/geometry/interpolate_voxel_grid.py")
+    qm = L(g + ".quaternion_matrix", "functions/geometry/quaternion_matrix.py")
+    tlm = L(g + ".translation_matrix", "functions/geometry/translation_matrix.py")
+    ct = L(g + ".compose_transform", "functions/geometry/compose_transform.py")
+    tfm = L(g + ".transformation_matrix", "functions/geometry/transformation_matrix.py")
+    tp = L(g + ".transform_points", "functions/geometry/transform_points.py")
+    fm = sys.modules["morefusion.functions"]
+    fm.transformation_matrix = tfm.transformation_matrix
+    fm.transform_points = tp.transform_points
+    fm.pseudo_occupancy_voxelization = tdf.pseudo_occupancy_voxelization
+    fm.truncated_distance_function = tdf.truncated_distance_function
+    sys.modules["morefusion"].functions = fm
+    nn = L("morefusion.geometry.knn.nn", "geometry/knn/nn.py")
+    icc = L("morefusion.contrib.iterative_collision_check_link", "contrib/iterative_collision_check_link.py")
+    icp = L("morefusion.contrib.iterative_closest_point_link", "contrib/iterative_closest_point_link.py")
+    rs = np.random.RandomState(0)
+
+    # ---- K7 / K8: truncated_distance_function forward + backward, three thresholds, a non-cubic grid
+    cases = {}
+    for tag, dims, thr, P in (("d32_t1", (32, 32, 32), 1.0, 1500), ("d32_t2", (32, 32, 32), 2.0, 1500),
+                              ("d32_t3", (32, 32, 32), 3.0, 600), ("d8x12x10_t2", (8, 12, 10), 2.0, 300)):
+        pitch = np.float32(0.0087058)
+        origin = (-np.array(dims, np.float32) / 2 * pitch).astype(np.float32)
+        # a noisy spherical shell plus a few points outside the grid
+        u = rs.normal(size=(P, 3))
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        centre = origin + np.array(dims, np.float32) * pitch / 2
+        points = (centre + u * pitch * min(dims) * 0.33 + rs.normal(0, pitch * 0.4, (P, 3))).astype(np.float32)
+        points[:5] += pitch * 40
+        f = tdf.TruncatedDistanceFunction(pitch=pitch, origin=origin, dims=dims, truncation=np.float32(thr) * pitch)
+        (matrix,) = f.forward_gpu((points,))
+        gmatrix = rs.uniform(-1, 1, dims).astype(np.float32)
+        (gpoints,) = f.backward_gpu((points,), (gmatrix,))
+        for k, v in dict(points=points, pitch=pitch, origin=origin, dims=np.array(dims, np.int32),
+                         truncation=np.float32(thr) * pitch, matrix=matrix, indices=f._indices,
+                         ksize=np.int32(f._ksize), gmatrix=gmatrix, gpoints=gpoints).items():
+            cases[f"{tag}__{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "ref_cuda_tdf.npz"), **cases)
+    print("tdf:", {k: v.shape for k, v in cases.items() if k.startswith("d32_t2")})
+
+    # ---- F2: pseudo_occupancy_voxelization (the Python around K7), two (threshold, sdf_offset)
+    out = {}
+    P = 2000
+    pitch = np.float32(0.0087058)
+    origin = np.full(3, -16 * pitch, np.float32)
+    u = rs.normal(size=(P, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    r = rs.uniform(0.3, 1.0, (P, 1))
+    points = (u * r * pitch * 11).astype(np.float32)
+    sdf = ((1.0 - r[:, 0]) * pitch * 11).astype(np.float32)  # positive inside, 0 at the surface
+    for tag, thr, off in (("t2_off0", 2, 0.0), ("t2_off002", 2, 0.02), ("t1_off0", 1, 0.0)):
+        gu, gs, gi = tdf.pseudo_occupancy_voxelization(points, sdf, pitch=pitch, origin=origin, dims=(32,) * 3,
+                                                       threshold=thr, sdf_offset=off)
+        out.update({f"{tag}__uniform": G._unwrap(gu), f"{tag}__surface": G._unwrap(gs), f"{tag}__inside": G._unwrap(gi)})
+    out.update(points=points, sdf=sdf, pitch=pitch, origin=origin)
+    np.savez_compressed(os.path.join(OUT, "ref_cuda_pseudo_occupancy.npz"), **out)
+
+    # ---- K5 / K6: interpolate_voxel_grid GPU forward and (the only) backward
+    B, C, X, Pn = 2, 3, 8, 200
+    vox = rs.uniform(-1, 1, (B, C, X, X, X)).astype(np.float32)
+    pts = (rs.uniform(-0.2, 1.15, (Pn, 3)) * X).astype(np.float32)
+    bi = rs.randint(0, B, Pn).astype(np.int32)
+    f = itp.InterpolateVoxelGrid()
+    (values,) = f.forward_gpu((vox, pts, bi))
+    gvalues = rs.uniform(-1, 1, (Pn, C)).astype(np.float32)
+    gvox = f.backward_gpu((vox, pts, bi), (gvalues,))[0]
+    np.savez_compressed(os.path.join(OUT, "ref_cuda_interpolate.npz"), voxelized=vox, points=pts, batch_indices=bi,
+                        values=values, gvalues=gvalues, gvoxelized=gvox)
+
+    # ---- K9: geometry.nn (RawKernel text + argmin), incl. exact ties and ragged tile edges
+    ref = rs.uniform(0, 1, (300, 3)).astype(np.float32)
+    ref[17] = ref[5]
+    query = rs.uniform(0, 1, (1001, 3)).astype(np.float32)
+    query[3] = ref[5]
+    idx = nn.nn_gpu(ref, query)
+    np.savez_compressed(os.path.join(OUT, "ref_cuda_nn.npz"), ref=ref, query=query, indices=np.asarray(idx, np.int64))
+
+    # ---- F3 / F4: the links' forward (poses set directly: no trimesh).  Scenes = the recorded
+    # fixtures (+ the synthetic objects of BASELINE config 3) exactly as the tests build them:
+    # morefusion_amd.synthetic.make_icc_scene(n, seed=0, fixtures=...)
+    import morefusion_amd.synthetic as synthetic
+    from oracle import oracle_np as O
+    fx = [np.load(os.path.join(OUT, f"fixture_pose_refinement_{i:08d}.npz")) for i in range(3)]
+    res = {}
+    for n, off in ((1, 0.0), (3, 0.0), (3, 0.02), (8, 0.0), (8, 0.02)):
+        sc = synthetic.make_icc_scene(n, seed=0, fixtures=fx)
+        q = np.stack([O.quaternion_from_matrix(T) for T in sc["transform_init"]]).astype(np.float32)
+        t = np.stack([T[:3, 3] for T in sc["transform_init"]]).astype(np.float32)
+        link = object.__new__(icc.IterativeCollisionCheckLink)
+        link._voxel_dim, link._voxel_threshold, link._sdf_offset = 32, 2, off
+        link.quaternion, link.translation = G.Variable(q), G.Variable(t)
+        loss = link.forward([p.astype(np.float32) for p in sc["points"]], [v.astype(np.float32) for v in sc["sdf"]],
+                            [np.float32(v) for v in sc["pitch"]], [o.astype(np.float32) for o in sc["origin"]],
+                            np.stack(sc["grid_target"]).astype(np.float32),
+                            np.stack(sc["grid_nontarget_empty"]).astype(np.float32))
+        res[f"icc_loss_n{n}_off{off}"] = np.float32(G._unwrap(loss))
+        res[f"icc_q_n{n}"], res[f"icc_t_n{n}"] = q, t
+    f2 = fx[2]
+    q2 = O.quaternion_from_matrix(f2["transform_init"]).astype(np.float32)
+    t2 = f2["transform_init"][:3, 3].astype(np.float32)
+    target = (np.argwhere(f2["grid_target"] >= 0.5) * f2["pitch"] + f2["origin"]).astype(np.float32)
+    link = object.__new__(icp.IterativeClosestPointLink)
+    link.quaternion, link.translation = G.Variable(q2), G.Variable(t2)
+    res["icp_loss"] = np.float32(G._unwrap(link.forward(f2["pcd_cad"].astype(np.float32), target)))
+    res["icp_T"] = G._unwrap(link.T)
+    res["icp_q"], res["icp_t"] = q2, t2
+    np.savez_compressed(os.path.join(OUT, "ref_cuda_links.npz"), **res)
+    print({k: (v if np.ndim(v) == 0 else np.shape(v)) for k, v in res.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -9,10 +9,16 @@ Every function cites the reference file:line it follows (paths relative to
 restatement is pinned against golden vectors produced by running that twin
 itself (``oracle/gen_golden.py`` -> ``tests/golden/ref_*.npz``,
 ``tests/test_oracle_golden.py``).  Where the reference is GPU-only CUDA text
-(truncated_distance_function, knn, ICC/ICP links) there is nothing executable to
-pin against: those restatements are cross-checked against the independent C
-restatement in ``oracle/mf_oracle.c`` and finite differences, and are declared
-**parity unpinned** (DESIGN.md section 3).
+(truncated_distance_function fwd/bwd, pseudo_occupancy_voxelization, the GPU forms of
+interpolate_voxel_grid incl. its only backward, knn, the ICC / ICP links' forward) the
+restatement is pinned against golden vectors produced by EXECUTING THAT TEXT: the kernel
+strings compiled by g++ and run sequentially, the Python around them run on NumPy
+(``oracle/cuda_text.py`` + ``oracle/gen_golden_cuda.py`` -> ``tests/golden/ref_cuda_*.npz``,
+``tests/test_oracle_vs_reference_cuda_text.py``): distances, winner indices and
+pseudo-occupancy grids bit-exact, losses to float32 rounding.  Still **parity unpinned**
+(third party, absent here): chainer's autograd through the links (their gradients are checked
+against finite differences and the independent C restatement instead), chainer's Adam,
+trimesh's quaternion_from_matrix, cv2 / imgviz resizing.
 
 ``mode`` selects between the reference's two semantic forks:
   "cpu": what ``forward_cpu`` does (NumPy promotion, round-half-even, floor)

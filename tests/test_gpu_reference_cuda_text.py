@@ -1,0 +1,86 @@
+"""The HIP kernels against golden vectors produced by EXECUTING THE REFERENCE'S OWN CUDA TEXT
+(``oracle/gen_golden_cuda.py`` -> tests/golden/ref_cuda_*.npz): no oracle in between.
+K7/K8 truncated_distance_function, F2 pseudo_occupancy_voxelization, K5/K6 interpolate_voxel_grid
+(GPU forms), K9 geometry.nn, F3/F4 the ICC / ICP links' loss on the fixture scenes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+import morefusion_amd as mf  # noqa: E402
+import morefusion_amd.functions as F  # noqa: E402
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("tag", ["d32_t1", "d32_t2", "d32_t3", "d8x12x10_t2"])
+def test_tdf_hip_vs_reference_cuda_text(tag):
+    g = golden("ref_cuda_tdf.npz")
+    c = {k.split("__", 1)[1]: g[k] for k in g if k.startswith(tag + "__")}
+    K = int(c["ksize"]) ** 3
+    pt = dev(c["points"]).requires_grad_(True)
+    tdf, idx = F.truncated_distance_function(pt, pitch=float(c["pitch"]), origin=tuple(c["origin"]),
+                                             dims=tuple(int(v) for v in c["dims"]),
+                                             truncation=float(c["truncation"]), return_indices=True)
+    np.testing.assert_array_equal(tdf.detach().cpu().numpy(), c["matrix"])
+    # the reference returns `indices // K` (point id of the winner; lowest flat index on ties)
+    np.testing.assert_array_equal(idx.cpu().numpy(), np.where(c["indices"] >= 0, c["indices"] // K, -1))
+    tdf.backward(dev(c["gmatrix"]))
+    np.testing.assert_allclose(pt.grad.cpu().numpy(), c["gpoints"], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag,thr,off", [("t2_off0", 2, 0.0), ("t2_off002", 2, 0.02), ("t1_off0", 1, 0.0)])
+def test_pseudo_occupancy_hip_vs_reference(tag, thr, off):
+    g = golden("ref_cuda_pseudo_occupancy.npz")
+    outs = F.pseudo_occupancy_voxelization(dev(g["points"]), dev(g["sdf"]), pitch=float(g["pitch"]),
+                                           origin=tuple(g["origin"]), dims=(32,) * 3, threshold=thr, sdf_offset=off)
+    for o, k in zip(outs, ("uniform", "surface", "inside")):
+        np.testing.assert_array_equal(o.cpu().numpy(), g[f"{tag}__{k}"])
+
+
+def test_interpolate_hip_vs_reference_cuda_text():
+    g = golden("ref_cuda_interpolate.npz")
+    vox = dev(g["voxelized"]).requires_grad_(True)
+    out = F.interpolate_voxel_grid(vox, dev(g["points"]), dev(g["batch_indices"]))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), g["values"])
+    out.backward(dev(g["gvalues"]))
+    np.testing.assert_allclose(vox.grad.cpu().numpy(), g["gvoxelized"], rtol=1e-5, atol=1e-6)
+
+
+def test_nn_hip_vs_reference_raw_kernel():
+    g = golden("ref_cuda_nn.npz")
+    np.testing.assert_array_equal(mf.geometry.nn(dev(g["ref"]), dev(g["query"])).cpu().numpy(), g["indices"])
+
+
+@pytest.mark.parametrize("n,off", [(1, 0.0), (3, 0.0), (3, 0.02), (8, 0.0), (8, 0.02)])
+def test_icc_link_loss_hip_vs_reference(n, off, fixtures3):
+    """IterativeCollisionCheckLink.forward of the reference, executed (K7 text underneath), vs the
+    fused HIP path on the same scene and poses (both iteration layouts)."""
+    g = golden("ref_cuda_links.npz")
+    sc = mf.synthetic.make_icc_scene(n, seed=0, fixtures=fixtures3)
+    link = mf.contrib.IterativeCollisionCheckLink(sc["transform_init"], sdf_offset=off).to_gpu()
+    with torch.no_grad():
+        link.quaternion.copy_(dev(g[f"icc_q_n{n}"]))
+        link.translation.copy_(dev(g[f"icc_t_n{n}"]))
+    args = ([dev(p) for p in sc["points"]], [dev(s) for s in sc["sdf"]], dev(np.asarray(sc["pitch"], np.float32)),
+            dev(np.stack(sc["origin"]).astype(np.float32)), dev(np.stack(sc["grid_target"]).astype(np.float32)),
+            dev(np.stack(sc["grid_nontarget_empty"]).astype(np.float32)))
+    loss = float(link(*args).detach())
+    np.testing.assert_allclose(loss, float(g[f"icc_loss_n{n}_off{off}"]), rtol=2e-5, atol=2e-6)
+
+
+def test_icp_link_loss_hip_vs_reference(fixtures3):
+    g = golden("ref_cuda_links.npz")
+    f = fixtures3[2]
+    target = dev((np.argwhere(f["grid_target"] >= 0.5) * f["pitch"] + f["origin"]).astype(np.float32))
+    link = mf.contrib.IterativeClosestPointLink(np.eye(4, dtype=np.float32)).to_gpu()
+    with torch.no_grad():
+        link.quaternion.copy_(dev(g["icp_q"]))
+        link.translation.copy_(dev(g["icp_t"]))
+    np.testing.assert_allclose(float(link(dev(f["pcd_cad"].astype(np.float32)), target).detach()),
+                               float(g["icp_loss"]), rtol=2e-5)
