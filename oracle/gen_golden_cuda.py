@@ -17,6 +17,7 @@ Reference files executed (under /root/reference/morefusion):
   functions/geometry/truncated_distance_function.py (forward_gpu, backward_gpu,
       truncated_distance_function, pseudo_occupancy_voxelization)
   functions/geometry/interpolate_voxel_grid.py (forward_gpu, backward_gpu)
+  functions/geometry/average_voxelization_3d.py, max_voxelization_3d.py (forward_gpu, backward_gpu)
   geometry/knn/nn.py (nn_gpu) + geometry/knn/cuComputeDistanceGlobal.cu
   contrib/iterative_collision_check_link.py (forward), contrib/iterative_closest_point_link.py
       (forward, T), with functions/geometry/{transformation_matrix, quaternion_matrix,
@@ -187,6 +188,33 @@ def main():
     query[3] = ref[5]
     idx = nn.nn_gpu(ref, query)
     np.savez_compressed(os.path.join(OUT, "ref_cuda_nn.npz"), ref=ref, query=query, indices=np.asarray(idx, np.int64))
+
+    # ---- K1-K4: the GPU forms of average / max voxelization (round-half-AWAY fork of the index
+    # rule, exercised by exact .5 coordinates; sequential atomics = increasing point index)
+    L(g + ".voxelization_3d", "functions/geometry/voxelization_3d.py")
+    avg = L(g + ".average_voxelization_3d", "functions/geometry/average_voxelization_3d.py")
+    mx = L(g + ".max_voxelization_3d", "functions/geometry/max_voxelization_3d.py")
+    D, C, B, P = 16, 5, 2, 600
+    origin = np.array([-1, -1, -1], dtype=np.float32)
+    pitch = np.float32(2.0 / D)
+    points = rs.uniform(-1.1, 1.05, (P, 3)).astype(np.float32)
+    points[:40] = (origin + pitch * (rs.randint(0, D, (40, 3)) + 0.5)).astype(np.float32)  # exact halves
+    points[40:80] = points[:40]                                                          # shared voxels
+    values = rs.uniform(-1, 1, (P, C)).astype(np.float32)
+    bidx = rs.randint(0, B, P).astype(np.int32)
+    inten = rs.uniform(0, 1, P).astype(np.float32)
+    inten[40:80] = inten[:40]                                                            # exact intensity ties
+    fa = avg.AverageVoxelization3D(batch_size=B, pitch=float(pitch), origin=origin, dimensions=(D, D, D))
+    (am,) = fa.forward_gpu((values, points, bidx))
+    gy = rs.uniform(-1, 1, (B, C, D, D, D)).astype(np.float32)
+    agv = fa.backward_gpu((values, points, bidx), (gy,))[0]
+    fmx = mx.MaxVoxelization3D(batch_size=B, pitch=float(pitch), origin=origin, dimensions=(D, D, D))
+    (mm,) = fmx.forward_gpu((values, points, bidx, inten))
+    mgv = fmx.backward_gpu((values, points, bidx, inten), (gy,))[0]
+    np.savez_compressed(os.path.join(OUT, "ref_cuda_voxelization.npz"), values=values, points=points,
+                        batch_indices=bidx, intensities=inten, origin=origin, pitch=pitch, dim=np.int32(D),
+                        batch_size=np.int32(B), avg_matrix=am, avg_counts=fa.counts, gy=gy, avg_gvalues=agv,
+                        max_matrix=mm, max_indices=fmx.indices, max_gvalues=mgv)
 
     # ---- F3 / F4: the links' forward (poses set directly: no trimesh).  Scenes = the recorded
     # fixtures (+ the synthetic objects of BASELINE config 3) exactly as the tests build them:

@@ -84,3 +84,22 @@ def test_icp_link_loss_hip_vs_reference(fixtures3):
         link.translation.copy_(dev(g["icp_t"]))
     np.testing.assert_allclose(float(link(dev(f["pcd_cad"].astype(np.float32)), target).detach()),
                                float(g["icp_loss"]), rtol=2e-5)
+
+
+def test_voxelization_hip_vs_reference_cuda_text():
+    g = golden("ref_cuda_voxelization.npz")
+    D, B = int(g["dim"]), int(g["batch_size"])
+    kw = dict(batch_size=B, origin=tuple(g["origin"]), pitch=float(g["pitch"]), dimensions=(D, D, D))
+    values = dev(g["values"]).requires_grad_(True)
+    y, counts = F.average_voxelization_3d(values, dev(g["points"]), dev(g["batch_indices"]), return_counts=True, **kw)
+    np.testing.assert_array_equal(counts.cpu().numpy(), g["avg_counts"])
+    np.testing.assert_array_equal(y.detach().cpu().numpy(), g["avg_matrix"])
+    y.backward(dev(g["gy"]))
+    np.testing.assert_array_equal(values.grad.cpu().numpy(), g["avg_gvalues"])
+    values = dev(g["values"]).requires_grad_(True)
+    ym, ind = F.max_voxelization_3d(values, dev(g["points"]), dev(g["batch_indices"]), dev(g["intensities"]),
+                                    return_indices=True, **kw)
+    np.testing.assert_array_equal(ind.cpu().numpy(), g["max_indices"])
+    np.testing.assert_array_equal(ym.detach().cpu().numpy(), g["max_matrix"])
+    ym.backward(dev(g["gy"]))
+    np.testing.assert_allclose(values.grad.cpu().numpy(), g["max_gvalues"], rtol=1e-6, atol=1e-7)

@@ -98,3 +98,25 @@ def test_icp_link_forward_vs_reference(fixtures3):
     loss = loss[0] if isinstance(loss, tuple) else loss
     np.testing.assert_allclose(float(loss), float(g["icp_loss"]), rtol=2e-6)
     np.testing.assert_allclose(OC.icp_loss_grad(source, target, g["icp_q"], g["icp_t"])[0], float(g["icp_loss"]), rtol=2e-5)
+
+
+def test_voxelization_gpu_forms_vs_reference_cuda_text():
+    """K1-K4 (the forward_gpu / backward_gpu kernels, round-half-away index rule) executed from the
+    reference: exact .5 coordinates, shared voxels, exact intensity ties."""
+    g = golden("ref_cuda_voxelization.npz")
+    D, B = int(g["dim"]), int(g["batch_size"])
+    kw = dict(batch_size=B, origin=g["origin"], pitch=g["pitch"], dimensions=(D, D, D))
+    m, c = O.average_voxelization_3d(g["values"], g["points"], g["batch_indices"], mode="gpu", **kw)
+    np.testing.assert_array_equal(c, g["avg_counts"])
+    np.testing.assert_array_equal(m, g["avg_matrix"])
+    gv = O.average_voxelization_3d_backward(g["gy"], g["points"], g["batch_indices"], c, origin=g["origin"],
+                                            pitch=g["pitch"], dimensions=(D, D, D), mode="gpu")
+    np.testing.assert_array_equal(gv, g["avg_gvalues"])
+    mm, ind = O.max_voxelization_3d(g["values"], g["points"], g["batch_indices"], g["intensities"], mode="gpu", **kw)
+    np.testing.assert_array_equal(ind, g["max_indices"])
+    np.testing.assert_array_equal(mm, g["max_matrix"])
+    np.testing.assert_allclose(O.max_voxelization_3d_backward(g["gy"], ind, len(g["points"])), g["max_gvalues"],
+                               rtol=1e-6, atol=1e-7)
+    # the CPU fork (round-half-even) differs on the exact halves: the fork is real
+    _, c_cpu = O.average_voxelization_3d(g["values"], g["points"], g["batch_indices"], mode="cpu", **kw)
+    assert (c_cpu != g["avg_counts"]).any()
