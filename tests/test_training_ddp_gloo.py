@@ -1,0 +1,148 @@
+"""BASELINE config 5 on the CPU: two-rank data-parallel training step of the pose network over gloo.
+
+The reference trains with ChainerMN's multi-node optimizer (gradient all-reduce,
+examples/ycb_video/singleview_3d/train.py:228-233,342-344); here the model is wrapped in torch's
+``DistributedDataParallel`` (RCCL on the GPUs, gloo in this test).  The two HIP ops of the
+training graph (dense average_voxelization_3d, interpolate_voxel_grid) and the valid-pixel
+compaction are replaced by autograd stand-ins built on the oracle (test-only), everything else is
+the product's host code: ``Model.forward`` -> ``predict`` -> ``loss`` (ADD; non-symmetric classes).
+Checked: after ``backward`` every rank holds the MEAN of the two ranks' local gradients, equal to
+what two single-process runs on the same data and seeds average to."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+WATCH = ("conv1_rot.weight", "conv3.weight", "conv4.weight", "resnet_extractor.res5.1.conv2.weight",
+         "pspnet_extractor.up3.conv.weight", "conv1_occ.weight")
+
+
+def _install_standins():
+    from oracle import oracle_c as OC
+    from oracle import oracle_np as O
+    import morefusion_amd.contrib.singleview_3d.models.model as model_mod
+    from morefusion_amd.contrib.singleview_3d.models import Model
+
+    class AvgVox(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, values, points, bi, B, origin, pitch, dims):
+            m, c = OC.average_voxelization_3d(values.detach().numpy(), points.numpy(), bi.numpy(), batch_size=B,
+                                              origin=origin, pitch=pitch, dimensions=dims)
+            ctx.aux = (points.numpy(), bi.numpy(), c, origin, pitch, dims)
+            return torch.from_numpy(m), torch.from_numpy(c)
+
+        @staticmethod
+        def backward(ctx, gm, gc):
+            points, bi, c, origin, pitch, dims = ctx.aux
+            gv = O.average_voxelization_3d_backward(gm.numpy(), points, bi, c, origin=origin, pitch=pitch,
+                                                    dimensions=dims, mode="gpu")
+            return torch.from_numpy(gv), None, None, None, None, None, None
+
+    def avg_cpu(values, points, batch_indices, *, batch_size, origin, pitch, dimensions, return_counts=False, **kw):
+        m, c = AvgVox.apply(values, points, batch_indices, batch_size, origin, pitch, dimensions)
+        return (m, c) if return_counts else m
+
+    class Interp(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, vox, points, bi):
+            ctx.aux = (points.numpy(), bi.numpy(), tuple(vox.shape))
+            return torch.from_numpy(OC.interpolate_voxel_grid(vox.detach().numpy(), points.numpy(), bi.numpy()))
+
+        @staticmethod
+        def backward(ctx, g):
+            points, bi, shape = ctx.aux
+            return torch.from_numpy(O.interpolate_voxel_grid_backward(np.ascontiguousarray(g.numpy()), points, bi,
+                                                                      shape, mode="gpu")), None, None
+
+    def interp_cpu(vox, points, batch_indices, channels_first=False, batch_start=None):
+        out = Interp.apply(vox, points, batch_indices)
+        return out.t().contiguous() if channels_first else out
+
+    def select_cpu(self, pcd):
+        order, counts = O.valid_pixel_order(pcd.numpy())
+        return self._subsample(torch.from_numpy(order), counts)
+
+    model_mod.functions_module.average_voxelization_3d = avg_cpu
+    model_mod.functions_module.interpolate_voxel_grid = interp_cpu
+    Model._select_points = select_cpu
+    return Model
+
+
+def _batch(rank):
+    import morefusion_amd as mf
+    b = mf.synthetic.make_singleview_batch(1, seed=50 + rank)
+    b["class_id"] = np.array([2], np.int32)  # a non-symmetric class: ADD (the CPU composite of the loss)
+    return {k: torch.as_tensor(b[k]) for k in ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty",
+                                               "quaternion_true", "translation_true")}
+
+
+def _build(Model):
+    import morefusion_amd as mf
+    from morefusion_amd.contrib.singleview_3d.models import PitchTableModels
+    torch.manual_seed(0)
+    rs = np.random.RandomState(0)
+    pcds = {c: rs.uniform(-0.05, 0.05, (600, 3)).astype(np.float32) for c in mf.synthetic.CLASS_PITCH}
+    return Model(n_fg_class=21, with_occupancy=True, models=PitchTableModels(pcds)).train()
+
+
+def _local_step(net, rank):
+    np.random.seed(1234 + rank)
+    torch.manual_seed(77 + rank)  # dropout masks
+    loss = net(**_batch(rank))
+    loss.backward()
+    return float(loss.detach())
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(4)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _build(_install_standins())
+        net = torch.nn.parallel.DistributedDataParallel(model)
+        loss = _local_step(net, rank)
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if n in WATCH}
+        torch.save({"loss": loss, "grads": grads}, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_training_step_averages_the_two_ranks_gradients(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
+    # single-process references on the same data / seeds
+    import morefusion_amd.contrib.singleview_3d.models.model as model_mod
+    from morefusion_amd.contrib.singleview_3d.models import Model as RealModel
+    saved = (model_mod.functions_module.average_voxelization_3d, model_mod.functions_module.interpolate_voxel_grid,
+             RealModel._select_points, torch.get_num_threads())
+    torch.set_num_threads(4)
+    try:
+        Model = _install_standins()
+        ref_grads, ref_loss = [], []
+        for r in range(2):
+            model = _build(Model)
+            ref_loss.append(_local_step(model, r))
+            ref_grads.append({n: p.grad.clone() for n, p in model.named_parameters() if n in WATCH})
+    finally:
+        (model_mod.functions_module.average_voxelization_3d, model_mod.functions_module.interpolate_voxel_grid,
+         RealModel._select_points) = saved[:3]
+        torch.set_num_threads(saved[3])
+    for r in range(2):
+        assert abs(got[r]["loss"] - ref_loss[r]) < 1e-5 * max(1.0, abs(ref_loss[r]))
+    assert set(got[0]["grads"]) == set(WATCH)
+    for n in WATCH:
+        mean = 0.5 * (ref_grads[0][n] + ref_grads[1][n])
+        assert float(mean.abs().max()) > 0, n
+        for r in range(2):
+            torch.testing.assert_close(got[r]["grads"][n], mean, rtol=2e-4, atol=1e-7 + 2e-4 * float(mean.abs().max()))
+        torch.testing.assert_close(got[0]["grads"][n], got[1]["grads"][n], rtol=0, atol=0)  # identical on both ranks
