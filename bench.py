@@ -248,12 +248,13 @@ def _icc_algorithmic_bytes(icc):
 
 
 def roofline_icc(wl, us_per_iter):
-    """k_icc_tile -- the hand-written kernel with the largest share of the step (100 launches per
-    refinement), timed live with HIP events through mf_icc_launch_stage on torch's current stream.
-    Its algorithmic HBM bytes per launch (8d, forward half of the TDF): every grid reads its source
-    points once, 16 B each.  ``iteration`` is the same accounting for one whole ICC iteration
-    (bin + tile + accum incl. the folded optimiser step): forward + backward re-read, 8d's
-    12.4 MB per 8-object scene.  The working set is L2/MALL resident and the kernels are bound by
+    """k_icc_fused (k_icc_tile on the two-kernel path of non-{0,1} no-entry grids) -- the hand-written
+    kernel with the largest share of the step (100 launches per refinement), timed live with HIP
+    events through mf_icc_launch_stage on torch's current stream.  Its algorithmic HBM bytes per
+    launch (8d): every grid reads its source points once, 16 B each, plus (single-pass kernel) its
+    two input grids.  ``iteration`` is the same accounting for one whole ICC iteration (k_icc_bin
+    incl. the folded optimiser step + k_icc_fused): forward + backward re-read, 8d's 11.3 MB per
+    8-object scene.  The working set is L2/MALL resident and the kernels are bound by
     dependent-load latency and instruction issue, not by HBM bandwidth -- the fractions below are
     what the contract asks for, not a claim that HBM is the limiter."""
     import ctypes
