@@ -103,6 +103,10 @@ def stream_ptr():
 
 
 def require_gpu(*tensors):
+    """Every tensor on the GPU, and on the CURRENT device: the kernels are launched on the current
+    device's stream (``stream_ptr``), so a tensor of another GPU would be dereferenced by the wrong
+    device (one process may drive several GPUs: select the device with ``torch.cuda.device``)."""
+    cur = None
     for t in tensors:
         if not isinstance(t, torch.Tensor):
             raise TypeError(f"expected torch.Tensor, got {type(t)}")
@@ -111,6 +115,12 @@ def require_gpu(*tensors):
                 "morefusion_amd voxel/refinement ops run on the MI355X only: got a "
                 f"{t.device} tensor (there is no CPU fallback; move inputs to 'cuda')."
             )
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(
+                f"tensor on {t.device} but the current device is cuda:{cur}: run the op under "
+                f"`with torch.cuda.device({t.device.index}):` (kernels launch on the current device's stream)")
 
 
 def ptr(t):
