@@ -249,5 +249,70 @@ def main():
     print({k: (v if np.ndim(v) == 0 else np.shape(v)) for k, v in res.items()})
 
 
+def main_gradients():
+    """Second pass: the links' GRADIENTS.  The reference modules are loaded again, this time under
+    ``oracle/chainer_tape.py`` (a reverse-mode tape with chainer's elementary rules): the backward of
+    every ``chainer.Function`` of the reference (QuaternionMatrix, ComposeTransform, and the CUDA text
+    of TruncatedDistanceFunction.backward_gpu) is reference code, executed."""
+    from oracle import chainer_tape as T
+    install()
+    chainer = sys.modules["chainer"]
+    F = sys.modules["chainer.functions"]
+    chainer.Variable, chainer.Function = T.Variable, T.Function
+    chainer.Parameter = lambda initializer=None, *a, **k: T.Variable(initializer, requires_grad=True)
+    F.sum, F.sqrt, F.repeat, F.concat, F.stack = T.F_sum, T.F_sqrt, T.F_repeat, T.F_concat, T.F_stack
+    F.matmul, F.maximum, F.argmin = T.F_matmul, T.F_maximum, T.F_argmin
+    g = "morefusion.functions.geometry"
+    L = G._load
+    tdf = L(g + ".truncated_distance_function", "functions/geometry/truncated_distance_function.py")
+    L(g + ".quaternion_matrix", "functions/geometry/quaternion_matrix.py")
+    L(g + ".translation_matrix", "functions/geometry/translation_matrix.py")
+    L(g + ".compose_transform", "functions/geometry/compose_transform.py")
+    tfm = L(g + ".transformation_matrix", "functions/geometry/transformation_matrix.py")
+    tp = L(g + ".transform_points", "functions/geometry/transform_points.py")
+    fm = sys.modules["morefusion.functions"]
+    fm.transformation_matrix = tfm.transformation_matrix
+    fm.transform_points = tp.transform_points
+    fm.pseudo_occupancy_voxelization = tdf.pseudo_occupancy_voxelization
+    sys.modules["morefusion"].functions = fm
+    icc = L("morefusion.contrib.iterative_collision_check_link", "contrib/iterative_collision_check_link.py")
+    icp = L("morefusion.contrib.iterative_closest_point_link", "contrib/iterative_closest_point_link.py")
+
+    import morefusion_amd.synthetic as synthetic
+    prev = np.load(os.path.join(OUT, "ref_cuda_links.npz"))
+    fx = [np.load(os.path.join(OUT, f"fixture_pose_refinement_{i:08d}.npz")) for i in range(3)]
+    res = {}
+    for n, off in ((1, 0.0), (3, 0.0), (3, 0.02), (8, 0.0), (8, 0.02)):
+        sc = synthetic.make_icc_scene(n, seed=0, fixtures=fx)
+        T.reset()
+        link = object.__new__(icc.IterativeCollisionCheckLink)
+        link._voxel_dim, link._voxel_threshold, link._sdf_offset = 32, 2, off
+        link.quaternion = T.Variable(prev[f"icc_q_n{n}"].copy(), requires_grad=True)
+        link.translation = T.Variable(prev[f"icc_t_n{n}"].copy(), requires_grad=True)
+        loss = link.forward([p.astype(np.float32) for p in sc["points"]], [v.astype(np.float32) for v in sc["sdf"]],
+                            [np.float32(v) for v in sc["pitch"]], [o.astype(np.float32) for o in sc["origin"]],
+                            np.stack(sc["grid_target"]).astype(np.float32),
+                            np.stack(sc["grid_nontarget_empty"]).astype(np.float32))
+        assert np.float32(loss.array) == prev[f"icc_loss_n{n}_off{off}"], (loss.array, prev[f"icc_loss_n{n}_off{off}"])
+        loss.backward()
+        res[f"icc_gq_n{n}_off{off}"] = link.quaternion.grad.astype(np.float32)
+        res[f"icc_gt_n{n}_off{off}"] = link.translation.grad.astype(np.float32)
+    T.reset()
+    f2 = fx[2]
+    target = (np.argwhere(f2["grid_target"] >= 0.5) * f2["pitch"] + f2["origin"]).astype(np.float32)
+    link = object.__new__(icp.IterativeClosestPointLink)
+    link.quaternion = T.Variable(prev["icp_q"].copy(), requires_grad=True)
+    link.translation = T.Variable(prev["icp_t"].copy(), requires_grad=True)
+    loss = link.forward(f2["pcd_cad"].astype(np.float32), target)
+    assert np.float32(loss.array) == prev["icp_loss"], (loss.array, prev["icp_loss"])
+    loss.backward()
+    res["icp_gq"], res["icp_gt"] = link.quaternion.grad.astype(np.float32), link.translation.grad.astype(np.float32)
+    T.reset()
+    np.savez_compressed(os.path.join(OUT, "ref_cuda_link_gradients.npz"), **res)
+    print({k: np.round(v, 5).tolist() if v.size <= 7 else v.shape for k, v in res.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if "--gradients-only" not in sys.argv:
+        main()
+    main_gradients()

@@ -15,10 +15,11 @@ restatement is pinned against golden vectors produced by EXECUTING THAT TEXT: th
 strings compiled by g++ and run sequentially, the Python around them run on NumPy
 (``oracle/cuda_text.py`` + ``oracle/gen_golden_cuda.py`` -> ``tests/golden/ref_cuda_*.npz``,
 ``tests/test_oracle_vs_reference_cuda_text.py``): distances, winner indices and
-pseudo-occupancy grids bit-exact, losses to float32 rounding.  Still **parity unpinned**
-(third party, absent here): chainer's autograd through the links (their gradients are checked
-against finite differences and the independent C restatement instead), chainer's Adam,
-trimesh's quaternion_from_matrix, cv2 / imgviz resizing.
+pseudo-occupancy grids bit-exact, losses to float32 rounding; the links' GRADIENTS against the
+reference's own ``Function.backward`` methods run under a reverse-mode tape that restates only
+chainer's elementary rules (``oracle/chainer_tape.py``).  Still **parity unpinned** (third party,
+absent here): chainer's Adam, trimesh's quaternion_from_matrix, cv2 / imgviz resizing (DESIGN.md
+section 3).
 
 ``mode`` selects between the reference's two semantic forks:
   "cpu": what ``forward_cpu`` does (NumPy promotion, round-half-even, floor)

@@ -18,6 +18,12 @@ def dev(x):
     return torch.as_tensor(np.ascontiguousarray(x)).cuda()
 
 
+def _close(got, want, rel=2e-4):
+    """Gradient vectors: float32 sums of ~10^4 terms in different orders."""
+    want = np.asarray(want, np.float64)
+    np.testing.assert_allclose(np.asarray(got, np.float64), want, rtol=1e-3, atol=rel * float(np.abs(want).max()))
+
+
 @pytest.mark.parametrize("tag", ["d32_t1", "d32_t2", "d32_t3", "d8x12x10_t2"])
 def test_tdf_hip_vs_reference_cuda_text(tag):
     g = golden("ref_cuda_tdf.npz")
@@ -70,8 +76,13 @@ def test_icc_link_loss_hip_vs_reference(n, off, fixtures3):
     args = ([dev(p) for p in sc["points"]], [dev(s) for s in sc["sdf"]], dev(np.asarray(sc["pitch"], np.float32)),
             dev(np.stack(sc["origin"]).astype(np.float32)), dev(np.stack(sc["grid_target"]).astype(np.float32)),
             dev(np.stack(sc["grid_nontarget_empty"]).astype(np.float32)))
-    loss = float(link(*args).detach())
-    np.testing.assert_allclose(loss, float(g[f"icc_loss_n{n}_off{off}"]), rtol=2e-5, atol=2e-6)
+    loss_t = link(*args)
+    np.testing.assert_allclose(float(loss_t.detach()), float(g[f"icc_loss_n{n}_off{off}"]), rtol=2e-5, atol=2e-6)
+    # gradients: the reference's own backward methods, run (oracle/chainer_tape.py + cuda_text.py)
+    gg = golden("ref_cuda_link_gradients.npz")
+    loss_t.backward()
+    _close(link.quaternion.grad.cpu().numpy(), gg[f"icc_gq_n{n}_off{off}"])
+    _close(link.translation.grad.cpu().numpy(), gg[f"icc_gt_n{n}_off{off}"])
 
 
 def test_icp_link_loss_hip_vs_reference(fixtures3):
@@ -82,8 +93,12 @@ def test_icp_link_loss_hip_vs_reference(fixtures3):
     with torch.no_grad():
         link.quaternion.copy_(dev(g["icp_q"]))
         link.translation.copy_(dev(g["icp_t"]))
-    np.testing.assert_allclose(float(link(dev(f["pcd_cad"].astype(np.float32)), target).detach()),
-                               float(g["icp_loss"]), rtol=2e-5)
+    loss_t = link(dev(f["pcd_cad"].astype(np.float32)), target)
+    np.testing.assert_allclose(float(loss_t.detach()), float(g["icp_loss"]), rtol=2e-5)
+    gg = golden("ref_cuda_link_gradients.npz")
+    loss_t.backward()
+    _close(link.quaternion.grad.cpu().numpy(), gg["icp_gq"])
+    _close(link.translation.grad.cpu().numpy(), gg["icp_gt"])
 
 
 def test_voxelization_hip_vs_reference_cuda_text():

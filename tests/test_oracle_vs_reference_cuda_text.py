@@ -120,3 +120,43 @@ def test_voxelization_gpu_forms_vs_reference_cuda_text():
     # the CPU fork (round-half-even) differs on the exact halves: the fork is real
     _, c_cpu = O.average_voxelization_3d(g["values"], g["points"], g["batch_indices"], mode="cpu", **kw)
     assert (c_cpu != g["avg_counts"]).any()
+
+
+def _close(got, want, rel=2e-4):
+    """Gradient vectors: float32 sums of ~10^4 terms in different orders."""
+    want = np.asarray(want, np.float64)
+    np.testing.assert_allclose(np.asarray(got, np.float64), want, rtol=1e-3, atol=rel * float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("n,off", [(1, 0.0), (3, 0.0), (3, 0.02), (8, 0.0), (8, 0.02)])
+def test_icc_link_gradients_vs_reference_backward(n, off, fixtures3):
+    """d loss / d (quaternion, translation) of the ICC link obtained by RUNNING the reference: its own
+    Function.backward methods (QuaternionMatrix, ComposeTransform, the CUDA text of the TDF backward)
+    composed by oracle/chainer_tape.py (chainer's elementary rules; maximum ties -> first argument)."""
+    import morefusion_amd.synthetic as synthetic
+    g, gg = golden("ref_cuda_links.npz"), golden("ref_cuda_link_gradients.npz")
+    sc = synthetic.make_icc_scene(n, seed=0, fixtures=fixtures3)
+    args = (sc["points"], sc["sdf"], sc["pitch"], sc["origin"], np.stack(sc["grid_target"]),
+            np.stack(sc["grid_nontarget_empty"]).astype(np.float32))
+    q, t = g[f"icc_q_n{n}"], g[f"icc_t_n{n}"]
+    want_q, want_t = gg[f"icc_gq_n{n}_off{off}"], gg[f"icc_gt_n{n}_off{off}"]
+    assert np.abs(want_t).max() > 0.1
+    _, (gq, gt, _aux) = O.icc_loss(*args, q, t, sdf_offset=off, grad=True)
+    _close(gq, want_q)
+    _close(gt, want_t)
+    out_c = OC.icc_loss_grad(*args, q, t, sdf_offset=off)
+    _close(out_c[1], want_q)
+    _close(out_c[2], want_t)
+
+
+def test_icp_link_gradient_vs_reference_backward(fixtures3):
+    g, gg = golden("ref_cuda_links.npz"), golden("ref_cuda_link_gradients.npz")
+    f = fixtures3[2]
+    target = (np.argwhere(f["grid_target"] >= 0.5) * f["pitch"] + f["origin"]).astype(np.float32)
+    source = f["pcd_cad"].astype(np.float32)
+    _, (gq, gt) = O.icp_loss(source, target, g["icp_q"], g["icp_t"], grad=True)
+    _close(gq, gg["icp_gq"])
+    _close(gt, gg["icp_gt"])
+    out_c = OC.icp_loss_grad(source, target, g["icp_q"], g["icp_t"])
+    _close(out_c[1], gg["icp_gq"])
+    _close(out_c[2], gg["icp_gt"])
