@@ -23,11 +23,13 @@ Reference files executed (under /root/reference/morefusion):
       (forward, T), with functions/geometry/{transformation_matrix, quaternion_matrix,
       translation_matrix, compose_transform, transform_points}.py underneath
 
-Not pinned by this (third party, absent): chainer's autograd through the links (their gradients),
-chainer.optimizers.Adam, trimesh.quaternion_from_matrix (the links are built around their
-``__init__``: quaternion / translation are set directly).
+Second pass (``main_gradients``): the links' gradients, by re-running the same reference code under
+``oracle/chainer_tape.py`` and calling the reference's own ``backward`` / ``backward_gpu`` methods.
 
-Usage:  python oracle/gen_golden_cuda.py   (writes tests/golden/ref_cuda_*.npz)
+Not pinned by this (third party, absent): chainer.optimizers.Adam, trimesh.quaternion_from_matrix
+(the links are built around their ``__init__``: quaternion / translation are set directly).
+
+Usage:  python oracle/gen_golden_cuda.py [--gradients-only]   (writes tests/golden/ref_cuda_*.npz)
 """
 import os
 import sys
