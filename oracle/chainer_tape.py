@@ -167,6 +167,12 @@ def F_sum(x, axis=None, keepdims=False):
     return _op(np.sum(a, axis=axis, keepdims=keepdims), [x], bwd)
 
 
+def F_mean(x, axis=None):
+    a = unwrap(x)
+    n = a.size if axis is None else a.shape[axis]
+    return F_sum(x, axis=axis) / a.dtype.type(n)
+
+
 def F_sqrt(x):
     y = np.sqrt(unwrap(x))
     return _op(y, [x], lambda g: (g / (2 * y),))

@@ -310,6 +310,39 @@ def main_gradients():
     loss.backward()
     res["icp_gq"], res["icp_gt"] = link.quaternion.grad.astype(np.float32), link.translation.grad.astype(np.float32)
     T.reset()
+
+    # ---- A12: functions.loss.average_distance, ADD and ADD-S (nn = the RawKernel text), values and
+    # the gradient to the predicted transforms
+    F.mean = T.F_mean
+    nn = L("morefusion.geometry.knn.nn", "geometry/knn/nn.py")
+    gm = sys.modules["morefusion.geometry"]
+    gm.nn = nn.nn_gpu  # what a GPU run dispatches to (arrays here are NumPy)
+    sys.modules["morefusion"].geometry = gm
+    sys.modules[g].transform_points = tp.transform_points
+    ad = L("morefusion.functions.loss.average_distance", "functions/loss/average_distance.py")
+    from oracle import oracle_np as O
+    rs = np.random.RandomState(7)
+    M, P = 500, 48
+    pts = rs.uniform(-0.06, 0.06, (M, 3)).astype(np.float32)
+    pts[10] = pts[3]                                  # duplicate model point: an exact nn tie
+    qt = rs.normal(size=4); qt /= np.linalg.norm(qt)
+    T_true = O.transformation_matrix(qt[None].astype(np.float32), np.array([[0.1, -0.05, 0.7]], np.float32))[0]
+    qp = qt[None] + rs.normal(0, 0.08, (P, 4)); qp /= np.linalg.norm(qp, axis=1, keepdims=True)
+    tpred = np.array([0.1, -0.05, 0.7]) + rs.normal(0, 0.01, (P, 3))
+    T_pred = O.transformation_matrix(qp.astype(np.float32), tpred.astype(np.float32))
+    out = dict(points=pts, transform_true=T_true.astype(np.float32), transforms_pred=T_pred.astype(np.float32))
+    for sym in (False, True):
+        T.reset()
+        Tp = T.Variable(T_pred.astype(np.float32), requires_grad=True)
+        val = ad.average_distance(pts, T.Variable(T_true.astype(np.float32)), Tp, symmetric=sym)
+        gout = rs.uniform(0.5, 1.5, P).astype(np.float32)
+        total = T.F_sum(val * gout)
+        total.backward()
+        tag = "adds" if sym else "add"
+        out[f"{tag}_value"], out[f"{tag}_gout"], out[f"{tag}_gT"] = val.array, gout, Tp.grad
+    T.reset()
+    np.savez_compressed(os.path.join(OUT, "ref_cuda_average_distance.npz"), **out)
+    print("average_distance:", out["add_value"][:3], out["adds_value"][:3])
     np.savez_compressed(os.path.join(OUT, "ref_cuda_link_gradients.npz"), **res)
     print({k: np.round(v, 5).tolist() if v.size <= 7 else v.shape for k, v in res.items()})
 

@@ -118,3 +118,18 @@ def test_voxelization_hip_vs_reference_cuda_text():
     np.testing.assert_array_equal(ym.detach().cpu().numpy(), g["max_matrix"])
     ym.backward(dev(g["gy"]))
     np.testing.assert_allclose(values.grad.cpu().numpy(), g["max_gvalues"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("sym", [False, True])
+def test_average_distance_hip_vs_reference(sym):
+    """ADD / ADD-S loss and its gradient to the predicted transforms against the reference's own
+    average_distance run on the CPU (nn = the RawKernel text; backward through oracle/chainer_tape.py)."""
+    g = golden("ref_cuda_average_distance.npz")
+    tag = "adds" if sym else "add"
+    Tp = dev(g["transforms_pred"]).requires_grad_(True)
+    out = F.average_distance(dev(g["points"]), dev(g["transform_true"]), Tp, symmetric=sym)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"{tag}_value"], rtol=5e-6, atol=1e-8)
+    (out * dev(g[f"{tag}_gout"])).sum().backward()
+    want = g[f"{tag}_gT"][:, :3, :]            # the bottom row of a rigid transform is constant
+    got = Tp.grad.cpu().numpy()[:, :3, :]
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 * float(np.abs(want).max()))

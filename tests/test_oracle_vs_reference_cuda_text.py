@@ -160,3 +160,11 @@ def test_icp_link_gradient_vs_reference_backward(fixtures3):
     out_c = OC.icp_loss_grad(source, target, g["icp_q"], g["icp_t"])
     _close(out_c[1], gg["icp_gq"])
     _close(out_c[2], gg["icp_gt"])
+
+
+@pytest.mark.parametrize("sym", [False, True])
+def test_average_distance_vs_reference(sym):
+    """functions/loss/average_distance.py:40-85 executed (ADD-S through the RawKernel nn text)."""
+    g = golden("ref_cuda_average_distance.npz")
+    out = O.average_distance(g["points"], g["transform_true"], g["transforms_pred"], symmetric=sym)
+    np.testing.assert_allclose(out, g["adds_value" if sym else "add_value"], rtol=2e-6, atol=1e-8)
