@@ -29,7 +29,7 @@ def _unb(g, shape):
 
 class Variable:
     __array_ufunc__ = None
-    _tape = []  # creation-ordered list of (output, inputs, backward_fn)
+    _tape = []  # creation-ordered list of (outputs tuple, inputs, backward_fn)
 
     def __init__(self, array, requires_grad=False):
         self.array = np.asarray(array)
@@ -109,10 +109,11 @@ class Variable:
     def backward(self):
         """Reverse sweep from this (scalar) variable; fills ``.grad`` of every variable on the tape."""
         self.grad = np.ones_like(self.array)
-        for out, inputs, bwd in reversed(Variable._tape):
-            if out.grad is None:
+        for outs, inputs, bwd in reversed(Variable._tape):
+            if all(o.grad is None for o in outs):
                 continue
-            grads = bwd(out.grad)
+            gys = tuple(o.grad if o.grad is not None else np.zeros_like(o.array) for o in outs)
+            grads = bwd(gys[0]) if len(outs) == 1 else bwd(gys)
             for v, g in zip(inputs, grads):
                 if g is None or not isinstance(v, Variable):
                     continue
@@ -130,7 +131,7 @@ def unwrap(x):
 
 def _op(value, inputs, bwd):
     out = Variable(value)
-    Variable._tape.append((out, inputs, bwd))
+    Variable._tape.append(((out,), inputs, bwd))
     return out
 
 
@@ -217,6 +218,29 @@ def F_maximum(a, b):
     return _op(np.maximum(av, bv), [a, b], lambda g: (np.where(cond, g, 0), np.where(cond, 0, g)))
 
 
+def F_min(x, axis=None):
+    a = np.asarray(unwrap(x))
+    y = np.min(a, axis=axis)
+    cond = a == (y if axis is None else np.expand_dims(y, axis))  # chainer's SelectorBase: every tied position
+
+    def bwd(g):
+        g = np.asarray(g)
+        return ((g if axis is None else np.expand_dims(g, axis)) * cond,)
+
+    return _op(y, [x], bwd)
+
+
+def F_relu(x):
+    a = np.asarray(unwrap(x))
+    return _op(np.maximum(a, 0), [x], lambda g: (g * (a > 0),))
+
+
+def F_minimum(a, b):
+    av, bv = np.asarray(unwrap(a)), np.asarray(unwrap(b))
+    cond = av <= bv  # chainer/functions/math/minimum.py: ties go to x1
+    return _op(np.minimum(av, bv), [a, b], lambda g: (np.where(cond, g, 0), np.where(cond, 0, g)))
+
+
 def F_argmin(x, axis=None):
     return Variable(np.argmin(unwrap(x), axis=axis))
 
@@ -237,19 +261,14 @@ class Function:
         arrays = tuple(np.asarray(unwrap(x)) for x in inputs)
         outs = self._pick("forward")(arrays)
         fn = self
+        vs = tuple(Variable(o) for o in outs)
 
-        def make_bwd(n_out, idx):
-            def bwd(g):
-                gys = [None] * n_out
-                gys[idx] = g
-                res = fn._pick("backward")(arrays, tuple(gys))
-                return tuple(res)
-            return bwd
+        def bwd(gys):  # ONE call with the gradients of all outputs, like chainer
+            gys = gys if isinstance(gys, tuple) else (gys,)
+            return tuple(fn._pick("backward")(arrays, gys))
 
-        vs = []
-        for i, o in enumerate(outs):
-            vs.append(_op(o, list(inputs), make_bwd(len(outs), i)))
-        return vs[0] if len(vs) == 1 else tuple(vs)
+        Variable._tape.append((vs, list(inputs), bwd))
+        return vs[0] if len(vs) == 1 else vs
 
     def retain_inputs(self, idx):
         pass

@@ -19,6 +19,8 @@ Reference files executed (under /root/reference/morefusion):
   functions/geometry/interpolate_voxel_grid.py (forward_gpu, backward_gpu)
   functions/geometry/average_voxelization_3d.py, max_voxelization_3d.py (forward_gpu, backward_gpu)
   geometry/knn/nn.py (nn_gpu) + geometry/knn/cuComputeDistanceGlobal.cu
+  contrib/occupancy_registration.py (OccupancyRegistrationLink.forward), functions/geometry/occupancy_grid_3d.py,
+  functions/loss/average_distance.py,
   contrib/iterative_collision_check_link.py (forward), contrib/iterative_closest_point_link.py
       (forward, T), with functions/geometry/{transformation_matrix, quaternion_matrix,
       translation_matrix, compose_transform, transform_points}.py underneath
@@ -343,6 +345,35 @@ def main_gradients():
     T.reset()
     np.savez_compressed(os.path.join(OUT, "ref_cuda_average_distance.npz"), **out)
     print("average_distance:", out["add_value"][:3], out["adds_value"][:3])
+    # ---- (f3) OccupancyRegistrationLink: loss + gradients at a non-trivial pose (16^3 grid)
+    F.min, F.relu, F.minimum = T.F_min, T.F_relu, T.F_minimum
+    occ = L(g + ".occupancy_grid_3d", "functions/geometry/occupancy_grid_3d.py")
+    qm = sys.modules[g + ".quaternion_matrix"]
+    ct = sys.modules[g + ".compose_transform"]
+    fm.quaternion_matrix, fm.compose_transform = qm.quaternion_matrix, ct.compose_transform
+    fm.occupancy_grid_3d = occ.occupancy_grid_3d
+    oreg = L("morefusion.contrib.occupancy_registration", "contrib/occupancy_registration.py")
+    rs = np.random.RandomState(0)
+    pitch, dim, origin = np.float32(0.01), 16, np.array([-0.075, -0.075, -0.075], np.float32)
+    model = rs.uniform(-0.03, 0.03, (300, 3)).astype(np.float32)
+    qg = np.array([0.98, 0.1, -0.12, 0.08]); qg /= np.linalg.norm(qg)
+    T_gt = O.transformation_matrix(qg[None].astype(np.float32), np.array([[0.01, -0.005, 0.008]], np.float32))[0]
+    T.reset()
+    tgt = occ.occupancy_grid_3d(O.transform_points(model, T_gt).astype(np.float32), pitch=pitch, origin=origin,
+                                dims=(dim,) * 3, threshold=1.5).array
+    grid_target = np.stack([(tgt > 0.3), (tgt == 0)]).astype(np.float32)
+    q0 = np.array([0.995, 0.05, 0.03, -0.04], np.float32); q0 /= np.linalg.norm(q0)
+    t0 = np.array([0.002, 0.001, -0.003], np.float32)
+    T.reset()
+    link = object.__new__(oreg.OccupancyRegistrationLink)
+    link.quaternion = T.Variable(q0.astype(np.float32), requires_grad=True)
+    link.translation = T.Variable(t0, requires_grad=True)
+    loss = link.forward(model, grid_target, pitch=pitch, origin=origin, threshold=1.5)
+    loss.backward()
+    res.update(occreg_model=model, occreg_grid_target=grid_target, occreg_pitch=pitch, occreg_origin=origin,
+               occreg_q=q0.astype(np.float32), occreg_t=t0, occreg_loss=np.float32(loss.array),
+               occreg_gq=link.quaternion.grad.astype(np.float32), occreg_gt=link.translation.grad.astype(np.float32))
+    T.reset()
     np.savez_compressed(os.path.join(OUT, "ref_cuda_link_gradients.npz"), **res)
     print({k: np.round(v, 5).tolist() if v.size <= 7 else v.shape for k, v in res.items()})
 

@@ -133,3 +133,17 @@ def test_average_distance_hip_vs_reference(sym):
     want = g[f"{tag}_gT"][:, :3, :]            # the bottom row of a rigid transform is constant
     got = Tp.grad.cpu().numpy()[:, :3, :]
     np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 * float(np.abs(want).max()))
+
+
+def test_occupancy_registration_link_hip_vs_reference():
+    """(f3) contrib/occupancy_registration.py:21-60 executed from the reference (its OccupancyGrid3D
+    forward / backward, QuaternionMatrix / ComposeTransform backward, under oracle/chainer_tape.py):
+    loss and gradients of the HIP-backed link at the same pose."""
+    g = golden("ref_cuda_link_gradients.npz")
+    link = mf.contrib.OccupancyRegistrationLink(g["occreg_q"], g["occreg_t"]).to_gpu()
+    loss = link(dev(g["occreg_model"]), dev(g["occreg_grid_target"]), pitch=float(g["occreg_pitch"]),
+                origin=tuple(g["occreg_origin"]), threshold=1.5)
+    np.testing.assert_allclose(float(loss.detach()), float(g["occreg_loss"]), rtol=2e-5, atol=2e-6)
+    loss.backward()
+    _close(link.quaternion.grad.cpu().numpy(), g["occreg_gq"])
+    _close(link.translation.grad.cpu().numpy(), g["occreg_gt"])

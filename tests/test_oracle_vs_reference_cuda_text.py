@@ -168,3 +168,21 @@ def test_average_distance_vs_reference(sym):
     g = golden("ref_cuda_average_distance.npz")
     out = O.average_distance(g["points"], g["transform_true"], g["transforms_pred"], symmetric=sym)
     np.testing.assert_allclose(out, g["adds_value" if sym else "add_value"], rtol=2e-6, atol=1e-8)
+
+
+def test_occupancy_registration_link_vs_reference():
+    """(f3) the oracle's occupancy_grid_3d forward / backward chained like
+    contrib/occupancy_registration.py:21-60 against the reference link, executed."""
+    g = golden("ref_cuda_link_gradients.npz")
+    model, gt = g["occreg_model"], g["occreg_grid_target"]
+    pitch, origin = float(g["occreg_pitch"]), tuple(g["occreg_origin"])
+    T = O.transformation_matrix(g["occreg_q"], g["occreg_t"])
+    pw = O.transform_points(model, T)
+    grid = O.occupancy_grid_3d(pw, pitch=pitch, origin=origin, dims=gt.shape[1:], threshold=1.5)
+    occd, unocc = gt[0], gt[1]
+    loss = (unocc * grid).sum() / grid.sum() - (occd * grid).sum() / occd.sum()
+    np.testing.assert_allclose(loss, float(g["occreg_loss"]), rtol=2e-5, atol=2e-6)
+    gg = unocc / grid.sum() - (unocc * grid).sum() / grid.sum() ** 2 - occd / occd.sum()
+    gp = O.occupancy_grid_3d_backward(gg.astype(np.float32), pw, pitch=pitch, origin=origin, dims=gt.shape[1:],
+                                      threshold=1.5)
+    _close(gp.sum(axis=0), g["occreg_gt"])  # d loss / d translation = sum of the point gradients
