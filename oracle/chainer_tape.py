@@ -54,6 +54,8 @@ class Variable:
         shape = self.array.shape
         dt = self.array.dtype
 
+        if isinstance(k, np.ndarray) and k.dtype == bool:  # boolean mask -> integer indices
+            k = np.nonzero(k)
         kk = k if isinstance(k, tuple) else (k,)
         advanced = any(isinstance(i, (np.ndarray, list)) for i in kk)
 
@@ -172,6 +174,11 @@ def F_mean(x, axis=None):
     a = unwrap(x)
     n = a.size if axis is None else a.shape[axis]
     return F_sum(x, axis=axis) / a.dtype.type(n)
+
+
+def F_log(x):
+    a = np.asarray(unwrap(x))
+    return _op(np.log(a), [x], lambda g: (g / a,))
 
 
 def F_sqrt(x):

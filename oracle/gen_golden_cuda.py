@@ -19,6 +19,7 @@ Reference files executed (under /root/reference/morefusion):
   functions/geometry/interpolate_voxel_grid.py (forward_gpu, backward_gpu)
   functions/geometry/average_voxelization_3d.py, max_voxelization_3d.py (forward_gpu, backward_gpu)
   geometry/knn/nn.py (nn_gpu) + geometry/knn/cuComputeDistanceGlobal.cu
+  contrib/singleview_3d/models/model.py (Model.loss), datasets/ycb_video/class_names.py,
   contrib/occupancy_registration.py (OccupancyRegistrationLink.forward), functions/geometry/occupancy_grid_3d.py,
   functions/loss/average_distance.py,
   contrib/iterative_collision_check_link.py (forward), contrib/iterative_closest_point_link.py
@@ -345,6 +346,62 @@ def main_gradients():
     T.reset()
     np.savez_compressed(os.path.join(OUT, "ref_cuda_average_distance.npz"), **out)
     print("average_distance:", out["add_value"][:3], out["adds_value"][:3])
+    # ---- A14: Model.loss (contrib/singleview_3d/models/model.py:377-434), the DenseFusion confidence
+    # loss over ADD / ADD-S, with its gradients to the per-point predictions.  The method is called
+    # unbound on a bare object (the Chain's __init__ builds the network, which is not needed here).
+    F.log = T.F_log
+    links = types.ModuleType("chainer.links")
+    sys.modules["chainer.links"] = links
+    chainer.links = links
+    chainer.Chain = chainer.Link
+    chainer.report = lambda *a, **k: None
+    cn = L("morefusion.datasets.ycb_video.class_names", "datasets/ycb_video/class_names.py")
+    ds = types.ModuleType("morefusion.datasets")
+    ds.ycb_video = types.SimpleNamespace(class_ids_symmetric=cn.class_ids_symmetric)
+    rs = np.random.RandomState(11)
+    cad = {c: rs.uniform(-0.05, 0.05, (500, 3)).astype(np.float32) for c in (2, 13)}
+
+    class _Models:
+        def get_pcd(self, class_id):
+            return cad[class_id]
+
+    ds.YCBVideoModels = _Models
+    sys.modules["morefusion.datasets"] = ds
+    sys.modules["morefusion"].datasets = ds
+    fm.average_distance = ad.average_distance
+    for pkg, sub in [("morefusion.contrib.singleview_3d", "contrib/singleview_3d"),
+                     ("morefusion.contrib.singleview_3d.models", "contrib/singleview_3d/models")]:
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(G.REF, sub)]
+        sys.modules[pkg] = m
+    mdl = L("morefusion.contrib.singleview_3d.models.model", "contrib/singleview_3d/models/model.py")
+    B, P = 2, 40
+    class_id = np.array([2, 13], np.int32)              # 13 (bowl) is symmetric: ADD-S
+    q_true = rs.normal(size=(B, 4)); q_true /= np.linalg.norm(q_true, axis=1, keepdims=True)
+    t_true = np.array([[0.05, 0.0, 0.7], [-0.1, 0.03, 0.65]])
+    q_pred = q_true[:, None] + rs.normal(0, 0.1, (B, P, 4)); q_pred /= np.linalg.norm(q_pred, axis=2, keepdims=True)
+    t_pred = t_true[:, None] + rs.normal(0, 0.01, (B, P, 3))
+    conf = rs.uniform(0.05, 1.0, (B, P)); conf[0, :3] = 0.0   # non-confident points are dropped (keep)
+    out = dict(class_id=class_id, quaternion_true=q_true.astype(np.float32), translation_true=t_true.astype(np.float32),
+               quaternion_pred=q_pred.astype(np.float32), translation_pred=t_pred.astype(np.float32),
+               confidence_pred=conf.astype(np.float32), cad_2=cad[2], cad_13=cad[13], seed=np.int64(4321))
+    for mode in ("add/add_s", "add"):
+        T.reset()
+        me = object.__new__(mdl.Model)
+        me.xp, me._loss = np, mode
+        qv = T.Variable(out["quaternion_pred"], requires_grad=True)
+        tv = T.Variable(out["translation_pred"], requires_grad=True)
+        cv = T.Variable(out["confidence_pred"], requires_grad=True)
+        np.random.seed(4321)                             # the CAD subsampling stream (model.py:411-414)
+        loss = mdl.Model.loss(me, class_id, out["quaternion_true"], out["translation_true"], qv, tv, cv)
+        loss.backward()
+        tag = mode.replace("/", "_")
+        out[f"{tag}__loss"] = np.float32(loss.array)
+        out[f"{tag}__gq"], out[f"{tag}__gt"], out[f"{tag}__gc"] = qv.grad, tv.grad, cv.grad
+    T.reset()
+    np.savez_compressed(os.path.join(OUT, "ref_cuda_model_loss.npz"), **out)
+    print("Model.loss:", out["add_add_s__loss"], out["add__loss"])
+
     # ---- (f3) OccupancyRegistrationLink: loss + gradients at a non-trivial pose (16^3 grid)
     F.min, F.relu, F.minimum = T.F_min, T.F_relu, T.F_minimum
     occ = L(g + ".occupancy_grid_3d", "functions/geometry/occupancy_grid_3d.py")

@@ -147,3 +147,27 @@ def test_occupancy_registration_link_hip_vs_reference():
     loss.backward()
     _close(link.quaternion.grad.cpu().numpy(), g["occreg_gq"])
     _close(link.translation.grad.cpu().numpy(), g["occreg_gt"])
+
+
+@pytest.mark.parametrize("mode", ["add/add_s", "add"])
+def test_model_loss_hip_vs_reference(mode):
+    """A14: contrib/singleview_3d/models/model.py:377-434 (Model.loss) executed from the reference
+    (per-object loop over its average_distance, nn = the RawKernel text) vs the batched fused loss of
+    this build: value and gradients to the per-point quaternions, translations and confidences."""
+    from morefusion_amd.contrib.singleview_3d.models import Model, PitchTableModels
+    g = golden("ref_cuda_model_loss.npz")
+    model = Model(n_fg_class=21, with_occupancy=True, loss=mode,
+                  models=PitchTableModels({2: g["cad_2"], 13: g["cad_13"]}))
+    q = dev(g["quaternion_pred"]).requires_grad_(True)
+    t = dev(g["translation_pred"]).requires_grad_(True)
+    c = dev(g["confidence_pred"]).requires_grad_(True)
+    np.random.seed(int(g["seed"]))
+    loss = model.loss(class_id=torch.as_tensor(g["class_id"]), quaternion_true=dev(g["quaternion_true"]),
+                      translation_true=dev(g["translation_true"]), quaternion_pred=q, translation_pred=t,
+                      confidence_pred=c)
+    tag = mode.replace("/", "_")
+    np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}__loss"]), rtol=1e-5)
+    loss.backward()
+    _close(q.grad.cpu().numpy(), g[f"{tag}__gq"], rel=5e-4)
+    _close(t.grad.cpu().numpy(), g[f"{tag}__gt"], rel=5e-4)
+    _close(c.grad.cpu().numpy(), g[f"{tag}__gc"], rel=5e-4)

@@ -186,3 +186,25 @@ def test_occupancy_registration_link_vs_reference():
     gp = O.occupancy_grid_3d_backward(gg.astype(np.float32), pw, pitch=pitch, origin=origin, dims=gt.shape[1:],
                                       threshold=1.5)
     _close(gp.sum(axis=0), g["occreg_gt"])  # d loss / d translation = sum of the point gradients
+
+
+def test_model_loss_add_host_logic_vs_reference():
+    """A14 on the CPU: Model.loss in 'add' mode (the plain-torch composite of the ADD loss, no HIP op
+    involved) against the reference's Model.loss executed under the tape -- value and gradients."""
+    import torch
+    from morefusion_amd.contrib.singleview_3d.models import Model, PitchTableModels
+    g = golden("ref_cuda_model_loss.npz")
+    model = Model(n_fg_class=21, with_occupancy=True, loss="add",
+                  models=PitchTableModels({2: g["cad_2"], 13: g["cad_13"]}))
+    q = torch.tensor(g["quaternion_pred"], requires_grad=True)
+    t = torch.tensor(g["translation_pred"], requires_grad=True)
+    c = torch.tensor(g["confidence_pred"], requires_grad=True)
+    np.random.seed(int(g["seed"]))
+    loss = model.loss(class_id=torch.as_tensor(g["class_id"]), quaternion_true=torch.tensor(g["quaternion_true"]),
+                      translation_true=torch.tensor(g["translation_true"]), quaternion_pred=q, translation_pred=t,
+                      confidence_pred=c)
+    np.testing.assert_allclose(float(loss.detach()), float(g["add__loss"]), rtol=1e-5)
+    loss.backward()
+    _close(q.grad.numpy(), g["add__gq"], rel=5e-4)
+    _close(t.grad.numpy(), g["add__gt"], rel=5e-4)
+    _close(c.grad.numpy(), g["add__gc"], rel=5e-4)
