@@ -260,7 +260,9 @@ class Model(nn.Module):
 
         fg_class_id = (class_id - 1).long()
         ar = torch.arange(B, device=dev)
-        rot = F.normalize(cls_rot[ar, fg_class_id], dim=1).transpose(1, 2)  # B4P -> BP4
+        rot = cls_rot[ar, fg_class_id]
+        # F.normalize of chainer (l2_normalization.py): x / (|x| + eps), eps = 1e-5 -- not torch's x / max(|x|, eps)
+        rot = (rot / (rot.norm(dim=1, keepdim=True) + 1e-5)).transpose(1, 2)  # B4P -> BP4
         trans = cls_trans[ar, fg_class_id].transpose(1, 2)  # B3P -> BP3
         conf = cls_conf[ar, fg_class_id]
         return rot, trans, conf
