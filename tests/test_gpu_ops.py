@@ -307,7 +307,8 @@ def test_model_predict_shapes_and_3d_part_vs_oracle():
     with torch.no_grad():
         rot, trans, conf = model.predict(**inputs)
         assert rot.shape == (2, 1000, 4) and trans.shape == (2, 1000, 3) and conf.shape == (2, 1000)
-        np.testing.assert_allclose(rot.norm(dim=2).cpu().numpy(), 1.0, atol=1e-5)
+        # chainer's F.normalize is x / (|x| + 1e-5): unit up to 1e-5 / |x| (random-init heads: |x| ~ 0.05)
+        np.testing.assert_allclose(rot.norm(dim=2).cpu().numpy(), 1.0, atol=2e-3)
         assert ((conf > 0) & (conf < 1)).all()
         # origin=None path: median - 15.5*pitch (model.py:202-205) == the synthetic origin
         r2, t2, c2 = model.predict(**{**inputs, "origin": None})

@@ -383,7 +383,8 @@ def test_predict_host_logic_decoder_modes_agree(monkeypatch):
             outs.append(model.predict(**inp))
     q, t, c = outs[0]
     assert q.shape == (1, 1000, 4) and t.shape == (1, 1000, 3) and c.shape == (1, 1000)
-    np.testing.assert_allclose(q.norm(dim=2).numpy(), 1.0, atol=1e-5)
+    # chainer's F.normalize is x / (|x| + 1e-5): unit up to 1e-5 / |x| (random-init heads: |x| ~ 0.05)
+    np.testing.assert_allclose(q.norm(dim=2).numpy(), 1.0, atol=2e-3)
     for other in outs[1:]:
         for a, b_ in zip(other, outs[0]):
             np.testing.assert_allclose(a.numpy(), b_.numpy(), rtol=0, atol=5e-6)
