@@ -263,7 +263,9 @@ inline void __syncthreads() {
   b.fib[b.cur].state = mf_emul::AT_BARRIER;
   mf_emul::yield_to_scheduler();
 }
-inline void __builtin_amdgcn_wave_barrier() {}
+// a real rendezvous of the wave's fibers (lanes run one after the other here: without it lane 0 would
+// read LDS slots its neighbours have not written yet)
+inline void __builtin_amdgcn_wave_barrier() { uint64_t act; (void)mf_emul::wave_exchange(0, &act); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 inline void __threadfence() {}
 inline unsigned long long wall_clock64() { return 0; }
@@ -303,6 +305,32 @@ template <class T> inline T __shfl_xor(T v, int m, int = 64) {
   return mf_emul_shfl(v, lane ^ m);
 }
 inline float __frsqrt_rn(float x) { return 1.0f / sqrtf(x); }
+// clang's ext_vector_type -> gcc's vector_size (element access v[i] and brace initialisers work alike)
+#define ext_vector_type(n) vector_size(4 * (n))
+typedef float mf_emul_f32x4 __attribute__((vector_size(16)));
+// v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] * B[k][j]; lane l supplies A[l % 16][l / 16] and
+// B[l / 16][l % 16] and holds D[4 * (l / 16) + r][l % 16] in element r (k in increasing order).
+inline mf_emul_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, mf_emul_f32x4 c, int, int, int) {
+  uint64_t act;
+  uint32_t ab, bb;
+  memcpy(&ab, &a, 4);
+  memcpy(&bb, &b, 4);
+  float A[64], B[64];
+  const uint64_t *all = mf_emul::wave_exchange(((uint64_t)ab << 32) | bb, &act);
+  for (int l = 0; l < 64; ++l) {
+    const uint32_t hi = (uint32_t)(all[l] >> 32), lo = (uint32_t)all[l];
+    memcpy(&A[l], &hi, 4);
+    memcpy(&B[l], &lo, 4);
+  }
+  const int lane = mf_emul::g_block.cur % 64, j = lane % 16;
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * (lane / 16) + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc += A[k * 16 + i] * B[k * 16 + j];
+    c[r] = acc;
+  }
+  return c;
+}
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }

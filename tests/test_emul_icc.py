@@ -188,3 +188,19 @@ def test_icc_kernel_source_fractional_no_entry_grid_takes_the_two_kernel_path(li
     np.testing.assert_allclose(loss[0], l_o, rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(gq, gq_o, rtol=2e-3, atol=2e-5)
     np.testing.assert_allclose(gt, gt_o, rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("n,off", [(3, 0.0), (3, 0.02)])
+def test_icc_kernel_source_vs_reference_link_executed(lib, fixtures3, sp, n, off):
+    """The ICC kernel text (both iteration layouts) against the REFERENCE's IterativeCollisionCheckLink,
+    executed: loss from its forward (K7 CUDA text underneath), gradients from its own backward methods
+    (tests/golden/ref_cuda_links.npz, ref_cuda_link_gradients.npz; oracle/gen_golden_cuda.py)."""
+    from conftest import golden
+    g, gg = golden("ref_cuda_links.npz"), golden("ref_cuda_link_gradients.npz")
+    sc = synthetic.make_icc_scene(n, seed=0, fixtures=fixtures3)
+    S = emul.EmulIccScenes(lib, [_dict(sc)], sdf_offset=off, single_pass=sp)
+    loss, gq, gt = S.loss_grad(g[f"icc_q_n{n}"], g[f"icc_t_n{n}"])
+    np.testing.assert_allclose(loss[0], float(g[f"icc_loss_n{n}_off{off}"]), rtol=2e-5, atol=2e-6)
+    wq, wt = gg[f"icc_gq_n{n}_off{off}"], gg[f"icc_gt_n{n}_off{off}"]
+    np.testing.assert_allclose(gq, wq, rtol=2e-3, atol=3e-4 * float(np.abs(wq).max()))
+    np.testing.assert_allclose(gt, wt, rtol=2e-3, atol=3e-4 * float(np.abs(wt).max()))

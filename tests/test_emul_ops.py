@@ -189,3 +189,152 @@ def test_valid_pixel_order_kernel_source_vs_numpy_where():
             assert counts[b] == len(want)
             np.testing.assert_array_equal(order[b, :len(want)], want)
             assert (order[b, len(want):] == -7).all()
+
+
+def test_sparse_conv3_kernel_sources_vs_dense_conv():
+    """sparseconv.hip on the host emulator (the fp32 MFMA builtin emulated lane-exactly in the shim):
+    points -> chains -> compact GEMM rows -> 8 parity-class MFMA GEMMs -> output-stationary reduce,
+    against a dense float64 k4 / s2 / p1 convolution of the oracle's average voxelization; the
+    dense-input entry point must give the same bits as the points-fed one."""
+    import torch
+    from oracle import oracle_np as O_
+    lib = emul.build(["sparseconv.hip"])
+    i64 = ctypes.c_int64
+    lib.mf_sparse_conv3d_workspace_bytes.restype = i64
+    lib.mf_sparse_conv3d_workspace_bytes.argtypes = [_i32] * 5 + [i64]
+    lib.mf_sparse_conv3d_pack_weights.argtypes = [_p, _i32, _i32, _i32, _i32, _p, _p]
+    lib.mf_sparse_conv3d_k4s2_points_fwd.argtypes = [_p, _p, _p, i64] + [ctypes.c_float] * 4 + [_p] * 5 + [_i32] * 6 + [_p]
+    lib.mf_sparse_conv3d_k4s2_fwd.argtypes = [_p] * 7 + [_i32] * 6 + [_p]
+    rs = np.random.RandomState(5)
+    B, Cs, Cout, D, n = 2, 8, 64, 8, 70
+    points = rs.uniform(-0.6, D - 0.4, (n, 3)).astype(np.float32)
+    points[:10] = points[10:20]                        # shared voxels: means over several points
+    values = rs.uniform(-1, 1, (n, Cs)).astype(np.float32)
+    bi = np.sort(rs.randint(0, B, n)).astype(np.int32)
+    W = (rs.uniform(-1, 1, (Cout, Cs + 3, 4, 4, 4)) * 0.2).astype(np.float32)   # conv weight with extra input channels
+    bias = rs.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    dense = rs.uniform(-0.1, 0.1, (B, Cout, D // 2, D // 2, D // 2)).astype(np.float32)
+    Wp = np.zeros(8 * Cs * 8 * Cout, np.float32)
+    assert lib.mf_sparse_conv3d_pack_weights(W.ctypes.data, Cout, Cs, Cs + 3, 2, Wp.ctypes.data, None) == 0
+    ws = np.zeros(int(lib.mf_sparse_conv3d_workspace_bytes(B, Cs, Cout, D, n, n)) // 4 + 64, np.float32)
+    out = np.full(dense.shape, 7.0, np.float32)
+    assert lib.mf_sparse_conv3d_k4s2_points_fwd(values.ctypes.data, points.ctypes.data, bi.ctypes.data, n, 0.0, 0.0, 0.0,
+                                                1.0, Wp.ctypes.data, dense.ctypes.data, bias.ctypes.data,
+                                                out.ctypes.data, ws.ctypes.data, B, Cs, Cout, D, n, 1, None) == 0
+    vox, counts = O_.average_voxelization_3d(values, points, bi, batch_size=B, origin=(0, 0, 0), pitch=1.0,
+                                             dimensions=(D, D, D), mode="gpu")
+    ref = torch.nn.functional.conv3d(torch.from_numpy(vox).double(), torch.from_numpy(W[:, 2:2 + Cs]).double(),
+                                     stride=2, padding=1).numpy()
+    ref = np.maximum(ref + dense + bias[None, :, None, None, None], 0)
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5)
+    assert (out > 0).mean() > 0.2
+    out2 = np.full(dense.shape, 7.0, np.float32)
+    ws2 = np.zeros_like(ws)
+    assert lib.mf_sparse_conv3d_k4s2_fwd(vox.ctypes.data, counts.ctypes.data, Wp.ctypes.data, dense.ctypes.data,
+                                         bias.ctypes.data, out2.ctypes.data, ws2.ctypes.data, B, Cs, Cout, D, n, 1,
+                                         None) == 0
+    np.testing.assert_array_equal(out2, out)
+
+
+def test_voxelize_kernel_sources_vs_reference_cuda_text():
+    """voxelize.hip (chains + wave-per-voxel ordered sums; 64-bit arg-max keys) on the host emulator,
+    directly against the output of the REFERENCE's CUDA text (tests/golden/ref_cuda_voxelization.npz):
+    average fwd + bwd and max fwd + bwd, bit-exact (round-half-away, intensity ties)."""
+    from conftest import golden
+    lib = emul.build(["voxelize.hip"])
+    i64, f = ctypes.c_int64, ctypes.c_float
+    lib.mf_average_voxelization_3d_fwd.argtypes = [_p, _p, _p, i64] + [ctypes.c_int] * 5 + [f] * 4 + [_p] * 6
+    lib.mf_average_voxelization_3d_bwd.argtypes = [_p, _p, _p, _p, i64] + [ctypes.c_int] * 5 + [f] * 4 + [_p, _p]
+    lib.mf_max_voxelization_3d_fwd.argtypes = [_p, _p, _p, _p, i64] + [ctypes.c_int] * 5 + [f] * 4 + [_p] * 5
+    lib.mf_max_voxelization_3d_bwd.argtypes = [_p, _p, i64] + [ctypes.c_int] * 5 + [_p, _p]
+    g = golden("ref_cuda_voxelization.npz")
+    D, B = int(g["dim"]), int(g["batch_size"])
+    values, points, bi = (np.ascontiguousarray(g[k]) for k in ("values", "points", "batch_indices"))
+    n, C = values.shape
+    o, pitch = [float(v) for v in g["origin"]], float(g["pitch"])
+    matrix = np.full((B, C, D, D, D), 9.0, np.float32)
+    counts = np.zeros((B, D, D, D), np.int32)
+    head = np.zeros(B * D ** 3, np.int32)
+    link = np.zeros(n, np.int32)
+    nan_flag = np.zeros(1, np.int32)
+    assert lib.mf_average_voxelization_3d_fwd(values.ctypes.data, points.ctypes.data, bi.ctypes.data, n, C, B, D, D, D,
+                                              *o, pitch, matrix.ctypes.data, counts.ctypes.data, head.ctypes.data,
+                                              link.ctypes.data, nan_flag.ctypes.data, None) == 0
+    np.testing.assert_array_equal(counts, g["avg_counts"])
+    np.testing.assert_array_equal(matrix, g["avg_matrix"])
+    assert nan_flag[0] == 0
+    gy = np.ascontiguousarray(g["gy"])
+    gv = np.full((n, C), 9.0, np.float32)
+    assert lib.mf_average_voxelization_3d_bwd(gy.ctypes.data, points.ctypes.data, bi.ctypes.data, counts.ctypes.data,
+                                              n, C, B, D, D, D, *o, pitch, gv.ctypes.data, None) == 0
+    np.testing.assert_array_equal(gv, g["avg_gvalues"])
+    inten = np.ascontiguousarray(g["intensities"])
+    mm = np.full((B, C, D, D, D), 9.0, np.float32)
+    ind = np.zeros((B, D, D, D), np.int32)
+    key = np.zeros(B * D ** 3, np.uint64)
+    assert lib.mf_max_voxelization_3d_fwd(values.ctypes.data, points.ctypes.data, bi.ctypes.data, inten.ctypes.data, n, C,
+                                          B, D, D, D, *o, pitch, mm.ctypes.data, ind.ctypes.data, key.ctypes.data,
+                                          nan_flag.ctypes.data, None) == 0
+    np.testing.assert_array_equal(ind, g["max_indices"])
+    np.testing.assert_array_equal(mm, g["max_matrix"])
+    mgv = np.zeros((n, C), np.float32)
+    assert lib.mf_max_voxelization_3d_bwd(gy.ctypes.data, ind.ctypes.data, n, C, B, D, D, D, mgv.ctypes.data, None) == 0
+    np.testing.assert_allclose(mgv, g["max_gvalues"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["d32_t2", "d32_t3", "d8x12x10_t2"])
+def test_tdf_kernel_sources_vs_reference_cuda_text(tag):
+    """tdf.hip (two-pass LDS (min, arg-min) tiles) on the host emulator against the reference's K7 / K8
+    text: distances and winner indices bit-exact, backward to float-atomic tolerance."""
+    from conftest import golden
+    lib = emul.build(["tdf.hip"])
+    i64, f, ci = ctypes.c_int64, ctypes.c_float, ctypes.c_int
+    lib.mf_truncated_distance_function_fwd.argtypes = [_p, i64, f, f, f, f, ci, ci, ci, f, _p, _p, _p]
+    lib.mf_truncated_distance_function_bwd.argtypes = [_p, _p, _p, i64, f, f, f, f, ci, ci, ci, f, _p, _p]
+    g = golden("ref_cuda_tdf.npz")
+    c = {k.split("__", 1)[1]: g[k] for k in g if k.startswith(tag + "__")}
+    X, Y, Z = (int(v) for v in c["dims"])
+    pts = np.ascontiguousarray(c["points"])
+    o = [float(v) for v in c["origin"]]
+    tdf = np.zeros((X, Y, Z), np.float32)
+    flat = np.zeros((X, Y, Z), np.int32)
+    assert lib.mf_truncated_distance_function_fwd(pts.ctypes.data, len(pts), float(c["pitch"]), *o, X, Y, Z,
+                                                  float(c["truncation"]), tdf.ctypes.data, flat.ctypes.data, None) == 0
+    np.testing.assert_array_equal(tdf, c["matrix"])
+    np.testing.assert_array_equal(flat, c["indices"])
+    gm = np.ascontiguousarray(c["gmatrix"])
+    gp = np.zeros_like(pts)
+    assert lib.mf_truncated_distance_function_bwd(gm.ctypes.data, pts.ctypes.data, flat.ctypes.data, len(pts),
+                                                  float(c["pitch"]), *o, X, Y, Z, float(c["truncation"]),
+                                                  gp.ctypes.data, None) == 0
+    np.testing.assert_allclose(gp, c["gpoints"], rtol=2e-5, atol=2e-6)
+
+
+def test_nn_and_interpolate_kernel_sources_vs_reference_cuda_text():
+    """k_nn (occgrid_knn.hip) against the reference's RawKernel + argmin, and interp.hip forward /
+    backward against its K5 / K6 text (tests/golden/ref_cuda_nn.npz, ref_cuda_interpolate.npz)."""
+    from conftest import golden
+    i64, ci = ctypes.c_int64, ctypes.c_int
+    lib = emul.build(["occgrid_knn.hip"])
+    lib.mf_nn.argtypes = [_p, i64, _p, i64, _p, _p, _p]
+    g = golden("ref_cuda_nn.npz")
+    ref, query = np.ascontiguousarray(g["ref"]), np.ascontiguousarray(g["query"])
+    out = np.zeros(len(query), np.int64)
+    assert lib.mf_nn(ref.ctypes.data, len(ref), query.ctypes.data, len(query), out.ctypes.data, None, None) == 0
+    np.testing.assert_array_equal(out, g["indices"])
+    lib = emul.build(["interp.hip"])
+    lib.mf_interpolate_voxel_grid_fwd.argtypes = [_p, _p, _p, _p, i64] + [ci] * 5 + [_p, ci, _p]
+    lib.mf_interpolate_voxel_grid_bwd.argtypes = [_p, _p, _p, _p, i64] + [ci] * 5 + [_p, ci, _p]
+    g = golden("ref_cuda_interpolate.npz")
+    vox, pts, bi = (np.ascontiguousarray(g[k]) for k in ("voxelized", "points", "batch_indices"))
+    B, C, X = vox.shape[0], vox.shape[1], vox.shape[2]
+    n = len(pts)
+    vals = np.full((n, C), 3.0, np.float32)
+    assert lib.mf_interpolate_voxel_grid_fwd(vox.ctypes.data, pts.ctypes.data, bi.ctypes.data, None, n, B, C, X, X, X,
+                                             vals.ctypes.data, 0, None) == 0
+    np.testing.assert_array_equal(vals, g["values"])
+    gv = np.ascontiguousarray(g["gvalues"])
+    gvox = np.full(vox.shape, 3.0, np.float32)
+    assert lib.mf_interpolate_voxel_grid_bwd(gv.ctypes.data, pts.ctypes.data, bi.ctypes.data, None, n, B, C, X, X, X,
+                                             gvox.ctypes.data, 0, None) == 0
+    np.testing.assert_allclose(gvox, g["gvoxelized"], rtol=1e-5, atol=1e-6)
