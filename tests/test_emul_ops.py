@@ -338,3 +338,46 @@ def test_nn_and_interpolate_kernel_sources_vs_reference_cuda_text():
     assert lib.mf_interpolate_voxel_grid_bwd(gv.ctypes.data, pts.ctypes.data, bi.ctypes.data, None, n, B, C, X, X, X,
                                              gvox.ctypes.data, 0, None) == 0
     np.testing.assert_allclose(gvox, g["gvoxelized"], rtol=1e-5, atol=1e-6)
+
+
+def test_occupancy_grid_and_loss_kernel_sources_vs_reference_outputs():
+    """occupancy_grid_3d kernel text against the reference's known-answer grid and BASELINE config 1
+    (tests/golden/ref_occupancy_grid_3d.npz, produced by the reference's NumPy code), and the fused
+    ADD / ADD-S loss kernels (loss.hip) against the reference's average_distance executed
+    (ref_cuda_average_distance.npz: values + gradient to the predicted transforms)."""
+    from conftest import golden
+    i64, f, ci = ctypes.c_int64, ctypes.c_float, ctypes.c_int
+    lib = emul.build(["occgrid_knn.hip"])
+    lib.mf_occupancy_grid_3d_fwd.argtypes = [_p, i64, f, f, f, f, ci, ci, ci, f, _p, _p, _p]
+    g = golden("ref_occupancy_grid_3d.npz")
+    pts = np.ascontiguousarray(g["known_points"])
+    grid, dmin = np.zeros((5, 5, 5), np.float32), np.zeros((5, 5, 5), np.float32)
+    assert lib.mf_occupancy_grid_3d_fwd(pts.ctypes.data, len(pts), 1.0, 0.0, 0.0, 0.0, 5, 5, 5, 1.0, grid.ctypes.data,
+                                        dmin.ctypes.data, None) == 0
+    np.testing.assert_array_equal(grid, g["known_grid"])
+    p = float(g["c1_pitch"])
+    pts = np.ascontiguousarray(g["c1_points"][:200])
+    grid, dmin = np.zeros((32,) * 3, np.float32), np.zeros((32,) * 3, np.float32)
+    assert lib.mf_occupancy_grid_3d_fwd(pts.ctypes.data, len(pts), p, -16 * p, -16 * p, -16 * p, 32, 32, 32, 2.0,
+                                        grid.ctypes.data, dmin.ctypes.data, None) == 0
+    np.testing.assert_array_equal(grid, g["c1_grid_thr2"])
+
+    lib = emul.build(["loss.hip"])
+    lib.mf_average_distance_fwd.argtypes = [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]
+    lib.mf_average_distance_bwd.argtypes = [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]
+    g = golden("ref_cuda_average_distance.npz")
+    pts, Tt, Tp = (np.ascontiguousarray(g[k]) for k in ("points", "transform_true", "transforms_pred"))
+    M, P = len(pts), len(Tp)
+    for tag, sym in (("add", 0), ("adds", 1)):
+        symm = np.array([sym], np.uint8)
+        out = np.zeros(P, np.float32)
+        idx = np.zeros((P, M), np.int32)
+        assert lib.mf_average_distance_fwd(pts.ctypes.data, Tt.ctypes.data, Tp.ctypes.data, symm.ctypes.data, 1, M, P,
+                                           out.ctypes.data, idx.ctypes.data, None) == 0
+        np.testing.assert_allclose(out, g[f"{tag}_value"], rtol=5e-6, atol=1e-8)
+        gout = np.ascontiguousarray(g[f"{tag}_gout"])
+        gT = np.zeros((P, 4, 4), np.float32)
+        assert lib.mf_average_distance_bwd(pts.ctypes.data, Tt.ctypes.data, Tp.ctypes.data, symm.ctypes.data,
+                                           gout.ctypes.data, 1, M, P, idx.ctypes.data, gT.ctypes.data, None) == 0
+        want = g[f"{tag}_gT"][:, :3, :]
+        np.testing.assert_allclose(gT[:, :3, :], want, rtol=2e-3, atol=2e-4 * float(np.abs(want).max()))
