@@ -65,6 +65,58 @@ cuda = _Cuda()
 backends = types.SimpleNamespace(cuda=cuda)
 
 
+class ArrayModule:
+    """``link.xp`` of a Chainer link on the GPU (cupy): the handful of array constructors the
+    reference's drivers call through it (``link.xp.asarray``, ``model.xp.arange / argmax``,
+    ``xp.concatenate / hstack / vstack / isnan / zeros / array``), producing torch tensors on the
+    link's device."""
+
+    def __init__(self, device_of):
+        self._device_of = device_of
+
+    def _dev(self):
+        return self._device_of()
+
+    def asarray(self, a, dtype=None):
+        t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(a))
+        t = t.to(self._dev())
+        return t if dtype is None else t.to(_torch_dtype(dtype))
+
+    array = asarray
+
+    def arange(self, *a, dtype=None):
+        return torch.arange(*a, device=self._dev(), dtype=None if dtype is None else _torch_dtype(dtype))
+
+    def zeros(self, shape, dtype=np.float32):
+        return torch.zeros(shape, device=self._dev(), dtype=_torch_dtype(dtype))
+
+    def argmax(self, a, axis=None):
+        return torch.argmax(a) if axis is None else torch.argmax(a, dim=axis)
+
+    def isnan(self, a):
+        return torch.isnan(a)
+
+    def concatenate(self, xs, axis=0):
+        return torch.cat([self.asarray(x) for x in xs], dim=axis)
+
+    def hstack(self, xs):
+        return torch.hstack([self.asarray(x) for x in xs])
+
+    def vstack(self, xs):
+        return torch.vstack([self.asarray(x) for x in xs])
+
+
+def _torch_dtype(dtype):
+    if isinstance(dtype, torch.dtype):
+        return dtype
+    return torch.from_numpy(np.zeros(0, dtype=np.dtype(dtype))).dtype
+
+
+def link_xp(module):
+    """``xp`` for a torch module standing in for a Chainer link: arrays land where its parameters are."""
+    return ArrayModule(lambda: next(module.parameters()).device)
+
+
 def no_backprop_mode():
     return torch.no_grad()
 

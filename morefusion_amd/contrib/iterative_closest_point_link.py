@@ -48,6 +48,12 @@ class IterativeClosestPointLink(torch.nn.Module):
         self.quaternion = torch.nn.Parameter(torch.from_numpy(quaternion))
         self.translation = torch.nn.Parameter(torch.from_numpy(translation))
 
+    @property
+    def xp(self):
+        """``link.xp`` of the reference's call sites (``link.xp.asarray(points)``): arrays on this link's device."""
+        from ..chainer_compat import link_xp
+        return link_xp(self)
+
     def to_gpu(self, device=None):
         return self.to("cuda" if device is None else f"cuda:{device}")
 

@@ -48,6 +48,12 @@ class IterativeCollisionCheckLink(torch.nn.Module):
         self._scenes_key = None
 
     # -- chainer.Link conveniences used by the reference's call sites ------------------
+    @property
+    def xp(self):
+        """``link.xp`` of the reference's call sites (``link.xp.asarray(points)``): arrays on this link's device."""
+        from ..chainer_compat import link_xp
+        return link_xp(self)
+
     def to_gpu(self, device=None):
         return self.to("cuda" if device is None else f"cuda:{device}")
 

@@ -26,6 +26,12 @@ class OccupancyRegistrationLink(torch.nn.Module):
         self.quaternion = torch.nn.Parameter(torch.as_tensor(quaternion_init, dtype=torch.float32))
         self.translation = torch.nn.Parameter(torch.as_tensor(translation_init, dtype=torch.float32))
 
+    @property
+    def xp(self):
+        """``link.xp`` of the reference's call sites (``link.xp.asarray(points)``): arrays on this link's device."""
+        from ..chainer_compat import link_xp
+        return link_xp(self)
+
     def to_gpu(self, device=None):
         return self.to("cuda" if device is None else f"cuda:{device}")
 

@@ -153,6 +153,12 @@ class Model(nn.Module):
         dt = feat1.dtype
         return torch.cat((feat1, feat2, feat3.to(dt), feat4.to(dt)), dim=1)
 
+    @property
+    def xp(self):
+        """``model.xp`` (``model.xp.arange / argmax`` in demo.py / evaluate.py): arrays on the model's device."""
+        from ....chainer_compat import link_xp
+        return link_xp(self)
+
     # ---- point selection (model.py:191-230) ---------------------------------------------
     _eval_keep_cache = {}
 

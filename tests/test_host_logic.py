@@ -451,3 +451,23 @@ def test_resnet18_extractor_architecture_and_checkpoint_keys(tmp_path):
         assert ka == kb and torch.equal(va, vb), ka
     with pytest.raises(NotImplementedError, match="occupancy term"):
         Model(n_fg_class=21, loss="add+occupancy")
+
+
+def test_reference_package_name_and_link_xp():
+    """Boundary conveniences: ``import morefusion`` resolves to this package (same module objects),
+    and links / the model expose ``xp`` like a Chainer link on the GPU (``link.xp.asarray(points)``,
+    ``model.xp.arange``: examples/ycb_video/singleview_3d/demo.py, contrib/occupancy_registration.py:86-88)."""
+    import importlib
+    import morefusion
+    import morefusion_amd
+    assert morefusion is morefusion_amd
+    assert importlib.import_module("morefusion.contrib.singleview_3d.models").Model is \
+        morefusion_amd.contrib.singleview_3d.models.Model
+    from morefusion.functions import average_voxelization_3d, truncated_distance_function  # noqa: F401
+    from morefusion.geometry import nn  # noqa: F401
+    link = morefusion.contrib.IterativeClosestPointLink(np.eye(4, dtype=np.float32))
+    x = link.xp.asarray(np.arange(6).reshape(2, 3), dtype=np.float32)
+    assert isinstance(x, torch.Tensor) and x.dtype == torch.float32 and x.device == link.quaternion.device
+    assert link.xp.concatenate([x, x], axis=0).shape == (4, 3)
+    assert link.xp.arange(3).tolist() == [0, 1, 2] and link.xp.zeros((2,), np.int32).dtype == torch.int32
+    assert not bool(link.xp.isnan(x).any())
