@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--priority", choices=["none", "net-high", "icc-high", "icc-low"], default="none",
                     help="HIP stream priorities for the two-stream step (tuning knob)")
     ap.add_argument("--stage-breakdown", action="store_true", default=True)
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="launcher / collective plumbing check without a GPU: N gloo ranks on the CPU, a stub "
+                         "step (synthetic [n_local,7] poses -> the same pose all-gather); no kernel runs and "
+                         "the JSON says so -- never a performance number")
     return ap.parse_args()
 
 
@@ -182,6 +186,31 @@ class Workload:
         out = parallel.all_gather_poses_equal(poses, out=self.gathered if self.world > 1 else None)
         self._mark("gather")
         return out, pred
+
+
+class StubWorkload:
+    """``--dry-run-cpu``: the step's communication skeleton only -- this rank's [n_local,7] "poses" are a
+    deterministic function of (rank, object) and go through the same ``all_gather_poses_equal`` the real
+    step ends with, over gloo.  Proves the launcher (N ranks, one JSON line from rank 0) and that the
+    gathered tensor has world x n_local rows in rank order."""
+
+    def __init__(self, args, rank, device):
+        self.B = args.scenes_per_gpu * args.objects
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        ids = torch.arange(rank * self.B, (rank + 1) * self.B, dtype=torch.float32, device=device)
+        self.poses = torch.stack([ids * 10.0 + k for k in range(7)], dim=1)
+        self.gathered = torch.empty((self.world * self.B, 7), device=device)
+
+    def step(self):
+        out = parallel.all_gather_poses_equal(self.poses, out=self.gathered if self.world > 1 else None)
+        return out, self.poses
+
+
+def gather_evidence(wl, device):
+    """What the last step's collective saw: rows of the gathered pose tensor and the rank census."""
+    out, _ = wl.step()
+    return dict(gathered_rows=int(out.shape[0]), rows_per_rank=int(wl.B),
+                ranks_seen=parallel.rank_census(device))
 
 
 def time_kernel_live(fn, reps):
@@ -430,11 +459,44 @@ def cpu_baseline(wl, args):
                        f"({t_pred1:.2f}s + {t_icc1:.2f}s per step)")
 
 
+def dry_run_cpu(args, world, rank):
+    """N gloo ranks, stub step, the bench's own timing contract and JSON shape."""
+    device = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    wl = StubWorkload(args, rank, device)
+    elapsed = parallel.timed_steps(wl.step, args.steps, args.warmup, device=None)
+    ev = gather_evidence(wl, device)
+    expect = torch.arange(world * wl.B, dtype=torch.float32) * 10.0
+    ev["rank_order_ok"] = bool(torch.equal(wl.step()[0][:, 0].cpu(), expect))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "objects/sec (32^3 voxelize+3D-CNN+ICC refine)", "value": None, "unit": "objects/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "DRY RUN on CPU (gloo): launcher + pose all-gather only, no kernel ran, not a measurement",
+            "config": {"workload": "stub step", "objects_per_gpu": wl.B,
+                       "parallelism": f"scene-sharded x{world}, pose all_gather"},
+            "collective": dict(ev, backend="gloo")}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and not parallel.launched():
+        # `python bench.py --gpus N` on its own: become N ranks of one node (the driver's
+        # torch.distributed.run launch arrives here with WORLD_SIZE set and skips this)
+        raise SystemExit(parallel.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
@@ -444,7 +506,6 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     wl = Workload(args, rank, device)
 
@@ -470,6 +531,8 @@ def main():
         if n1 != "start":
             stages[n1] = stages.get(n1, 0.0) + e0.elapsed_time(e1) / 5
     out = None
+    collective = gather_evidence(wl, device) if world > 1 else None  # every rank takes part
+    torch.cuda.synchronize()
     if rank == 0:
         total_objects = world * wl.B * args.steps
         ms_per_step = elapsed / args.steps * 1e3
@@ -502,6 +565,8 @@ def main():
             # the same step with the two stages back to back on one stream (no pipelining credit)
             "value_serial": round(world * wl.B / (sum(stages.values()) / 1e3), 3) if stages else None,
         }
+        if collective is not None:
+            out["collective"] = dict(collective, backend="nccl (RCCL)")
         t_vol, t_icc = handwritten_path(wl)
         out["value_handwritten_path"] = round(world * wl.B / ((t_vol + t_icc) / 1e3), 3)
         out["handwritten_path_ms"] = {"volumetric_network_part": round(t_vol, 4), "icc": round(t_icc, 4)}

@@ -5,13 +5,14 @@ examples/ycb_video/singleview_3d/train.py:143-493 for BASELINE config 5
 offline), Adam(lr 1e-4) (train.py:342), batch 16 // n_gpu per rank (train.py:361).
 
 Single GPU:   python examples/singleview_3d_train.py --steps 5
-N GPUs (DP):  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 \
-                  examples/singleview_3d_train.py --steps 5
+N GPUs (DP):  python examples/singleview_3d_train.py --gpus N --steps 5      (launches its own N ranks;
+              an external `python -m torch.distributed.run --nproc-per-node N ...` works too)
 The reference all-reduces gradients with ChainerMN `pure_nccl` (train.py:231,344); here it is
 torch DDP over RCCL (bucketed all-reduce overlapped with backward).  Convolutions / GEMMs run
 under bf16 autocast; the voxel ops and the loss stay fp32 (the HIP kernels are fp32).
 """
 import argparse
+import json
 import os
 import sys
 import time
@@ -22,35 +23,76 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import morefusion_amd as morefusion  # noqa: E402
+from morefusion_amd import parallel  # noqa: E402
 from morefusion_amd.contrib.singleview_3d.models import Model, PitchTableModels  # noqa: E402
+
+
+def dry_run_cpu(args, world, rank):
+    """Launcher + DDP plumbing without a GPU: N gloo ranks wrap a stub module in DistributedDataParallel,
+    take one optimiser step on rank-dependent data and check that every rank holds the rank-averaged
+    gradient (the all-reduce train.py:344 gets from ChainerMN).  No kernel of the pose network runs."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    stub = torch.nn.Linear(7, 3)
+    net = torch.nn.parallel.DistributedDataParallel(stub) if world > 1 else stub
+    x = torch.full((4, 7), float(rank + 1))
+    net(x).sum().backward()
+    # d/dW sum(Wx + b) = sum_rows x  -> rank r contributes 4 (r + 1); DDP leaves the mean over ranks
+    expect = 4.0 * sum(r + 1 for r in range(world)) / world
+    ok = bool(torch.allclose(stub.weight.grad, torch.full_like(stub.weight.grad, expect)))
+    census = parallel.rank_census(torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"dry_run": "cpu/gloo stub module, no pose-network kernel ran", "n_ranks": world,
+                          "ranks_seen": census, "ddp_gradient_is_rank_mean": ok}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: the launcher's WORLD_SIZE or 1")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--global-batch", type=int, default=16)
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-bf16", action="store_true")
+    ap.add_argument("--ddp", action="store_true",
+                    help="wrap the model in DistributedDataParallel over RCCL even at world size 1")
+    ap.add_argument("--json", default=None, help="write a one-line JSON record of the run to this path")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="launcher + DDP plumbing on CPU/gloo, stub module")
     args = ap.parse_args()
 
+    if args.gpus and args.gpus > 1 and not parallel.launched():
+        raise SystemExit(parallel.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert args.gpus in (None, world), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, world, rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_ddp = world > 1 or args.ddp
+    if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(parallel.free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     torch.manual_seed(0)  # identical initial weights on every rank
     rs = np.random.RandomState(0)
     pcds = {c: rs.uniform(-0.05, 0.05, (2000, 3)).astype(np.float32) for c in morefusion.synthetic.CLASS_PITCH}
     model = Model(n_fg_class=21, with_occupancy=True, models=PitchTableModels(pcds)).to(device).train()
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if use_ddp else model
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
 
     per_rank = max(1, args.global_batch // world)
     np.random.seed(1234 + rank)  # per-rank point / CAD subsampling streams
+    rates, losses = [], []
     for step in range(args.steps):
         b = morefusion.synthetic.make_singleview_batch(per_rank, seed=1000 * rank + step)
         inputs = {k: torch.as_tensor(b[k]).to(device) for k in
@@ -71,10 +113,21 @@ def main():
             loss_avg = float(lt) / world
         else:
             loss_avg = float(loss.detach())
+        rates.append(per_rank * world / dt)
+        losses.append(loss_avg)
         if rank == 0:
             print(f"step {step}: loss {loss_avg:.5f}  {per_rank * world / dt:.1f} objects/s "
                   f"(global batch {per_rank * world}, {world} GPU(s))", flush=True)
-    if world > 1:
+    if rank == 0 and args.json:
+        steady = rates[2:] or rates  # the first steps carry MIOpen's algorithm search
+        rec = {"what": "singleview_3d training step (BASELINE config 5 on this many GPUs), synthetic batch",
+               "n_gpus": world, "global_batch": per_rank * world, "dtype": "f32" if args.no_bf16 else "bf16 autocast",
+               "ddp": bool(use_ddp), "backend": "nccl (RCCL)" if use_ddp else None, "steps": args.steps,
+               "objects_per_s_steady_mean": round(float(np.mean(steady)), 2),
+               "objects_per_s_per_step": [round(r, 2) for r in rates], "loss_per_step": [round(x, 5) for x in losses]}
+        with open(args.json, "w") as f:
+            f.write(json.dumps(rec) + "\n")
+    if use_ddp:
         dist.destroy_process_group()
 
 

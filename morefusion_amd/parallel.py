@@ -10,10 +10,52 @@ exchange BASELINE config 4 names: [n_local, 7] float32 per rank (1.8 KB for 8 x 
 -> one latency-bound ``all_gather_into_tensor`` over RCCL/xGMI at the END of the step,
 never per iteration.
 """
+import os
+import socket
+import subprocess
+import sys
 import time
 
 import torch
 import torch.distributed as dist
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n_procs, script, argv, env=None):
+    """``python script --gpus N`` with no launcher around it: re-run ``script`` as N ranks of ONE
+    node under ``torch.distributed.run`` (one process per GPU, rendezvous on 127.0.0.1 and a free
+    port) and return its exit code.  The counterpart of the reference's ``mpirun -n N ... train.py
+    --multi-node`` (README.md:130-148, train.py:228-233), without the external launcher.  Callers
+    use it only when ``WORLD_SIZE`` is absent from the environment, i.e. not already launched."""
+    port = free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_procs)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script, *argv]
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
+    e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // int(n_procs))))
+    return subprocess.call(cmd, env=e)
+
+
+def launched():
+    """True inside a rank started by torch.distributed.run / torchrun / the driver's launcher."""
+    return "WORLD_SIZE" in os.environ
+
+
+def rank_census(device, group=None):
+    """Which ranks took part in a collective over ``group``: every rank contributes its own id to
+    one all-gather; returns the list every rank sees (``[0..world-1]`` when the job is whole)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [0]
+    world = dist.get_world_size(group)
+    mine = torch.tensor([dist.get_rank(group)], dtype=torch.int64, device=device)
+    out = torch.empty((world,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out.cpu().tolist()
 
 
 def shard_range(n_items, rank, world_size):
