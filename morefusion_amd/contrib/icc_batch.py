@@ -84,7 +84,10 @@ class IccScenes:
 
     def prepare(self):
         """(Re-)derive what depends on the point / grid arrays: bounding spheres, sum(grid_target),
-        tables.  Call again after updating ``pts4`` / ``grid_target`` / ``pitch`` / ``origin`` in place."""
+        tables, and whether ``grid_ne`` is {0,1}-valued (selects the single-pass kernel; other values,
+        e.g. OctoMap probabilities, take the two-kernel path).  Call again after updating ``pts4`` /
+        ``grid_target`` / ``grid_ne`` / ``pitch`` / ``origin`` in place (one host sync for the flag)."""
+        self.desc.grid_ne_binary = int(bool(((self.grid_ne == 0) | (self.grid_ne == 1)).all()))
         _lib.check(_lib.lib().mf_icc_prepare(ctypes.byref(self.desc), self.ws.data_ptr(), _lib.stream_ptr()),
                    "mf_icc_prepare")
 

@@ -71,24 +71,29 @@ class IterativeClosestPointLink(torch.nn.Module):
         return _IcpLoss.apply(T[:3, :3], T[:3, 3], source, target, 0.02)
 
     @torch.no_grad()
-    def refine(self, source, target, n_iter=100, alpha=0.01, translation_alpha_scale=0.1, return_history=False):
+    def refine(self, source, target, n_iter=100, alpha=0.01, translation_alpha_scale=0.1, return_history=False,
+               reset_optimizer=False):
         """The driver's loop for this one link, fused on the device; updates the parameters in place."""
         return icp_refine([self], [source], [target], n_iter=n_iter, alpha=alpha,
-                          translation_alpha_scale=translation_alpha_scale, return_history=return_history)
+                          translation_alpha_scale=translation_alpha_scale, return_history=return_history,
+                          reset_optimizer=reset_optimizer)
 
 
 @torch.no_grad()
 def icp_refine(links, sources, targets, n_iter=100, alpha=0.01, translation_alpha_scale=0.1, thresh=0.02,
-               return_history=False):
+               return_history=False, reset_optimizer=False):
     """``links``: IterativeClosestPointLink list (the driver's ChainList), ``sources`` / ``targets``: one
     [S_l,3] / [T_l,3] CUDA tensor per link.  Runs n_iter x {loss + gradient of every link, Adam step}
     as ``mf_icp_refine`` and writes the refined poses back into the links.  Optionally returns the
-    per-iteration losses [n_iter, L] (their sum over L is the driver's loss)."""
+    per-iteration losses [n_iter, L] (their sum over L is the driver's loss).  The Adam moments and step
+    count live on the links between calls (as an optimizer object would hold them);
+    ``reset_optimizer=True`` starts from a fresh optimizer like a re-run of the reference driver
+    (check_iterative_closest_point_link.py:40-45 builds a new ``Adam`` per run)."""
     L = len(links)
     if not (L == len(sources) == len(targets)):
         raise ValueError("one source and one target point set per link")
     dev = links[0].quaternion.device
-    _lib.require_gpu(links[0].quaternion, *sources, *targets)
+    _lib.require_gpu(*[k.quaternion for k in links], *[k.translation for k in links], *sources, *targets)
     src = torch.cat([_lib.f32c(s) for s in sources]).contiguous()
     tgt = torch.cat([_lib.f32c(t) for t in targets]).contiguous()
     src_off = torch.tensor(np.r_[0, np.cumsum([s.shape[0] for s in sources])], dtype=torch.int32, device=dev)
@@ -97,7 +102,7 @@ def icp_refine(links, sources, targets, n_iter=100, alpha=0.01, translation_alph
     t = torch.stack([k.translation.data for k in links]).float().contiguous()
     state = []
     for k in links:  # Adam moments persist on the link across calls, like an optimizer would hold them
-        if getattr(k, "_adam", None) is None:
+        if reset_optimizer or getattr(k, "_adam", None) is None:
             k._adam = [torch.zeros(7, dtype=torch.float32, device=dev) for _ in range(2)]
             k._adam_t = 0
         state.append(k)

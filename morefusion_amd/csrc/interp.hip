@@ -60,15 +60,22 @@ __device__ __forceinline__ bool plausible(float px, float py, float pz) {
 // outside every range) are owned by the workgroups of item 0, which write zeros for them.
 constexpr int kScanU = 8;
 
+// Precondition of ``batch_start``: points sorted by batch item and offsets consistent with
+// batch_indices (the wrapper documents it).  Offsets are clamped to [0, n] so that a stale or
+// inconsistent table can give wrong VALUES but never an out-of-bounds read or write.
+__device__ __forceinline__ int64_t row_clamp(int32_t r, int64_t n) {
+  return r < 0 ? 0 : (r > n ? n : (int64_t)r);
+}
+
 template <class F>
 __device__ __forceinline__ void for_rows_of_item(const int32_t *__restrict__ batch_indices,
                                                  const int32_t *__restrict__ batch_start,
                                                  int64_t n, int b, int B, F &&visit) {
   if (batch_start) {
-    const int64_t p0 = batch_start[b], p1 = batch_start[b + 1];
+    const int64_t p0 = row_clamp(batch_start[b], n), p1 = row_clamp(batch_start[b + 1], n);
     for (int64_t p = p0 + threadIdx.x; p < p1; p += kInterpThreads) visit(p, true);
     if (b == 0) {
-      const int64_t lo = batch_start[0], hi = batch_start[B];
+      const int64_t lo = row_clamp(batch_start[0], n), hi = row_clamp(batch_start[B], n);
       for (int64_t p = threadIdx.x; p < n; p += kInterpThreads)
         if (p < lo || p >= hi) visit(p, false);
     }
@@ -98,7 +105,8 @@ constexpr int kStageU = 8;
 
 __device__ __forceinline__ void stage_copy(float *__restrict__ dst, const float *__restrict__ src,
                                            int total) {
-  if ((total & 3) == 0) {
+  // 16-byte path only when both ends are 16-byte aligned (odd V with a channel offset is not)
+  if ((total & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
     const float4 *s4 = reinterpret_cast<const float4 *>(src);
     float4 *d4 = reinterpret_cast<float4 *>(dst);
     const int n4 = total / 4;
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_lds(
   // 4 per lane): the point loads are issued BEFORE the grid chunk is staged, so their latency
   // hides behind the 64 KB copy instead of costing one dependent round trip per loop iteration.
   if (batch_start) {
-    const int64_t p0 = batch_start[b], p1 = batch_start[b + 1];
+    const int64_t p0 = row_clamp(batch_start[b], n), p1 = row_clamp(batch_start[b + 1], n);
     if (p1 - p0 <= (int64_t)kInterpThreads * kInterpPre) {
       float px[kInterpPre], py[kInterpPre], pz[kInterpPre];
 #pragma unroll
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_lds(
         if (p < p1) sample(p, true, px[u], py[u], pz[u]);
       }
       if (b == 0) {  // rows outside every item: zeros (same contract as the scan path)
-        const int64_t lo = batch_start[0], hi = batch_start[B];
+        const int64_t lo = row_clamp(batch_start[0], n), hi = row_clamp(batch_start[B], n);
         for (int64_t p = threadIdx.x; p < n; p += kInterpThreads)
           if (p < lo || p >= hi) sample(p, false, 0.0f, 0.0f, 0.0f);
       }
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_vm(
     }
   };
   if (batch_start) {
-    const int64_t p0 = batch_start[b], p1 = batch_start[b + 1];
+    const int64_t p0 = row_clamp(batch_start[b], n), p1 = row_clamp(batch_start[b + 1], n);
     if (p1 - p0 <= (int64_t)kInterpThreads * kInterpPre) {
       float px[kInterpPre], py[kInterpPre], pz[kInterpPre];
 #pragma unroll
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_vm(
         if (p < p1) sample(p, true, px[u], py[u], pz[u]);
       }
       if (b == 0) {  // rows outside every item: zeros (same contract as the scan path)
-        const int64_t lo = batch_start[0], hi = batch_start[B];
+        const int64_t lo = row_clamp(batch_start[0], n), hi = row_clamp(batch_start[B], n);
         for (int64_t p = threadIdx.x; p < n; p += kInterpThreads)
           if (p < lo || p >= hi) sample(p, false, 0.0f, 0.0f, 0.0f);
       }

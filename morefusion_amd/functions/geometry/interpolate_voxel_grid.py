@@ -4,6 +4,8 @@ API of morefusion/functions/geometry/interpolate_voxel_grid.py:271-272; kernels
 (:170-212, :224-266) replaced by ``mf_interpolate_voxel_grid_{fwd,bwd}``
 (morefusion_amd/csrc/interp.hip).  Points are in voxel-index units.
 """
+import os
+
 import torch
 
 from ... import _lib
@@ -59,5 +61,20 @@ def interpolate_voxel_grid(voxelized, points, batch_indices, channels_first=Fals
     (the coalesced layout the pose network consumes, saving a transpose).  ``batch_start``
     (int32 [B+1] row offsets, optional) tells the kernel that the rows of item b are
     ``batch_start[b]:batch_start[b+1]`` (points sorted by batch index, as the pose network's
-    are): each workgroup then visits only its own rows."""
+    are): each workgroup then visits only its own rows.
+
+    Precondition with ``batch_start``: the points ARE sorted by batch item and the offsets agree with
+    ``batch_indices`` (the kernels trust the offsets and do not look at ``batch_indices`` then); offsets are
+    clamped to ``[0, P]`` on the device, so an inconsistent table cannot read or write out of bounds, but it
+    gives wrong values.  Set ``MF_DEBUG_CHECKS=1`` to have the wrapper verify the table (one host sync)."""
+    if batch_start is not None and os.environ.get("MF_DEBUG_CHECKS"):
+        bs = batch_start.detach().cpu().long()
+        bi = batch_indices.detach().cpu().long()
+        ok = bool((bs[1:] >= bs[:-1]).all()) and int(bs[0]) >= 0 and int(bs[-1]) <= bi.shape[0]
+        if ok:
+            expect = torch.repeat_interleave(torch.arange(bs.shape[0] - 1), bs[1:] - bs[:-1])
+            ok = torch.equal(bi[int(bs[0]):int(bs[-1])], expect)
+        if not ok:
+            raise ValueError("interpolate_voxel_grid: batch_start is inconsistent with batch_indices "
+                             "(points must be sorted by batch item)")
     return InterpolateVoxelGrid.apply(voxelized, points, batch_indices, channels_first, batch_start)
