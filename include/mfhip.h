@@ -289,6 +289,27 @@ int mf_sparse_conv3d_k4s2_points_fwd(const float *values, const float *points,
                                      int32_t Cs, int32_t Cout, int32_t D, int32_t max_rows,
                                      int32_t relu, mfStream_t stream);
 
+/* ---- A13 conv4 (and the dense occupancy channels of conv3): Convolution3D k=4 s=2 pad=1 ----
+ * replaces the cuDNN convolutions at
+ *   morefusion/contrib/singleview_3d/models/model.py:74,139  (conv4: 256 -> 512 on 16^3, + ReLU)
+ *   morefusion/contrib/singleview_3d/models/model.py:73,128  (conv3's 16 dense occupancy channels)
+ * with an fp32-MFMA (v_mfma_f32_32x32x2_f32, exact fp32) implicit GEMM over CHANNELS-LAST tensors:
+ *   x    [B, D,D,D, Cin]          Cin a power of two >= 4
+ *   wt   [Cout, 64, Cin]          from mf_conv3d_k4s2_pack_weights (tap = (kx*4 + ky)*4 + kz)
+ *   bias [Cout] or NULL, add [B, (D/2)^3, Cout] or NULL (added before the activation)
+ *   out  [B, D/2,D/2,D/2, Cout]   Cout % 128 == 0; relu != 0 applies max(., 0)
+ *   split: K (taps) is cut into `split` slabs (mf_conv3d_k4s2_default_split picks >= 512 workgroups),
+ *   partial sums go to ws (mf_conv3d_k4s2_workspace_bytes) and are added in slab order: deterministic. */
+int mf_conv3d_k4s2_pack_weights(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin, int32_t c_off,
+                                float *wt, mfStream_t stream);
+int32_t mf_conv3d_k4s2_default_split(int32_t B, int32_t Cin, int32_t Cout, int32_t D);
+int64_t mf_conv3d_k4s2_workspace_bytes(int32_t B, int32_t Cout, int32_t D, int32_t split);
+int mf_conv3d_k4s2_fwd(const float *x, const float *wt, const float *bias, const float *add, float *out,
+                       void *ws, int32_t B, int32_t Cin, int32_t Cout, int32_t D, int32_t split,
+                       int32_t relu, mfStream_t stream);
+/* [B, C, V] -> [B, V, C] (channels-first grid -> channels-last) */
+int mf_to_channels_last(const float *src, float *dst, int32_t B, int32_t C, int64_t V, mfStream_t stream);
+
 /* small fused helpers of the same path */
 /* pack [Ptot,3] points + [Ptot] sdf into float4 */
 int mf_pack_points_sdf(const float *points, const float *sdf, int64_t n, void *pts4,

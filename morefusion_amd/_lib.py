@@ -65,6 +65,11 @@ _SIGNATURES = {
     "mf_pack_points_sdf": ([_p, _p, _i64, _p, _p], _i),
     "mf_average_distance_fwd": ([_p, _p, _p, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p, _p], _i),
     "mf_average_distance_bwd": ([_p, _p, _p, _p, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p, _p], _i),
+    "mf_conv3d_k4s2_pack_weights": ([_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p], _i),
+    "mf_conv3d_k4s2_default_split": ([ctypes.c_int32] * 4, ctypes.c_int32),
+    "mf_conv3d_k4s2_workspace_bytes": ([ctypes.c_int32] * 4, _i64),
+    "mf_conv3d_k4s2_fwd": ([_p, _p, _p, _p, _p, _p] + [ctypes.c_int32] * 6 + [_p], _i),
+    "mf_to_channels_last": ([_p, _p, ctypes.c_int32, ctypes.c_int32, _i64, _p], _i),
     "mf_valid_pixel_order": ([_p, ctypes.c_int32, ctypes.c_int32, _p, _p, _p], _i),
     "mf_instance_stats": ([_p, _p, _i, _i, _p, _i, _p, _p], _i),
     "mf_instance_crops": ([_p, _p, _p, _i, _i, _d, _d, _d, _d, _p, _p, _i, _i, _i, _p, _p, _p, _p], _i),

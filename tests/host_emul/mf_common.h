@@ -331,6 +331,31 @@ inline mf_emul_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, mf_e
   }
   return c;
 }
+// v_mfma_f32_32x32x2_f32: D[i][j] += sum_k A[i][k] * B[k][j]; lane l supplies A[l % 32][l / 32] and
+// B[l / 32][l % 32] and holds D[(e & 3) + 8 * (e >> 2) + 4 * (l / 32)][l % 32] in element e (k increasing).
+typedef float mf_emul_f32x16 __attribute__((vector_size(64)));
+inline mf_emul_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, mf_emul_f32x16 c, int, int, int) {
+  uint64_t act;
+  uint32_t ab, bb;
+  memcpy(&ab, &a, 4);
+  memcpy(&bb, &b, 4);
+  float A[64], B[64];
+  const uint64_t *all = mf_emul::wave_exchange(((uint64_t)ab << 32) | bb, &act);
+  for (int l = 0; l < 64; ++l) {
+    const uint32_t hi = (uint32_t)(all[l] >> 32), lo = (uint32_t)all[l];
+    memcpy(&A[l], &hi, 4);
+    memcpy(&B[l], &lo, 4);
+  }
+  const int lane = mf_emul::g_block.cur % 64, j = lane % 32;
+  for (int e = 0; e < 16; ++e) {
+    const int i = (e & 3) + 8 * (e >> 2) + 4 * (lane / 32);
+    float acc = c[e];
+    for (int k = 0; k < 2; ++k) acc += A[k * 32 + i] * B[k * 32 + j];
+    c[e] = acc;
+  }
+  return c;
+}
+inline void __builtin_amdgcn_sched_barrier(int) {}
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }

@@ -1,0 +1,100 @@
+"""csrc/conv3d.hip (fp32-MFMA implicit GEMM, kernel 4 / stride 2 / pad 1, channels-last) run on the CPU
+behind the fiber emulator (tests/host_emul) and checked against torch's dense Conv3d -- the operator the
+reference applies there (contrib/singleview_3d/models/model.py:73-74,128,139: Convolution3D(.., 4, 2, pad=1)).
+fp32 sums in a different order: tolerance 2e-5 of the largest output."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from host_emul import emul
+
+pytestmark = pytest.mark.skipif(not emul.available(), reason="g++ not available")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = emul.build(["conv3d.hip"])
+    i32, p = ctypes.c_int32, ctypes.c_void_p
+    L.mf_conv3d_k4s2_pack_weights.argtypes = [p, i32, i32, i32, i32, p, p]
+    L.mf_conv3d_k4s2_workspace_bytes.restype = ctypes.c_int64
+    L.mf_conv3d_k4s2_workspace_bytes.argtypes = [i32] * 4
+    L.mf_conv3d_k4s2_default_split.argtypes = [i32] * 4
+    L.mf_conv3d_k4s2_fwd.argtypes = [p] * 6 + [i32] * 6 + [p]
+    L.mf_to_channels_last.argtypes = [p, p, i32, i32, ctypes.c_int64, p]
+    return L
+
+
+def _run(L, x_cf, W, bias, add_cl, split, relu, c_off=0, cin=None):
+    """x_cf [B,Cin_total,D,D,D] channels-first (torch layout); returns out channels-first."""
+    B, _, D = x_cf.shape[:3]
+    Cout, w_cin = W.shape[:2]
+    cin = cin or w_cin
+    x_cl = np.ascontiguousarray(x_cf[:, c_off:c_off + cin].transpose(0, 2, 3, 4, 1))
+    wt = np.zeros((Cout, 64, cin), np.float32)
+    assert L.mf_conv3d_k4s2_pack_weights(emul.ptr(np.ascontiguousarray(W)), Cout, cin, w_cin, c_off, emul.ptr(wt), None) == 0
+    np.testing.assert_array_equal(wt, W[:, c_off:c_off + cin].reshape(Cout, cin, 64).transpose(0, 2, 1))
+    Do = D // 2
+    out = np.full((B, Do, Do, Do, Cout), np.nan, np.float32)
+    nbytes = L.mf_conv3d_k4s2_workspace_bytes(B, Cout, D, split)
+    ws = np.zeros(max(nbytes, 4) // 4, np.float32)
+    rc = L.mf_conv3d_k4s2_fwd(emul.ptr(x_cl), emul.ptr(wt), emul.ptr(bias), emul.ptr(add_cl), emul.ptr(out),
+                              emul.ptr(ws), B, cin, Cout, D, split, int(relu), None)
+    assert rc == 0
+    return out.transpose(0, 4, 1, 2, 3)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,D,split,relu", [
+    (2, 32, 128, 8, 1, True),     # M = 128: one full tile, every tap, padding on all six faces
+    (1, 32, 128, 8, 4, True),     # M = 64 < tile (row guard) + split-K slabs + finish kernel
+    (3, 16, 128, 4, 2, False),    # Cin = 16: two taps per K-tile; M = 24; no activation
+    (1, 64, 256, 6, 8, True),     # two N tiles, odd output extent (Do = 3)
+])
+def test_conv3d_k4s2_matches_torch(lib, B, Cin, Cout, D, split, relu):
+    rs = np.random.RandomState(B * 100 + Cin)
+    x = rs.uniform(-1, 1, (B, Cin, D, D, D)).astype(np.float32)
+    x[rs.uniform(size=x.shape) < 0.3] = 0.0   # post-ReLU-like input
+    W = (rs.uniform(-1, 1, (Cout, Cin, 4, 4, 4)) / np.sqrt(Cin * 64)).astype(np.float32)
+    bias = rs.uniform(-0.2, 0.2, Cout).astype(np.float32)
+    got = _run(lib, x, W, bias, None, split, relu)
+    ref = torch.nn.functional.conv3d(torch.from_numpy(x).double(), torch.from_numpy(W).double(),
+                                     torch.from_numpy(bias).double(), stride=2, padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    ref = ref.numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_conv3d_channel_slice_and_addend(lib):
+    """The conv3 use: convolve only channels [c_off, c_off + 16) of a wider weight tensor and add the
+    result of the sparse part (``add``, channels-last) before the activation."""
+    rs = np.random.RandomState(7)
+    B, D, Cout, w_cin, c_off, cin = 1, 8, 128, 24, 8, 16
+    x = rs.uniform(0, 1, (B, w_cin, D, D, D)).astype(np.float32)
+    W = (rs.uniform(-1, 1, (Cout, w_cin, 4, 4, 4)) / 30).astype(np.float32)
+    bias = rs.uniform(-0.2, 0.2, Cout).astype(np.float32)
+    add = rs.uniform(-1, 1, (B, D // 2, D // 2, D // 2, Cout)).astype(np.float32)
+    for split in (1, 2):
+        got = _run(lib, x, W, bias, add, split, True, c_off=c_off, cin=cin)
+        ref = torch.nn.functional.conv3d(torch.from_numpy(x[:, c_off:c_off + cin]).double(),
+                                         torch.from_numpy(W[:, c_off:c_off + cin]).double(),
+                                         torch.from_numpy(bias).double(), stride=2, padding=1)
+        ref = torch.relu(ref + torch.from_numpy(add).double().permute(0, 4, 1, 2, 3)).numpy()
+        assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_conv3d_rejects_bad_shapes(lib):
+    z = np.zeros(4, np.float32)
+    for B, Cin, Cout, D, split in [(1, 24, 128, 8, 1), (1, 32, 96, 8, 1), (1, 32, 128, 7, 1), (1, 32, 128, 8, 3)]:
+        assert lib.mf_conv3d_k4s2_fwd(emul.ptr(z), emul.ptr(z), None, None, emul.ptr(z), emul.ptr(z),
+                                      B, Cin, Cout, D, split, 1, None) != 0
+
+
+def test_to_channels_last(lib):
+    rs = np.random.RandomState(0)
+    x = rs.uniform(-1, 1, (2, 19, 45)).astype(np.float32)
+    y = np.zeros((2, 45, 19), np.float32)
+    assert lib.mf_to_channels_last(emul.ptr(x), emul.ptr(y), 2, 19, 45, None) == 0
+    np.testing.assert_array_equal(y, x.transpose(0, 2, 1))
