@@ -310,6 +310,27 @@ int mf_conv3d_k4s2_fwd(const float *x, const float *wt, const float *bias, const
 /* [B, C, V] -> [B, V, C] (channels-first grid -> channels-last) */
 int mf_to_channels_last(const float *src, float *dst, int32_t B, int32_t C, int64_t V, mfStream_t stream);
 
+/* Channels-last forms of the inference path between conv3 and the heads (same results as the
+ * channels-first entries above, other memory layout):
+ *   mf_sparse_conv3d_k4s2_points_cl_fwd: as mf_sparse_conv3d_k4s2_points_fwd, but values rows have pitch
+ *     ldv floats (a column block of a wider matrix), dense / out are [B, (D/2)^3, Cout]; Cout % 256 == 0.
+ *   mf_interpolate_voxel_grid_cl_fwd (replaces K5, interpolate_voxel_grid.py:170-212, for vox
+ *     [B, X*Y*Z, C]): out[p*ldo + c], rows of pitch ldo floats; rows with a batch index outside [0,B) = 0.
+ *   mf_occupancy_convs_fwd (replaces the cuDNN Convolution3D pair model.py:69-72,120-124: 1 -> 8 k3 pad 1,
+ *     8 -> 16 k3 dilation 2 pad 2, ReLU after each): grid [B,D,D,D] -> h2 [B, D^3, 16]; h1 [B, D^3, 8] scratch;
+ *     w1 [27,1,8], w2 [27,8,16] = W.permute(2,3,4,1,0) of the Chainer/torch weight. */
+int mf_sparse_conv3d_k4s2_points_cl_fwd(const float *values, int64_t ldv, const float *points,
+                                        const int32_t *batch_indices, int64_t n, float ox, float oy,
+                                        float oz, float pitch, const float *Wp, const float *dense,
+                                        const float *bias, float *out, void *ws, int32_t B, int32_t Cs,
+                                        int32_t Cout, int32_t D, int32_t max_rows, int32_t relu,
+                                        mfStream_t stream);
+int mf_interpolate_voxel_grid_cl_fwd(const float *vox, const float *points, const int32_t *batch_indices,
+                                     int64_t n, int B, int C, int X, int Y, int Z, float *out, int64_t ldo,
+                                     mfStream_t stream);
+int mf_occupancy_convs_fwd(const float *grid, const float *w1, const float *b1, const float *w2,
+                           const float *b2, float *h1, float *h2, int32_t B, int32_t D, mfStream_t stream);
+
 /* small fused helpers of the same path */
 /* pack [Ptot,3] points + [Ptot] sdf into float4 */
 int mf_pack_points_sdf(const float *points, const float *sdf, int64_t n, void *pts4,

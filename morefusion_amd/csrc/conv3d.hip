@@ -248,6 +248,63 @@ __global__ __launch_bounds__(256) void k_to_channels_last(const float *__restric
     if (v0 + j < V && c0 + tx < C) dst[((int64_t)b * V + v0 + j) * C + c0 + tx] = tile[tx][j];
 }
 
+// ---- occupancy branch: conv1_occ (1 -> 8, k3 p1) and conv2_occ (8 -> 16, k3 dilation 2 p2), + ReLU ----
+// Reference: model.py:69-72,120-124 (two cuDNN Convolution3D on the 32^3 no-entry grid).  0.24 GFLOP per
+// object: VALU work.  One lane per output voxel, all output channels in registers, channels-last
+// in / out (the 16-channel result feeds conv3's implicit GEMM as it is); the weights are uniform ->
+// scalar loads, every v_fma takes its weight from an SGPR.  Packed weights: w[tap][ci][co].
+template <int CI, int CO, int DIL>
+__global__ __launch_bounds__(256) void k_occ_conv3(const float *__restrict__ x, const float *__restrict__ w,
+                                                   const float *__restrict__ bias, float *__restrict__ out,
+                                                   int B, int D) {
+  const int64_t total = (int64_t)B * D * D * D;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int iz = (int)(i % D), iy = (int)((i / D) % D), ix = (int)((i / ((int64_t)D * D)) % D);
+  const int64_t b = i / ((int64_t)D * D * D);
+  float acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = bias[co];
+#pragma unroll 1
+  for (int kx = 0; kx < 3; ++kx) {
+    const int jx = ix + (kx - 1) * DIL;
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+      const int jy = iy + (ky - 1) * DIL;
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz) {
+        const int jz = iz + (kz - 1) * DIL;
+        const bool ok = (unsigned)jx < (unsigned)D && (unsigned)jy < (unsigned)D && (unsigned)jz < (unsigned)D;
+        const float *src = x + (ok ? (((b * D + jx) * D + jy) * D + jz) * CI : 0);
+        float in[CI];
+        if (CI % 4 == 0) {
+#pragma unroll
+          for (int q = 0; q < CI / 4; ++q) {
+            const float4 v = reinterpret_cast<const float4 *>(src)[q];
+            in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int ci = 0; ci < CI; ++ci) in[ci] = src[ci];
+        }
+        const float *wt = w + ((kx * 3 + ky) * 3 + kz) * CI * CO;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+          const float v = ok ? in[ci] : 0.0f;
+#pragma unroll
+          for (int co = 0; co < CO; ++co) acc[co] = fmaf(v, wt[ci * CO + co], acc[co]);
+        }
+      }
+    }
+  }
+  float *dst = out + i * CO;
+#pragma unroll
+  for (int q = 0; q < CO / 4; ++q)
+    reinterpret_cast<float4 *>(dst)[q] =
+        make_float4(fmaxf(acc[4 * q], 0.0f), fmaxf(acc[4 * q + 1], 0.0f), fmaxf(acc[4 * q + 2], 0.0f),
+                    fmaxf(acc[4 * q + 3], 0.0f));
+}
+
 int ilog2(int x) {
   int l = 0;
   while ((1 << l) < x) ++l;
@@ -317,4 +374,22 @@ extern "C" int mf_to_channels_last(const float *src, float *dst, int32_t B, int3
   hipLaunchKernelGGL(k_to_channels_last, dim3((unsigned)((V + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B),
                      dim3(256), 0, stream, src, dst, C, (int)V);
   return mf::check_launch("mf_to_channels_last");
+}
+
+/* w1 [27][1][8], w2 [27][8][16] (tap-major, output channel innermost), biases [8], [16];
+ * grid [B,D,D,D] -> h1 [B,D^3,8] (scratch) -> h2 [B,D^3,16], both ReLU-ed, channels-last. */
+extern "C" int mf_occupancy_convs_fwd(const float *grid, const float *w1, const float *b1, const float *w2,
+                                      const float *b2, float *h1, float *h2, int32_t B, int32_t D,
+                                      mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0) return 0;
+  const int64_t total = (int64_t)B * D * D * D;
+  if (total * 16 >= (1ll << 31)) {
+    mf::set_last_error(hipErrorInvalidValue, "occupancy_convs: B * D^3 * 16 must stay below 2^31");
+    return -(int)hipErrorInvalidValue;
+  }
+  const unsigned nb = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL((k_occ_conv3<1, 8, 1>), dim3(nb), dim3(256), 0, stream, grid, w1, b1, h1, B, D);
+  hipLaunchKernelGGL((k_occ_conv3<8, 16, 2>), dim3(nb), dim3(256), 0, stream, (const float *)h1, w2, b2, h2, B, D);
+  return mf::check_launch("mf_occupancy_convs_fwd");
 }

@@ -393,6 +393,52 @@ int pick_cpw(int C, int B, int64_t V) {
   return cpw;
 }
 
+// ---- channels-last forward: vox [B][X*Y*Z][C] -> out rows of pitch ``ldo`` ---------------------
+// With the channel index innermost a corner is C contiguous floats: one WAVE per point reads its 8
+// corners as whole rows (16 bytes per lane, 1 KB per wave instruction, straight from L2 -- no LDS
+// staging, no transpose) and writes C contiguous outputs at out[p * ldo ..], which lets the caller
+// sample straight into a column block of the heads' [n, 984] feature matrix.  Weights, corner order
+// and the per-channel sum order are those of ``corners`` / k_interp_fwd_vm: identical bits.
+constexpr int kClPointsPerWave = 2;
+
+__global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_cl(
+    const float *__restrict__ vox, const float *__restrict__ points,
+    const int32_t *__restrict__ batch_indices, int64_t n, int B, int C, int X, int Y, int Z,
+    float *__restrict__ out, int64_t ldo) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t V = (int64_t)X * Y * Z;
+  const int64_t p0 = ((int64_t)blockIdx.x * (kInterpThreads / 64) + wave) * kClPointsPerWave;
+#pragma unroll
+  for (int u = 0; u < kClPointsPerWave; ++u) {
+    const int64_t p = p0 + u;
+    if (p >= n) break;  // wave-uniform
+    const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+    const int b = batch_indices[p];
+    const bool ok = b >= 0 && b < B && plausible(px, py, pz);
+    Corner k;
+    if (ok) corners(px, py, pz, X, Y, Z, k);
+    const float *grid = vox + (int64_t)(ok ? b : 0) * V * C;
+    for (int c = 4 * lane; c < C; c += 256) {
+      float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (ok) {
+        float4 g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          g[j] = *reinterpret_cast<const float4 *>(grid + (int64_t)(k.off[j] < 0 ? 0 : k.off[j]) * C + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (k.off[j] < 0) continue;
+          acc.x += k.w[j] * g[j].x;
+          acc.y += k.w[j] * g[j].y;
+          acc.z += k.w[j] * g[j].z;
+          acc.w += k.w[j] * g[j].w;
+        }
+      }
+      *reinterpret_cast<float4 *>(out + p * ldo + c) = acc;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int mf_interpolate_voxel_grid_fwd(const float *vox, const float *points,
@@ -454,4 +500,21 @@ extern "C" int mf_interpolate_voxel_grid_bwd(const float *gvalues, const float *
                          X, Y, Z, gvox, channels_first);
   }
   return mf::check_launch("mf_interpolate_voxel_grid_bwd");
+}
+
+extern "C" int mf_interpolate_voxel_grid_cl_fwd(const float *vox, const float *points,
+                                                const int32_t *batch_indices, int64_t n, int B, int C,
+                                                int X, int Y, int Z, float *out, int64_t ldo,
+                                                mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n <= 0) return 0;
+  if (C % 4 || ldo % 4 || ldo < C || ((uintptr_t)out & 15) || ((uintptr_t)vox & 15)) {
+    mf::set_last_error(hipErrorInvalidValue,
+                       "interpolate_voxel_grid (channels-last): need C % 4 == 0, ldo % 4 == 0, 16-byte aligned out");
+    return -(int)hipErrorInvalidValue;
+  }
+  const int64_t per_block = (kInterpThreads / 64) * kClPointsPerWave;
+  hipLaunchKernelGGL(k_interp_fwd_cl, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kInterpThreads), 0,
+                     stream, vox, points, batch_indices, n, B, C, X, Y, Z, out, ldo);
+  return mf::check_launch("mf_interpolate_voxel_grid_cl_fwd");
 }

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_sc_rows_from_chains(ScArgs a, const flo
                                                             const int32_t *__restrict__ batch_indices,
                                                             int64_t n, float ox, float oy, float oz,
                                                             float pitch, const int32_t *__restrict__ head,
-                                                            const int32_t *__restrict__ link) {
+                                                            const int32_t *__restrict__ link, int64_t ldv) {
   __shared__ int s_ids[4][64];
   __shared__ int s_sorted[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_sc_rows_from_chains(ScArgs a, const flo
   if (row < 0) return;  // outside the grid, or beyond max_rows (wave-uniform)
   float *dst = a.A + (int64_t)row * a.Cs;
   mf::chain_mean(values, points, batch_indices, a.counts, head, link, i, a.Cs, a.B, a.D, a.D, a.D, ox, oy, oz,
-                 pitch, s_ids[wave], s_sorted[wave], lane, [&](int ch, float mean) { dst[ch] = mean; });
+                 pitch, s_ids[wave], s_sorted[wave], lane, [&](int ch, float mean) { dst[ch] = mean; }, ldv);
 }
 
 // C[row][n] = sum_k A[row][k] * Wp[class(row)][k][n],  n in [0, 8*Cout)
@@ -297,6 +297,80 @@ __global__ __launch_bounds__(kRedThreads) void k_sc_reduce(ScArgs a, const float
   }
 }
 
+// The same reduce for a CHANNELS-LAST output [B][Vo][Cout] (what conv4's implicit GEMM and the
+// channels-last trilinear sampler consume): lanes run over channels, 4 each -- a contributing
+// (row, slot) is ONE 16-byte load per lane (a whole 1 KB row segment per wave), the store is a
+// 16-byte row segment, no LDS transpose.  Same taps in the same order, then + dense + bias:
+// the same bits as k_sc_reduce.  Cout % 256 == 0, Cout <= 512.
+__global__ __launch_bounds__(kRedThreads) void k_sc_reduce_cl(ScArgs a, const float *__restrict__ dense,
+                                                             const float *__restrict__ bias, int relu,
+                                                             float *__restrict__ out) {
+  const int D = a.D, Do = D / 2, V = D * D * D, Vo = Do * Do * Do;
+  const int b = blockIdx.y;
+  const int o0 = blockIdx.x * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int kWaves = kRedThreads / 64, kPerWave = 64 / kWaves;
+  const int N = 8 * a.Cout;
+  const int nj = a.Cout / 256;
+  const int kx = lane >> 4, ky = (lane >> 2) & 3, kz = lane & 3;
+  const int slot = (kx >> 1) | ((ky >> 1) << 1) | ((kz >> 1) << 2);
+  int rows[kPerWave];
+#pragma unroll
+  for (int t = 0; t < kPerWave; ++t) {
+    const int o = o0 + wave * kPerWave + t;
+    rows[t] = -1;
+    if (o < Vo) {
+      const int oz = o % Do, oy = (o / Do) % Do, oxx = o / (Do * Do);
+      const int vx = 2 * oxx - 1 + kx, vy = 2 * oy - 1 + ky, vz = 2 * oz - 1 + kz;
+      if (vx >= 0 && vx < D && vy >= 0 && vy < D && vz >= 0 && vz < D)
+        rows[t] = a.rowmap[(int64_t)b * V + (vx * D + vy) * D + vz];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kPerWave; ++t) {
+    const int o = o0 + wave * kPerWave + t;
+    if (o >= Vo) continue;  // wave-uniform
+    const int64_t obase = ((int64_t)b * Vo + o) * a.Cout;
+    float4 dn[2], acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {  // the dense addend's load overlaps the tap walk
+      dn[j] = acc[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (j >= nj) continue;
+      dn[j] = dense ? *reinterpret_cast<const float4 *>(dense + obase + 256 * j + 4 * lane)
+                    : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      acc[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    unsigned long long hits = __ballot(rows[t] >= 0);
+    while (hits) {  // taps in increasing k: fixed summation order
+      const int src = __ffsll((long long)hits) - 1;
+      hits &= hits - 1;
+      const int r = __shfl(rows[t], src, 64);
+      const int sl = __shfl(slot, src, 64);
+      const float *crow = a.C + (int64_t)r * N + sl * a.Cout + 4 * lane;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j >= nj) continue;
+        const float4 c = *reinterpret_cast<const float4 *>(crow + 256 * j);
+        acc[j].x += c.x; acc[j].y += c.y; acc[j].z += c.z; acc[j].w += c.w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j >= nj) continue;
+      float4 bs = bias ? *reinterpret_cast<const float4 *>(bias + 256 * j + 4 * lane)
+                       : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      float4 v;
+      v.x = acc[j].x + dn[j].x + bs.x; v.y = acc[j].y + dn[j].y + bs.y;
+      v.z = acc[j].z + dn[j].z + bs.z; v.w = acc[j].w + dn[j].w + bs.w;
+      if (relu) {
+        v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f;
+        v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f;
+      }
+      *reinterpret_cast<float4 *>(out + obase + 256 * j + 4 * lane) = v;
+    }
+  }
+}
+
 // Wp[class][c][slot*Cout + co] = W[co][c][kx][ky][kz],  k = parity + 2*slot bit per axis
 __global__ void k_sc_pack(const float *__restrict__ W, int Cout, int Cs, int w_cin, int c_off,
                           float *__restrict__ Wp) {
@@ -384,11 +458,16 @@ void sc_index(const ScArgs &a, hipStream_t stream) {
 
 // 8 parity-class GEMMs + output-stationary reduce
 void sc_gemm_reduce(const ScArgs &a, const float *Wp, const float *dense, const float *bias, int relu,
-                    float *out, hipStream_t stream) {
+                    float *out, hipStream_t stream, int channels_last = 0) {
   const size_t lds_g = (size_t)a.Cs * (kTM + 4 + kTN + 4) * sizeof(float);
   // persistent-style: 2 workgroups per CU walk the (class, row tile, column tile) list
   hipLaunchKernelGGL(k_sc_gemm, dim3(512), dim3(256), lds_g, stream, a, Wp);
   const int Vo = (a.D / 2) * (a.D / 2) * (a.D / 2);
+  if (channels_last) {
+    hipLaunchKernelGGL(k_sc_reduce_cl, dim3((Vo + 63) / 64, a.B), dim3(kRedThreads), 0, stream, a, dense, bias,
+                       relu, out);
+    return;
+  }
   hipLaunchKernelGGL(k_sc_reduce, dim3((Vo + 63) / 64, a.B), dim3(kRedThreads),
                      (size_t)a.Cout * 65 * sizeof(float), stream, a, dense, bias, relu, out);
 }
@@ -435,7 +514,38 @@ extern "C" int mf_sparse_conv3d_k4s2_points_fwd(const float *values, const float
   sc_index(w.a, stream);
   if (n > 0)
     hipLaunchKernelGGL(k_sc_rows_from_chains, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, w.a,
-                       values, points, batch_indices, n, ox, oy, oz, pitch, w.head, w.link);
+                       values, points, batch_indices, n, ox, oy, oz, pitch, w.head, w.link, (int64_t)Cs);
   sc_gemm_reduce(w.a, Wp, dense, bias, relu, out, stream);
   return mf::check_launch("mf_sparse_conv3d_k4s2_points_fwd");
+}
+
+extern "C" int mf_sparse_conv3d_k4s2_points_cl_fwd(const float *values, int64_t ldv, const float *points,
+                                                const int32_t *batch_indices, int64_t n, float ox,
+                                                float oy, float oz, float pitch, const float *Wp,
+                                                const float *dense, const float *bias, float *out,
+                                                void *ws, int32_t B, int32_t Cs, int32_t Cout,
+                                                int32_t D, int32_t max_rows, int32_t relu,
+                                                mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || max_rows <= 0) return 0;
+  if (int e = sc_check(B, Cs, Cout, D)) return e;
+  if (Cout % 256 || ldv < Cs) {
+    mf::set_last_error(hipErrorInvalidValue, "sparse_conv3d (channels-last): need Cout % 256 == 0, ldv >= Cs");
+    return -(int)hipErrorInvalidValue;
+  }
+  const int64_t V = (int64_t)D * D * D;
+  ScWs w = sc_carve(ws, B, Cs, Cout, D, max_rows, n);
+  w.a.counts = w.counts_own;
+  MF_TRY(hipMemsetAsync(w.a.class_cnt, 0, 512, stream));
+  MF_TRY(hipMemsetAsync(w.counts_own, 0, sizeof(int32_t) * B * V, stream));
+  MF_TRY(hipMemsetAsync(w.head, 0xff, sizeof(int32_t) * B * V, stream));
+  if (n > 0)
+    hipLaunchKernelGGL(k_sc_link, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, points,
+                       batch_indices, n, B, D, ox, oy, oz, pitch, w.counts_own, w.head, w.link);
+  sc_index(w.a, stream);
+  if (n > 0)
+    hipLaunchKernelGGL(k_sc_rows_from_chains, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, w.a,
+                       values, points, batch_indices, n, ox, oy, oz, pitch, w.head, w.link, ldv);
+  sc_gemm_reduce(w.a, Wp, dense, bias, relu, out, stream, 1);
+  return mf::check_launch("mf_sparse_conv3d_k4s2_points_cl_fwd");
 }

@@ -56,7 +56,8 @@ __device__ __forceinline__ int64_t chain_mean(const float *__restrict__ values,
                                               const int32_t *__restrict__ link, int64_t i, int C,
                                               int B, int X, int Y, int Z, float ox, float oy,
                                               float oz, float pitch, int *s_ids, int *s_sorted,
-                                              int lane, Store &&store) {
+                                              int lane, Store &&store, int64_t ldv = 0) {
+  if (ldv == 0) ldv = C;  // row pitch of ``values`` (floats); 0 = dense rows
   int v;
   bool has_nan;
   const bool ok = voxel_of(points, i, ox, oy, oz, pitch, X, Y, Z, v, has_nan);
@@ -85,7 +86,7 @@ __device__ __forceinline__ int64_t chain_mean(const float *__restrict__ values,
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int ch = lane; ch < C; ch += 64) {
       float s = 0.0f;
-      for (int k = 0; k < cnt; ++k) s += values[(int64_t)s_sorted[k] * C + ch];
+      for (int k = 0; k < cnt; ++k) s += values[(int64_t)s_sorted[k] * ldv + ch];
       store(ch, s / (float)cnt);
     }
   } else {  // pathological pile-up in one voxel: repeated selection, still in index order
@@ -96,7 +97,7 @@ __device__ __forceinline__ int64_t chain_mean(const float *__restrict__ values,
         int best = 0x7fffffff;
         for (int m = (int)i; m >= 0; m = link[m])
           if (m > last && m < best) best = m;
-        s += values[(int64_t)best * C + ch];
+        s += values[(int64_t)best * ldv + ch];
         last = best;
       }
       store(ch, s / (float)cnt);

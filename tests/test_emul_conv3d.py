@@ -98,3 +98,29 @@ def test_to_channels_last(lib):
     y = np.zeros((2, 45, 19), np.float32)
     assert lib.mf_to_channels_last(emul.ptr(x), emul.ptr(y), 2, 19, 45, None) == 0
     np.testing.assert_array_equal(y, x.transpose(0, 2, 1))
+
+
+def test_occupancy_convs_match_torch(lib):
+    """conv1_occ (1 -> 8, k3 p1) + ReLU + conv2_occ (8 -> 16, k3 dilation 2 p2) + ReLU, channels-last out."""
+    i32, p = ctypes.c_int32, ctypes.c_void_p
+    lib.mf_occupancy_convs_fwd.argtypes = [p] * 7 + [i32] * 2 + [p]
+    rs = np.random.RandomState(3)
+    B, D = 2, 6
+    grid = (rs.uniform(size=(B, D, D, D)) < 0.4).astype(np.float32)
+    W1 = rs.uniform(-0.5, 0.5, (8, 1, 3, 3, 3)).astype(np.float32)
+    b1 = rs.uniform(-0.1, 0.1, 8).astype(np.float32)
+    W2 = rs.uniform(-0.3, 0.3, (16, 8, 3, 3, 3)).astype(np.float32)
+    b2 = rs.uniform(-0.1, 0.1, 16).astype(np.float32)
+    w1 = np.ascontiguousarray(W1.transpose(2, 3, 4, 1, 0)).reshape(27, 1, 8)
+    w2 = np.ascontiguousarray(W2.transpose(2, 3, 4, 1, 0)).reshape(27, 8, 16)
+    h1 = np.zeros((B, D ** 3, 8), np.float32)
+    h2 = np.zeros((B, D ** 3, 16), np.float32)
+    assert lib.mf_occupancy_convs_fwd(emul.ptr(grid), emul.ptr(w1), emul.ptr(b1), emul.ptr(w2), emul.ptr(b2),
+                                      emul.ptr(h1), emul.ptr(h2), B, D, None) == 0
+    F = torch.nn.functional
+    t1 = torch.relu(F.conv3d(torch.from_numpy(grid)[:, None].double(), torch.from_numpy(W1).double(),
+                             torch.from_numpy(b1).double(), padding=1))
+    t2 = torch.relu(F.conv3d(t1, torch.from_numpy(W2).double(), torch.from_numpy(b2).double(), padding=2, dilation=2))
+    np.testing.assert_allclose(h1.reshape(B, D, D, D, 8).transpose(0, 4, 1, 2, 3), t1.numpy(), atol=2e-6)
+    np.testing.assert_allclose(h2.reshape(B, D, D, D, 16).transpose(0, 4, 1, 2, 3), t2.numpy(), atol=5e-6)
+    assert (h2 > 0).mean() > 0.2

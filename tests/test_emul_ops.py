@@ -381,3 +381,62 @@ def test_occupancy_grid_and_loss_kernel_sources_vs_reference_outputs():
                                            gout.ctypes.data, 1, M, P, idx.ctypes.data, gT.ctypes.data, None) == 0
         want = g[f"{tag}_gT"][:, :3, :]
         np.testing.assert_allclose(gT[:, :3, :], want, rtol=2e-3, atol=2e-4 * float(np.abs(want).max()))
+
+
+def test_channels_last_sparse_conv3_and_sampler_give_the_channels_first_bits():
+    """The channels-last entries of the inference path (sparse conv3 reduce -> [B,Vo,Cout]; trilinear sampler
+    reading whole voxel rows and writing into a column block of a wider matrix) against the channels-first
+    kernels they stand beside: bit-identical results (same taps / corners in the same order)."""
+    lib = emul.build(["sparseconv.hip", "interp.hip"])
+    i64, f = ctypes.c_int64, ctypes.c_float
+    lib.mf_sparse_conv3d_workspace_bytes.restype = i64
+    lib.mf_sparse_conv3d_workspace_bytes.argtypes = [_i32] * 5 + [i64]
+    lib.mf_sparse_conv3d_pack_weights.argtypes = [_p, _i32, _i32, _i32, _i32, _p, _p]
+    lib.mf_sparse_conv3d_k4s2_points_fwd.argtypes = [_p, _p, _p, i64] + [f] * 4 + [_p] * 5 + [_i32] * 6 + [_p]
+    lib.mf_sparse_conv3d_k4s2_points_cl_fwd.argtypes = [_p, i64, _p, _p, i64] + [f] * 4 + [_p] * 5 + [_i32] * 6 + [_p]
+    lib.mf_interpolate_voxel_grid_fwd.argtypes = [_p, _p, _p, _p, i64] + [ctypes.c_int] * 5 + [_p, ctypes.c_int, _p]
+    lib.mf_interpolate_voxel_grid_cl_fwd.argtypes = [_p, _p, _p, i64] + [ctypes.c_int] * 5 + [_p, i64, _p]
+    rs = np.random.RandomState(11)
+    B, Cs, Cout, D, n, ld = 2, 8, 256, 8, 90, 20
+    points = rs.uniform(-0.6, D - 0.4, (n, 3)).astype(np.float32)
+    points[:10] = points[10:20]
+    wide = rs.uniform(-1, 1, (n, ld)).astype(np.float32)          # values = columns 4..12 of a wider matrix
+    values = np.ascontiguousarray(wide[:, 4:4 + Cs])
+    bi = np.sort(rs.randint(0, B, n)).astype(np.int32)
+    W = (rs.uniform(-1, 1, (Cout, Cs, 4, 4, 4)) * 0.2).astype(np.float32)
+    bias = rs.uniform(-0.1, 0.1, Cout).astype(np.float32)
+    Do = D // 2
+    dense_cf = rs.uniform(-0.1, 0.1, (B, Cout, Do, Do, Do)).astype(np.float32)
+    dense_cl = np.ascontiguousarray(dense_cf.transpose(0, 2, 3, 4, 1))
+    Wp = np.zeros(8 * Cs * 8 * Cout, np.float32)
+    assert lib.mf_sparse_conv3d_pack_weights(W.ctypes.data, Cout, Cs, Cs, 0, Wp.ctypes.data, None) == 0
+    ws = np.zeros(int(lib.mf_sparse_conv3d_workspace_bytes(B, Cs, Cout, D, n, n)) // 4 + 64, np.float32)
+    out_cf = np.full(dense_cf.shape, 7.0, np.float32)
+    assert lib.mf_sparse_conv3d_k4s2_points_fwd(values.ctypes.data, points.ctypes.data, bi.ctypes.data, n, 0.0, 0.0,
+                                                0.0, 1.0, Wp.ctypes.data, dense_cf.ctypes.data, bias.ctypes.data,
+                                                out_cf.ctypes.data, ws.ctypes.data, B, Cs, Cout, D, n, 1, None) == 0
+    out_cl = np.full(dense_cl.shape, 7.0, np.float32)
+    ws[:] = 0
+    assert lib.mf_sparse_conv3d_k4s2_points_cl_fwd(wide[:, 4:].ctypes.data, ld, points.ctypes.data, bi.ctypes.data, n,
+                                                   0.0, 0.0, 0.0, 1.0, Wp.ctypes.data, dense_cl.ctypes.data,
+                                                   bias.ctypes.data, out_cl.ctypes.data, ws.ctypes.data, B, Cs, Cout,
+                                                   D, n, 1, None) == 0
+    np.testing.assert_array_equal(out_cl.transpose(0, 4, 1, 2, 3), out_cf)
+    assert (out_cf > 0).mean() > 0.2
+
+    # sampler: points in the half-resolution frame, incl. out-of-grid corners and an invalid batch index
+    pts = (points / 2.0).astype(np.float32)
+    pts[3] = (-0.5, 1.0, 1.0)
+    pts[4] = (Do - 0.5, Do - 0.2, 0.3)
+    bi2 = bi.copy()
+    bi2[5] = 9
+    ref = np.zeros((n, Cout), np.float32)
+    assert lib.mf_interpolate_voxel_grid_fwd(out_cf.ctypes.data, pts.ctypes.data, bi2.ctypes.data, None, n, B, Cout,
+                                             Do, Do, Do, ref.ctypes.data, 0, None) == 0
+    ldo = Cout + 24
+    got = np.full((n, ldo), 5.0, np.float32)
+    assert lib.mf_interpolate_voxel_grid_cl_fwd(out_cl.ctypes.data, pts.ctypes.data, bi2.ctypes.data, n, B, Cout, Do,
+                                                Do, Do, got[:, 8:].ctypes.data, ldo, None) == 0
+    np.testing.assert_array_equal(got[:, 8:8 + Cout], ref)
+    assert (got[:, :8] == 5.0).all() and (got[:, 8 + Cout:] == 5.0).all()   # neighbours untouched
+    assert (ref[5] == 0).all() and np.abs(ref).sum() > 0
