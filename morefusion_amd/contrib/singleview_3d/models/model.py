@@ -29,6 +29,7 @@ from .... import metrics
 from ....models import PSPNetExtractor, ResNet18, ResNet18Extractor
 from ....synthetic import CLASS_IDS_SYMMETRIC, CLASS_PITCH
 from .sparse_conv import SparseVoxelConv3d
+from .volumetric_cl import ChannelsLastVolumetric
 
 
 class PitchTableModels:
@@ -75,6 +76,10 @@ class Model(nn.Module):
         self.sparse_pspnet_tail = True
         # inference: conv3 on fp32 MFMA over the occupied voxels only (csrc/sparseconv.hip)
         self.sparse_conv3 = True
+        # inference: the whole volumetric part hand-written in channels-last layout (volumetric_cl.py:
+        # occupancy convs, conv3 dense + sparse, conv4 as fp32-MFMA implicit GEMMs, samplers writing
+        # into the heads' input matrix); False = round 2's channels-first path (stock conv4 / occ convs)
+        self.channels_last_3d = True
 
         # model.py:50-56: the ImageNet-pretrained chainercv2 ResNet-18 (frozen BatchNorm, no
         # gradient below res2) or the DenseFusion ResNet18.  The pretrained weights are a
@@ -248,6 +253,8 @@ class Model(nn.Module):
         B = values.shape[0]
         dev = values.device
         points = (points - origin[:, :, None]) / pitch[:, None, None]  # camera -> voxel frame
+        if self.channels_last_3d and self.sparse_conv3 and not torch.is_grad_enabled() and values.is_cuda:
+            return self._pose_from_features_cl(class_id, values, points, pitch, origin, grid_nontarget_empty)
         h = self._extract(values, points, grid_nontarget_empty)
 
         outs = {}
@@ -271,6 +278,23 @@ class Model(nn.Module):
         rot = (rot / (rot.norm(dim=1, keepdim=True) + 1e-5)).transpose(1, 2)  # B4P -> BP4
         trans = cls_trans[ar, fg_class_id].transpose(1, 2)  # B3P -> BP3
         conf = cls_conf[ar, fg_class_id]
+        return rot, trans, conf
+
+    def _pose_from_features_cl(self, class_id, values, points, pitch, origin, grid_nontarget_empty):
+        """``_pose_from_features`` (points already in the voxel frame) on the channels-last kernels."""
+        B, _, P = values.shape
+        if getattr(self, "_volumetric_cl", None) is None:
+            self.__dict__["_volumetric_cl"] = ChannelsLastVolumetric(self)
+        vol = self._volumetric_cl
+        feat = vol.features(values, points, grid_nontarget_empty)
+        cls_rot, cls_trans, cls_conf = vol.heads(feat, B, P)          # [B,P,n_fg,c]
+        fg = (class_id - 1).long()
+        ar = torch.arange(B, device=values.device)
+        rot = cls_rot[ar, :, fg]                                       # [B,P,4]
+        rot = rot / (rot.norm(dim=2, keepdim=True) + 1e-5)             # chainer F.normalize (see below)
+        points_cam = (points * pitch[:, None, None] + origin[:, :, None]).transpose(1, 2)  # [B,P,3]
+        trans = points_cam + cls_trans[ar, :, fg] * pitch[:, None, None]
+        conf = cls_conf[ar, :, fg]
         return rot, trans, conf
 
     # ---- training (model.py:277-481) ------------------------------------------------------

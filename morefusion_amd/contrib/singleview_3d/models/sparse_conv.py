@@ -91,3 +91,28 @@ class SparseVoxelConv3d:
             self.Wp.data_ptr(), _lib.ptr(dense), _lib.ptr(bias), out.data_ptr(), self._ws.data_ptr(),
             B, Cs, Cout, D, max_rows, int(relu), _lib.stream_ptr()), "mf_sparse_conv3d_k4s2_points_fwd")
         return out
+
+    @torch.no_grad()
+    def from_points_cl(self, values, ldv, points, batch_indices, batch_size, dense_cl=None, dim=32, relu=True):
+        """Channels-last form of ``from_points``: ``values`` is an [n, Cs] column block of a wider row-major
+        matrix (row pitch ``ldv`` floats), ``dense_cl`` / the result are [B, (D/2)^3, Cout]."""
+        _lib.require_gpu(values, points, batch_indices)
+        n, Cs = values.shape
+        B, D = int(batch_size), int(dim)
+        Cout = self.conv.out_channels
+        if values.dtype != torch.float32 or values.stride(1) != 1 or values.stride(0) != ldv:
+            raise TypeError("values must be a float32 column block with row pitch ldv")
+        self._prepare(Cs)
+        lib = _lib.lib()
+        max_rows = max(int(n), 1)
+        nbytes = lib.mf_sparse_conv3d_workspace_bytes(B, Cs, Cout, D, max_rows, n)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=values.device)
+        pts, bi = _lib.f32c(points), _lib.i32c(batch_indices)
+        out = torch.empty((B, (D // 2) ** 3, Cout), dtype=torch.float32, device=values.device)
+        bias = self.conv.bias.detach().float().contiguous() if self.conv.bias is not None else None
+        _lib.check(lib.mf_sparse_conv3d_k4s2_points_cl_fwd(
+            values.data_ptr(), int(ldv), pts.data_ptr(), bi.data_ptr(), n, 0.0, 0.0, 0.0, 1.0,
+            self.Wp.data_ptr(), _lib.ptr(dense_cl), _lib.ptr(bias), out.data_ptr(), self._ws.data_ptr(),
+            B, Cs, Cout, D, max_rows, int(relu), _lib.stream_ptr()), "mf_sparse_conv3d_k4s2_points_cl_fwd")
+        return out
