@@ -224,6 +224,69 @@ class Model(nn.Module):
         return self._predict_device(torch.as_tensor(class_id, device=dev), rgb, pcd, pix, pitch,
                                     origin, grid_nontarget_empty)
 
+    def predict_graphed(self, *, class_id, rgb, pcd, pitch=None, origin=None, grid_nontarget_empty=None,
+                        pix=None, clone=True):
+        """``predict`` with everything after the point selection replayed from ONE hipGraph per input shape
+        (BASELINE config 2, batch = 1: ~300 short launches whose host-side launch cost exceeds their GPU time).
+        The first call of a shape warms up (MIOpen solver search) and captures; later calls copy the inputs
+        into the graph's static buffers (skipped for tensors that still live at the captured address) and
+        replay.  ``pix`` [B,P]: a point selection computed ahead (``select_points_async``), which removes the
+        call's only host synchronisation.  ``clone=False`` returns the graph's static output tensors (valid
+        until the next call)."""
+        if self.training or torch.is_grad_enabled():
+            raise RuntimeError("predict_graphed is an inference path: call under torch.no_grad() in eval mode")
+        dev = rgb.device
+        if pitch is None:
+            pitch = torch.tensor([self._models.get_voxel_pitch(self._voxel_dim, int(c))
+                                  for c in class_id.tolist()], dtype=torch.float32, device=dev)
+        pitch = torch.as_tensor(pitch, dtype=torch.float32, device=dev)
+        if origin is None:
+            origin = geometry_module.grid_origin(pcd.float(), pitch, dim=self._voxel_dim)
+        origin = torch.as_tensor(origin, dtype=torch.float32, device=dev)
+        if pix is None:
+            pix = self._select_points(pcd)
+        if getattr(self, "_graphed", None) is None:
+            from .graphed import GraphedPredict
+            self.__dict__["_graphed"] = GraphedPredict(self)
+        outs = self._graphed(torch.as_tensor(class_id, device=dev), rgb, pcd, pix, pitch, origin,
+                             grid_nontarget_empty)
+        return tuple(o.clone() for o in outs) if clone else outs
+
+    def select_points_async(self, pcd, stream=None):
+        """Point selection of a FUTURE frame on a side stream: launches ``mf_valid_pixel_order`` and the
+        device-to-host copy of the counts into pinned memory, returns a handle whose ``result()`` finishes
+        the host-side RNG subsample.  Issued while the network of the current frame runs, the host
+        synchronisation of ``predict`` hides behind it (demo.py:80-100 processes frames in sequence)."""
+        B, HW = pcd.shape[0], pcd.shape[1] * pcd.shape[2]
+        _lib.require_gpu(pcd)
+        stream = stream or torch.cuda.Stream(device=pcd.device)
+        stream.wait_stream(torch.cuda.current_stream())
+        model = self
+
+        class _Pending:
+            def __init__(self):
+                with torch.cuda.stream(stream):
+                    p = _lib.f32c(pcd)
+                    self.order = torch.empty((B, HW), dtype=torch.int32, device=pcd.device)
+                    counts = torch.empty((B,), dtype=torch.int32, device=pcd.device)
+                    _lib.check(_lib.lib().mf_valid_pixel_order(p.data_ptr(), B, HW, self.order.data_ptr(),
+                                                               counts.data_ptr(), stream.cuda_stream),
+                               "mf_valid_pixel_order")
+                    self.counts_host = torch.empty((B,), dtype=torch.int32, pin_memory=True)
+                    self.counts_host.copy_(counts, non_blocking=True)
+                    self.done = torch.cuda.Event()
+                    self.done.record(stream)
+                    self._keep = (p, counts)
+
+            def result(self):
+                self.done.synchronize()
+                with torch.cuda.stream(stream):
+                    pix = model._subsample(self.order, self.counts_host.numpy())
+                torch.cuda.current_stream().wait_stream(stream)
+                return pix
+
+        return _Pending()
+
     def _predict_device(self, class_id, rgb, pcd, pix, pitch, origin, grid_nontarget_empty):
         """Everything after point selection: pure device work, no host synchronisation."""
         values, points = self._backbone_features(rgb, pcd, pix)

@@ -47,7 +47,18 @@
 
 namespace {
 
-__device__ unsigned long long g_dbg_stamps[4096 * 8];  // tuning aid (MF_ICC_DEBUG & 32)
+// Tuning aids (per-phase time stamps, phase skipping: MF_ICC_DEBUG bit mask at run time) exist only in a
+// build with -DMF_ICC_DEBUG_BUILD=1 (`make ICC_DEBUG=1`, tools/stamps_*.py); the production kernels carry
+// none of their branches.
+#ifndef MF_ICC_DEBUG_BUILD
+#define MF_ICC_DEBUG_BUILD 0
+#endif
+#define MF_DBG(a_, bits_) (MF_ICC_DEBUG_BUILD != 0 && ((a_).dbg & (bits_)) != 0)
+#if MF_ICC_DEBUG_BUILD
+__device__ unsigned long long g_dbg_stamps[4096 * 8];  // (MF_ICC_DEBUG & 32)
+#else
+__device__ unsigned long long g_dbg_stamps[8];
+#endif
 
 constexpr int kAccThreads = 512;
 constexpr int kVoxPerBlock = 1024;  // k_icc_accum: voxels per workgroup
@@ -91,11 +102,21 @@ struct IccArgs {
   int4 *tab2;             // [n_tab] {scene first object, objects in scene, scene, 1 = designated entry of j}
   int n_tab;
   int hmax;               // largest TDF half-kernel of the batch
-  int nbins;              // kHalves * (D + 2 hmax): (x-plane of the rounded x in [-hmax, D-1+hmax], y-half)
+  int nbins;              // COUNTER STRIDE of a grid: kHalves * (D + 2 hmax) real bins ((x-plane of the rounded x in
+                          // [-hmax, D-1+hmax], y-half)) + 1: the last word counts the grid's OVERFLOW records
   uint32_t *bin_cnt;      // [2 parities][2*O][nbins] records in each bin: iteration k fills parity k & 1,
                           // the step side of k_icc_bin empties the other one for iteration k + 1
-  int32_t *bin_cap;       // [2*O] capacity of each bin of grid g = number of its source points
-  int64_t *bin_base;      // [2*O] first record of grid g's bins; bin b starts at base + b*cap
+  // A (point, grid) pair lands in ONE plane (two bins when its rows straddle the halves), so a bin can
+  // hold all P_g source points of its grid in the worst case -- but reserving that for every bin is
+  // nbins x the records that can exist (3.3 GB for 32 objects x 3000 points).  A bin therefore gets
+  // cap_g = max(kBinMinCap, P_g / kBinShare) slots; records beyond it go to the grid's overflow list
+  // (2 P_g slots behind its bins), which EVERY tile of the grid scans with the bin-membership test
+  // when its counter is non-zero.  Winners are exact minima with lowest-id ties and the sums are
+  // fixed point: where a record is stored cannot change a bit of the result.
+  int32_t *bin_cap;       // [2*O] capacity cap_g of each bin of grid g
+  int32_t *bin_pts;       // [2*O] P_g = source points of grid g (overflow capacity = 2 P_g)
+  int64_t *bin_base;      // [2*O] first record of grid g; bin b starts at base + b*cap_g, overflow at base + nreal*cap_g
+  int bin_cap_force;      // > 0: every cap_g = this (MF_ICC_BIN_CAP: exercises the overflow path in tests)
   float4 *rec;            // records {fx, fy, fz, point id bits}: voxel-frame coordinates
   int dbg;                // tuning aid: MF_ICC_DEBUG bit mask (0 in production)
 };
@@ -214,6 +235,13 @@ constexpr int kBinPPT = 4;                          // points per thread (2: 23.
 constexpr int kBinChunk = kBinThreads * kBinPPT;    // points per workgroup
 constexpr int kHalves = 2;                          // y-halves of a plane: rows [0, D/2), [D/2, D)
 constexpr int kMaxBins = kHalves * (64 + 6);        // D <= 64, ks <= 7
+constexpr int kBinShare = 8;                        // a bin holds 1/8 of its grid's source points ...
+constexpr int kBinMinCap = 64;                      // ... at least this many, the rest overflows
+
+__host__ __device__ inline int bin_cap_of(int P, int force) {
+  int c = force > 0 ? force : max(kBinMinCap, (P + kBinShare - 1) / kBinShare);
+  return min(max(c, 1), max(P, 1));
+}
 
 // Once per batch: bin capacities/offsets per grid and the (target, source, point chunk) table.
 __global__ __launch_bounds__(256) void k_icc_tables(IccArgs a) {
@@ -226,12 +254,15 @@ __global__ __launch_bounds__(256) void k_icc_tables(IccArgs a) {
       const int ja = a.scene_off[sc], jb = a.scene_off[sc + 1];
       const int p_own = a.obj_off[o + 1] - a.obj_off[o];
       const int p_all = a.obj_off[jb] - a.obj_off[ja];
-      a.bin_cap[2 * o] = p_own;
+      const int nreal = a.nbins - 1;
+      a.bin_cap[2 * o] = bin_cap_of(p_own, a.bin_cap_force);
+      a.bin_pts[2 * o] = p_own;
       a.bin_base[2 * o] = rec_off;
-      rec_off += (int64_t)a.nbins * p_own;
-      a.bin_cap[2 * o + 1] = p_all - p_own;
+      rec_off += (int64_t)nreal * a.bin_cap[2 * o] + 2 * (int64_t)p_own;
+      a.bin_cap[2 * o + 1] = bin_cap_of(p_all - p_own, a.bin_cap_force);
+      a.bin_pts[2 * o + 1] = p_all - p_own;
       a.bin_base[2 * o + 1] = rec_off;
-      rec_off += (int64_t)a.nbins * (p_all - p_own);
+      rec_off += (int64_t)nreal * a.bin_cap[2 * o + 1] + 2 * (int64_t)(p_all - p_own);
       for (int j = ja; j < jb; ++j) {
         const int p0 = a.obj_off[j], p1 = a.obj_off[j + 1];
         // the first chunk of the pair (j, j) is the designated entry of object j: it stores the
@@ -458,7 +489,7 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
   __shared__ float s_sum[kStepSums], s_state[kStateFloats];
   __shared__ long long s_raw[kStepRawWords];
   auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
-    if ((a.dbg & 32) && threadIdx.x == 0 && blockIdx.x < 1024)
+    if (MF_DBG(a, 32) && threadIdx.x == 0 && blockIdx.x < 1024)
       g_dbg_stamps[(3072 + blockIdx.x) * 8 + i] = wall_clock64();
   };
   stamp(0);
@@ -488,14 +519,16 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
   const float pitch = a.pitch[o];
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
   const int cap = a.bin_cap[g];
+  const int ovf_cap = 2 * a.bin_pts[g];
   const int64_t base_g = a.bin_base[g];
+  const int nbr = nb - 1;  // real bins; counter nbr = the grid's overflow records
   float4 m[kBinPPT];
 #pragma unroll
   for (int u = 0; u < kBinPPT; ++u) {
     const int p = e.z + u * kBinThreads + (int)threadIdx.x;
     m[u] = p < e.w ? a.pts4[p] : make_float4(0, 0, 0, 0);
   }
-  for (int i = threadIdx.x; i < nb; i += kBinThreads) s_cnt[i] = 0;
+  for (int i = threadIdx.x; i < nbr; i += kBinThreads) s_cnt[i] = 0;
   if (sp.mode != 0) {
     // the previous iteration's reduced sums of object j (fixed point)
     if (sp.fused)
@@ -591,7 +624,7 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
   }
   __syncthreads();
   stamp(1);
-  for (int i = threadIdx.x; i < nb; i += kBinThreads) {
+  for (int i = threadIdx.x; i < nbr; i += kBinThreads) {
     const int c = s_cnt[i];
     s_base[i] = c > 0 ? (int)atomicAdd(&a.bin_cnt[((int64_t)sp.cpar * 2 * a.O + g) * nb + i], (uint32_t)c) : 0;
   }
@@ -604,9 +637,13 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
     for (int hf = 0; hf < kHalves; ++hf) {
       if (bin[u][hf] < 0) continue;
       const int idx = s_base[bin[u][hf]] + slot[u][hf];
-      if (idx >= cap) continue;  // cannot happen while bin_cnt starts at zero; never write out of bounds
-      a.rec[base_g + (int64_t)bin[u][hf] * cap + idx] =
-          make_float4(fx[u], fy[u], fz[u], __uint_as_float((uint32_t)p));
+      const float4 r = make_float4(fx[u], fy[u], fz[u], __uint_as_float((uint32_t)p));
+      if (idx < cap) {
+        a.rec[base_g + (int64_t)bin[u][hf] * cap + idx] = r;
+      } else {  // bin full: the grid's overflow list (its tiles find the record by the membership test)
+        const uint32_t k = atomicAdd(&a.bin_cnt[((int64_t)sp.cpar * 2 * a.O + g) * nb + nbr], 1u);
+        if ((int)k < ovf_cap) a.rec[base_g + (int64_t)nbr * cap + k] = r;  // (k < 2 P_g always: a point adds <= 2 records)
+      }
     }
   }
   stamp(3);
@@ -655,19 +692,21 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
   const int64_t base_g = a.bin_base[g];
   const float pitch = a.pitch[o];
   const int bin0 = x + hmax - h;  // plane x - h
+  const int nbr = nb - 1;
+  const int nov = min((int)a.bin_cnt[((int64_t)par * 2 * a.O + g) * nb + nbr], 2 * a.bin_pts[g]);
 #pragma unroll
   for (int b = 0; b < 7; ++b) {
     int n = 0;
     if (b < ks) n = min((int)a.bin_cnt[((int64_t)par * 2 * a.O + g) * nb + (bin0 + b) * kHalves + half], cap);
     c[b + 1] = c[b] + n;
   }
-  const int T = c[7];
+  const int T = c[7] + nov;  // the tile's bins, then the grid's overflow list (filtered by fetch)
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
   auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
-    if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
+    if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
   };
   stamp(0);
-  if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)T;
+  if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)T;
   const float trunc = a.thr * pitch;
   for (int i = threadIdx.x; i < nvox; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
   __syncthreads();
@@ -680,6 +719,13 @@ __device__ __forceinline__ void icc_tile_body(const IccArgs &a, const int ks_rt,
   auto fetch = [&](const int i, float4 &rv, int &rb) {
     rb = -1;
     if (i >= T) return;
+    if (i >= c[7]) {  // overflow record: belongs to this tile iff its plane is in x-h..x+h and its rows touch the half
+      rv = recs[(int64_t)nbr * cap + (i - c[7])];
+      const int pl = (int)roundf(rv.x) - (x - h), iry_ = (int)roundf(rv.y);
+      const bool in_half = half == 0 ? (iry_ - h < Dh) : (iry_ + h >= Dh);
+      rb = (pl >= 0 && pl < ks && in_half) ? pl : -1;
+      return;
+    }
     int b = 0;
 #pragma unroll
     for (int k = 1; k < 7; ++k) b += (k < ks && i >= c[k]) ? 1 : 0;
@@ -928,7 +974,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   const int o = blockIdx.y;
   const int wg2 = 2048 + blockIdx.y * gridDim.x + blockIdx.x;
   auto stamp = [&](int i) {
-    if ((a.dbg & 32) && threadIdx.x == 0 && wg2 < 4096) g_dbg_stamps[wg2 * 8 + i] = wall_clock64();
+    if (MF_DBG(a, 32) && threadIdx.x == 0 && wg2 < 4096) g_dbg_stamps[wg2 * 8 + i] = wall_clock64();
   };
   stamp(0);
   const int D = a.D, V = D * D * D;
@@ -1180,15 +1226,18 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   const int ja = meta.x, Ns = meta.y - meta.x;
   // independent loads: bin counts of both grids, capacities, offsets, scalars, scene tables
   int c[2][8];
-  int cap[2];
+  int cap[2], nov[2], tot[2];
   int64_t base_g[2];
   const float pitch = a.pitch[o];
   const int bin0 = x + hmax - h;  // plane x - h
+  const int nbr = nb - 1;
 #pragma unroll
   for (int kd = 0; kd < 2; ++kd) {
     const int g = 2 * o + kd;
     cap[kd] = a.bin_cap[g];
     base_g[kd] = a.bin_base[g];
+    nov[kd] = (kd == 0 || Ns > 1)
+                  ? min((int)a.bin_cnt[((int64_t)par * 2 * a.O + g) * nb + nbr], 2 * a.bin_pts[g]) : 0;
     c[kd][0] = 0;
 #pragma unroll
     for (int b = 0; b < 7; ++b) {
@@ -1197,8 +1246,9 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
         n = min((int)a.bin_cnt[((int64_t)par * 2 * a.O + g) * nb + (bin0 + b) * kHalves + half], cap[kd]);
       c[kd][b + 1] = c[kd][b] + n;
     }
+    tot[kd] = c[kd][7] + nov[kd];  // the tile's bins, then the grid's overflow list (filtered by fetch)
   }
-  if (c[0][7] + c[1][7] == 0) return;  // block-uniform: no record of either grid reaches this tile
+  if (tot[0] + tot[1] == 0) return;  // block-uniform: no record of either grid reaches this tile
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
   if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
@@ -1208,10 +1258,10 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   for (int i = threadIdx.x; i < (kTileThreads / 16) * (kNumF + 1); i += kTileThreads) (&s_rows[0][0])[i] = 0.0f;
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
   auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
-    if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
+    if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
   };
   stamp(0);
-  if ((a.dbg & 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)(c[0][7] + c[1][7]);
+  if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)(c[0][7] + c[1][7]);
   // the voxel phase's first-level loads, issued now: this lane's voxel of the two input grids
   float ne0 = 0.0f, tg0 = 0.0f;
   if ((int)threadIdx.x < nvox) {
@@ -1229,7 +1279,14 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   // record i of grid kd's concatenated bins -> (plane offset b, record); rb < 0: none
   auto fetch = [&](const int kd, const int i, float4 &rv, int &rb) {
     rb = -1;
-    if (i >= c[kd][7]) return;
+    if (i >= tot[kd]) return;
+    if (i >= c[kd][7]) {  // overflow record: this tile's iff its plane is in x-h..x+h and its rows touch the half
+      rv = a.rec[base_g[kd] + (int64_t)nbr * cap[kd] + (i - c[kd][7])];
+      const int pl = (int)roundf(rv.x) - (x - h), iry_ = (int)roundf(rv.y);
+      const bool in_half = half == 0 ? (iry_ - h < Dh) : (iry_ + h >= Dh);
+      rb = (pl >= 0 && pl < ks && in_half) ? pl : -1;
+      return;
+    }
     int b = 0;
 #pragma unroll
     for (int k = 1; k < 7; ++k) b += (k < ks && i >= c[kd][k]) ? 1 : 0;
@@ -1361,7 +1418,7 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
 #pragma unroll
     for (int kd = 0; kd < 2; ++kd) {
       const int first = kTileThreads * (kd == 0 ? kFusedKeepOwn : kFusedKeepOth);
-      for (int base = first; base < c[kd][7]; base += kTileThreads * kTileR) {
+      for (int base = first; base < tot[kd]; base += kTileThreads * kTileR) {
         float4 xv[kTileR];
         int xb[kTileR];
 #pragma unroll
@@ -1372,13 +1429,13 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
       }
     }
   };
-  if (!(a.dbg & 128)) pass_over(1);  // (MF_ICC_DEBUG & 128 / 256 / 512: skip a phase to time the others; results invalid)
+  if (!MF_DBG(a, 128)) pass_over(1);  // (MF_ICC_DEBUG & 128 / 256 / 512: skip a phase to time the others; results invalid)
   __syncthreads();
   stamp(2);
-  if (!(a.dbg & 256)) pass_over(2);
+  if (!MF_DBG(a, 256)) pass_over(2);
   __syncthreads();
   stamp(3);
-  if (a.dbg & 512) return;
+  if (MF_DBG(a, 512)) return;
 
   // ---- voxel phase.  Only a voxel WITH an own winner adds to any sum (without one g = 0 and
   // w = 0), and those are the few voxels of the surface shell, scattered over most waves of
@@ -1630,7 +1687,7 @@ __global__ void k_pack(const float *__restrict__ points, const float *__restrict
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 struct WsLayout {
-  int64_t W, M, Rt, bound, St, acc_own, acc_oth, state_alt, meta, tab, tab2, bin_cnt, bin_cap, bin_base,
+  int64_t W, M, Rt, bound, St, acc_own, acc_oth, state_alt, meta, tab, tab2, bin_cnt, bin_cap, bin_pts, bin_base,
       rec, total;
   int NB, n_tab, nbins;
 };
@@ -1643,12 +1700,17 @@ int ksize_host(float thr) {
   return ks;
 }
 
+int icc_bin_cap_force() {  // testing knob: MF_ICC_BIN_CAP=<n> forces every bin's capacity (overflow path)
+  const char *e = getenv("MF_ICC_BIN_CAP");
+  return e ? atoi(e) : 0;
+}
+
 WsLayout ws_layout(const mfIccBatch *b) {
   WsLayout l;
   const int O = b->n_objects, S = b->n_scenes, D = b->dim, max_ns = b->max_scene_objects;
   const int64_t V = (int64_t)D * D * D;
   l.NB = (int)((V + kVoxPerBlock - 1) / kVoxPerBlock);
-  l.nbins = kHalves * (D + 2 * (ksize_host(b->voxel_threshold) / 2));
+  l.nbins = kHalves * (D + 2 * (ksize_host(b->voxel_threshold) / 2)) + 1;  // + the overflow counter
   // every (target, source) pair of a scene in chunks of kBinChunk points:
   // sum_pairs ceil(P_j / chunk) <= max_ns * n_points / chunk + O * max_ns (+ O designated entries)
   l.n_tab = (int)(((int64_t)max_ns * b->n_points + kBinChunk - 1) / kBinChunk) + O * max_ns + O;
@@ -1666,10 +1728,17 @@ WsLayout ws_layout(const mfIccBatch *b) {
   l.tab2 = off; off = align256(off + (int64_t)l.n_tab * 16);
   l.bin_cnt = off; off = align256(off + (int64_t)2 * 2 * O * l.nbins * 4);
   l.bin_cap = off; off = align256(off + (int64_t)2 * O * 4);
+  l.bin_pts = off; off = align256(off + (int64_t)2 * O * 4);
   l.bin_base = off; off = align256(off + (int64_t)2 * O * 8);
-  // a grid's bins hold <= (its source points) records each: sum over grids of a scene
-  // = Ns * P_scene <= max_ns * n_points, times nbins (plane, half) bins
-  l.rec = off; off = align256(off + (int64_t)l.nbins * max_ns * b->n_points * 16);
+  // records: per grid (nbins - 1) bins of cap_g <= P_g / kBinShare + kBinMinCap + 1 slots + an overflow list of
+  // 2 P_g; sum_g P_g = sum over scenes of Ns * P_scene <= max_ns * n_points  ->  O(N * sum P), not nbins x that
+  {
+    const int64_t sumP = (int64_t)max_ns * b->n_points;
+    const int force = icc_bin_cap_force();
+    const int64_t per_grid_extra = (force > 0 ? force : kBinMinCap) + 1;
+    const int64_t binned = force > 0 ? 0 : sumP / kBinShare;
+    l.rec = off; off = align256(off + ((int64_t)(l.nbins - 1) * (binned + 2 * O * per_grid_extra) + 2 * sumP) * 16);
+  }
   l.total = off;
   return l;
 }
@@ -1713,6 +1782,8 @@ IccArgs make_args(const mfIccBatch *b, void *ws) {
   a.hmax = ksize_host(b->voxel_threshold) / 2;
   a.bin_cnt = (uint32_t *)(p + l.bin_cnt);
   a.bin_cap = (int32_t *)(p + l.bin_cap);
+  a.bin_pts = (int32_t *)(p + l.bin_pts);
+  a.bin_cap_force = icc_bin_cap_force();
   a.bin_base = (int64_t *)(p + l.bin_base);
   a.rec = (float4 *)(p + l.rec);
   return a;
@@ -1782,6 +1853,10 @@ static int icc_validate(const mfIccBatch *b) {
 }
 
 extern "C" int mf_icc_debug_stamps(unsigned long long *host_out, int n) {
+  if (!MF_ICC_DEBUG_BUILD) {
+    mf::set_last_error(hipErrorInvalidValue, "mf_icc_debug_stamps: build with `make ICC_DEBUG=1`");
+    return -(int)hipErrorInvalidValue;
+  }
   return -(int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg_stamps), sizeof(unsigned long long) * n);
 }
 
@@ -1875,6 +1950,7 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
   int dev = 0;
   MF_TRY(hipGetDevice(&dev));
   key.v.push_back(((uint64_t)(uint32_t)dev << 32) | ((uint32_t)max_ns << 1) | (uint32_t)a.ne_binary);
+  key.v.push_back((uint64_t)(uint32_t)a.bin_cap_force);
 
   std::lock_guard<std::mutex> lock(g_graph_mu);
   auto itg = g_graphs.find(key);

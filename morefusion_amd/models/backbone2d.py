@@ -224,7 +224,7 @@ class PSPNetExtractor(nn.Module):
         B, P = pix.shape
         Ho, Wo = 2 * H, 2 * W
         py, px = pix // Wo, pix % Wo  # [B,P]
-        d = torch.tensor([-1, 0, 1], device=pix.device)
+        d = torch.arange(-1, 2, device=pix.device)  # (a device-side arange: safe under hipGraph capture)
         yy = (py[:, :, None, None] + d[None, None, :, None]).expand(B, P, 3, 3).reshape(B, P * 9)
         xx = (px[:, :, None, None] + d[None, None, None, :]).expand(B, P, 3, 3).reshape(B, P * 9)
         valid = (yy >= 0) & (yy < Ho) & (xx >= 0) & (xx < Wo)  # zero padding of the 3x3 conv

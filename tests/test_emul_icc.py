@@ -204,3 +204,32 @@ def test_icc_kernel_source_vs_reference_link_executed(lib, fixtures3, sp, n, off
     wq, wt = gg[f"icc_gq_n{n}_off{off}"], gg[f"icc_gt_n{n}_off{off}"]
     np.testing.assert_allclose(gq, wq, rtol=2e-3, atol=3e-4 * float(np.abs(wq).max()))
     np.testing.assert_allclose(gt, wt, rtol=2e-3, atol=3e-4 * float(np.abs(wt).max()))
+
+
+def test_icc_bin_overflow_list_gives_the_same_bits(lib, fixtures3, sp, monkeypatch):
+    """Compact bins: a bin holds max(64, P_g / 8) records, the rest of a crowded bin goes to the grid's overflow
+    list, which every tile of the grid scans with the bin-membership test.  Winners are exact (lowest-id ties)
+    and the sums are fixed point, so WHERE a record is stored cannot change a bit: with the capacity forced
+    down to 3 records per bin (MF_ICC_BIN_CAP, nearly everything overflows) loss, gradients and a 3-iteration
+    refinement equal the default layout's bit for bit -- and the workspace is O(N * sum P)."""
+    sc = synthetic.make_icc_scene(3, seed=2, fixtures=fixtures3)
+    q0, t0 = _pose0(sc)
+
+    def run():
+        S = emul.EmulIccScenes(lib, [_dict(sc)], sdf_offset=0.02, single_pass=sp)
+        out = S.loss_grad(q0, t0)
+        q, t = q0.copy(), t0.copy()
+        m, v = np.zeros((3, 7), np.float32), np.zeros((3, 7), np.float32)
+        losses = np.zeros((3, 1), np.float32)
+        S.refine(q, t, m, v, 3, losses=losses)
+        return out + (q, t, losses), S.ws.nbytes
+
+    ref, nbytes = run()
+    monkeypatch.setenv("MF_ICC_BIN_CAP", "3")
+    got, _ = run()
+    for a_, b_ in zip(ref, got):
+        np.testing.assert_array_equal(a_, b_)
+    assert np.abs(ref[1]).sum() > 0
+    # round 2 reserved nbins * Ns * sum(P) records: 68 * 3 * P * 16 B
+    P = sum(p.shape[0] for p in sc["points"])
+    assert nbytes < 0.4 * 68 * 3 * P * 16 + 2 * 3 * 32 ** 3 * 8 + (1 << 20)

@@ -153,6 +153,29 @@ def test_icc_refine_is_bitwise_reproducible(scene8):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("general", [False, True], ids=["single_pass", "two_kernel"])
+def test_icc_compact_bins_overflow_list_gives_the_same_bits(scene8, monkeypatch, general):
+    """Compact bins (a bin holds max(64, P_g / 8) records; the excess goes to the grid's overflow list that its
+    tiles scan with the membership test): forcing the capacity down to 5 records per bin -- nearly every record
+    overflows -- must not change one bit of a 20-iteration refinement, and the workspace of the 8-object
+    scene is an order of magnitude below round 2's nbins x Ns x sum(P) x 16 B (242 MB)."""
+    if general:
+        monkeypatch.setenv("MF_ICC_GENERAL", "1")
+    args = to_dev(scene_args(scene8, 8))
+    outs, sizes = [], []
+    for cap in (None, "5"):
+        if cap:
+            monkeypatch.setenv("MF_ICC_BIN_CAP", cap)
+        link = mf.contrib.IterativeCollisionCheckLink(scene8["transform_init"], sdf_offset=0.02).to_gpu()
+        losses, _ = link.refine(*args, n_iter=20, return_history=True)
+        outs.append((torch.cat([link.quaternion.data, link.translation.data], 1).cpu().numpy(), losses.cpu().numpy()))
+        sizes.append(link._scenes.ws.numel() if hasattr(link, "_scenes") else None)
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    if sizes[0] is not None:
+        assert sizes[0] < 60e6, sizes
+
+
 def test_icc_multi_scene_batch_equals_single_scenes(fixtures3):
     scenes = [mf.synthetic.make_icc_scene(4, seed=s, fixtures=fixtures3 if s == 0 else None) for s in range(3)]
     dicts = [dict(points=s["points"], sdf=s["sdf"], pitch=s["pitch"], origin=s["origin"],

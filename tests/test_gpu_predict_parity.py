@@ -84,17 +84,21 @@ def _add(points, qa, ta, qb, tb):
     return float(np.linalg.norm(pa - pb, axis=1).mean())
 
 
-@pytest.mark.parametrize("batch", [1, 8])
-def test_predict_end_to_end_vs_cpu_restatement(batch):
+@pytest.mark.parametrize("batch,graphed", [(1, False), (1, True), (8, False)])
+def test_predict_end_to_end_vs_cpu_restatement(batch, graphed):
+    """``graphed``: BASELINE config 2 (batch 1) through ``Model.predict_graphed`` -- the hipGraph replay path."""
     torch.manual_seed(0)
     torch.backends.cudnn.benchmark = False
     model = Model(n_fg_class=21, with_occupancy=True).cuda().eval()
     assert model.sparse_pspnet_tail and model.sparse_conv3  # the shipped inference path
     b = mf.synthetic.make_singleview_batch(batch, seed=7)
     inputs = {k: torch.as_tensor(b[k]).cuda() for k in KEYS}
+    predict = model.predict_graphed if graphed else model.predict
     with torch.no_grad():
-        model.predict(**inputs)  # MIOpen solver choice settles on the first call of a shape
-        rot_g, trans_g, conf_g = (x.cpu() for x in model.predict(**inputs))
+        predict(**inputs)  # MIOpen solver choice settles on the first call of a shape (graphed: capture)
+        rot_g, trans_g, conf_g = (x.cpu() for x in predict(**inputs))
+    if graphed:
+        assert len(model._graphed.entries) == 1
     rot_c, trans_c, conf_c = _cpu_restatement(model, inputs)
 
     assert rot_g.shape == (batch, 1000, 4) and trans_g.shape == (batch, 1000, 3) and conf_g.shape == (batch, 1000)
@@ -118,3 +122,27 @@ def test_predict_end_to_end_vs_cpu_restatement(batch):
             q_gi, t_gi = q_g[i], t_g[i]
         add = _add(cad, q_gi.numpy(), t_gi.numpy(), q_c[i].numpy(), t_c[i].numpy())
         assert add < 1e-4, (i, add)
+
+
+def test_graph_replay_with_new_frames_and_prefetched_selection():
+    """One captured graph serves every frame of its shape: replaying it on other inputs gives what the eager
+    path gives for them, also when the point selection was prefetched on a side stream
+    (``select_points_async``) and when the caller's tensors move to new addresses."""
+    torch.manual_seed(0)
+    torch.backends.cudnn.benchmark = False
+    model = Model(n_fg_class=21, with_occupancy=True).cuda().eval()
+    frames = []
+    for seed in (21, 22, 23):
+        b = mf.synthetic.make_singleview_batch(1, seed=seed)
+        frames.append({k: torch.as_tensor(b[k]).cuda() for k in KEYS})
+    with torch.no_grad():
+        eager = [tuple(x.clone() for x in model.predict(**f)) for f in frames]
+        eager = [tuple(x.clone() for x in model.predict(**f)) for f in frames]   # settled solver choice
+        for i, f in enumerate(frames):
+            pending = model.select_points_async(f["pcd"])
+            got = model.predict_graphed(**f, pix=pending.result())
+            for g, e in zip(got, eager[i]):
+                np.testing.assert_allclose(g.cpu().numpy(), e.cpu().numpy(), rtol=0, atol=2e-5)
+        assert len(model._graphed.entries) == 1    # one shape, one graph
+        # the selection the handle returns is the synchronous one
+        assert torch.equal(model.select_points_async(frames[0]["pcd"]).result(), model._select_points(frames[0]["pcd"]))
