@@ -251,7 +251,7 @@ def roofline_voxelize(wl):
     # HBM bytes per call from the PMC passes committed under profiles/ (separate rocprofv3
     # --pmc FETCH_SIZE / WRITE_SIZE runs of tools/prof_voxelize.py at this exact shape)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_voxelize_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_voxelize_pmc.json")  # this round's kernels only
     if os.path.exists(pmc):
         rec = json.load(open(pmc))
         if rec["shape"] == dict(B=B, P=P, C=C, D=D):
@@ -304,8 +304,8 @@ def roofline_icc(wl, us_per_iter):
     alg = pts_bytes + grid_bytes if single_pass else pts_bytes
     kname = "k_icc_fused" if single_pass else "k_icc_tile"
     achieved = alg / (ms * 1e-3) / 1e9
-    traffic = None  # PMC passes committed under profiles/ (tools/r02_profiles.sh), same scene
-    pmc = os.path.join(ROOT, "profiles", "r02_icc_pmc.json")
+    traffic = None  # PMC passes of THIS round committed under profiles/ (tools/gpu_call.sh pmc=...), same scene; else null
+    pmc = os.path.join(ROOT, "profiles", "r03_icc_pmc.json")  # this round's kernels only
     if os.path.exists(pmc):
         rec = json.load(open(pmc)).get(kname)
         if rec and rec["n_objects"] == icc.n_objects and rec["n_points"] == icc.n_points:
@@ -340,19 +340,66 @@ def handwritten_path(wl, reps=10):
     return t_vol, t_icc
 
 
-def latency_batch1(wl, reps=20):
-    """BASELINE configs[1]: singleview_3d inference at batch = 1 -- latency of one
-    Model.predict call (ms, incl. its one host synchronisation for the point counts)."""
+def latency_batch1(wl, reps=30):
+    """BASELINE configs[1]: singleview_3d inference at batch = 1.  Per-frame latency (ms, host clock around
+    call + device sync, i.e. input ready -> poses ready) of
+      predict            eager launches, incl. the host synchronisation of the point selection;
+      predict_graphed    the same work with everything after the selection replayed from one hipGraph;
+      predict_graphed_prefetched_selection
+                         the deployment loop: frame k+1's valid-pixel selection is issued on a side stream
+                         (select_points_async) before frame k's graph is replayed, so the replay starts
+                         without waiting for the host."""
     one = {k: v[:1].contiguous() for k, v in wl.inputs.items()}
-    with torch.no_grad():
+    m = wl.model
+
+    def per_frame(fn):
         for _ in range(3):
-            wl.model.predict(**one)
+            fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            wl.model.predict(**one)
-        torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps * 1e3
+            fn()
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    out = {}
+    with torch.no_grad():
+        out["predict"] = round(per_frame(lambda: m.predict(**one)), 4)
+        try:
+            out["predict_graphed"] = round(per_frame(lambda: m.predict_graphed(**one, clone=False)), 4)
+            state = {"pend": m.select_points_async(one["pcd"])}
+
+            def frame():
+                pix = state["pend"].result()
+                state["pend"] = m.select_points_async(one["pcd"])   # next frame's selection, side stream
+                m.predict_graphed(**one, pix=pix, clone=False)
+
+            out["predict_graphed_prefetched_selection"] = round(per_frame(frame), 4)
+        except Exception as e:  # a capture failure must not cost the headline line
+            out["predict_graphed_error"] = f"{type(e).__name__}: {e}"[:300]
+    return out
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+
+
+def roofline_conv4(wl, B):
+    """k_conv3d_k4s2_mfma on conv4's shape (256 -> 512 channels, 16^3 -> 8^3, B objects): the largest GEMM of the
+    hand-written volumetric part, timed live with HIP events (split-K slabs + k_conv_finish included)."""
+    m = wl.model
+    if getattr(m, "_volumetric_cl", None) is None:
+        return None
+    vol = m._volumetric_cl
+    h3 = torch.relu(torch.randn(B, 16 ** 3, 256, device=wl.device))
+    with torch.no_grad():
+        ms = time_kernel_live(lambda: vol.conv_k4s2("conv4", m.conv4, h3, B, 16, cin=256), 30)
+    flop = 2.0 * B * 512 * 512 * 64 * 256
+    tf = flop / (ms * 1e-3) / 1e12
+    return dict(kernel="k_conv3d_k4s2_mfma (+ k_conv_finish) on conv4, mf_conv3d_k4s2_fwd", bound="mfma",
+                achieved=round(tf, 1), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, flop_per_launch=flop,
+                avg_launch_ms=round(ms, 5), shape=dict(B=B, Cin=256, Cout=512, D=16),
+                split_k=mf._lib.lib().mf_conv3d_k4s2_default_split(B, 256, 512, 16))
 
 
 def accuracy(wl):
@@ -570,7 +617,9 @@ def main():
         t_vol, t_icc = handwritten_path(wl)
         out["value_handwritten_path"] = round(world * wl.B / ((t_vol + t_icc) / 1e3), 3)
         out["handwritten_path_ms"] = {"volumetric_network_part": round(t_vol, 4), "icc": round(t_icc, 4)}
-        out["latency_batch1_ms"] = {"predict": round(latency_batch1(wl), 4)}
+        out["latency_batch1_ms"] = latency_batch1(wl)
+        out["roofline_conv4"] = roofline_conv4(wl, wl.B)
+        out["roofline_conv4_batch1"] = roofline_conv4(wl, 1)
         out["roofline"] = roofline_icc(wl, t_icc * 1e3 / args.icc_iters)  # all scenes share the launches
         out["roofline_voxelize"] = roofline_voxelize(wl)
         out["accuracy"] = accuracy(wl)

@@ -331,6 +331,18 @@ int mf_interpolate_voxel_grid_cl_fwd(const float *vox, const float *points, cons
 int mf_occupancy_convs_fwd(const float *grid, const float *w1, const float *b1, const float *w2,
                            const float *b2, float *h1, float *h2, int32_t B, int32_t D, mfStream_t stream);
 
+/* ---- per-point 1x1 convolutions (heads, point MLP) as row-major fp32-MFMA GEMMs ---------------
+ * replaces the cuDNN Convolution1D(k = 1) chains at
+ *   morefusion/contrib/singleview_3d/models/model.py:76-91,245-262 (three heads: 984-640-256-128-n_fg*c)
+ * on points-major activations:  out[m][n] = act( sum_k A[m][k] * W[n][k] + bias[n] ),  m < M, n < N.
+ *   A [M, lda], W [Npad, ldw] (Convolution1D's W[:, :, 0], zero rows up to Npad % 128 == 0), out [M, ldo];
+ *   `groups` independent problems per launch at the given element strides (heads side by side, each
+ *   reading / writing its own column block); K % 4 == 0 (no multiple of 32 needed); relu != 0: max(., 0). */
+int mf_linear_fwd(const float *A, int64_t a_group_stride, int32_t lda, const float *W, int64_t w_group_stride,
+                  int32_t ldw, const float *bias, int64_t b_group_stride, float *out, int64_t o_group_stride,
+                  int32_t ldo, int32_t M, int32_t N, int32_t Npad, int32_t K, int32_t groups, int32_t relu,
+                  mfStream_t stream);
+
 /* small fused helpers of the same path */
 /* pack [Ptot,3] points + [Ptot] sdf into float4 */
 int mf_pack_points_sdf(const float *points, const float *sdf, int64_t n, void *pts4,

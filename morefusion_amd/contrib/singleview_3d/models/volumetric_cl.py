@@ -3,7 +3,7 @@
 Restates morefusion/contrib/singleview_3d/models/model.py:93-164,232-275 (``_extract`` + the three
 per-point heads) for ``torch.no_grad()`` on the MI355X with every 3-D operator hand-written:
 
-  point MLP (conv1/2_rgb, conv1/2_pcd: stock GEMMs on [n, C] rows, n = B * P)
+  point MLP          conv1/2_rgb, conv1/2_pcd through mf_linear_fwd, written into F's column blocks
   occupancy branch   mf_occupancy_convs_fwd            (csrc/conv3d.hip, VALU, scalar weights)
   conv3              mf_conv3d_k4s2_fwd on the 16 occupancy channels (fp32 MFMA implicit GEMM)
                      + mf_sparse_conv3d_k4s2_points_cl_fwd on the 144 voxelized channels
@@ -11,7 +11,9 @@ per-point heads) for ``torch.no_grad()`` on the MI355X with every 3-D operator h
   conv4              mf_conv3d_k4s2_fwd (256 -> 512, split-K, bias + ReLU in the finish pass)
   trilinear sampling mf_interpolate_voxel_grid_cl_fwd x2, written straight into the column blocks
                      [216:472] and [472:984] of the heads' input matrix F [n, 984]
-  heads              stock GEMMs on F (row-major [n, C]: ``F.linear``)
+  heads              mf_linear_fwd (csrc/linear.hip: grouped fp32-MFMA GEMM + bias + ReLU): layer 1 of the three
+                     heads as ONE [n, 984] x [984, 1920] GEMM, layers 2-4 with the heads side by side, each
+                     reading / writing its column block (under bf16 autocast: stock ``F.linear``)
 
 Grids are [B, D^3, C] (a voxel's channels are contiguous: the implicit GEMM's K runs over
 (tap, channel) without gathers, and a trilinear corner is one coalesced row read); nothing is
@@ -34,6 +36,7 @@ class ChannelsLastVolumetric:
         self._packs = {}
         self._buf = {}
         self._sparse = SparseVoxelConv3d(model.conv3)
+        self.mfma_linear = True  # 1x1 convolutions on csrc/linear.hip (False: stock F.linear)
 
     # ---- cached weight packs (re-packed when a parameter changes in place or is re-assigned) ----
     def _pack(self, name, tensors, build):
@@ -127,16 +130,25 @@ class ChannelsLastVolumetric:
         batch_indices = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(P)
         feat = torch.empty((n, 984), dtype=torch.float32, device=dev)
 
-        w, b = self._linear_pack("conv1_rgb", m.conv1_rgb)
-        h_rgb = F.relu(F.linear(x_rgb, w, b))
-        w, b = self._linear_pack("conv1_pcd", m.conv1_pcd)
-        h_pcd = F.relu(F.linear(to_center.to(x_rgb.dtype), w, b))
-        feat[:, 0:64] = h_rgb
-        feat[:, 64:72] = h_pcd
-        w, b = self._linear_pack("conv2_rgb", m.conv2_rgb)
-        feat[:, 72:200] = F.relu(F.linear(h_rgb, w, b))
-        w, b = self._linear_pack("conv2_pcd", m.conv2_pcd)
-        feat[:, 200:216] = F.relu(F.linear(h_pcd, w, b))
+        if self.mfma_linear and not torch.is_autocast_enabled():
+            x_rgb = x_rgb.float().contiguous()
+            tc4 = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+            tc4[:, :3] = to_center
+            self._linear("conv1_rgb", [m.conv1_rgb], x_rgb, 32, feat[:, 0:64], 984, relu=True)
+            self._linear("conv1_pcd", [m.conv1_pcd], tc4, 4, feat[:, 64:72], 984, relu=True, k_pad=4)
+            self._linear("conv2_rgb", [m.conv2_rgb], feat[:, 0:64], 984, feat[:, 72:200], 984, relu=True)
+            self._linear("conv2_pcd", [m.conv2_pcd], feat[:, 64:72], 984, feat[:, 200:216], 984, relu=True)
+        else:
+            w, b = self._linear_pack("conv1_rgb", m.conv1_rgb)
+            h_rgb = F.relu(F.linear(x_rgb, w, b))
+            w, b = self._linear_pack("conv1_pcd", m.conv1_pcd)
+            h_pcd = F.relu(F.linear(to_center.to(x_rgb.dtype), w, b))
+            feat[:, 0:64] = h_rgb
+            feat[:, 64:72] = h_pcd
+            w, b = self._linear_pack("conv2_rgb", m.conv2_rgb)
+            feat[:, 72:200] = F.relu(F.linear(h_rgb, w, b))
+            w, b = self._linear_pack("conv2_pcd", m.conv2_pcd)
+            feat[:, 200:216] = F.relu(F.linear(h_pcd, w, b))
 
         # conv3 = dense 16 occupancy channels (implicit GEMM) + sparse 144 voxelized channels
         dense = None
@@ -149,17 +161,88 @@ class ChannelsLastVolumetric:
         self.sample(h4, D // 4, pts / 4.0, batch_indices, feat[:, 472:984], 984)
         return feat
 
+    # ---- 1x1 convolutions as grouped fp32-MFMA GEMMs -------------------------------------------
+    def _gemm_pack(self, name, convs, k_pad=None):
+        """Weights of the ``convs`` (one per group; equal shapes) as [G, Npad, K] (zero rows up to Npad % 128
+        == 0, zero columns up to k_pad), biases [G, N]."""
+        def build():
+            ws, bs = [], []
+            for c in convs:
+                w = c.weight.detach().float().squeeze(-1)
+                N, K = w.shape
+                Kp = k_pad or K
+                Np = -(-N // 128) * 128
+                wp = torch.zeros((Np, Kp), dtype=torch.float32, device=w.device)
+                wp[:N, :K] = w
+                ws.append(wp)
+                bs.append(c.bias.detach().float())
+            return torch.stack(ws).contiguous(), torch.stack(bs).contiguous()
+        return self._pack("gemm_" + name, [t for c in convs for t in (c.weight, c.bias)], build)
+
+    def _linear(self, name, convs, a, lda, out, ldo, relu, k_pad=None, a_gs=0, o_gs=0):
+        """out[:, g-th block] = act(a[:, g-th block] @ W_g^T + b_g) for every conv of ``convs`` in one launch.
+        ``a`` / ``out``: views whose first element is the first group's block; group g starts a_gs / o_gs
+        floats further; row pitches lda / ldo."""
+        w, b = self._gemm_pack(name, convs, k_pad)
+        G, Np, K = w.shape
+        N = b.shape[1]
+        _lib.check(_lib.lib().mf_linear_fwd(a.data_ptr(), a_gs, lda, w.data_ptr(), Np * K, K, b.data_ptr(), N,
+                                            out.data_ptr(), o_gs, ldo, a.shape[0], N, Np, K, G, int(relu),
+                                            _lib.stream_ptr()), "mf_linear_fwd")
+
     def heads(self, feat, B, P):
         """F [B*P, 984] -> per-point class outputs rot [B,P,n_fg,4], trans [B,P,n_fg,3], conf [B,P,n_fg]."""
         m = self.m
+        nf = m._n_fg_class
+        names = ("rot", "trans", "conf")
+        if self.mfma_linear and not torch.is_autocast_enabled() and feat.dtype == torch.float32:
+            n, dev = feat.shape[0], feat.device
+            # layer 1 of the three heads = one GEMM against the stacked weights [1920, 984]
+            def build1():
+                w = torch.cat([getattr(m, f"conv1_{k}").weight.detach().float().squeeze(-1) for k in names])
+                b = torch.cat([getattr(m, f"conv1_{k}").bias.detach().float() for k in names])
+                return w.contiguous()[None], b.contiguous()[None]
+            w1, b1 = self._pack("gemm_heads1", [t for k in names for t in (getattr(m, f"conv1_{k}").weight,
+                                                                            getattr(m, f"conv1_{k}").bias)], build1)
+            h1 = self._scratch("heads_h1", (n, 1920), dev)
+            h2 = self._scratch("heads_h2", (n, 768), dev)
+            h3 = self._scratch("heads_h3", (n, 384), dev)
+            np4 = -(-(nf * 4) // 128) * 128
+            o = torch.empty((n, 3 * np4), dtype=torch.float32, device=dev)
+            L = _lib.lib()
+            _lib.check(L.mf_linear_fwd(feat.data_ptr(), 0, feat.stride(0), w1.data_ptr(), 0, 984, b1.data_ptr(), 0,
+                                       h1.data_ptr(), 0, 1920, n, 1920, 1920, 984, 1, 1, _lib.stream_ptr()),
+                       "mf_linear_fwd")
+            self._linear("heads2", [getattr(m, f"conv2_{k}") for k in names], h1, 1920, h2, 768, True, a_gs=640, o_gs=256)
+            self._linear("heads3", [getattr(m, f"conv3_{k}") for k in names], h2, 768, h3, 384, True, a_gs=256, o_gs=128)
+            # layer 4: N = n_fg * {4, 3, 1} -> pad every head to the widest (equal shapes per launch)
+            w4, b4 = self._pack("gemm_heads4", [t for k in names for t in (getattr(m, f"conv4_{k}").weight,
+                                                                           getattr(m, f"conv4_{k}").bias)],
+                                lambda: self._pad_heads4(names, nf, np4))
+            _lib.check(L.mf_linear_fwd(h3.data_ptr(), 128, 384, w4.data_ptr(), np4 * 128, 128, b4.data_ptr(), np4,
+                                       o.data_ptr(), np4, 3 * np4, n, np4, np4, 128, 3, 0, _lib.stream_ptr()),
+                       "mf_linear_fwd")
+            rot = o[:, 0:nf * 4].reshape(B, P, nf, 4)
+            trans = o[:, np4:np4 + nf * 3].reshape(B, P, nf, 3)
+            conf = torch.sigmoid(o[:, 2 * np4:2 * np4 + nf]).reshape(B, P, nf)
+            return rot, trans, conf
         outs = {}
-        for name in ("rot", "trans", "conf"):
+        for name in names:
             x = feat
             for i in (1, 2, 3):
                 w, b = self._linear_pack(f"conv{i}_{name}", getattr(m, f"conv{i}_{name}"))
                 x = F.relu(F.linear(x, w, b))
             w, b = self._linear_pack(f"conv4_{name}", getattr(m, f"conv4_{name}"))
             outs[name] = F.linear(x, w, b).float()
-        nf = m._n_fg_class
         return (outs["rot"].reshape(B, P, nf, 4), outs["trans"].reshape(B, P, nf, 3),
                 torch.sigmoid(outs["conf"]).reshape(B, P, nf))
+
+    def _pad_heads4(self, names, nf, np4):
+        m = self.m
+        w = torch.zeros((3, np4, 128), dtype=torch.float32, device=m.conv4_rot.weight.device)
+        b = torch.zeros((3, np4), dtype=torch.float32, device=w.device)
+        for g, k in enumerate(names):
+            c = getattr(m, f"conv4_{k}")
+            w[g, :c.out_channels] = c.weight.detach().float().squeeze(-1)
+            b[g, :c.out_channels] = c.bias.detach().float()
+        return w.contiguous(), b.contiguous()

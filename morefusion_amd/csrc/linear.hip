@@ -1,0 +1,184 @@
+// Row-major fp32 GEMM with a fused bias + ReLU epilogue on v_mfma_f32_32x32x2_f32, for gfx950.
+//
+// Reference: the per-point 1x1 convolutions of the pose network -- `L.Convolution1D(c_in, c_out, 1)` x 4
+// in each of the three heads (contrib/singleview_3d/models/model.py:76-91,245-262: 984 -> 640 -> 256 -> 128
+// -> n_fg * {4,3,1}, ReLU between) and the point MLP in front of the voxelization (:59-66,101-111).  On
+// points-major activations ([n points, channels], n = B * 1000) a 1x1 convolution is
+//     out[m][n] = act( sum_k A[m][k] * W[n][k] + bias[n] ),
+// 5.0 GFLOP per object for the heads.
+//
+// Same tile machinery as csrc/conv3d.hip (128 x 128 x 32 per 256-lane workgroup, 2 x 2 accumulators of
+// 32 x 32 per wave, k-contiguous LDS rows of pitch 36 read with one conflict-free ds_read_b128 per
+// fragment, register-staged double buffering); the A operand is a plain matrix with a row pitch, so a
+// layer reads its input in place from a column block of a wider activation matrix and writes its output
+// into one (`groups` independent GEMMs per launch: the three heads' layers 2-4 run side by side).
+// K need not be a multiple of 32 (984): chunks of 4 beyond K load zeros.  W rows beyond N (the caller
+// pads W to a multiple of 128 rows) are computed and not stored.
+#include "mf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBM = 128, kBN = 128, kBK = 32;
+constexpr int kPitch = kBK + 4;
+constexpr int kTileFloats = (kBM + kBN) * kPitch;
+constexpr int kLinLds = 2 * kTileFloats * (int)sizeof(float);
+
+struct LinArgs {
+  const float *A;     // [M][lda], group g at A + g * a_gs
+  const float *W;     // [Npad][ldw] (k-contiguous rows), group g at W + g * w_gs
+  const float *bias;  // [N] or null, group g at bias + g * b_gs
+  float *out;         // [M][ldo], group g at out + g * o_gs
+  int64_t a_gs, w_gs, b_gs, o_gs;
+  int M, N, Npad, K, lda, ldw, ldo, groups, relu;
+};
+
+
+__global__ __launch_bounds__(256, 2) void k_linear_mfma(LinArgs a) {
+  MF_DYN_LDS(float, s_mem);
+  const int tiles_m = (a.M + kBM - 1) / kBM, tiles_n = a.Npad / kBN;
+  const int per_group = tiles_m * tiles_n;
+  // XCD-aware order as in conv3d.hip: an XCD gets a contiguous range of (group, N tile, M tile)
+  const int G = gridDim.x;
+  int L = blockIdx.x;
+  if ((G & 7) == 0) L = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int grp = L / per_group;
+  const int rem = L - grp * per_group;
+  const int m0 = (rem % tiles_m) * kBM, n0 = (rem / tiles_m) * kBN;
+  const float *A = a.A + grp * a.a_gs, *W = a.W + grp * a.w_gs;
+  const int T = (a.K + kBK - 1) / kBK;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  const int chunk = tid & 7, r0 = tid >> 3;
+
+  const float *arow[4], *wrow[4];
+  bool aok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    aok[i] = m < a.M;
+    arow[i] = A + (int64_t)(aok[i] ? m : 0) * a.lda + 4 * chunk;
+    wrow[i] = W + (int64_t)(n0 + r0 + 32 * i) * a.ldw + 4 * chunk;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // a chunk past K reads the row's first chunk (mapped, cached) and selects zeros
+#define MF_LIN_FETCH(kt_)                                                                         \
+  {                                                                                               \
+    const int ko = (kt_) * kBK;                                                                   \
+    const bool kin = ko + 4 * chunk + 4 <= a.K;                                                   \
+    const int kq = kin ? ko : 0;                                                                  \
+    ra0 = *reinterpret_cast<const float4 *>(arow[0] + kq);                                        \
+    ra1 = *reinterpret_cast<const float4 *>(arow[1] + kq);                                        \
+    ra2 = *reinterpret_cast<const float4 *>(arow[2] + kq);                                        \
+    ra3 = *reinterpret_cast<const float4 *>(arow[3] + kq);                                        \
+    rb0 = *reinterpret_cast<const float4 *>(wrow[0] + kq);                                        \
+    rb1 = *reinterpret_cast<const float4 *>(wrow[1] + kq);                                        \
+    rb2 = *reinterpret_cast<const float4 *>(wrow[2] + kq);                                        \
+    rb3 = *reinterpret_cast<const float4 *>(wrow[3] + kq);                                        \
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                         \
+    if (!(kin && aok[0])) ra0 = z;                                                                \
+    if (!(kin && aok[1])) ra1 = z;                                                                \
+    if (!(kin && aok[2])) ra2 = z;                                                                \
+    if (!(kin && aok[3])) ra3 = z;                                                                \
+    if (!kin) { rb0 = z; rb1 = z; rb2 = z; rb3 = z; }                                             \
+  }
+#define MF_LIN_STASH(buf_)                                                                        \
+  {                                                                                               \
+    float *As_ = s_mem + (buf_) * kTileFloats + r0 * kPitch + 4 * chunk;                          \
+    float *Bs_ = As_ + kBM * kPitch;                                                              \
+    *reinterpret_cast<float4 *>(As_) = ra0;                                                       \
+    *reinterpret_cast<float4 *>(As_ + 32 * kPitch) = ra1;                                         \
+    *reinterpret_cast<float4 *>(As_ + 64 * kPitch) = ra2;                                         \
+    *reinterpret_cast<float4 *>(As_ + 96 * kPitch) = ra3;                                         \
+    *reinterpret_cast<float4 *>(Bs_) = rb0;                                                       \
+    *reinterpret_cast<float4 *>(Bs_ + 32 * kPitch) = rb1;                                         \
+    *reinterpret_cast<float4 *>(Bs_ + 64 * kPitch) = rb2;                                         \
+    *reinterpret_cast<float4 *>(Bs_ + 96 * kPitch) = rb3;                                         \
+  }
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  MF_LIN_FETCH(0);
+  MF_LIN_STASH(0);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    MF_LIN_FETCH(t + 1 < T ? t + 1 : t);
+    asm volatile("" ::: "memory");  // keep the eight loads in front of the MFMAs (see conv3d.hip)
+    __builtin_amdgcn_sched_barrier(0);
+    const float *As = s_mem + (t & 1) * kTileFloats + (wm * 64 + lrow) * kPitch + 4 * lhalf;
+    const float *Bs = s_mem + (t & 1) * kTileFloats + (kBM + wn * 64 + lrow) * kPitch + 4 * lhalf;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float4 a0 = *reinterpret_cast<const float4 *>(As + 8 * kk);
+      const float4 a1 = *reinterpret_cast<const float4 *>(As + 32 * kPitch + 8 * kk);
+      const float4 b0 = *reinterpret_cast<const float4 *>(Bs + 8 * kk);
+      const float4 b1 = *reinterpret_cast<const float4 *>(Bs + 32 * kPitch + 8 * kk);
+#define MF_LIN_STEP(c_)                                                                           \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c_, b0.c_, acc[0][0], 0, 0, 0);         \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c_, b1.c_, acc[0][1], 0, 0, 0);         \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c_, b0.c_, acc[1][0], 0, 0, 0);         \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c_, b1.c_, acc[1][1], 0, 0, 0);
+      MF_LIN_STEP(x)
+      MF_LIN_STEP(y)
+      MF_LIN_STEP(z)
+      MF_LIN_STEP(w)
+#undef MF_LIN_STEP
+    }
+    MF_LIN_STASH((t + 1) & 1);
+    __syncthreads();
+  }
+#undef MF_LIN_FETCH
+#undef MF_LIN_STASH
+
+  float *dst = a.out + grp * a.o_gs;
+  const float *bias = a.bias ? a.bias + grp * a.b_gs : nullptr;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 64 + ni * 32 + lrow;
+      if (n >= a.N) continue;
+      const float bn = bias ? bias[n] : 0.0f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+        if (m >= a.M) continue;
+        float v = acc[mi][ni][e] + bn;
+        if (a.relu) v = v > 0.0f ? v : 0.0f;
+        dst[(int64_t)m * a.ldo + n] = v;
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int mf_linear_fwd(const float *A, int64_t a_group_stride, int32_t lda, const float *W,
+                             int64_t w_group_stride, int32_t ldw, const float *bias, int64_t b_group_stride,
+                             float *out, int64_t o_group_stride, int32_t ldo, int32_t M, int32_t N, int32_t Npad,
+                             int32_t K, int32_t groups, int32_t relu, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M <= 0 || N <= 0 || groups <= 0) return 0;
+  if (K <= 0 || K % 4 || lda % 4 || ldw % 4 || a_group_stride % 4 || w_group_stride % 4 || Npad % kBN || Npad < N ||
+      lda < K || ldw < K || ldo < N || (((uintptr_t)A | (uintptr_t)W) & 15)) {
+    mf::set_last_error(hipErrorInvalidValue,
+                       "linear: need K, lda, ldw, group strides % 4 == 0, 16-byte aligned A / W, W padded to Npad % 128 == 0 rows");
+    return -(int)hipErrorInvalidValue;
+  }
+  if (int e = mf::allow_big_lds((const void *)k_linear_mfma, kLinLds)) return e;
+  LinArgs a;
+  a.A = A; a.W = W; a.bias = bias; a.out = out;
+  a.a_gs = a_group_stride; a.w_gs = w_group_stride; a.b_gs = b_group_stride; a.o_gs = o_group_stride;
+  a.M = M; a.N = N; a.Npad = Npad; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.groups = groups; a.relu = relu;
+  const int64_t grid = (int64_t)((M + kBM - 1) / kBM) * (Npad / kBN) * groups;
+  hipLaunchKernelGGL(k_linear_mfma, dim3((unsigned)grid), dim3(256), kLinLds, stream, a);
+  return mf::check_launch("mf_linear_fwd");
+}

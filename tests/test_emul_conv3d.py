@@ -124,3 +124,31 @@ def test_occupancy_convs_match_torch(lib):
     np.testing.assert_allclose(h1.reshape(B, D, D, D, 8).transpose(0, 4, 1, 2, 3), t1.numpy(), atol=2e-6)
     np.testing.assert_allclose(h2.reshape(B, D, D, D, 16).transpose(0, 4, 1, 2, 3), t2.numpy(), atol=5e-6)
     assert (h2 > 0).mean() > 0.2
+
+
+def test_linear_mfma_gemm_vs_float64():
+    """csrc/linear.hip: grouped row-major GEMM + bias + ReLU (the heads' 1x1 convolutions on points-major rows):
+    K not a multiple of 32, M not a multiple of 128, N < Npad, column-block inputs / outputs, two groups."""
+    L = emul.build(["linear.hip"])
+    i32, i64, p = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+    L.mf_linear_fwd.argtypes = [p, i64, i32, p, i64, i32, p, i64, p, i64] + [i32] * 7 + [p]
+    rs = np.random.RandomState(4)
+    M, K, N, Npad, groups = 150, 72, 84, 128, 2
+    lda, ldo = 200, 300
+    A = rs.uniform(-1, 1, (M, lda)).astype(np.float32)      # group g reads columns [8 + 80 g, 8 + 80 g + K)
+    W = np.zeros((groups, Npad, K), np.float32)
+    W[:, :N] = rs.uniform(-1, 1, (groups, N, K)) / np.sqrt(K)
+    bias = rs.uniform(-0.3, 0.3, (groups, N)).astype(np.float32)
+    out = np.full((M, ldo), 9.0, np.float32)                 # group g writes columns [4 + 100 g, 4 + 100 g + N)
+    for relu in (1, 0):
+        out[:] = 9.0
+        assert L.mf_linear_fwd(A[:, 8:].ctypes.data, 80, lda, emul.ptr(W), Npad * K, K, emul.ptr(bias), N,
+                               out[:, 4:].ctypes.data, 100, ldo, M, N, Npad, K, groups, relu, None) == 0
+        for g in range(groups):
+            ref = A[:, 8 + 80 * g:8 + 80 * g + K].astype(np.float64) @ W[g, :N].astype(np.float64).T + bias[g]
+            if relu:
+                ref = np.maximum(ref, 0)
+            np.testing.assert_allclose(out[:, 4 + 100 * g:4 + 100 * g + N], ref, rtol=0, atol=2e-6)
+        assert (out[:, :4] == 9.0).all() and (out[:, 4 + N:104] == 9.0).all() and (out[:, 104 + N:] == 9.0).all()
+    z = np.zeros(8, np.float32)
+    assert L.mf_linear_fwd(emul.ptr(z), 0, 8, emul.ptr(z), 0, 8, None, 0, emul.ptr(z), 0, 8, 1, 1, 100, 8, 1, 0, None) != 0

@@ -22,7 +22,7 @@ def test_channels_last_volumetric_path_matches_dense_formulation(monkeypatch):
     import morefusion_amd.contrib.singleview_3d.models.model as model_mod
     from morefusion_amd.contrib.singleview_3d.models import Model
 
-    L = emul.build(["conv3d.hip", "sparseconv.hip", "interp.hip"])
+    L = emul.build(["conv3d.hip", "sparseconv.hip", "interp.hip", "linear.hip"])
     for name, (argtypes, restype) in _lib._SIGNATURES.items():
         fn = getattr(L, name, None)
         if fn is not None:
