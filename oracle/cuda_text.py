@@ -36,6 +36,11 @@ import subprocess
 import numpy as np
 
 _CACHE = os.environ.get("MF_CUDA_TEXT_CACHE", "/tmp/mf_cuda_text")
+# "off" (default): the C meaning of the text, one rounding per operation -- what the goldens are made with.
+# "fast": the OTHER legal compilation -- a*b+c contracted into fused multiply-adds wherever the compiler sees
+# one (g++ -ffp-contract=fast -mfma), as nvcc does by default (-fmad=true).  oracle/gen_golden_cuda_fma.py
+# regenerates every CUDA-text golden in this mode and records which outputs move.
+FP_CONTRACT = os.environ.get("MF_CUDA_TEXT_CONTRACT", "off")
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _EMUL = os.path.join(os.path.dirname(_HERE), "tests", "host_emul")
 
@@ -68,13 +73,15 @@ struct IndexerStub { long long n; long long size() const { return n; } };
 
 def _compile(src, tag, extra=()):
     os.makedirs(_CACHE, exist_ok=True)
-    h = hashlib.sha1((src + "|".join(extra)).encode()).hexdigest()[:16]
+    # (g++ forms FMAs in its widening_mul pass, which -O1 does not run: the contracted fork is built at -O2)
+    fp = ["-ffp-contract=off"] if FP_CONTRACT == "off" else [f"-ffp-contract={FP_CONTRACT}", "-mfma", "-O2"]
+    h = hashlib.sha1((src + "|".join(extra) + "|".join(fp)).encode()).hexdigest()[:16]
     so = os.path.join(_CACHE, f"{tag}_{h}.so")
     if not os.path.exists(so):
         cpp = so[:-3] + ".cpp"
         with open(cpp, "w") as f:
             f.write(src)
-        cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w", *extra, "-o", so, cpp]
+        cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", *fp, "-w", *extra, "-o", so, cpp]
         subprocess.run(cmd, check=True)
     return ctypes.CDLL(so)
 
