@@ -20,10 +20,12 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBM = 128, kBN = 128, kBK = 32;
+constexpr int kBN = 128, kBK = 32;
 constexpr int kPitch = kBK + 4;
-constexpr int kTileFloats = (kBM + kBN) * kPitch;
-constexpr int kLinLds = 2 * kTileFloats * (int)sizeof(float);
+// MI = 32-row accumulator blocks per wave along M: 2 -> 128 x 128 tiles, 1 -> 64 x 128 tiles (small M: batch 1
+// has 1000 rows = 8 tiles of 128; the half-height tile doubles the workgroups that share the chip)
+template <int MI> constexpr int tile_floats() { return (64 * MI + kBN) * kPitch; }
+template <int MI> constexpr int lin_lds() { return 2 * tile_floats<MI>() * (int)sizeof(float); }
 
 struct LinArgs {
   const float *A;     // [M][lda], group g at A + g * a_gs
@@ -35,8 +37,10 @@ struct LinArgs {
 };
 
 
+template <int MI>
 __global__ __launch_bounds__(256, 2) void k_linear_mfma(LinArgs a) {
   MF_DYN_LDS(float, s_mem);
+  constexpr int kBM = 64 * MI, kTileFloats = tile_floats<MI>();
   const int tiles_m = (a.M + kBM - 1) / kBM, tiles_n = a.Npad / kBN;
   const int per_group = tiles_m * tiles_n;
   // XCD-aware order as in conv3d.hip: an XCD gets a contiguous range of (group, N tile, M tile)
@@ -59,29 +63,31 @@ __global__ __launch_bounds__(256, 2) void k_linear_mfma(LinArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + r0 + 32 * i;
-    aok[i] = m < a.M;
-    arow[i] = A + (int64_t)(aok[i] ? m : 0) * a.lda + 4 * chunk;
-    wrow[i] = W + (int64_t)(n0 + r0 + 32 * i) * a.ldw + 4 * chunk;
+    aok[i] = m < a.M && i < 2 * MI;
+    arow[i] = A + (int64_t)(aok[i] ? m : 0) * a.lda;
+    wrow[i] = W + (int64_t)(n0 + r0 + 32 * i) * a.ldw;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  // a chunk past K reads the row's first chunk (mapped, cached) and selects zeros
+  // a chunk past K reads the row's FIRST chunk (always inside the matrix) and selects zeros
 #define MF_LIN_FETCH(kt_)                                                                         \
   {                                                                                               \
     const int ko = (kt_) * kBK;                                                                   \
     const bool kin = ko + 4 * chunk + 4 <= a.K;                                                   \
-    const int kq = kin ? ko : 0;                                                                  \
+    const int kq = kin ? ko + 4 * chunk : 0;                                                      \
     ra0 = *reinterpret_cast<const float4 *>(arow[0] + kq);                                        \
     ra1 = *reinterpret_cast<const float4 *>(arow[1] + kq);                                        \
-    ra2 = *reinterpret_cast<const float4 *>(arow[2] + kq);                                        \
-    ra3 = *reinterpret_cast<const float4 *>(arow[3] + kq);                                        \
+    if constexpr (MI == 2) {                                                                      \
+      ra2 = *reinterpret_cast<const float4 *>(arow[2] + kq);                                      \
+      ra3 = *reinterpret_cast<const float4 *>(arow[3] + kq);                                      \
+    }                                                                                             \
     rb0 = *reinterpret_cast<const float4 *>(wrow[0] + kq);                                        \
     rb1 = *reinterpret_cast<const float4 *>(wrow[1] + kq);                                        \
     rb2 = *reinterpret_cast<const float4 *>(wrow[2] + kq);                                        \
@@ -99,14 +105,16 @@ __global__ __launch_bounds__(256, 2) void k_linear_mfma(LinArgs a) {
     float *Bs_ = As_ + kBM * kPitch;                                                              \
     *reinterpret_cast<float4 *>(As_) = ra0;                                                       \
     *reinterpret_cast<float4 *>(As_ + 32 * kPitch) = ra1;                                         \
-    *reinterpret_cast<float4 *>(As_ + 64 * kPitch) = ra2;                                         \
-    *reinterpret_cast<float4 *>(As_ + 96 * kPitch) = ra3;                                         \
+    if constexpr (MI == 2) {                                                                      \
+      *reinterpret_cast<float4 *>(As_ + 64 * kPitch) = ra2;                                       \
+      *reinterpret_cast<float4 *>(As_ + 96 * kPitch) = ra3;                                       \
+    }                                                                                             \
     *reinterpret_cast<float4 *>(Bs_) = rb0;                                                       \
     *reinterpret_cast<float4 *>(Bs_ + 32 * kPitch) = rb1;                                         \
     *reinterpret_cast<float4 *>(Bs_ + 64 * kPitch) = rb2;                                         \
     *reinterpret_cast<float4 *>(Bs_ + 96 * kPitch) = rb3;                                         \
   }
-  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  float4 ra0, ra1, ra2 = make_float4(0, 0, 0, 0), ra3 = ra2, rb0, rb1, rb2, rb3;
   MF_LIN_FETCH(0);
   MF_LIN_STASH(0);
   __syncthreads();
@@ -114,19 +122,21 @@ __global__ __launch_bounds__(256, 2) void k_linear_mfma(LinArgs a) {
     MF_LIN_FETCH(t + 1 < T ? t + 1 : t);
     asm volatile("" ::: "memory");  // keep the eight loads in front of the MFMAs (see conv3d.hip)
     __builtin_amdgcn_sched_barrier(0);
-    const float *As = s_mem + (t & 1) * kTileFloats + (wm * 64 + lrow) * kPitch + 4 * lhalf;
+    const float *As = s_mem + (t & 1) * kTileFloats + (wm * 32 * MI + lrow) * kPitch + 4 * lhalf;
     const float *Bs = s_mem + (t & 1) * kTileFloats + (kBM + wn * 64 + lrow) * kPitch + 4 * lhalf;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const float4 a0 = *reinterpret_cast<const float4 *>(As + 8 * kk);
-      const float4 a1 = *reinterpret_cast<const float4 *>(As + 32 * kPitch + 8 * kk);
+      const float4 a1 = MI == 2 ? *reinterpret_cast<const float4 *>(As + 32 * kPitch + 8 * kk) : a0;
       const float4 b0 = *reinterpret_cast<const float4 *>(Bs + 8 * kk);
       const float4 b1 = *reinterpret_cast<const float4 *>(Bs + 32 * kPitch + 8 * kk);
 #define MF_LIN_STEP(c_)                                                                           \
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c_, b0.c_, acc[0][0], 0, 0, 0);         \
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c_, b1.c_, acc[0][1], 0, 0, 0);         \
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c_, b0.c_, acc[1][0], 0, 0, 0);         \
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c_, b1.c_, acc[1][1], 0, 0, 0);
+      if constexpr (MI == 2) {                                                                    \
+        acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c_, b0.c_, acc[MI - 1][0], 0, 0, 0); \
+        acc[MI - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c_, b1.c_, acc[MI - 1][1], 0, 0, 0); \
+      }
       MF_LIN_STEP(x)
       MF_LIN_STEP(y)
       MF_LIN_STEP(z)
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_mfma(LinArgs a) {
   float *dst = a.out + grp * a.o_gs;
   const float *bias = a.bias ? a.bias + grp * a.b_gs : nullptr;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int n = n0 + wn * 64 + ni * 32 + lrow;
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_mfma(LinArgs a) {
       const float bn = bias ? bias[n] : 0.0f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+        const int m = m0 + wm * 32 * MI + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
         if (m >= a.M) continue;
         float v = acc[mi][ni][e] + bn;
         if (a.relu) v = v > 0.0f ? v : 0.0f;
@@ -173,12 +183,21 @@ extern "C" int mf_linear_fwd(const float *A, int64_t a_group_stride, int32_t lda
                        "linear: need K, lda, ldw, group strides % 4 == 0, 16-byte aligned A / W, W padded to Npad % 128 == 0 rows");
     return -(int)hipErrorInvalidValue;
   }
-  if (int e = mf::allow_big_lds((const void *)k_linear_mfma, kLinLds)) return e;
+  // half-height tiles when full-height ones leave the chip under-filled (< 1 workgroup per CU)
+  const int64_t full = (int64_t)((M + 127) / 128) * (Npad / kBN) * groups;
+  const bool half = full < 256;
+  if (int e = mf::allow_big_lds(half ? (const void *)k_linear_mfma<1> : (const void *)k_linear_mfma<2>,
+                                half ? lin_lds<1>() : lin_lds<2>()))
+    return e;
   LinArgs a;
   a.A = A; a.W = W; a.bias = bias; a.out = out;
   a.a_gs = a_group_stride; a.w_gs = w_group_stride; a.b_gs = b_group_stride; a.o_gs = o_group_stride;
   a.M = M; a.N = N; a.Npad = Npad; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.groups = groups; a.relu = relu;
-  const int64_t grid = (int64_t)((M + kBM - 1) / kBM) * (Npad / kBN) * groups;
-  hipLaunchKernelGGL(k_linear_mfma, dim3((unsigned)grid), dim3(256), kLinLds, stream, a);
+  if (half) {
+    const int64_t grid = (int64_t)((M + 63) / 64) * (Npad / kBN) * groups;
+    hipLaunchKernelGGL(k_linear_mfma<1>, dim3((unsigned)grid), dim3(256), lin_lds<1>(), stream, a);
+  } else {
+    hipLaunchKernelGGL(k_linear_mfma<2>, dim3((unsigned)full), dim3(256), lin_lds<2>(), stream, a);
+  }
   return mf::check_launch("mf_linear_fwd");
 }

@@ -136,3 +136,27 @@ class EmulIccScenes:
                                     int(step0), float(alpha_q), float(alpha_t), ptr(losses), ptr(traj),
                                     self.ws_ptr, None)
         assert rc == 0, rc
+
+
+def guarded(a):
+    """Copy of ``a`` whose last byte sits right in front of an inaccessible page: a kernel that reads or writes
+    past the end of the buffer segfaults in the emulator instead of passing by luck (what the GPU does when the
+    allocation happens to end at a mapping boundary).  The array must be 16-byte sized for aligned kernels."""
+    import mmap
+    a = np.ascontiguousarray(a)
+    page = mmap.PAGESIZE
+    n = a.nbytes
+    npages = (n + page - 1) // page
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.mmap.restype = ctypes.c_void_p
+    libc.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long]
+    libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    base = libc.mmap(None, (npages + 1) * page, mmap.PROT_READ | mmap.PROT_WRITE,
+                     mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, -1, 0)
+    assert base not in (None, ctypes.c_void_p(-1).value)
+    assert libc.mprotect(base + npages * page, page, 0) == 0  # PROT_NONE
+    start = base + npages * page - n
+    buf = (ctypes.c_char * n).from_address(start)
+    out = np.frombuffer(buf, dtype=a.dtype).reshape(a.shape)
+    out[...] = a
+    return out

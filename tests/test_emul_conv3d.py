@@ -150,5 +150,14 @@ def test_linear_mfma_gemm_vs_float64():
                 ref = np.maximum(ref, 0)
             np.testing.assert_allclose(out[:, 4 + 100 * g:4 + 100 * g + N], ref, rtol=0, atol=2e-6)
         assert (out[:, :4] == 9.0).all() and (out[:, 4 + N:104] == 9.0).all() and (out[:, 104 + N:] == 9.0).all()
+    # K = 4 (the padded conv1_pcd): chunks 1..7 of the only K-tile lie past K -- they must not be dereferenced
+    # beyond the matrices (buffers end at an inaccessible page)
+    A4 = emul.guarded(rs.uniform(-1, 1, (70, 4)).astype(np.float32))
+    W4 = emul.guarded(np.concatenate([rs.uniform(-1, 1, (8, 4)), np.zeros((120, 4))]).astype(np.float32))
+    b4 = emul.guarded(rs.uniform(-1, 1, 8).astype(np.float32))
+    o4 = emul.guarded(np.zeros((70, 8), np.float32))
+    assert L.mf_linear_fwd(A4.ctypes.data, 0, 4, W4.ctypes.data, 0, 4, b4.ctypes.data, 0, o4.ctypes.data, 0, 8,
+                           70, 8, 128, 4, 1, 1, None) == 0
+    np.testing.assert_allclose(o4, np.maximum(A4.astype(np.float64) @ W4[:8].astype(np.float64).T + b4, 0), atol=1e-6)
     z = np.zeros(8, np.float32)
     assert L.mf_linear_fwd(emul.ptr(z), 0, 8, emul.ptr(z), 0, 8, None, 0, emul.ptr(z), 0, 8, 1, 1, 100, 8, 1, 0, None) != 0

@@ -21,12 +21,13 @@ def main():
             n = short(r["Kernel_Name"]).replace("void ", "")
             if not n.startswith(tuple(p.replace("void ", "") for p in pick)):
                 continue
+            n = f'{n} grid={r.get("Grid_Size", "?")}'   # one kernel at two shapes = two rows
             c = acc[n][r["Counter_Name"]]
             c[0] += float(r["Counter_Value"]); c[1] += 1
     dur = collections.defaultdict(lambda: [0, 0])
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            n = short(r["Kernel_Name"]).replace("void ", "")
+            n = short(r["Kernel_Name"]).replace("void ", "") + f' grid={r.get("Grid_Size", "?")}'
             if n in acc:
                 dur[n][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); dur[n][1] += 1
     out = {}
