@@ -31,12 +31,13 @@ def _run(L, x_cf, W, bias, add_cl, split, relu, c_off=0, cin=None):
     B, _, D = x_cf.shape[:3]
     Cout, w_cin = W.shape[:2]
     cin = cin or w_cin
-    x_cl = np.ascontiguousarray(x_cf[:, c_off:c_off + cin].transpose(0, 2, 3, 4, 1))
-    wt = np.zeros((Cout, 64, cin), np.float32)
+    # (buffers end at an inaccessible page: an out-of-bounds tap / weight / store read faults here too)
+    x_cl = emul.guarded(np.ascontiguousarray(x_cf[:, c_off:c_off + cin].transpose(0, 2, 3, 4, 1)))
+    wt = emul.guarded(np.zeros((Cout, 64, cin), np.float32))
     assert L.mf_conv3d_k4s2_pack_weights(emul.ptr(np.ascontiguousarray(W)), Cout, cin, w_cin, c_off, emul.ptr(wt), None) == 0
     np.testing.assert_array_equal(wt, W[:, c_off:c_off + cin].reshape(Cout, cin, 64).transpose(0, 2, 1))
     Do = D // 2
-    out = np.full((B, Do, Do, Do, Cout), np.nan, np.float32)
+    out = emul.guarded(np.full((B, Do, Do, Do, Cout), np.nan, np.float32))
     nbytes = L.mf_conv3d_k4s2_workspace_bytes(B, Cout, D, split)
     ws = np.zeros(max(nbytes, 4) // 4, np.float32)
     rc = L.mf_conv3d_k4s2_fwd(emul.ptr(x_cl), emul.ptr(wt), emul.ptr(bias), emul.ptr(add_cl), emul.ptr(out),
@@ -150,6 +151,15 @@ def test_linear_mfma_gemm_vs_float64():
                 ref = np.maximum(ref, 0)
             np.testing.assert_allclose(out[:, 4 + 100 * g:4 + 100 * g + N], ref, rtol=0, atol=2e-6)
         assert (out[:, :4] == 9.0).all() and (out[:, 4 + N:104] == 9.0).all() and (out[:, 104 + N:] == 9.0).all()
+    # full-height (128 x 128) tiles: taken when >= 256 of them exist (the heads' first layer at batch 8)
+    Mb, Nb, Kb = 2200, 1920, 40
+    Ab = emul.guarded(rs.uniform(-1, 1, (Mb, Kb)).astype(np.float32))
+    Wb = emul.guarded((rs.uniform(-1, 1, (Nb, Kb)) / 6).astype(np.float32))
+    bb = rs.uniform(-1, 1, Nb).astype(np.float32)
+    ob = emul.guarded(np.zeros((Mb, Nb), np.float32))
+    assert L.mf_linear_fwd(Ab.ctypes.data, 0, Kb, Wb.ctypes.data, 0, Kb, emul.ptr(bb), 0, ob.ctypes.data, 0, Nb,
+                           Mb, Nb, Nb, Kb, 1, 1, None) == 0
+    np.testing.assert_allclose(ob, np.maximum(Ab.astype(np.float64) @ Wb.astype(np.float64).T + bb, 0), atol=2e-6)
     # K = 4 (the padded conv1_pcd): chunks 1..7 of the only K-tile lie past K -- they must not be dereferenced
     # beyond the matrices (buffers end at an inaccessible page)
     A4 = emul.guarded(rs.uniform(-1, 1, (70, 4)).astype(np.float32))
