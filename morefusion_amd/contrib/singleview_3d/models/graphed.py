@@ -31,14 +31,19 @@ class GraphedPredict:
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=cur.device)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):  # MIOpen solver search, workspaces, LDS opt-ins: before the capture
-            for _ in range(self.warmup):
-                self.model._predict_device(*e.inputs)
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        e.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(e.graph):
-            e.outputs = self.model._predict_device(*e.inputs)
+        # MIOpen's find mode (cudnn.benchmark) may select solvers whose launches are not replayable -- grouped
+        # composable-kernel convolutions pass per-launch argument buffers; measured: the SECOND replay of a
+        # graph captured under benchmark=True faults the GPU.  Warm-up and capture therefore run with
+        # immediate-mode solver selection, whose kernels replay fine.
+        with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+            with torch.cuda.stream(side):  # solver selection, workspaces, LDS opt-ins: before the capture
+                for _ in range(self.warmup):
+                    self.model._predict_device(*e.inputs)
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            e.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(e.graph):
+                e.outputs = self.model._predict_device(*e.inputs)
         e.ptrs = [a.data_ptr() if a is not None else 0 for a in e.inputs]
         return e
 

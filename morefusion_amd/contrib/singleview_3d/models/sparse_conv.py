@@ -50,6 +50,7 @@ class SparseVoxelConv3d:
         lib = _lib.lib()
         nbytes = lib.mf_sparse_conv3d_workspace_bytes(B, Cs, Cout, D, max_rows, 0)
         if self._ws is None or self._ws.numel() < nbytes:
+            self._ws_retired = getattr(self, "_ws_retired", []) + [self._ws]  # a captured hipGraph may hold it
             self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=voxelized.device)
         x = voxelized.float().contiguous()
         counts = counts.to(torch.int32)
@@ -81,6 +82,7 @@ class SparseVoxelConv3d:
         max_rows = max(int(n), 1)
         nbytes = lib.mf_sparse_conv3d_workspace_bytes(B, Cs, Cout, D, max_rows, n)
         if self._ws is None or self._ws.numel() < nbytes:
+            self._ws_retired = getattr(self, "_ws_retired", []) + [self._ws]  # a captured hipGraph may hold it
             self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=values.device)
         vals, pts, bi = _lib.f32c(values), _lib.f32c(points), _lib.i32c(batch_indices)
         out = torch.empty((B, Cout, D // 2, D // 2, D // 2), dtype=torch.float32, device=values.device)
@@ -107,6 +109,7 @@ class SparseVoxelConv3d:
         max_rows = max(int(n), 1)
         nbytes = lib.mf_sparse_conv3d_workspace_bytes(B, Cs, Cout, D, max_rows, n)
         if self._ws is None or self._ws.numel() < nbytes:
+            self._ws_retired = getattr(self, "_ws_retired", []) + [self._ws]  # a captured hipGraph may hold it
             self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=values.device)
         pts, bi = _lib.f32c(points), _lib.i32c(batch_indices)
         out = torch.empty((B, (D // 2) ** 3, Cout), dtype=torch.float32, device=values.device)

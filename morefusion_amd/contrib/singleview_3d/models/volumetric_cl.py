@@ -75,10 +75,13 @@ class ChannelsLastVolumetric:
                           lambda: (conv.weight.detach().squeeze(-1).contiguous(), conv.bias.detach()))
 
     def _scratch(self, name, shape, device, dtype=torch.float32):
-        t = self._buf.get(name)
-        if t is None or t.shape != tuple(shape) or t.device != device or t.dtype != dtype:
+        """Reusable intermediate of one shape.  Keyed by (name, shape): a buffer is never replaced or freed once
+        handed out, because a captured hipGraph (predict_graphed) of another batch size keeps its address."""
+        key = (name, tuple(shape), str(device), dtype)
+        t = self._buf.get(key)
+        if t is None:
             t = torch.empty(shape, dtype=dtype, device=device)
-            self._buf[name] = t
+            self._buf[key] = t
         return t
 
     # ---- stages -----------------------------------------------------------------------------

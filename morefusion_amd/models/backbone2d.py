@@ -5,6 +5,7 @@ Restates morefusion/models/dense_fusion/resnet.py:9-136 and pspnet.py:10-82 with
 No BatchNorm anywhere (the reference has none); ``F.resize_images`` == bilinear with
 align_corners=True; PReLU has one shared slope initialised to 0.25.
 """
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -154,19 +155,52 @@ class PSPModule(nn.Module):
             [nn.Conv2d(in_channels, in_channels, 1, bias=False) for _ in sizes])
         self.bottleneck = nn.Conv2d(in_channels * (len(sizes) + 1), out_channels, 1)
 
+    def _pool_matrix(self, H, W, device, dtype):
+        """[H*W, sum(size^2)] matrix whose column (size, by, bx) averages that bin's window:
+        ``F.avg_pool2d(x, k, k)`` with k = (H // size, W // size) for every size at once (non-overlapping
+        windows, remainder rows / columns dropped: pspnet.py's pooling pyramid)."""
+        key = (H, W, str(device), dtype)
+        cache = self.__dict__.setdefault("_pool_cache", {})
+        if key not in cache:
+            import numpy as np
+            cols = []
+            for size in self.sizes:
+                kh, kw = H // size, W // size
+                for by in range((H - kh) // kh + 1):
+                    for bx in range((W - kw) // kw + 1):
+                        m = np.zeros((H, W), np.float32)
+                        m[by * kh:(by + 1) * kh, bx * kw:(bx + 1) * kw] = 1.0 / (kh * kw)
+                        cols.append(m.reshape(-1))
+            cache[key] = torch.from_numpy(np.stack(cols, 1)).to(device=device, dtype=dtype)
+        return cache[key]
+
+    def _pooled(self, x):
+        """The pooling pyramid as ONE GEMM against the constant bin matrix (torch's avg_pool2d kernel walks each
+        32 x 32 ... 5 x 5 window with a single thread: measured 0.09-0.28 ms per call, 0.4 ms per predict at
+        any batch size; a strided ``mean`` is fast but its reduce kernel faults under hipGraph replay)."""
+        B, C, H, W = x.shape
+        Pm = self._pool_matrix(H, W, x.device, x.dtype)
+        out, o = [], 0
+        if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+            pooled = torch.matmul(Pm.t(), x.permute(0, 2, 3, 1).reshape(B, H * W, C))  # [B, bins, C]
+            for size in self.sizes:
+                n_y, n_x = (H - H // size) // (H // size) + 1, (W - W // size) // (W // size) + 1
+                out.append(pooled[:, o:o + n_y * n_x].transpose(1, 2).reshape(B, C, n_y, n_x))
+                o += n_y * n_x
+        else:
+            pooled = torch.matmul(x.reshape(B * C, H * W), Pm)  # [B*C, bins]
+            for size in self.sizes:
+                n_y, n_x = (H - H // size) // (H // size) + 1, (W - W // size) // (W // size) + 1
+                out.append(pooled[:, o:o + n_y * n_x].reshape(B, C, n_y, n_x))
+                o += n_y * n_x
+        return out
+
     def branches(self, x):
         """The four pooled-context maps, up-sampled back to [H,W] (global receptive field)."""
         H, W = x.shape[2:]
         hs = []
-        for size, conv in zip(self.sizes, self.convs):
-            k = (H // size, W // size)
-            # F.avg_pool2d(x, k, k) (pspnet.py: non-overlapping windows, kernel = stride, the remainder rows /
-            # columns dropped) as a strided mean: torch's pooling kernel walks each 32 x 32 ... 5 x 5 window
-            # with ONE thread (measured 0.09-0.28 ms per call, 0.4 ms per predict at any batch size)
-            n_y, n_x = (H - k[0]) // k[0] + 1, (W - k[1]) // k[1] + 1
-            pooled = x[:, :, :n_y * k[0], :n_x * k[1]].unflatten(3, (n_x, k[1])).unflatten(2, (n_y, k[0])).mean(dim=(3, 5))
-            h = conv(pooled)
-            hs.append(F.interpolate(h, (H, W), mode="bilinear", align_corners=True))
+        for pooled, conv in zip(self._pooled(x), self.convs):
+            hs.append(F.interpolate(conv(pooled), (H, W), mode="bilinear", align_corners=True))
         return hs
 
     def forward(self, x):
