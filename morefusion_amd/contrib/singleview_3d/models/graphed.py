@@ -5,7 +5,9 @@ a time) the network is a chain of ~300 kernels of a few microseconds each: eager
 host (3-4 us per launch) and by inter-kernel gaps, not by the GPU.  Capturing the chain once per input shape
 and replaying it removes the host from the loop.  All device work of the chain is capture-safe: the hand-written
 ops only enqueue kernels / memsets on the current stream, workspaces are allocated (and LDS attributes set)
-during the warm-up, the PSPNet tail's taps are computed on the device from ``pix``.
+during the warm-up, the PSPNet tail's taps are computed on the device from ``pix``.  (One torch operator is NOT
+replayable on this stack: a strided ``Tensor.mean`` over two dimensions -- its reduce kernel faulted the GPU on
+the second replay; the PSP pooling pyramid is a GEMM for that reason, models/backbone2d.py.)
 """
 import torch
 
@@ -31,19 +33,14 @@ class GraphedPredict:
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=cur.device)
         side.wait_stream(cur)
-        # MIOpen's find mode (cudnn.benchmark) may select solvers whose launches are not replayable -- grouped
-        # composable-kernel convolutions pass per-launch argument buffers; measured: the SECOND replay of a
-        # graph captured under benchmark=True faults the GPU.  Warm-up and capture therefore run with
-        # immediate-mode solver selection, whose kernels replay fine.
-        with torch.backends.cudnn.flags(enabled=True, benchmark=False):
-            with torch.cuda.stream(side):  # solver selection, workspaces, LDS opt-ins: before the capture
-                for _ in range(self.warmup):
-                    self.model._predict_device(*e.inputs)
-            cur.wait_stream(side)
-            torch.cuda.synchronize()
-            e.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(e.graph):
-                e.outputs = self.model._predict_device(*e.inputs)
+        with torch.cuda.stream(side):  # MIOpen solver search, workspaces, LDS opt-ins: before the capture
+            for _ in range(self.warmup):
+                self.model._predict_device(*e.inputs)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        e.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(e.graph):
+            e.outputs = self.model._predict_device(*e.inputs)
         e.ptrs = [a.data_ptr() if a is not None else 0 for a in e.inputs]
         return e
 

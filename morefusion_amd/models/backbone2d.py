@@ -180,19 +180,16 @@ class PSPModule(nn.Module):
         any batch size; a strided ``mean`` is fast but its reduce kernel faults under hipGraph replay)."""
         B, C, H, W = x.shape
         Pm = self._pool_matrix(H, W, x.device, x.dtype)
+        # always through the [B, H*W, C] view (free for a channels-last x, one 2 MB copy per object otherwise): the
+        # pooled maps come out channels-last, so the 1x1 convolutions and the up-sampling behind them run their
+        # NHWC kernels whatever layout MIOpen's solver search left x in (torch's NCHW bilinear kernel: 0.15 ms a call)
+        pooled = torch.matmul(Pm.t(), x.permute(0, 2, 3, 1).reshape(B, H * W, C))  # [B, bins, C]
         out, o = [], 0
-        if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
-            pooled = torch.matmul(Pm.t(), x.permute(0, 2, 3, 1).reshape(B, H * W, C))  # [B, bins, C]
-            for size in self.sizes:
-                n_y, n_x = (H - H // size) // (H // size) + 1, (W - W // size) // (W // size) + 1
-                out.append(pooled[:, o:o + n_y * n_x].transpose(1, 2).reshape(B, C, n_y, n_x))
-                o += n_y * n_x
-        else:
-            pooled = torch.matmul(x.reshape(B * C, H * W), Pm)  # [B*C, bins]
-            for size in self.sizes:
-                n_y, n_x = (H - H // size) // (H // size) + 1, (W - W // size) // (W // size) + 1
-                out.append(pooled[:, o:o + n_y * n_x].reshape(B, C, n_y, n_x))
-                o += n_y * n_x
+        for size in self.sizes:
+            n_y, n_x = (H - H // size) // (H // size) + 1, (W - W // size) // (W // size) + 1
+            out.append(pooled[:, o:o + n_y * n_x].transpose(1, 2).reshape(B, C, n_y, n_x)
+                       .contiguous(memory_format=torch.channels_last))
+            o += n_y * n_x
         return out
 
     def branches(self, x):
@@ -200,7 +197,8 @@ class PSPModule(nn.Module):
         H, W = x.shape[2:]
         hs = []
         for pooled, conv in zip(self._pooled(x), self.convs):
-            hs.append(F.interpolate(conv(pooled), (H, W), mode="bilinear", align_corners=True))
+            h = conv(pooled).contiguous(memory_format=torch.channels_last)
+            hs.append(F.interpolate(h, (H, W), mode="bilinear", align_corners=True))
         return hs
 
     def forward(self, x):
