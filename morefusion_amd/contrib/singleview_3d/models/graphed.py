@@ -33,14 +33,18 @@ class GraphedPredict:
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=cur.device)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):  # MIOpen solver search, workspaces, LDS opt-ins: before the capture
-            for _ in range(self.warmup):
-                self.model._predict_device(*e.inputs)
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        e.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(e.graph):
-            e.outputs = self.model._predict_device(*e.inputs)
+        # Warm-up and capture run with IMMEDIATE-mode solver selection (cudnn.benchmark off): under MIOpen's find
+        # mode the selected solvers vary from run to run, and some of them are not replayable (measured: the same
+        # capture replays fine in one process and faults the GPU in the next; with immediate mode it is stable).
+        with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+            with torch.cuda.stream(side):  # solver selection, workspaces, LDS opt-ins: before the capture
+                for _ in range(self.warmup):
+                    self.model._predict_device(*e.inputs)
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            e.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(e.graph):
+                e.outputs = self.model._predict_device(*e.inputs)
         e.ptrs = [a.data_ptr() if a is not None else 0 for a in e.inputs]
         return e
 

@@ -22,7 +22,7 @@ for step in "$@"; do
     tests) timeout 2400 python -m pytest tests -m gpu -x -q > "$O/tests.log" 2>&1; echo "rc $?"; tail -5 "$O/tests.log" ;;
     k) timeout 1500 python -m pytest tests -m gpu -x -q -k "$arg" > "$O/k.log" 2>&1; echo "rc $?"; tail -15 "$O/k.log" ;;
     t) f=$(echo $arg | tr ' /' '__'); timeout 1500 python -m pytest -m gpu -x -q $(for a in $arg; do echo tests/$a; done) > "$O/t_$f.log" 2>&1; echo "rc $?"; tail -15 "$O/t_$f.log" ;;
-    bench) n=$(ls "$O"/bench*.json 2>/dev/null | wc -l); timeout 900 python bench.py $arg > "$O/bench$n.json" 2> "$O/bench$n.err"; echo "rc $?"; cut -c1-600 "$O/bench$n.json"; tail -3 "$O/bench$n.err" ;;
+    bench) n=$(ls "$O"/bench*.json 2>/dev/null | wc -l); timeout 900 python -X faulthandler bench.py $arg > "$O/bench$n.json" 2> "$O/bench$n.err"; echo "rc $?"; cut -c1-600 "$O/bench$n.json"; tail -3 "$O/bench$n.err" ;;
     py) s=$(echo "$arg" | cut -d' ' -f1 | xargs basename | sed 's/\.py$//'); timeout 900 python $arg > "$O/py_$s.log" 2>&1; echo "rc $?"; tail -40 "$O/py_$s.log" ;;
     prof) pn=${arg%%=*}; cmd=${arg#*=}; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$pn" -o p -- env $cmd > "$O/prof_$pn.log" 2>&1; echo "rc $?"
           MF_MARK=${MF_MARK:-} python tools/kernel_stats.py "$O/prof_$pn" > "$O/prof_${pn}_kernel_stats.csv"; head -25 "$O/prof_${pn}_kernel_stats.csv" | cut -c1-160; rm -rf "$O/prof_$pn" ;;
