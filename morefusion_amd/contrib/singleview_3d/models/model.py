@@ -232,7 +232,8 @@ class Model(nn.Module):
         into the graph's static buffers (skipped for tensors that still live at the captured address) and
         replay.  ``pix`` [B,P]: a point selection computed ahead (``select_points_async``), which removes the
         call's only host synchronisation.  ``clone=False`` returns the graph's static output tensors (valid
-        until the next call)."""
+        until the next call).  Run it with ``torch.backends.cudnn.benchmark = False``: with MIOpen's find mode on,
+        replays of the stock 2-D backbone faulted or hung intermittently on this stack."""
         if self.training or torch.is_grad_enabled():
             raise RuntimeError("predict_graphed is an inference path: call under torch.no_grad() in eval mode")
         dev = rgb.device
@@ -282,7 +283,9 @@ class Model(nn.Module):
                 self.done.synchronize()
                 with torch.cuda.stream(stream):
                     pix = model._subsample(self.order, self.counts_host.numpy())
-                torch.cuda.current_stream().wait_stream(stream)
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(stream)
+                pix.record_stream(cur)  # allocated on the side stream, consumed on the caller's
                 return pix
 
         return _Pending()

@@ -84,9 +84,31 @@ def _add(points, qa, ta, qb, tb):
     return float(np.linalg.norm(pa - pb, axis=1).mean())
 
 
-@pytest.mark.parametrize("batch,graphed", [(1, False), (1, True), (8, False)])
-def test_predict_end_to_end_vs_cpu_restatement(batch, graphed):
-    """``graphed``: BASELINE config 2 (batch 1) through ``Model.predict_graphed`` -- the hipGraph replay path."""
+def _in_child(test_name):
+    """Run one test function of this module in a process of its own: a hipGraph replay that faults the GPU
+    (seen intermittently with MIOpen's find mode on) then fails ONE test instead of aborting the whole session."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, 'tests'); import test_gpu_predict_parity as t; "
+            f"t.{test_name}; print('CHILD-OK')")
+    p = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], cwd=root, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0 and "CHILD-OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+def test_predict_end_to_end_graph_path_batch1():
+    """BASELINE config 2 (batch 1) through ``Model.predict_graphed`` -- the hipGraph replay path."""
+    _in_child("_predict_end_to_end(1, True)")
+
+
+@pytest.mark.parametrize("batch", [1, 8])
+def test_predict_end_to_end_vs_cpu_restatement(batch):
+    _predict_end_to_end(batch, False)
+
+
+def _predict_end_to_end(batch, graphed):
     torch.manual_seed(0)
     torch.backends.cudnn.benchmark = False
     model = Model(n_fg_class=21, with_occupancy=True).cuda().eval()
@@ -125,6 +147,10 @@ def test_predict_end_to_end_vs_cpu_restatement(batch, graphed):
 
 
 def test_graph_replay_with_new_frames_and_prefetched_selection():
+    _in_child("_graph_replay_with_new_frames_and_prefetched_selection()")
+
+
+def _graph_replay_with_new_frames_and_prefetched_selection():
     """One captured graph serves every frame of its shape: replaying it on other inputs gives what the eager
     path gives for them, also when the point selection was prefetched on a side stream
     (``select_points_async``) and when the caller's tensors move to new addresses."""
