@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256, 2) void k_linear_mfma(LinArgs a) {
   if ((G & 7) == 0) L = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   const int grp = L / per_group;
   const int rem = L - grp * per_group;
-  const int m0 = (rem % tiles_m) * kBM, n0 = (rem / tiles_m) * kBN;
+  // N tile fastest: an XCD's contiguous range is a band of M tiles x all N tiles, so its 4 MB L2 holds the band's
+  // rows of A (the wide operand: 31 MB for the heads' first layer) while W streams from the Infinity Cache
+  // (M tile fastest: 562 MB of HBM-side fetches per launch for 39 MB of operands, profiles/r03_kernels_pmc.json)
+  const int m0 = (rem / tiles_n) * kBM, n0 = (rem % tiles_n) * kBN;
   const float *A = a.A + grp * a.a_gs, *W = a.W + grp * a.w_gs;
   const int T = (a.K + kBK - 1) / kBK;
 

@@ -24,17 +24,26 @@ def main():
             n = f'{n} grid={r.get("Grid_Size", "?")}'   # one kernel at two shapes = two rows
             c = acc[n][r["Counter_Name"]]
             c[0] += float(r["Counter_Value"]); c[1] += 1
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):   # the dispatch's duration under the PMC pass
+                d = acc[n]["__dur_ns"]
+                d[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); d[1] += 1
     dur = collections.defaultdict(lambda: [0, 0])
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            n = short(r["Kernel_Name"]).replace("void ", "") + f' grid={r.get("Grid_Size", "?")}'
+            g = r.get("Grid_Size")
+            if g is None and r.get("Grid_Size_X"):
+                g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+            n = short(r["Kernel_Name"]).replace("void ", "") + f' grid={g}'
             if n in acc:
                 dur[n][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); dur[n][1] += 1
     out = {}
     for n, cs in acc.items():
+        dd = cs.pop("__dur_ns", None)
         rec = {k: v[0] / v[1] for k, v in cs.items()}
         rec["launches"] = max(v[1] for v in cs.values())
-        if dur[n][1]:
+        if dd and dd[1] and dd[0] > 0:
+            rec["avg_duration_us_under_pmc"] = round(dd[0] / dd[1] / 1e3, 3)
+        elif dur[n][1]:
             rec["avg_duration_us_under_pmc"] = round(dur[n][0] / dur[n][1] / 1e3, 3)
         if "FETCH_SIZE" in rec:
             rec["fetch_bytes_x2_gfx950"] = round(rec["FETCH_SIZE"] * 1024 * 2)

@@ -86,6 +86,26 @@ if "net" in WHAT or "valid" in WHAT:
             h3 = torch.relu(torch.randn(1, 16 ** 3, 256, device="cuda"))
             for _ in range(REPS):
                 vol.conv_k4s2("conv4", model.conv4, h3, 1, 16, cin=256)
+if WHAT & {"conv4", "conv3d", "conv4b1", "heads1"}:   # one shape of the MFMA kernels per process (same grid size otherwise)
+    model = Model(n_fg_class=21, with_occupancy=True).cuda().eval()
+    vol = ChannelsLastVolumetric(model)
+    with torch.no_grad():
+        if "conv4" in WHAT:
+            h3 = torch.relu(torch.randn(B, 16 ** 3, 256, device="cuda"))
+            for _ in range(REPS):
+                vol.conv_k4s2("conv4", model.conv4, h3, B, 16, cin=256)
+        if "conv4b1" in WHAT:
+            h3 = torch.relu(torch.randn(1, 16 ** 3, 256, device="cuda"))
+            for _ in range(REPS):
+                vol.conv_k4s2("conv4", model.conv4, h3, 1, 16, cin=256)
+        if "conv3d" in WHAT:
+            h_occ = torch.relu(torch.randn(B, 32 ** 3, 16, device="cuda"))
+            for _ in range(REPS):
+                vol.conv_k4s2("conv3_occ", model.conv3, h_occ, B, 32, cin=16, c_off=144, relu=False, bias=False)
+        if "heads1" in WHAT:
+            feat = torch.randn(B * P, 984, device="cuda")
+            for _ in range(REPS):
+                vol.heads(feat, B, P)
 if "icc" in WHAT:   # pose_refinement ICC: 1 scene x 8 objects, 100 iterations
     sc = mf.synthetic.make_icc_scene(8, seed=0, fixtures=[dict(np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"fixture_pose_refinement_0000000{i}.npz"))) for i in range(3)])
     d = dict(points=sc["points"], sdf=sc["sdf"], pitch=sc["pitch"], origin=sc["origin"], grid_target=sc["grid_target"],
