@@ -42,8 +42,11 @@ def test_workspace_size_is_host_only_arithmetic():
                                 n_points, 32, max_ns, thr, 0.0, 1)
     ws = mf._lib.lib().mf_icc_workspace_bytes
     n = ws(ctypes.byref(desc(8, 1, 28000, 8)))
-    # winners of 16 grids + the x-plane bins (34 planes x 8 grids' worth of point records)
-    assert n >= 2 * 8 * 32 ** 3 * 8 + 34 * 8 * 28000 * 16
+    # winners of 16 grids + compact bins: per grid 68 bins of max(64, P_g / 8) records + an overflow list of 2 P_g,
+    # summed over the grids (sum_g P_g = Ns * P_scene) -- O(N * sum P), not nbins x that (round 2: 68 x 8 x 28000 x 16 B)
+    sumP = 8 * 28000
+    assert n >= 2 * 8 * 32 ** 3 * 8 + (68 * sumP // 8 + 2 * sumP) * 16
+    assert n < 2 * 8 * 32 ** 3 * 8 + 0.25 * 68 * sumP * 16
     assert ws(ctypes.byref(desc(64, 8, 8 * 28000, 8))) > n
     assert ws(ctypes.byref(desc(8, 1, 28000, 8, thr=4.0))) > n       # kernel size 5: two more planes
     assert ws(ctypes.byref(desc(40, 1, 28000, 40))) < 0              # > 32 objects in a scene

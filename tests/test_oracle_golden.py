@@ -186,7 +186,7 @@ def test_cuda_text_goldens_do_not_depend_on_fma_contraction_where_it_matters():
     hinge on which fork a CUDA compiler picks; the HIP kernels are built -ffp-contract=off.)"""
     import json
     import os
-    from conftest import GOLDEN_DIR
+    from conftest import GOLDEN as GOLDEN_DIR
     rep = json.load(open(os.path.join(GOLDEN_DIR, "ref_cuda_fma_fork.json")))
     assert rep["integer_outputs_identical"] is True and rep["integer_elements_that_differ"] == 0
     assert set(rep["files"]) == {"ref_cuda_tdf.npz", "ref_cuda_pseudo_occupancy.npz", "ref_cuda_interpolate.npz",
