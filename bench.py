@@ -277,6 +277,36 @@ def _icc_algorithmic_bytes(icc):
     return pairs * 16, icc.n_objects * 2 * icc.dim ** 3 * 4
 
 
+def icc_many_scenes(wl, n_scenes=8):
+    """The same two kernels with 8 scenes x 8 objects in one batch (BASELINE config 4's per-GPU share when a
+    node runs 64 objects on ONE GPU): the launches are shared, so the per-scene latency terms amortise."""
+    args = wl.args
+    fixtures = load_fixtures()
+    scenes = [mf.synthetic.make_icc_scene(args.objects, seed=50 + s, fixtures=fixtures) for s in range(n_scenes)]
+    dicts = [dict(points=s["points"], sdf=s["sdf"], pitch=s["pitch"], origin=s["origin"],
+                  grid_target=s["grid_target"], grid_nontarget_empty=s["grid_nontarget_empty"]) for s in scenes]
+    icc = mf.contrib.IccScenes(dicts, sdf_offset=0.02, device=wl.device)
+    from morefusion_amd.geometry import quaternion_from_matrix
+    q0 = torch.as_tensor(np.concatenate([np.stack([quaternion_from_matrix(T) for T in s["transform_init"]])
+                                         for s in scenes]).astype(np.float32)).to(wl.device)
+    t0 = torch.as_tensor(np.concatenate([s["transform_init"][:, :3, 3] for s in scenes]).astype(np.float32)).to(wl.device)
+    q, t = q0.clone(), t0.clone()
+    m, v = torch.zeros((q.shape[0], 7), device=wl.device), torch.zeros((q.shape[0], 7), device=wl.device)
+
+    def run():
+        q.copy_(q0); t.copy_(t0); m.zero_(); v.zero_()
+        icc.refine(q, t, m, v, args.icc_iters, step0=0, alpha_q=0.01, alpha_t=0.001)
+
+    ms = time_kernel_live(run, 3)
+    pts_bytes, grid_bytes = _icc_algorithmic_bytes(icc)
+    it_bytes = 2 * (pts_bytes + grid_bytes)
+    us = ms * 1e3 / args.icc_iters
+    gbs = it_bytes / (us * 1e-6) / 1e9
+    return dict(scenes=n_scenes, objects=int(q.shape[0]), algorithmic_bytes=it_bytes, us=round(us, 3),
+                us_per_scene=round(us / n_scenes, 3), achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
+                workspace_mb=round(icc.ws.numel() / 1e6, 1))
+
+
 def roofline_icc(wl, us_per_iter):
     """k_icc_fused (k_icc_tile on the two-kernel path of non-{0,1} no-entry grids) -- the hand-written
     kernel with the largest share of the step (100 launches per refinement), timed live with HIP
@@ -313,6 +343,7 @@ def roofline_icc(wl, us_per_iter):
             traffic = rec["traffic_bytes"]
     it_bytes = 2 * (pts_bytes + grid_bytes)
     it_achieved = it_bytes / (us_per_iter * 1e-6) / 1e9
+    many = icc_many_scenes(wl)
     return dict(kernel=(f"{kname} (launch 2 of 2 per ICC iteration; mf_icc_refine)" if single_pass else
                         f"{kname} (launch 2 of 3 per ICC iteration; mf_icc_refine)"), bound="hbm",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -322,6 +353,7 @@ def roofline_icc(wl, us_per_iter):
                                        ("k_icc_fused" if single_pass else "k_icc_tile + k_icc_accum"),
                                algorithmic_bytes=it_bytes, us=round(us_per_iter, 3),
                                achieved=round(it_achieved, 1), frac=round(it_achieved / HBM_PEAK_GBS, 4)),
+                iteration_8_scenes=many,
                 note="L2-resident working set; latency / instruction-issue bound (DESIGN.md 4)")
 
 
