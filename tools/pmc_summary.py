@@ -25,8 +25,8 @@ def main():
             c = acc[n][r["Counter_Name"]]
             c[0] += float(r["Counter_Value"]); c[1] += 1
             if r.get("Start_Timestamp") and r.get("End_Timestamp"):   # the dispatch's duration under the PMC pass
-                d = acc[n]["__dur_ns"]
-                d[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); d[1] += 1
+                dn = acc[n]["__dur_ns"]
+                dn[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); dn[1] += 1
     dur = collections.defaultdict(lambda: [0, 0])
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
