@@ -78,7 +78,7 @@ class IccScenes:
             int(bool(((self.grid_ne == 0) | (self.grid_ne == 1)).all())))
         nbytes = L.mf_icc_workspace_bytes(ctypes.byref(self.desc))
         if nbytes < 0:
-            raise ValueError("mf_icc: invalid batch descriptor (objects per scene <= 32, dim <= 64)")
+            raise ValueError("mf_icc: invalid batch descriptor (objects per scene <= 64, dim <= 64)")
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         self.prepare()
 

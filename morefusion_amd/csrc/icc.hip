@@ -70,7 +70,8 @@ constexpr int kNumF = 65;                    // single-pass path: 5 scene sums +
 constexpr int kOwnSlots = kNumF + 1;         // accumulator words per object; the slot after the sums
                                              // counts non-finite block sums (-> NaN loss)
 constexpr int kStateFloats = 21;             // q[4] t[3] m[7] v[7] of one object
-constexpr int kMaxSceneObjects = 32;
+constexpr int kMaxSceneObjects = 64;  // LDS tables of a scene (R|t, offsets, staged sums); scenes beyond 32 objects
+                                      // take > 64 KB of dynamic LDS in the tile kernels (one workgroup per CU)
 
 struct IccArgs {
   const float4 *pts4;
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   // fixed-point LDS atomics behind float64 conversions: ~600 instructions per colliding voxel,
   // 3-5 us in the crowded blocks.)
   MF_DYN_LDS(float, s_rows2);   // [max_ns][kAccThreads / 16][12 + 1] row sums per other object
-  __shared__ uint32_t s_emask;  // scene objects some voxel of this block collides with
+  __shared__ unsigned long long s_emask;  // scene objects some voxel of this block collides with (<= 64 per scene)
   __shared__ float s_Rt[kMaxSceneObjects][12];
   __shared__ int s_off[kMaxSceneObjects + 1];
   const int o = blockIdx.y;
@@ -984,7 +985,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   // all independent loads first: scene tables, scalars, and this thread's voxels
   if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
-  if (threadIdx.x == 0) s_emask = 0u;
+  if (threadIdx.x == 0) s_emask = 0ull;
   const float pitch = a.pitch[o];
   // candidate ids are point * K + offset with this grid's own kernel size
   const int ks_o = ksize_of(a.thr, pitch);
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   }
 #pragma unroll
   for (int it = 0; it < kVPT; ++it)
-    if (ecol[it] >= 0) atomicOr(&s_emask, 1u << ecol[it]);
+    if (ecol[it] >= 0) atomicOr(&s_emask, 1ull << ecol[it]);
   // fixed-order block reduction: every component is summed over each 16-lane row on DPP (4 VALU
   // steps, no LDS), the 32 row sums go through LDS, one lane per component adds them in order.
   stamp(2);
@@ -1138,10 +1139,10 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   // loop over the set bits, no barrier inside), ONE barrier, then 12 lanes per object add the
   // rows in order
   long long *po = a.acc_oth + ((int64_t)par * a.O + o) * a.max_ns * 12;
-  const uint32_t em0 = s_emask;  // complete: every atomicOr precedes the barrier above
+  const unsigned long long em0 = s_emask;  // complete: every atomicOr precedes the barrier above
   constexpr int kRows = kAccThreads / 16;
-  for (uint32_t em = em0; em != 0u; em &= em - 1u) {
-    const int e = __ffs((int)em) - 1;
+  for (unsigned long long em = em0; em != 0ull; em &= em - 1ull) {
+    const int e = __ffsll((long long)em) - 1;
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
       float v = 0.0f;
@@ -1151,11 +1152,11 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
       if ((threadIdx.x & 15) == 0) s_rows2[(e * kRows + (threadIdx.x >> 4)) * 13 + c] = r;
     }
   }
-  if (em0 == 0u) return;  // block-uniform
+  if (em0 == 0ull) return;  // block-uniform
   __syncthreads();
   for (int i = threadIdx.x; i < a.max_ns * 12; i += kAccThreads) {
     const int e = i / 12, c = i - 12 * e;
-    if (!((em0 >> e) & 1u)) continue;
+    if (!((em0 >> e) & 1ull)) continue;
     float sacc = 0.0f;
 #pragma unroll
     for (int r = 0; r < kRows; ++r) sacc += s_rows2[(e * kRows + r) * 13 + c];
@@ -1617,13 +1618,15 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
     } else {
       atomicAdd(reinterpret_cast<unsigned long long *>(own + kNumF), 1ull);  // -> NaN loss
     }
-  } else if (tid < kNumF + 12 * Ns) {
+  } else {  // (one trip up to 37 scene objects; a 64-object scene takes two)
     long long *po = a.acc_oth + ((int64_t)par * a.O + o) * a.max_ns * 12;
-    const int i = tid - kNumF, e = i / 12, cc = i - 12 * e;
-    float sacc = 0.0f;
-    for (int r = 0; r < n_rows; ++r) sacc += s_rows2[(e * kRows + r) * 13 + cc];
-    const long long xq = isfinite(sacc) ? __double2ll_rn((double)sacc * kFixOth) : 0;
-    if (xq != 0) atomicAdd(reinterpret_cast<unsigned long long *>(po + i), (unsigned long long)xq);
+    for (int i = tid - kNumF; i < 12 * Ns; i += kTileThreads - kNumF) {
+      const int e = i / 12, cc = i - 12 * e;
+      float sacc = 0.0f;
+      for (int r = 0; r < n_rows; ++r) sacc += s_rows2[(e * kRows + r) * 13 + cc];
+      const long long xq = isfinite(sacc) ? __double2ll_rn((double)sacc * kFixOth) : 0;
+      if (xq != 0) atomicAdd(reinterpret_cast<unsigned long long *>(po + i), (unsigned long long)xq);
+    }
   }
   stamp(4);
 }
@@ -1797,7 +1800,7 @@ void launch_iteration(const IccArgs &a, IccStepArgs sp, int NB, int k, hipStream
   sp.fused = a.ne_binary;
   hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, sp);
   const size_t lds_tile = (size_t)((D + 1) / 2) * D * 2 * sizeof(uint32_t);  // 4 KB at D = 32
-  const size_t lds_rows2 = (size_t)a.max_ns * (kAccThreads / 16) * 13 * sizeof(float);  // <= 53 KB
+  const size_t lds_rows2 = (size_t)a.max_ns * (kAccThreads / 16) * 13 * sizeof(float);  // 53 KB at 32, 106 KB at 64 objects
   if (a.ne_binary) {
     hipLaunchKernelGGL(k_icc_fused, dim3(D * kHalves, a.O), dim3(kTileThreads),
                        4 * fused_tile_words(D) * sizeof(uint32_t) + lds_rows2, stream, a, par);
@@ -1844,7 +1847,9 @@ extern "C" int mf_pack_points_sdf(const float *points, const float *sdf, int64_t
 }
 
 static int icc_validate(const mfIccBatch *b) {
-  if (int e = mf::allow_big_lds((const void *)k_icc_fused, 80 * 1024)) return e;
+  // collision-moment rows: max_scene_objects x 1664 B of dynamic LDS (106 KB at 64 objects)
+  if (int e = mf::allow_big_lds((const void *)k_icc_fused, 124 * 1024)) return e;
+  if (int e = mf::allow_big_lds((const void *)k_icc_accum, 124 * 1024)) return e;
   if (!icc_batch_ok(b)) {
     mf::set_last_error(hipErrorInvalidValue, "mf_icc: invalid batch descriptor");
     return -(int)hipErrorInvalidValue;

@@ -49,7 +49,8 @@ def test_workspace_size_is_host_only_arithmetic():
     assert n < 2 * 8 * 32 ** 3 * 8 + 0.25 * 68 * sumP * 16
     assert ws(ctypes.byref(desc(64, 8, 8 * 28000, 8))) > n
     assert ws(ctypes.byref(desc(8, 1, 28000, 8, thr=4.0))) > n       # kernel size 5: two more planes
-    assert ws(ctypes.byref(desc(40, 1, 28000, 40))) < 0              # > 32 objects in a scene
+    assert ws(ctypes.byref(desc(40, 1, 28000, 40))) > n              # 33..64 objects in a scene: allowed since round 3
+    assert ws(ctypes.byref(desc(70, 1, 28000, 70))) < 0              # > 64 objects in a scene
     assert ws(ctypes.byref(desc(8, 1, 28000, 8, thr=9.0))) < 0       # kernel size > 7
 
 
