@@ -460,9 +460,21 @@ def roofline_conv4(wl, B):
         ms = time_kernel_live(lambda: vol.conv_k4s2("conv4", m.conv4, h3, B, 16, cin=256), 30)
     flop = 2.0 * B * 512 * 512 * 64 * 256
     tf = flop / (ms * 1e-3) / 1e12
+    traffic, mfma_busy = None, None  # PMC passes of THIS round (profiles/r03_mfma_kernels_pmc.json), B = 8 only
+    pmc = os.path.join(ROOT, "profiles", "r03_mfma_kernels_pmc.json")
+    if B == 8 and os.path.exists(pmc):
+        ps = json.load(open(pmc))["passes"]
+        k, f = "k_conv3d_k4s2_mfma grid=131072", "k_conv_finish grid=524288"
+        try:
+            traffic = int(ps["fetch_conv4"][k]["fetch_bytes_x2_gfx950"] + ps["write_conv4"][k]["write_bytes"]
+                          + ps["fetch_conv4"][f]["fetch_bytes_x2_gfx950"] + ps["write_conv4"][f]["write_bytes"])
+            mfma_busy = ps["mfma_conv4"][k]["mfma_pipe_util"]
+        except KeyError:
+            pass
     return dict(kernel="k_conv3d_k4s2_mfma (+ k_conv_finish) on conv4, mf_conv3d_k4s2_fwd", bound="mfma",
                 achieved=round(tf, 1), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, flop_per_launch=flop,
+                frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic, mfma_pipe_busy_pmc=mfma_busy,
+                flop_per_launch=flop,
                 avg_launch_ms=round(ms, 5), shape=dict(B=B, Cin=256, Cout=512, D=16),
                 split_k=mf._lib.lib().mf_conv3d_k4s2_default_split(B, 256, 512, 16))
 
