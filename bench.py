@@ -376,10 +376,10 @@ def handwritten_path(wl, reps=10):
 def latency_batch1_measure(model, one, reps=30):
     """Per-frame latency (ms, host clock around call + device sync, i.e. input ready -> poses ready) of
       predict            eager launches, incl. the host synchronisation of the point selection;
-      predict_graphed    the same work with everything after the selection replayed from one hipGraph;
-      predict_graphed_prefetched_selection
-                         the deployment loop: frame k+1's valid-pixel selection is issued on a side stream
-                         (select_points_async) before frame k's graph is replayed."""
+      predict_graphed    the same work with everything after the selection replayed from one hipGraph.
+    (Round 3 also measured the graph with the NEXT frame's selection prefetched on a side stream,
+    Model.select_points_async: 2.1-2.3 ms vs 1.8 ms -- slower, and that phase faulted the GPU in 3 of 9
+    probe processes; it is not part of the probe any more)"""
     m = model
 
     def per_frame(fn):
@@ -397,15 +397,6 @@ def latency_batch1_measure(model, one, reps=30):
         out["predict"] = round(per_frame(lambda: m.predict(**one)), 4)
         print(json.dumps(out), flush=True)  # (the probe's parent keeps the last complete line)
         out["predict_graphed"] = round(per_frame(lambda: m.predict_graphed(**one, clone=False)), 4)
-        print(json.dumps(out), flush=True)
-        state = {"pend": m.select_points_async(one["pcd"])}
-
-        def frame():
-            pix = state["pend"].result()
-            state["pend"] = m.select_points_async(one["pcd"])   # next frame's selection, side stream
-            m.predict_graphed(**one, pix=pix, clone=False)
-
-        out["predict_graphed_prefetched_selection"] = round(per_frame(frame), 4)
         print(json.dumps(out), flush=True)
     return out
 

@@ -146,14 +146,23 @@ def _predict_end_to_end(batch, graphed):
         assert add < 1e-4, (i, add)
 
 
-def test_graph_replay_with_new_frames_and_prefetched_selection():
-    _in_child("_graph_replay_with_new_frames_and_prefetched_selection()")
+def test_graph_replay_with_new_frames():
+    _in_child("_graph_replay_with_new_frames()")
 
 
-def _graph_replay_with_new_frames_and_prefetched_selection():
+def test_point_selection_on_a_side_stream_equals_the_synchronous_one():
+    """``Model.select_points_async`` (valid-pixel compaction + count read-back on a side stream, host RNG subsample
+    when the handle is resolved) returns what ``_select_points`` returns."""
+    model = Model(n_fg_class=21, with_occupancy=True).cuda().eval()
+    for seed in (21, 22):
+        b = mf.synthetic.make_singleview_batch(2, seed=seed)
+        pcd = torch.as_tensor(b["pcd"]).cuda()
+        assert torch.equal(model.select_points_async(pcd).result(), model._select_points(pcd))
+
+
+def _graph_replay_with_new_frames():
     """One captured graph serves every frame of its shape: replaying it on other inputs gives what the eager
-    path gives for them, also when the point selection was prefetched on a side stream
-    (``select_points_async``) and when the caller's tensors move to new addresses."""
+    path gives for them, also when the caller's tensors move to new addresses."""
     torch.manual_seed(0)
     torch.backends.cudnn.benchmark = False
     model = Model(n_fg_class=21, with_occupancy=True).cuda().eval()
@@ -165,10 +174,7 @@ def _graph_replay_with_new_frames_and_prefetched_selection():
         eager = [tuple(x.clone() for x in model.predict(**f)) for f in frames]
         eager = [tuple(x.clone() for x in model.predict(**f)) for f in frames]   # settled solver choice
         for i, f in enumerate(frames):
-            pending = model.select_points_async(f["pcd"])
-            got = model.predict_graphed(**f, pix=pending.result())
+            got = model.predict_graphed(**f)
             for g, e in zip(got, eager[i]):
                 np.testing.assert_allclose(g.cpu().numpy(), e.cpu().numpy(), rtol=0, atol=2e-5)
         assert len(model._graphed.entries) == 1    # one shape, one graph
-        # the selection the handle returns is the synchronous one
-        assert torch.equal(model.select_points_async(frames[0]["pcd"]).result(), model._select_points(frames[0]["pcd"]))
