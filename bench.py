@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--priority", choices=["none", "net-high", "icc-high", "icc-low"], default="none",
                     help="HIP stream priorities for the two-stream step (tuning knob)")
     ap.add_argument("--stage-breakdown", action="store_true", default=True)
+    ap.add_argument("--no-latency-probe", action="store_true", help="skip the batch-1 latency child process")
     ap.add_argument("--probe-latency-b1", action="store_true", help="(internal) batch-1 latency probe, own process")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher / collective plumbing check without a GPU: N gloo ranks on the CPU, a stub "
@@ -695,7 +696,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args)
         torch.cuda.synchronize()
-        out["latency_batch1_ms"] = latency_batch1(wl)  # child process, last: nothing of this one depends on it
+        if not args.no_latency_probe:
+            out["latency_batch1_ms"] = latency_batch1(wl)  # child process, last: nothing of this one depends on it
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
