@@ -343,6 +343,20 @@ int mf_linear_fwd(const float *A, int64_t a_group_stride, int32_t lda, const flo
                   int32_t ldo, int32_t M, int32_t N, int32_t Npad, int32_t K, int32_t groups, int32_t relu,
                   mfStream_t stream);
 
+/* Point-wise prologue / epilogue of the volumetric part (inference), one launch each instead of ~25 torch launches:
+ *   mf_point_prep: camera-frame points [B,3,P] + image features [B,Cv,P] -> voxel-frame points [n,3]
+ *     ((p - origin) / pitch, model.py:236), to_center [n,4] = (center - p | 0) (:101), feature rows [n,Cv],
+ *     batch indices [n];  n = B*P, Cv % 4 == 0.
+ *   mf_pose_epilogue: heads' output rows [n, ldo] (rot at column 0, trans at np4, conf at 2*np4; class c at
+ *     4c / 3c / c) -> rot [n,4] = q / (|q| + 1e-5) (chainer F.normalize), trans [n,3] = (p*pitch + origin) +
+ *     t*pitch (:264-266), conf [n] = sigmoid (:262) of each object's class (class_id int64 [B], 1-based). */
+int mf_point_prep(const float *points_cam, const float *values, const float *origin, const float *pitch,
+                  int32_t B, int32_t P, int32_t Cv, float center, float *pts, float *tc4, float *x_rows,
+                  int32_t *batch_indices, mfStream_t stream);
+int mf_pose_epilogue(const float *heads_out, int64_t ldo, int32_t np4, const int64_t *class_id,
+                     const float *pts, const float *origin, const float *pitch, int32_t B, int32_t P,
+                     float *rot, float *trans, float *conf, mfStream_t stream);
+
 /* small fused helpers of the same path */
 /* pack [Ptot,3] points + [Ptot] sdf into float4 */
 int mf_pack_points_sdf(const float *points, const float *sdf, int64_t n, void *pts4,

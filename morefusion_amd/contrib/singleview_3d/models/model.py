@@ -318,9 +318,9 @@ class Model(nn.Module):
         branch + conv3/conv4 -> trilinear sampling -> the three per-point heads."""
         B = values.shape[0]
         dev = values.device
-        points = (points - origin[:, :, None]) / pitch[:, None, None]  # camera -> voxel frame
         if self.channels_last_3d and self.sparse_conv3 and not torch.is_grad_enabled() and values.is_cuda:
             return self._pose_from_features_cl(class_id, values, points, pitch, origin, grid_nontarget_empty)
+        points = (points - origin[:, :, None]) / pitch[:, None, None]  # camera -> voxel frame
         h = self._extract(values, points, grid_nontarget_empty)
 
         outs = {}
@@ -347,21 +347,10 @@ class Model(nn.Module):
         return rot, trans, conf
 
     def _pose_from_features_cl(self, class_id, values, points, pitch, origin, grid_nontarget_empty):
-        """``_pose_from_features`` (points already in the voxel frame) on the channels-last kernels."""
-        B, _, P = values.shape
+        """``_pose_from_features`` (camera-frame points) on the channels-last kernels (volumetric_cl.py)."""
         if getattr(self, "_volumetric_cl", None) is None:
             self.__dict__["_volumetric_cl"] = ChannelsLastVolumetric(self)
-        vol = self._volumetric_cl
-        feat = vol.features(values, points, grid_nontarget_empty)
-        cls_rot, cls_trans, cls_conf = vol.heads(feat, B, P)          # [B,P,n_fg,c]
-        fg = (class_id - 1).long()
-        ar = torch.arange(B, device=values.device)
-        rot = cls_rot[ar, :, fg]                                       # [B,P,4]
-        rot = rot / (rot.norm(dim=2, keepdim=True) + 1e-5)             # chainer F.normalize (see below)
-        points_cam = (points * pitch[:, None, None] + origin[:, :, None]).transpose(1, 2)  # [B,P,3]
-        trans = points_cam + cls_trans[ar, :, fg] * pitch[:, None, None]
-        conf = cls_conf[ar, :, fg]
-        return rot, trans, conf
+        return self._volumetric_cl.pose(class_id, values, points, pitch, origin, grid_nontarget_empty)
 
     # ---- training (model.py:277-481) ------------------------------------------------------
     def forward(self, *, class_id, rgb, pcd, quaternion_true, translation_true, pitch=None,

@@ -119,24 +119,35 @@ class ChannelsLastVolumetric:
             vox_cl.data_ptr(), pts.data_ptr(), batch_indices.data_ptr(), pts.shape[0], B, C, D, D, D,
             out_block.data_ptr(), ldo, _lib.stream_ptr()), "mf_interpolate_voxel_grid_cl_fwd")
 
-    def features(self, values, points, grid_nontarget_empty):
-        """values [B,32,P] image features, points [B,3,P] voxel-frame coordinates, no-entry grid
-        [B,D,D,D] (or None) -> F [B*P, 984] = (feat1 | feat2 | feat3 | feat4) per point."""
+    def prep(self, values, points_cam, pitch, origin):
+        """One launch (mf_point_prep): camera-frame points [B,3,P] -> voxel-frame rows ``pts`` [n,3]
+        (model.py:236), ``tc4`` [n,4] = (to_center | 0) (:101), image features as rows [n,32], batch indices [n]."""
+        B, Cv, P = values.shape
+        n, dev = B * P, values.device
+        _lib.require_gpu(values, points_cam, pitch, origin)
+        pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        tc4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        x_rows = torch.empty((n, Cv), dtype=torch.float32, device=dev)
+        bi = torch.empty((n,), dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().mf_point_prep(
+            _lib.f32c(points_cam).data_ptr(), _lib.f32c(values).data_ptr(), _lib.f32c(origin).data_ptr(),
+            _lib.f32c(pitch).data_ptr(), B, P, Cv, self.m._voxel_dim / 2.0 - 0.5, pts.data_ptr(), tc4.data_ptr(),
+            x_rows.data_ptr(), bi.data_ptr(), _lib.stream_ptr()), "mf_point_prep")
+        return pts, tc4, x_rows, bi
+
+    def features(self, values, points_cam, pitch, origin, grid_nontarget_empty):
+        """values [B,32,P] image features, points_cam [B,3,P] camera-frame coordinates, pitch [B], origin [B,3],
+        no-entry grid [B,D,D,D] (or None) -> (F [B*P, 984] = feat1 | feat2 | feat3 | feat4 per point,
+        voxel-frame points [n,3])."""
         m = self.m
         B, _, P = values.shape
         n, D = B * P, m._voxel_dim
         dev = values.device
-        _lib.require_gpu(values, points)
-        pts = points.float().transpose(1, 2).reshape(n, 3).contiguous()
-        x_rgb = values.transpose(1, 2).reshape(n, values.shape[1])
-        to_center = (D / 2.0 - 0.5) - pts
-        batch_indices = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(P)
+        pts, tc4, x_rgb, batch_indices = self.prep(values, points_cam, pitch, origin)
+        to_center = tc4[:, :3]
         feat = torch.empty((n, 984), dtype=torch.float32, device=dev)
 
         if self.mfma_linear and not torch.is_autocast_enabled():
-            x_rgb = x_rgb.float().contiguous()
-            tc4 = torch.zeros((n, 4), dtype=torch.float32, device=dev)
-            tc4[:, :3] = to_center
             self._linear("conv1_rgb", [m.conv1_rgb], x_rgb, 32, feat[:, 0:64], 984, relu=True)
             self._linear("conv1_pcd", [m.conv1_pcd], tc4, 4, feat[:, 64:72], 984, relu=True, k_pad=4)
             self._linear("conv2_rgb", [m.conv2_rgb], feat[:, 0:64], 984, feat[:, 72:200], 984, relu=True)
@@ -159,10 +170,11 @@ class ChannelsLastVolumetric:
             h_occ = self.occupancy(grid_nontarget_empty)
             dense = self.conv_k4s2("conv3_occ", m.conv3, h_occ, B, D, cin=16, c_off=144, relu=False, bias=False)
         h3 = self._sparse.from_points_cl(feat[:, 72:216], 984, pts, batch_indices, B, dense, D)  # [B, 16^3, 256]
-        self.sample(h3, D // 2, pts / 2.0, batch_indices, feat[:, 216:472], 984)
+        pts2 = pts * 0.5  # == pts / 2.0 (a power of two: same bits); one launch serves both samplers' scales
+        self.sample(h3, D // 2, pts2, batch_indices, feat[:, 216:472], 984)
         h4 = self.conv_k4s2("conv4", m.conv4, h3, B, D // 2, cin=256)                            # [B, 8^3, 512]
-        self.sample(h4, D // 4, pts / 4.0, batch_indices, feat[:, 472:984], 984)
-        return feat
+        self.sample(h4, D // 4, pts2 * 0.5, batch_indices, feat[:, 472:984], 984)
+        return feat, pts
 
     # ---- 1x1 convolutions as grouped fp32-MFMA GEMMs -------------------------------------------
     def _gemm_pack(self, name, convs, k_pad=None):
@@ -193,8 +205,10 @@ class ChannelsLastVolumetric:
                                             out.data_ptr(), o_gs, ldo, a.shape[0], N, Np, K, G, int(relu),
                                             _lib.stream_ptr()), "mf_linear_fwd")
 
-    def heads(self, feat, B, P):
-        """F [B*P, 984] -> per-point class outputs rot [B,P,n_fg,4], trans [B,P,n_fg,3], conf [B,P,n_fg]."""
+    def heads(self, feat, B, P, raw=False):
+        """F [B*P, 984] -> per-point class outputs rot [B,P,n_fg,4], trans [B,P,n_fg,3], conf [B,P,n_fg].
+        ``raw=True``: the MFMA path's unsplit output rows (o [n, 3*np4], np4) for mf_pose_epilogue, or
+        (None, 0) when the stock-GEMM path is active."""
         m = self.m
         nf = m._n_fg_class
         names = ("rot", "trans", "conf")
@@ -225,10 +239,14 @@ class ChannelsLastVolumetric:
             _lib.check(L.mf_linear_fwd(h3.data_ptr(), 128, 384, w4.data_ptr(), np4 * 128, 128, b4.data_ptr(), np4,
                                        o.data_ptr(), np4, 3 * np4, n, np4, np4, 128, 3, 0, _lib.stream_ptr()),
                        "mf_linear_fwd")
+            if raw:
+                return o, np4
             rot = o[:, 0:nf * 4].reshape(B, P, nf, 4)
             trans = o[:, np4:np4 + nf * 3].reshape(B, P, nf, 3)
             conf = torch.sigmoid(o[:, 2 * np4:2 * np4 + nf]).reshape(B, P, nf)
             return rot, trans, conf
+        if raw:
+            return None, 0
         outs = {}
         for name in names:
             x = feat
@@ -249,3 +267,30 @@ class ChannelsLastVolumetric:
             w[g, :c.out_channels] = c.weight.detach().float().squeeze(-1)
             b[g, :c.out_channels] = c.bias.detach().float()
         return w.contiguous(), b.contiguous()
+
+    def pose(self, class_id, values, points_cam, pitch, origin, grid_nontarget_empty):
+        """The whole volumetric part: -> (rot [B,P,4], trans [B,P,3], conf [B,P]) of each object's class."""
+        B, _, P = values.shape
+        feat, pts = self.features(values, points_cam, pitch, origin, grid_nontarget_empty)
+        o, np4 = self.heads(feat, B, P, raw=True)
+        if o is not None:
+            dev = values.device
+            rot = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
+            trans = torch.empty((B, P, 3), dtype=torch.float32, device=dev)
+            conf = torch.empty((B, P), dtype=torch.float32, device=dev)
+            cid = class_id.to(device=dev, dtype=torch.int64).contiguous()
+            _lib.check(_lib.lib().mf_pose_epilogue(
+                o.data_ptr(), o.stride(0), np4, cid.data_ptr(), pts.data_ptr(), _lib.f32c(origin).data_ptr(),
+                _lib.f32c(pitch).data_ptr(), B, P, rot.data_ptr(), trans.data_ptr(), conf.data_ptr(),
+                _lib.stream_ptr()), "mf_pose_epilogue")
+            return rot, trans, conf
+        cls_rot, cls_trans, cls_conf = self.heads(feat, B, P)          # [B,P,n_fg,c]
+        fg = (class_id - 1).long()
+        ar = torch.arange(B, device=values.device)
+        rot = cls_rot[ar, :, fg]                                       # [B,P,4]
+        rot = rot / (rot.norm(dim=2, keepdim=True) + 1e-5)             # chainer F.normalize: x / (|x| + eps)
+        pts_b = pts.reshape(B, P, 3)
+        points_back = pts_b * pitch[:, None, None] + origin[:, None, :]  # voxel -> camera frame (model.py:264)
+        trans = points_back + cls_trans[ar, :, fg] * pitch[:, None, None]
+        conf = cls_conf[ar, :, fg]
+        return rot, trans, conf

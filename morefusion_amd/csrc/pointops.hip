@@ -1,0 +1,101 @@
+// Point-wise prologue / epilogue of the pose network's volumetric part (inference), for gfx950.
+//
+// Reference: contrib/singleview_3d/models/model.py:232-275 -- the camera -> voxel frame change of the sampled
+// points (:236), `to_center` (:101), and after the heads the class selection, the quaternion
+// normalisation (`F.normalize`, chainer: x / (|x| + 1e-5)), `cls_trans * pitch + points` (:264-266) and
+// the confidence sigmoid (:262).  In torch these are ~25 launches of a few microseconds; at batch 1
+// (BASELINE config 2) that is ~5 % of the frame.  Two kernels, one lane per point:
+//   k_point_prep     [B,3,P] camera points, [B,32,P] image features -> voxel-frame points [n,3],
+//                    to_center [n,4] (4th column zero: the K-padded input of conv1_pcd), image features as
+//                    rows [n,32] (the point MLP's GEMM input), batch indices [n]
+//   k_pose_epilogue  heads' output rows [n, 3*np4] -> (quaternion [B,P,4], translation [B,P,3],
+//                    confidence [B,P]) of each object's class
+// Arithmetic is the torch expression order ((p - origin) / pitch with an IEEE divide; p * pitch + origin).
+#include "mf_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_point_prep(const float *__restrict__ points_cam,  // [B,3,P]
+                                                    const float *__restrict__ values,      // [B,Cv,P]
+                                                    const float *__restrict__ origin,      // [B,3]
+                                                    const float *__restrict__ pitch,       // [B]
+                                                    int B, int P, int Cv, float center,
+                                                    float *__restrict__ pts,               // [n,3]
+                                                    float *__restrict__ tc4,               // [n,4]
+                                                    float *__restrict__ x_rows,            // [n,Cv]
+                                                    int32_t *__restrict__ batch_indices) { // [n]
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * P) return;
+  const int b = (int)(i / P), p = (int)(i - (int64_t)b * P);
+  const float pit = pitch[b];
+  float v[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    v[a] = (points_cam[((int64_t)b * 3 + a) * P + p] - origin[3 * b + a]) / pit;
+    pts[3 * i + a] = v[a];
+  }
+  *reinterpret_cast<float4 *>(tc4 + 4 * i) = make_float4(center - v[0], center - v[1], center - v[2], 0.0f);
+  batch_indices[i] = b;
+  const float *src = values + (int64_t)b * Cv * P + p;
+  float *dst = x_rows + i * Cv;
+  for (int c = 0; c < Cv; c += 4) {  // Cv % 4 == 0
+    *reinterpret_cast<float4 *>(dst + c) = make_float4(src[(int64_t)c * P], src[(int64_t)(c + 1) * P],
+                                                       src[(int64_t)(c + 2) * P], src[(int64_t)(c + 3) * P]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pose_epilogue(const float *__restrict__ o, int64_t ldo, int np4,
+                                                       const int64_t *__restrict__ class_id,  // [B], 1-based
+                                                       const float *__restrict__ pts,          // [n,3] voxel frame
+                                                       const float *__restrict__ origin, const float *__restrict__ pitch,
+                                                       int B, int P, float *__restrict__ rot,  // [n,4]
+                                                       float *__restrict__ trans,              // [n,3]
+                                                       float *__restrict__ conf) {             // [n]
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * P) return;
+  const int b = (int)(i / P);
+  const int fg = (int)class_id[b] - 1;
+  const float pit = pitch[b];
+  const float *row = o + i * ldo;
+  const float q0 = row[4 * fg], q1 = row[4 * fg + 1], q2 = row[4 * fg + 2], q3 = row[4 * fg + 3];
+  const float nrm = sqrtf(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3) + 1e-5f;
+  *reinterpret_cast<float4 *>(rot + 4 * i) = make_float4(q0 / nrm, q1 / nrm, q2 / nrm, q3 / nrm);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float pc = pts[3 * i + a] * pit + origin[3 * b + a];  // voxel -> camera frame (model.py:264)
+    trans[3 * i + a] = pc + row[np4 + 3 * fg + a] * pit;
+  }
+  conf[i] = 1.0f / (1.0f + expf(-row[2 * np4 + fg]));
+}
+
+}  // namespace
+
+extern "C" int mf_point_prep(const float *points_cam, const float *values, const float *origin, const float *pitch,
+                             int32_t B, int32_t P, int32_t Cv, float center, float *pts, float *tc4, float *x_rows,
+                             int32_t *batch_indices, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || P <= 0) return 0;
+  if (Cv % 4 || (((uintptr_t)tc4 | (uintptr_t)x_rows) & 15)) {
+    mf::set_last_error(hipErrorInvalidValue, "point_prep: need Cv % 4 == 0 and 16-byte aligned outputs");
+    return -(int)hipErrorInvalidValue;
+  }
+  const int64_t n = (int64_t)B * P;
+  hipLaunchKernelGGL(k_point_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, points_cam, values, origin,
+                     pitch, B, P, Cv, center, pts, tc4, x_rows, batch_indices);
+  return mf::check_launch("mf_point_prep");
+}
+
+extern "C" int mf_pose_epilogue(const float *heads_out, int64_t ldo, int32_t np4, const int64_t *class_id,
+                                const float *pts, const float *origin, const float *pitch, int32_t B, int32_t P,
+                                float *rot, float *trans, float *conf, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || P <= 0) return 0;
+  if (((uintptr_t)rot & 15) || ldo < 3 * (int64_t)np4) {
+    mf::set_last_error(hipErrorInvalidValue, "pose_epilogue: need a 16-byte aligned rot and ldo >= 3 * np4");
+    return -(int)hipErrorInvalidValue;
+  }
+  const int64_t n = (int64_t)B * P;
+  hipLaunchKernelGGL(k_pose_epilogue, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, heads_out, ldo, np4,
+                     class_id, pts, origin, pitch, B, P, rot, trans, conf);
+  return mf::check_launch("mf_pose_epilogue");
+}

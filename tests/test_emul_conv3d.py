@@ -171,3 +171,45 @@ def test_linear_mfma_gemm_vs_float64():
     np.testing.assert_allclose(o4, np.maximum(A4.astype(np.float64) @ W4[:8].astype(np.float64).T + b4, 0), atol=1e-6)
     z = np.zeros(8, np.float32)
     assert L.mf_linear_fwd(emul.ptr(z), 0, 8, emul.ptr(z), 0, 8, None, 0, emul.ptr(z), 0, 8, 1, 1, 100, 8, 1, 0, None) != 0
+
+
+def test_point_prep_and_pose_epilogue_vs_numpy():
+    """csrc/pointops.hip: the point-wise prologue (camera -> voxel frame, to_center, feature rows, batch indices) and
+    epilogue (class selection, chainer's normalize, translation, sigmoid) against the torch expressions of
+    contrib/singleview_3d/models/model.py:236,101,262-273 restated in NumPy float32."""
+    L = emul.build(["pointops.hip"])
+    i32, i64, p, f = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_float
+    L.mf_point_prep.argtypes = [p, p, p, p, i32, i32, i32, f, p, p, p, p, p]
+    L.mf_pose_epilogue.argtypes = [p, i64, i32, p, p, p, p, i32, i32, p, p, p, p]
+    rs = np.random.RandomState(9)
+    B, P, Cv = 3, 70, 8
+    n = B * P
+    pc = rs.uniform(-0.3, 0.9, (B, 3, P)).astype(np.float32)
+    vals = rs.uniform(-1, 1, (B, Cv, P)).astype(np.float32)
+    origin = rs.uniform(-0.4, 0.2, (B, 3)).astype(np.float32)
+    pitch = rs.uniform(0.004, 0.01, B).astype(np.float32)
+    pts, tc4 = emul.guarded(np.zeros((n, 3), np.float32)), emul.guarded(np.zeros((n, 4), np.float32))
+    xr, bi = emul.guarded(np.zeros((n, Cv), np.float32)), emul.guarded(np.zeros(n, np.int32))
+    assert L.mf_point_prep(emul.ptr(pc), emul.ptr(vals), emul.ptr(origin), emul.ptr(pitch), B, P, Cv, 15.5,
+                           pts.ctypes.data, tc4.ctypes.data, xr.ctypes.data, bi.ctypes.data, None) == 0
+    pv = ((pc - origin[:, :, None]) / pitch[:, None, None]).astype(np.float32)           # model.py:236
+    np.testing.assert_array_equal(pts, pv.transpose(0, 2, 1).reshape(n, 3))
+    np.testing.assert_array_equal(tc4[:, :3], (np.float32(15.5) - pts).astype(np.float32))
+    assert (tc4[:, 3] == 0).all()
+    np.testing.assert_array_equal(xr, vals.transpose(0, 2, 1).reshape(n, Cv))
+    np.testing.assert_array_equal(bi, np.repeat(np.arange(B), P))
+
+    nf, np4 = 21, 128
+    o = emul.guarded(rs.uniform(-2, 2, (n, 3 * np4)).astype(np.float32))
+    cid = np.array([1, 21, 7], np.int64)
+    rot, trans, conf = (emul.guarded(np.zeros((n, k), np.float32)) for k in (4, 3, 1))
+    assert L.mf_pose_epilogue(o.ctypes.data, 3 * np4, np4, emul.ptr(cid), pts.ctypes.data, emul.ptr(origin),
+                              emul.ptr(pitch), B, P, rot.ctypes.data, trans.ctypes.data, conf.ctypes.data, None) == 0
+    fg = np.repeat(cid - 1, P)
+    rows = np.arange(n)
+    q = np.stack([o[rows, 4 * fg + k] for k in range(4)], 1)
+    np.testing.assert_allclose(rot, q / (np.linalg.norm(q.astype(np.float64), axis=1, keepdims=True) + 1e-5), atol=2e-7)
+    pb = np.repeat(pitch, P)[:, None]
+    t = np.stack([o[rows, np4 + 3 * fg + k] for k in range(3)], 1)
+    np.testing.assert_allclose(trans, (pts * pb + np.repeat(origin, P, 0)) + t * pb, atol=1e-7)
+    np.testing.assert_allclose(conf[:, 0], 1 / (1 + np.exp(-o[rows, 2 * np4 + fg].astype(np.float64))), atol=2e-7)

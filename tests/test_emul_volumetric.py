@@ -22,7 +22,7 @@ def test_channels_last_volumetric_path_matches_dense_formulation(monkeypatch):
     import morefusion_amd.contrib.singleview_3d.models.model as model_mod
     from morefusion_amd.contrib.singleview_3d.models import Model
 
-    L = emul.build(["conv3d.hip", "sparseconv.hip", "interp.hip", "linear.hip"])
+    L = emul.build(["conv3d.hip", "sparseconv.hip", "interp.hip", "linear.hip", "pointops.hip"])
     for name, (argtypes, restype) in _lib._SIGNATURES.items():
         fn = getattr(L, name, None)
         if fn is not None:
@@ -64,8 +64,7 @@ def test_channels_last_volumetric_path_matches_dense_formulation(monkeypatch):
         model.sparse_conv3 = False          # dense channels-first formulation (CPU torch convs)
         want = model._pose_from_features(class_id, values, points_cam, pitch, origin, grid)
         model.sparse_conv3 = True
-        pv = (points_cam - origin[:, :, None]) / pitch[:, None, None]
-        got = model._pose_from_features_cl(class_id, values, pv, pitch, origin, grid)
+        got = model._pose_from_features_cl(class_id, values, points_cam, pitch, origin, grid)
     for g, w, tol in zip(got, want, (2e-4, 2e-6, 2e-4)):
         assert g.shape == w.shape
         np.testing.assert_allclose(g.numpy(), w.numpy(), rtol=0, atol=tol)

@@ -91,8 +91,9 @@ def test_channels_last_path_equals_channels_first_path_stage_by_stage():
         # stage check: sparse conv3 (no dense part) channels-last vs channels-first, bit-identical
         vol = model._volumetric_cl
         pv = ((points - inp["origin"].float()[:, :, None]) / inp["pitch"].float()[:, None, None])
-        feat = vol.features(values, pv, inp["grid_nontarget_empty"])
+        feat, pts_k = vol.features(values, points, inp["pitch"].float(), inp["origin"].float(), inp["grid_nontarget_empty"])
         pts = pv.transpose(1, 2).reshape(B * P, 3).contiguous()
+        assert torch.equal(pts_k, pts)   # mf_point_prep: the torch expression's bits
         bi = torch.arange(B, dtype=torch.int32, device="cuda").repeat_interleave(P)
         f2 = feat[:, 72:216].contiguous()
         h3_cf = vol._sparse.from_points(f2, pts, bi, batch_size=B, h_dense=None, dim=32)

@@ -70,7 +70,7 @@ def main():
             args = (inp["class_id"], values, points, inp["pitch"].float(), inp["origin"].float(), inp["grid_nontarget_empty"])
             pv = (points - inp["origin"].float()[:, :, None]) / inp["pitch"].float()[:, None, None]
             P = values.shape[2]
-            feat = vol.features(values, pv, inp["grid_nontarget_empty"])
+            feat, _ = vol.features(values, points, inp["pitch"].float(), inp["origin"].float(), inp["grid_nontarget_empty"])
             pts = pv.transpose(1, 2).reshape(B * P, 3).contiguous()
             bi = torch.arange(B, dtype=torch.int32, device="cuda").repeat_interleave(P)
             dense = vol.conv_k4s2("conv3_occ", model.conv3, h_occ, B, 32, cin=16, c_off=144, relu=False, bias=False)
@@ -84,7 +84,8 @@ def main():
             r["sample_feat3_cl_ms"] = round(t_ms(lambda: vol.sample(h3r, 16, pts / 2.0, bi, feat[:, 216:472], 984)), 4)
             r["sample_feat4_cl_ms"] = round(t_ms(lambda: vol.sample(h4r, 8, pts / 4.0, bi, feat[:, 472:984], 984)), 4)
             r["heads_ms"] = round(t_ms(lambda: vol.heads(feat, B, P)), 4)
-            r["features_ms"] = round(t_ms(lambda: vol.features(values, pv, inp["grid_nontarget_empty"])), 4)
+            r["features_ms"] = round(t_ms(lambda: vol.features(values, points, inp["pitch"].float(), inp["origin"].float(),
+                                                               inp["grid_nontarget_empty"])), 4)
             model.channels_last_3d = True
             r["pose_from_features_cl_ms"] = round(t_ms(lambda: model._pose_from_features(*args)), 4)
             model.channels_last_3d = False
