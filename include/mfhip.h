@@ -357,6 +357,16 @@ int mf_pose_epilogue(const float *heads_out, int64_t ldo, int32_t np4, const int
                      const float *pts, const float *origin, const float *pitch, int32_t B, int32_t P,
                      float *rot, float *trans, float *conf, mfStream_t stream);
 
+/* The last PSPNet level (up3: bilinear x2 + Convolution2D 3x3 64->64 + PReLU; conv1 1x1 64->32; log-softmax,
+ *   morefusion/models/dense_fusion/pspnet.py:10-35,57-73) evaluated ONLY at the sampled pixels the pose network
+ *   reads (contrib/singleview_3d/models/model.py:222), one launch:
+ *   u2 [B,64,H,W] with element strides (sb, sc, sy, sx) (NCHW or channels-last), pix [B*P] int64 flat indices into
+ *   the [2H,2W] full-resolution map, w3t [9,64,64] = W3.permute(2,3,1,0), w1t [64,32] = W1[:, :, 0, 0].T,
+ *   prelu_slope: device pointer to the single PReLU parameter -> out [B*P, 32] (rows). */
+int mf_psp_tail_fwd(const float *u2, int64_t sb, int64_t sc, int64_t sy, int64_t sx, const int64_t *pix,
+                    const float *w3t, const float *b3, const float *prelu_slope, const float *w1t,
+                    const float *b1, int32_t B, int32_t P, int32_t H, int32_t W, float *out, mfStream_t stream);
+
 /* small fused helpers of the same path */
 /* pack [Ptot,3] points + [Ptot] sdf into float4 */
 int mf_pack_points_sdf(const float *points, const float *sdf, int64_t n, void *pts4,

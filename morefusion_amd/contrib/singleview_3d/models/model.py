@@ -292,16 +292,22 @@ class Model(nn.Module):
 
     def _predict_device(self, class_id, rgb, pcd, pix, pitch, origin, grid_nontarget_empty):
         """Everything after point selection: pure device work, no host synchronisation."""
-        values, points = self._backbone_features(rgb, pcd, pix)
+        # inference on the channels-last kernels: the PSPNet tail hands over feature ROWS [n,32] (one launch)
+        rows = (self.channels_last_3d and self.sparse_conv3 and self.sparse_pspnet_tail and rgb.is_cuda
+                and not torch.is_grad_enabled() and not torch.is_autocast_enabled())
+        values, points = self._backbone_features(rgb, pcd, pix, rows=rows)
         return self._pose_from_features(class_id, values, points, pitch, origin, grid_nontarget_empty)
 
-    def _backbone_features(self, rgb, pcd, pix):
+    def _backbone_features(self, rgb, pcd, pix, rows=False):
         """The stock 2-D part (ResNet18 + PSPNet on MIOpen) and the gathers at the sampled pixels:
-        -> per-point image features [B,32,P] and camera-frame points [B,3,P]."""
+        -> per-point image features [B,32,P] (``rows=True``: [B*P,32] from the fused tail kernel) and
+        camera-frame points [B,3,P]."""
         B = rgb.shape[0]
         rgb = rgb.float().permute(0, 3, 1, 2)
         pcd = pcd.float().permute(0, 3, 1, 2)
-        if self.sparse_pspnet_tail:
+        if self.sparse_pspnet_tail and rows:
+            values = self.pspnet_extractor.forward_sampled_rows(self.resnet_extractor(rgb), pix)
+        elif self.sparse_pspnet_tail:
             # last PSPNet level evaluated only at the sampled pixels (identical features)
             plan = self.pspnet_extractor.plan(pix, rgb.shape[2] // 8, rgb.shape[3] // 8)
             values = self.pspnet_extractor.forward_sampled(self.resnet_extractor(rgb), pix, plan=plan)
@@ -316,10 +322,10 @@ class Model(nn.Module):
     def _pose_from_features(self, class_id, values, points, pitch, origin, grid_nontarget_empty):
         """The volumetric part (the hand-written path of the network): voxelize -> occupancy
         branch + conv3/conv4 -> trilinear sampling -> the three per-point heads."""
-        B = values.shape[0]
-        dev = values.device
         if self.channels_last_3d and self.sparse_conv3 and not torch.is_grad_enabled() and values.is_cuda:
             return self._pose_from_features_cl(class_id, values, points, pitch, origin, grid_nontarget_empty)
+        B = values.shape[0]
+        dev = values.device
         points = (points - origin[:, :, None]) / pitch[:, None, None]  # camera -> voxel frame
         h = self._extract(values, points, grid_nontarget_empty)
 

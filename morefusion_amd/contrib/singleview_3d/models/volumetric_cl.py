@@ -122,12 +122,16 @@ class ChannelsLastVolumetric:
     def prep(self, values, points_cam, pitch, origin):
         """One launch (mf_point_prep): camera-frame points [B,3,P] -> voxel-frame rows ``pts`` [n,3]
         (model.py:236), ``tc4`` [n,4] = (to_center | 0) (:101), image features as rows [n,32], batch indices [n]."""
-        B, Cv, P = values.shape
+        B, _, P = points_cam.shape
         n, dev = B * P, values.device
         _lib.require_gpu(values, points_cam, pitch, origin)
         pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
         tc4 = torch.empty((n, 4), dtype=torch.float32, device=dev)
-        x_rows = torch.empty((n, Cv), dtype=torch.float32, device=dev)
+        if values.ndim == 2:   # already rows [n, Cv] (PSPNetExtractor.forward_sampled_rows): nothing to transpose
+            x_rows, Cv = _lib.f32c(values), 0
+        else:
+            Cv = values.shape[1]
+            x_rows = torch.empty((n, Cv), dtype=torch.float32, device=dev)
         bi = torch.empty((n,), dtype=torch.int32, device=dev)
         _lib.check(_lib.lib().mf_point_prep(
             _lib.f32c(points_cam).data_ptr(), _lib.f32c(values).data_ptr(), _lib.f32c(origin).data_ptr(),
@@ -140,7 +144,7 @@ class ChannelsLastVolumetric:
         no-entry grid [B,D,D,D] (or None) -> (F [B*P, 984] = feat1 | feat2 | feat3 | feat4 per point,
         voxel-frame points [n,3])."""
         m = self.m
-        B, _, P = values.shape
+        B, _, P = points_cam.shape
         n, D = B * P, m._voxel_dim
         dev = values.device
         pts, tc4, x_rgb, batch_indices = self.prep(values, points_cam, pitch, origin)
@@ -270,7 +274,7 @@ class ChannelsLastVolumetric:
 
     def pose(self, class_id, values, points_cam, pitch, origin, grid_nontarget_empty):
         """The whole volumetric part: -> (rot [B,P,4], trans [B,P,3], conf [B,P]) of each object's class."""
-        B, _, P = values.shape
+        B, _, P = points_cam.shape
         feat, pts = self.features(values, points_cam, pitch, origin, grid_nontarget_empty)
         o, np4 = self.heads(feat, B, P, raw=True)
         if o is not None:

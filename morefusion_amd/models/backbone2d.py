@@ -254,6 +254,38 @@ class PSPNetExtractor(nn.Module):
         u2 = F.dropout(self.up2(h), 0.15, self.training)  # [B,64,H,W], H = W = 128
         return self._tail(u2, taps)
 
+    def forward_sampled_rows(self, x, pix):
+        """``forward_sampled`` through ONE HIP launch (csrc/psp_tail.hip) -> rows [B*P, 32] (the point MLP's
+        GEMM input): the taps' index arithmetic, the four gathers, the 3x3 convolution + PReLU, the 1x1
+        convolution and the log-softmax of the torch formulation (~55 launches) fused.  Inference, fp32, CUDA."""
+        from .. import _lib
+        h = self.psp(x)
+        h = self.up1(h)
+        u2 = self.up2(h)  # [B,64,H,W], H = W = 128; NCHW or channels-last strides, both read in place
+        if u2.dtype != torch.float32:
+            u2 = u2.float()
+        B, C, H, W = u2.shape
+        assert C == 64 and self.conv1.out_channels == 32
+        key = (self.up3.conv.weight.data_ptr(), self.up3.conv.weight._version, self.conv1.weight.data_ptr(),
+               self.conv1.weight._version)
+        pack = self.__dict__.get("_tail_pack")
+        if pack is None or pack[0] != key:
+            w3t = self.up3.conv.weight.detach().float().permute(2, 3, 1, 0).reshape(9, 64, 64).contiguous()
+            w1t = self.conv1.weight.detach().float().reshape(32, 64).t().contiguous()
+            pack = (key, w3t, w1t)
+            self.__dict__["_tail_pack"] = pack
+        _, w3t, w1t = pack
+        _lib.require_gpu(u2, pix)
+        pixc = pix.reshape(-1).to(torch.int64).contiguous()
+        P = pix.shape[1]
+        out = torch.empty((B * P, 32), dtype=torch.float32, device=u2.device)
+        _lib.check(_lib.lib().mf_psp_tail_fwd(
+            u2.data_ptr(), u2.stride(0), u2.stride(1), u2.stride(2), u2.stride(3), pixc.data_ptr(), w3t.data_ptr(),
+            self.up3.conv.bias.detach().float().data_ptr(), self.up3.prelu.weight.detach().float().data_ptr(),
+            w1t.data_ptr(), self.conv1.bias.detach().float().data_ptr(), B, P, H, W, out.data_ptr(),
+            _lib.stream_ptr()), "mf_psp_tail_fwd")
+        return out
+
     @staticmethod
     def _tail_taps(pix, H, W):
         """Source taps at the [H,W] level (128^2) of every 3x3 window element of the sampled

@@ -213,3 +213,40 @@ def test_point_prep_and_pose_epilogue_vs_numpy():
     t = np.stack([o[rows, np4 + 3 * fg + k] for k in range(3)], 1)
     np.testing.assert_allclose(trans, (pts * pb + np.repeat(origin, P, 0)) + t * pb, atol=1e-7)
     np.testing.assert_allclose(conf[:, 0], 1 / (1 + np.exp(-o[rows, 2 * np4 + fg].astype(np.float64))), atol=2e-7)
+
+
+def test_psp_tail_kernel_vs_torch_formulation():
+    """csrc/psp_tail.hip (the last PSPNet level at the sampled pixels, one launch) against the torch formulation
+    it replaces (PSPNetExtractor._tail over _tail_taps: gathers + einsum + conv1d + log_softmax), which
+    tests/test_host_logic.py pins against the dense decoder of models/dense_fusion/pspnet.py.  NCHW and
+    channels-last source maps, image-border pixels (zero padding of the 3x3 convolution) included."""
+    from morefusion_amd.models.backbone2d import PSPNetExtractor
+    L = emul.build(["psp_tail.hip"])
+    i32, i64, p = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+    L.mf_psp_tail_fwd.argtypes = [p, i64, i64, i64, i64, p, p, p, p, p, p] + [i32] * 4 + [p, p]
+    torch.manual_seed(0)
+    net = PSPNetExtractor().eval()
+    with torch.no_grad():
+        net.up3.prelu.weight.fill_(0.2)
+    B, H, W, P = 2, 12, 10, 37
+    u2 = torch.randn(B, 64, H, W)
+    Ho, Wo = 2 * H, 2 * W
+    rs = np.random.RandomState(1)
+    pix = rs.randint(0, Ho * Wo, (B, P))
+    pix[0, :6] = [0, Wo - 1, (Ho - 1) * Wo, Ho * Wo - 1, Wo, 2 * Wo - 1]   # corners and edges
+    pix = torch.from_numpy(pix)
+    with torch.no_grad():
+        ref = net._tail(u2, net._tail_taps(pix, H, W)).transpose(1, 2).reshape(B * P, 32).numpy()
+    w3t = net.up3.conv.weight.detach().permute(2, 3, 1, 0).reshape(9, 64, 64).contiguous().numpy()
+    w1t = net.conv1.weight.detach().reshape(32, 64).t().contiguous().numpy()
+    b3, b1 = net.up3.conv.bias.detach().numpy(), net.conv1.bias.detach().numpy()
+    slope = net.up3.prelu.weight.detach().numpy()
+    pixc = np.ascontiguousarray(pix.numpy().reshape(-1).astype(np.int64))
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        x = u2.contiguous(memory_format=fmt)
+        out = emul.guarded(np.zeros((B * P, 32), np.float32))
+        assert L.mf_psp_tail_fwd(x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), x.stride(3), emul.ptr(pixc),
+                                 emul.ptr(w3t), emul.ptr(b3), emul.ptr(slope), emul.ptr(w1t), emul.ptr(b1), B, P, H, W,
+                                 out.ctypes.data, None) == 0
+        np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
+    assert np.abs(np.exp(ref).sum(1) - 1).max() < 1e-5   # rows are log-probabilities
