@@ -417,24 +417,37 @@ def latency_probe_main():
 
 
 def latency_batch1(wl):
-    """BASELINE configs[1]: singleview_3d inference at batch = 1 (see latency_batch1_measure).  Measured in a
-    CHILD process after this process' own work: the hipGraph replay of the stock 2-D backbone is not reliable
-    on this stack (some of MIOpen's solver picks fault the GPU on a later replay, intermittently), and a GPU
-    fault must not cost the headline line.  A failed probe is reported as such."""
+    """BASELINE configs[1]: singleview_3d inference at batch = 1.  ``predict`` (eager launches, incl. the host
+    synchronisation of the point selection) is measured here, in this process, with the bench's own model
+    (MIOpen find mode on).  The hipGraph replay is measured in a CHILD process (``probe``): replaying the stock
+    2-D backbone from a graph is not reliable on this stack (intermittent GPU faults), and a fault
+    must not cost the headline line.  A failed probe is reported as such."""
     import subprocess
+    one = {k: v[:1].contiguous() for k, v in wl.inputs.items()}
+    out = {}
+    with torch.no_grad():
+        for _ in range(3):
+            wl.model.predict(**one)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            wl.model.predict(**one)
+            torch.cuda.synchronize()
+        out["predict"] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    probe = {"note": "own process, cudnn.benchmark off (immediate-mode MIOpen solvers), host clock incl. device sync"}
     try:
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-latency-b1"], env=env,
                            capture_output=True, text=True, timeout=150)
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-        out = json.loads(lines[-1]) if lines else {}
-        out["note"] = "own process, cudnn.benchmark off (immediate-mode MIOpen solvers), host clock incl. device sync"
+        probe.update(json.loads(lines[-1]) if lines else {})
         if p.returncode != 0:
-            out["probe_error"] = f"exit code {p.returncode}: " + (p.stderr.strip().splitlines() or ["?"])[-1][:200]
-        return out
+            probe["probe_error"] = f"exit code {p.returncode}: " + (p.stderr.strip().splitlines() or ["?"])[-1][:200]
     except Exception as e:  # noqa: BLE001
-        return {"probe_error": f"{type(e).__name__}: {e}"[:300]}
+        probe["probe_error"] = f"{type(e).__name__}: {e}"[:300]
+    out["probe"] = probe
+    return out
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
