@@ -61,6 +61,9 @@ def parse():
                     help="keep the 2-D backbone (ResNet18 + PSPNet) in NHWC memory format")
     ap.add_argument("--priority", choices=["none", "net-high", "icc-high", "icc-low"], default="none",
                     help="HIP stream priorities for the two-stream step (tuning knob)")
+    ap.add_argument("--icc-cus", type=int, default=0,
+                    help="run the ICC stream on this many of the 256 CUs only (CU-masked HIP stream; 0 = no mask)")
+    ap.add_argument("--icc-cu-pattern", choices=["low", "spread"], default="spread")
     ap.add_argument("--stage-breakdown", action="store_true", default=True)
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the batch-1 latency child process")
     ap.add_argument("--probe-latency-b1", action="store_true", help="(internal) batch-1 latency probe, own process")
@@ -88,6 +91,22 @@ def _low_priority_stream(device):
     assert hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0
     handle = ctypes.c_void_p()
     assert hip.hipStreamCreateWithPriority(ctypes.byref(handle), 1, least.value) == 0  # 1 = non-blocking
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
+def _cu_masked_stream(device, n_cus, pattern="low"):
+    """A HIP stream whose kernels may only run on ``n_cus`` of the 256 CUs (hipExtStreamCreateWithCUMask):
+    confines the refinement's many short launches to a part of the chip while the network keeps the rest."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (ctypes.c_uint32 * 8)()
+    total = 256
+    picked = range(n_cus) if pattern == "low" else range(0, total, max(1, total // n_cus))
+    for cu in list(picked)[:n_cus]:
+        words[cu // 32] |= 1 << (cu % 32)
+    handle = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), 8, words)
+    assert rc == 0, f"hipExtStreamCreateWithCUMask failed ({rc})"
     return torch.cuda.ExternalStream(handle.value, device=device)
 
 
@@ -131,6 +150,8 @@ class Workload:
         self.net_stream = torch.cuda.Stream(device=device, priority=-1) if args.priority == "net-high" else None
         if args.priority == "icc-low":
             self.icc_stream = _low_priority_stream(device)
+        if args.icc_cus:
+            self.icc_stream = _cu_masked_stream(device, args.icc_cus, args.icc_cu_pattern)
 
     def _mark(self, name):
         if self._timing:
@@ -688,7 +709,7 @@ def main():
                 "streams": "1 (serial)" if args.no_overlap else
                            "2 (pipelined: ICC(k) waits on network(k)'s event and overlaps network(k+1); "
                            "stage_ms are the serial stage times)",
-                "stream_priority": args.priority, "backbone_memory_format":
+                "stream_priority": args.priority, "icc_cu_mask": args.icc_cus or None, "backbone_memory_format":
                     "channels_last" if args.channels_last else "contiguous",
             },
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},

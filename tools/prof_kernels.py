@@ -82,6 +82,8 @@ if "net" in WHAT or "valid" in WHAT:
             args = (inp["class_id"], values, points, inp["pitch"].float(), inp["origin"].float(), inp["grid_nontarget_empty"])
             for _ in range(REPS):
                 model._pose_from_features(*args)
+            for _ in range(REPS):
+                model.predict(**inp)                                    # incl. k_psp_tail, rows hand-over
             vol = model._volumetric_cl
             h3 = torch.relu(torch.randn(1, 16 ** 3, 256, device="cuda"))
             for _ in range(REPS):
