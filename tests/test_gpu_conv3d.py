@@ -107,3 +107,21 @@ def test_channels_last_path_equals_channels_first_path_stage_by_stage():
     np.testing.assert_allclose(conf1.cpu().numpy(), conf0.cpu().numpy(), rtol=0, atol=2e-4)
     pitch = inp["pitch"].float().cpu().numpy().reshape(B, 1, 1)
     np.testing.assert_allclose(trans1.cpu().numpy() / pitch, trans0.cpu().numpy() / pitch, rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("fmt", [torch.contiguous_format, torch.channels_last], ids=["nchw", "nhwc"])
+def test_psp_tail_kernel_vs_torch_formulation_on_gpu(fmt):
+    """``PSPNetExtractor.forward_sampled_rows`` (csrc/psp_tail.hip, one launch) against ``forward_sampled`` (the torch
+    formulation of round 1-2, pinned against the dense decoder of models/dense_fusion/pspnet.py by
+    tests/test_host_logic.py) at the network's size: 8 objects x 1000 pixels of a 256^2 image, incl. border pixels."""
+    torch.manual_seed(3)
+    model = _model(3)
+    net = model.pspnet_extractor
+    x = torch.randn(8, 512, 32, 32, device="cuda").contiguous(memory_format=fmt)
+    pix = torch.randint(0, 256 * 256, (8, 1000), device="cuda")
+    pix[:, :4] = torch.tensor([0, 255, 255 * 256, 256 * 256 - 1], device="cuda")
+    with torch.no_grad():
+        ref = net.forward_sampled(x, pix).transpose(1, 2).reshape(8000, 32)
+        got = net.forward_sampled_rows(x, pix)
+    assert float((got - ref).abs().max()) < 5e-5 * max(1.0, float(ref.abs().max()))
+    assert float((got.exp().sum(1) - 1).abs().max()) < 1e-4
