@@ -79,76 +79,99 @@ __global__ __launch_bounds__(256, 2) void k_linear_mfma(LinArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  // a chunk past K reads the row's FIRST chunk (always inside the matrix) and selects zeros
-#define MF_LIN_FETCH(kt_)                                                                         \
+  // a chunk past K reads the row's FIRST chunk (always inside the matrix) and selects zeros.
+  // Two register sets (P, Q): the loads of K-tile t + 2 are issued while tile t is multiplied and tile t + 1 waits in
+  // the other set -- a TWO-tile prefetch distance.  The wide operand (the heads' [8000, 984] input) streams from HBM /
+  // Infinity Cache with no reuse inside a workgroup: one tile ahead (1.7-3.4 us of MFMAs) did not cover a loaded
+  // miss (MFMA pipe 0.69 busy, profiles/r03_mfma_kernels_pmc.json; conv4, whose taps re-hit L2, runs at 0.84).
+#define MF_LIN_FETCH(S, kt_)                                                                      \
   {                                                                                               \
     const int ko = (kt_) * kBK;                                                                   \
-    const bool kin = ko + 4 * chunk + 4 <= a.K;                                                   \
-    const int kq = kin ? ko + 4 * chunk : 0;                                                      \
-    ra0 = *reinterpret_cast<const float4 *>(arow[0] + kq);                                        \
-    ra1 = *reinterpret_cast<const float4 *>(arow[1] + kq);                                        \
+    kin##S = ko + 4 * chunk + 4 <= a.K;                                                           \
+    const int kq = kin##S ? ko + 4 * chunk : 0;                                                   \
+    ra0##S = *reinterpret_cast<const float4 *>(arow[0] + kq);                                     \
+    ra1##S = *reinterpret_cast<const float4 *>(arow[1] + kq);                                     \
     if constexpr (MI == 2) {                                                                      \
-      ra2 = *reinterpret_cast<const float4 *>(arow[2] + kq);                                      \
-      ra3 = *reinterpret_cast<const float4 *>(arow[3] + kq);                                      \
+      ra2##S = *reinterpret_cast<const float4 *>(arow[2] + kq);                                   \
+      ra3##S = *reinterpret_cast<const float4 *>(arow[3] + kq);                                   \
     }                                                                                             \
-    rb0 = *reinterpret_cast<const float4 *>(wrow[0] + kq);                                        \
-    rb1 = *reinterpret_cast<const float4 *>(wrow[1] + kq);                                        \
-    rb2 = *reinterpret_cast<const float4 *>(wrow[2] + kq);                                        \
-    rb3 = *reinterpret_cast<const float4 *>(wrow[3] + kq);                                        \
-    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                         \
-    if (!(kin && aok[0])) ra0 = z;                                                                \
-    if (!(kin && aok[1])) ra1 = z;                                                                \
-    if (!(kin && aok[2])) ra2 = z;                                                                \
-    if (!(kin && aok[3])) ra3 = z;                                                                \
-    if (!kin) { rb0 = z; rb1 = z; rb2 = z; rb3 = z; }                                             \
+    rb0##S = *reinterpret_cast<const float4 *>(wrow[0] + kq);                                     \
+    rb1##S = *reinterpret_cast<const float4 *>(wrow[1] + kq);                                     \
+    rb2##S = *reinterpret_cast<const float4 *>(wrow[2] + kq);                                     \
+    rb3##S = *reinterpret_cast<const float4 *>(wrow[3] + kq);                                     \
   }
-#define MF_LIN_STASH(buf_)                                                                        \
+  // Rows past M read row 0 and compute values nobody stores (the epilogue skips them).  Chunks past K are zeroed in
+  // the STASH, behind a branch that is only ever taken in the last K-tile: as selects right behind the loads they made
+  // every fetch wait for its own data (s_waitcnt vmcnt(0) immediately after issue) -- the prefetch hid nothing.
+#define MF_LIN_STASH(S, buf_)                                                                     \
   {                                                                                               \
     float *As_ = s_mem + (buf_) * kTileFloats + r0 * kPitch + 4 * chunk;                          \
     float *Bs_ = As_ + kBM * kPitch;                                                              \
-    *reinterpret_cast<float4 *>(As_) = ra0;                                                       \
-    *reinterpret_cast<float4 *>(As_ + 32 * kPitch) = ra1;                                         \
-    if constexpr (MI == 2) {                                                                      \
-      *reinterpret_cast<float4 *>(As_ + 64 * kPitch) = ra2;                                       \
-      *reinterpret_cast<float4 *>(As_ + 96 * kPitch) = ra3;                                       \
+    if (!kin##S) { /* only in the last K-tile of a K that is no multiple of 32 */                 \
+      ra0##S = ra1##S = ra2##S = ra3##S = z4;                                                     \
+      rb0##S = rb1##S = rb2##S = rb3##S = z4;                                                     \
     }                                                                                             \
-    *reinterpret_cast<float4 *>(Bs_) = rb0;                                                       \
-    *reinterpret_cast<float4 *>(Bs_ + 32 * kPitch) = rb1;                                         \
-    *reinterpret_cast<float4 *>(Bs_ + 64 * kPitch) = rb2;                                         \
-    *reinterpret_cast<float4 *>(Bs_ + 96 * kPitch) = rb3;                                         \
+    *reinterpret_cast<float4 *>(As_) = ra0##S;                                                    \
+    *reinterpret_cast<float4 *>(As_ + 32 * kPitch) = ra1##S;                                      \
+    if constexpr (MI == 2) {                                                                      \
+      *reinterpret_cast<float4 *>(As_ + 64 * kPitch) = ra2##S;                                    \
+      *reinterpret_cast<float4 *>(As_ + 96 * kPitch) = ra3##S;                                    \
+    }                                                                                             \
+    *reinterpret_cast<float4 *>(Bs_) = rb0##S;                                                    \
+    *reinterpret_cast<float4 *>(Bs_ + 32 * kPitch) = rb1##S;                                      \
+    *reinterpret_cast<float4 *>(Bs_ + 64 * kPitch) = rb2##S;                                      \
+    *reinterpret_cast<float4 *>(Bs_ + 96 * kPitch) = rb3##S;                                      \
   }
-  float4 ra0, ra1, ra2 = make_float4(0, 0, 0, 0), ra3 = ra2, rb0, rb1, rb2, rb3;
-  MF_LIN_FETCH(0);
-  MF_LIN_STASH(0);
-  __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    MF_LIN_FETCH(t + 1 < T ? t + 1 : t);
-    asm volatile("" ::: "memory");  // keep the eight loads in front of the MFMAs (see conv3d.hip)
-    __builtin_amdgcn_sched_barrier(0);
-    const float *As = s_mem + (t & 1) * kTileFloats + (wm * 32 * MI + lrow) * kPitch + 4 * lhalf;
-    const float *Bs = s_mem + (t & 1) * kTileFloats + (kBM + wn * 64 + lrow) * kPitch + 4 * lhalf;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const float4 a0 = *reinterpret_cast<const float4 *>(As + 8 * kk);
-      const float4 a1 = MI == 2 ? *reinterpret_cast<const float4 *>(As + 32 * kPitch + 8 * kk) : a0;
-      const float4 b0 = *reinterpret_cast<const float4 *>(Bs + 8 * kk);
-      const float4 b1 = *reinterpret_cast<const float4 *>(Bs + 32 * kPitch + 8 * kk);
 #define MF_LIN_STEP(c_)                                                                           \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c_, b0.c_, acc[0][0], 0, 0, 0);         \
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c_, b1.c_, acc[0][1], 0, 0, 0);         \
-      if constexpr (MI == 2) {                                                                    \
-        acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c_, b0.c_, acc[MI - 1][0], 0, 0, 0); \
-        acc[MI - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c_, b1.c_, acc[MI - 1][1], 0, 0, 0); \
-      }
-      MF_LIN_STEP(x)
-      MF_LIN_STEP(y)
-      MF_LIN_STEP(z)
-      MF_LIN_STEP(w)
-#undef MF_LIN_STEP
-    }
-    MF_LIN_STASH((t + 1) & 1);
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c_, b0.c_, acc[0][0], 0, 0, 0);             \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c_, b1.c_, acc[0][1], 0, 0, 0);             \
+  if constexpr (MI == 2) {                                                                        \
+    acc[MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c_, b0.c_, acc[MI - 1][0], 0, 0, 0); \
+    acc[MI - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c_, b1.c_, acc[MI - 1][1], 0, 0, 0); \
+  }
+  // the 16 (MI = 2) MFMAs x 4 k-steps of K-tile `buf_`'s LDS buffer
+#define MF_LIN_COMPUTE(buf_)                                                                      \
+  {                                                                                               \
+    const float *As = s_mem + (buf_) * kTileFloats + (wm * 32 * MI + lrow) * kPitch + 4 * lhalf;  \
+    const float *Bs = s_mem + (buf_) * kTileFloats + (kBM + wn * 64 + lrow) * kPitch + 4 * lhalf; \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                            \
+      const float4 a0 = *reinterpret_cast<const float4 *>(As + 8 * kk);                           \
+      const float4 a1 = MI == 2 ? *reinterpret_cast<const float4 *>(As + 32 * kPitch + 8 * kk) : a0; \
+      const float4 b0 = *reinterpret_cast<const float4 *>(Bs + 8 * kk);                           \
+      const float4 b1 = *reinterpret_cast<const float4 *>(Bs + 32 * kPitch + 8 * kk);             \
+      MF_LIN_STEP(x) MF_LIN_STEP(y) MF_LIN_STEP(z) MF_LIN_STEP(w)                                 \
+    }                                                                                             \
+  }
+#define MF_LIN_PIN()                                                                              \
+  asm volatile("" ::: "memory"); /* keep the eight loads in front of the MFMAs (see conv3d.hip) */ \
+  __builtin_amdgcn_sched_barrier(0);
+  const float4 z4 = make_float4(0, 0, 0, 0);
+  float4 ra0P, ra1P, ra2P = z4, ra3P = z4, rb0P, rb1P, rb2P, rb3P;
+  float4 ra0Q, ra1Q, ra2Q = z4, ra3Q = z4, rb0Q, rb1Q, rb2Q, rb3Q;
+  bool kinP = false, kinQ = false;
+  const int Tl = T - 1;  // (tile indices past the end re-fetch the last tile: branch-free loads)
+  MF_LIN_FETCH(P, 0);
+  MF_LIN_STASH(P, 0);
+  MF_LIN_FETCH(P, min(1, Tl));  // set P <- tile 1
+  __syncthreads();
+  for (int t = 0; t < T; t += 2) {
+    // even tile t: LDS buffer 0; set Q <- tile t + 2; set P (tile t + 1) -> buffer 1
+    MF_LIN_FETCH(Q, min(t + 2, Tl));
+    MF_LIN_PIN();
+    MF_LIN_COMPUTE(0);
+    MF_LIN_STASH(P, 1);
+    __syncthreads();
+    if (t + 1 >= T) break;  // block-uniform
+    // odd tile t + 1: LDS buffer 1; set P <- tile t + 3; set Q (tile t + 2) -> buffer 0
+    MF_LIN_FETCH(P, min(t + 3, Tl));
+    MF_LIN_PIN();
+    MF_LIN_COMPUTE(1);
+    MF_LIN_STASH(Q, 0);
     __syncthreads();
   }
+#undef MF_LIN_PIN
+#undef MF_LIN_COMPUTE
+#undef MF_LIN_STEP
 #undef MF_LIN_FETCH
 #undef MF_LIN_STASH
 
