@@ -175,24 +175,43 @@ __global__ __launch_bounds__(256, 2) void k_linear_mfma(LinArgs a) {
 #undef MF_LIN_FETCH
 #undef MF_LIN_STASH
 
+  // Epilogue through LDS (the operand buffers are free: the loop ended on a barrier): a lane holds one COLUMN of
+  // sixteen rows per accumulator, i.e. 64 four-byte stores scattered over 64 output rows -- store-issue bound, 8 us of
+  // a 60 us workgroup at K = 984.  Bias + activation are applied on the way into a [rows][128 + 4] tile, each lane then
+  // writes 16-byte row segments: 16 coalesced stores per lane instead of 64 scalar ones.
   float *dst = a.out + grp * a.o_gs;
   const float *bias = a.bias ? a.bias + grp * a.b_gs : nullptr;
+  constexpr int kEp = kBN + 4;
+  float *s_out = s_mem;  // [kBM][kEp] floats: 67.6 KB (MI = 2) / 33.8 KB (MI = 1) <= the two operand buffers
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-      const int n = n0 + wn * 64 + ni * 32 + lrow;
-      if (n >= a.N) continue;
-      const float bn = bias ? bias[n] : 0.0f;
+      const int nl = wn * 64 + ni * 32 + lrow;
+      const float bn = (bias && n0 + nl < a.N) ? bias[n0 + nl] : 0.0f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 32 * MI + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-        if (m >= a.M) continue;
+        const int ml = wm * 32 * MI + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
         float v = acc[mi][ni][e] + bn;
         if (a.relu) v = v > 0.0f ? v : 0.0f;
-        dst[(int64_t)m * a.ldo + n] = v;
+        s_out[ml * kEp + nl] = v;
       }
     }
+  __syncthreads();
+  const bool vec_ok = (a.ldo & 3) == 0 && (((uintptr_t)dst) & 15) == 0;  // 16-byte stores need aligned rows
+  for (int i = tid; i < kBM * (kBN / 4); i += 256) {
+    const int ml = i / (kBN / 4), c4 = i - ml * (kBN / 4);
+    const int m = m0 + ml, n = n0 + 4 * c4;
+    if (m >= a.M || n >= a.N) continue;
+    const float4 v = *reinterpret_cast<const float4 *>(s_out + ml * kEp + 4 * c4);
+    float *o = dst + (int64_t)m * a.ldo + n;
+    if (vec_ok && n + 4 <= a.N) {
+      *reinterpret_cast<float4 *>(o) = v;
+    } else {
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      for (int j = 0; j < 4 && n + j < a.N; ++j) o[j] = vv[j];
+    }
+  }
 }
 
 }  // namespace

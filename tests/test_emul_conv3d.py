@@ -151,6 +151,14 @@ def test_linear_mfma_gemm_vs_float64():
                 ref = np.maximum(ref, 0)
             np.testing.assert_allclose(out[:, 4 + 100 * g:4 + 100 * g + N], ref, rtol=0, atol=2e-6)
         assert (out[:, :4] == 9.0).all() and (out[:, 4 + N:104] == 9.0).all() and (out[:, 104 + N:] == 9.0).all()
+    # an output block that is not 16-byte aligned takes the scalar-store path of the epilogue
+    out[:] = 9.0
+    assert L.mf_linear_fwd(A[:, 8:].ctypes.data, 80, lda, emul.ptr(W), Npad * K, K, emul.ptr(bias), N,
+                           out[:, 5:].ctypes.data, 100, ldo, M, N, Npad, K, groups, 1, None) == 0
+    for g in range(groups):
+        ref = np.maximum(A[:, 8 + 80 * g:8 + 80 * g + K].astype(np.float64) @ W[g, :N].astype(np.float64).T + bias[g], 0)
+        np.testing.assert_allclose(out[:, 5 + 100 * g:5 + 100 * g + N], ref, rtol=0, atol=2e-6)
+    assert (out[:, :5] == 9.0).all() and (out[:, 5 + N:105] == 9.0).all()
     # full-height (128 x 128) tiles: taken when >= 256 of them exist (the heads' first layer at batch 8)
     Mb, Nb, Kb = 2200, 1920, 40
     Ab = emul.guarded(rs.uniform(-1, 1, (Mb, Kb)).astype(np.float32))
