@@ -28,6 +28,12 @@ from .... import _lib
 from .sparse_conv import SparseVoxelConv3d
 
 
+# Row pitch of the heads' input matrix F: 984 feature columns padded to 992 floats = 31 x 128 bytes, so that every
+# row -- and every 128-byte K chunk the GEMM kernels stage -- starts on a cache-line boundary (984 x 4 B = 30.75
+# lines: every chunk straddled two).  Columns 984..991 are zero (and so are the packed weights' columns there).
+F_COLS, F_LD = 984, 992
+
+
 class ChannelsLastVolumetric:
     """Weight packs, workspaces and the launch sequence; one instance per Model (and device)."""
 
@@ -149,13 +155,14 @@ class ChannelsLastVolumetric:
         dev = values.device
         pts, tc4, x_rgb, batch_indices = self.prep(values, points_cam, pitch, origin)
         to_center = tc4[:, :3]
-        feat = torch.empty((n, 984), dtype=torch.float32, device=dev)
+        feat = torch.empty((n, F_LD), dtype=torch.float32, device=dev)
+        feat[:, F_COLS:].zero_()
 
         if self.mfma_linear and not torch.is_autocast_enabled():
-            self._linear("conv1_rgb", [m.conv1_rgb], x_rgb, 32, feat[:, 0:64], 984, relu=True)
-            self._linear("conv1_pcd", [m.conv1_pcd], tc4, 4, feat[:, 64:72], 984, relu=True, k_pad=4)
-            self._linear("conv2_rgb", [m.conv2_rgb], feat[:, 0:64], 984, feat[:, 72:200], 984, relu=True)
-            self._linear("conv2_pcd", [m.conv2_pcd], feat[:, 64:72], 984, feat[:, 200:216], 984, relu=True)
+            self._linear("conv1_rgb", [m.conv1_rgb], x_rgb, 32, feat[:, 0:64], F_LD, relu=True)
+            self._linear("conv1_pcd", [m.conv1_pcd], tc4, 4, feat[:, 64:72], F_LD, relu=True, k_pad=4)
+            self._linear("conv2_rgb", [m.conv2_rgb], feat[:, 0:64], F_LD, feat[:, 72:200], F_LD, relu=True)
+            self._linear("conv2_pcd", [m.conv2_pcd], feat[:, 64:72], F_LD, feat[:, 200:216], F_LD, relu=True)
         else:
             w, b = self._linear_pack("conv1_rgb", m.conv1_rgb)
             h_rgb = F.relu(F.linear(x_rgb, w, b))
@@ -173,11 +180,11 @@ class ChannelsLastVolumetric:
         if m._with_occupancy:
             h_occ = self.occupancy(grid_nontarget_empty)
             dense = self.conv_k4s2("conv3_occ", m.conv3, h_occ, B, D, cin=16, c_off=144, relu=False, bias=False)
-        h3 = self._sparse.from_points_cl(feat[:, 72:216], 984, pts, batch_indices, B, dense, D)  # [B, 16^3, 256]
+        h3 = self._sparse.from_points_cl(feat[:, 72:216], F_LD, pts, batch_indices, B, dense, D)  # [B, 16^3, 256]
         pts2 = pts * 0.5  # == pts / 2.0 (a power of two: same bits); one launch serves both samplers' scales
-        self.sample(h3, D // 2, pts2, batch_indices, feat[:, 216:472], 984)
+        self.sample(h3, D // 2, pts2, batch_indices, feat[:, 216:472], F_LD)
         h4 = self.conv_k4s2("conv4", m.conv4, h3, B, D // 2, cin=256)                            # [B, 8^3, 512]
-        self.sample(h4, D // 4, pts2 * 0.5, batch_indices, feat[:, 472:984], 984)
+        self.sample(h4, D // 4, pts2 * 0.5, batch_indices, feat[:, 472:984], F_LD)
         return feat, pts
 
     # ---- 1x1 convolutions as grouped fp32-MFMA GEMMs -------------------------------------------
@@ -221,8 +228,10 @@ class ChannelsLastVolumetric:
             # layer 1 of the three heads = one GEMM against the stacked weights [1920, 984]
             def build1():
                 w = torch.cat([getattr(m, f"conv1_{k}").weight.detach().float().squeeze(-1) for k in names])
+                wp = torch.zeros((w.shape[0], F_LD), dtype=torch.float32, device=w.device)
+                wp[:, :F_COLS] = w
                 b = torch.cat([getattr(m, f"conv1_{k}").bias.detach().float() for k in names])
-                return w.contiguous()[None], b.contiguous()[None]
+                return wp.contiguous()[None], b.contiguous()[None]
             w1, b1 = self._pack("gemm_heads1", [t for k in names for t in (getattr(m, f"conv1_{k}").weight,
                                                                             getattr(m, f"conv1_{k}").bias)], build1)
             h1 = self._scratch("heads_h1", (n, 1920), dev)
@@ -231,8 +240,9 @@ class ChannelsLastVolumetric:
             np4 = -(-(nf * 4) // 128) * 128
             o = torch.empty((n, 3 * np4), dtype=torch.float32, device=dev)
             L = _lib.lib()
-            _lib.check(L.mf_linear_fwd(feat.data_ptr(), 0, feat.stride(0), w1.data_ptr(), 0, 984, b1.data_ptr(), 0,
-                                       h1.data_ptr(), 0, 1920, n, 1920, 1920, 984, 1, 1, _lib.stream_ptr()),
+            assert feat.stride(0) == F_LD
+            _lib.check(L.mf_linear_fwd(feat.data_ptr(), 0, F_LD, w1.data_ptr(), 0, F_LD, b1.data_ptr(), 0,
+                                       h1.data_ptr(), 0, 1920, n, 1920, 1920, F_LD, 1, 1, _lib.stream_ptr()),
                        "mf_linear_fwd")
             self._linear("heads2", [getattr(m, f"conv2_{k}") for k in names], h1, 1920, h2, 768, True, a_gs=640, o_gs=256)
             self._linear("heads3", [getattr(m, f"conv3_{k}") for k in names], h2, 768, h3, 384, True, a_gs=256, o_gs=128)
@@ -253,7 +263,7 @@ class ChannelsLastVolumetric:
             return None, 0
         outs = {}
         for name in names:
-            x = feat
+            x = feat[:, :F_COLS]
             for i in (1, 2, 3):
                 w, b = self._linear_pack(f"conv{i}_{name}", getattr(m, f"conv{i}_{name}"))
                 x = F.relu(F.linear(x, w, b))

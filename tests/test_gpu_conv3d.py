@@ -97,7 +97,7 @@ def test_channels_last_path_equals_channels_first_path_stage_by_stage():
         bi = torch.arange(B, dtype=torch.int32, device="cuda").repeat_interleave(P)
         f2 = feat[:, 72:216].contiguous()
         h3_cf = vol._sparse.from_points(f2, pts, bi, batch_size=B, h_dense=None, dim=32)
-        h3_cl = vol._sparse.from_points_cl(feat[:, 72:216], 984, pts, bi, B, None, 32)
+        h3_cl = vol._sparse.from_points_cl(feat[:, 72:216], feat.stride(0), pts, bi, B, None, 32)
         assert torch.equal(_cf(h3_cl, 16), h3_cf)
         s_cf = mf.functions.interpolate_voxel_grid(h3_cf, pts / 2.0, bi)
         blk = torch.zeros((B * P, 260), device="cuda")

@@ -105,7 +105,7 @@ if WHAT & {"conv4", "conv3d", "conv4b1", "heads1"}:   # one shape of the MFMA ke
             for _ in range(REPS):
                 vol.conv_k4s2("conv3_occ", model.conv3, h_occ, B, 32, cin=16, c_off=144, relu=False, bias=False)
         if "heads1" in WHAT:
-            feat = torch.randn(B * P, 984, device="cuda")
+            feat = torch.zeros(B * P, 992, device="cuda"); feat[:, :984].normal_()
             for _ in range(REPS):
                 vol.heads(feat, B, P)
 if "icc" in WHAT:   # pose_refinement ICC: 1 scene x 8 objects, 100 iterations

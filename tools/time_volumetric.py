@@ -74,15 +74,15 @@ def main():
             pts = pv.transpose(1, 2).reshape(B * P, 3).contiguous()
             bi = torch.arange(B, dtype=torch.int32, device="cuda").repeat_interleave(P)
             dense = vol.conv_k4s2("conv3_occ", model.conv3, h_occ, B, 32, cin=16, c_off=144, relu=False, bias=False)
-            r["sparse_conv3_cl_ms"] = round(t_ms(lambda: vol._sparse.from_points_cl(feat[:, 72:216], 984, pts, bi, B, dense, 32)), 4)
+            r["sparse_conv3_cl_ms"] = round(t_ms(lambda: vol._sparse.from_points_cl(feat[:, 72:216], feat.stride(0), pts, bi, B, dense, 32)), 4)
             f2 = feat[:, 72:216].contiguous()
             dense_cf = dense.transpose(1, 2).reshape(B, 256, 16, 16, 16).contiguous()
             # channels-first kernel with a precomputed dense addend (h_dense=None path adds nothing; time the kernels only)
             r["sparse_conv3_cf_ms"] = round(t_ms(lambda: vol._sparse.from_points(f2, pts, bi, batch_size=B, h_dense=None, dim=32)), 4)
-            h3r = vol._sparse.from_points_cl(feat[:, 72:216], 984, pts, bi, B, dense, 32)
+            h3r = vol._sparse.from_points_cl(feat[:, 72:216], feat.stride(0), pts, bi, B, dense, 32)
             h4r = vol.conv_k4s2("conv4", model.conv4, h3r, B, 16, cin=256)
-            r["sample_feat3_cl_ms"] = round(t_ms(lambda: vol.sample(h3r, 16, pts / 2.0, bi, feat[:, 216:472], 984)), 4)
-            r["sample_feat4_cl_ms"] = round(t_ms(lambda: vol.sample(h4r, 8, pts / 4.0, bi, feat[:, 472:984], 984)), 4)
+            r["sample_feat3_cl_ms"] = round(t_ms(lambda: vol.sample(h3r, 16, pts / 2.0, bi, feat[:, 216:472], feat.stride(0))), 4)
+            r["sample_feat4_cl_ms"] = round(t_ms(lambda: vol.sample(h4r, 8, pts / 4.0, bi, feat[:, 472:984], feat.stride(0))), 4)
             r["heads_ms"] = round(t_ms(lambda: vol.heads(feat, B, P)), 4)
             r["features_ms"] = round(t_ms(lambda: vol.features(values, points, inp["pitch"].float(), inp["origin"].float(),
                                                                inp["grid_nontarget_empty"])), 4)
