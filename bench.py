@@ -395,7 +395,7 @@ def handwritten_path(wl, reps=10):
     return t_vol, t_icc
 
 
-def latency_batch1_measure(model, one, reps=30):
+def latency_batch1_measure(model, one, reps=12):
     """Per-frame latency (ms, host clock around call + device sync, i.e. input ready -> poses ready) of
       predict            eager launches, incl. the host synchronisation of the point selection;
       predict_graphed    the same work with everything after the selection replayed from one hipGraph.
