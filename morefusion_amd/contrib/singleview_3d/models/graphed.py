@@ -36,19 +36,6 @@ class GraphedPredict:
         # Warm-up and capture run with IMMEDIATE-mode solver selection (cudnn.benchmark off): under MIOpen's find
         # mode the selected solvers vary from run to run, and some of them are not replayable (measured: the same
         # capture replays fine in one process and faults the GPU in the next; with immediate mode it is stable).
-        # The graph is captured with the TORCH formulation of the sampled PSPNet tail: with k_psp_tail inside, the
-        # replay phase of the latency probe faulted the GPU in 3 of 6 processes, with the torch tail in 0 of 13 (the
-        # kernel itself reads and writes in bounds: emulator run with every buffer in front of a guard page, and
-        # hundreds of eager launches).  Cause unknown; the eager path with the kernel is as fast as the replay.
-        self.model.__dict__["_torch_tail_only"] = True
-        try:
-            self._capture_locked(e, cur, side)
-        finally:
-            self.model.__dict__["_torch_tail_only"] = False
-        e.ptrs = [a.data_ptr() if a is not None else 0 for a in e.inputs]
-        return e
-
-    def _capture_locked(self, e, cur, side):
         with torch.backends.cudnn.flags(enabled=True, benchmark=False):
             with torch.cuda.stream(side):  # solver selection, workspaces, LDS opt-ins: before the capture
                 for _ in range(self.warmup):
@@ -58,6 +45,8 @@ class GraphedPredict:
             e.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(e.graph):
                 e.outputs = self.model._predict_device(*e.inputs)
+        e.ptrs = [a.data_ptr() if a is not None else 0 for a in e.inputs]
+        return e
 
     def __call__(self, *args):
         key = self._key(args)

@@ -296,7 +296,6 @@ class Model(nn.Module):
         # inference on the channels-last kernels: the PSPNet tail hands over feature ROWS [n,32] (one launch)
         rows = (self.channels_last_3d and self.sparse_conv3 and self.sparse_pspnet_tail and rgb.is_cuda
                 and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
-                and not getattr(self, "_torch_tail_only", False)      # set while a hipGraph is warmed up / captured
                 and os.environ.get("MF_NO_TAIL_KERNEL") != "1")  # (A/B knob: the torch formulation of the tail)
         values, points = self._backbone_features(rgb, pcd, pix, rows=rows)
         return self._pose_from_features(class_id, values, points, pitch, origin, grid_nontarget_empty)
