@@ -983,7 +983,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   const int ja = meta.x, jb = meta.y;
   const int Ns = jb - ja;
   // all independent loads first: scene tables, scalars, and this thread's voxels
-  if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
+  for (int i = threadIdx.x; i < Ns * 12; i += blockDim.x) s_Rt[i / 12][i % 12] = a.Rt[12 * ja + i];  // Ns up to 64: 768 words
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
   if (threadIdx.x == 0) s_emask = 0ull;
   const float pitch = a.pitch[o];
@@ -1251,7 +1251,7 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   }
   if (tot[0] + tot[1] == 0) return;  // block-uniform: no record of either grid reaches this tile
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
-  if (threadIdx.x < Ns * 12) s_Rt[threadIdx.x / 12][threadIdx.x % 12] = a.Rt[12 * ja + threadIdx.x];
+  for (int i = threadIdx.x; i < Ns * 12; i += blockDim.x) s_Rt[i / 12][i % 12] = a.Rt[12 * ja + i];  // Ns up to 64: 768 words
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
   const float trunc = a.thr * pitch;
   for (int i = threadIdx.x; i < 2 * nvh; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }

@@ -235,12 +235,14 @@ def test_icc_bin_overflow_list_gives_the_same_bits(lib, fixtures3, sp, monkeypat
     assert nbytes < 0.4 * 68 * 3 * P * 16 + 2 * 3 * 32 ** 3 * 8 + (1 << 20)
 
 
-def test_icc_scene_of_more_than_32_objects(lib, sp):
+@pytest.mark.parametrize("n_obj", [40, 64])
+def test_icc_scene_of_more_than_32_objects(lib, sp, n_obj):
     """kMaxSceneObjects is 64 since round 3 (the reference has no limit; round 2 rejected > 32): a 40-object scene
     (thinned point sets: the emulator runs one GPU thread at a time) gives the oracle's loss and gradients.
     40 objects: the 64-bit object masks of k_icc_accum and the second trip of k_icc_fused's moment reduction
-    (one trip covers 37 objects) are both exercised."""
-    sc = synthetic.make_icc_scene(40, seed=5)
+    (one trip covers 37 objects) are both exercised; 64 objects (the limit): the scene pose table is 768 words,
+    more than one word per lane of the 512-lane workgroups that stage it (objects 43.. were uninitialised LDS)."""
+    sc = synthetic.make_icc_scene(n_obj, seed=5)
     sc = dict(sc)
     sc["points"] = [p[::20].copy() for p in sc["points"]]
     sc["sdf"] = [s[::20].copy() for s in sc["sdf"]]
