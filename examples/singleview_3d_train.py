@@ -93,7 +93,13 @@ def main():
     per_rank = max(1, args.global_batch // world)
     np.random.seed(1234 + rank)  # per-rank point / CAD subsampling streams
     rates, losses = [], []
+    # profiling aid: MF_TRAIN_MARK=1 launches a recognisable kernel (erfinv) at program start and in front of the
+    # last two steps, so that `MF_MARK=erfinv tools/kernel_stats.py` keeps exactly one steady-state step
+    mark = (lambda: torch.zeros(1, device=device).erfinv_()) if os.environ.get("MF_TRAIN_MARK") == "1" else (lambda: None)
+    mark()
     for step in range(args.steps):
+        if step >= args.steps - 2:
+            mark()
         b = morefusion.synthetic.make_singleview_batch(per_rank, seed=1000 * rank + step)
         inputs = {k: torch.as_tensor(b[k]).to(device) for k in
                   ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty",

@@ -24,8 +24,12 @@ class IccScenes:
     (points: list of [P_i,3]; sdf: list of [P_i]; pitch [N]; origin [N,3];
     grid_target, grid_nontarget_empty [N,D,D,D])."""
 
-    def __init__(self, scenes, voxel_dim=32, voxel_threshold=2, sdf_offset=0.0, device="cuda"):
+    def __init__(self, scenes, voxel_dim=32, voxel_threshold=2, sdf_offset=0.0, device="cuda", single_pass=None):
+        """``single_pass``: None = choose by the no-entry grids' values (binary -> the single-pass kernel);
+        False forces the general two-kernel iteration (k_icc_tile -> W -> k_icc_accum) on any grids; True is
+        honoured only for {0,1} grids (the polynomial form of the loss holds for those alone)."""
         dev = torch.device(device)
+        self._single_pass = single_pass
         if dev.type != "cuda":
             raise RuntimeError("IccScenes lives on the MI355X (device must be 'cuda')")
         pts, sdf, obj_off, scene_off, obj_scene = [], [], [0], [0], []
@@ -88,6 +92,10 @@ class IccScenes:
         e.g. OctoMap probabilities, take the two-kernel path).  Call again after updating ``pts4`` /
         ``grid_target`` / ``grid_ne`` / ``pitch`` / ``origin`` in place (one host sync for the flag)."""
         self.desc.grid_ne_binary = int(bool(((self.grid_ne == 0) | (self.grid_ne == 1)).all()))
+        if self._single_pass is False:
+            self.desc.grid_ne_binary = 0
+        elif self._single_pass and not self.desc.grid_ne_binary:
+            raise ValueError("single_pass=True needs {0,1}-valued no-entry grids")
         _lib.check(_lib.lib().mf_icc_prepare(ctypes.byref(self.desc), self.ws.data_ptr(), _lib.stream_ptr()),
                    "mf_icc_prepare")
 

@@ -14,7 +14,30 @@ std::mutex g_attr_mu;
 std::set<std::pair<int, const void *>> g_attr_done;
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void k_fill_words(uint32_t *__restrict__ p, uint32_t word, int64_t n) {
+  // 16-byte stores where the address allows it; head / tail words singly
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 4 <= n && (((uintptr_t)(p + i)) & 15) == 0) {
+    *reinterpret_cast<uint4 *>(p + i) = make_uint4(word, word, word, word);
+  } else {
+    for (int64_t j = i; j < n && j < i + 4; ++j) p[j] = word;
+  }
+}
+}  // namespace
+
 namespace mf {
+int fill_bytes(void *dst, int value, int64_t nbytes, hipStream_t stream) {
+  if (nbytes <= 0) return 0;
+  if ((nbytes & 3) || (((uintptr_t)dst) & 3)) {
+    set_last_error(hipErrorInvalidValue, "fill_bytes: 4-byte aligned address and size");
+    return -(int)hipErrorInvalidValue;
+  }
+  const int64_t n = nbytes / 4;
+  const uint32_t word = (uint32_t)(value & 0xff) * 0x01010101u;
+  hipLaunchKernelGGL(k_fill_words, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, (uint32_t *)dst, word, n);
+  return check_launch("fill_bytes");
+}
 void set_last_error(hipError_t e, const char *where) {
   snprintf(g_err, sizeof(g_err), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
 }

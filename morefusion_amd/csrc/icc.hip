@@ -1874,7 +1874,7 @@ extern "C" int mf_icc_launch_stage(const mfIccBatch *batch, const float *q, cons
   if (stage == 0) {
     if (q && t) hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t, (float *)nullptr);
     // inside an iteration k_icc_accum empties the bins; this hook has no accum launch
-    MF_TRY(hipMemsetAsync(a.bin_cnt, 0, sizeof(uint32_t) * 2 * a.O * a.nbins, stream));
+    if (int e_ = mf::fill_bytes(a.bin_cnt, 0, sizeof(uint32_t) * 2 * a.O * a.nbins, stream)) return e_;
     IccStepArgs sp = {};
     hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, sp);
   } else if (stage == 1) {

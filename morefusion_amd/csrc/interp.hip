@@ -491,7 +491,7 @@ extern "C" int mf_interpolate_voxel_grid_bwd(const float *gvalues, const float *
                        stream, gvalues, points, batch_indices, batch_start, n, B, C, X, Y, Z, cpw,
                        gvox, channels_first);
   } else {
-    MF_TRY(hipMemsetAsync(gvox, 0, sizeof(float) * B * C * V, stream));
+    if (int e_ = mf::fill_bytes(gvox, 0, sizeof(float) * B * C * V, stream)) return e_;
     if (n > 0)
       hipLaunchKernelGGL(k_interp_bwd_direct,
                          dim3((unsigned)((n + kInterpThreads - 1) / kInterpThreads),

@@ -32,6 +32,13 @@ inline int check_launch(const char *where) {
 // (device, function) set.
 int allow_big_lds(const void *kernel, int bytes);
 
+// Fill ``nbytes`` (a multiple of 4) at a 4-byte aligned address with the byte ``value``, by a KERNEL on ``stream``.
+// The library never calls hipMemsetAsync: captured into a hipGraph it becomes a memset NODE, and on this stack
+// (ROCm 7.0/7.2 runtime) the kernels behind such a node were seen to start before the fill had landed when the
+// graph is replayed (tools/repro_graph_memset.hip) -- stale per-voxel chain heads then walk out of
+// the point arrays.  A kernel node is ordered like every other kernel of the captured stream.
+int fill_bytes(void *dst, int value, int64_t nbytes, hipStream_t stream);
+
 constexpr int kWave = 64;
 
 // dynamic LDS of the workgroup (tests/host_emul/mf_common.h gives the host-emulation form)

@@ -322,7 +322,7 @@ extern "C" int mf_valid_pixel_order(const float *pcd, int32_t B, int32_t HW, int
   }
   // 16-byte loads need every image to start 16-byte aligned: HW * 3 floats per image
   const int vec = (reinterpret_cast<uintptr_t>(pcd) & 15u) == 0 && HW % 4 == 0;
-  if (HW == 0) return -(int)hipMemsetAsync(counts, 0, sizeof(int32_t) * B, stream);
+  if (HW == 0) return mf::fill_bytes(counts, 0, sizeof(int32_t) * B, stream);
   hipLaunchKernelGGL(k_valid_order, dim3((HW + kCompactChunk - 1) / kCompactChunk, B), dim3(kCompactThreads), 0, stream,
                      pcd, (int)HW, vec, order, counts);
   return mf::check_launch("mf_valid_pixel_order");

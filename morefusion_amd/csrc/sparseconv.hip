@@ -484,7 +484,7 @@ extern "C" int mf_sparse_conv3d_k4s2_fwd(const float *x, const int32_t *counts, 
   ScWs w = sc_carve(ws, B, Cs, Cout, D, max_rows, 0);
   w.a.x = x;
   w.a.counts = counts;
-  MF_TRY(hipMemsetAsync(w.a.class_cnt, 0, 512, stream));  // class_cnt and class_fill
+  if (int e_ = mf::fill_bytes(w.a.class_cnt, 0, 512, stream)) return e_;  // class_cnt and class_fill
   sc_index(w.a, stream);
   hipLaunchKernelGGL(k_sc_gather, dim3((unsigned)(((int64_t)max_rows * Cs + 255) / 256)),
                      dim3(256), 0, stream, w.a);
@@ -505,9 +505,9 @@ extern "C" int mf_sparse_conv3d_k4s2_points_fwd(const float *values, const float
   const int64_t V = (int64_t)D * D * D;
   ScWs w = sc_carve(ws, B, Cs, Cout, D, max_rows, n);
   w.a.counts = w.counts_own;
-  MF_TRY(hipMemsetAsync(w.a.class_cnt, 0, 512, stream));
-  MF_TRY(hipMemsetAsync(w.counts_own, 0, sizeof(int32_t) * B * V, stream));
-  MF_TRY(hipMemsetAsync(w.head, 0xff, sizeof(int32_t) * B * V, stream));
+  if (int e_ = mf::fill_bytes(w.a.class_cnt, 0, 512, stream)) return e_;
+  if (int e_ = mf::fill_bytes(w.counts_own, 0, sizeof(int32_t) * B * V, stream)) return e_;
+  if (int e_ = mf::fill_bytes(w.head, 0xff, sizeof(int32_t) * B * V, stream)) return e_;
   if (n > 0)
     hipLaunchKernelGGL(k_sc_link, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, points,
                        batch_indices, n, B, D, ox, oy, oz, pitch, w.counts_own, w.head, w.link);
@@ -536,9 +536,9 @@ extern "C" int mf_sparse_conv3d_k4s2_points_cl_fwd(const float *values, int64_t 
   const int64_t V = (int64_t)D * D * D;
   ScWs w = sc_carve(ws, B, Cs, Cout, D, max_rows, n);
   w.a.counts = w.counts_own;
-  MF_TRY(hipMemsetAsync(w.a.class_cnt, 0, 512, stream));
-  MF_TRY(hipMemsetAsync(w.counts_own, 0, sizeof(int32_t) * B * V, stream));
-  MF_TRY(hipMemsetAsync(w.head, 0xff, sizeof(int32_t) * B * V, stream));
+  if (int e_ = mf::fill_bytes(w.a.class_cnt, 0, 512, stream)) return e_;
+  if (int e_ = mf::fill_bytes(w.counts_own, 0, sizeof(int32_t) * B * V, stream)) return e_;
+  if (int e_ = mf::fill_bytes(w.head, 0xff, sizeof(int32_t) * B * V, stream)) return e_;
   if (n > 0)
     hipLaunchKernelGGL(k_sc_link, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, points,
                        batch_indices, n, B, D, ox, oy, oz, pitch, w.counts_own, w.head, w.link);

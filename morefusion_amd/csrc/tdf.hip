@@ -235,7 +235,7 @@ extern "C" int mf_pseudo_occupancy_weights(const float *tdf, const int32_t *flat
   hipStream_t stream = (hipStream_t)stream_;
   const int V = X * Y * Z;
   if (V == 0) return 0;
-  MF_TRY(hipMemsetAsync(wmax, 0, sizeof(float), stream));
+  if (int e_ = mf::fill_bytes(wmax, 0, sizeof(float), stream)) return e_;
   hipLaunchKernelGGL(k_pocc_wraw, dim3((V + 255) / 256), dim3(256), 0, stream, flat, sdf, V, K,
                      sdf_offset, win, wsurf, (uint32_t *)wmax);
   hipLaunchKernelGGL(k_pocc_grids, dim3((V + 255) / 256), dim3(256), 0, stream, tdf, V, truncation,

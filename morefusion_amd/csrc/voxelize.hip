@@ -182,16 +182,16 @@ extern "C" int mf_average_voxelization_3d_fwd(const float *values, const float *
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t V = (int64_t)X * Y * Z;
   if (B <= 0 || C <= 0 || V <= 0) return 0;
-  MF_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * B * V, stream));
-  MF_TRY(hipMemsetAsync(head, 0xff, sizeof(int32_t) * B * V, stream));
-  if (nan_flag) MF_TRY(hipMemsetAsync(nan_flag, 0, sizeof(int32_t), stream));
+  if (int e_ = mf::fill_bytes(counts, 0, sizeof(int32_t) * B * V, stream)) return e_;
+  if (int e_ = mf::fill_bytes(head, 0xff, sizeof(int32_t) * B * V, stream)) return e_;
+  if (nan_flag) if (int e_ = mf::fill_bytes(nan_flag, 0, sizeof(int32_t), stream)) return e_;
   if (n > 0) {
     hipLaunchKernelGGL(k_avgvox_link, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                        points, batch_indices, n, B, X, Y, Z, ox, oy, oz, pitch, counts, head, link,
                        nan_flag);
   }
   // dense part at memset speed, then the sparse part (one wave per occupied voxel)
-  MF_TRY(hipMemsetAsync(matrix, 0, sizeof(float) * B * C * V, stream));
+  if (int e_ = mf::fill_bytes(matrix, 0, sizeof(float) * B * C * V, stream)) return e_;
   if (n > 0)
     hipLaunchKernelGGL(k_avgvox_scatter, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
                        values, points, batch_indices, counts, head, link, n, C, B, X, Y, Z, ox,
@@ -221,8 +221,8 @@ extern "C" int mf_max_voxelization_3d_fwd(const float *values, const float *poin
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t V = (int64_t)X * Y * Z;
   if (B <= 0 || C <= 0 || V <= 0) return 0;
-  MF_TRY(hipMemsetAsync(key, 0, sizeof(uint64_t) * B * V, stream));
-  if (nan_flag) MF_TRY(hipMemsetAsync(nan_flag, 0, sizeof(int32_t), stream));
+  if (int e_ = mf::fill_bytes(key, 0, sizeof(uint64_t) * B * V, stream)) return e_;
+  if (nan_flag) if (int e_ = mf::fill_bytes(nan_flag, 0, sizeof(int32_t), stream)) return e_;
   if (n > 0)
     hipLaunchKernelGGL(k_maxvox_key, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                        points, batch_indices, intensities, n, B, X, Y, Z, ox, oy, oz, pitch,

@@ -88,10 +88,13 @@ def all_gather_poses(local_poses, group=None):
     return torch.cat([out[r * n_max: r * n_max + c] for r, c in enumerate(counts)], dim=0)
 
 
-def all_gather_poses_equal(local_poses, out=None, group=None):
+def all_gather_poses_equal(local_poses, out=None, group=None, always=False):
     """Fast path for equal shards (the benchmark's weak-scaling layout): one collective,
-    no host synchronisation, optional preallocated output."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    no host synchronisation, optional preallocated output.  ``always=True`` issues the collective even in a
+    group of one rank (the single-GPU test of the RCCL path)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_poses
+    if dist.get_world_size(group) == 1 and not always:
         return local_poses
     world = dist.get_world_size(group)
     if out is None:

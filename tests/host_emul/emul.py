@@ -160,3 +160,90 @@ def guarded(a):
     out = np.frombuffer(buf, dtype=a.dtype).reshape(a.shape)
     out[...] = a
     return out
+
+
+class GuardedTensors:
+    """Every torch (CPU) tensor whose ``data_ptr()`` is handed to the emulated library lives, for the duration
+    of the call, in a mapping fenced by an inaccessible page -- ``side="after"``: the storage's last byte sits
+    (up to 16-byte alignment) right in front of it, ``side="before"``: its first byte right behind it.  A kernel
+    that touches one byte outside ANY of its buffers -- inputs, weights, scratch, outputs, whatever the host code
+    allocated -- segfaults deterministically instead of reading a neighbour allocation by luck, which is what the
+    GPU's caching allocator lets it do until an allocation ends at a mapping boundary.
+
+    How: ``torch.Tensor.data_ptr`` is patched to mirror the tensor's whole storage into such a mapping (copy in)
+    and to return the address inside the mirror; the library proxy copies every mirror back after each call.
+    Mirrors are cached per (storage address, size), so addresses are stable (weight-pack cache keys)."""
+
+    def __init__(self, lib, side="after", log=None):
+        import mmap
+        assert side in ("after", "before")
+        self.lib, self.side, self.log = lib, side, log
+        self.page = mmap.PAGESIZE
+        self._prot_rw = mmap.PROT_READ | mmap.PROT_WRITE
+        self._flags = mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS
+        self.libc = ctypes.CDLL(None, use_errno=True)
+        self.libc.mmap.restype = ctypes.c_void_p
+        self.libc.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_long]
+        self.libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        self.mirrors, self.pending = {}, {}
+        self.calls = 0
+
+    def _mirror(self, base, n):
+        key = (base, n)
+        addr = self.mirrors.get(key)
+        if addr is None:
+            page = self.page
+            npages = max((n + page - 1) // page, 1)
+            m = self.libc.mmap(None, (npages + 1) * page, self._prot_rw, self._flags, -1, 0)
+            assert m not in (None, ctypes.c_void_p(-1).value)
+            if self.side == "after":
+                assert self.libc.mprotect(m + npages * page, page, 0) == 0
+                addr = (m + npages * page - n) & ~15
+            else:
+                assert self.libc.mprotect(m, page, 0) == 0
+                addr = m + page
+            self.mirrors[key] = addr
+        return addr
+
+    def __enter__(self):
+        import torch
+        self._orig = torch.Tensor.data_ptr
+        orig, me = self._orig, self
+
+        def data_ptr(t):
+            st = t.untyped_storage()
+            base, n = st.data_ptr(), st.nbytes()
+            if n == 0:
+                return orig(t)
+            addr = me._mirror(base, n)
+            ctypes.memmove(addr, base, n)
+            me.pending[(base, n)] = addr
+            return addr + (orig(t) - base)
+
+        torch.Tensor.data_ptr = data_ptr
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        torch.Tensor.data_ptr = self._orig
+        self._flush()
+
+    def _flush(self):
+        for (base, n), addr in self.pending.items():
+            ctypes.memmove(base, addr, n)
+        self.pending.clear()
+
+    def __getattr__(self, name):  # library proxy
+        fn = getattr(self.lib, name)
+
+        def call(*args):
+            if self.log is not None:
+                self.log.write(f"{name}\n")
+                self.log.flush()
+            try:
+                return fn(*args)
+            finally:
+                self.calls += 1
+                self._flush()
+        return call

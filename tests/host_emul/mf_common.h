@@ -424,6 +424,12 @@ namespace mf {
 inline void set_last_error(int, const char *) {}
 inline int check_launch(const char *) { return 0; }
 inline int allow_big_lds(const void *, int) { return 0; }
+inline int fill_bytes(void *dst, int value, int64_t nbytes, hipStream_t st) {  // csrc/api.hip: a fill KERNEL
+  if (nbytes <= 0) return 0;
+  if ((nbytes & 3) || (((uintptr_t)dst) & 3)) return -1;
+  mf_emul::enqueue(st, [=]() { memset(dst, value, (size_t)nbytes); });
+  return 0;
+}
 constexpr int kWave = 64;
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline float voxel_coord(float p, float o, float pitch) { return (p - o) / pitch; }
