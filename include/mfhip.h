@@ -343,6 +343,51 @@ int mf_linear_fwd(const float *A, int64_t a_group_stride, int32_t lda, const flo
                   int32_t ldo, int32_t M, int32_t N, int32_t Npad, int32_t K, int32_t groups, int32_t relu,
                   mfStream_t stream);
 
+/* ---- bf16 training / inference path of the 3-D CNN and the 1x1 convolution chains (round 4) --------------------
+ * replaces cuDNN's forward, backward-data and backward-filter of
+ *   morefusion/contrib/singleview_3d/models/model.py:73-74,125-139 (conv3, conv4: Convolution3D(.., 4, 2, pad = 1))
+ *   morefusion/contrib/singleview_3d/models/model.py:59-66,76-91,101-111,239-258 (Convolution1D chains)
+ * as trained by examples/ycb_video/singleview_3d/train.py:342-369 (BASELINE config 5: bf16, data-parallel).
+ * All activations / gradients are bf16 (the framework's bfloat16 bit pattern, passed as void *), accumulation is
+ * fp32 on v_mfma_f32_32x32x16_bf16, parameters and their gradients stay fp32 (csrc/gemm_bf16.hip).
+ *
+ * mf_cast_rows_bf16     fp32 [rows, src_ld] -> bf16 [rows, dst_ld] (columns >= cols zero; dst_ld % 8 == 0)
+ * mf_relu_mask_bf16     dz = (y > 0) ? dy : 0 over n elements (n % 8 == 0); dy bf16, or dy32 fp32 (exactly one)
+ * mf_linear_bf16        out = act(A W^T + bias): A [M, lda], W [N, ldw] bf16 (rows k-contiguous), bias fp32 [N],
+ *                       out [M, ldo] bf16 or fp32 (out_f32), `accumulate`: out += (fp32 only); `groups` problems
+ *                       per launch at the given element strides.  The data gradient of a layer is the same call
+ *                       with the transposed weight: dA = dY W  ->  mf_linear_bf16(dY, W^T [K, N]).
+ * mf_linear_wgrad_bf16  dW [N, ldc] fp32 = sum_m dY[m][n] A[m][k]; split > 1: row ranges into ws
+ *                       (split * groups * N * ldc floats), summed in range order.
+ * mf_conv3d_k4s2_pack_bf16   W fp32 [Cout, w_cin, 4, 4, 4] (channels c_off .. c_off + Cin) -> fwd bf16
+ *                       [Cout, 64, Cin] and / or dgrad bf16 [8 parity classes, Cin, 8 slots, Cout] (either may be null)
+ * mf_conv3d_k4s2_bf16_fwd    out [B, (D/2)^3, Cout] = act(conv(x [B, D^3, Cin]) + bias)      (channels-last)
+ * mf_conv3d_k4s2_bf16_dgrad  dx [B, D^3, Cin] (+)= conv^T(dy [B, (D/2)^3, Cout]); bf16, or fp32 (+ accumulate)
+ * mf_conv3d_k4s2_bf16_wgrad  dW fp32 in the framework layout (channels c_off ..) = sum_voxels dy (x) im2col(x);
+ *                       ws: mf_conv3d_k4s2_bf16_wgrad_workspace_bytes(Cin, Cout, split)
+ * D is a power of two, Cin % 8 == 0, Cout % 8 == 0.  Asynchronous, never allocate or synchronise. */
+int mf_cast_rows_bf16(const float *src, int64_t src_ld, void *dst, int64_t dst_ld, int64_t rows, int32_t cols,
+                      mfStream_t stream);
+int mf_relu_mask_bf16(const void *y, const void *dy, const float *dy32, void *dz, int64_t n, mfStream_t stream);
+int mf_linear_bf16(const void *A, int64_t a_group_stride, int32_t lda, const void *W, int64_t w_group_stride,
+                   int32_t ldw, const float *bias, int64_t b_group_stride, void *out, int64_t o_group_stride,
+                   int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t groups, int32_t relu, int32_t out_f32,
+                   int32_t accumulate, mfStream_t stream);
+int mf_linear_wgrad_bf16(const void *dY, int64_t y_group_stride, int32_t ldy, const void *A, int64_t a_group_stride,
+                         int32_t lda, float *dW, int64_t w_group_stride, int32_t ldc, void *ws, int32_t M, int32_t N,
+                         int32_t K, int32_t groups, int32_t split, mfStream_t stream);
+int mf_conv3d_k4s2_pack_bf16(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin, int32_t c_off, void *fwd,
+                             void *dgrad, mfStream_t stream);
+int mf_conv3d_k4s2_bf16_fwd(const void *x, const void *wt, const float *bias, void *out, int32_t B, int32_t Cin,
+                            int32_t Cout, int32_t D, int32_t relu, int32_t out_f32, mfStream_t stream);
+int mf_conv3d_k4s2_bf16_dgrad(const void *dy, const void *wd, void *dx, int32_t B, int32_t Cin, int32_t Cout,
+                              int32_t D, int32_t out_f32, int32_t accumulate, mfStream_t stream);
+int64_t mf_conv3d_k4s2_bf16_wgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t split);
+int32_t mf_conv3d_k4s2_bf16_wgrad_default_split(int32_t B, int32_t Cin, int32_t Cout, int32_t D);
+int mf_conv3d_k4s2_bf16_wgrad(const void *dy, const void *x, float *dW, void *ws, int32_t B, int32_t Cin,
+                              int32_t Cout, int32_t D, int32_t w_cin, int32_t c_off, int32_t split,
+                              mfStream_t stream);
+
 /* Point-wise prologue / epilogue of the volumetric part (inference), one launch each instead of ~25 torch launches:
  *   mf_point_prep: camera-frame points [B,3,P] + image features [B,Cv,P] -> voxel-frame points [n,3]
  *     ((p - origin) / pitch, model.py:236), to_center [n,4] = (center - p | 0) (:101), feature rows [n,Cv],

@@ -74,6 +74,17 @@ _SIGNATURES = {
     "mf_interpolate_voxel_grid_cl_fwd": ([_p, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _i64, _p], _i),
     "mf_occupancy_convs_fwd": ([_p] * 7 + [ctypes.c_int32] * 2 + [_p], _i),
     "mf_linear_fwd": ([_p, _i64, ctypes.c_int32, _p, _i64, ctypes.c_int32, _p, _i64, _p, _i64] + [ctypes.c_int32] * 7 + [_p], _i),
+    "mf_cast_rows_bf16": ([_p, _i64, _p, _i64, _i64, ctypes.c_int32, _p], _i),
+    "mf_relu_mask_bf16": ([_p, _p, _p, _p, _i64, _p], _i),
+    "mf_linear_bf16": ([_p, _i64, ctypes.c_int32, _p, _i64, ctypes.c_int32, _p, _i64, _p, _i64] + [ctypes.c_int32] * 8 + [_p], _i),
+    "mf_linear_wgrad_bf16": ([_p, _i64, ctypes.c_int32, _p, _i64, ctypes.c_int32, _p, _i64, ctypes.c_int32, _p]
+                             + [ctypes.c_int32] * 5 + [_p], _i),
+    "mf_conv3d_k4s2_pack_bf16": ([_p] + [ctypes.c_int32] * 4 + [_p, _p, _p], _i),
+    "mf_conv3d_k4s2_bf16_fwd": ([_p, _p, _p, _p] + [ctypes.c_int32] * 6 + [_p], _i),
+    "mf_conv3d_k4s2_bf16_dgrad": ([_p, _p, _p] + [ctypes.c_int32] * 6 + [_p], _i),
+    "mf_conv3d_k4s2_bf16_wgrad_workspace_bytes": ([ctypes.c_int32] * 3, _i64),
+    "mf_conv3d_k4s2_bf16_wgrad_default_split": ([ctypes.c_int32] * 4, ctypes.c_int32),
+    "mf_conv3d_k4s2_bf16_wgrad": ([_p, _p, _p, _p] + [ctypes.c_int32] * 7 + [_p], _i),
     "mf_point_prep": ([_p, _p, _p, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _f, _p, _p, _p, _p, _p], _i),
     "mf_pose_epilogue": ([_p, _i64, ctypes.c_int32, _p, _p, _p, _p, ctypes.c_int32, ctypes.c_int32, _p, _p, _p, _p], _i),
     "mf_psp_tail_fwd": ([_p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p] + [ctypes.c_int32] * 4 + [_p, _p], _i),

@@ -1,0 +1,710 @@
+// bf16 MFMA GEMM engines (fp32 accumulate) for the 3-D CNN and the per-point 1x1 convolutions, forward AND
+// backward, for gfx950 -- the kernels BASELINE config 5 (bf16 training) and `--dtype bf16` inference run on.
+//
+// Reference: contrib/singleview_3d/models/model.py:114-139 (conv3 / conv4: `L.Convolution3D(.., 4, 2, pad=1)`),
+// :239-258 (the three heads' Convolution1D chains), :59-66,101-111 (point MLP), trained by
+// examples/ycb_video/singleview_3d/train.py:342-369 (cuDNN forward + backward-data + backward-filter).
+//
+// Two engines on v_mfma_f32_32x32x16_bf16 (16x the fp32-MFMA rate of csrc/conv3d.hip / linear.hip):
+//
+//   NT   C[m][n] = sum_k A(m, k) * W[n][k]        both operands k-contiguous in memory
+//        A loaders:  rows          a row-major activation matrix with a row pitch   (linear forward / dgrad)
+//                    conv forward  im2col rows of a channels-last grid, k = (tap, cin)
+//                    conv dgrad    rows = INPUT voxels grouped by parity class, k = (slot, cout): an input
+//                                  voxel x receives from the 2 x 2 x 2 output voxels o = h + p - s with tap
+//                                  (1 - p) + 2 s per axis (x = 2 h + p); a tile of 128 rows is class-homogeneous
+//                                  and multiplies that class's [Cin][8 Cout] weight slice
+//   TN   C[i][j] = sum_m P[m][i] * Q(m, j)        the reduction index is the ROW index of both operands
+//        (weight gradients: P = dY, Q = the layer's input rows / im2col rows).  Rows are staged through a
+//        4 x 8 register transpose into an LDS image [i][m] so that the MFMA fragments stay ONE ds_read_b128;
+//        split over m into fp32 slabs, summed in slab order by k_wgrad_finish (deterministic, no float atomics).
+//
+// Tile: 128 x 128 x 64 per 256-lane workgroup (4 waves, each a 64 x 64 corner = 2 x 2 accumulators of 32 x 32),
+// LDS rows of 64 bf16 at a pitch of 144 bytes (36 dwords: the sixteen rows a ds_read_b128 phase touches start
+// 4 dwords apart modulo 64 banks -- conflict-free), register-staged double buffering with the next tile's
+// global loads pinned in front of this tile's 16 MFMAs, one barrier per K-tile, 2 workgroups per CU.
+// The epilogue goes through LDS: bias + ReLU on the way in, 16-byte row segments out (bf16 or fp32,
+// optionally accumulating into an fp32 tensor).
+#include "mf_common.h"
+
+namespace {
+
+using mf::mf_f32x16;
+
+constexpr int kBN = 128, kBK = 64;
+constexpr int kPitch = 144;  // bytes per LDS row (64 bf16 + 16 bytes)
+template <int MI> constexpr int nt_buf_bytes() { return (64 * MI + kBN) * kPitch; }
+template <int MI> constexpr int nt_lds() {
+  return 2 * nt_buf_bytes<MI>() > 64 * MI * (kBN + 4) * 4 ? 2 * nt_buf_bytes<MI>() : 64 * MI * (kBN + 4) * 4;
+}
+
+enum { kRows = 0, kConvFwd = 1, kConvDgrad = 2 };
+
+struct NtArgs {
+  const uint16_t *A;   // bf16 operand (rows / channels-last grid / channels-last output gradient)
+  const uint16_t *W;   // bf16 [N][ldw] k-contiguous; group g at W + g * w_gs; dgrad: class p at W + p * N * ldw
+  const float *bias;   // fp32 [N] or null; group g at bias + g * b_gs
+  void *out;           // bf16 or fp32 rows, pitch ldo (elements); group g at out + g * o_gs
+  int64_t a_gs, w_gs, b_gs, o_gs;
+  int M, N, K, lda, ldw, ldo, groups;
+  int relu, out_f32, accumulate;
+  int B, D, dlog, Cin, Cout;  // conv geometry: D = INPUT grid size (a power of two), Do = D / 2
+};
+
+__device__ __forceinline__ uint4 ld16(const uint16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
+
+// One 16-byte chunk (8 bf16) of an A row: element offset base + off, or zeros.  A masked chunk reads the
+// operand's first 16 bytes (always mapped) and selects zeros.
+__device__ __forceinline__ uint4 ld_chunk(const uint16_t *__restrict__ A, int base, int off, bool ok) {
+  const uint4 r = ld16(A + (ok ? base + off : 0));
+  return ok ? r : make_uint4(0u, 0u, 0u, 0u);
+}
+
+template <int MODE, int MI>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
+  MF_DYN_LDS(unsigned char, s_raw);
+  constexpr int kBM = 64 * MI, kBuf = nt_buf_bytes<MI>();
+  const int tiles_m = (a.M + kBM - 1) / kBM, tiles_n = (a.N + kBN - 1) / kBN;
+  const int per_group = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  int L = blockIdx.x;
+  if ((G & 7) == 0) L = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous logical order
+  const int grp = L / per_group;
+  const int rem = L - grp * per_group;
+  const int m0 = (rem / tiles_n) * kBM, n0 = (rem % tiles_n) * kBN;  // N tile fastest (csrc/linear.hip)
+  const int T = (a.K + kBK - 1) / kBK;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  const int chunk = tid & 7, r0 = tid >> 3;  // this lane stages rows r0 + 32 i, bf16 8 chunk .. + 7 of the K-tile
+
+  const int Do = a.D >> 1, dol = a.dlog - 1;
+  const uint16_t *A = a.A + grp * a.a_gs;
+  const uint16_t *W = a.W + grp * a.w_gs;
+  int cls = 0;
+  if (MODE == kConvDgrad) {  // tile-uniform parity class: its weight slice
+    cls = (m0 >> (3 * dol)) & 7;
+    W += (int64_t)cls * a.N * a.ldw;
+  }
+  // per staged row: element offset of its k = 0 chunk and validity bits
+  //   rows:        bit 12 = row exists
+  //   conv fwd:    bits kx | 4 + ky | 8 + kz = tap coordinate inside the grid (csrc/conv3d.hip)
+  //   conv dgrad:  bits sx | 4 + sy | 8 + sz = contributing output voxel h + p - s inside the output grid
+  int base[2 * MI], mask[2 * MI];
+#pragma unroll
+  for (int i = 0; i < 2 * MI; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    const bool row_ok = m < a.M;
+    const int mm = row_ok ? m : 0;
+    int mk = row_ok ? 1 << 12 : 0;
+    if (MODE == kRows) {
+      base[i] = mm * a.lda;
+    } else if (MODE == kConvFwd) {
+      const int b = mm >> (3 * dol), o = mm & ((1 << (3 * dol)) - 1);
+      const int ox = o >> (2 * dol), oy = (o >> dol) & (Do - 1), oz = o & (Do - 1);
+      const int x0 = 2 * ox - 1, y0 = 2 * oy - 1, z0 = 2 * oz - 1;
+      base[i] = (((b * a.D + x0) * a.D + y0) * a.D + z0) * a.Cin;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        mk |= ((unsigned)(x0 + k) < (unsigned)a.D ? 1 : 0) << k;
+        mk |= ((unsigned)(y0 + k) < (unsigned)a.D ? 1 : 0) << (4 + k);
+        mk |= ((unsigned)(z0 + k) < (unsigned)a.D ? 1 : 0) << (8 + k);
+      }
+    } else {
+      // m = ((b * 8 + p) * Do^3 + h): input voxel x = 2 h + p per axis
+      const int h = mm & ((1 << (3 * dol)) - 1), b = mm >> (3 * dol + 3);
+      const int hx = h >> (2 * dol), hy = (h >> dol) & (Do - 1), hz = h & (Do - 1);
+      const int ux = hx + (cls & 1), uy = hy + ((cls >> 1) & 1), uz = hz + ((cls >> 2) & 1);  // slot (0,0,0)
+      base[i] = (((b * Do + ux) * Do + uy) * Do + uz) * a.Cout;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        mk |= ((unsigned)(ux - s) < (unsigned)Do ? 1 : 0) << s;
+        mk |= ((unsigned)(uy - s) < (unsigned)Do ? 1 : 0) << (4 + s);
+        mk |= ((unsigned)(uz - s) < (unsigned)Do ? 1 : 0) << (8 + s);
+      }
+    }
+    mask[i] = mk;
+  }
+  const uint16_t *wrow[4];
+  bool wok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + r0 + 32 * i;
+    wok[i] = n < a.N;
+    wrow[i] = W + (int64_t)(wok[i] ? n : 0) * a.ldw;
+  }
+
+  mf_f32x16 acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  uint4 ra[2 * MI], rb[4];
+  // K-tile kt -> registers
+  auto fetch = [&](int kt) {
+    const int kg = kt * kBK + 8 * chunk;
+    const bool kin = kg + 8 <= a.K;
+    int off = kg, bits = 1 << 12;
+    if (MODE == kConvFwd) {
+      const int tap = kg / a.Cin, c = kg - tap * a.Cin;
+      const int kx = tap >> 4, ky = (tap >> 2) & 3, kz = tap & 3;
+      off = ((kx * a.D + ky) * a.D + kz) * a.Cin + c;
+      bits = (1 << kx) | (16 << ky) | (256 << kz) | (1 << 12);
+    } else if (MODE == kConvDgrad) {
+      const int slot = kg / a.Cout, co = kg - slot * a.Cout;
+      const int sx = slot & 1, sy = (slot >> 1) & 1, sz = slot >> 2;
+      off = co - ((sx * Do + sy) * Do + sz) * a.Cout;
+      bits = (1 << sx) | (16 << sy) | (256 << sz) | (1 << 12);
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * MI; ++i) ra[i] = ld_chunk(A, base[i], off, kin && (mask[i] & bits) == bits);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint4 r = ld16(wrow[i] + (kin ? kg : 0));
+      rb[i] = (kin && wok[i]) ? r : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto stash = [&](int buf) {
+    unsigned char *As = s_raw + buf * kBuf + r0 * kPitch + 16 * chunk;
+    unsigned char *Bs = As + kBM * kPitch;
+#pragma unroll
+    for (int i = 0; i < 2 * MI; ++i) *reinterpret_cast<uint4 *>(As + 32 * i * kPitch) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(Bs + 32 * i * kPitch) = rb[i];
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    fetch(t + 1 < T ? t + 1 : t);  // (the last iteration re-fetches its own tile: branch-free body)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char *As = s_raw + (t & 1) * kBuf + (wm * 32 * MI + lrow) * kPitch + 16 * lhalf;
+    const unsigned char *Bs = s_raw + (t & 1) * kBuf + (kBM + wn * 64 + lrow) * kPitch + 16 * lhalf;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4 a0 = *reinterpret_cast<const uint4 *>(As + 32 * s);
+      const uint4 b0 = *reinterpret_cast<const uint4 *>(Bs + 32 * s);
+      const uint4 b1 = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * s);
+      acc[0][0] = mf::mfma_bf16_32x32x16(a0, b0, acc[0][0]);
+      acc[0][1] = mf::mfma_bf16_32x32x16(a0, b1, acc[0][1]);
+      if constexpr (MI == 2) {
+        const uint4 a1 = *reinterpret_cast<const uint4 *>(As + 32 * kPitch + 32 * s);
+        acc[MI - 1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[MI - 1][0]);
+        acc[MI - 1][1] = mf::mfma_bf16_32x32x16(a1, b1, acc[MI - 1][1]);
+      }
+    }
+    stash((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // epilogue through LDS (the loop ended on a barrier: the operand buffers are free)
+  constexpr int kEp = kBN + 4;
+  float *s_out = reinterpret_cast<float *>(s_raw);  // [kBM][kEp]
+  const float *bias = a.bias ? a.bias + grp * a.b_gs : nullptr;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int nl = wn * 64 + ni * 32 + lrow;
+      const float bn = (bias && n0 + nl < a.N) ? bias[n0 + nl] : 0.0f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ml = wm * 32 * MI + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+        float v = acc[mi][ni][e] + bn;
+        if (a.relu) v = v > 0.0f ? v : 0.0f;
+        s_out[ml * kEp + nl] = v;
+      }
+    }
+  __syncthreads();
+  for (int i = tid; i < kBM * (kBN / 8); i += 256) {
+    const int ml = i / (kBN / 8), c8 = i - ml * (kBN / 8);
+    const int m = m0 + ml, n = n0 + 8 * c8;
+    if (m >= a.M || n >= a.N) continue;
+    int64_t orow = m;
+    if (MODE == kConvDgrad) {  // class-ordered row -> channels-last voxel row of the input gradient
+      const int h = m & ((1 << (3 * dol)) - 1), p = (m >> (3 * dol)) & 7, b = m >> (3 * dol + 3);
+      const int x = 2 * (h >> (2 * dol)) + (p & 1), y = 2 * ((h >> dol) & (Do - 1)) + ((p >> 1) & 1),
+                z = 2 * (h & (Do - 1)) + (p >> 2);
+      orow = (((int64_t)b * a.D + x) * a.D + y) * a.D + z;
+    }
+    const float4 v0 = *reinterpret_cast<const float4 *>(s_out + ml * kEp + 8 * c8);
+    const float4 v1 = *reinterpret_cast<const float4 *>(s_out + ml * kEp + 8 * c8 + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    const int nv = a.N - n < 8 ? a.N - n : 8;
+    if (a.out_f32) {
+      float *o = reinterpret_cast<float *>(a.out) + grp * a.o_gs + orow * a.ldo + n;
+      if (nv == 8 && (a.ldo & 3) == 0 && ((uintptr_t)o & 15) == 0) {
+        float4 *o4 = reinterpret_cast<float4 *>(o);
+        if (a.accumulate) {
+          const float4 p0 = o4[0], p1 = o4[1];
+          v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
+          v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+        }
+        o4[0] = make_float4(v[0], v[1], v[2], v[3]);
+        o4[1] = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        for (int j = 0; j < nv; ++j) o[j] = a.accumulate ? o[j] + v[j] : v[j];
+      }
+    } else {
+      uint16_t *o = reinterpret_cast<uint16_t *>(a.out) + grp * a.o_gs + orow * a.ldo + n;
+      if (nv == 8 && (a.ldo & 7) == 0 && ((uintptr_t)o & 15) == 0) {
+        *reinterpret_cast<uint4 *>(o) = make_uint4(mf::pack_bf16x2(v[0], v[1]), mf::pack_bf16x2(v[2], v[3]),
+                                                   mf::pack_bf16x2(v[4], v[5]), mf::pack_bf16x2(v[6], v[7]));
+      } else {
+        for (int j = 0; j < nv; ++j) o[j] = (uint16_t)mf::bf16_bits(v[j]);
+      }
+    }
+  }
+}
+
+// ---- TN engine: C[i][j] = sum_m P[m][i] * Q(m, j) -------------------------------------------------------------
+constexpr int kTnOperand = 128 * kPitch + 512;  // transposed image of one operand, rows at tn_phys(i)
+constexpr int kTnBuf = 2 * kTnOperand;
+constexpr int kTnLds = 2 * kTnBuf > 128 * (128 + 4) * 4 ? 2 * kTnBuf : 128 * (128 + 4) * 4;
+
+struct TnArgs {
+  const uint16_t *P;  // bf16 [M][ldp]  (dY), group g at P + g * p_gs
+  const uint16_t *Q;  // bf16 rows [M][ldq] (group g at Q + g * q_gs) or a channels-last grid [B][D^3][Cin] (conv)
+  float *out;         // S == 1: C [Ni][ldc] (group g at out + g * c_gs); S > 1: slabs [S][groups][Ni][ldc]
+  int64_t p_gs, q_gs, c_gs;
+  int M, Ni, Nj, ldp, ldq, ldc, groups, S;
+  int conv, B, D, dlog, Cin;  // conv: Q(m, j = tap * Cin + cin) = x[b][2 o - 1 + tap][cin], m = (b, o)
+};
+
+// Byte offset of row i of a transposed operand image.  Groups of 16 rows are shifted by 16 banks against each other
+// (rows 8 c + e, c = 0..7, of one staging store then spread over all 64 banks: 2 lanes per bank, the minimum for
+// 512 bytes), and the second 64 rows by a whole bank sweep so that the shifted groups never overlap.
+__device__ __forceinline__ int tn_phys(int row) { return row * kPitch + ((row >> 4) & 3) * 64 + (row >> 6) * 256; }
+
+// rows r = 0..3 (four consecutive m) x 8 columns -> eight 8-byte column vectors (m0..m3 of one column)
+__device__ __forceinline__ void transpose4x8(const uint4 r[4], uint2 out[8]) {
+  const uint32_t w[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w},
+                            {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    out[2 * d].x = (w[0][d] & 0xffffu) | (w[1][d] << 16);
+    out[2 * d].y = (w[2][d] & 0xffffu) | (w[3][d] << 16);
+    out[2 * d + 1].x = (w[0][d] >> 16) | (w[1][d] & 0xffff0000u);
+    out[2 * d + 1].y = (w[2][d] >> 16) | (w[3][d] & 0xffff0000u);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
+  MF_DYN_LDS(unsigned char, s_raw);
+  const int tiles_i = (a.Ni + 127) / 128, tiles_j = (a.Nj + 127) / 128;
+  const int per_group = tiles_i * tiles_j;
+  const int G = gridDim.x;
+  int L = blockIdx.x;
+  if ((G & 7) == 0) L = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int split = L / (per_group * a.groups);
+  const int rem0 = L - split * per_group * a.groups;
+  const int grp = rem0 / per_group;
+  const int rem = rem0 - grp * per_group;
+  const int i0 = (rem % tiles_i) * 128, j0 = (rem / tiles_i) * 128;  // i tile fastest: neighbours share Q columns
+  // this split's rows: K-tiles of 64 rows, contiguous ranges
+  const int Tall = (a.M + 63) / 64;
+  const int Tper = (Tall + a.S - 1) / a.S;
+  const int t0 = split * Tper, t1 = min(Tall, t0 + Tper);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  // staging block of this lane: rows 4 mg .. + 3 of the K-tile, columns 8 c .. + 7 of the 128-wide operand tile
+  const int c = 8 * (wave & 1) + (lane & 7), mg = 8 * (wave >> 1) + (lane >> 3);
+
+  const uint16_t *P = a.P + grp * a.p_gs;
+  const uint16_t *Q = a.Q + grp * a.q_gs;
+  const int Do = a.D >> 1, dol = a.dlog - 1;
+  const bool pcol_ok = i0 + 8 * c + 8 <= a.Ni, qcol_ok = j0 + 8 * c + 8 <= a.Nj;
+  // conv: this lane's column chunk is one (tap, cin .. cin + 7) for the whole loop
+  int q_off = j0 + 8 * c, q_bits = 1 << 12;
+  if (a.conv) {
+    const int jj = qcol_ok ? j0 + 8 * c : 0;
+    const int tap = jj / a.Cin, ci = jj - tap * a.Cin;
+    const int kx = tap >> 4, ky = (tap >> 2) & 3, kz = tap & 3;
+    q_off = ((kx * a.D + ky) * a.D + kz) * a.Cin + ci;
+    q_bits = (1 << kx) | (16 << ky) | (256 << kz) | (1 << 12);
+  }
+
+  mf_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  uint4 rp[4], rq[4];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = t * 64 + 4 * mg + r;
+      const bool ok = m < a.M;
+      const int mm = ok ? m : 0;
+      rp[r] = ld_chunk(P, mm * a.ldp, i0 + 8 * c, ok && pcol_ok);
+      if (a.conv) {
+        const int b = mm >> (3 * dol), o = mm & ((1 << (3 * dol)) - 1);
+        const int x0 = 2 * (o >> (2 * dol)) - 1, y0 = 2 * ((o >> dol) & (Do - 1)) - 1, z0 = 2 * (o & (Do - 1)) - 1;
+        int mk = 1 << 12;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          mk |= ((unsigned)(x0 + k) < (unsigned)a.D ? 1 : 0) << k;
+          mk |= ((unsigned)(y0 + k) < (unsigned)a.D ? 1 : 0) << (4 + k);
+          mk |= ((unsigned)(z0 + k) < (unsigned)a.D ? 1 : 0) << (8 + k);
+        }
+        const int base = (((b * a.D + x0) * a.D + y0) * a.D + z0) * a.Cin;
+        rq[r] = ld_chunk(Q, base, q_off, ok && qcol_ok && (mk & q_bits) == q_bits);
+      } else {
+        rq[r] = ld_chunk(Q, mm * a.ldq, q_off, ok && qcol_ok);
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    uint2 col[8];
+    unsigned char *Ps = s_raw + buf * kTnBuf + 8 * mg;
+    transpose4x8(rp, col);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) *reinterpret_cast<uint2 *>(Ps + tn_phys(8 * c + e)) = col[e];
+    transpose4x8(rq, col);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) *reinterpret_cast<uint2 *>(Ps + kTnOperand + tn_phys(8 * c + e)) = col[e];
+  };
+  if (t0 < t1) {
+    fetch(t0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    fetch(t + 1 < t1 ? t + 1 : t);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char *Ps = s_raw + buf * kTnBuf + 16 * lhalf;
+    const unsigned char *Qs = Ps + kTnOperand;
+    const int pa0 = tn_phys(wm * 64 + lrow), pa1 = tn_phys(wm * 64 + 32 + lrow);
+    const int qb0 = tn_phys(wn * 64 + lrow), qb1 = tn_phys(wn * 64 + 32 + lrow);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4 a0 = *reinterpret_cast<const uint4 *>(Ps + pa0 + 32 * s);
+      const uint4 a1 = *reinterpret_cast<const uint4 *>(Ps + pa1 + 32 * s);
+      const uint4 b0 = *reinterpret_cast<const uint4 *>(Qs + qb0 + 32 * s);
+      const uint4 b1 = *reinterpret_cast<const uint4 *>(Qs + qb1 + 32 * s);
+      acc[0][0] = mf::mfma_bf16_32x32x16(a0, b0, acc[0][0]);
+      acc[0][1] = mf::mfma_bf16_32x32x16(a0, b1, acc[0][1]);
+      acc[1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[1][0]);
+      acc[1][1] = mf::mfma_bf16_32x32x16(a1, b1, acc[1][1]);
+    }
+    stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  constexpr int kEp = 128 + 4;
+  float *s_out = reinterpret_cast<float *>(s_raw);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int nl = wn * 64 + ni * 32 + lrow;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ml = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+        s_out[ml * kEp + nl] = acc[mi][ni][e];
+      }
+    }
+  __syncthreads();
+  float *dst = a.out + ((int64_t)split * a.groups + grp) * (a.S > 1 ? (int64_t)a.Ni * a.ldc : 0) +
+               (a.S > 1 ? 0 : grp * a.c_gs);
+  for (int i = tid; i < 128 * 32; i += 256) {
+    const int il = i >> 5, c4 = i & 31;
+    const int ii = i0 + il, jj = j0 + 4 * c4;
+    if (ii >= a.Ni || jj >= a.Nj) continue;
+    const float4 v = *reinterpret_cast<const float4 *>(s_out + il * kEp + 4 * c4);
+    float *o = dst + (int64_t)ii * a.ldc + jj;
+    if (jj + 4 <= a.Nj && (a.ldc & 3) == 0 && ((uintptr_t)o & 15) == 0) {
+      *reinterpret_cast<float4 *>(o) = v;
+    } else {
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      for (int j = 0; j < 4 && jj + j < a.Nj; ++j) o[j] = vv[j];
+    }
+  }
+}
+
+// out[g][i][f(j)] = sum_s slab[s][g][i][j] (increasing s); conv: j = tap * Cin + cin -> f(j) = cin * 64 + tap
+// (the torch / Chainer ConvolutionND weight layout [Cout][Cin][4][4][4]).
+__global__ __launch_bounds__(256) void k_wgrad_finish(const float *__restrict__ slabs, float *__restrict__ out,
+                                                      int64_t per_slab, int Nj, int ldc, int S, int conv_cin,
+                                                      int64_t c_gs, int64_t per_group, int64_t out_row_pitch) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per_slab) return;
+  const int64_t g = idx / per_group, in_g = idx - g * per_group;
+  const int64_t i = in_g / ldc;
+  const int j = (int)(in_g - i * ldc);
+  if (j >= Nj) return;
+  float v = slabs[idx];
+  for (int s = 1; s < S; ++s) v += slabs[(int64_t)s * per_slab + idx];
+  int64_t o = j;
+  if (conv_cin) {
+    const int tap = j / conv_cin, ci = j - tap * conv_cin;
+    o = (int64_t)ci * 64 + tap;
+  }
+  out[g * c_gs + i * out_row_pitch + o] = v;
+}
+
+// ---- operand preparation ---------------------------------------------------------------------------------
+// fp32 [rows][src_ld] -> bf16 [rows][dst_ld] (zero columns beyond ``cols``), 8 elements per lane
+__global__ __launch_bounds__(256) void k_cast_rows_bf16(const float *__restrict__ src, int64_t src_ld,
+                                                        uint16_t *__restrict__ dst, int64_t dst_ld, int64_t rows,
+                                                        int cols) {
+  const int per_row = (int)(dst_ld / 8);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * per_row) return;
+  const int64_t r = i / per_row;
+  const int c0 = (int)(i - r * per_row) * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = c0 + j < cols ? src[r * src_ld + c0 + j] : 0.0f;
+  *reinterpret_cast<uint4 *>(dst + r * dst_ld + c0) =
+      make_uint4(mf::pack_bf16x2(v[0], v[1]), mf::pack_bf16x2(v[2], v[3]), mf::pack_bf16x2(v[4], v[5]),
+                 mf::pack_bf16x2(v[6], v[7]));
+}
+
+// W [Cout][w_cin][4][4][4] fp32 (channels c_off .. c_off + Cin) ->
+//   fwd   [Cout][tap][Cin]            (k = tap * Cin + cin)
+//   dgrad [class p][Cin][slot][Cout]  (k = slot * Cout + cout; tap = (1 - p) + 2 s per axis)
+__global__ __launch_bounds__(256) void k_conv_pack_bf16(const float *__restrict__ W, int Cout, int Cin, int w_cin,
+                                                        int c_off, uint16_t *__restrict__ fwd,
+                                                        uint16_t *__restrict__ dgrad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)Cout * 64 * Cin;
+  if (i >= total) return;
+  if (fwd) {
+    const int ci = (int)(i % Cin), tap = (int)((i / Cin) % 64), co = (int)(i / ((int64_t)64 * Cin));
+    fwd[i] = (uint16_t)mf::bf16_bits(W[((int64_t)co * w_cin + c_off + ci) * 64 + tap]);
+  }
+  if (dgrad) {
+    const int co = (int)(i % Cout), slot = (int)((i / Cout) % 8), ci = (int)((i / ((int64_t)8 * Cout)) % Cin);
+    const int p = (int)(i / ((int64_t)8 * Cout * Cin));
+    const int kx = (1 - (p & 1)) + 2 * (slot & 1), ky = (1 - ((p >> 1) & 1)) + 2 * ((slot >> 1) & 1),
+              kz = (1 - (p >> 2)) + 2 * (slot >> 2);
+    dgrad[i] = (uint16_t)mf::bf16_bits(W[((int64_t)co * w_cin + c_off + ci) * 64 + (kx * 16 + ky * 4 + kz)]);
+  }
+}
+
+// dz = dy where y > 0 else 0 (the ReLU behind a fused GEMM epilogue), bf16 in / out, 8 elements per lane.
+// ``dy32``: an fp32 gradient instead (the accumulated gradient of a sampled grid).
+__global__ __launch_bounds__(256) void k_relu_mask_bf16(const uint16_t *__restrict__ y, const uint16_t *__restrict__ dy,
+                                                        const float *__restrict__ dy32, uint16_t *__restrict__ dz,
+                                                        int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 yv = reinterpret_cast<const uint4 *>(y)[i];
+  const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
+  uint32_t ow[4];
+  if (dy32) {
+    const float4 g0 = reinterpret_cast<const float4 *>(dy32)[2 * i], g1 = reinterpret_cast<const float4 *>(dy32)[2 * i + 1];
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      ow[d] = mf::pack_bf16x2(mf::bf16_lo(yw[d]) > 0.0f ? g[2 * d] : 0.0f, mf::bf16_hi(yw[d]) > 0.0f ? g[2 * d + 1] : 0.0f);
+  } else {
+    const uint4 gv = reinterpret_cast<const uint4 *>(dy)[i];
+    const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      ow[d] = (mf::bf16_lo(yw[d]) > 0.0f ? gw[d] & 0xffffu : 0u) | (mf::bf16_hi(yw[d]) > 0.0f ? gw[d] & 0xffff0000u : 0u);
+  }
+  reinterpret_cast<uint4 *>(dz)[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+}
+
+int ilog2_exact(int x) {
+  int l = 0;
+  while ((1 << l) < x) ++l;
+  return (1 << l) == x ? l : -1;
+}
+
+template <int MODE>
+int launch_nt(const NtArgs &a, hipStream_t stream) {
+  const int64_t full = (int64_t)((a.M + 127) / 128) * ((a.N + kBN - 1) / kBN) * a.groups;
+  const bool half = full < 256 && MODE != kConvDgrad;  // (dgrad tiles must stay class-homogeneous: 128 | Do^3)
+  if (half) {
+    if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16<MODE, 1>, nt_lds<1>())) return e;
+    const int64_t grid = (int64_t)((a.M + 63) / 64) * ((a.N + kBN - 1) / kBN) * a.groups;
+    hipLaunchKernelGGL((k_gemm_nt_bf16<MODE, 1>), dim3((unsigned)grid), dim3(256), nt_lds<1>(), stream, a);
+  } else {
+    if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16<MODE, 2>, nt_lds<2>())) return e;
+    hipLaunchKernelGGL((k_gemm_nt_bf16<MODE, 2>), dim3((unsigned)full), dim3(256), nt_lds<2>(), stream, a);
+  }
+  return 0;
+}
+
+int bad(const char *msg) {
+  mf::set_last_error(hipErrorInvalidValue, msg);
+  return -(int)hipErrorInvalidValue;
+}
+
+}  // namespace
+
+extern "C" int mf_cast_rows_bf16(const float *src, int64_t src_ld, void *dst, int64_t dst_ld, int64_t rows,
+                                 int32_t cols, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (rows <= 0) return 0;
+  if (dst_ld % 8 || cols > dst_ld || src_ld < cols || ((uintptr_t)dst & 15)) return bad("cast_rows_bf16: dst_ld % 8 == 0, cols <= dst_ld");
+  const int64_t n = rows * (dst_ld / 8);
+  hipLaunchKernelGGL(k_cast_rows_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, src_ld,
+                     (uint16_t *)dst, dst_ld, rows, cols);
+  return mf::check_launch("mf_cast_rows_bf16");
+}
+
+extern "C" int mf_relu_mask_bf16(const void *y, const void *dy, const float *dy32, void *dz, int64_t n,
+                                 mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n <= 0) return 0;
+  if (n % 8 || (!dy == !dy32)) return bad("relu_mask_bf16: n % 8 == 0 and exactly one of dy / dy32");
+  hipLaunchKernelGGL(k_relu_mask_bf16, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream,
+                     (const uint16_t *)y, (const uint16_t *)dy, dy32, (uint16_t *)dz, n / 8);
+  return mf::check_launch("mf_relu_mask_bf16");
+}
+
+/* out = act(A W^T + bias): A bf16 [M][lda], W bf16 [N][ldw] (k-contiguous rows), bias fp32; out bf16 or fp32
+ * [M][ldo] (accumulate: out += , fp32 only); ``groups`` independent problems at the given element strides. */
+extern "C" int mf_linear_bf16(const void *A, int64_t a_gs, int32_t lda, const void *W, int64_t w_gs, int32_t ldw,
+                              const float *bias, int64_t b_gs, void *out, int64_t o_gs, int32_t ldo, int32_t M,
+                              int32_t N, int32_t K, int32_t groups, int32_t relu, int32_t out_f32,
+                              int32_t accumulate, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M <= 0 || N <= 0 || groups <= 0) return 0;
+  if (K <= 0 || K % 8 || lda % 8 || ldw % 8 || a_gs % 8 || w_gs % 8 || lda < K || ldw < K || ldo < N ||
+      (((uintptr_t)A | (uintptr_t)W) & 15) || (accumulate && !out_f32))
+    return bad("linear_bf16: K, lda, ldw, group strides % 8 == 0, 16-byte aligned A / W, accumulate needs fp32 out");
+  NtArgs a = {};
+  a.A = (const uint16_t *)A; a.W = (const uint16_t *)W; a.bias = bias; a.out = out;
+  a.a_gs = a_gs; a.w_gs = w_gs; a.b_gs = b_gs; a.o_gs = o_gs;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.groups = groups;
+  a.relu = relu; a.out_f32 = out_f32; a.accumulate = accumulate;
+  if (int e = launch_nt<kRows>(a, stream)) return e;
+  return mf::check_launch("mf_linear_bf16");
+}
+
+/* Weight gradient of out = A W^T: dW[n][k] (fp32, row pitch ldc) = sum_m dY[m][n] A[m][k]; ``split`` > 1: partial
+ * sums over row ranges in ws (split * groups * N * ldc floats), added in order. */
+extern "C" int mf_linear_wgrad_bf16(const void *dY, int64_t y_gs, int32_t ldy, const void *A, int64_t a_gs, int32_t lda,
+                                    float *dW, int64_t w_gs, int32_t ldc, void *ws, int32_t M, int32_t N, int32_t K,
+                                    int32_t groups, int32_t split, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M <= 0 || N <= 0 || K <= 0 || groups <= 0) return 0;
+  if (N % 8 || K % 8 || ldy % 8 || lda % 8 || y_gs % 8 || a_gs % 8 || split < 1 || (split > 1 && !ws) || ldc < K ||
+      (((uintptr_t)dY | (uintptr_t)A) & 15))
+    return bad("linear_wgrad_bf16: N, K, ldy, lda, group strides % 8 == 0, 16-byte aligned operands");
+  if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16, kTnLds)) return e;
+  TnArgs a = {};
+  a.P = (const uint16_t *)dY; a.Q = (const uint16_t *)A; a.out = split > 1 ? (float *)ws : dW;
+  a.p_gs = y_gs; a.q_gs = a_gs; a.c_gs = w_gs;
+  a.M = M; a.Ni = N; a.Nj = K; a.ldp = ldy; a.ldq = lda; a.ldc = ldc; a.groups = groups; a.S = split;
+  const int64_t grid = (int64_t)((N + 127) / 128) * ((K + 127) / 128) * groups * split;
+  hipLaunchKernelGGL(k_gemm_tn_bf16, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
+  if (split > 1) {
+    const int64_t per_group = (int64_t)N * ldc, per_slab = per_group * groups;
+    hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, stream,
+                       (const float *)ws, dW, per_slab, K, ldc, split, 0, w_gs, per_group, (int64_t)ldc);
+  }
+  return mf::check_launch("mf_linear_wgrad_bf16");
+}
+
+/* Convolution3D(Cin, Cout, 4, 2, pad = 1) on channels-last bf16 grids.  W: fp32 in the framework layout
+ * [Cout][w_cin][4][4][4]; the packed bf16 operands are [Cout][64][Cin] (forward / wgrad order) and
+ * [8][Cin][8][Cout] (dgrad). */
+extern "C" int mf_conv3d_k4s2_pack_bf16(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin, int32_t c_off,
+                                        void *fwd, void *dgrad, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t total = (int64_t)Cout * 64 * Cin;
+  hipLaunchKernelGGL(k_conv_pack_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, W, Cout, Cin,
+                     w_cin, c_off, (uint16_t *)fwd, (uint16_t *)dgrad);
+  return mf::check_launch("mf_conv3d_k4s2_pack_bf16");
+}
+
+static int conv_check(int32_t B, int32_t Cin, int32_t Cout, int32_t D) {
+  const int dl = ilog2_exact(D);
+  if (dl < 2 || Cin % 8 || Cout % 8 || (int64_t)B * D * D * D * Cin >= (1ll << 31) ||
+      (int64_t)B * (D / 2) * (D / 2) * (D / 2) * Cout >= (1ll << 31) || (int64_t)Cout * 64 * Cin >= (1ll << 31))
+    return bad("conv3d_k4s2 (bf16): D a power of two >= 4, Cin % 8 == 0, Cout % 8 == 0, tensors < 2^31 elements");
+  return 0;
+}
+
+/* out [B][(D/2)^3][Cout] = act(conv(x [B][D^3][Cin]) + bias): x, wt (packed forward layout) bf16; out bf16 / fp32 */
+extern "C" int mf_conv3d_k4s2_bf16_fwd(const void *x, const void *wt, const float *bias, void *out, int32_t B,
+                                       int32_t Cin, int32_t Cout, int32_t D, int32_t relu, int32_t out_f32,
+                                       mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0) return 0;
+  if (int e = conv_check(B, Cin, Cout, D)) return e;
+  const int Do = D / 2;
+  NtArgs a = {};
+  a.A = (const uint16_t *)x; a.W = (const uint16_t *)wt; a.bias = bias; a.out = out;
+  a.M = B * Do * Do * Do; a.N = Cout; a.K = 64 * Cin; a.ldw = 64 * Cin; a.ldo = Cout; a.groups = 1;
+  a.relu = relu; a.out_f32 = out_f32;
+  a.B = B; a.D = D; a.dlog = ilog2_exact(D); a.Cin = Cin; a.Cout = Cout;
+  if (int e = launch_nt<kConvFwd>(a, stream)) return e;
+  return mf::check_launch("mf_conv3d_k4s2_bf16_fwd");
+}
+
+/* dx [B][D^3][Cin] (+)= conv^T(dy [B][(D/2)^3][Cout]): dy, wd (packed dgrad layout) bf16; dx bf16, or fp32 with
+ * ``accumulate`` (dx already holds another consumer's gradient). */
+extern "C" int mf_conv3d_k4s2_bf16_dgrad(const void *dy, const void *wd, void *dx, int32_t B, int32_t Cin,
+                                         int32_t Cout, int32_t D, int32_t out_f32, int32_t accumulate,
+                                         mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0) return 0;
+  if (int e = conv_check(B, Cin, Cout, D)) return e;
+  const int Do = D / 2;
+  if ((Do * Do * Do) % 128 || (accumulate && !out_f32)) return bad("conv3d_k4s2 dgrad: (D/2)^3 % 128 == 0; accumulate needs fp32");
+  NtArgs a = {};
+  a.A = (const uint16_t *)dy; a.W = (const uint16_t *)wd; a.out = dx;
+  a.M = B * D * D * D; a.N = Cin; a.K = 8 * Cout; a.ldw = 8 * Cout; a.ldo = Cin; a.groups = 1;
+  a.out_f32 = out_f32; a.accumulate = accumulate;
+  a.B = B; a.D = D; a.dlog = ilog2_exact(D); a.Cin = Cin; a.Cout = Cout;
+  if (int e = launch_nt<kConvDgrad>(a, stream)) return e;
+  return mf::check_launch("mf_conv3d_k4s2_bf16_dgrad");
+}
+
+extern "C" int64_t mf_conv3d_k4s2_bf16_wgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t split) {
+  return split > 1 ? (int64_t)split * Cout * 64 * Cin * 4 : (int64_t)Cout * 64 * Cin * 4;
+}
+
+extern "C" int32_t mf_conv3d_k4s2_bf16_wgrad_default_split(int32_t B, int32_t Cin, int32_t Cout, int32_t D) {
+  const int64_t tiles = (int64_t)((Cout + 127) / 128) * ((64 * Cin + 127) / 128);
+  const int64_t ktiles = ((int64_t)B * (D / 2) * (D / 2) * (D / 2) + 63) / 64;
+  int S = 1;
+  while (tiles * S < 512 && ktiles / (S * 2) >= 16) S *= 2;
+  return S;
+}
+
+/* dW [Cout][w_cin][4][4][4] (channels c_off ..: fp32, the framework layout) = sum over output voxels of
+ * dy (x) im2col(x); ws: mf_conv3d_k4s2_bf16_wgrad_workspace_bytes. */
+extern "C" int mf_conv3d_k4s2_bf16_wgrad(const void *dy, const void *x, float *dW, void *ws, int32_t B, int32_t Cin,
+                                         int32_t Cout, int32_t D, int32_t w_cin, int32_t c_off, int32_t split,
+                                         mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0) return 0;
+  if (int e = conv_check(B, Cin, Cout, D)) return e;
+  if (split < 1 || !ws) return bad("conv3d_k4s2 wgrad: workspace required");
+  if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16, kTnLds)) return e;
+  const int Do = D / 2;
+  TnArgs a = {};
+  a.P = (const uint16_t *)dy; a.Q = (const uint16_t *)x; a.out = (float *)ws;
+  a.M = B * Do * Do * Do; a.Ni = Cout; a.Nj = 64 * Cin; a.ldp = Cout; a.ldc = 64 * Cin; a.groups = 1;
+  a.S = split > 1 ? split : 1;
+  a.conv = 1; a.B = B; a.D = D; a.dlog = ilog2_exact(D); a.Cin = Cin;
+  // (S == 1 also goes through the workspace: the finish pass permutes (tap, cin) -> (cin, tap))
+  const int64_t grid = (int64_t)((Cout + 127) / 128) * ((64 * Cin + 127) / 128) * a.S;
+  hipLaunchKernelGGL(k_gemm_tn_bf16, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
+  const int64_t per_slab = (int64_t)Cout * 64 * Cin;
+  hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, stream,
+                     (const float *)ws, dW + (int64_t)c_off * 64, per_slab, 64 * Cin, 64 * Cin, a.S, Cin, (int64_t)0,
+                     per_slab, (int64_t)w_cin * 64);
+  return mf::check_launch("mf_conv3d_k4s2_bf16_wgrad");
+}

@@ -46,6 +46,25 @@ constexpr int kWave = 64;
 
 __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- bf16 (round 4: csrc/gemm_bf16.hip and the bf16 point / voxel kernels) -----------------------------------
+// Eight bf16 travel as one uint4 (16 bytes: one global / LDS access, one MFMA operand).
+typedef float mf_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 mf_bf16x8_t __attribute__((ext_vector_type(8)));
+// v_mfma_f32_32x32x16_bf16: D[i][j] += sum_k A[i][k] B[k][j]; lane l supplies A[l % 32][8 (l / 32) .. + 7] and
+// B[8 (l / 32) .. + 7][l % 32] (element e of the uint4 = k offset e, low half-word first) and holds
+// D[(e & 3) + 8 (e >> 2) + 4 (l / 32)][l % 32] in accumulator element e.
+__device__ __forceinline__ mf_f32x16 mfma_bf16_32x32x16(uint4 a, uint4 b, mf_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mf_bf16x8_t, a), __builtin_bit_cast(mf_bf16x8_t, b),
+                                                 c, 0, 0, 0);
+}
+// float -> bf16, round to nearest even (NaN stays NaN): what torch's .to(torch.bfloat16) does
+__device__ __forceinline__ uint32_t bf16_bits(float f) {
+  return (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return bf16_bits(lo) | (bf16_bits(hi) << 16); }
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
 // round((p - o) / pitch), CUDA round() == roundf(): half away from zero.
 // Division stays a correctly-rounded IEEE divide (no reciprocal tricks): voxel
 // indices must be bit-identical to the oracle.

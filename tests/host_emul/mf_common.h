@@ -403,6 +403,44 @@ inline mf_emul_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, mf_
   return c;
 }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+namespace mf {
+typedef mf_emul_f32x16 mf_f32x16;
+// bf16 helpers of csrc/mf_common.h.  float -> bf16 is round-to-nearest-even, NaN stays NaN (quiet).
+inline uint32_t bf16_bits(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+inline uint32_t pack_bf16x2(float lo, float hi) { return bf16_bits(lo) | (bf16_bits(hi) << 16); }
+inline float bf16_lo(uint32_t w) { uint32_t u = w << 16; float f; memcpy(&f, &u, 4); return f; }
+inline float bf16_hi(uint32_t w) { uint32_t u = w & 0xffff0000u; float f; memcpy(&f, &u, 4); return f; }
+// v_mfma_f32_32x32x16_bf16, lane-exact operand / result layout (csrc/mf_common.h); products of bf16 pairs are
+// exact in fp32, the 16-term sum is taken in increasing k on top of the accumulator (the hardware's internal
+// association is not architecturally specified: tests compare at bf16 tolerances).
+inline mf_emul_f32x16 mfma_bf16_32x32x16(uint4 a, uint4 b, mf_emul_f32x16 c) {
+  uint64_t act;
+  float A[64][8], B[64][8];
+  const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+  for (int w = 0; w < 4; ++w) {
+    const uint64_t *all = mf_emul::wave_exchange(((uint64_t)aw[w] << 32) | bw[w], &act);
+    for (int l = 0; l < 64; ++l) {
+      const uint32_t hi = (uint32_t)(all[l] >> 32), lo = (uint32_t)all[l];
+      A[l][2 * w] = bf16_lo(hi); A[l][2 * w + 1] = bf16_hi(hi);
+      B[l][2 * w] = bf16_lo(lo); B[l][2 * w + 1] = bf16_hi(lo);
+    }
+  }
+  const int lane = mf_emul::g_block.cur % 64, j = lane % 32;
+  for (int e = 0; e < 16; ++e) {
+    const int i = (e & 3) + 8 * (e >> 2) + 4 * (lane / 32);
+    float acc = c[e];
+    for (int kb = 0; kb < 2; ++kb)
+      for (int k = 0; k < 8; ++k) acc += A[kb * 32 + i][k] * B[kb * 32 + j][k];
+    c[e] = acc;
+  }
+  return c;
+}
+}  // namespace mf
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
