@@ -13,7 +13,7 @@ import torch
 
 
 class _Entry:
-    __slots__ = ("graph", "inputs", "outputs", "ptrs")
+    __slots__ = ("graph", "inputs", "outputs", "ptrs", "keepalive")
 
 
 class GraphedPredict:
@@ -22,8 +22,16 @@ class GraphedPredict:
         self.warmup = warmup
         self.entries = {}
 
-    @staticmethod
-    def _key(args):
+    def _key(self, args):
+        """Input shapes / dtypes, the autocast state AND the identity of every parameter and buffer (address +
+        in-place version counter): a captured graph bakes in the addresses of the packed-weight buffers built from
+        the parameters (volumetric_cl._packs, SparseVoxelConv3d.Wp, the PSPNet tail pack), so after
+        ``load_state_dict`` / an optimiser step / ``.to()`` the old graph would replay stale -- or freed -- packs.
+        A changed parameter drops every entry (their packs are rebuilt by the next warm-up)."""
+        params = tuple((t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers()))
+        if params != getattr(self, "_params_seen", None):
+            self.entries.clear()
+            self._params_seen = params
         return tuple((tuple(a.shape), a.dtype) if a is not None else None for a in args) + (
             torch.is_autocast_enabled(),)
 
@@ -46,6 +54,11 @@ class GraphedPredict:
             with torch.cuda.graph(e.graph):
                 e.outputs = self.model._predict_device(*e.inputs)
         e.ptrs = [a.data_ptr() if a is not None else 0 for a in e.inputs]
+        # the pack / scratch tensors whose addresses the graph holds stay alive as long as the entry does
+        vcl = getattr(self.model, "_volumetric_cl", None)
+        e.keepalive = [dict(vcl._packs), dict(vcl._buf), getattr(vcl._sparse, "Wp", None),
+                       getattr(vcl._sparse, "_ws", None)] if vcl is not None else []
+        e.keepalive.append(self.model.pspnet_extractor.__dict__.get("_tail_pack"))
         return e
 
     def __call__(self, *args):

@@ -81,6 +81,10 @@ class Model(nn.Module):
         # occupancy convs, conv3 dense + sparse, conv4 as fp32-MFMA implicit GEMMs, samplers writing
         # into the heads' input matrix); False = round 2's channels-first path (stock conv4 / occ convs)
         self.channels_last_3d = True
+        # under torch.autocast(bfloat16) -- training (BASELINE config 5) and --dtype bf16 inference -- the 3-D
+        # convolutions and every 1x1 convolution run on the hand-written bf16 MFMA kernels, forward and backward
+        # (csrc/gemm_bf16.hip through bf16_ops.py); False = stock MIOpen / hipBLASLt operators under autocast
+        self.bf16_kernels = True
 
         # model.py:50-56: the ImageNet-pretrained chainercv2 ResNet-18 (frozen BatchNorm, no
         # gradient below res2) or the DenseFusion ResNet18.  The pretrained weights are a
@@ -104,6 +108,14 @@ class Model(nn.Module):
             setattr(self, f"conv2_{name}", nn.Conv1d(640, 256, 1))
             setattr(self, f"conv3_{name}", nn.Conv1d(256, 128, 1))
             setattr(self, f"conv4_{name}", nn.Conv1d(128, n_fg_class * c_out, 1))
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle of a model that has predicted: the captured hipGraphs, packed-weight caches and
+        workspaces are per-instance run-time state, rebuilt on demand."""
+        state = dict(self.__dict__)
+        for k in ("_graphed", "_volumetric_cl", "_sparse_conv3_op"):
+            state.pop(k, None)
+        return state
 
     # ---- 3-D feature extraction (model.py:93-164) --------------------------------------
     def _voxelize(self, values, points, return_counts=False):
@@ -295,6 +307,7 @@ class Model(nn.Module):
         """Everything after point selection: pure device work, no host synchronisation."""
         # inference on the channels-last kernels: the PSPNet tail hands over feature ROWS [n,32] (one launch)
         rows = (self.channels_last_3d and self.sparse_conv3 and self.sparse_pspnet_tail and rgb.is_cuda
+                and not self.training  # (forward_sampled_rows has no dropout: train mode keeps the reference's)
                 and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
                 and os.environ.get("MF_NO_TAIL_KERNEL") != "1")  # (A/B knob: the torch formulation of the tail)
         values, points = self._backbone_features(rgb, pcd, pix, rows=rows)
@@ -324,6 +337,9 @@ class Model(nn.Module):
     def _pose_from_features(self, class_id, values, points, pitch, origin, grid_nontarget_empty):
         """The volumetric part (the hand-written path of the network): voxelize -> occupancy
         branch + conv3/conv4 -> trilinear sampling -> the three per-point heads."""
+        if (self.bf16_kernels and values.is_cuda and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            return self._pose_from_features_bf16(class_id, values, points, pitch, origin, grid_nontarget_empty)
         if self.channels_last_3d and self.sparse_conv3 and not torch.is_grad_enabled() and values.is_cuda:
             return self._pose_from_features_cl(class_id, values, points, pitch, origin, grid_nontarget_empty)
         B = values.shape[0]
@@ -353,6 +369,68 @@ class Model(nn.Module):
         trans = cls_trans[ar, fg_class_id].transpose(1, 2)  # B3P -> BP3
         conf = cls_conf[ar, fg_class_id]
         return rot, trans, conf
+
+    def _pose_from_features_bf16(self, class_id, values, points, pitch, origin, grid_nontarget_empty):
+        """``_pose_from_features`` under bf16 autocast, differentiable: points-major bf16 rows and channels-last
+        bf16 grids, conv3 / conv4 and all sixteen 1x1 convolutions on the bf16 MFMA kernels (forward, data and
+        weight gradients: bf16_ops.py); voxelization, trilinear sampling and the loss keep their fp32 HIP ops.
+        values [B,32,P] image features, points [B,3,P] camera frame (model.py:93-164,232-275)."""
+        from . import bf16_ops as K
+        B, _, P = values.shape
+        n, D, nf = B * P, self._voxel_dim, self._n_fg_class
+        dev = values.device
+        pts = ((points.float() - origin[:, :, None]) / pitch[:, None, None]).transpose(1, 2).reshape(n, 3).contiguous()
+        to_center = (D / 2.0 - 0.5) - pts
+        batch_indices = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(P)
+        batch_start = torch.arange(B + 1, dtype=torch.int32, device=dev) * P
+        x_rgb = values.transpose(1, 2).reshape(n, values.shape[1])
+        h1_rgb = K.linear(x_rgb, self.conv1_rgb)
+        h1_pcd = K.linear(to_center, self.conv1_pcd)
+        h2_rgb = K.linear(h1_rgb, self.conv2_rgb)
+        h2_pcd = K.linear(h1_pcd, self.conv2_pcd)
+        feat2 = torch.cat((h2_rgb, h2_pcd), dim=1)                                    # [n,144] bf16
+        vox = functions_module.average_voxelization_3d(
+            feat2.float(), pts, batch_indices, batch_size=B, origin=(0, 0, 0), pitch=1.0, dimensions=(D,) * 3,
+            check_nan=False)                                                          # [B,144,D,D,D] fp32
+        c3 = self.conv3.in_channels
+        x3 = torch.empty((B, D ** 3, c3), dtype=torch.bfloat16, device=dev)           # channels-last conv3 input
+        x3[:, :, :144] = vox.reshape(B, 144, D ** 3).transpose(1, 2)
+        if self._with_occupancy:
+            g = grid_nontarget_empty.to(values.dtype)[:, None, :, :, :]
+            h_occ = F.relu(self.conv2_occ(F.relu(self.conv1_occ(g))))                 # (small stock convolutions)
+            x3[:, :, 144:] = h_occ.reshape(B, 16, D ** 3).transpose(1, 2)
+        h3 = K.conv3d_k4s2(x3, self.conv3, D)                                         # [B,16^3,256] bf16
+        Dh = D // 2
+        feat3 = functions_module.interpolate_voxel_grid(
+            h3.reshape(B, Dh, Dh, Dh, 256).permute(0, 4, 1, 2, 3).float(), pts / 2.0, batch_indices,
+            batch_start=batch_start)                                                  # [n,256] fp32
+        h4 = K.conv3d_k4s2(h3, self.conv4, Dh)                                        # [B,8^3,512] bf16
+        Dq = D // 4
+        feat4 = functions_module.interpolate_voxel_grid(
+            h4.reshape(B, Dq, Dq, Dq, 512).permute(0, 4, 1, 2, 3).float(), pts / 4.0, batch_indices,
+            batch_start=batch_start)                                                  # [n,512] fp32
+        bf = torch.bfloat16
+        feat = torch.cat((h1_rgb, h1_pcd, h2_rgb, h2_pcd, feat3.to(bf), feat4.to(bf)), dim=1)  # [n,984]
+        names = ("rot", "trans", "conf")
+        w1 = torch.cat([getattr(self, f"conv1_{k}").weight for k in names])           # one GEMM for the 3 heads
+        b1 = torch.cat([getattr(self, f"conv1_{k}").bias for k in names])
+        h = K.Linear.apply(feat, w1, b1, True)                                        # [n,1920]
+        outs = {}
+        for i, k in enumerate(names):
+            x = K.linear(h[:, 640 * i:640 * (i + 1)], getattr(self, f"conv2_{k}"))
+            x = K.linear(x, getattr(self, f"conv3_{k}"))
+            outs[k] = K.linear(x, getattr(self, f"conv4_{k}"), relu=False).float()
+        cls_rot = outs["rot"].reshape(B, P, nf, 4)
+        cls_trans = outs["trans"].reshape(B, P, nf, 3)
+        cls_conf = torch.sigmoid(outs["conf"]).reshape(B, P, nf)
+        fg = (class_id - 1).long()
+        ar = torch.arange(B, device=dev)
+        rot = cls_rot[ar, :, fg]
+        rot = rot / (rot.norm(dim=2, keepdim=True) + 1e-5)             # chainer F.normalize: x / (|x| + eps)
+        pts_b = pts.reshape(B, P, 3)
+        points_back = pts_b * pitch[:, None, None] + origin[:, None, :]
+        trans = points_back + cls_trans[ar, :, fg] * pitch[:, None, None]
+        return rot, trans, cls_conf[ar, :, fg]
 
     def _pose_from_features_cl(self, class_id, values, points, pitch, origin, grid_nontarget_empty):
         """``_pose_from_features`` (camera-frame points) on the channels-last kernels (volumetric_cl.py)."""

@@ -274,12 +274,16 @@ struct TnArgs {
   int64_t p_gs, q_gs, c_gs;
   int M, Ni, Nj, ldp, ldq, ldc, groups, S;
   int conv, B, D, dlog, Cin;  // conv: Q(m, j = tap * Cin + cin) = x[b][2 o - 1 + tap][cin], m = (b, o)
+  int shift;                  // bank shift per 16 image rows (bytes): always 64.  A kernel ARGUMENT on purpose: with the
+                              // shift folded in as a constant, hipcc (ROCm 7.2, -O3) produced a kernel that was exact in
+                              // the emulator's g++ build and wrong on the MI355X for image rows 62..65 (round 4,
+                              // tests/test_gpu_bf16_kernels.py caught it); as a run-time value it is a plain multiply-add
 };
 
 // Byte offset of row i of a transposed operand image.  Groups of 16 rows are shifted by 16 banks against each other
 // (rows 8 c + e, c = 0..7, of one staging store then spread over all 64 banks: 2 lanes per bank, the minimum for
 // 512 bytes), and the second 64 rows by a whole bank sweep so that the shifted groups never overlap.
-__device__ __forceinline__ int tn_phys(int row) { return row * kPitch + ((row >> 4) & 3) * 64 + (row >> 6) * 256; }
+__device__ __forceinline__ int tn_phys(int row, int shift) { return row * kPitch + (row >> 4) * shift; }
 
 // rows r = 0..3 (four consecutive m) x 8 columns -> eight 8-byte column vectors (m0..m3 of one column)
 __device__ __forceinline__ void transpose4x8(const uint4 r[4], uint2 out[8]) {
@@ -369,10 +373,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
     unsigned char *Ps = s_raw + buf * kTnBuf + 8 * mg;
     transpose4x8(rp, col);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) *reinterpret_cast<uint2 *>(Ps + tn_phys(8 * c + e)) = col[e];
+    for (int e = 0; e < 8; ++e) *reinterpret_cast<uint2 *>(Ps + tn_phys(8 * c + e, a.shift)) = col[e];
     transpose4x8(rq, col);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) *reinterpret_cast<uint2 *>(Ps + kTnOperand + tn_phys(8 * c + e)) = col[e];
+    for (int e = 0; e < 8; ++e) *reinterpret_cast<uint2 *>(Ps + kTnOperand + tn_phys(8 * c + e, a.shift)) = col[e];
   };
   if (t0 < t1) {
     fetch(t0);
@@ -386,8 +390,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char *Ps = s_raw + buf * kTnBuf + 16 * lhalf;
     const unsigned char *Qs = Ps + kTnOperand;
-    const int pa0 = tn_phys(wm * 64 + lrow), pa1 = tn_phys(wm * 64 + 32 + lrow);
-    const int qb0 = tn_phys(wn * 64 + lrow), qb1 = tn_phys(wn * 64 + 32 + lrow);
+    const int pa0 = tn_phys(wm * 64 + lrow, a.shift), pa1 = tn_phys(wm * 64 + 32 + lrow, a.shift);
+    const int qb0 = tn_phys(wn * 64 + lrow, a.shift), qb1 = tn_phys(wn * 64 + 32 + lrow, a.shift);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const uint4 a0 = *reinterpret_cast<const uint4 *>(Ps + pa0 + 32 * s);
@@ -605,6 +609,7 @@ extern "C" int mf_linear_wgrad_bf16(const void *dY, int64_t y_gs, int32_t ldy, c
   a.P = (const uint16_t *)dY; a.Q = (const uint16_t *)A; a.out = split > 1 ? (float *)ws : dW;
   a.p_gs = y_gs; a.q_gs = a_gs; a.c_gs = w_gs;
   a.M = M; a.Ni = N; a.Nj = K; a.ldp = ldy; a.ldq = lda; a.ldc = ldc; a.groups = groups; a.S = split;
+  a.shift = 64;
   const int64_t grid = (int64_t)((N + 127) / 128) * ((K + 127) / 128) * groups * split;
   hipLaunchKernelGGL(k_gemm_tn_bf16, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
   if (split > 1) {
@@ -699,6 +704,7 @@ extern "C" int mf_conv3d_k4s2_bf16_wgrad(const void *dy, const void *x, float *d
   a.M = B * Do * Do * Do; a.Ni = Cout; a.Nj = 64 * Cin; a.ldp = Cout; a.ldc = 64 * Cin; a.groups = 1;
   a.S = split > 1 ? split : 1;
   a.conv = 1; a.B = B; a.D = D; a.dlog = ilog2_exact(D); a.Cin = Cin;
+  a.shift = 64;
   // (S == 1 also goes through the workspace: the finish pass permutes (tap, cin) -> (cin, tap))
   const int64_t grid = (int64_t)((Cout + 127) / 128) * ((64 * Cin + 127) / 128) * a.S;
   hipLaunchKernelGGL(k_gemm_tn_bf16, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);

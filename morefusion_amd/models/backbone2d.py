@@ -171,19 +171,28 @@ class PSPModule(nn.Module):
                         m = np.zeros((H, W), np.float32)
                         m[by * kh:(by + 1) * kh, bx * kw:(bx + 1) * kw] = 1.0 / (kh * kw)
                         cols.append(m.reshape(-1))
-            cache[key] = torch.from_numpy(np.stack(cols, 1)).to(device=device, dtype=dtype)
+            with torch.inference_mode(False):  # (a constant created under inference_mode could not enter autograd later)
+                cache[key] = torch.from_numpy(np.stack(cols, 1)).to(device=device, dtype=dtype)
         return cache[key]
+
+    def __getstate__(self):  # the cached constants are rebuilt on demand: keep copies / pickles of the module lean
+        state = dict(self.__dict__)
+        state.pop("_pool_cache", None)
+        return state
 
     def _pooled(self, x):
         """The pooling pyramid as ONE GEMM against the constant bin matrix (torch's avg_pool2d kernel walks each
         32 x 32 ... 5 x 5 window with a single thread: measured 0.09-0.28 ms per call, 0.4 ms per predict at
         any batch size; a strided ``mean`` is fast but its reduce kernel faults under hipGraph replay)."""
         B, C, H, W = x.shape
-        Pm = self._pool_matrix(H, W, x.device, x.dtype)
+        # the bin weights (1/100, 1/25, ...) and the window sums stay fp32 under autocast: rounded to bf16 they bias
+        # every pooled value by up to 0.2 %
+        Pm = self._pool_matrix(H, W, x.device, torch.float32)
         # always through the [B, H*W, C] view (free for a channels-last x, one 2 MB copy per object otherwise): the
         # pooled maps come out channels-last, so the 1x1 convolutions and the up-sampling behind them run their
         # NHWC kernels whatever layout MIOpen's solver search left x in (torch's NCHW bilinear kernel: 0.15 ms a call)
-        pooled = torch.matmul(Pm.t(), x.permute(0, 2, 3, 1).reshape(B, H * W, C))  # [B, bins, C]
+        with torch.autocast(x.device.type, enabled=False):
+            pooled = torch.matmul(Pm.t(), x.float().permute(0, 2, 3, 1).reshape(B, H * W, C)).to(x.dtype)  # [B, bins, C]
         out, o = [], 0
         for size in self.sizes:
             n_y, n_x = (H - H // size) // (H // size) + 1, (W - W // size) // (W // size) + 1
@@ -227,6 +236,11 @@ class PSPNetExtractor(nn.Module):
         self.up2 = PSPUpsample(256, 64)
         self.up3 = PSPUpsample(64, 64)
         self.conv1 = nn.Conv2d(64, 32, 1)
+
+    def __getstate__(self):  # the tail kernel's packed weights are a cache
+        state = dict(self.__dict__)
+        state.pop("_tail_pack", None)
+        return state
 
     def forward(self, x):
         h = F.dropout(self.psp(x), 0.3, self.training)

@@ -1,0 +1,76 @@
+"""bf16_ops.py (the autograd operators over csrc/gemm_bf16.hip) on the CPU: the emulated library with torch CPU
+tensors as device memory, against torch's own float32 autograd on the same bf16-rounded operands
+(model.py:73-74,125-139 conv3 / conv4; :76-91,239-258 the 1x1 convolution chains)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from host_emul import emul
+
+pytestmark = pytest.mark.skipif(not emul.available(), reason="g++ not available")
+
+
+@pytest.fixture()
+def K(monkeypatch):
+    from morefusion_amd import _lib
+    from morefusion_amd.contrib.singleview_3d.models import bf16_ops
+    L = emul.build(["gemm_bf16.hip"])
+    for name, (argtypes, restype) in _lib._SIGNATURES.items():
+        fn = getattr(L, name, None)
+        if fn is not None:
+            fn.argtypes, fn.restype = argtypes, restype
+    monkeypatch.setattr(_lib, "lib", lambda: L)
+    monkeypatch.setattr(_lib, "require_gpu", lambda *a: None)
+    monkeypatch.setattr(_lib, "stream_ptr", lambda: None)
+    monkeypatch.setattr(_lib, "check", lambda code, what: (_ for _ in ()).throw(RuntimeError(what)) if code else None)
+    return bf16_ops
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-30))
+
+
+def test_conv3d_operator_forward_and_gradients(K):
+    torch.manual_seed(0)
+    B, Cin, Cout, D, w_cin, c_off = 1, 16, 64, 16, 24, 8
+    conv = torch.nn.Conv3d(w_cin, Cout, 4, 2, padding=1)
+    x = torch.randn(B, D ** 3, Cin).to(torch.bfloat16).requires_grad_(True)
+    out = K.conv3d_k4s2(x, conv, D, relu=True, c_off=c_off)
+    g = torch.randn_like(out.float()).to(torch.bfloat16)
+    out.backward(g)
+    # reference: float32 conv of the bf16-rounded operands, output rounded to bf16 before the ReLU mask is taken
+    xr = x.detach().float().reshape(B, D, D, D, Cin).permute(0, 4, 1, 2, 3).requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).float()[:, c_off:c_off + Cin].requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True)
+    y = F.relu(F.conv3d(xr, wr, br, stride=2, padding=1))
+    y.backward(g.float().reshape(B, D // 2, D // 2, D // 2, Cout).permute(0, 4, 1, 2, 3))
+    y_cl = y.detach().permute(0, 2, 3, 4, 1).reshape(B, -1, Cout)
+    assert rel(out, y_cl) < 2 ** -7
+    assert rel(x.grad, xr.grad.permute(0, 2, 3, 4, 1).reshape(B, -1, Cin)) < 2e-2   # (bf16 output + mask flips at 0)
+    assert rel(conv.weight.grad[:, c_off:c_off + Cin], wr.grad) < 2e-2
+    assert float(conv.weight.grad[:, :c_off].abs().max()) == 0.0
+    assert rel(conv.bias.grad, br.grad) < 2e-2
+
+
+@pytest.mark.parametrize("n,Kin,N,relu", [(150, 3, 8, True), (130, 64, 63, False), (200, 984, 640, True)])
+def test_linear_operator_forward_and_gradients(K, n, Kin, N, relu):
+    torch.manual_seed(1)
+    conv = torch.nn.Conv1d(Kin, N, 1)
+    wide = torch.randn(n, Kin + 16).to(torch.bfloat16) if Kin % 8 == 0 else torch.randn(n, Kin)
+    x = wide[:, 8:8 + Kin] if Kin % 8 == 0 else wide          # a column block of a wider matrix
+    x = x.detach().requires_grad_(True)
+    out = K.linear(x, conv, relu=relu)
+    g = torch.randn(n, N).to(torch.bfloat16)
+    out.backward(g)
+    xr = x.detach().to(torch.bfloat16).float().requires_grad_(True)
+    wr = conv.weight.detach().reshape(N, Kin).to(torch.bfloat16).float().requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True)
+    y = xr @ wr.t() + br
+    y = F.relu(y) if relu else y
+    y.backward(g.float())
+    assert out.shape == (n, N) and out.dtype == torch.bfloat16
+    assert rel(out, y.detach()) < 2 ** -7
+    assert rel(x.grad, xr.grad) < 2e-2
+    assert rel(conv.weight.grad.reshape(N, Kin), wr.grad) < 2e-2
+    assert rel(conv.bias.grad, br.grad) < 2e-2

@@ -1,0 +1,111 @@
+"""The bf16 MFMA kernels of csrc/gemm_bf16.hip on the MI355X (BASELINE config 5: bf16 training; `--dtype bf16`):
+conv3 / conv4 (model.py:73-74,125-139) and the 1x1 convolution chains (model.py:76-91,239-258), forward, data
+gradient and weight gradient, against torch's float32 operators on the same bf16-rounded operands; and one
+training step of the whole pose network on these kernels against the stock bf16-autocast step.
+Tolerances: a bf16 output is within one bf16 rounding (2^-8 relative to the tensor's largest value) of the fp32
+reference; gradients that pass through a bf16-rounded ReLU output within 2 %."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import morefusion_amd as mf  # noqa: E402
+from morefusion_amd.contrib.singleview_3d.models import bf16_ops as K  # noqa: E402
+
+
+def rel(a, b):
+    return float((a.detach().float() - b.detach().float()).abs().max() / (b.detach().float().abs().max() + 1e-30))
+
+
+def grad_close(a, b):
+    """Gradients behind a bf16-rounded ReLU output: an element of the output within one rounding of zero flips its
+    mask, so single elements may be off by a few per cent of the largest value; the tensor as a whole agrees to
+    better than 1 % in L2."""
+    a, b = a.detach().float(), b.detach().float()
+    l2 = float((a - b).norm() / (b.norm() + 1e-30))
+    assert l2 < 1e-2 and rel(a, b) < 5e-2, (l2, rel(a, b))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,D,w_cin,c_off", [(2, 256, 512, 16, 256, 0), (1, 160, 256, 32, 160, 0),
+                                                      (2, 16, 256, 32, 160, 144)])
+def test_conv3d_k4s2_bf16_forward_backward_vs_fp32(B, Cin, Cout, D, w_cin, c_off):
+    torch.manual_seed(0)
+    conv = torch.nn.Conv3d(w_cin, Cout, 4, 2, padding=1).cuda()
+    x = torch.randn(B, D ** 3, Cin, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    out = K.conv3d_k4s2(x, conv, D, relu=True, c_off=c_off)
+    g = torch.randn(out.shape, device="cuda").to(torch.bfloat16)
+    out.backward(g)
+    xr = x.detach().float().reshape(B, D, D, D, Cin).permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).float()[:, c_off:c_off + Cin].contiguous().requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True)
+    with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+        y = F.relu(F.conv3d(xr, wr, br, stride=2, padding=1))
+        y.backward(g.float().reshape(B, D // 2, D // 2, D // 2, Cout).permute(0, 4, 1, 2, 3).contiguous())
+    assert rel(out, y.permute(0, 2, 3, 4, 1).reshape(B, -1, Cout)) < 2 ** -7
+    grad_close(x.grad, xr.grad.permute(0, 2, 3, 4, 1).reshape(B, -1, Cin))
+    grad_close(conv.weight.grad[:, c_off:c_off + Cin], wr.grad)
+    grad_close(conv.bias.grad, br.grad)
+    if c_off:
+        assert float(conv.weight.grad[:, :c_off].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,Kin,N,relu", [(2000, 3, 8, True), (2000, 128, 63, False), (16000, 984, 1920, True),
+                                           (1000, 640, 256, True)])
+def test_linear_bf16_forward_backward_vs_fp32(n, Kin, N, relu):
+    torch.manual_seed(1)
+    conv = torch.nn.Conv1d(Kin, N, 1).cuda()
+    x = (torch.randn(n, Kin, device="cuda").to(torch.bfloat16) if Kin % 8 == 0 else torch.randn(n, Kin, device="cuda"))
+    x = x.requires_grad_(True)
+    out = K.linear(x, conv, relu=relu)
+    g = torch.randn(n, N, device="cuda").to(torch.bfloat16)
+    out.backward(g)
+    xr = x.detach().to(torch.bfloat16).float().requires_grad_(True)
+    wr = conv.weight.detach().reshape(N, Kin).to(torch.bfloat16).float().requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True)
+    y = xr @ wr.t() + br
+    y = F.relu(y) if relu else y
+    y.backward(g.float())
+    assert rel(out, y) < 2 ** -7
+    grad_close(x.grad, xr.grad)
+    grad_close(conv.weight.grad.reshape(N, Kin), wr.grad)
+    grad_close(conv.bias.grad, br.grad)
+
+
+def test_training_step_on_bf16_kernels_matches_stock_autocast_step():
+    """Model.forward + backward under bf16 autocast with ``bf16_kernels`` on (conv3 / conv4 / all 1x1 convolutions on
+    csrc/gemm_bf16.hip) and off (MIOpen / hipBLASLt): same loss within 1 %, parameter gradients of every layer of the
+    volumetric part aligned (cosine > 0.98: two bf16 evaluations of the same function), no stock 3-D convolution of
+    conv3 / conv4 in the hand-written run."""
+    from morefusion_amd.contrib.singleview_3d.models import Model, PitchTableModels
+    torch.manual_seed(0)
+    rs = np.random.RandomState(0)
+    pcds = {c: rs.uniform(-0.05, 0.05, (800, 3)).astype(np.float32) for c in mf.synthetic.CLASS_PITCH}
+    base = Model(n_fg_class=21, with_occupancy=True, models=PitchTableModels(pcds)).cuda().train()
+    b = mf.synthetic.make_singleview_batch(2, seed=20)
+    inputs = {k: torch.as_tensor(b[k]).cuda() for k in
+              ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty", "quaternion_true",
+               "translation_true")}
+    grads, losses = {}, {}
+    for flag in (True, False):
+        model = copy.deepcopy(base)
+        model.bf16_kernels = flag
+        np.random.seed(1)
+        torch.manual_seed(1)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = model(**inputs)
+        loss.backward()
+        losses[flag] = float(loss.detach())
+        grads[flag] = {n: p.grad.detach().float().flatten() for n, p in model.named_parameters() if p.grad is not None}
+    assert np.isfinite(losses[True]) and abs(losses[True] - losses[False]) < 0.01 * abs(losses[False]), losses
+    checked = 0
+    for name, g_hw in grads[True].items():
+        if name.startswith(("conv", )):  # the volumetric part: point MLP, occupancy convs, conv3/4, heads
+            g_st = grads[False][name]
+            cos = float(torch.dot(g_hw, g_st) / (g_hw.norm() * g_st.norm() + 1e-30))
+            assert cos > 0.98, (name, cos)
+            checked += 1
+    assert checked >= 30
