@@ -365,7 +365,17 @@ int mf_linear_fwd(const float *A, int64_t a_group_stride, int32_t lda, const flo
  * mf_conv3d_k4s2_bf16_dgrad  dx [B, D^3, Cin] (+)= conv^T(dy [B, (D/2)^3, Cout]); bf16, or fp32 (+ accumulate)
  * mf_conv3d_k4s2_bf16_wgrad  dW fp32 in the framework layout (channels c_off ..) = sum_voxels dy (x) im2col(x);
  *                       ws: mf_conv3d_k4s2_bf16_wgrad_workspace_bytes(Cin, Cout, split)
- * D is a power of two, Cin % 8 == 0, Cout % 8 == 0.  Asynchronous, never allocate or synchronise. */
+ * D is a power of two, Cin % 8 == 0, Cout % 8 == 0.  Asynchronous, never allocate or synchronise.
+ *
+ * The same engines with a general geometry -- kernel ks in {3, 4}, stride in {1, 2}, pad, dilation; output size
+ * Do = (D + 2 pad - dil (ks - 1) - 1) / stride + 1 a power of two -- run the occupancy branch
+ *   morefusion/contrib/singleview_3d/models/model.py:69-72,120-124 (conv1_occ 1 -> 8 k3 p1, conv2_occ 8 -> 16 k3
+ *   dilation 2 p2; a 1-channel input is fed as 8 channels, 7 of them zero):
+ * mf_conv3d_bf16_pack   fwd [Cout, ks^3, Cin]; dgrad_k4s2 (ks = 4 only); flipT [Cin, ks^3, Cout] = the forward operand
+ *                       of a stride-1 layer's data-gradient convolution (dx = conv(dy, flipT), pad' = dil (ks-1) - pad);
+ *                       input channels at or beyond w_cin pack as zeros
+ * mf_conv3d_bf16_fwd    out rows have pitch ldo >= Cout (a column block of a wider channels-last grid)
+ * mf_conv3d_bf16_wgrad  as above; only the channels below w_cin are written */
 int mf_cast_rows_bf16(const float *src, int64_t src_ld, void *dst, int64_t dst_ld, int64_t rows, int32_t cols,
                       mfStream_t stream);
 int mf_relu_mask_bf16(const void *y, const void *dy, const float *dy32, void *dz, int64_t n, mfStream_t stream);
@@ -387,6 +397,17 @@ int32_t mf_conv3d_k4s2_bf16_wgrad_default_split(int32_t B, int32_t Cin, int32_t 
 int mf_conv3d_k4s2_bf16_wgrad(const void *dy, const void *x, float *dW, void *ws, int32_t B, int32_t Cin,
                               int32_t Cout, int32_t D, int32_t w_cin, int32_t c_off, int32_t split,
                               mfStream_t stream);
+
+int mf_conv3d_bf16_pack(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin, int32_t c_off, int32_t ks, void *fwd,
+                        void *dgrad_k4s2, void *flipT, mfStream_t stream);
+int mf_conv3d_bf16_fwd(const void *x, const void *wt, const float *bias, void *out, int32_t B, int32_t Cin,
+                       int32_t Cout, int32_t D, int32_t ks, int32_t stride, int32_t pad, int32_t dil, int32_t relu,
+                       int32_t out_f32, int32_t ldo, mfStream_t stream);
+int64_t mf_conv3d_bf16_wgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t ks, int32_t split);
+int32_t mf_conv3d_bf16_wgrad_default_split(int32_t B, int32_t Cin, int32_t Cout, int32_t Do, int32_t ks);
+int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, void *ws, int32_t B, int32_t Cin, int32_t Cout,
+                         int32_t D, int32_t ks, int32_t stride, int32_t pad, int32_t dil, int32_t w_cin, int32_t c_off,
+                         int32_t split, mfStream_t stream);
 
 /* Point-wise prologue / epilogue of the volumetric part (inference), one launch each instead of ~25 torch launches:
  *   mf_point_prep: camera-frame points [B,3,P] + image features [B,Cv,P] -> voxel-frame points [n,3]

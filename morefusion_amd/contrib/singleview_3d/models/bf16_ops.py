@@ -45,55 +45,68 @@ def relu_mask(y, dy):
     return dz
 
 
-class Conv3dK4S2(torch.autograd.Function):
-    """``relu?(Convolution3D(Cin, Cout, 4, 2, pad=1)(x))`` on a channels-last bf16 grid:
-    x [B, D^3, Cin] -> [B, (D/2)^3, Cout].  ``weight`` fp32 [Cout, w_cin, 4, 4, 4]; the convolution uses its input
-    channels [c_off, c_off + Cin) (conv3's occupancy / voxelized channel groups can be fed separately)."""
+class Conv3d(torch.autograd.Function):
+    """``relu?(Convolution3D(x))`` on a channels-last bf16 grid x [B, D^3, Cin] -> [B, Do^3, Cout], geometry
+    ``(ks, stride, pad, dil)``: (4, 2, 1, 1) = conv3 / conv4, (3, 1, 1, 1) = conv1_occ, (3, 1, 2, 2) = conv2_occ.
+    ``weight`` fp32 [Cout, w_cin, ks, ks, ks]; the convolution uses its input channels [c_off, c_off + Cin), reading
+    channels at or beyond w_cin as zeros (conv1_occ's single input channel travels as 8 channels, 7 of them zero)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, D, relu, c_off=0):
+    def forward(ctx, x, weight, bias, D, geom, relu, c_off=0):
         _lib.require_gpu(x, weight)
         L = _lib.lib()
+        ks, stride, pad, dil = geom
         x = _bf16c(x)
         B, V, Cin = x.shape
         Cout, w_cin = weight.shape[0], weight.shape[1]
-        assert V == D ** 3 and weight.shape[2:] == (4, 4, 4) and c_off + Cin <= w_cin
+        assert V == D ** 3 and tuple(weight.shape[2:]) == (ks, ks, ks)
+        Do = (D + 2 * pad - dil * (ks - 1) - 1) // stride + 1
         w = weight.detach().float().contiguous()
-        wt = _empty((Cout, 64, Cin), BF16, x)
+        wt = _empty((Cout, ks ** 3, Cin), BF16, x)
         need_dx = ctx.needs_input_grad[0]
-        wd = _empty((8, Cin, 8, Cout), BF16, x) if need_dx else None
-        _lib.check(L.mf_conv3d_k4s2_pack_bf16(w.data_ptr(), Cout, Cin, w_cin, c_off, wt.data_ptr(), _lib.ptr(wd),
-                                              _lib.stream_ptr()), "mf_conv3d_k4s2_pack_bf16")
-        out = _empty((B, (D // 2) ** 3, Cout), BF16, x)
+        k4s2 = tuple(geom) == (4, 2, 1, 1)
+        if need_dx and not (k4s2 or stride == 1):
+            raise NotImplementedError("data gradient: k4/s2/p1 or stride-1 layers")
+        wd = _empty((8, Cin, 8, Cout), BF16, x) if need_dx and k4s2 else None
+        wf = _empty((Cin, ks ** 3, Cout), BF16, x) if need_dx and not k4s2 else None
+        _lib.check(L.mf_conv3d_bf16_pack(w.data_ptr(), Cout, Cin, w_cin, c_off, ks, wt.data_ptr(), _lib.ptr(wd),
+                                         _lib.ptr(wf), _lib.stream_ptr()), "mf_conv3d_bf16_pack")
+        out = _empty((B, Do ** 3, Cout), BF16, x)
         b = bias.detach().float().contiguous() if bias is not None else None
-        _lib.check(L.mf_conv3d_k4s2_bf16_fwd(x.data_ptr(), wt.data_ptr(), _lib.ptr(b), out.data_ptr(), B, Cin, Cout, D,
-                                             int(relu), 0, _lib.stream_ptr()), "mf_conv3d_k4s2_bf16_fwd")
-        ctx.save_for_backward(x, wd, out if relu else None)
-        ctx.geom = (B, Cin, Cout, D, w_cin, c_off, bool(relu), bias is not None, weight.shape)
+        _lib.check(L.mf_conv3d_bf16_fwd(x.data_ptr(), wt.data_ptr(), _lib.ptr(b), out.data_ptr(), B, Cin, Cout, D, ks,
+                                        stride, pad, dil, int(relu), 0, Cout, _lib.stream_ptr()), "mf_conv3d_bf16_fwd")
+        ctx.save_for_backward(x, wd, wf, out if relu else None)
+        ctx.geom = (B, Cin, Cout, D, Do, ks, stride, pad, dil, w_cin, c_off, bool(relu), bias is not None, weight.shape)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, wd, out = ctx.saved_tensors
-        B, Cin, Cout, D, w_cin, c_off, relu, has_bias, wshape = ctx.geom
+        x, wd, wf, out = ctx.saved_tensors
+        B, Cin, Cout, D, Do, ks, stride, pad, dil, w_cin, c_off, relu, has_bias, wshape = ctx.geom
         L = _lib.lib()
         dz = relu_mask(out, dy) if relu else _bf16c(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.check(L.mf_conv3d_k4s2_bf16_dgrad(dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, Cin, Cout, D, 0, 0,
-                                                   _lib.stream_ptr()), "mf_conv3d_k4s2_bf16_dgrad")
+            if wd is not None:
+                _lib.check(L.mf_conv3d_k4s2_bf16_dgrad(dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, Cin, Cout, D, 0,
+                                                       0, _lib.stream_ptr()), "mf_conv3d_k4s2_bf16_dgrad")
+            else:  # stride 1: dx = conv(dz, flipped / transposed weights), pad' = dil (ks - 1) - pad
+                _lib.check(L.mf_conv3d_bf16_fwd(dz.data_ptr(), wf.data_ptr(), None, dx.data_ptr(), B, Cout, Cin, Do, ks,
+                                                1, dil * (ks - 1) - pad, dil, 0, 0, Cin, _lib.stream_ptr()),
+                           "mf_conv3d_bf16_fwd (data gradient)")
         if ctx.needs_input_grad[1]:
-            split = L.mf_conv3d_k4s2_bf16_wgrad_default_split(B, Cin, Cout, D)
-            ws = _empty((L.mf_conv3d_k4s2_bf16_wgrad_workspace_bytes(Cin, Cout, split),), torch.uint8, x)
-            dw = torch.zeros(wshape, dtype=torch.float32, device=x.device) if w_cin != Cin else \
-                _empty(wshape, torch.float32, x)
-            _lib.check(L.mf_conv3d_k4s2_bf16_wgrad(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, Cin,
-                                                   Cout, D, w_cin, c_off, split, _lib.stream_ptr()),
-                       "mf_conv3d_k4s2_bf16_wgrad")
+            split = L.mf_conv3d_bf16_wgrad_default_split(B, Cin, Cout, Do, ks)
+            ws = _empty((L.mf_conv3d_bf16_wgrad_workspace_bytes(Cin, Cout, ks, split),), torch.uint8, x)
+            covered = c_off == 0 and Cin >= w_cin   # every input channel of the weight is written by this call
+            dw = _empty(wshape, torch.float32, x) if covered else torch.zeros(wshape, dtype=torch.float32,
+                                                                                device=x.device)
+            _lib.check(L.mf_conv3d_bf16_wgrad(dz.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, Cin, Cout, D,
+                                              ks, stride, pad, dil, w_cin, c_off, split, _lib.stream_ptr()),
+                       "mf_conv3d_bf16_wgrad")
         if has_bias and ctx.needs_input_grad[2]:
             db = dz.reshape(-1, Cout).sum(dim=0, dtype=torch.float32)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def _wgrad_split(M, N, K, groups):
@@ -171,9 +184,15 @@ class Linear(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def conv3d(x_cl, conv, D, relu=True, c_off=0):
+    """``conv``: a torch.nn.Conv3d with a cubic kernel of 3 or 4, stride 1 or 2 (its own padding / dilation)."""
+    geom = (conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0])
+    return Conv3d.apply(x_cl, conv.weight, conv.bias, D, geom, relu, c_off)
+
+
 def conv3d_k4s2(x_cl, conv, D, relu=True, c_off=0):
     """``conv``: torch.nn.Conv3d(.., 4, 2, padding=1)."""
-    return Conv3dK4S2.apply(x_cl, conv.weight, conv.bias, D, relu, c_off)
+    return Conv3d.apply(x_cl, conv.weight, conv.bias, D, (4, 2, 1, 1), relu, c_off)
 
 
 def linear(x_rows, conv, relu=True):

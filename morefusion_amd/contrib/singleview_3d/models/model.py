@@ -396,9 +396,10 @@ class Model(nn.Module):
         x3 = torch.empty((B, D ** 3, c3), dtype=torch.bfloat16, device=dev)           # channels-last conv3 input
         x3[:, :, :144] = vox.reshape(B, 144, D ** 3).transpose(1, 2)
         if self._with_occupancy:
-            g = grid_nontarget_empty.to(values.dtype)[:, None, :, :, :]
-            h_occ = F.relu(self.conv2_occ(F.relu(self.conv1_occ(g))))                 # (small stock convolutions)
-            x3[:, :, 144:] = h_occ.reshape(B, 16, D ** 3).transpose(1, 2)
+            g8 = torch.zeros((B, D ** 3, 8), dtype=torch.bfloat16, device=dev)        # 1 channel + 7 zeros (16 B / voxel)
+            g8[:, :, 0] = grid_nontarget_empty.reshape(B, D ** 3)
+            h_occ = K.conv3d(K.conv3d(g8, self.conv1_occ, D), self.conv2_occ, D)      # [B,D^3,16] bf16
+            x3[:, :, 144:] = h_occ
         h3 = K.conv3d_k4s2(x3, self.conv3, D)                                         # [B,16^3,256] bf16
         Dh = D // 2
         feat3 = functions_module.interpolate_voxel_grid(

@@ -48,7 +48,9 @@ struct NtArgs {
   int64_t a_gs, w_gs, b_gs, o_gs;
   int M, N, K, lda, ldw, ldo, groups;
   int relu, out_f32, accumulate;
-  int B, D, dlog, Cin, Cout;  // conv geometry: D = INPUT grid size (a power of two), Do = D / 2
+  // conv geometry: D = INPUT grid size, Do = OUTPUT grid size = 1 << olog; forward taps ks^3 at x = stride * o - pad
+  // + dil * k per axis (dgrad: the k4 / s2 / p1 parity-class form only)
+  int B, D, Do, olog, Cin, Cout, ks, stride, pad, dil;
 };
 
 __device__ __forceinline__ uint4 ld16(const uint16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
   const int lrow = lane & 31, lhalf = lane >> 5;
   const int chunk = tid & 7, r0 = tid >> 3;  // this lane stages rows r0 + 32 i, bf16 8 chunk .. + 7 of the K-tile
 
-  const int Do = a.D >> 1, dol = a.dlog - 1;
+  const int Do = a.Do, dol = a.olog;
   const uint16_t *A = a.A + grp * a.a_gs;
   const uint16_t *W = a.W + grp * a.w_gs;
   int cls = 0;
@@ -103,13 +105,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
     } else if (MODE == kConvFwd) {
       const int b = mm >> (3 * dol), o = mm & ((1 << (3 * dol)) - 1);
       const int ox = o >> (2 * dol), oy = (o >> dol) & (Do - 1), oz = o & (Do - 1);
-      const int x0 = 2 * ox - 1, y0 = 2 * oy - 1, z0 = 2 * oz - 1;
+      const int x0 = a.stride * ox - a.pad, y0 = a.stride * oy - a.pad, z0 = a.stride * oz - a.pad;
       base[i] = (((b * a.D + x0) * a.D + y0) * a.D + z0) * a.Cin;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        mk |= ((unsigned)(x0 + k) < (unsigned)a.D ? 1 : 0) << k;
-        mk |= ((unsigned)(y0 + k) < (unsigned)a.D ? 1 : 0) << (4 + k);
-        mk |= ((unsigned)(z0 + k) < (unsigned)a.D ? 1 : 0) << (8 + k);
+      for (int k = 0; k < 4; ++k) {  // (k >= ks: never asked for)
+        mk |= ((unsigned)(x0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << k;
+        mk |= ((unsigned)(y0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (4 + k);
+        mk |= ((unsigned)(z0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (8 + k);
       }
     } else {
       // m = ((b * 8 + p) * Do^3 + h): input voxel x = 2 h + p per axis
@@ -151,9 +153,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
     int off = kg, bits = 1 << 12;
     if (MODE == kConvFwd) {
       const int tap = kg / a.Cin, c = kg - tap * a.Cin;
-      const int kx = tap >> 4, ky = (tap >> 2) & 3, kz = tap & 3;
-      off = ((kx * a.D + ky) * a.D + kz) * a.Cin + c;
-      bits = (1 << kx) | (16 << ky) | (256 << kz) | (1 << 12);
+      const int kxy = tap / a.ks, kz = tap - kxy * a.ks, kx = kxy / a.ks, ky = kxy - kx * a.ks;
+      off = ((kx * a.D + ky) * a.D + kz) * a.dil * a.Cin + c;
+      bits = kx < a.ks ? (1 << kx) | (16 << ky) | (256 << kz) | (1 << 12) : 1 << 13;  // (past the last tap: never valid)
     } else if (MODE == kConvDgrad) {
       const int slot = kg / a.Cout, co = kg - slot * a.Cout;
       const int sx = slot & 1, sy = (slot >> 1) & 1, sz = slot >> 2;
@@ -273,7 +275,7 @@ struct TnArgs {
   float *out;         // S == 1: C [Ni][ldc] (group g at out + g * c_gs); S > 1: slabs [S][groups][Ni][ldc]
   int64_t p_gs, q_gs, c_gs;
   int M, Ni, Nj, ldp, ldq, ldc, groups, S;
-  int conv, B, D, dlog, Cin;  // conv: Q(m, j = tap * Cin + cin) = x[b][2 o - 1 + tap][cin], m = (b, o)
+  int conv, B, D, Do, olog, Cin, ks, stride, pad, dil;  // conv: Q(m, j = tap * Cin + cin) = x[b][stride o - pad + dil tap][cin], m = (b, o)
   int shift;                  // bank shift per 16 image rows (bytes): always 64.  A kernel ARGUMENT on purpose: with the
                               // shift folded in as a constant, hipcc (ROCm 7.2, -O3) produced a kernel that was exact in
                               // the emulator's g++ build and wrong on the MI355X for image rows 62..65 (round 4,
@@ -323,15 +325,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
 
   const uint16_t *P = a.P + grp * a.p_gs;
   const uint16_t *Q = a.Q + grp * a.q_gs;
-  const int Do = a.D >> 1, dol = a.dlog - 1;
+  const int Do = a.Do, dol = a.olog;
   const bool pcol_ok = i0 + 8 * c + 8 <= a.Ni, qcol_ok = j0 + 8 * c + 8 <= a.Nj;
   // conv: this lane's column chunk is one (tap, cin .. cin + 7) for the whole loop
   int q_off = j0 + 8 * c, q_bits = 1 << 12;
   if (a.conv) {
     const int jj = qcol_ok ? j0 + 8 * c : 0;
     const int tap = jj / a.Cin, ci = jj - tap * a.Cin;
-    const int kx = tap >> 4, ky = (tap >> 2) & 3, kz = tap & 3;
-    q_off = ((kx * a.D + ky) * a.D + kz) * a.Cin + ci;
+    const int kxy = tap / a.ks, kz = tap - kxy * a.ks, kx = kxy / a.ks, ky = kxy - kx * a.ks;
+    q_off = ((kx * a.D + ky) * a.D + kz) * a.dil * a.Cin + ci;
     q_bits = (1 << kx) | (16 << ky) | (256 << kz) | (1 << 12);
   }
 
@@ -353,13 +355,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
       rp[r] = ld_chunk(P, mm * a.ldp, i0 + 8 * c, ok && pcol_ok);
       if (a.conv) {
         const int b = mm >> (3 * dol), o = mm & ((1 << (3 * dol)) - 1);
-        const int x0 = 2 * (o >> (2 * dol)) - 1, y0 = 2 * ((o >> dol) & (Do - 1)) - 1, z0 = 2 * (o & (Do - 1)) - 1;
+        const int x0 = a.stride * (o >> (2 * dol)) - a.pad, y0 = a.stride * ((o >> dol) & (Do - 1)) - a.pad,
+                  z0 = a.stride * (o & (Do - 1)) - a.pad;
         int mk = 1 << 12;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          mk |= ((unsigned)(x0 + k) < (unsigned)a.D ? 1 : 0) << k;
-          mk |= ((unsigned)(y0 + k) < (unsigned)a.D ? 1 : 0) << (4 + k);
-          mk |= ((unsigned)(z0 + k) < (unsigned)a.D ? 1 : 0) << (8 + k);
+          mk |= ((unsigned)(x0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << k;
+          mk |= ((unsigned)(y0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (4 + k);
+          mk |= ((unsigned)(z0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (8 + k);
         }
         const int base = (((b * a.D + x0) * a.D + y0) * a.D + z0) * a.Cin;
         rq[r] = ld_chunk(Q, base, q_off, ok && qcol_ok && (mk & q_bits) == q_bits);
@@ -438,11 +441,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
   }
 }
 
-// out[g][i][f(j)] = sum_s slab[s][g][i][j] (increasing s); conv: j = tap * Cin + cin -> f(j) = cin * 64 + tap
-// (the torch / Chainer ConvolutionND weight layout [Cout][Cin][4][4][4]).
+// out[g][i][f(j)] = sum_s slab[s][g][i][j] (increasing s); conv: j = tap * Cin + cin -> f(j) = cin * taps + tap
+// (the torch / Chainer ConvolutionND weight layout [Cout][w_cin][ks][ks][ks]); channels cin >= cin_keep (the zero
+// padding of a narrow layer's input up to 8 channels) are dropped.
 __global__ __launch_bounds__(256) void k_wgrad_finish(const float *__restrict__ slabs, float *__restrict__ out,
                                                       int64_t per_slab, int Nj, int ldc, int S, int conv_cin,
-                                                      int64_t c_gs, int64_t per_group, int64_t out_row_pitch) {
+                                                      int64_t c_gs, int64_t per_group, int64_t out_row_pitch,
+                                                      int taps, int cin_keep) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= per_slab) return;
   const int64_t g = idx / per_group, in_g = idx - g * per_group;
@@ -454,7 +459,8 @@ __global__ __launch_bounds__(256) void k_wgrad_finish(const float *__restrict__ 
   int64_t o = j;
   if (conv_cin) {
     const int tap = j / conv_cin, ci = j - tap * conv_cin;
-    o = (int64_t)ci * 64 + tap;
+    if (ci >= cin_keep) return;
+    o = (int64_t)ci * taps + tap;
   }
   out[g * c_gs + i * out_row_pitch + o] = v;
 }
@@ -477,25 +483,35 @@ __global__ __launch_bounds__(256) void k_cast_rows_bf16(const float *__restrict_
                  mf::pack_bf16x2(v[6], v[7]));
 }
 
-// W [Cout][w_cin][4][4][4] fp32 (channels c_off .. c_off + Cin) ->
-//   fwd   [Cout][tap][Cin]            (k = tap * Cin + cin)
-//   dgrad [class p][Cin][slot][Cout]  (k = slot * Cout + cout; tap = (1 - p) + 2 s per axis)
+// W [Cout][w_cin][ks][ks][ks] fp32 (input channels c_off .. c_off + Cin; channels past w_cin read as zero) ->
+//   fwd   [Cout][tap][Cin]            (k = tap * Cin + cin)                                  taps = ks^3
+//   dgrad [class p][Cin][slot][Cout]  (k4 / s2 / p1 only: k = slot * Cout + cout; tap = (1 - p) + 2 s per axis)
+//   flipT [Cin][tap][Cout]            the forward operand of the DATA-GRADIENT convolution of a stride-1 layer:
+//                                     dx = conv(dy, flipT), flipT[ci][tap][co] = W[co][ci][ks^3 - 1 - tap]
 __global__ __launch_bounds__(256) void k_conv_pack_bf16(const float *__restrict__ W, int Cout, int Cin, int w_cin,
-                                                        int c_off, uint16_t *__restrict__ fwd,
-                                                        uint16_t *__restrict__ dgrad) {
+                                                        int c_off, int ks, uint16_t *__restrict__ fwd,
+                                                        uint16_t *__restrict__ dgrad, uint16_t *__restrict__ flipT) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)Cout * 64 * Cin;
+  const int taps = ks * ks * ks;
+  const int64_t total = (int64_t)Cout * taps * Cin;
   if (i >= total) return;
+  auto w_at = [&](int co, int ci, int tap) {
+    return c_off + ci < w_cin ? W[((int64_t)co * w_cin + c_off + ci) * taps + tap] : 0.0f;
+  };
   if (fwd) {
-    const int ci = (int)(i % Cin), tap = (int)((i / Cin) % 64), co = (int)(i / ((int64_t)64 * Cin));
-    fwd[i] = (uint16_t)mf::bf16_bits(W[((int64_t)co * w_cin + c_off + ci) * 64 + tap]);
+    const int ci = (int)(i % Cin), tap = (int)((i / Cin) % taps), co = (int)(i / ((int64_t)taps * Cin));
+    fwd[i] = (uint16_t)mf::bf16_bits(w_at(co, ci, tap));
   }
   if (dgrad) {
     const int co = (int)(i % Cout), slot = (int)((i / Cout) % 8), ci = (int)((i / ((int64_t)8 * Cout)) % Cin);
     const int p = (int)(i / ((int64_t)8 * Cout * Cin));
     const int kx = (1 - (p & 1)) + 2 * (slot & 1), ky = (1 - ((p >> 1) & 1)) + 2 * ((slot >> 1) & 1),
               kz = (1 - (p >> 2)) + 2 * (slot >> 2);
-    dgrad[i] = (uint16_t)mf::bf16_bits(W[((int64_t)co * w_cin + c_off + ci) * 64 + (kx * 16 + ky * 4 + kz)]);
+    dgrad[i] = (uint16_t)mf::bf16_bits(w_at(co, ci, kx * 16 + ky * 4 + kz));
+  }
+  if (flipT) {
+    const int co = (int)(i % Cout), tap = (int)((i / Cout) % taps), ci = (int)(i / ((int64_t)taps * Cout));
+    flipT[i] = (uint16_t)mf::bf16_bits(w_at(co, ci, taps - 1 - tap));
   }
 }
 
@@ -615,102 +631,139 @@ extern "C" int mf_linear_wgrad_bf16(const void *dY, int64_t y_gs, int32_t ldy, c
   if (split > 1) {
     const int64_t per_group = (int64_t)N * ldc, per_slab = per_group * groups;
     hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, stream,
-                       (const float *)ws, dW, per_slab, K, ldc, split, 0, w_gs, per_group, (int64_t)ldc);
+                       (const float *)ws, dW, per_slab, K, ldc, split, 0, w_gs, per_group, (int64_t)ldc, 0, 0);
   }
   return mf::check_launch("mf_linear_wgrad_bf16");
 }
 
-/* Convolution3D(Cin, Cout, 4, 2, pad = 1) on channels-last bf16 grids.  W: fp32 in the framework layout
- * [Cout][w_cin][4][4][4]; the packed bf16 operands are [Cout][64][Cin] (forward / wgrad order) and
- * [8][Cin][8][Cout] (dgrad). */
-extern "C" int mf_conv3d_k4s2_pack_bf16(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin, int32_t c_off,
-                                        void *fwd, void *dgrad, mfStream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  const int64_t total = (int64_t)Cout * 64 * Cin;
-  hipLaunchKernelGGL(k_conv_pack_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, W, Cout, Cin,
-                     w_cin, c_off, (uint16_t *)fwd, (uint16_t *)dgrad);
-  return mf::check_launch("mf_conv3d_k4s2_pack_bf16");
-}
-
-static int conv_check(int32_t B, int32_t Cin, int32_t Cout, int32_t D) {
-  const int dl = ilog2_exact(D);
-  if (dl < 2 || Cin % 8 || Cout % 8 || (int64_t)B * D * D * D * Cin >= (1ll << 31) ||
-      (int64_t)B * (D / 2) * (D / 2) * (D / 2) * Cout >= (1ll << 31) || (int64_t)Cout * 64 * Cin >= (1ll << 31))
-    return bad("conv3d_k4s2 (bf16): D a power of two >= 4, Cin % 8 == 0, Cout % 8 == 0, tensors < 2^31 elements");
+/* Convolution3D on channels-last bf16 grids: kernel ks in {3, 4}, stride in {1, 2}, any pad / dilation whose output
+ * size Do = (D + 2 pad - dil (ks - 1) - 1) / stride + 1 is a power of two.  W: fp32 in the framework layout
+ * [Cout][w_cin][ks][ks][ks]. */
+namespace {
+struct Geom { int Do, olog, taps; };
+int conv_geom(int32_t B, int32_t Cin, int32_t Cout, int32_t D, int32_t ks, int32_t stride, int32_t pad, int32_t dil,
+              Geom *g) {
+  const int span = dil * (ks - 1) + 1;
+  if ((ks != 3 && ks != 4) || (stride != 1 && stride != 2) || dil < 1 || pad < 0 || D + 2 * pad < span)
+    return bad("conv3d (bf16): kernel 3 or 4, stride 1 or 2");
+  g->Do = (D + 2 * pad - span) / stride + 1;
+  g->olog = ilog2_exact(g->Do);
+  g->taps = ks * ks * ks;
+  if (g->olog < 1 || Cin % 8 || Cout % 8 || (int64_t)B * D * D * D * Cin >= (1ll << 31) ||
+      (int64_t)B * g->Do * g->Do * g->Do * Cout >= (1ll << 31) || (int64_t)Cout * g->taps * Cin >= (1ll << 31))
+    return bad("conv3d (bf16): output size a power of two, Cin % 8 == 0, Cout % 8 == 0, tensors < 2^31 elements");
   return 0;
 }
+}  // namespace
 
-/* out [B][(D/2)^3][Cout] = act(conv(x [B][D^3][Cin]) + bias): x, wt (packed forward layout) bf16; out bf16 / fp32 */
-extern "C" int mf_conv3d_k4s2_bf16_fwd(const void *x, const void *wt, const float *bias, void *out, int32_t B,
-                                       int32_t Cin, int32_t Cout, int32_t D, int32_t relu, int32_t out_f32,
-                                       mfStream_t stream_) {
+extern "C" int mf_conv3d_bf16_pack(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin, int32_t c_off, int32_t ks,
+                                   void *fwd, void *dgrad_k4s2, void *flipT, mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (B <= 0) return 0;
-  if (int e = conv_check(B, Cin, Cout, D)) return e;
-  const int Do = D / 2;
-  NtArgs a = {};
-  a.A = (const uint16_t *)x; a.W = (const uint16_t *)wt; a.bias = bias; a.out = out;
-  a.M = B * Do * Do * Do; a.N = Cout; a.K = 64 * Cin; a.ldw = 64 * Cin; a.ldo = Cout; a.groups = 1;
-  a.relu = relu; a.out_f32 = out_f32;
-  a.B = B; a.D = D; a.dlog = ilog2_exact(D); a.Cin = Cin; a.Cout = Cout;
-  if (int e = launch_nt<kConvFwd>(a, stream)) return e;
-  return mf::check_launch("mf_conv3d_k4s2_bf16_fwd");
+  if ((ks != 3 && ks != 4) || (dgrad_k4s2 && ks != 4)) return bad("conv3d_bf16_pack: kernel 3 or 4 (parity-class dgrad: 4)");
+  const int64_t total = (int64_t)Cout * ks * ks * ks * Cin;
+  hipLaunchKernelGGL(k_conv_pack_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, W, Cout, Cin,
+                     w_cin, c_off, ks, (uint16_t *)fwd, (uint16_t *)dgrad_k4s2, (uint16_t *)flipT);
+  return mf::check_launch("mf_conv3d_bf16_pack");
 }
 
-/* dx [B][D^3][Cin] (+)= conv^T(dy [B][(D/2)^3][Cout]): dy, wd (packed dgrad layout) bf16; dx bf16, or fp32 with
- * ``accumulate`` (dx already holds another consumer's gradient). */
+/* out [B][Do^3][ldo >= Cout] = act(conv(x [B][D^3][Cin]) + bias): x, wt ([Cout][ks^3][Cin]) bf16; out bf16 / fp32 */
+extern "C" int mf_conv3d_bf16_fwd(const void *x, const void *wt, const float *bias, void *out, int32_t B, int32_t Cin,
+                                  int32_t Cout, int32_t D, int32_t ks, int32_t stride, int32_t pad, int32_t dil,
+                                  int32_t relu, int32_t out_f32, int32_t ldo, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0) return 0;
+  Geom g;
+  if (int e = conv_geom(B, Cin, Cout, D, ks, stride, pad, dil, &g)) return e;
+  if (ldo < Cout) return bad("conv3d_bf16_fwd: ldo >= Cout");
+  NtArgs a = {};
+  a.A = (const uint16_t *)x; a.W = (const uint16_t *)wt; a.bias = bias; a.out = out;
+  a.M = B * g.Do * g.Do * g.Do; a.N = Cout; a.K = g.taps * Cin; a.ldw = g.taps * Cin; a.ldo = ldo; a.groups = 1;
+  a.relu = relu; a.out_f32 = out_f32;
+  a.B = B; a.D = D; a.Do = g.Do; a.olog = g.olog; a.Cin = Cin; a.Cout = Cout;
+  a.ks = ks; a.stride = stride; a.pad = pad; a.dil = dil;
+  if (int e = launch_nt<kConvFwd>(a, stream)) return e;
+  return mf::check_launch("mf_conv3d_bf16_fwd");
+}
+
+/* dx [B][D^3][Cin] (+)= conv^T(dy [B][(D/2)^3][Cout]) of the k4 / s2 / p1 layers: dy, wd (packed parity-class layout)
+ * bf16; dx bf16, or fp32 with ``accumulate`` (dx already holds another consumer's gradient).  (Stride-1 layers take
+ * their data gradient through mf_conv3d_bf16_fwd on the flipT operand.) */
 extern "C" int mf_conv3d_k4s2_bf16_dgrad(const void *dy, const void *wd, void *dx, int32_t B, int32_t Cin,
                                          int32_t Cout, int32_t D, int32_t out_f32, int32_t accumulate,
                                          mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0) return 0;
-  if (int e = conv_check(B, Cin, Cout, D)) return e;
-  const int Do = D / 2;
-  if ((Do * Do * Do) % 128 || (accumulate && !out_f32)) return bad("conv3d_k4s2 dgrad: (D/2)^3 % 128 == 0; accumulate needs fp32");
+  Geom g;
+  if (int e = conv_geom(B, Cin, Cout, D, 4, 2, 1, 1, &g)) return e;
+  if ((g.Do * g.Do * g.Do) % 128 || (accumulate && !out_f32)) return bad("conv3d_k4s2 dgrad: (D/2)^3 % 128 == 0; accumulate needs fp32");
   NtArgs a = {};
   a.A = (const uint16_t *)dy; a.W = (const uint16_t *)wd; a.out = dx;
   a.M = B * D * D * D; a.N = Cin; a.K = 8 * Cout; a.ldw = 8 * Cout; a.ldo = Cin; a.groups = 1;
   a.out_f32 = out_f32; a.accumulate = accumulate;
-  a.B = B; a.D = D; a.dlog = ilog2_exact(D); a.Cin = Cin; a.Cout = Cout;
+  a.B = B; a.D = D; a.Do = g.Do; a.olog = g.olog; a.Cin = Cin; a.Cout = Cout; a.ks = 4; a.stride = 2; a.pad = 1; a.dil = 1;
   if (int e = launch_nt<kConvDgrad>(a, stream)) return e;
   return mf::check_launch("mf_conv3d_k4s2_bf16_dgrad");
 }
 
-extern "C" int64_t mf_conv3d_k4s2_bf16_wgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t split) {
-  return split > 1 ? (int64_t)split * Cout * 64 * Cin * 4 : (int64_t)Cout * 64 * Cin * 4;
+extern "C" int64_t mf_conv3d_bf16_wgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t ks, int32_t split) {
+  return (int64_t)(split > 1 ? split : 1) * Cout * ks * ks * ks * Cin * 4;
 }
 
-extern "C" int32_t mf_conv3d_k4s2_bf16_wgrad_default_split(int32_t B, int32_t Cin, int32_t Cout, int32_t D) {
-  const int64_t tiles = (int64_t)((Cout + 127) / 128) * ((64 * Cin + 127) / 128);
-  const int64_t ktiles = ((int64_t)B * (D / 2) * (D / 2) * (D / 2) + 63) / 64;
+extern "C" int32_t mf_conv3d_bf16_wgrad_default_split(int32_t B, int32_t Cin, int32_t Cout, int32_t Do, int32_t ks) {
+  const int64_t tiles = (int64_t)((Cout + 127) / 128) * (((int64_t)ks * ks * ks * Cin + 127) / 128);
+  const int64_t ktiles = ((int64_t)B * Do * Do * Do + 63) / 64;
   int S = 1;
   while (tiles * S < 512 && ktiles / (S * 2) >= 16) S *= 2;
   return S;
 }
 
-/* dW [Cout][w_cin][4][4][4] (channels c_off ..: fp32, the framework layout) = sum over output voxels of
- * dy (x) im2col(x); ws: mf_conv3d_k4s2_bf16_wgrad_workspace_bytes. */
-extern "C" int mf_conv3d_k4s2_bf16_wgrad(const void *dy, const void *x, float *dW, void *ws, int32_t B, int32_t Cin,
-                                         int32_t Cout, int32_t D, int32_t w_cin, int32_t c_off, int32_t split,
-                                         mfStream_t stream_) {
+/* dW [Cout][w_cin][ks][ks][ks] (input channels c_off .., those below w_cin: fp32, the framework layout) = sum over
+ * output voxels of dy (x) im2col(x); ws: mf_conv3d_bf16_wgrad_workspace_bytes. */
+extern "C" int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, void *ws, int32_t B, int32_t Cin,
+                                    int32_t Cout, int32_t D, int32_t ks, int32_t stride, int32_t pad, int32_t dil,
+                                    int32_t w_cin, int32_t c_off, int32_t split, mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0) return 0;
-  if (int e = conv_check(B, Cin, Cout, D)) return e;
-  if (split < 1 || !ws) return bad("conv3d_k4s2 wgrad: workspace required");
+  Geom g;
+  if (int e = conv_geom(B, Cin, Cout, D, ks, stride, pad, dil, &g)) return e;
+  if (split < 1 || !ws) return bad("conv3d wgrad: workspace required");
   if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16, kTnLds)) return e;
-  const int Do = D / 2;
   TnArgs a = {};
   a.P = (const uint16_t *)dy; a.Q = (const uint16_t *)x; a.out = (float *)ws;
-  a.M = B * Do * Do * Do; a.Ni = Cout; a.Nj = 64 * Cin; a.ldp = Cout; a.ldc = 64 * Cin; a.groups = 1;
-  a.S = split > 1 ? split : 1;
-  a.conv = 1; a.B = B; a.D = D; a.dlog = ilog2_exact(D); a.Cin = Cin;
+  a.M = B * g.Do * g.Do * g.Do; a.Ni = Cout; a.Nj = g.taps * Cin; a.ldp = Cout; a.ldc = g.taps * Cin; a.groups = 1;
+  a.S = split;
+  a.conv = 1; a.B = B; a.D = D; a.Do = g.Do; a.olog = g.olog; a.Cin = Cin;
+  a.ks = ks; a.stride = stride; a.pad = pad; a.dil = dil;
   a.shift = 64;
   // (S == 1 also goes through the workspace: the finish pass permutes (tap, cin) -> (cin, tap))
-  const int64_t grid = (int64_t)((Cout + 127) / 128) * ((64 * Cin + 127) / 128) * a.S;
+  const int64_t grid = (int64_t)((Cout + 127) / 128) * ((g.taps * Cin + 127) / 128) * a.S;
   hipLaunchKernelGGL(k_gemm_tn_bf16, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
-  const int64_t per_slab = (int64_t)Cout * 64 * Cin;
+  const int64_t per_slab = (int64_t)Cout * g.taps * Cin;
+  const int keep = w_cin - c_off < Cin ? w_cin - c_off : Cin;
   hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, stream,
-                     (const float *)ws, dW + (int64_t)c_off * 64, per_slab, 64 * Cin, 64 * Cin, a.S, Cin, (int64_t)0,
-                     per_slab, (int64_t)w_cin * 64);
-  return mf::check_launch("mf_conv3d_k4s2_bf16_wgrad");
+                     (const float *)ws, dW + (int64_t)c_off * g.taps, per_slab, g.taps * Cin, g.taps * Cin, a.S, Cin,
+                     (int64_t)0, per_slab, (int64_t)w_cin * g.taps, g.taps, keep);
+  return mf::check_launch("mf_conv3d_bf16_wgrad");
+}
+
+/* the k4 / s2 / p1 forms (conv3, conv4) under their round-4 names */
+extern "C" int mf_conv3d_k4s2_pack_bf16(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin, int32_t c_off,
+                                        void *fwd, void *dgrad, mfStream_t stream) {
+  return mf_conv3d_bf16_pack(W, Cout, Cin, w_cin, c_off, 4, fwd, dgrad, nullptr, stream);
+}
+extern "C" int mf_conv3d_k4s2_bf16_fwd(const void *x, const void *wt, const float *bias, void *out, int32_t B,
+                                       int32_t Cin, int32_t Cout, int32_t D, int32_t relu, int32_t out_f32,
+                                       mfStream_t stream) {
+  return mf_conv3d_bf16_fwd(x, wt, bias, out, B, Cin, Cout, D, 4, 2, 1, 1, relu, out_f32, Cout, stream);
+}
+extern "C" int64_t mf_conv3d_k4s2_bf16_wgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t split) {
+  return mf_conv3d_bf16_wgrad_workspace_bytes(Cin, Cout, 4, split);
+}
+extern "C" int32_t mf_conv3d_k4s2_bf16_wgrad_default_split(int32_t B, int32_t Cin, int32_t Cout, int32_t D) {
+  return mf_conv3d_bf16_wgrad_default_split(B, Cin, Cout, D / 2, 4);
+}
+extern "C" int mf_conv3d_k4s2_bf16_wgrad(const void *dy, const void *x, float *dW, void *ws, int32_t B, int32_t Cin,
+                                         int32_t Cout, int32_t D, int32_t w_cin, int32_t c_off, int32_t split,
+                                         mfStream_t stream) {
+  return mf_conv3d_bf16_wgrad(dy, x, dW, ws, B, Cin, Cout, D, 4, 2, 1, 1, w_cin, c_off, split, stream);
 }

@@ -53,6 +53,40 @@ def test_conv3d_operator_forward_and_gradients(K):
     assert rel(conv.bias.grad, br.grad) < 2e-2
 
 
+def test_occupancy_branch_operator_chain(K):
+    """conv1_occ -> conv2_occ (model.py:69-72,120-124) through the general-geometry operator: values and the
+    gradients of both layers' parameters vs torch's float32 convolutions."""
+    torch.manual_seed(2)
+    B, D = 1, 8
+    c1 = torch.nn.Conv3d(1, 8, 3, 1, padding=1)
+    c2 = torch.nn.Conv3d(8, 16, 3, 1, padding=2, dilation=2)
+    grid = (torch.rand(B, D, D, D) > 0.5).float()
+    g8 = torch.zeros(B, D ** 3, 8, dtype=torch.bfloat16)
+    g8[:, :, 0] = grid.reshape(B, -1)
+    out = K.conv3d(K.conv3d(g8, c1, D), c2, D)
+    g = torch.randn(out.shape).to(torch.bfloat16)
+    out.backward(g)
+    r1, r2 = torch.nn.Conv3d(1, 8, 3, 1, padding=1), torch.nn.Conv3d(8, 16, 3, 1, padding=2, dilation=2)
+    with torch.no_grad():
+        for a, b in ((r1, c1), (r2, c2)):
+            a.weight.copy_(b.weight.to(torch.bfloat16).float())
+            a.bias.copy_(b.bias)
+    h1 = F.relu(r1(grid[:, None])).to(torch.bfloat16).float()   # (the operator hands bf16 activations on)
+    y = F.relu(r2(h1))
+    assert rel(out, y.permute(0, 2, 3, 4, 1).reshape(B, -1, 16)) < 2 ** -7
+    # gradients of the second layer against autograd on the same (bf16-rounded) intermediate
+    h1l = h1.detach().requires_grad_(True)
+    y2 = F.relu(r2(h1l))
+    y2.backward(g.float().reshape(B, D, D, D, 16).permute(0, 4, 1, 2, 3))
+    assert rel(c2.weight.grad, r2.weight.grad) < 2e-2 and rel(c2.bias.grad, r2.bias.grad) < 2e-2
+    assert c1.weight.grad is not None and float(c1.weight.grad.abs().sum()) > 0 and c1.weight.grad.shape == (8, 1, 3, 3, 3)
+    # first layer: chain the reference's dh1 (masked by its own ReLU) through conv1's weight gradient
+    dz1 = (h1l.grad * (h1 > 0)).to(torch.bfloat16).float()
+    h1_pre = r1(grid[:, None])
+    h1_pre.backward(dz1)
+    assert rel(c1.weight.grad, r1.weight.grad) < 3e-2
+
+
 @pytest.mark.parametrize("n,Kin,N,relu", [(150, 3, 8, True), (130, 64, 63, False), (200, 984, 640, True)])
 def test_linear_operator_forward_and_gradients(K, n, Kin, N, relu):
     torch.manual_seed(1)

@@ -156,3 +156,46 @@ def test_conv3d_k4s2_bf16_forward_dgrad_wgrad(L, B, Cin, Cout, D, w_cin, c_off):
         if w_cin > Cin:
             rest = torch.cat([dW[:, :c_off], dW[:, c_off + Cin:]], 1)
             assert float(rest.min()) == 3.0 and float(rest.max()) == 3.0
+
+
+@pytest.mark.parametrize("name,Cin_real,Cout,ks,pad,dil", [("conv1_occ", 1, 8, 3, 1, 1), ("conv2_occ", 8, 16, 3, 2, 2)])
+def test_occupancy_branch_convolutions_on_the_general_geometry(L, name, Cin_real, Cout, ks, pad, dil):
+    """conv1_occ (1 -> 8, k3 p1; the single input channel travels as 8 with 7 zeros) and conv2_occ (8 -> 16, k3,
+    dilation 2, p2) of model.py:69-72,120-124: forward, weight gradient (only the real input channels are written)
+    and the data gradient as a forward convolution with the flipped / transposed operand."""
+    torch.manual_seed(3)
+    B, D, Cin = 1, 8, 8
+    x_cf = torch.zeros(B, Cin, D, D, D)
+    x_cf[:, :Cin_real] = bf(torch.randn(B, Cin_real, D, D, D)).float()
+    x_cf.requires_grad_(True)
+    W = bf(torch.randn(Cout, Cin_real, ks, ks, ks) / (Cin_real * ks ** 3) ** 0.5).float().requires_grad_(True)
+    bias = torch.randn(Cout)
+    y = F.conv3d(x_cf[:, :Cin_real], W, bias, stride=1, padding=pad, dilation=dil)
+    dy_cf = bf(torch.randn_like(y)).float()
+    y.backward(dy_cf)
+    cl = lambda t: t.permute(0, 2, 3, 4, 1).contiguous()  # noqa: E731
+    x_cl, dy_cl = cl(x_cf.detach()).to(torch.bfloat16), cl(dy_cf).to(torch.bfloat16)
+    taps = ks ** 3
+    wt = torch.empty(Cout, taps, Cin, dtype=torch.bfloat16)
+    wf = torch.empty(Cin, taps, Cout, dtype=torch.bfloat16)
+    assert L.mf_conv3d_bf16_pack(p(W.detach()), Cout, Cin, Cin_real, 0, ks, p(wt), None, p(wf), None) == 0
+    assert float(wt[:, :, Cin_real:].abs().max() if Cin_real < Cin else 0.0) == 0.0
+    # forward into a column block of a wider grid (pitch 24)
+    out = torch.full((B, D ** 3, 24), -3.0, dtype=torch.bfloat16)
+    assert L.mf_conv3d_bf16_fwd(p(x_cl), p(wt), p(bias), p(out[:, :, 4:]), B, Cin, Cout, D, ks, 1, pad, dil, 1, 0, 24,
+                                None) == 0
+    close_bf16(out[:, :, 4:4 + Cout], cl(F.relu(y.detach())).reshape(B, D ** 3, Cout))
+    assert float(out[:, :, :4].float().max()) == -3.0 and float(out[:, :, 4 + Cout:].float().max()) == -3.0
+    # weight gradient
+    for split in (1, 2):
+        dW = torch.full((Cout, Cin_real, ks, ks, ks), 9.0)
+        ws = torch.empty(L.mf_conv3d_bf16_wgrad_workspace_bytes(Cin, Cout, ks, split) // 4)
+        assert L.mf_conv3d_bf16_wgrad(p(dy_cl), p(x_cl), p(dW), p(ws), B, Cin, Cout, D, ks, 1, pad, dil, Cin_real, 0,
+                                      split, None) == 0
+        close(dW, W.grad)
+    # data gradient = conv(dy, flipT) with pad' = dil (ks - 1) - pad
+    if Cin_real == Cin:
+        dx = torch.empty(B, D ** 3, Cin)
+        assert L.mf_conv3d_bf16_fwd(p(dy_cl), p(wf), None, p(dx), B, Cout, Cin, D, ks, 1, dil * (ks - 1) - pad, dil, 0, 1,
+                                    Cin, None) == 0
+        close(dx, cl(x_cf.grad).reshape(B, D ** 3, Cin))

@@ -109,3 +109,36 @@ def test_training_step_on_bf16_kernels_matches_stock_autocast_step():
             assert cos > 0.98, (name, cos)
             checked += 1
     assert checked >= 30
+
+
+def test_occupancy_branch_on_the_bf16_kernels_vs_fp32():
+    """conv1_occ (1 -> 8, k3 p1) -> ReLU -> conv2_occ (8 -> 16, k3, dilation 2, p2) -> ReLU (model.py:69-72,120-124)
+    at the network's size (32^3, B = 2) through the general-geometry kernels: values and parameter gradients vs
+    torch's float32 convolutions."""
+    torch.manual_seed(2)
+    B, D = 2, 32
+    c1 = torch.nn.Conv3d(1, 8, 3, 1, padding=1).cuda()
+    c2 = torch.nn.Conv3d(8, 16, 3, 1, padding=2, dilation=2).cuda()
+    grid = (torch.rand(B, D, D, D, device="cuda") > 0.5).float()
+    g8 = torch.zeros(B, D ** 3, 8, dtype=torch.bfloat16, device="cuda")
+    g8[:, :, 0] = grid.reshape(B, -1)
+    out = K.conv3d(K.conv3d(g8, c1, D), c2, D)
+    g = torch.randn(out.shape, device="cuda").to(torch.bfloat16)
+    out.backward(g)
+    r1, r2 = copy.deepcopy(c1), copy.deepcopy(c2)
+    for r in (r1, r2):
+        r.weight.grad = r.bias.grad = None
+        with torch.no_grad():
+            r.weight.copy_(r.weight.to(torch.bfloat16).float())
+    h1 = F.relu(r1(grid[:, None]))
+    h1b = h1.to(torch.bfloat16).float()
+    y = F.relu(r2(h1b.detach().requires_grad_(True)))
+    assert rel(out, y.permute(0, 2, 3, 4, 1).reshape(B, -1, 16)) < 2 ** -7
+    h1l = h1b.detach().requires_grad_(True)
+    y2 = F.relu(r2(h1l))
+    y2.backward(g.float().reshape(B, D, D, D, 16).permute(0, 4, 1, 2, 3))
+    grad_close(c2.weight.grad, r2.weight.grad)
+    grad_close(c2.bias.grad, r2.bias.grad)
+    h1.backward((h1l.grad * (h1b > 0)).to(torch.bfloat16).float())
+    grad_close(c1.weight.grad, r1.weight.grad)
+    grad_close(c1.bias.grad, r1.bias.grad)
