@@ -4,16 +4,18 @@
 // (K7: one thread per (point, kernel offset); float atomicMin on a global grid, then
 // a racy atomicExch of the candidate id), :105-166 (K8), :181-213 (weights).
 //
-// MI355X design: a workgroup owns a tile of the voxel grid in LDS as two 32-bit words per
-// voxel (distance bits, candidate id).  Distances are >= 0, so unsigned integer order ==
-// float order: pass 0 takes a 32-bit atomicMin of the distance bits, pass 1 a 32-bit
-// atomicMin of the flat id among the candidates that equal the minimum -- exact minimum AND
-// deterministic arg-min (lowest flat id among equal distances); the reference's
-// atomicMin + atomicExch pair can record a non-minimal writer.  (A packed 64-bit key with one
-// ds_min_u64 was the first version: 64-bit LDS atomics measured ~10x slower than 32-bit ones.)
-// Tiles are x-slabs (optionally split in y) of <= 64 KB, so two workgroups share a CU's 160 KB
-// LDS; every workgroup streams the whole point list (12 B/point, L2-resident) and keeps only
-// candidates that land in its tile.  No global atomics, no pre-filled global grids, one
+// MI355X design (round 4): a workgroup owns ONE x-plane x a y-range of the voxel grid in LDS as two 32-bit words
+// per voxel (distance bits, candidate id).  Distances are >= 0, so unsigned integer order == float order: pass 0
+// takes a 32-bit atomicMin of the distance bits, pass 1 a 32-bit atomicMin of the flat id among the candidates that
+// equal the minimum -- exact minimum AND deterministic arg-min (lowest flat id among equal distances); the
+// reference's atomicMin + atomicExch pair can record a non-minimal writer.  (A packed 64-bit key with one ds_min_u64
+// was the first version: 64-bit LDS atomics measured ~10x slower than 32-bit ones.)
+// Every workgroup streams the whole point list (12 B/point, L2-resident) and keeps the points whose kernel
+// neighbourhood meets its plane: 3 of 32 planes for the default kernel size, i.e. ~10 % of the points reach the
+// candidate loop, and only with the ONE kernel offset b that lands on the plane.  Round 1-3 used 8 x-slabs of 4
+// planes (8 workgroups on a 256-CU chip, each lane walking ~12 points x 27 candidates twice: measured 148 us for
+// 3000 points into 32^3); plane x y-range tiles give 128-256 workgroups whose lanes see ~1 in-range point per pass.
+// Same float expressions in the same order -> the same bits.  No global atomics, no pre-filled global grids, one
 // coalesced write.
 #include <algorithm>
 
@@ -31,75 +33,109 @@ __device__ __forceinline__ int tdf_ksize(float pitch, float trunc) {
 namespace {
 
 constexpr int kTdfThreads = 256;
+constexpr int kTdfChunk = 4096;  // points per filter round = capacity of the in-range list (64 KB of LDS)
 
 // Kernel offsets follow numpy.meshgrid's default 'xy' indexing used at
 // truncated_distance_function.py:39-41: flat k = (a*ks + b)*ks + c  ->  (b, a, c) - ks/2.
+//
+// Two phases per chunk of 4096 points.  FILTER: a lane takes 16 points (all loads issued before the first use),
+// one divide + round decides whether the point's kernel neighbourhood meets this x-plane (3 planes of 32 for the
+// default kernel), the survivors' other two coordinates decide the y-range; survivors go to an LDS list
+// {fx, fy, fz, point id} -- ~50 of 3000 points for a 4-row tile.  SCAN: the lanes run over (list entry, a, c)
+// triples, i.e. over the CANDIDATE voxels (b is fixed by the plane), so the work is balanced whatever the points'
+// order and the code is a short rolled loop (round 4, second version: 16 points x 9 candidates x 2 passes fully
+// unrolled per lane -- a 90 KB instruction stream, 47 us).
 template <int KS>
 __global__ __launch_bounds__(kTdfThreads) void k_tdf_fwd(const float *__restrict__ points,
                                                          int64_t P, float pitch, float ox,
                                                          float oy, float oz, int X, int Y, int Z,
-                                                         float trunc, int ks_rt, int SX, int SY,
+                                                         float trunc, int ks_rt, int SY,
                                                          float *__restrict__ tdf,
                                                          int32_t *__restrict__ flat) {
-  MF_DYN_LDS(uint32_t, s_w);  // dist bits [nvox], id [nvox]
+  MF_DYN_LDS(uint32_t, s_w);  // dist bits [SY * Z], id [SY * Z], list [kTdfChunk] x float4
+  __shared__ int s_n;
   const int ks = KS > 0 ? KS : ks_rt;
   const int h = ks / 2, K = ks * ks * ks;
-  const int x0 = blockIdx.x * SX, y0 = blockIdx.y * SY;
-  const int sx = min(SX, X - x0), sy = min(SY, Y - y0);
-  const int nvox = sx * sy * Z;
-  uint32_t *s_dist = s_w, *s_id = s_w + SX * SY * Z;
+  const int x0 = blockIdx.x, y0 = blockIdx.y * SY;
+  const int sy = min(SY, Y - y0);
+  const int nvox = sy * Z;
+  uint32_t *s_dist = s_w, *s_id = s_w + SY * Z;
+  float4 *s_list = reinterpret_cast<float4 *>(s_w + 2 * ((SY * Z + 3) & ~3));
   const uint32_t tbits = __float_as_uint(trunc);
   for (int i = threadIdx.x; i < nvox; i += kTdfThreads) { s_dist[i] = tbits; s_id[i] = 0xffffffffu; }
-  __syncthreads();
   const float fh = (float)h;
+  auto filter = [&](int64_t base) {
+    constexpr int R = kTdfChunk / kTdfThreads;
+    float px[R], py[R], pz[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t p = base + (int64_t)r * kTdfThreads + threadIdx.x;
+      const int64_t q = p < P ? p : 0;
+      px[r] = p < P ? points[3 * q] : __uint_as_float(0x7fc00000u);
+      py[r] = points[3 * q + 1];
+      pz[r] = points[3 * q + 2];
+    }
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+      const float fx = (px[r] - ox) / pitch;
+      const float rx = roundf(fx);
+      if (!(rx + fh >= (float)x0 && rx - fh < (float)(x0 + 1))) continue;  // (false for NaN)
+      const float fy = (py[r] - oy) / pitch, fz = (pz[r] - oz) / pitch;
+      const float ry = roundf(fy), rz = roundf(fz);
+      if (!(ry + fh >= (float)y0 && ry - fh < (float)(y0 + sy) && rz + fh >= 0.0f && rz - fh < (float)Z)) continue;
+      const int slot = atomicAdd(&s_n, 1);  // < kTdfChunk: a chunk holds that many points
+      s_list[slot] = make_float4(fx, fy, fz, __int_as_float((int)(r * kTdfThreads + threadIdx.x)));
+    }
+  };
   // pass 0: minimum distance per voxel (32-bit atomicMin on the float bits; distances >= 0);
   // pass 1: lowest flat id among the candidates whose distance equals that minimum.
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int64_t p = threadIdx.x; p < P; p += kTdfThreads) {
-      const float fx = (points[3 * p] - ox) / pitch;
-      const float fy = (points[3 * p + 1] - oy) / pitch;
-      const float fz = (points[3 * p + 2] - oz) / pitch;
-      const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
-      // neighbourhood vs tile (false for NaN)
-      if (!(rx + fh >= (float)x0 && rx - fh < (float)(x0 + sx) && ry + fh >= (float)y0 &&
-            ry - fh < (float)(y0 + sy) && rz + fh >= 0.0f && rz - fh < (float)Z))
-        continue;
-      const int irx = (int)rx, iry = (int)ry, irz = (int)rz;
-#pragma unroll
-      for (int a = 0; a < ks; ++a) {
-        const int iy = iry + a - h;
-        if (iy < y0 || iy >= y0 + sy) continue;
-        const float dy = fy - (float)iy;
-#pragma unroll
-        for (int b = 0; b < ks; ++b) {
-          const int ix = irx + b - h;
-          if (ix < x0 || ix >= x0 + sx) continue;
-          const float dx = fx - (float)ix;
-          const float dxy = dx * dx + dy * dy;
-#pragma unroll
-          for (int c = 0; c < ks; ++c) {
-            const int iz = irz + c - h;
-            if (iz < 0 || iz >= Z) continue;
-            const float dz = fz - (float)iz;
-            const float dist = pitch * sqrtf(dxy + dz * dz);
-            if (dist < trunc) {
-              const int li = ((ix - x0) * sy + (iy - y0)) * Z + iz;
-              const uint32_t db = __float_as_uint(dist);
-              if (pass == 0) {
-                if (db < s_dist[li]) atomicMin(&s_dist[li], db);
-              } else if (db == s_dist[li]) {
-                atomicMin(&s_id[li], (uint32_t)(p * K + (a * ks + b) * ks + c));
-              }
-            }
-          }
+  auto scan = [&](int pass, int64_t base) {
+    const int n = s_n * ks * ks;
+    for (int w = threadIdx.x; w < n; w += kTdfThreads) {
+      const int e = w / (ks * ks), ac = w - e * ks * ks;
+      const int a = ac / ks, c = ac - a * ks;
+      const float4 rec = s_list[e];
+      const int irx = (int)roundf(rec.x), iry = (int)roundf(rec.y), irz = (int)roundf(rec.z);
+      const int b = x0 - irx + h;  // the one x offset of the kernel that lands on this plane: 0 <= b < ks
+      const int iy = iry + a - h, iz = irz + c - h;
+      if (iy < y0 || iy >= y0 + sy || iz < 0 || iz >= Z) continue;
+      const float dx = rec.x - (float)x0, dy = rec.y - (float)iy, dz = rec.z - (float)iz;
+      const float dxy = dx * dx + dy * dy;
+      const float dist = pitch * sqrtf(dxy + dz * dz);
+      if (dist < trunc) {
+        const int li = (iy - y0) * Z + iz;
+        const uint32_t db = __float_as_uint(dist);
+        if (pass == 0) {
+          if (db < s_dist[li]) atomicMin(&s_dist[li], db);
+        } else if (db == s_dist[li]) {
+          const int64_t p = base + __float_as_int(rec.w);
+          atomicMin(&s_id[li], (uint32_t)(p * K + (a * ks + b) * ks + c));
         }
       }
     }
+  };
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  if (P <= kTdfChunk) {  // the usual case: one filter round serves both passes
+    if (P > 0) filter(0);  // (an empty point list may come with a null pointer)
     __syncthreads();
+    scan(0, 0);
+    __syncthreads();
+    scan(1, 0);
+  } else {
+    for (int pass = 0; pass < 2; ++pass)
+      for (int64_t base = 0; base < P; base += kTdfChunk) {
+        filter(base);
+        __syncthreads();
+        scan(pass, base);
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+      }
   }
+  __syncthreads();
   for (int i = threadIdx.x; i < nvox; i += kTdfThreads) {
-    const int iz = i % Z, iy = (i / Z) % sy, ix = i / (Z * sy);
-    const int64_t g = ((int64_t)(x0 + ix) * Y + (y0 + iy)) * Z + iz;
+    const int64_t g = ((int64_t)x0 * Y + y0) * Z + i;  // (iy - y0) * Z + iz == i: the tile is contiguous in the grid
     tdf[g] = __uint_as_float(s_dist[i]);
     const uint32_t lo = s_id[i];
     flat[g] = lo == 0xffffffffu ? -1 : (int32_t)lo;
@@ -185,30 +221,23 @@ extern "C" int mf_truncated_distance_function_fwd(const float *points, int64_t P
     mf::set_last_error(hipErrorInvalidValue, "tdf: P*K exceeds 32-bit candidate ids");
     return -(int)hipErrorInvalidValue;
   }
-  // tile: <= 8192 voxels (64 KB of keys); split x first, then y.
-  const int cap = 8192;
-  int SX, SY;
+  // tile = one x-plane x SY rows: <= 4096 voxels (32 KB of keys + the 64 KB list), split further until ~256 workgroups exist
+  const int cap = 4096;
   if (Z > cap) {
     mf::set_last_error(hipErrorInvalidValue, "tdf: Z dimension too large for an LDS tile");
     return -(int)hipErrorInvalidValue;
   }
-  if ((int64_t)Y * Z <= cap) {
-    SY = Y;
-    SX = std::max(1, std::min(X, cap / (Y * Z)));
-    // keep at least ~8 workgroups when the grid allows it
-    while (SX > 1 && (X + SX - 1) / SX < 8) SX = (SX + 1) / 2;
-  } else {
-    SX = 1;
-    SY = std::max(1, cap / Z);
-  }
-  dim3 grid((X + SX - 1) / SX, (Y + SY - 1) / SY);
-  const size_t lds = (size_t)SX * SY * Z * 2 * sizeof(uint32_t);
+  int SY = std::max(1, std::min(Y, cap / Z));
+  while (SY > 4 && (int64_t)X * ((Y + SY - 1) / SY) < 256) SY = (SY + 1) / 2;
+  dim3 grid(X, (Y + SY - 1) / SY);
+  const size_t lds = (size_t)((SY * Z + 3) & ~3) * 2 * sizeof(uint32_t) + (size_t)kTdfChunk * 16;
+  if (int e = mf::allow_big_lds(ks == 3 ? (const void *)k_tdf_fwd<3> : (const void *)k_tdf_fwd<0>, (int)lds)) return e;
   if (ks == 3)
     hipLaunchKernelGGL(k_tdf_fwd<3>, grid, dim3(kTdfThreads), lds, stream, points, P, pitch, ox,
-                       oy, oz, X, Y, Z, truncation, ks, SX, SY, tdf, flat);
+                       oy, oz, X, Y, Z, truncation, ks, SY, tdf, flat);
   else
     hipLaunchKernelGGL(k_tdf_fwd<0>, grid, dim3(kTdfThreads), lds, stream, points, P, pitch, ox,
-                       oy, oz, X, Y, Z, truncation, ks, SX, SY, tdf, flat);
+                       oy, oz, X, Y, Z, truncation, ks, SY, tdf, flat);
   return mf::check_launch("mf_truncated_distance_function_fwd");
 }
 

@@ -310,6 +310,30 @@ def test_tdf_kernel_sources_vs_reference_cuda_text(tag):
     np.testing.assert_allclose(gp, c["gpoints"], rtol=2e-5, atol=2e-6)
 
 
+def test_tdf_kernel_with_more_points_than_one_register_chunk():
+    """tdf.hip keeps 16 points per lane in registers: above 4096 points it walks the list in chunks, once per pass.
+    6000 points (two chunks, the second ragged) incl. NaN rows, exact duplicates (arg-min ties -> lowest id) and
+    points outside the grid, vs the C oracle: distances and winner ids bit-exact."""
+    from oracle import oracle_c as OC
+    lib = emul.build(["tdf.hip"])
+    i64, f, ci = ctypes.c_int64, ctypes.c_float, ctypes.c_int
+    lib.mf_truncated_distance_function_fwd.argtypes = [_p, i64, f, f, f, f, ci, ci, ci, f, _p, _p, _p]
+    rs = np.random.RandomState(5)
+    dims, pitch, origin = (16, 12, 20), 0.01, (-0.08, -0.06, -0.1)
+    pts = rs.uniform(-0.1, 0.12, (6000, 3)).astype(np.float32)
+    pts[100] = np.nan
+    pts[4500:4600] = pts[200:300]          # duplicates across the chunk boundary: the lower id must win
+    trunc = float(np.float32(2) * np.float32(pitch))
+    tdf = np.zeros(dims, np.float32)
+    flat = np.zeros(dims, np.int32)
+    assert lib.mf_truncated_distance_function_fwd(pts.ctypes.data, len(pts), pitch, *origin, *dims, trunc,
+                                                  tdf.ctypes.data, flat.ctypes.data, None) == 0
+    want, want_idx = OC.truncated_distance_function(pts, pitch=pitch, origin=origin, dims=dims, truncation=trunc)
+    np.testing.assert_array_equal(tdf, want)
+    np.testing.assert_array_equal(flat, want_idx)
+    assert (flat >= 0).sum() > 1000
+
+
 def test_nn_and_interpolate_kernel_sources_vs_reference_cuda_text():
     """k_nn (occgrid_knn.hip) against the reference's RawKernel + argmin, and interp.hip forward /
     backward against its K5 / K6 text (tests/golden/ref_cuda_nn.npz, ref_cuda_interpolate.npz)."""
