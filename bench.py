@@ -274,12 +274,12 @@ def roofline_voxelize(wl):
     # HBM bytes per call from the PMC passes committed under profiles/ (separate rocprofv3
     # --pmc FETCH_SIZE / WRITE_SIZE runs of tools/prof_voxelize.py at this exact shape)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r03_voxelize_pmc.json")  # this round's kernels only
+    pmc = os.path.join(ROOT, "profiles", "r04_voxelize_pmc.json")  # this round's kernels (fill kernel + link + scatter)
     if os.path.exists(pmc):
         rec = json.load(open(pmc))
         if rec["shape"] == dict(B=B, P=P, C=C, D=D):
             traffic = rec["traffic_bytes"]
-    return dict(kernel="mf_average_voxelization_3d_fwd (memset fill + k_avgvox_link + k_avgvox_scatter)",
+    return dict(kernel="mf_average_voxelization_3d_fwd (k_fill_words + k_avgvox_link + k_avgvox_scatter)",
                 bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                 algorithmic_bytes_per_launch=alg, avg_launch_ms=round(ms, 5),
@@ -329,6 +329,39 @@ def icc_many_scenes(wl, n_scenes=8):
                 workspace_mb=round(icc.ws.numel() / 1e6, 1))
 
 
+def icc_issue_model(kname, icc, us_live):
+    """A ceiling that is not HBM: what the kernel would take if only INSTRUCTION ISSUE and the LDS pipe limited it,
+    from rocprofv3 --pmc passes of the same launches (profiles/r04_icc_issue_pmc.json: SQ_INSTS_* / SQ_WAVES /
+    SQ_LDS_* / SQ_WAVE_CYCLES per launch, 1 scene x 8 objects).
+      valu_floor_us      wave-level VALU instructions / 1024 SIMDs x 4 cycles (a wave64 VALU op occupies its SIMD
+                         for 4 cycles) at 2.4 GHz -- perfect balance over every SIMD of the chip
+      lds_floor_us       SQ_LDS_IDX_ACTIVE + SQ_LDS_BANK_CONFLICT cycles / 256 CUs
+      latency_chain_us   the dependent global round trips on a workgroup's critical path (bin counts -> records ->
+                         winner gathers: 3 x ~0.8 us, MI355X_MICROARCH.md) + one kernel boundary (1.45 us)
+      floor_us           max(valu, lds) + latency chain: nothing overlaps the chain, issue overlaps perfectly
+    ``frac_of_floor`` = floor / measured: how far the kernel is from that (unreachable) bound."""
+    path = os.path.join(ROOT, "profiles", "r04_icc_issue_pmc.json")
+    if not os.path.exists(path):
+        return None
+    rec = next((v for k, v in json.load(open(path)).items() if k.startswith(kname + " ")), None)
+    if rec is None or icc.n_objects != 8:
+        return None
+    ghz = 2.4
+    valu = rec["SQ_INSTS_VALU"] / 1024 * 4 / (ghz * 1e3)
+    lds = (rec["SQ_LDS_IDX_ACTIVE"] + rec["SQ_LDS_BANK_CONFLICT"]) / 256 / (ghz * 1e3)
+    chain = 3 * 0.8 + 1.45
+    floor = max(valu, lds) + chain
+    waves = rec["SQ_WAVES"]
+    return dict(source="profiles/r04_icc_issue_pmc.json", waves=int(waves),
+                insts_per_wave=dict(valu=round(rec["SQ_INSTS_VALU"] / waves, 1), salu=round(rec["SQ_INSTS_SALU"] / waves, 1),
+                                    lds=round(rec["SQ_INSTS_LDS"] / waves, 1), vmem_rd=round(rec["SQ_INSTS_VMEM_RD"] / waves, 1)),
+                wave_lifetime_us=round(rec["SQ_WAVE_CYCLES"] * 4 / waves / (ghz * 1e3), 2),
+                wait_frac_of_wave_cycles=round(rec["SQ_WAIT_INST_ANY"] / rec["SQ_WAVE_CYCLES"], 3),
+                valu_floor_us=round(valu, 2), lds_floor_us=round(lds, 2), latency_chain_us=round(chain, 2),
+                floor_us=round(floor, 2), measured_us=round(us_live, 2), frac_of_floor=round(floor / us_live, 3),
+                us_under_pmc=rec.get("avg_duration_us_under_pmc"))
+
+
 def roofline_icc(wl, us_per_iter):
     """k_icc_fused (k_icc_tile on the two-kernel path of non-{0,1} no-entry grids) -- the hand-written
     kernel with the largest share of the step (100 launches per refinement), timed live with HIP
@@ -358,11 +391,14 @@ def roofline_icc(wl, us_per_iter):
     kname = "k_icc_fused" if single_pass else "k_icc_tile"
     achieved = alg / (ms * 1e-3) / 1e9
     traffic = None  # PMC passes of THIS round committed under profiles/ (tools/gpu_call.sh pmc=...), same scene; else null
-    pmc = os.path.join(ROOT, "profiles", "r03_icc_pmc.json")  # this round's kernels only
-    if os.path.exists(pmc):
-        rec = json.load(open(pmc)).get(kname)
-        if rec and rec["n_objects"] == icc.n_objects and rec["n_points"] == icc.n_points:
-            traffic = rec["traffic_bytes"]
+    for name in ("r04_icc_pmc.json", "r03_icc_pmc.json"):  # newest PMC passes of these kernels, same scene
+        pmc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc):
+            rec = json.load(open(pmc)).get(kname)
+            if rec and rec["n_objects"] == icc.n_objects and rec["n_points"] == icc.n_points:
+                traffic = rec["traffic_bytes"]
+                break
+    issue = icc_issue_model(kname, icc, ms * 1e3)
     it_bytes = 2 * (pts_bytes + grid_bytes)
     it_achieved = it_bytes / (us_per_iter * 1e-6) / 1e9
     many = icc_many_scenes(wl)
@@ -371,6 +407,9 @@ def roofline_icc(wl, us_per_iter):
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                 algorithmic_bytes_per_launch=alg, avg_launch_ms=round(ms, 5),
+                clock="avg_launch_ms / us: live HIP events at un-profiled clocks; traffic and issue_model counters: "
+                      "rocprofv3 --pmc passes (the same launches run ~10-15 % longer under the profiler)",
+                issue_model=issue,
                 iteration=dict(kernels="k_icc_bin (+ folded optimiser step) + " +
                                        ("k_icc_fused" if single_pass else "k_icc_tile + k_icc_accum"),
                                algorithmic_bytes=it_bytes, us=round(us_per_iter, 3),
@@ -503,6 +542,45 @@ def roofline_conv4(wl, B):
                 flop_per_launch=flop,
                 avg_launch_ms=round(ms, 5), shape=dict(B=B, Cin=256, Cout=512, D=16),
                 split_k=mf._lib.lib().mf_conv3d_k4s2_default_split(B, 256, 512, 16))
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+
+
+def roofline_bf16_kernels(wl, B=16):
+    """The bf16 MFMA kernels of csrc/gemm_bf16.hip (BASELINE config 5's 3-D CNN: forward, data and weight gradients
+    of conv3 160 -> 256 on 32^3 and conv4 256 -> 512 on 16^3, at the per-GPU training batch of 16 objects), timed live
+    with HIP events; TFLOP/s against the dense bf16 MFMA peak."""
+    L, st, p = mf._lib.lib(), mf._lib.stream_ptr, (lambda t: t.data_ptr())
+    dev, bf = wl.device, torch.bfloat16
+    out = {}
+    for name, Cin, Cout, D in (("conv3", 160, 256, 32), ("conv4", 256, 512, 16)):
+        Do = D // 2
+        flop = 2.0 * B * Do ** 3 * Cout * 64 * Cin
+        x = torch.randn(B, D ** 3, Cin, device=dev).to(bf)
+        dy = torch.randn(B, Do ** 3, Cout, device=dev).to(bf)
+        W = torch.randn(Cout, Cin, 4, 4, 4, device=dev) / (64 * Cin) ** 0.5
+        wt = torch.empty(Cout, 64, Cin, dtype=bf, device=dev)
+        wd = torch.empty(8, Cin, 8, Cout, dtype=bf, device=dev)
+        L.mf_conv3d_k4s2_pack_bf16(p(W), Cout, Cin, Cin, 0, p(wt), p(wd), st())
+        y = torch.empty(B, Do ** 3, Cout, dtype=bf, device=dev)
+        dx = torch.empty(B, D ** 3, Cin, dtype=bf, device=dev)
+        dW = torch.empty_like(W)
+        split = L.mf_conv3d_k4s2_bf16_wgrad_default_split(B, Cin, Cout, D)
+        ws = torch.empty(L.mf_conv3d_k4s2_bf16_wgrad_workspace_bytes(Cin, Cout, split), dtype=torch.uint8, device=dev)
+        runs = dict(
+            fwd=lambda: L.mf_conv3d_k4s2_bf16_fwd(p(x), p(wt), None, p(y), B, Cin, Cout, D, 1, 0, st()),
+            dgrad=lambda: L.mf_conv3d_k4s2_bf16_dgrad(p(dy), p(wd), p(dx), B, Cin, Cout, D, 0, 0, st()),
+            wgrad=lambda: L.mf_conv3d_k4s2_bf16_wgrad(p(dy), p(x), p(dW), p(ws), B, Cin, Cout, D, Cin, 0, split, st()))
+        for kind, fn in runs.items():
+            ms = time_kernel_live(fn, 10)
+            tf = flop / (ms * 1e-3) / 1e12
+            out[f"{name}_{kind}"] = dict(kernel={"fwd": "k_gemm_nt_bf16<conv forward>", "dgrad": "k_gemm_nt_bf16<conv dgrad>",
+                                                 "wgrad": "k_gemm_tn_bf16 (+ k_wgrad_finish)"}[kind], bound="mfma",
+                                         achieved=round(tf, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                                         frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), flop_per_launch=flop,
+                                         avg_launch_ms=round(ms, 5), shape=dict(B=B, Cin=Cin, Cout=Cout, D=D))
+    return out
 
 
 def accuracy(wl):
@@ -726,6 +804,7 @@ def main():
         out["roofline_conv4_batch1"] = roofline_conv4(wl, 1)
         out["roofline"] = roofline_icc(wl, t_icc * 1e3 / args.icc_iters)  # all scenes share the launches
         out["roofline_voxelize"] = roofline_voxelize(wl)
+        out["roofline_bf16_kernels"] = roofline_bf16_kernels(wl)
         out["accuracy"] = accuracy(wl)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args)

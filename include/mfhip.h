@@ -409,6 +409,28 @@ int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, void *ws, int
                          int32_t D, int32_t ks, int32_t stride, int32_t pad, int32_t dil, int32_t w_cin, int32_t c_off,
                          int32_t split, mfStream_t stream);
 
+/* Channels-last bf16 voxelization and trilinear sampling of the bf16 training path (K1/K2 and K5/K6 of SURVEY 2.1 --
+ * functions/geometry/average_voxelization_3d.py:8-113, interpolate_voxel_grid.py:61-215 -- on the layout the bf16
+ * convolutions consume; origin 0, pitch 1, cubic grids, as contrib/singleview_3d/models/model.py:113,131,141 call them):
+ *   mf_average_voxelization_cl_bf16_fwd  values bf16 [n, ldv] -> x bf16 [B, D^3, ldx] columns [0, C): voxel means
+ *     (fp32 sum in increasing point index), zeros elsewhere; counts / head [B*D^3], link [n]: int32 scratch
+ *   mf_average_voxelization_cl_bf16_bwd  gvalues[p] = gx[b, voxel(p)] / count
+ *   mf_interpolate_voxel_grid_cl_bf16_fwd / _bwd   vox bf16 [B, X*Y*Z, C] <-> rows bf16 [n, ld]; the backward
+ *     accumulates fp32 into a zero-filled gvox [B, X*Y*Z, C] */
+int mf_average_voxelization_cl_bf16_fwd(const void *values, int64_t ldv, const float *points,
+                                        const int32_t *batch_indices, int64_t n, int32_t C, int32_t B, int32_t D,
+                                        void *x, int64_t ldx, int32_t *counts, int32_t *head, int32_t *link,
+                                        mfStream_t stream);
+int mf_average_voxelization_cl_bf16_bwd(const void *gx, int64_t ldx, const float *points, const int32_t *batch_indices,
+                                        const int32_t *counts, int64_t n, int32_t C, int32_t B, int32_t D,
+                                        void *gvalues, int64_t ldg, mfStream_t stream);
+int mf_interpolate_voxel_grid_cl_bf16_fwd(const void *vox, const float *points, const int32_t *batch_indices,
+                                          int64_t n, int B, int C, int X, int Y, int Z, void *out, int64_t ldo,
+                                          mfStream_t stream);
+int mf_interpolate_voxel_grid_cl_bf16_bwd(const void *gout, int64_t ldg, const float *points,
+                                          const int32_t *batch_indices, int64_t n, int B, int C, int X, int Y, int Z,
+                                          float *gvox, mfStream_t stream);
+
 /* Point-wise prologue / epilogue of the volumetric part (inference), one launch each instead of ~25 torch launches:
  *   mf_point_prep: camera-frame points [B,3,P] + image features [B,Cv,P] -> voxel-frame points [n,3]
  *     ((p - origin) / pitch, model.py:236), to_center [n,4] = (center - p | 0) (:101), feature rows [n,Cv],

@@ -198,3 +198,79 @@ def conv3d_k4s2(x_cl, conv, D, relu=True, c_off=0):
 def linear(x_rows, conv, relu=True):
     """``conv``: torch.nn.Conv1d(K, N, 1) (or nn.Linear) applied to point rows."""
     return Linear.apply(x_rows, conv.weight, conv.bias, relu)
+
+
+class AverageVoxelizationCL(torch.autograd.Function):
+    """``average_voxelization_3d`` (origin 0, pitch 1, grid D^3) of bf16 point rows straight into the channels-last
+    bf16 conv3 input: values [n, C] -> x [B, D^3, ldx] with columns [0, C) filled (columns [C, ldx) are the caller's:
+    conv3's occupancy channels).  Reference: functions/geometry/average_voxelization_3d.py:8-113 as called at
+    contrib/singleview_3d/models/model.py:113."""
+
+    @staticmethod
+    def forward(ctx, values, points, batch_indices, B, D, ldx):
+        _lib.require_gpu(values, points, batch_indices)
+        L = _lib.lib()
+        values = _bf16c(values)
+        n, C = values.shape
+        pts, bi = _lib.f32c(points), _lib.i32c(batch_indices)
+        V = D ** 3
+        x = _empty((B, V, ldx), BF16, values)
+        counts = _empty((B * V,), torch.int32, values)
+        head = _empty((B * V,), torch.int32, values)
+        link = _empty((max(n, 1),), torch.int32, values)
+        _lib.check(L.mf_average_voxelization_cl_bf16_fwd(values.data_ptr(), C, pts.data_ptr(), bi.data_ptr(), n, C, B, D,
+                                                         x.data_ptr(), ldx, counts.data_ptr(), head.data_ptr(),
+                                                         link.data_ptr(), _lib.stream_ptr()),
+                   "mf_average_voxelization_cl_bf16_fwd")
+        ctx.save_for_backward(pts, bi, counts)
+        ctx.geom = (n, C, B, D, ldx)
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        pts, bi, counts = ctx.saved_tensors
+        n, C, B, D, ldx = ctx.geom
+        gx = _bf16c(gx)
+        gv = _empty((n, C), BF16, gx)
+        _lib.check(_lib.lib().mf_average_voxelization_cl_bf16_bwd(gx.data_ptr(), ldx, pts.data_ptr(), bi.data_ptr(),
+                                                                  counts.data_ptr(), n, C, B, D, gv.data_ptr(), C,
+                                                                  _lib.stream_ptr()),
+                   "mf_average_voxelization_cl_bf16_bwd")
+        return gv, None, None, None, None, None
+
+
+class InterpolateVoxelGridCL(torch.autograd.Function):
+    """``interpolate_voxel_grid`` on a channels-last bf16 grid: vox [B, X^3, C], points [n, 3] (voxel units),
+    batch_indices [n] -> rows [n, C] bf16.  Reference: functions/geometry/interpolate_voxel_grid.py:61-215 as called
+    at contrib/singleview_3d/models/model.py:131,141."""
+
+    @staticmethod
+    def forward(ctx, vox, points, batch_indices, X):
+        _lib.require_gpu(vox, points, batch_indices)
+        vox = _bf16c(vox)
+        B, V, C = vox.shape
+        assert V == X ** 3
+        pts, bi = _lib.f32c(points), _lib.i32c(batch_indices)
+        n = pts.shape[0]
+        out = _empty((n, C), BF16, vox)
+        _lib.check(_lib.lib().mf_interpolate_voxel_grid_cl_bf16_fwd(vox.data_ptr(), pts.data_ptr(), bi.data_ptr(), n, B,
+                                                                    C, X, X, X, out.data_ptr(), C, _lib.stream_ptr()),
+                   "mf_interpolate_voxel_grid_cl_bf16_fwd")
+        ctx.save_for_backward(pts, bi)
+        ctx.geom = (n, B, C, X)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pts, bi = ctx.saved_tensors
+        n, B, C, X = ctx.geom
+        L = _lib.lib()
+        g = _bf16c(g)
+        gv32 = _empty((B, X ** 3, C), torch.float32, g)
+        _lib.check(L.mf_interpolate_voxel_grid_cl_bf16_bwd(g.data_ptr(), C, pts.data_ptr(), bi.data_ptr(), n, B, C, X, X,
+                                                           X, gv32.data_ptr(), _lib.stream_ptr()),
+                   "mf_interpolate_voxel_grid_cl_bf16_bwd")
+        gv = _empty((B, X ** 3, C), BF16, g)
+        _lib.check(L.mf_cast_rows_bf16(gv32.data_ptr(), C, gv.data_ptr(), C, B * X ** 3, C, _lib.stream_ptr()),
+                   "mf_cast_rows_bf16")
+        return gv, None, None, None

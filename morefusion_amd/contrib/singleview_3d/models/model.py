@@ -372,8 +372,9 @@ class Model(nn.Module):
 
     def _pose_from_features_bf16(self, class_id, values, points, pitch, origin, grid_nontarget_empty):
         """``_pose_from_features`` under bf16 autocast, differentiable: points-major bf16 rows and channels-last
-        bf16 grids, conv3 / conv4 and all sixteen 1x1 convolutions on the bf16 MFMA kernels (forward, data and
-        weight gradients: bf16_ops.py); voxelization, trilinear sampling and the loss keep their fp32 HIP ops.
+        bf16 grids; conv3 / conv4, the occupancy convolutions and all sixteen 1x1 convolutions on the bf16 MFMA kernels,
+        voxelization and trilinear sampling on their channels-last bf16 kernels -- forward, data and weight gradients
+        (bf16_ops.py); the loss keeps its fp32 HIP op.
         values [B,32,P] image features, points [B,3,P] camera frame (model.py:93-164,232-275)."""
         from . import bf16_ops as K
         B, _, P = values.shape
@@ -382,19 +383,14 @@ class Model(nn.Module):
         pts = ((points.float() - origin[:, :, None]) / pitch[:, None, None]).transpose(1, 2).reshape(n, 3).contiguous()
         to_center = (D / 2.0 - 0.5) - pts
         batch_indices = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(P)
-        batch_start = torch.arange(B + 1, dtype=torch.int32, device=dev) * P
         x_rgb = values.transpose(1, 2).reshape(n, values.shape[1])
         h1_rgb = K.linear(x_rgb, self.conv1_rgb)
         h1_pcd = K.linear(to_center, self.conv1_pcd)
         h2_rgb = K.linear(h1_rgb, self.conv2_rgb)
         h2_pcd = K.linear(h1_pcd, self.conv2_pcd)
         feat2 = torch.cat((h2_rgb, h2_pcd), dim=1)                                    # [n,144] bf16
-        vox = functions_module.average_voxelization_3d(
-            feat2.float(), pts, batch_indices, batch_size=B, origin=(0, 0, 0), pitch=1.0, dimensions=(D,) * 3,
-            check_nan=False)                                                          # [B,144,D,D,D] fp32
         c3 = self.conv3.in_channels
-        x3 = torch.empty((B, D ** 3, c3), dtype=torch.bfloat16, device=dev)           # channels-last conv3 input
-        x3[:, :, :144] = vox.reshape(B, 144, D ** 3).transpose(1, 2)
+        x3 = K.AverageVoxelizationCL.apply(feat2, pts, batch_indices, B, D, c3)       # [B,D^3,160] bf16, cols 0:144
         if self._with_occupancy:
             g8 = torch.zeros((B, D ** 3, 8), dtype=torch.bfloat16, device=dev)        # 1 channel + 7 zeros (16 B / voxel)
             g8[:, :, 0] = grid_nontarget_empty.reshape(B, D ** 3)
@@ -402,16 +398,10 @@ class Model(nn.Module):
             x3[:, :, 144:] = h_occ
         h3 = K.conv3d_k4s2(x3, self.conv3, D)                                         # [B,16^3,256] bf16
         Dh = D // 2
-        feat3 = functions_module.interpolate_voxel_grid(
-            h3.reshape(B, Dh, Dh, Dh, 256).permute(0, 4, 1, 2, 3).float(), pts / 2.0, batch_indices,
-            batch_start=batch_start)                                                  # [n,256] fp32
+        feat3 = K.InterpolateVoxelGridCL.apply(h3, pts / 2.0, batch_indices, Dh)      # [n,256] bf16
         h4 = K.conv3d_k4s2(h3, self.conv4, Dh)                                        # [B,8^3,512] bf16
-        Dq = D // 4
-        feat4 = functions_module.interpolate_voxel_grid(
-            h4.reshape(B, Dq, Dq, Dq, 512).permute(0, 4, 1, 2, 3).float(), pts / 4.0, batch_indices,
-            batch_start=batch_start)                                                  # [n,512] fp32
-        bf = torch.bfloat16
-        feat = torch.cat((h1_rgb, h1_pcd, h2_rgb, h2_pcd, feat3.to(bf), feat4.to(bf)), dim=1)  # [n,984]
+        feat4 = K.InterpolateVoxelGridCL.apply(h4, pts / 4.0, batch_indices, D // 4)  # [n,512] bf16
+        feat = torch.cat((h1_rgb, h1_pcd, h2_rgb, h2_pcd, feat3, feat4), dim=1)       # [n,984] bf16
         names = ("rot", "trans", "conf")
         w1 = torch.cat([getattr(self, f"conv1_{k}").weight for k in names])           # one GEMM for the 3 heads
         b1 = torch.cat([getattr(self, f"conv1_{k}").bias for k in names])

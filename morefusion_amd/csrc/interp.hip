@@ -439,6 +439,80 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_fwd_cl(
   }
 }
 
+
+// ---- channels-last bf16 sampler, forward and backward (round 4: the bf16 training path) ------------------------
+// vox bf16 [B][V][C] -> out bf16 rows [n][ldo]; one wave per point, a lane takes 8 channels (one 16-byte load per
+// corner), fp32 accumulation in the corner order of ``corners`` (the weights are interpolate_voxel_grid.py:27-58's).
+// Backward: the point's gradient row is scattered to its 8 corner rows with fp32 row atomics into a zero-filled
+// gvox fp32 [B][V][C] (a corner row is C contiguous floats: one coalesced atomic instruction per 64 channels).
+__global__ __launch_bounds__(kInterpThreads) void k_interp_cl_bf16_fwd(
+    const uint16_t *__restrict__ vox, const float *__restrict__ points, const int32_t *__restrict__ batch_indices,
+    int64_t n, int B, int C, int X, int Y, int Z, uint16_t *__restrict__ out, int64_t ldo) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t V = (int64_t)X * Y * Z;
+  const int64_t p0 = ((int64_t)blockIdx.x * (kInterpThreads / 64) + wave) * kClPointsPerWave;
+#pragma unroll
+  for (int u = 0; u < kClPointsPerWave; ++u) {
+    const int64_t p = p0 + u;
+    if (p >= n) break;  // wave-uniform
+    const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+    const int b = batch_indices[p];
+    const bool ok = b >= 0 && b < B && plausible(px, py, pz);
+    Corner k;
+    if (ok) corners(px, py, pz, X, Y, Z, k);
+    const uint16_t *grid = vox + (int64_t)(ok ? b : 0) * V * C;
+    for (int c = 8 * lane; c < C; c += 512) {
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok) {
+        uint4 g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          g[j] = *reinterpret_cast<const uint4 *>(grid + (int64_t)(k.off[j] < 0 ? 0 : k.off[j]) * C + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (k.off[j] < 0) continue;
+          const uint32_t w[4] = {g[j].x, g[j].y, g[j].z, g[j].w};
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            acc[2 * d] += k.w[j] * mf::bf16_lo(w[d]);
+            acc[2 * d + 1] += k.w[j] * mf::bf16_hi(w[d]);
+          }
+        }
+      }
+      *reinterpret_cast<uint4 *>(out + p * ldo + c) =
+          make_uint4(mf::pack_bf16x2(acc[0], acc[1]), mf::pack_bf16x2(acc[2], acc[3]), mf::pack_bf16x2(acc[4], acc[5]),
+                     mf::pack_bf16x2(acc[6], acc[7]));
+    }
+  }
+}
+
+__global__ __launch_bounds__(kInterpThreads) void k_interp_cl_bf16_bwd(
+    const uint16_t *__restrict__ gout, int64_t ldg, const float *__restrict__ points,
+    const int32_t *__restrict__ batch_indices, int64_t n, int B, int C, int X, int Y, int Z,
+    float *__restrict__ gvox) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t V = (int64_t)X * Y * Z;
+  const int64_t p = (int64_t)blockIdx.x * (kInterpThreads / 64) + wave;
+  if (p >= n) return;
+  const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+  const int b = batch_indices[p];
+  if (!(b >= 0 && b < B && plausible(px, py, pz))) return;
+  Corner k;
+  corners(px, py, pz, X, Y, Z, k);
+  float *grid = gvox + (int64_t)b * V * C;
+  for (int c = 2 * lane; c < C; c += 128) {  // two channels per lane: consecutive lanes -> consecutive addresses
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(gout + p * ldg + c);
+    const float g0 = mf::bf16_lo(w), g1 = mf::bf16_hi(w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (k.off[j] < 0) continue;
+      float *dst = grid + (int64_t)k.off[j] * C + c;
+      atomicAdd(dst, k.w[j] * g0);
+      atomicAdd(dst + 1, k.w[j] * g1);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int mf_interpolate_voxel_grid_fwd(const float *vox, const float *points,
@@ -517,4 +591,39 @@ extern "C" int mf_interpolate_voxel_grid_cl_fwd(const float *vox, const float *p
   hipLaunchKernelGGL(k_interp_fwd_cl, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kInterpThreads), 0,
                      stream, vox, points, batch_indices, n, B, C, X, Y, Z, out, ldo);
   return mf::check_launch("mf_interpolate_voxel_grid_cl_fwd");
+}
+
+/* Channels-last bf16 sampler of the training path: vox bf16 [B, X*Y*Z, C] -> out bf16 [n, ldo >= C] (C % 8 == 0,
+ * 16-byte aligned rows); backward: gout bf16 [n, ldg] -> gvox fp32 [B, X*Y*Z, C] (zero-filled here, fp32 atomics). */
+extern "C" int mf_interpolate_voxel_grid_cl_bf16_fwd(const void *vox, const float *points,
+                                                     const int32_t *batch_indices, int64_t n, int B, int C, int X,
+                                                     int Y, int Z, void *out, int64_t ldo, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n <= 0) return 0;
+  if (C % 8 || ldo % 8 || ldo < C || ((uintptr_t)out & 15) || ((uintptr_t)vox & 15)) {
+    mf::set_last_error(hipErrorInvalidValue, "interpolate_voxel_grid_cl_bf16: C % 8 == 0, ldo % 8 == 0, aligned");
+    return -(int)hipErrorInvalidValue;
+  }
+  const int64_t per_block = (kInterpThreads / 64) * kClPointsPerWave;
+  hipLaunchKernelGGL(k_interp_cl_bf16_fwd, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kInterpThreads), 0,
+                     stream, (const uint16_t *)vox, points, batch_indices, n, B, C, X, Y, Z, (uint16_t *)out, ldo);
+  return mf::check_launch("mf_interpolate_voxel_grid_cl_bf16_fwd");
+}
+
+extern "C" int mf_interpolate_voxel_grid_cl_bf16_bwd(const void *gout, int64_t ldg, const float *points,
+                                                     const int32_t *batch_indices, int64_t n, int B, int C, int X,
+                                                     int Y, int Z, float *gvox, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t V = (int64_t)X * Y * Z;
+  if ((int64_t)B * V * C == 0) return 0;
+  if (C % 2 || ldg % 2) {
+    mf::set_last_error(hipErrorInvalidValue, "interpolate_voxel_grid_cl_bf16 backward: even C and ldg");
+    return -(int)hipErrorInvalidValue;
+  }
+  if (int e_ = mf::fill_bytes(gvox, 0, sizeof(float) * B * V * C, stream)) return e_;
+  if (n > 0)
+    hipLaunchKernelGGL(k_interp_cl_bf16_bwd, dim3((unsigned)((n + kInterpThreads / 64 - 1) / (kInterpThreads / 64))),
+                       dim3(kInterpThreads), 0, stream, (const uint16_t *)gout, ldg, points, batch_indices, n, B, C, X,
+                       Y, Z, gvox);
+  return mf::check_launch("mf_interpolate_voxel_grid_cl_bf16_bwd");
 }

@@ -163,6 +163,112 @@ __global__ __launch_bounds__(256) void k_maxvox_bwd(const float *__restrict__ gm
   if (n >= 0) gvalues[(int64_t)n * C + c] = gmatrix[i];
 }
 
+
+// ---- channels-LAST bf16 average voxelization (round 4: the conv3 input of the bf16 training path) ------------
+// values rows [n][ldv] bf16 -> x [B][V][ldx] bf16, columns [0, C): the mean of the rows of a voxel's points (fp32
+// sum in increasing point index, divided, rounded to bf16), zeros elsewhere.  A voxel's C channels are one
+// contiguous row: the scatter is a coalesced row store per occupied voxel (the channels-first op writes C strided
+// planes and its result has to be transposed and cast for the channels-last convolution: 302 MB + 151 MB at B = 16).
+// Backward: every point reads its voxel's gradient row and divides by the voxel's count.
+__global__ __launch_bounds__(256) void k_avgvox_cl_fwd(const uint16_t *__restrict__ values, int64_t ldv,
+                                                       const float *__restrict__ points,
+                                                       const int32_t *__restrict__ batch_indices,
+                                                       const int32_t *__restrict__ counts,
+                                                       const int32_t *__restrict__ head,
+                                                       const int32_t *__restrict__ link, int64_t n, int C, int B, int D,
+                                                       uint16_t *__restrict__ x, int64_t ldx) {
+  __shared__ int s_ids[4][64];
+  __shared__ int s_sorted[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  int v;
+  bool has_nan;
+  const bool ok = mf::voxel_of(points, i, 0.0f, 0.0f, 0.0f, 1.0f, D, D, D, v, has_nan);
+  const int b = batch_indices[i];
+  if (!(ok && b >= 0 && b < B)) return;
+  const int64_t key = (int64_t)b * D * D * D + v;
+  if (head[key] != (int32_t)i) return;  // one wave per occupied voxel: its chain head's
+  const int cnt = counts[key];
+  uint16_t *dst = x + key * ldx;
+  const float inv = (float)cnt;
+  if (cnt <= 64) {
+    if (lane == 0) {
+      int m = (int)i;
+      for (int k = 0; k < cnt; ++k) { s_ids[wave][k] = m; m = link[m]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < cnt) {
+      const int mine = s_ids[wave][lane];
+      int rank = 0;
+      for (int k = 0; k < cnt; ++k) rank += s_ids[wave][k] < mine ? 1 : 0;
+      s_sorted[wave][rank] = mine;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int c2 = lane; 2 * c2 < C; c2 += 64) {  // two channels (one dword) per lane
+      float s0 = 0.0f, s1 = 0.0f;
+      for (int k = 0; k < cnt; ++k) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(values + (int64_t)s_sorted[wave][k] * ldv + 2 * c2);
+        s0 += mf::bf16_lo(w);
+        s1 += mf::bf16_hi(w);
+      }
+      *reinterpret_cast<uint32_t *>(dst + 2 * c2) = mf::pack_bf16x2(s0 / inv, s1 / inv);
+    }
+  } else {  // pathological pile-up in one voxel: repeated selection, still in index order
+    for (int c2 = lane; 2 * c2 < C; c2 += 64) {
+      float s0 = 0.0f, s1 = 0.0f;
+      int last = -1;
+      for (int k = 0; k < cnt; ++k) {
+        int best = 0x7fffffff;
+        for (int m = (int)i; m >= 0; m = link[m])
+          if (m > last && m < best) best = m;
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(values + (int64_t)best * ldv + 2 * c2);
+        s0 += mf::bf16_lo(w);
+        s1 += mf::bf16_hi(w);
+        last = best;
+      }
+      *reinterpret_cast<uint32_t *>(dst + 2 * c2) = mf::pack_bf16x2(s0 / inv, s1 / inv);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_avgvox_cl_bwd(const uint16_t *__restrict__ gx, int64_t ldx,
+                                                       const float *__restrict__ points,
+                                                       const int32_t *__restrict__ batch_indices,
+                                                       const int32_t *__restrict__ counts, int64_t n, int C, int B,
+                                                       int D, uint16_t *__restrict__ gvalues, int64_t ldg) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  int v;
+  bool has_nan;
+  const bool ok = mf::voxel_of(points, i, 0.0f, 0.0f, 0.0f, 1.0f, D, D, D, v, has_nan);
+  const int b = batch_indices[i];
+  const bool in = ok && b >= 0 && b < B;
+  const int64_t key = in ? (int64_t)b * D * D * D + v : 0;
+  const float cnt = in ? (float)counts[key] : 1.0f;
+  for (int c2 = lane; 2 * c2 < C; c2 += 64) {
+    uint32_t w = 0u;
+    if (in) {
+      const uint32_t g = *reinterpret_cast<const uint32_t *>(gx + key * ldx + 2 * c2);
+      w = mf::pack_bf16x2(mf::bf16_lo(g) / cnt, mf::bf16_hi(g) / cnt);
+    }
+    *reinterpret_cast<uint32_t *>(gvalues + i * ldg + 2 * c2) = w;
+  }
+}
+
+
+__global__ __launch_bounds__(256) void k_zero_cols_bf16(uint16_t *__restrict__ x, int64_t ldx, int64_t rows, int c2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * c2) return;
+  const int64_t r = i / c2;
+  *reinterpret_cast<uint32_t *>(x + r * ldx + 2 * (i - r * c2)) = 0u;
+}
+
 // channels per workgroup: enough workgroups to cover 256 CUs several times, but
 // keep >= 2 channels so the per-thread count/head loads amortise.
 int pick_cpw(int C, int B, int tiles) {
@@ -210,6 +316,51 @@ extern "C" int mf_average_voxelization_3d_bwd(const float *gmatrix, const float 
                      gmatrix, points, batch_indices, counts, n, C, B, X, Y, Z, ox, oy, oz, pitch,
                      gvalues);
   return mf::check_launch("mf_average_voxelization_3d_bwd");
+}
+
+
+/* Channels-last bf16 average voxelization of the pose network's point features (origin 0, pitch 1, cubic grid of D):
+ * values bf16 [n, ldv >= C], points fp32 [n,3], batch_indices [n] -> x bf16 [B, D^3, ldx >= C] columns [0, C)
+ * (zero where no point falls; columns >= C are left untouched) + counts / head [B*D^3], link [n] (int32 scratch the
+ * backward reuses).  C even. */
+extern "C" int mf_average_voxelization_cl_bf16_fwd(const void *values, int64_t ldv, const float *points,
+                                                   const int32_t *batch_indices, int64_t n, int32_t C, int32_t B,
+                                                   int32_t D, void *x, int64_t ldx, int32_t *counts, int32_t *head,
+                                                   int32_t *link, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t V = (int64_t)D * D * D;
+  if (B <= 0 || C <= 0 || V <= 0) return 0;
+  if (C % 2 || ldv % 2 || ldx % 2 || ldx < C || ldv < C) {
+    mf::set_last_error(hipErrorInvalidValue, "average_voxelization_cl_bf16: even C, ldv, ldx");
+    return -(int)hipErrorInvalidValue;
+  }
+  if (int e_ = mf::fill_bytes(counts, 0, sizeof(int32_t) * B * V, stream)) return e_;
+  if (int e_ = mf::fill_bytes(head, 0xff, sizeof(int32_t) * B * V, stream)) return e_;
+  if (n > 0)
+    hipLaunchKernelGGL(k_avgvox_link, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, points, batch_indices,
+                       n, B, D, D, D, 0.0f, 0.0f, 0.0f, 1.0f, counts, head, link, (int32_t *)nullptr);
+  if (ldx == C) {
+    if (int e_ = mf::fill_bytes(x, 0, (int64_t)B * V * ldx * 2, stream)) return e_;
+  } else {  // only the C columns: a strided zero fill
+    hipLaunchKernelGGL(k_zero_cols_bf16, dim3((unsigned)(((int64_t)B * V * (C / 2) + 255) / 256)), dim3(256), 0, stream,
+                       (uint16_t *)x, ldx, (int64_t)B * V, C / 2);
+  }
+  if (n > 0)
+    hipLaunchKernelGGL(k_avgvox_cl_fwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const uint16_t *)values,
+                       ldv, points, batch_indices, counts, head, link, n, C, B, D, (uint16_t *)x, ldx);
+  return mf::check_launch("mf_average_voxelization_cl_bf16_fwd");
+}
+
+/* gvalues bf16 [n, ldg >= C] = gx[b, voxel(point), :C] / count(voxel)  (zero for points outside the grid) */
+extern "C" int mf_average_voxelization_cl_bf16_bwd(const void *gx, int64_t ldx, const float *points,
+                                                   const int32_t *batch_indices, const int32_t *counts, int64_t n,
+                                                   int32_t C, int32_t B, int32_t D, void *gvalues, int64_t ldg,
+                                                   mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(k_avgvox_cl_bwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const uint16_t *)gx, ldx,
+                     points, batch_indices, counts, n, C, B, D, (uint16_t *)gvalues, ldg);
+  return mf::check_launch("mf_average_voxelization_cl_bf16_bwd");
 }
 
 extern "C" int mf_max_voxelization_3d_fwd(const float *values, const float *points,

@@ -108,3 +108,66 @@ def test_linear_operator_forward_and_gradients(K, n, Kin, N, relu):
     assert rel(x.grad, xr.grad) < 2e-2
     assert rel(conv.weight.grad.reshape(N, Kin), wr.grad) < 2e-2
     assert rel(conv.bias.grad, br.grad) < 2e-2
+
+
+@pytest.fixture()
+def KV(monkeypatch):
+    """bf16_ops over the emulated voxelize / interp / gemm sources."""
+    from morefusion_amd import _lib
+    from morefusion_amd.contrib.singleview_3d.models import bf16_ops
+    L = emul.build(["gemm_bf16.hip", "voxelize.hip", "interp.hip"])
+    for name, (argtypes, restype) in _lib._SIGNATURES.items():
+        fn = getattr(L, name, None)
+        if fn is not None:
+            fn.argtypes, fn.restype = argtypes, restype
+    monkeypatch.setattr(_lib, "lib", lambda: L)
+    monkeypatch.setattr(_lib, "require_gpu", lambda *a: None)
+    monkeypatch.setattr(_lib, "stream_ptr", lambda: None)
+    monkeypatch.setattr(_lib, "check", lambda code, what: (_ for _ in ()).throw(RuntimeError(what)) if code else None)
+    return bf16_ops
+
+
+def test_channels_last_bf16_voxelization_and_sampling_vs_oracle(KV):
+    """AverageVoxelizationCL / InterpolateVoxelGridCL (the bf16 training path's voxel ops) against the oracle's
+    channels-first float32 restatements of average_voxelization_3d.py:8-113 and interpolate_voxel_grid.py:61-215 on
+    the same bf16-rounded inputs: forward within one bf16 rounding, backward within bf16 / float-atomic tolerance.
+    Points outside the grid, a pile-up of 70 points in one voxel (the chain fallback), two batch items."""
+    from oracle import oracle_np as O
+    rs = np.random.RandomState(0)
+    B, D, C, n = 2, 8, 16, 300
+    pts = rs.uniform(-1.0, D + 0.5, (n, 3)).astype(np.float32)
+    pts[100:170] = (3.2, 4.1, 2.9)          # 70 points in one voxel (NaN rows: the reference raises, model.py never has them)
+    bi = np.repeat(np.arange(B), n // B).astype(np.int32)
+    vals = torch.from_numpy(rs.uniform(-1, 1, (n, C)).astype(np.float32)).to(torch.bfloat16)
+    v = vals.clone().requires_grad_(True)
+    ldx = C + 8
+    x = KV.AverageVoxelizationCL.apply(v, torch.from_numpy(pts), torch.from_numpy(bi), B, D, ldx)
+    want, counts = O.average_voxelization_3d(vals.float().numpy(), pts, bi, batch_size=B, origin=(0, 0, 0), pitch=1.0,
+                                             dimensions=(D, D, D))
+    want_cl = torch.from_numpy(want).reshape(B, C, D ** 3).transpose(1, 2)
+    got = x[:, :, :C].float()
+    assert float((got - want_cl).abs().max()) <= 2.0 ** -8 * float(want_cl.abs().max()) + 1e-6
+    assert int((counts > 0).sum()) > 50
+    # backward: gradient rows gathered from the voxels, / count
+    gx = torch.zeros(B, D ** 3, ldx, dtype=torch.bfloat16)
+    gx[:, :, :C] = torch.from_numpy(rs.uniform(-1, 1, (B, D ** 3, C)).astype(np.float32)).to(torch.bfloat16)
+    x.backward(gx)
+    gm = gx[:, :, :C].float().transpose(1, 2).reshape(B, C, D, D, D).numpy()
+    gv_o = O.average_voxelization_3d_backward(gm, pts, bi, counts, origin=(0, 0, 0), pitch=1.0, dimensions=(D, D, D))
+    assert float((v.grad.float() - torch.from_numpy(gv_o)).abs().max()) <= 2.0 ** -8 * float(np.abs(gv_o).max()) + 1e-6
+
+    # sampler
+    X, Cs = 8, 16
+    vox = torch.from_numpy(rs.uniform(-1, 1, (B, X ** 3, Cs)).astype(np.float32)).to(torch.bfloat16)
+    vg = vox.clone().requires_grad_(True)
+    sp = rs.uniform(-0.6, X - 0.4, (n, 3)).astype(np.float32)
+    sp[7] = np.nan
+    out = KV.InterpolateVoxelGridCL.apply(vg, torch.from_numpy(sp), torch.from_numpy(bi), X)
+    vox_cf = vox.float().transpose(1, 2).reshape(B, Cs, X, X, X).numpy()
+    want = O.interpolate_voxel_grid(vox_cf, sp, bi)
+    assert float((out.float() - torch.from_numpy(want)).abs().max()) <= 2.0 ** -8 * float(np.abs(want).max()) + 1e-6
+    g = torch.from_numpy(rs.uniform(-1, 1, (n, Cs)).astype(np.float32)).to(torch.bfloat16)
+    out.backward(g)
+    gv_o = O.interpolate_voxel_grid_backward(g.float().numpy(), sp, bi, (B, Cs, X, X, X))
+    gv_cl = torch.from_numpy(gv_o).reshape(B, Cs, X ** 3).transpose(1, 2)
+    assert float((vg.grad.float() - gv_cl).abs().max()) <= 2.0 ** -7 * float(gv_cl.abs().max()) + 1e-5

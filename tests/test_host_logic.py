@@ -471,3 +471,26 @@ def test_reference_package_name_and_link_xp():
     assert link.xp.concatenate([x, x], axis=0).shape == (4, 3)
     assert link.xp.arange(3).tolist() == [0, 1, 2] and link.xp.zeros((2,), np.int32).dtype == torch.int32
     assert not bool(link.xp.isnan(x).any())
+
+
+def test_grids_for_network_vs_the_executed_reference_transform():
+    """data_formats.grids_for_network against tests/golden/ref_transform.npz: the reference's own ``Transform``
+    (examples/ycb_video/singleview_3d/train.py:27-140) executed by oracle/gen_golden_transform.py -- evaluation mode
+    and training mode over all nine grid cases, with none / one / several non-target instance ids (the RNG call
+    sequence is part of the contract: same seeded RandomState -> same case and id subset)."""
+    from conftest import golden
+    from morefusion_amd.data_formats import grids_for_network
+    g = golden("ref_transform.npz")
+    tags = sorted({k.split("__")[0] for k in g})
+    assert len(tags) >= 40
+    cases = set()
+    for tag in tags:
+        c = {k.split("__", 1)[1]: g[k] for k in g if k.startswith(tag + "__")}
+        train, seed = bool(c["train"]), int(c["seed"])
+        target, nte = grids_for_network(c["grid_target"], c["grid_nontarget"], c["grid_empty"], c["grid_target_full"],
+                                        c["grid_nontarget_full"], train=train, random_state=np.random.RandomState(seed))
+        assert target.dtype == bool and nte.dtype == bool
+        np.testing.assert_array_equal(target, c["out_grid_target"], err_msg=tag)
+        np.testing.assert_array_equal(nte, c["out_grid_nontarget_empty"], err_msg=f"{tag} case {c['case']}")
+        cases.add(str(c["case"]))
+    assert len(cases) == 9
