@@ -55,11 +55,11 @@ struct NtArgs {
 
 __device__ __forceinline__ uint4 ld16(const uint16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
 
-// One 16-byte chunk (8 bf16) of an A row: element offset base + off, or zeros.  A masked chunk reads the
-// operand's first 16 bytes (always mapped) and selects zeros.
-__device__ __forceinline__ uint4 ld_chunk(const uint16_t *__restrict__ A, int base, int off, bool ok) {
-  const uint4 r = ld16(A + (ok ? base + off : 0));
-  return ok ? r : make_uint4(0u, 0u, 0u, 0u);
+// r if bit 0 of ``flag`` is set, else zeros -- as four ANDs with an all-ones / all-zero mask (written as a 128-bit
+// select the compiler built a two-entry table in scratch memory and indexed it)
+__device__ __forceinline__ uint4 keep16(uint4 r, unsigned flag) {
+  const uint32_t m = 0u - (flag & 1u);
+  return make_uint4(r.x & m, r.y & m, r.z & m, r.w & m);
 }
 
 template <int MODE, int MI>
@@ -145,44 +145,60 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  uint4 ra[2 * MI], rb[4];
-  // K-tile kt -> registers
-  auto fetch = [&](int kt) {
-    const int kg = kt * kBK + 8 * chunk;
-    const bool kin = kg + 8 <= a.K;
-    int off = kg, bits = 1 << 12;
-    if (MODE == kConvFwd) {
-      const int tap = kg / a.Cin, c = kg - tap * a.Cin;
-      const int kxy = tap / a.ks, kz = tap - kxy * a.ks, kx = kxy / a.ks, ky = kxy - kx * a.ks;
-      off = ((kx * a.D + ky) * a.D + kz) * a.dil * a.Cin + c;
-      bits = kx < a.ks ? (1 << kx) | (16 << ky) | (256 << kz) | (1 << 12) : 1 << 13;  // (past the last tap: never valid)
-    } else if (MODE == kConvDgrad) {
-      const int slot = kg / a.Cout, co = kg - slot * a.Cout;
-      const int sx = slot & 1, sy = (slot >> 1) & 1, sz = slot >> 2;
-      off = co - ((sx * Do + sy) * Do + sz) * a.Cout;
-      bits = (1 << sx) | (16 << sy) | (256 << sz) | (1 << 12);
-    }
-#pragma unroll
-    for (int i = 0; i < 2 * MI; ++i) ra[i] = ld_chunk(A, base[i], off, kin && (mask[i] & bits) == bits);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint4 r = ld16(wrow[i] + (kin ? kg : 0));
-      rb[i] = (kin && wok[i]) ? r : make_uint4(0u, 0u, 0u, 0u);
-    }
-  };
-  auto stash = [&](int buf) {
-    unsigned char *As = s_raw + buf * kBuf + r0 * kPitch + 16 * chunk;
-    unsigned char *Bs = As + kBM * kPitch;
-#pragma unroll
-    for (int i = 0; i < 2 * MI; ++i) *reinterpret_cast<uint4 *>(As + 32 * i * kPitch) = ra[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(Bs + 32 * i * kPitch) = rb[i];
-  };
-  fetch(0);
-  stash(0);
+  // K-tile kt -> registers.  A masked chunk (padding tap, row / column past the edge, K tail) still issues its load --
+  // from the operand's first 16 bytes -- and is zeroed in the STASH: a select right behind the load would make the
+  // wave wait for its own data at once (s_waitcnt vmcnt(0) in front of the MFMAs) and the prefetch would hide nothing.
+  // (Scalars and macros, not arrays in lambdas: behind the "memory" clobber that pins the loads in front of the MFMAs,
+  // arrays captured by reference were kept in scratch memory -- every load waited for and stored.)
+  uint4 ra0, ra1, ra2 = make_uint4(0u, 0u, 0u, 0u), ra3 = ra2, rb0, rb1, rb2, rb3;
+  unsigned live = 0;  // bit i: ra<i> is a real chunk, bit 8 + i: rb<i> is (else the register holds a dummy read)
+#define MF_NT_LOAD_A(i_, reg_)                                                                        \
+  {                                                                                                   \
+    const bool ok_ = kin_ && (mask[i_] & bits_) == bits_;                                             \
+    reg_ = ld16(A + (ok_ ? base[i_] + off_ : 0));                                                     \
+    live |= (ok_ ? 1u : 0u) << (i_);                                                                  \
+  }
+#define MF_NT_LOAD_B(i_, reg_)                                                                        \
+  {                                                                                                   \
+    reg_ = ld16(wrow[i_] + (kin_ ? kg_ : 0));                                                         \
+    live |= ((kin_ && wok[i_]) ? 1u : 0u) << (8 + (i_));                                              \
+  }
+#define MF_NT_FETCH(kt_)                                                                              \
+  {                                                                                                   \
+    const int kg_ = (kt_) * kBK + 8 * chunk;                                                          \
+    const bool kin_ = kg_ + 8 <= a.K;                                                                 \
+    int off_ = kg_, bits_ = 1 << 12;                                                                  \
+    if (MODE == kConvFwd) {                                                                           \
+      const int tap = kg_ / a.Cin, c = kg_ - tap * a.Cin;                                             \
+      const int kxy = tap / a.ks, kz = tap - kxy * a.ks, kx = kxy / a.ks, ky = kxy - kx * a.ks;       \
+      off_ = ((kx * a.D + ky) * a.D + kz) * a.dil * a.Cin + c;                                        \
+      bits_ = kx < a.ks ? (1 << kx) | (16 << ky) | (256 << kz) | (1 << 12) : 1 << 13;                 \
+    } else if (MODE == kConvDgrad) {                                                                  \
+      const int slot = kg_ / a.Cout, co = kg_ - slot * a.Cout;                                        \
+      const int sx = slot & 1, sy = (slot >> 1) & 1, sz = slot >> 2;                                  \
+      off_ = co - ((sx * Do + sy) * Do + sz) * a.Cout;                                                \
+      bits_ = (1 << sx) | (16 << sy) | (256 << sz) | (1 << 12);                                       \
+    }                                                                                                 \
+    live = 0;                                                                                         \
+    MF_NT_LOAD_A(0, ra0) MF_NT_LOAD_A(1, ra1)                                                         \
+    if constexpr (MI == 2) { MF_NT_LOAD_A(2 * MI - 2, ra2) MF_NT_LOAD_A(2 * MI - 1, ra3) }            \
+    MF_NT_LOAD_B(0, rb0) MF_NT_LOAD_B(1, rb1) MF_NT_LOAD_B(2, rb2) MF_NT_LOAD_B(3, rb3)               \
+  }
+#define MF_NT_PUT(ptr_, bit_, reg_) *reinterpret_cast<uint4 *>(ptr_) = keep16(reg_, live >> (bit_))
+#define MF_NT_STASH(buf_)                                                                             \
+  {                                                                                                   \
+    unsigned char *As_ = s_raw + (buf_) * kBuf + r0 * kPitch + 16 * chunk;                            \
+    unsigned char *Bs_ = As_ + kBM * kPitch;                                                          \
+    MF_NT_PUT(As_, 0, ra0); MF_NT_PUT(As_ + 32 * kPitch, 1, ra1);                                     \
+    if constexpr (MI == 2) { MF_NT_PUT(As_ + 64 * kPitch, 2, ra2); MF_NT_PUT(As_ + 96 * kPitch, 3, ra3); } \
+    MF_NT_PUT(Bs_, 8, rb0); MF_NT_PUT(Bs_ + 32 * kPitch, 9, rb1);                                     \
+    MF_NT_PUT(Bs_ + 64 * kPitch, 10, rb2); MF_NT_PUT(Bs_ + 96 * kPitch, 11, rb3);                     \
+  }
+  MF_NT_FETCH(0);
+  MF_NT_STASH(0);
   __syncthreads();
   for (int t = 0; t < T; ++t) {
-    fetch(t + 1 < T ? t + 1 : t);  // (the last iteration re-fetches its own tile: branch-free body)
+    MF_NT_FETCH(t + 1 < T ? t + 1 : t);  // (the last iteration re-fetches its own tile: branch-free body)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char *As = s_raw + (t & 1) * kBuf + (wm * 32 * MI + lrow) * kPitch + 16 * lhalf;
@@ -200,9 +216,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
         acc[MI - 1][1] = mf::mfma_bf16_32x32x16(a1, b1, acc[MI - 1][1]);
       }
     }
-    stash((t + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);  // (the stash -- and with it the wait for the loads -- stays BEHIND the MFMAs)
+    MF_HOLD(ra0); MF_HOLD(ra1); MF_HOLD(rb0); MF_HOLD(rb1); MF_HOLD(rb2); MF_HOLD(rb3);
+    if constexpr (MI == 2) { MF_HOLD(ra2); MF_HOLD(ra3); }
+    MF_NT_STASH((t + 1) & 1);
     __syncthreads();
   }
+#undef MF_NT_STASH
+#undef MF_NT_PUT
+#undef MF_NT_FETCH
+#undef MF_NT_LOAD_B
+#undef MF_NT_LOAD_A
 
   // epilogue through LDS (the loop ended on a barrier: the operand buffers are free)
   constexpr int kEp = kBN + 4;
@@ -345,50 +369,65 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  uint4 rp[4], rq[4];
-  auto fetch = [&](int t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = t * 64 + 4 * mg + r;
-      const bool ok = m < a.M;
-      const int mm = ok ? m : 0;
-      rp[r] = ld_chunk(P, mm * a.ldp, i0 + 8 * c, ok && pcol_ok);
-      if (a.conv) {
-        const int b = mm >> (3 * dol), o = mm & ((1 << (3 * dol)) - 1);
-        const int x0 = a.stride * (o >> (2 * dol)) - a.pad, y0 = a.stride * ((o >> dol) & (Do - 1)) - a.pad,
-                  z0 = a.stride * (o & (Do - 1)) - a.pad;
-        int mk = 1 << 12;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          mk |= ((unsigned)(x0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << k;
-          mk |= ((unsigned)(y0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (4 + k);
-          mk |= ((unsigned)(z0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (8 + k);
-        }
-        const int base = (((b * a.D + x0) * a.D + y0) * a.D + z0) * a.Cin;
-        rq[r] = ld_chunk(Q, base, q_off, ok && qcol_ok && (mk & q_bits) == q_bits);
-      } else {
-        rq[r] = ld_chunk(Q, mm * a.ldq, q_off, ok && qcol_ok);
-      }
-    }
-  };
-  auto stash = [&](int buf) {
-    uint2 col[8];
-    unsigned char *Ps = s_raw + buf * kTnBuf + 8 * mg;
-    transpose4x8(rp, col);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) *reinterpret_cast<uint2 *>(Ps + tn_phys(8 * c + e, a.shift)) = col[e];
-    transpose4x8(rq, col);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) *reinterpret_cast<uint2 *>(Ps + kTnOperand + tn_phys(8 * c + e, a.shift)) = col[e];
-  };
+  uint4 rp0, rp1, rp2, rp3, rq0, rq1, rq2, rq3;
+  unsigned live = 0;  // bit r: rp<r> is a real chunk, bit 4 + r: rq<r> (zeroed in the stash, see the NT kernel)
+#define MF_TN_LOAD(r_, rp_, rq_)                                                                      \
+  {                                                                                                   \
+    const int m_ = t_ * 64 + 4 * mg + (r_);                                                           \
+    const bool ok_ = m_ < a.M;                                                                        \
+    const int mm_ = ok_ ? m_ : 0;                                                                     \
+    const bool pok_ = ok_ && pcol_ok;                                                                 \
+    rp_ = ld16(P + (pok_ ? mm_ * a.ldp + i0 + 8 * c : 0));                                            \
+    bool qok_ = ok_ && qcol_ok;                                                                       \
+    int qaddr_ = mm_ * a.ldq + q_off;                                                                 \
+    if (a.conv) {                                                                                     \
+      const int b_ = mm_ >> (3 * dol), o_ = mm_ & ((1 << (3 * dol)) - 1);                             \
+      const int x0 = a.stride * (o_ >> (2 * dol)) - a.pad, y0 = a.stride * ((o_ >> dol) & (Do - 1)) - a.pad, \
+                z0 = a.stride * (o_ & (Do - 1)) - a.pad;                                              \
+      int mk = 1 << 12;                                                                               \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                 \
+        mk |= ((unsigned)(x0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << k;                              \
+        mk |= ((unsigned)(y0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (4 + k);                        \
+        mk |= ((unsigned)(z0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (8 + k);                        \
+      }                                                                                               \
+      qok_ = qok_ && (mk & q_bits) == q_bits;                                                         \
+      qaddr_ = (((b_ * a.D + x0) * a.D + y0) * a.D + z0) * a.Cin + q_off;                             \
+    }                                                                                                 \
+    rq_ = ld16(Q + (qok_ ? qaddr_ : 0));                                                              \
+    live |= (pok_ ? 1u : 0u) << (r_) | (qok_ ? 1u : 0u) << (4 + (r_));                                \
+  }
+#define MF_TN_FETCH(tt_)                                                                              \
+  {                                                                                                   \
+    const int t_ = (tt_);                                                                             \
+    live = 0;                                                                                         \
+    MF_TN_LOAD(0, rp0, rq0) MF_TN_LOAD(1, rp1, rq1) MF_TN_LOAD(2, rp2, rq2) MF_TN_LOAD(3, rp3, rq3)   \
+  }
+#define MF_TN_SEL(bit_, reg_) keep16(reg_, live >> (bit_))
+#define MF_TN_STASH(buf_)                                                                             \
+  {                                                                                                   \
+    uint2 col[8];                                                                                     \
+    unsigned char *Ps_ = s_raw + (buf_) * kTnBuf + 8 * mg;                                            \
+    {                                                                                                 \
+      const uint4 t4[4] = {MF_TN_SEL(0, rp0), MF_TN_SEL(1, rp1), MF_TN_SEL(2, rp2), MF_TN_SEL(3, rp3)}; \
+      transpose4x8(t4, col);                                                                          \
+    }                                                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                     \
+        *reinterpret_cast<uint2 *>(Ps_ + tn_phys(8 * c + e, a.shift)) = col[e];                       \
+    {                                                                                                 \
+      const uint4 t4[4] = {MF_TN_SEL(4, rq0), MF_TN_SEL(5, rq1), MF_TN_SEL(6, rq2), MF_TN_SEL(7, rq3)}; \
+      transpose4x8(t4, col);                                                                          \
+    }                                                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                     \
+        *reinterpret_cast<uint2 *>(Ps_ + kTnOperand + tn_phys(8 * c + e, a.shift)) = col[e];          \
+  }
   if (t0 < t1) {
-    fetch(t0);
-    stash(0);
+    MF_TN_FETCH(t0);
+    MF_TN_STASH(0);
   }
   __syncthreads();
   for (int t = t0; t < t1; ++t) {
     const int buf = (t - t0) & 1;
-    fetch(t + 1 < t1 ? t + 1 : t);
+    MF_TN_FETCH(t + 1 < t1 ? t + 1 : t);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char *Ps = s_raw + buf * kTnBuf + 16 * lhalf;
@@ -406,9 +445,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
       acc[1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[1][0]);
       acc[1][1] = mf::mfma_bf16_32x32x16(a1, b1, acc[1][1]);
     }
-    stash(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    MF_HOLD(rp0); MF_HOLD(rp1); MF_HOLD(rp2); MF_HOLD(rp3); MF_HOLD(rq0); MF_HOLD(rq1); MF_HOLD(rq2); MF_HOLD(rq3);
+    MF_TN_STASH(buf ^ 1);
     __syncthreads();
   }
+#undef MF_TN_STASH
+#undef MF_TN_SEL
+#undef MF_TN_FETCH
+#undef MF_TN_LOAD
 
   constexpr int kEp = 128 + 4;
   float *s_out = reinterpret_cast<float *>(s_raw);

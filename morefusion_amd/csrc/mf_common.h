@@ -41,6 +41,11 @@ int fill_bytes(void *dst, int value, int64_t nbytes, hipStream_t stream);
 
 constexpr int kWave = 64;
 
+// Opaque use of a staged 16-byte register at a program point (MF_HOLD(r) after a block of MFMAs): without it the
+// compiler hoists arithmetic on a prefetched value -- and with it the wait for the load -- to right behind the load,
+// in front of the MFMAs the load is meant to overlap.  (tests/host_emul/mf_common.h: a no-op.)
+#define MF_HOLD(r_) asm volatile("" : "+v"(r_.x), "+v"(r_.y), "+v"(r_.z), "+v"(r_.w))
+
 // dynamic LDS of the workgroup (tests/host_emul/mf_common.h gives the host-emulation form)
 #define MF_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 
