@@ -431,6 +431,26 @@ int mf_interpolate_voxel_grid_cl_bf16_bwd(const void *gout, int64_t ldg, const f
                                           const int32_t *batch_indices, int64_t n, int B, int C, int X, int Y, int Z,
                                           float *gvox, mfStream_t stream);
 
+/* Element-wise pieces of the 2-D backbone's decoder (morefusion/models/dense_fusion/pspnet.py:10-35,40-73:
+ * F.resize_images bilinear align_corners, L.PReLU with one slope), forward and backward, channels-last tensors
+ * [B, H, W, C], float32 (bf16 = 0) or bfloat16 (bf16 = 1), C % 8 == 0:
+ *   mf_upsample_bilinear_cl_fwd  y [B, Ho, Wo, C] from x [B, H, W, C]
+ *   mf_upsample_bilinear_cl_bwd  gx from gy: a gather in increasing (oy, ox) -- deterministic, no atomics
+ *   mf_prelu_fwd / mf_prelu_bwd  y = x > 0 ? x : a x;  dx and dslope[0] = sum_{x <= 0} dy x (ws: mf_prelu_bwd_workspace_floats) */
+int mf_upsample_bilinear_cl_fwd(const void *x, void *y, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                int32_t C, int32_t bf16, mfStream_t stream);
+int mf_upsample_bilinear_cl_bwd(const void *gy, void *gx, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                int32_t C, int32_t bf16, mfStream_t stream);
+/* ... and for channels-first tensors [B*C, H, W] (one lane per element) */
+int mf_upsample_bilinear_cf_fwd(const void *x, void *y, int64_t BC, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                int32_t bf16, mfStream_t stream);
+int mf_upsample_bilinear_cf_bwd(const void *gy, void *gx, int64_t BC, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                int32_t bf16, mfStream_t stream);
+int mf_prelu_fwd(const void *x, const float *slope, void *y, int64_t n, int32_t bf16, mfStream_t stream);
+int64_t mf_prelu_bwd_workspace_floats(int64_t n);
+int mf_prelu_bwd(const void *x, const void *dy, const float *slope, void *dx, float *dslope, float *ws, int64_t n,
+                 int32_t bf16, mfStream_t stream);
+
 /* Point-wise prologue / epilogue of the volumetric part (inference), one launch each instead of ~25 torch launches:
  *   mf_point_prep: camera-frame points [B,3,P] + image features [B,Cv,P] -> voxel-frame points [n,3]
  *     ((p - origin) / pitch, model.py:236), to_center [n,4] = (center - p | 0) (:101), feature rows [n,Cv],

@@ -10,6 +10,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops2d
+
 
 class BasicBlock(nn.Module):
     def __init__(self, in_channels, out_channels, stride, dilate, residual_conv=False):
@@ -207,7 +209,8 @@ class PSPModule(nn.Module):
         hs = []
         for pooled, conv in zip(self._pooled(x), self.convs):
             h = conv(pooled).contiguous(memory_format=torch.channels_last)
-            hs.append(F.interpolate(h, (H, W), mode="bilinear", align_corners=True))
+            hs.append(ops2d.upsample_bilinear(h, (H, W)) if ops2d.supported(h) else
+                      F.interpolate(h, (H, W), mode="bilinear", align_corners=True))
         return hs
 
     def forward(self, x):
@@ -222,8 +225,15 @@ class PSPUpsample(nn.Module):
 
     def forward(self, x):
         H, W = x.shape[2:]
-        h = F.interpolate(x, (H * 2, W * 2), mode="bilinear", align_corners=True)
-        return self.prelu(self.conv(h))
+        # the resize and the single-slope PReLU on csrc/backbone2d.hip (memory-bound maps, forward + backward)
+        if ops2d.supported(x):
+            h = ops2d.upsample_bilinear(x, (H * 2, W * 2))
+        else:
+            h = F.interpolate(x, (H * 2, W * 2), mode="bilinear", align_corners=True)
+        h = self.conv(h)
+        if ops2d.supported(h, self.prelu.weight.numel()):
+            return ops2d.prelu(h, self.prelu.weight)
+        return self.prelu(h)
 
 
 class PSPNetExtractor(nn.Module):

@@ -1,0 +1,106 @@
+"""Autograd operators over csrc/backbone2d.hip: the memory-bound maps of PSPNet's decoder -- bilinear resize with
+``align_corners`` (morefusion/models/dense_fusion/pspnet.py:18-22,50-56: ``F.resize_images``) and the single-slope
+PReLU (:57) -- forward and backward, on channels-last float32 / bfloat16 tensors.
+
+The stock kernels run these far below the HBM roofline (the resize backward is a float-atomic scatter, the PReLU slope
+gradient a whole-tensor reduction: 2.8 + 1.3 ms of a 25 ms bf16 training step); here the backward passes are a
+deterministic gather and a two-stage block sum.  No fallback: tensors must live on the GPU."""
+import torch
+
+from .. import _lib
+
+
+def _dense(x):
+    """[B,C,H,W] in one of the two dense layouts the kernels read in place: (tensor, memory_format).  A tensor that is
+    neither channels-first nor channels-last contiguous is copied to the one it is closer to (channels-last when its
+    channel stride is 1)."""
+    if x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 8 == 0 and x.shape[1] > 1:
+        return x, torch.channels_last
+    if x.is_contiguous():
+        return x, torch.contiguous_format
+    if x.stride(1) == 1 and x.shape[1] % 8 == 0:
+        return x.contiguous(memory_format=torch.channels_last), torch.channels_last
+    return x.contiguous(), torch.contiguous_format
+
+
+def supported(x, n_slope=1):
+    return x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and n_slope == 1
+
+
+class _Upsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        _lib.require_gpu(x)
+        x, fmt = _dense(x.detach())
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=fmt)
+        bf = int(x.dtype == torch.bfloat16)
+        if fmt == torch.channels_last:
+            _lib.check(_lib.lib().mf_upsample_bilinear_cl_fwd(x.data_ptr(), y.data_ptr(), B, H, W, Ho, Wo, C, bf,
+                                                              _lib.stream_ptr()), "mf_upsample_bilinear_cl_fwd")
+        else:
+            _lib.check(_lib.lib().mf_upsample_bilinear_cf_fwd(x.data_ptr(), y.data_ptr(), B * C, H, W, Ho, Wo, bf,
+                                                              _lib.stream_ptr()), "mf_upsample_bilinear_cf_fwd")
+        ctx.geom = (B, C, H, W, Ho, Wo, fmt)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C, H, W, Ho, Wo, fmt = ctx.geom
+        gy = gy.contiguous(memory_format=fmt)
+        gx = torch.empty((B, C, H, W), dtype=gy.dtype, device=gy.device, memory_format=fmt)
+        bf = int(gy.dtype == torch.bfloat16)
+        if fmt == torch.channels_last:
+            _lib.check(_lib.lib().mf_upsample_bilinear_cl_bwd(gy.data_ptr(), gx.data_ptr(), B, H, W, Ho, Wo, C, bf,
+                                                              _lib.stream_ptr()), "mf_upsample_bilinear_cl_bwd")
+        else:
+            _lib.check(_lib.lib().mf_upsample_bilinear_cf_bwd(gy.data_ptr(), gx.data_ptr(), B * C, H, W, Ho, Wo, bf,
+                                                              _lib.stream_ptr()), "mf_upsample_bilinear_cf_bwd")
+        return gx, None, None
+
+
+class _PReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        _lib.require_gpu(x, slope)
+        x, fmt = _dense(x.detach())       # element-wise with one slope: either dense layout is read as it lies
+        if x.numel() % 8:
+            raise ValueError("prelu: the element count must be a multiple of 8")
+        a = slope.detach().float().contiguous()
+        y = torch.empty_like(x)
+        ctx.fmt = fmt
+        _lib.check(_lib.lib().mf_prelu_fwd(x.data_ptr(), a.data_ptr(), y.data_ptr(), x.numel(),
+                                           int(x.dtype == torch.bfloat16), _lib.stream_ptr()), "mf_prelu_fwd")
+        ctx.save_for_backward(x, a)
+        ctx.slope_meta = (slope.dtype, slope.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, a = ctx.saved_tensors
+        L = _lib.lib()
+        gy = gy.to(x.dtype).contiguous(memory_format=ctx.fmt)
+        dx = torch.empty_like(x)
+        da = torch.empty((1,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((max(int(L.mf_prelu_bwd_workspace_floats(x.numel())), 1),), dtype=torch.float32, device=x.device)
+        _lib.check(L.mf_prelu_bwd(x.data_ptr(), gy.data_ptr(), a.data_ptr(), dx.data_ptr(), da.data_ptr(), ws.data_ptr(),
+                                  x.numel(), int(x.dtype == torch.bfloat16), _lib.stream_ptr()), "mf_prelu_bwd")
+        dtype, shape = ctx.slope_meta
+        return dx, da.to(dtype).reshape(shape)
+
+
+def _autocast_dtype(x):
+    if x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        return x.to(torch.bfloat16)  # the convolution behind the resize would round to bf16 anyway
+    return x
+
+
+def upsample_bilinear(x, size):
+    """``F.interpolate(x, size, mode="bilinear", align_corners=True)`` for [B,C,H,W] on the MI355X; the result has
+    the memory format of the input (channels-first or channels-last, read and written in place)."""
+    return _Upsample.apply(_autocast_dtype(x), int(size[0]), int(size[1]))
+
+
+def prelu(x, slope):
+    """``F.prelu(x, slope)`` for a single slope."""
+    return _PReLU.apply(_autocast_dtype(x), slope)

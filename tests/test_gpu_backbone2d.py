@@ -1,0 +1,52 @@
+"""csrc/backbone2d.hip on the MI355X: bilinear resize (align_corners) and single-slope PReLU of PSPNet's decoder
+(morefusion/models/dense_fusion/pspnet.py:18-22,50-57), forward and backward, at the decoder's shapes, against
+torch's own CUDA operators (whose backward is a float-atomic scatter: compared at 1e-5 relative)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from morefusion_amd.models import ops2d  # noqa: E402
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize("shape,size", [((2, 256, 64, 64), (128, 128)), ((2, 1024, 32, 32), (64, 64)),
+                                        ((2, 512, 6, 6), (32, 32)), ((2, 512, 1, 1), (32, 32))])
+@pytest.mark.parametrize("fmt", [torch.channels_last, torch.contiguous_format], ids=["channels_last", "channels_first"])
+def test_bilinear_resize_vs_torch(dtype, tol, shape, size, fmt):
+    torch.manual_seed(0)
+    x = torch.randn(shape, device="cuda").to(dtype).contiguous(memory_format=fmt)
+    xa = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    y = ops2d.upsample_bilinear(xa, size)
+    g = torch.randn(y.shape, device="cuda").to(dtype)
+    y.backward(g)
+    xr = x.float().requires_grad_(True)
+    yr = F.interpolate(xr, size, mode="bilinear", align_corners=True)
+    yr.backward(g.float())
+    assert y.is_contiguous(memory_format=fmt) or shape[2] * shape[3] == 1
+    assert float((y.float() - yr).abs().max()) <= tol * max(1.0, float(yr.abs().max()))
+    assert float((xa.grad.float() - xr.grad).abs().max()) <= tol * max(1.0, float(xr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 2.0 ** -7)])
+def test_prelu_vs_torch(dtype, tol):
+    torch.manual_seed(1)
+    x = torch.randn(2, 64, 128, 128, device="cuda").to(dtype)
+    slope = torch.tensor([0.25], device="cuda", requires_grad=True)
+    xa = x.clone().requires_grad_(True)
+    y = ops2d.prelu(xa, slope)
+    g = torch.randn(y.shape, device="cuda").to(dtype)
+    y.backward(g)
+    xr = x.float().requires_grad_(True)
+    sr = torch.tensor([0.25], device="cuda", requires_grad=True)
+    yr = F.prelu(xr, sr)
+    yr.backward(g.float())
+    assert float((y.float() - yr).abs().max()) <= tol * float(yr.abs().max())
+    assert float((xa.grad.float() - xr.grad).abs().max()) <= tol * float(xr.grad.abs().max())
+    assert abs(float(slope.grad) - float(sr.grad)) <= 2e-3 * abs(float(sr.grad)) + 1e-3
+    # deterministic (a fixed-order block sum, no float atomics)
+    xa2 = x.clone().requires_grad_(True)
+    s2 = torch.tensor([0.25], device="cuda", requires_grad=True)
+    ops2d.prelu(xa2, s2).backward(g)
+    assert float(s2.grad) == float(slope.grad)
