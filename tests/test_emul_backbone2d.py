@@ -29,7 +29,8 @@ def ops(monkeypatch):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2.0 ** -7)])
 @pytest.mark.parametrize("shape,size", [((2, 16, 5, 7), (10, 14)), ((1, 8, 1, 1), (6, 6)), ((1, 8, 3, 2), (12, 12)),
-                                        ((2, 8, 6, 6), (12, 12))])
+                                        ((2, 8, 6, 6), (12, 12)), ((1, 64, 9, 11), (18, 22)), ((1, 64, 8, 8), (13, 16)),
+                                        ((1, 64, 1, 1), (8, 8)), ((2, 64, 3, 2), (16, 16))])
 @pytest.mark.parametrize("layout", ["channels_first", "channels_last"])
 def test_bilinear_resize_forward_and_backward(ops, dtype, tol, shape, size, layout):
     torch.manual_seed(0)
