@@ -457,12 +457,13 @@ int mf_prelu_bwd(const void *x, const void *dy, const float *slope, void *dx, fl
  *     batch indices [n];  n = B*P, Cv % 4 == 0.
  *   mf_pose_epilogue: heads' output rows [n, ldo] (rot at column 0, trans at np4, conf at 2*np4; class c at
  *     4c / 3c / c) -> rot [n,4] = q / (|q| + 1e-5) (chainer F.normalize), trans [n,3] = (p*pitch + origin) +
- *     t*pitch (:264-266), conf [n] = sigmoid (:262) of each object's class (class_id int64 [B], 1-based). */
+ *     t*pitch (:264-266), conf [n] = sigmoid (:262) of each object's class (class_id int64 [B], 1-based; an id
+ *     outside 1 .. n_fg gives NaN outputs, never a read outside the row). */
 int mf_point_prep(const float *points_cam, const float *values, const float *origin, const float *pitch,
                   int32_t B, int32_t P, int32_t Cv, float center, float *pts, float *tc4, float *x_rows,
                   int32_t *batch_indices, mfStream_t stream);
 int mf_pose_epilogue(const float *heads_out, int64_t ldo, int32_t np4, const int64_t *class_id,
-                     const float *pts, const float *origin, const float *pitch, int32_t B, int32_t P,
+                     const float *pts, const float *origin, const float *pitch, int32_t B, int32_t P, int32_t n_fg,
                      float *rot, float *trans, float *conf, mfStream_t stream);
 
 /* The last PSPNet level (up3: bilinear x2 + Convolution2D 3x3 64->64 + PReLU; conv1 1x1 64->32; log-softmax,

@@ -267,7 +267,9 @@ class Model(nn.Module):
         return tuple(o.clone() for o in outs) if clone else outs
 
     def select_points_async(self, pcd, stream=None):
-        """Point selection of a FUTURE frame on a side stream: launches ``mf_valid_pixel_order`` and the
+        """EXPERIMENTAL (measured slower than the synchronous selection at batch 1: 2.1-2.3 vs 1.8 ms per frame, the
+        cross-stream hand-over costs more than the 30 us it hides; kept for larger batches / pipelines that already
+        own a side stream).  Point selection of a FUTURE frame on a side stream: launches ``mf_valid_pixel_order`` and the
         device-to-host copy of the counts into pinned memory, returns a handle whose ``result()`` finishes
         the host-side RNG subsample.  Issued while the network of the current frame runs, the host
         synchronisation of ``predict`` hides behind it (demo.py:80-100 processes frames in sequence)."""

@@ -295,7 +295,7 @@ class ChannelsLastVolumetric:
             cid = class_id.to(device=dev, dtype=torch.int64).contiguous()
             _lib.check(_lib.lib().mf_pose_epilogue(
                 o.data_ptr(), o.stride(0), np4, cid.data_ptr(), pts.data_ptr(), _lib.f32c(origin).data_ptr(),
-                _lib.f32c(pitch).data_ptr(), B, P, rot.data_ptr(), trans.data_ptr(), conf.data_ptr(),
+                _lib.f32c(pitch).data_ptr(), B, P, self.m._n_fg_class, rot.data_ptr(), trans.data_ptr(), conf.data_ptr(),
                 _lib.stream_ptr()), "mf_pose_epilogue")
             return rot, trans, conf
         cls_rot, cls_trans, cls_conf = self.heads(feat, B, P)          # [B,P,n_fg,c]

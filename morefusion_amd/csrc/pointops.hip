@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_pose_epilogue(const float *__restrict__
                                                        const int64_t *__restrict__ class_id,  // [B], 1-based
                                                        const float *__restrict__ pts,          // [n,3] voxel frame
                                                        const float *__restrict__ origin, const float *__restrict__ pitch,
-                                                       int B, int P, float *__restrict__ rot,  // [n,4]
+                                                       int B, int P, int n_fg, float *__restrict__ rot,  // [n,4]
                                                        float *__restrict__ trans,              // [n,3]
                                                        float *__restrict__ conf) {             // [n]
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,6 +57,13 @@ __global__ __launch_bounds__(256) void k_pose_epilogue(const float *__restrict__
   const int fg = (int)class_id[b] - 1;
   const float pit = pitch[b];
   const float *row = o + i * ldo;
+  if (fg < 0 || fg >= n_fg) {  // background (0) or an id beyond the heads' classes: no pose -- NaN, never a read
+    const float nan = __uint_as_float(0x7fc00000u);  // outside the row (the torch indexing it replaces raises / wraps)
+    *reinterpret_cast<float4 *>(rot + 4 * i) = make_float4(nan, nan, nan, nan);
+    trans[3 * i] = trans[3 * i + 1] = trans[3 * i + 2] = nan;
+    conf[i] = nan;
+    return;
+  }
   const float q0 = row[4 * fg], q1 = row[4 * fg + 1], q2 = row[4 * fg + 2], q3 = row[4 * fg + 3];
   const float nrm = sqrtf(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3) + 1e-5f;
   *reinterpret_cast<float4 *>(rot + 4 * i) = make_float4(q0 / nrm, q1 / nrm, q2 / nrm, q3 / nrm);
@@ -87,15 +94,15 @@ extern "C" int mf_point_prep(const float *points_cam, const float *values, const
 
 extern "C" int mf_pose_epilogue(const float *heads_out, int64_t ldo, int32_t np4, const int64_t *class_id,
                                 const float *pts, const float *origin, const float *pitch, int32_t B, int32_t P,
-                                float *rot, float *trans, float *conf, mfStream_t stream_) {
+                                int32_t n_fg, float *rot, float *trans, float *conf, mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || P <= 0) return 0;
-  if (((uintptr_t)rot & 15) || ldo < 3 * (int64_t)np4) {
-    mf::set_last_error(hipErrorInvalidValue, "pose_epilogue: need a 16-byte aligned rot and ldo >= 3 * np4");
+  if (((uintptr_t)rot & 15) || ldo < 3 * (int64_t)np4 || n_fg < 1 || 4 * n_fg > np4) {
+    mf::set_last_error(hipErrorInvalidValue, "pose_epilogue: need a 16-byte aligned rot, ldo >= 3 * np4, 4 * n_fg <= np4");
     return -(int)hipErrorInvalidValue;
   }
   const int64_t n = (int64_t)B * P;
   hipLaunchKernelGGL(k_pose_epilogue, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, heads_out, ldo, np4,
-                     class_id, pts, origin, pitch, B, P, rot, trans, conf);
+                     class_id, pts, origin, pitch, B, P, n_fg, rot, trans, conf);
   return mf::check_launch("mf_pose_epilogue");
 }

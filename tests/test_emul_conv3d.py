@@ -188,7 +188,7 @@ def test_point_prep_and_pose_epilogue_vs_numpy():
     L = emul.build(["pointops.hip"])
     i32, i64, p, f = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_float
     L.mf_point_prep.argtypes = [p, p, p, p, i32, i32, i32, f, p, p, p, p, p]
-    L.mf_pose_epilogue.argtypes = [p, i64, i32, p, p, p, p, i32, i32, p, p, p, p]
+    L.mf_pose_epilogue.argtypes = [p, i64, i32, p, p, p, p, i32, i32, i32, p, p, p, p]
     rs = np.random.RandomState(9)
     B, P, Cv = 3, 70, 8
     n = B * P
@@ -212,7 +212,14 @@ def test_point_prep_and_pose_epilogue_vs_numpy():
     cid = np.array([1, 21, 7], np.int64)
     rot, trans, conf = (emul.guarded(np.zeros((n, k), np.float32)) for k in (4, 3, 1))
     assert L.mf_pose_epilogue(o.ctypes.data, 3 * np4, np4, emul.ptr(cid), pts.ctypes.data, emul.ptr(origin),
-                              emul.ptr(pitch), B, P, rot.ctypes.data, trans.ctypes.data, conf.ctypes.data, None) == 0
+                              emul.ptr(pitch), B, P, nf, rot.ctypes.data, trans.ctypes.data, conf.ctypes.data, None) == 0
+    # a background / out-of-range class id gives NaN poses and never reads outside the heads' row
+    bad_cid = np.array([0, 22, 7], np.int64)
+    r2, t2, c2 = (emul.guarded(np.zeros((n, k), np.float32)) for k in (4, 3, 1))
+    assert L.mf_pose_epilogue(o.ctypes.data, 3 * np4, np4, emul.ptr(bad_cid), pts.ctypes.data, emul.ptr(origin),
+                              emul.ptr(pitch), B, P, nf, r2.ctypes.data, t2.ctypes.data, c2.ctypes.data, None) == 0
+    assert np.isnan(r2[:2 * P]).all() and np.isnan(t2[:2 * P]).all() and np.isnan(c2[:2 * P]).all()
+    np.testing.assert_array_equal(r2[2 * P:], rot[2 * P:])
     fg = np.repeat(cid - 1, P)
     rows = np.arange(n)
     q = np.stack([o[rows, 4 * fg + k] for k in range(4)], 1)
