@@ -145,6 +145,29 @@ def frontend(side):
             valid = np.flatnonzero(~np.isnan(pcd[i]).any(-1))
             keep = m._keep_indices(len(valid))
             np.testing.assert_array_equal(got[i].numpy(), valid[keep])
+    # instance crops (mf_instance_stats + mf_instance_crops): masks touching the image border, an empty instance, an
+    # instance with too few valid depths, vs the oracle's restatement of the reference's host loop
+    from oracle import oracle_np as O
+    from morefusion_amd.geometry import instance_crops
+    Hh, Ww, S = 60, 72, 32
+    rgb = rs.randint(0, 255, (Hh, Ww, 3)).astype(np.uint8)
+    depth = rs.uniform(0.4, 1.2, (Hh, Ww)).astype(np.float32)
+    depth[rs.uniform(size=(Hh, Ww)) < 0.1] = np.nan
+    label = np.zeros((Hh, Ww), np.int32)
+    label[0:20, 0:25] = 1            # touches two borders
+    label[30:60, 50:72] = 2          # touches the far corner
+    label[25:28, 30:33] = 3          # 9 pixels: fewer than min_valid
+    Kmat = np.array([[80.0, 0, 36.0], [0, 80.0, 30.0], [0, 0, 1]])
+    ids = np.array([1, 2, 3, 7], np.int32)   # 7: no pixel at all
+    with emul.GuardedTensors(L, side, log) as G:
+        _patch_lib(G)
+        out = instance_crops(torch.from_numpy(rgb), torch.from_numpy(depth), Kmat, torch.from_numpy(label), ids,
+                             image_size=S, min_valid=20)
+    w_rgb, w_pcd, w_keep, _ = O.instance_crops(rgb, depth, Kmat, label, ids, image_size=S, min_valid=20)
+    np.testing.assert_array_equal(out["keep"].numpy(), w_keep)
+    np.testing.assert_array_equal(out["rgb"].numpy()[w_keep], w_rgb[w_keep])
+    np.testing.assert_array_equal(out["pcd"].numpy()[w_keep], w_pcd[w_keep].astype(np.float32))
+    assert list(out["keep"].numpy()) == [True, True, False, False]
     print(f"GUARD_OK frontend {side}")
 
 
