@@ -128,13 +128,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
     }
     mask[i] = mk;
   }
-  const uint16_t *wrow[4];
-  bool wok[4];
+  uint32_t wrow[4];  // byte offsets into W (weights: far below 2^32 bytes)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + r0 + 32 * i;
-    wok[i] = n < a.N;
-    wrow[i] = W + (int64_t)(wok[i] ? n : 0) * a.ldw;
+    wrow[i] = 2u * (uint32_t)((int64_t)(n < a.N ? n : 0) * a.ldw);
   }
 
   mf_f32x16 acc[MI][2];
@@ -145,85 +143,117 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  // K-tile kt -> registers.  A masked chunk (padding tap, row / column past the edge, K tail) still issues its load --
-  // from the operand's first 16 bytes -- and is zeroed in the STASH: a select right behind the load would make the
-  // wave wait for its own data at once (s_waitcnt vmcnt(0) in front of the MFMAs) and the prefetch would hide nothing.
+  // K-tile kt -> registers.  Nothing touches the loaded data before the stash: a select right behind a load would
+  // make the wave wait for its own data at once (s_waitcnt vmcnt(0) in front of the MFMAs) and the prefetch would
+  // hide nothing.
   // (Scalars and macros, not arrays in lambdas: behind the "memory" clobber that pins the loads in front of the MFMAs,
   // arrays captured by reference were kept in scratch memory -- every load waited for and stored.)
-  uint4 ra0, ra1, ra2 = make_uint4(0u, 0u, 0u, 0u), ra3 = ra2, rb0, rb1, rb2, rb3;
-  unsigned live = 0;  // bit i: ra<i> is a real chunk, bit 8 + i: rb<i> is (else the register holds a dummy read)
-#define MF_NT_LOAD_A(i_, reg_)                                                                        \
-  {                                                                                                   \
-    const bool ok_ = kin_ && (mask[i_] & bits_) == bits_;                                             \
-    reg_ = ld16(A + (ok_ ? base[i_] + off_ : 0));                                                     \
-    live |= (ok_ ? 1u : 0u) << (i_);                                                                  \
+  // ONE register set, one tile ahead.  (Two sets -- tile t + 2 in flight while t + 1 waits -- were measured twice in
+  // round 4, before and after the VALU diet: no gain on any shape, 90 more registers.)
+  uint4 ra0P, ra1P, ra2P = make_uint4(0u, 0u, 0u, 0u), ra3P = ra2P, rb0P, rb1P, rb2P, rb3P;
+  // This lane's position in K, advanced by one K-tile per fetch (the fetches run over kt = 0, 1, 2, ... in order): the
+  // chunk's k offset and, for the convolutions, its (tap, channel) -- tracked incrementally (round 4, first version:
+  // two integer divisions per fetch and 64-bit address arithmetic per load, 12 VALU instructions per MFMA by
+  // SQ_INSTS_VALU; the MFMA pipe at 0.37).
+  int kg = 8 * chunk, tc = 0, tx = 0, ty = 0, tz = 0;  // conv fwd: tap (tx, ty, tz), channel tc; dgrad: slot tx, cout tc
+  if (MODE == kConvFwd) {
+    const int tap = kg / a.Cin;
+    tc = kg - tap * a.Cin;
+    const int kxy = tap / a.ks;
+    tz = tap - kxy * a.ks; tx = kxy / a.ks; ty = kxy - tx * a.ks;
+  } else if (MODE == kConvDgrad) {
+    tx = kg / a.Cout;
+    tc = kg - tx * a.Cout;
   }
-#define MF_NT_LOAD_B(i_, reg_)                                                                        \
+  // A masked chunk (padding tap, row past the edge, K tail) is a buffer load at an OUT-OF-RANGE offset: the hardware
+  // returns zeros (mf_common.h).  No select or AND on the loaded data (that was 44 VALU instructions per K-tile in
+  // every wave that touches a border -- nearly all of them in a 16^3 grid), and the stash is eight plain
+  // ds_write_b128.  The weight operand needs no mask at all: behind the K tail it re-reads k = 0 (finite; the A chunk
+  // there is zero), and a column past N re-reads row 0 into an accumulator column the epilogue never stores.
+  const mf::BufRsrc Ars = mf::make_rsrc(A), Wrs = mf::make_rsrc(W);
+#define MF_NT_LOAD_A(S, i_, reg_)                                                                     \
+  reg_ = mf::buf_load16(Ars, (mask[i_] & bits_) == bits_ ? 2u * (uint32_t)(base[i_] + off_) : mf::kBufMasked);
+#define MF_NT_LOAD_B(S, i_, reg_) reg_ = mf::buf_load16(Wrs, wrow[i_] + kofs_);
+#define MF_NT_FETCH(S)                                                                                \
   {                                                                                                   \
-    reg_ = ld16(wrow[i_] + (kin_ ? kg_ : 0));                                                         \
-    live |= ((kin_ && wok[i_]) ? 1u : 0u) << (8 + (i_));                                              \
-  }
-#define MF_NT_FETCH(kt_)                                                                              \
-  {                                                                                                   \
-    const int kg_ = (kt_) * kBK + 8 * chunk;                                                          \
-    const bool kin_ = kg_ + 8 <= a.K;                                                                 \
-    int off_ = kg_, bits_ = 1 << 12;                                                                  \
+    const bool kin_ = kg + 8 <= a.K;                                                                  \
+    const uint32_t kofs_ = kin_ ? 2u * (uint32_t)kg : 0u;                                             \
+    int off_ = kg, bits_ = 1 << 12;                                                                   \
     if (MODE == kConvFwd) {                                                                           \
-      const int tap = kg_ / a.Cin, c = kg_ - tap * a.Cin;                                             \
-      const int kxy = tap / a.ks, kz = tap - kxy * a.ks, kx = kxy / a.ks, ky = kxy - kx * a.ks;       \
-      off_ = ((kx * a.D + ky) * a.D + kz) * a.dil * a.Cin + c;                                        \
-      bits_ = kx < a.ks ? (1 << kx) | (16 << ky) | (256 << kz) | (1 << 12) : 1 << 13;                 \
+      off_ = ((tx * a.D + ty) * a.D + tz) * a.dil * a.Cin + tc;                                       \
+      bits_ = tx < a.ks ? (1 << tx) | (16 << ty) | (256 << tz) | (1 << 12) : 1 << 13;                 \
     } else if (MODE == kConvDgrad) {                                                                  \
-      const int slot = kg_ / a.Cout, co = kg_ - slot * a.Cout;                                        \
-      const int sx = slot & 1, sy = (slot >> 1) & 1, sz = slot >> 2;                                  \
-      off_ = co - ((sx * Do + sy) * Do + sz) * a.Cout;                                                \
+      const int sx = tx & 1, sy = (tx >> 1) & 1, sz = tx >> 2;                                        \
+      off_ = tc - ((sx * Do + sy) * Do + sz) * a.Cout;                                                \
       bits_ = (1 << sx) | (16 << sy) | (256 << sz) | (1 << 12);                                       \
     }                                                                                                 \
-    live = 0;                                                                                         \
-    MF_NT_LOAD_A(0, ra0) MF_NT_LOAD_A(1, ra1)                                                         \
-    if constexpr (MI == 2) { MF_NT_LOAD_A(2 * MI - 2, ra2) MF_NT_LOAD_A(2 * MI - 1, ra3) }            \
-    MF_NT_LOAD_B(0, rb0) MF_NT_LOAD_B(1, rb1) MF_NT_LOAD_B(2, rb2) MF_NT_LOAD_B(3, rb3)               \
+    if (!kin_) bits_ = 1 << 13; /* (no row has bit 13) */                                             \
+    MF_NT_LOAD_A(S, 0, ra0##S) MF_NT_LOAD_A(S, 1, ra1##S)                                             \
+    if constexpr (MI == 2) { MF_NT_LOAD_A(S, 2 * MI - 2, ra2##S) MF_NT_LOAD_A(S, 2 * MI - 1, ra3##S) } \
+    MF_NT_LOAD_B(S, 0, rb0##S) MF_NT_LOAD_B(S, 1, rb1##S) MF_NT_LOAD_B(S, 2, rb2##S) MF_NT_LOAD_B(S, 3, rb3##S) \
+    kg += kBK;                                                                                        \
+    if (MODE == kConvFwd) {                                                                           \
+      tc += kBK;                                                                                      \
+      while (tc >= a.Cin) {                                                                           \
+        tc -= a.Cin;                                                                                  \
+        if (++tz == a.ks) { tz = 0; if (++ty == a.ks) { ty = 0; ++tx; } }                             \
+      }                                                                                               \
+    } else if (MODE == kConvDgrad) {                                                                  \
+      tc += kBK;                                                                                      \
+      while (tc >= a.Cout) { tc -= a.Cout; ++tx; }                                                    \
+    }                                                                                                 \
   }
-#define MF_NT_PUT(ptr_, bit_, reg_) *reinterpret_cast<uint4 *>(ptr_) = keep16(reg_, live >> (bit_))
-#define MF_NT_STASH(buf_)                                                                             \
+  // (MF_HOLD: the staged registers stay opaque until here, BEHIND the MFMAs -- and with them the wait for the loads.)
+#define MF_NT_STASH(S, buf_)                                                                          \
   {                                                                                                   \
+    MF_HOLD(ra0##S); MF_HOLD(ra1##S); MF_HOLD(rb0##S); MF_HOLD(rb1##S); MF_HOLD(rb2##S); MF_HOLD(rb3##S); \
+    if constexpr (MI == 2) { MF_HOLD(ra2##S); MF_HOLD(ra3##S); }                                      \
     unsigned char *As_ = s_raw + (buf_) * kBuf + r0 * kPitch + 16 * chunk;                            \
     unsigned char *Bs_ = As_ + kBM * kPitch;                                                          \
-    MF_NT_PUT(As_, 0, ra0); MF_NT_PUT(As_ + 32 * kPitch, 1, ra1);                                     \
-    if constexpr (MI == 2) { MF_NT_PUT(As_ + 64 * kPitch, 2, ra2); MF_NT_PUT(As_ + 96 * kPitch, 3, ra3); } \
-    MF_NT_PUT(Bs_, 8, rb0); MF_NT_PUT(Bs_ + 32 * kPitch, 9, rb1);                                     \
-    MF_NT_PUT(Bs_ + 64 * kPitch, 10, rb2); MF_NT_PUT(Bs_ + 96 * kPitch, 11, rb3);                     \
+    *reinterpret_cast<uint4 *>(As_) = ra0##S; *reinterpret_cast<uint4 *>(As_ + 32 * kPitch) = ra1##S; \
+    if constexpr (MI == 2) {                                                                          \
+      *reinterpret_cast<uint4 *>(As_ + 64 * kPitch) = ra2##S; *reinterpret_cast<uint4 *>(As_ + 96 * kPitch) = ra3##S; \
+    }                                                                                                 \
+    *reinterpret_cast<uint4 *>(Bs_) = rb0##S; *reinterpret_cast<uint4 *>(Bs_ + 32 * kPitch) = rb1##S; \
+    *reinterpret_cast<uint4 *>(Bs_ + 64 * kPitch) = rb2##S; *reinterpret_cast<uint4 *>(Bs_ + 96 * kPitch) = rb3##S; \
   }
-  MF_NT_FETCH(0);
-  MF_NT_STASH(0);
+#define MF_NT_COMPUTE(buf_)                                                                           \
+  {                                                                                                   \
+    asm volatile("" ::: "memory");                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    const unsigned char *As = s_raw + (buf_) * kBuf + (wm * 32 * MI + lrow) * kPitch + 16 * lhalf;    \
+    const unsigned char *Bs = s_raw + (buf_) * kBuf + (kBM + wn * 64 + lrow) * kPitch + 16 * lhalf;   \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
+      const uint4 a0 = *reinterpret_cast<const uint4 *>(As + 32 * s);                                 \
+      const uint4 b0 = *reinterpret_cast<const uint4 *>(Bs + 32 * s);                                 \
+      const uint4 b1 = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * s);                   \
+      acc[0][0] = mf::mfma_bf16_32x32x16(a0, b0, acc[0][0]);                                          \
+      acc[0][1] = mf::mfma_bf16_32x32x16(a0, b1, acc[0][1]);                                          \
+      if constexpr (MI == 2) {                                                                        \
+        const uint4 a1 = *reinterpret_cast<const uint4 *>(As + 32 * kPitch + 32 * s);                 \
+        acc[MI - 1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[MI - 1][0]);                              \
+        acc[MI - 1][1] = mf::mfma_bf16_32x32x16(a1, b1, acc[MI - 1][1]);                              \
+      }                                                                                               \
+    }                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  }
+  // Per K-tile t: the loads of tile t + 1 are issued, tile t is multiplied, the registers go into the other buffer,
+  // barrier.  (Stash AFTER the barrier and the next fetch right behind it -- the order the 256^2-tile GEMMs of the
+  // programming guide prefer -- measured 3 - 5 % slower here, at 2 workgroups per CU.)  The fetches run over the
+  // K-tiles in order, one past the last (k beyond K: every chunk masked, zeros into the buffer nobody reads again) --
+  // NOT under "if (t + 1 < T)": behind a branch the compiler copies the loaded registers at the join and waits for
+  // the loads right where they are issued (measured: 2x slower).
+  MF_NT_FETCH(P);  // tile 0
+  MF_NT_STASH(P, 0);
   __syncthreads();
   for (int t = 0; t < T; ++t) {
-    MF_NT_FETCH(t + 1 < T ? t + 1 : t);  // (the last iteration re-fetches its own tile: branch-free body)
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned char *As = s_raw + (t & 1) * kBuf + (wm * 32 * MI + lrow) * kPitch + 16 * lhalf;
-    const unsigned char *Bs = s_raw + (t & 1) * kBuf + (kBM + wn * 64 + lrow) * kPitch + 16 * lhalf;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const uint4 a0 = *reinterpret_cast<const uint4 *>(As + 32 * s);
-      const uint4 b0 = *reinterpret_cast<const uint4 *>(Bs + 32 * s);
-      const uint4 b1 = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * s);
-      acc[0][0] = mf::mfma_bf16_32x32x16(a0, b0, acc[0][0]);
-      acc[0][1] = mf::mfma_bf16_32x32x16(a0, b1, acc[0][1]);
-      if constexpr (MI == 2) {
-        const uint4 a1 = *reinterpret_cast<const uint4 *>(As + 32 * kPitch + 32 * s);
-        acc[MI - 1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[MI - 1][0]);
-        acc[MI - 1][1] = mf::mfma_bf16_32x32x16(a1, b1, acc[MI - 1][1]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);  // (the stash -- and with it the wait for the loads -- stays BEHIND the MFMAs)
-    MF_HOLD(ra0); MF_HOLD(ra1); MF_HOLD(rb0); MF_HOLD(rb1); MF_HOLD(rb2); MF_HOLD(rb3);
-    if constexpr (MI == 2) { MF_HOLD(ra2); MF_HOLD(ra3); }
-    MF_NT_STASH((t + 1) & 1);
+    MF_NT_FETCH(P);  // tile t + 1 in flight under the MFMAs of tile t
+    MF_NT_COMPUTE(t & 1);
+    MF_NT_STASH(P, (t + 1) & 1);
     __syncthreads();
   }
+#undef MF_NT_COMPUTE
 #undef MF_NT_STASH
-#undef MF_NT_PUT
 #undef MF_NT_FETCH
 #undef MF_NT_LOAD_B
 #undef MF_NT_LOAD_A
@@ -300,15 +330,17 @@ struct TnArgs {
   int64_t p_gs, q_gs, c_gs;
   int M, Ni, Nj, ldp, ldq, ldc, groups, S;
   int conv, B, D, Do, olog, Cin, ks, stride, pad, dil;  // conv: Q(m, j = tap * Cin + cin) = x[b][stride o - pad + dil tap][cin], m = (b, o)
-  int shift;                  // bank shift per 16 image rows (bytes): always 64.  A kernel ARGUMENT on purpose: with the
+  int shift;                  // bank shift per 16 image rows (bytes): always 32.  A kernel ARGUMENT on purpose: with the
                               // shift folded in as a constant, hipcc (ROCm 7.2, -O3) produced a kernel that was exact in
                               // the emulator's g++ build and wrong on the MI355X for image rows 62..65 (round 4,
                               // tests/test_gpu_bf16_kernels.py caught it); as a run-time value it is a plain multiply-add
 };
 
-// Byte offset of row i of a transposed operand image.  Groups of 16 rows are shifted by 16 banks against each other
-// (rows 8 c + e, c = 0..7, of one staging store then spread over all 64 banks: 2 lanes per bank, the minimum for
-// 512 bytes), and the second 64 rows by a whole bank sweep so that the shifted groups never overlap.
+// Byte offset of row i of a transposed operand image.  Groups of 16 rows are shifted by ``shift`` = 32 bytes (8 banks)
+// against each other: a staging store writes rows 8 c + e for 8 consecutive c -- row stride 8 x 144 B = 32 banks mod 64,
+// so without the shift the eight rows start at only two bank positions; with 8 banks per pair of c they start at
+// {0, 32, 8, 40, 16, 48, 24, 56}: each half-wave (4 m-groups x 8 bytes per row) hits 64 distinct banks.  (A shift of
+// 16 banks measured 0.67 conflict cycles per LDS cycle: the bases repeat after four pairs.)
 __device__ __forceinline__ int tn_phys(int row, int shift) { return row * kPitch + (row >> 4) * shift; }
 
 // rows r = 0..3 (four consecutive m) x 8 columns -> eight 8-byte column vectors (m0..m3 of one column)
@@ -350,15 +382,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
   const uint16_t *P = a.P + grp * a.p_gs;
   const uint16_t *Q = a.Q + grp * a.q_gs;
   const int Do = a.Do, dol = a.olog;
-  const bool pcol_ok = i0 + 8 * c + 8 <= a.Ni, qcol_ok = j0 + 8 * c + 8 <= a.Nj;
-  // conv: this lane's column chunk is one (tap, cin .. cin + 7) for the whole loop
-  int q_off = j0 + 8 * c, q_bits = 1 << 12;
+  const bool pcol_ok = i0 + 8 * c + 8 <= a.Ni;
+  // conv: this lane's column chunk is one (tap, cin .. cin + 7) for the whole loop: tap coordinate offsets from the
+  // row's first tap (stride * o - pad), first channel; a chunk past the last tap is never valid
+  const int q_off = j0 + 8 * c;
+  int tap_x = 0, tap_y = 0, tap_z = 0, tap_c = 0;
+  bool qcol_ok = j0 + 8 * c + 8 <= a.Nj;
   if (a.conv) {
     const int jj = qcol_ok ? j0 + 8 * c : 0;
-    const int tap = jj / a.Cin, ci = jj - tap * a.Cin;
+    const int tap = jj / a.Cin;
+    tap_c = jj - tap * a.Cin;
     const int kxy = tap / a.ks, kz = tap - kxy * a.ks, kx = kxy / a.ks, ky = kxy - kx * a.ks;
-    q_off = ((kx * a.D + ky) * a.D + kz) * a.dil * a.Cin + ci;
-    q_bits = (1 << kx) | (16 << ky) | (256 << kz) | (1 << 12);
+    tap_x = a.dil * kx - a.pad; tap_y = a.dil * ky - a.pad; tap_z = a.dil * kz - a.pad;
+    qcol_ok = qcol_ok && kx < a.ks;
   }
 
   mf_f32x16 acc[2][2];
@@ -369,9 +405,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  uint4 rp0, rp1, rp2, rp3, rq0, rq1, rq2, rq3;
-  unsigned live = 0;  // bit r: rp<r> is a real chunk, bit 4 + r: rq<r> (zeroed in the stash, see the NT kernel)
-#define MF_TN_LOAD(r_, rp_, rq_)                                                                      \
+  // two register sets (P: even K-tiles + 1, Q: odd): a two-tile prefetch distance, as in the NT kernel
+  uint4 rp0P, rp1P, rp2P, rp3P, rq0P, rq1P, rq2P, rq3P;
+  uint4 rp0Q, rp1Q, rp2Q, rp3Q, rq0Q, rq1Q, rq2Q, rq3Q;
+  unsigned liveP = 0, liveQ = 0;  // bit r: rp<r> is a real chunk, bit 4 + r: rq<r> (zeroed in the stash, see the NT kernel)
+#define MF_TN_LOAD(S, r_, rp_, rq_)                                                                   \
   {                                                                                                   \
     const int m_ = t_ * 64 + 4 * mg + (r_);                                                           \
     const bool ok_ = m_ < a.M;                                                                        \
@@ -380,76 +418,82 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
     rp_ = ld16(P + (pok_ ? mm_ * a.ldp + i0 + 8 * c : 0));                                            \
     bool qok_ = ok_ && qcol_ok;                                                                       \
     int qaddr_ = mm_ * a.ldq + q_off;                                                                 \
-    if (a.conv) {                                                                                     \
+    if (a.conv) { /* this lane's tap is fixed for the whole loop: only its coordinate per row is left */   \
       const int b_ = mm_ >> (3 * dol), o_ = mm_ & ((1 << (3 * dol)) - 1);                             \
-      const int x0 = a.stride * (o_ >> (2 * dol)) - a.pad, y0 = a.stride * ((o_ >> dol) & (Do - 1)) - a.pad, \
-                z0 = a.stride * (o_ & (Do - 1)) - a.pad;                                              \
-      int mk = 1 << 12;                                                                               \
-      _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                 \
-        mk |= ((unsigned)(x0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << k;                              \
-        mk |= ((unsigned)(y0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (4 + k);                        \
-        mk |= ((unsigned)(z0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (8 + k);                        \
-      }                                                                                               \
-      qok_ = qok_ && (mk & q_bits) == q_bits;                                                         \
-      qaddr_ = (((b_ * a.D + x0) * a.D + y0) * a.D + z0) * a.Cin + q_off;                             \
+      const int X_ = a.stride * (o_ >> (2 * dol)) + tap_x, Y_ = a.stride * ((o_ >> dol) & (Do - 1)) + tap_y, \
+                Z_ = a.stride * (o_ & (Do - 1)) + tap_z;                                              \
+      qok_ = qok_ && (unsigned)X_ < (unsigned)a.D && (unsigned)Y_ < (unsigned)a.D && (unsigned)Z_ < (unsigned)a.D; \
+      qaddr_ = (((b_ * a.D + X_) * a.D + Y_) * a.D + Z_) * a.Cin + tap_c;                             \
     }                                                                                                 \
     rq_ = ld16(Q + (qok_ ? qaddr_ : 0));                                                              \
-    live |= (pok_ ? 1u : 0u) << (r_) | (qok_ ? 1u : 0u) << (4 + (r_));                                \
+    live##S |= (pok_ ? 1u : 0u) << (r_) | (qok_ ? 1u : 0u) << (4 + (r_));                             \
   }
-#define MF_TN_FETCH(tt_)                                                                              \
+#define MF_TN_FETCH(S, tt_)                                                                           \
   {                                                                                                   \
     const int t_ = (tt_);                                                                             \
-    live = 0;                                                                                         \
-    MF_TN_LOAD(0, rp0, rq0) MF_TN_LOAD(1, rp1, rq1) MF_TN_LOAD(2, rp2, rq2) MF_TN_LOAD(3, rp3, rq3)   \
+    live##S = 0;                                                                                      \
+    MF_TN_LOAD(S, 0, rp0##S, rq0##S) MF_TN_LOAD(S, 1, rp1##S, rq1##S)                                 \
+    MF_TN_LOAD(S, 2, rp2##S, rq2##S) MF_TN_LOAD(S, 3, rp3##S, rq3##S)                                 \
   }
-#define MF_TN_SEL(bit_, reg_) keep16(reg_, live >> (bit_))
-#define MF_TN_STASH(buf_)                                                                             \
+#define MF_TN_SEL(S, bit_, reg_) keep16(reg_, live##S >> (bit_))
+#define MF_TN_STASH(S, buf_)                                                                          \
   {                                                                                                   \
+    MF_HOLD(rp0##S); MF_HOLD(rp1##S); MF_HOLD(rp2##S); MF_HOLD(rp3##S);                               \
+    MF_HOLD(rq0##S); MF_HOLD(rq1##S); MF_HOLD(rq2##S); MF_HOLD(rq3##S);                               \
     uint2 col[8];                                                                                     \
     unsigned char *Ps_ = s_raw + (buf_) * kTnBuf + 8 * mg;                                            \
     {                                                                                                 \
-      const uint4 t4[4] = {MF_TN_SEL(0, rp0), MF_TN_SEL(1, rp1), MF_TN_SEL(2, rp2), MF_TN_SEL(3, rp3)}; \
+      const uint4 t4[4] = {MF_TN_SEL(S, 0, rp0##S), MF_TN_SEL(S, 1, rp1##S), MF_TN_SEL(S, 2, rp2##S), MF_TN_SEL(S, 3, rp3##S)}; \
       transpose4x8(t4, col);                                                                          \
     }                                                                                                 \
     _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                     \
         *reinterpret_cast<uint2 *>(Ps_ + tn_phys(8 * c + e, a.shift)) = col[e];                       \
     {                                                                                                 \
-      const uint4 t4[4] = {MF_TN_SEL(4, rq0), MF_TN_SEL(5, rq1), MF_TN_SEL(6, rq2), MF_TN_SEL(7, rq3)}; \
+      const uint4 t4[4] = {MF_TN_SEL(S, 4, rq0##S), MF_TN_SEL(S, 5, rq1##S), MF_TN_SEL(S, 6, rq2##S), MF_TN_SEL(S, 7, rq3##S)}; \
       transpose4x8(t4, col);                                                                          \
     }                                                                                                 \
     _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                     \
         *reinterpret_cast<uint2 *>(Ps_ + kTnOperand + tn_phys(8 * c + e, a.shift)) = col[e];          \
   }
+#define MF_TN_COMPUTE(buf_)                                                                           \
+  {                                                                                                   \
+    asm volatile("" ::: "memory");                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    const unsigned char *Ps = s_raw + (buf_) * kTnBuf + 16 * lhalf;                                   \
+    const unsigned char *Qs = Ps + kTnOperand;                                                        \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
+      const uint4 a0 = *reinterpret_cast<const uint4 *>(Ps + pa0 + 32 * s);                           \
+      const uint4 a1 = *reinterpret_cast<const uint4 *>(Ps + pa1 + 32 * s);                           \
+      const uint4 b0 = *reinterpret_cast<const uint4 *>(Qs + qb0 + 32 * s);                           \
+      const uint4 b1 = *reinterpret_cast<const uint4 *>(Qs + qb1 + 32 * s);                           \
+      acc[0][0] = mf::mfma_bf16_32x32x16(a0, b0, acc[0][0]);                                          \
+      acc[0][1] = mf::mfma_bf16_32x32x16(a0, b1, acc[0][1]);                                          \
+      acc[1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[1][0]);                                          \
+      acc[1][1] = mf::mfma_bf16_32x32x16(a1, b1, acc[1][1]);                                          \
+    }                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  }
+  const int pa0 = tn_phys(wm * 64 + lrow, a.shift), pa1 = tn_phys(wm * 64 + 32 + lrow, a.shift);
+  const int qb0 = tn_phys(wn * 64 + lrow, a.shift), qb1 = tn_phys(wn * 64 + 32 + lrow, a.shift);
+  const int tl = t1 - 1;  // (tile indices past the end re-fetch the last tile)
   if (t0 < t1) {
-    MF_TN_FETCH(t0);
-    MF_TN_STASH(0);
+    MF_TN_FETCH(P, t0);
+    MF_TN_STASH(P, 0);
+    MF_TN_FETCH(P, min(t0 + 1, tl));
   }
   __syncthreads();
-  for (int t = t0; t < t1; ++t) {
-    const int buf = (t - t0) & 1;
-    MF_TN_FETCH(t + 1 < t1 ? t + 1 : t);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned char *Ps = s_raw + buf * kTnBuf + 16 * lhalf;
-    const unsigned char *Qs = Ps + kTnOperand;
-    const int pa0 = tn_phys(wm * 64 + lrow, a.shift), pa1 = tn_phys(wm * 64 + 32 + lrow, a.shift);
-    const int qb0 = tn_phys(wn * 64 + lrow, a.shift), qb1 = tn_phys(wn * 64 + 32 + lrow, a.shift);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const uint4 a0 = *reinterpret_cast<const uint4 *>(Ps + pa0 + 32 * s);
-      const uint4 a1 = *reinterpret_cast<const uint4 *>(Ps + pa1 + 32 * s);
-      const uint4 b0 = *reinterpret_cast<const uint4 *>(Qs + qb0 + 32 * s);
-      const uint4 b1 = *reinterpret_cast<const uint4 *>(Qs + qb1 + 32 * s);
-      acc[0][0] = mf::mfma_bf16_32x32x16(a0, b0, acc[0][0]);
-      acc[0][1] = mf::mfma_bf16_32x32x16(a0, b1, acc[0][1]);
-      acc[1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[1][0]);
-      acc[1][1] = mf::mfma_bf16_32x32x16(a1, b1, acc[1][1]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    MF_HOLD(rp0); MF_HOLD(rp1); MF_HOLD(rp2); MF_HOLD(rp3); MF_HOLD(rq0); MF_HOLD(rq1); MF_HOLD(rq2); MF_HOLD(rq3);
-    MF_TN_STASH(buf ^ 1);
+  for (int t = t0; t < t1; t += 2) {
+    MF_TN_FETCH(Q, min(t + 2, tl));
+    MF_TN_COMPUTE(0);
+    MF_TN_STASH(P, 1);
+    __syncthreads();
+    if (t + 1 >= t1) break;  // block-uniform
+    MF_TN_FETCH(P, min(t + 3, tl));
+    MF_TN_COMPUTE(1);
+    MF_TN_STASH(Q, 0);
     __syncthreads();
   }
+#undef MF_TN_COMPUTE
 #undef MF_TN_STASH
 #undef MF_TN_SEL
 #undef MF_TN_FETCH
@@ -670,7 +714,7 @@ extern "C" int mf_linear_wgrad_bf16(const void *dY, int64_t y_gs, int32_t ldy, c
   a.P = (const uint16_t *)dY; a.Q = (const uint16_t *)A; a.out = split > 1 ? (float *)ws : dW;
   a.p_gs = y_gs; a.q_gs = a_gs; a.c_gs = w_gs;
   a.M = M; a.Ni = N; a.Nj = K; a.ldp = ldy; a.ldq = lda; a.ldc = ldc; a.groups = groups; a.S = split;
-  a.shift = 64;
+  a.shift = 32;
   const int64_t grid = (int64_t)((N + 127) / 128) * ((K + 127) / 128) * groups * split;
   hipLaunchKernelGGL(k_gemm_tn_bf16, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
   if (split > 1) {
@@ -779,7 +823,7 @@ extern "C" int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, vo
   a.S = split;
   a.conv = 1; a.B = B; a.D = D; a.Do = g.Do; a.olog = g.olog; a.Cin = Cin;
   a.ks = ks; a.stride = stride; a.pad = pad; a.dil = dil;
-  a.shift = 64;
+  a.shift = 32;
   // (S == 1 also goes through the workspace: the finish pass permutes (tap, cin) -> (cin, tap))
   const int64_t grid = (int64_t)((Cout + 127) / 128) * ((g.taps * Cin + 127) / 128) * a.S;
   hipLaunchKernelGGL(k_gemm_tn_bf16, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);

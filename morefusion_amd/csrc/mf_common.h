@@ -46,6 +46,26 @@ constexpr int kWave = 64;
 // in front of the MFMAs the load is meant to overlap.  (tests/host_emul/mf_common.h: a no-op.)
 #define MF_HOLD(r_) asm volatile("" : "+v"(r_.x), "+v"(r_.y), "+v"(r_.z), "+v"(r_.w))
 
+// ---- buffer loads with a hardware range check (round 4: the masked operand chunks of csrc/gemm_bf16.hip) -----------
+// A raw buffer resource over [p, p + kBufSpan): buf_load16(rs, off) is one buffer_load_dwordx4 at byte offset `off`;
+// an offset >= kBufSpan -- kBufMasked -- is out of range and the hardware returns ZEROS without touching memory.
+// A masked lane therefore costs one v_cndmask on its 32-bit offset: no pointer select, no AND on the loaded data.
+// (Real offsets must stay below 2^31 bytes: the callers' tensors do.)
+constexpr uint32_t kBufSpan = 0x80000000u, kBufMasked = 0x80000000u;
+struct BufRsrc {
+  __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ BufRsrc make_rsrc(const void *p) {
+  BufRsrc b;
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, kBufSpan, 0x00020000);
+  return b;
+}
+__device__ __forceinline__ uint4 buf_load16(const BufRsrc &b, uint32_t byte_off) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)byte_off, 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // dynamic LDS of the workgroup (tests/host_emul/mf_common.h gives the host-emulation form)
 #define MF_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 

@@ -469,6 +469,17 @@ inline int fill_bytes(void *dst, int value, int64_t nbytes, hipStream_t st) {  /
   mf_emul::enqueue(st, [=]() { memset(dst, value, (size_t)nbytes); });
   return 0;
 }
+// csrc/mf_common.h's range-checked buffer loads: out of range reads as zeros and touches nothing
+constexpr uint32_t kBufSpan = 0x80000000u, kBufMasked = 0x80000000u;
+struct BufRsrc {
+  const unsigned char *p;
+};
+inline BufRsrc make_rsrc(const void *p) { return BufRsrc{static_cast<const unsigned char *>(p)}; }
+inline uint4 buf_load16(const BufRsrc &b, uint32_t byte_off) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (byte_off < kBufSpan && byte_off + 16u <= kBufSpan) memcpy(&v, b.p + byte_off, 16);
+  return v;
+}
 constexpr int kWave = 64;
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline float voxel_coord(float p, float o, float pitch) { return (p - o) / pitch; }
