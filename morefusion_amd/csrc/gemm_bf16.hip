@@ -53,14 +53,6 @@ struct NtArgs {
   int B, D, Do, olog, Cin, Cout, ks, stride, pad, dil;
 };
 
-__device__ __forceinline__ uint4 ld16(const uint16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
-
-// r if bit 0 of ``flag`` is set, else zeros -- as four ANDs with an all-ones / all-zero mask (written as a 128-bit
-// select the compiler built a two-entry table in scratch memory and indexed it)
-__device__ __forceinline__ uint4 keep16(uint4 r, unsigned flag) {
-  const uint32_t m = 0u - (flag & 1u);
-  return make_uint4(r.x & m, r.y & m, r.z & m, r.w & m);
-}
 
 template <int MODE, int MI>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
@@ -319,7 +311,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
 }
 
 // ---- TN engine: C[i][j] = sum_m P[m][i] * Q(m, j) -------------------------------------------------------------
-constexpr int kTnOperand = 128 * kPitch + 512;  // transposed image of one operand, rows at tn_phys(i)
+// Both operands arrive with the reduction index m as the SLOW dimension (rows of dY, rows of x / of the im2col view),
+// the MFMA wants 8 consecutive m per lane.  The LDS image keeps the global order -- 16-byte chunks land with a plain
+// ds_write_b128 -- and the fragments come out through gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane
+// group reads a [4 m][16 columns] block, lane c receives column c).  Round 4's first version transposed 4 x 8 blocks
+// in registers on the way in: 17 VALU instructions per MFMA and LDS bank conflicts on half of the LDS cycles.
+//   image of one operand: 8 subtiles of 16 columns, each [64 m][16] bf16 (32 bytes per m) + 128 bytes, so that two
+//   neighbouring subtiles -- the two 16-lane groups of a half-wave -- sit 32 banks apart
+constexpr int kTnSub = 64 * 32 + 128;
+constexpr int kTnOperand = 8 * kTnSub;
 constexpr int kTnBuf = 2 * kTnOperand;
 constexpr int kTnLds = 2 * kTnBuf > 128 * (128 + 4) * 4 ? 2 * kTnBuf : 128 * (128 + 4) * 4;
 
@@ -330,32 +330,9 @@ struct TnArgs {
   int64_t p_gs, q_gs, c_gs;
   int M, Ni, Nj, ldp, ldq, ldc, groups, S;
   int conv, B, D, Do, olog, Cin, ks, stride, pad, dil;  // conv: Q(m, j = tap * Cin + cin) = x[b][stride o - pad + dil tap][cin], m = (b, o)
-  int shift;                  // bank shift per 16 image rows (bytes): always 32.  A kernel ARGUMENT on purpose: with the
-                              // shift folded in as a constant, hipcc (ROCm 7.2, -O3) produced a kernel that was exact in
-                              // the emulator's g++ build and wrong on the MI355X for image rows 62..65 (round 4,
-                              // tests/test_gpu_bf16_kernels.py caught it); as a run-time value it is a plain multiply-add
 };
 
-// Byte offset of row i of a transposed operand image.  Groups of 16 rows are shifted by ``shift`` = 32 bytes (8 banks)
-// against each other: a staging store writes rows 8 c + e for 8 consecutive c -- row stride 8 x 144 B = 32 banks mod 64,
-// so without the shift the eight rows start at only two bank positions; with 8 banks per pair of c they start at
-// {0, 32, 8, 40, 16, 48, 24, 56}: each half-wave (4 m-groups x 8 bytes per row) hits 64 distinct banks.  (A shift of
-// 16 banks measured 0.67 conflict cycles per LDS cycle: the bases repeat after four pairs.)
-__device__ __forceinline__ int tn_phys(int row, int shift) { return row * kPitch + (row >> 4) * shift; }
-
-// rows r = 0..3 (four consecutive m) x 8 columns -> eight 8-byte column vectors (m0..m3 of one column)
-__device__ __forceinline__ void transpose4x8(const uint4 r[4], uint2 out[8]) {
-  const uint32_t w[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w},
-                            {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    out[2 * d].x = (w[0][d] & 0xffffu) | (w[1][d] << 16);
-    out[2 * d].y = (w[2][d] & 0xffffu) | (w[3][d] << 16);
-    out[2 * d + 1].x = (w[0][d] >> 16) | (w[1][d] & 0xffff0000u);
-    out[2 * d + 1].y = (w[2][d] >> 16) | (w[3][d] & 0xffff0000u);
-  }
-}
-
+template <bool CONV>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
   MF_DYN_LDS(unsigned char, s_raw);
   const int tiles_i = (a.Ni + 127) / 128, tiles_j = (a.Nj + 127) / 128;
@@ -376,25 +353,47 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave & 1, wn = wave >> 1;
   const int lrow = lane & 31, lhalf = lane >> 5;
-  // staging block of this lane: rows 4 mg .. + 3 of the K-tile, columns 8 c .. + 7 of the 128-wide operand tile
-  const int c = 8 * (wave & 1) + (lane & 7), mg = 8 * (wave >> 1) + (lane >> 3);
+  // staging: load r (0..3) of this lane is row 16 r + 4 wave + kr of the K-tile, columns 16 sub + 8 half .. + 7.  Eight
+  // consecutive lanes (the unit a ds_write_b128 is served in) fill 4 rows x 32 bytes = 128 contiguous bytes of one
+  // subtile: 32 distinct banks; a wave's load covers 4 rows x 256 contiguous bytes.
+  const int half = lane & 1, kr = (lane >> 1) & 3, sub = lane >> 3;
+  const int col = 16 * sub + 8 * half;
+  const int st_off = sub * kTnSub + (4 * wave + kr) * 32 + 16 * half;  // + 512 r
 
   const uint16_t *P = a.P + grp * a.p_gs;
   const uint16_t *Q = a.Q + grp * a.q_gs;
   const int Do = a.Do, dol = a.olog;
-  const bool pcol_ok = i0 + 8 * c + 8 <= a.Ni;
-  // conv: this lane's column chunk is one (tap, cin .. cin + 7) for the whole loop: tap coordinate offsets from the
-  // row's first tap (stride * o - pad), first channel; a chunk past the last tap is never valid
-  const int q_off = j0 + 8 * c;
-  int tap_x = 0, tap_y = 0, tap_z = 0, tap_c = 0;
-  bool qcol_ok = j0 + 8 * c + 8 <= a.Nj;
-  if (a.conv) {
-    const int jj = qcol_ok ? j0 + 8 * c : 0;
-    const int tap = jj / a.Cin;
-    tap_c = jj - tap * a.Cin;
+  const bool pcol_ok = i0 + col + 8 <= a.Ni;
+  // conv: this lane's column chunk is one (tap, cin .. cin + 7) for the whole loop, so per row only the output voxel
+  // (b, ox, oy, oz) is decoded: the address is linear in it, and "the tap lies inside the grid" is one range test per
+  // axis on the output coordinate (lo <= o <= lo + span, as one unsigned compare); a chunk past the last tap, or a
+  // tap no output voxel can reach, is never valid
+  const int q_off = j0 + col;
+  int tap_const = 0, lo_x = 0, lo_y = 0, lo_z = 0;
+  unsigned span_x = 0, span_y = 0, span_z = 0;
+  bool qcol_ok = j0 + col + 8 <= a.Nj;
+  const int cxs = a.stride * a.D * a.D * a.Cin, cys = a.stride * a.D * a.Cin, czs = a.stride * a.Cin;
+  const int cb = a.D * a.D * a.D * a.Cin;
+  if (CONV) {
+    const int jj = qcol_ok ? j0 + col : 0;
+    const int tap = jj / a.Cin, tap_c = jj - tap * a.Cin;
     const int kxy = tap / a.ks, kz = tap - kxy * a.ks, kx = kxy / a.ks, ky = kxy - kx * a.ks;
-    tap_x = a.dil * kx - a.pad; tap_y = a.dil * ky - a.pad; tap_z = a.dil * kz - a.pad;
+    const int tx = a.dil * kx - a.pad, ty = a.dil * ky - a.pad, tz = a.dil * kz - a.pad;
+    tap_const = ((tx * a.D + ty) * a.D + tz) * a.Cin + tap_c;
     qcol_ok = qcol_ok && kx < a.ks;
+    const int t3[3] = {tx, ty, tz};
+    int lo3[3];
+    unsigned sp3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // 0 <= stride * o + t < D
+      const int lo = t3[k] >= 0 ? 0 : (-t3[k] + a.stride - 1) / a.stride;
+      const int hi = a.D - 1 - t3[k] >= 0 ? min((a.D - 1 - t3[k]) / a.stride, Do - 1) : -1;
+      qcol_ok = qcol_ok && hi >= lo;
+      lo3[k] = lo;
+      sp3[k] = (unsigned)max(hi - lo, 0);
+    }
+    lo_x = lo3[0]; lo_y = lo3[1]; lo_z = lo3[2];
+    span_x = sp3[0]; span_y = sp3[1]; span_z = sp3[2];
   }
 
   mf_f32x16 acc[2][2];
@@ -405,67 +404,56 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  // two register sets (P: even K-tiles + 1, Q: odd): a two-tile prefetch distance, as in the NT kernel
-  uint4 rp0P, rp1P, rp2P, rp3P, rq0P, rq1P, rq2P, rq3P;
-  uint4 rp0Q, rp1Q, rp2Q, rp3Q, rq0Q, rq1Q, rq2Q, rq3Q;
-  unsigned liveP = 0, liveQ = 0;  // bit r: rp<r> is a real chunk, bit 4 + r: rq<r> (zeroed in the stash, see the NT kernel)
-#define MF_TN_LOAD(S, r_, rp_, rq_)                                                                   \
+  // one register set, one tile ahead; a masked chunk (row past M, column past the edge, padding tap) is a buffer
+  // load at an out-of-range offset and comes back as zeros (see the NT kernel)
+  const mf::BufRsrc Prs = mf::make_rsrc(P), Qrs = mf::make_rsrc(Q);
+  uint4 rp0, rp1, rp2, rp3, rq0, rq1, rq2, rq3;
+#define MF_TN_LOAD(r_, rp_, rq_)                                                                      \
   {                                                                                                   \
-    const int m_ = t_ * 64 + 4 * mg + (r_);                                                           \
+    const int m_ = t_ * 64 + 16 * (r_) + 4 * wave + kr;                                               \
     const bool ok_ = m_ < a.M;                                                                        \
-    const int mm_ = ok_ ? m_ : 0;                                                                     \
-    const bool pok_ = ok_ && pcol_ok;                                                                 \
-    rp_ = ld16(P + (pok_ ? mm_ * a.ldp + i0 + 8 * c : 0));                                            \
+    rp_ = mf::buf_load16(Prs, ok_ && pcol_ok ? 2u * (uint32_t)(m_ * a.ldp + i0 + col) : mf::kBufMasked); \
     bool qok_ = ok_ && qcol_ok;                                                                       \
-    int qaddr_ = mm_ * a.ldq + q_off;                                                                 \
-    if (a.conv) { /* this lane's tap is fixed for the whole loop: only its coordinate per row is left */   \
-      const int b_ = mm_ >> (3 * dol), o_ = mm_ & ((1 << (3 * dol)) - 1);                             \
-      const int X_ = a.stride * (o_ >> (2 * dol)) + tap_x, Y_ = a.stride * ((o_ >> dol) & (Do - 1)) + tap_y, \
-                Z_ = a.stride * (o_ & (Do - 1)) + tap_z;                                              \
-      qok_ = qok_ && (unsigned)X_ < (unsigned)a.D && (unsigned)Y_ < (unsigned)a.D && (unsigned)Z_ < (unsigned)a.D; \
-      qaddr_ = (((b_ * a.D + X_) * a.D + Y_) * a.D + Z_) * a.Cin + tap_c;                             \
+    int qaddr_ = m_ * a.ldq + q_off;                                                                  \
+    if (CONV) {                                                                                       \
+      const int b_ = m_ >> (3 * dol), ox_ = (m_ >> (2 * dol)) & (Do - 1), oy_ = (m_ >> dol) & (Do - 1), \
+                oz_ = m_ & (Do - 1);                                                                  \
+      qok_ = qok_ && (unsigned)(ox_ - lo_x) <= span_x && (unsigned)(oy_ - lo_y) <= span_y &&          \
+             (unsigned)(oz_ - lo_z) <= span_z;                                                        \
+      qaddr_ = tap_const + b_ * cb + ox_ * cxs + oy_ * cys + oz_ * czs;                               \
     }                                                                                                 \
-    rq_ = ld16(Q + (qok_ ? qaddr_ : 0));                                                              \
-    live##S |= (pok_ ? 1u : 0u) << (r_) | (qok_ ? 1u : 0u) << (4 + (r_));                             \
+    rq_ = mf::buf_load16(Qrs, qok_ ? 2u * (uint32_t)qaddr_ : mf::kBufMasked);                         \
   }
-#define MF_TN_FETCH(S, tt_)                                                                           \
+#define MF_TN_FETCH(tt_)                                                                              \
   {                                                                                                   \
     const int t_ = (tt_);                                                                             \
-    live##S = 0;                                                                                      \
-    MF_TN_LOAD(S, 0, rp0##S, rq0##S) MF_TN_LOAD(S, 1, rp1##S, rq1##S)                                 \
-    MF_TN_LOAD(S, 2, rp2##S, rq2##S) MF_TN_LOAD(S, 3, rp3##S, rq3##S)                                 \
+    MF_TN_LOAD(0, rp0, rq0) MF_TN_LOAD(1, rp1, rq1) MF_TN_LOAD(2, rp2, rq2) MF_TN_LOAD(3, rp3, rq3)   \
   }
-#define MF_TN_SEL(S, bit_, reg_) keep16(reg_, live##S >> (bit_))
-#define MF_TN_STASH(S, buf_)                                                                          \
+#define MF_TN_STASH(buf_)                                                                             \
   {                                                                                                   \
-    MF_HOLD(rp0##S); MF_HOLD(rp1##S); MF_HOLD(rp2##S); MF_HOLD(rp3##S);                               \
-    MF_HOLD(rq0##S); MF_HOLD(rq1##S); MF_HOLD(rq2##S); MF_HOLD(rq3##S);                               \
-    uint2 col[8];                                                                                     \
-    unsigned char *Ps_ = s_raw + (buf_) * kTnBuf + 8 * mg;                                            \
-    {                                                                                                 \
-      const uint4 t4[4] = {MF_TN_SEL(S, 0, rp0##S), MF_TN_SEL(S, 1, rp1##S), MF_TN_SEL(S, 2, rp2##S), MF_TN_SEL(S, 3, rp3##S)}; \
-      transpose4x8(t4, col);                                                                          \
-    }                                                                                                 \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                     \
-        *reinterpret_cast<uint2 *>(Ps_ + tn_phys(8 * c + e, a.shift)) = col[e];                       \
-    {                                                                                                 \
-      const uint4 t4[4] = {MF_TN_SEL(S, 4, rq0##S), MF_TN_SEL(S, 5, rq1##S), MF_TN_SEL(S, 6, rq2##S), MF_TN_SEL(S, 7, rq3##S)}; \
-      transpose4x8(t4, col);                                                                          \
-    }                                                                                                 \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                     \
-        *reinterpret_cast<uint2 *>(Ps_ + kTnOperand + tn_phys(8 * c + e, a.shift)) = col[e];          \
+    MF_HOLD(rp0); MF_HOLD(rp1); MF_HOLD(rp2); MF_HOLD(rp3);                                           \
+    MF_HOLD(rq0); MF_HOLD(rq1); MF_HOLD(rq2); MF_HOLD(rq3);                                           \
+    unsigned char *Ps_ = s_raw + (buf_) * kTnBuf + st_off;                                            \
+    *reinterpret_cast<uint4 *>(Ps_) = rp0; *reinterpret_cast<uint4 *>(Ps_ + 512) = rp1;               \
+    *reinterpret_cast<uint4 *>(Ps_ + 1024) = rp2; *reinterpret_cast<uint4 *>(Ps_ + 1536) = rp3;       \
+    unsigned char *Qs_ = Ps_ + kTnOperand;                                                            \
+    *reinterpret_cast<uint4 *>(Qs_) = rq0; *reinterpret_cast<uint4 *>(Qs_ + 512) = rq1;               \
+    *reinterpret_cast<uint4 *>(Qs_ + 1024) = rq2; *reinterpret_cast<uint4 *>(Qs_ + 1536) = rq3;       \
   }
+  // fragment of a 32-column block at subtile pair (2 n, 2 n + 1), k-step s: lane l = 16 g + c takes column c of
+  // subtile 2 n + (g & 1), m = 16 s + 8 (g >> 1) + 0..3 (first read) and + 4..7 (second): the operand layout of
+  // v_mfma_f32_32x32x16_bf16 (row l % 32, k = 8 (l / 32) .. + 7)
+  const int frag = ((lane >> 4) & 1) * kTnSub + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + 8 * (lane & 3);
+#define MF_TN_FRAG(ptr_, s_) mf::lds_read_tr16_b64x2((ptr_) + 512 * (s_), 128)
 #define MF_TN_COMPUTE(buf_)                                                                           \
   {                                                                                                   \
     asm volatile("" ::: "memory");                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                \
-    const unsigned char *Ps = s_raw + (buf_) * kTnBuf + 16 * lhalf;                                   \
-    const unsigned char *Qs = Ps + kTnOperand;                                                        \
+    const unsigned char *Ps = s_raw + (buf_) * kTnBuf + 4 * wm * kTnSub + frag;                       \
+    const unsigned char *Qs = s_raw + (buf_) * kTnBuf + kTnOperand + 4 * wn * kTnSub + frag;          \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
-      const uint4 a0 = *reinterpret_cast<const uint4 *>(Ps + pa0 + 32 * s);                           \
-      const uint4 a1 = *reinterpret_cast<const uint4 *>(Ps + pa1 + 32 * s);                           \
-      const uint4 b0 = *reinterpret_cast<const uint4 *>(Qs + qb0 + 32 * s);                           \
-      const uint4 b1 = *reinterpret_cast<const uint4 *>(Qs + qb1 + 32 * s);                           \
+      const uint4 a0 = MF_TN_FRAG(Ps, s), a1 = MF_TN_FRAG(Ps + 2 * kTnSub, s);                        \
+      const uint4 b0 = MF_TN_FRAG(Qs, s), b1 = MF_TN_FRAG(Qs + 2 * kTnSub, s);                        \
       acc[0][0] = mf::mfma_bf16_32x32x16(a0, b0, acc[0][0]);                                          \
       acc[0][1] = mf::mfma_bf16_32x32x16(a0, b1, acc[0][1]);                                          \
       acc[1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[1][0]);                                          \
@@ -473,29 +461,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
     }                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                \
   }
-  const int pa0 = tn_phys(wm * 64 + lrow, a.shift), pa1 = tn_phys(wm * 64 + 32 + lrow, a.shift);
-  const int qb0 = tn_phys(wn * 64 + lrow, a.shift), qb1 = tn_phys(wn * 64 + 32 + lrow, a.shift);
-  const int tl = t1 - 1;  // (tile indices past the end re-fetch the last tile)
+  // (the fetch past this split's last tile reads the next split's rows, or rows past M as zeros, into a buffer nobody
+  // reads: unconditional on purpose, see the NT kernel)
   if (t0 < t1) {
-    MF_TN_FETCH(P, t0);
-    MF_TN_STASH(P, 0);
-    MF_TN_FETCH(P, min(t0 + 1, tl));
+    MF_TN_FETCH(t0);
+    MF_TN_STASH(0);
   }
   __syncthreads();
-  for (int t = t0; t < t1; t += 2) {
-    MF_TN_FETCH(Q, min(t + 2, tl));
-    MF_TN_COMPUTE(0);
-    MF_TN_STASH(P, 1);
-    __syncthreads();
-    if (t + 1 >= t1) break;  // block-uniform
-    MF_TN_FETCH(P, min(t + 3, tl));
-    MF_TN_COMPUTE(1);
-    MF_TN_STASH(Q, 0);
+  for (int t = t0; t < t1; ++t) {
+    MF_TN_FETCH(t + 1);
+    MF_TN_COMPUTE((t - t0) & 1);
+    MF_TN_STASH((t - t0 + 1) & 1);
     __syncthreads();
   }
 #undef MF_TN_COMPUTE
+#undef MF_TN_FRAG
 #undef MF_TN_STASH
-#undef MF_TN_SEL
 #undef MF_TN_FETCH
 #undef MF_TN_LOAD
 
@@ -709,14 +690,13 @@ extern "C" int mf_linear_wgrad_bf16(const void *dY, int64_t y_gs, int32_t ldy, c
   if (N % 8 || K % 8 || ldy % 8 || lda % 8 || y_gs % 8 || a_gs % 8 || split < 1 || (split > 1 && !ws) || ldc < K ||
       (((uintptr_t)dY | (uintptr_t)A) & 15))
     return bad("linear_wgrad_bf16: N, K, ldy, lda, group strides % 8 == 0, 16-byte aligned operands");
-  if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16, kTnLds)) return e;
+  if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16<false>, kTnLds)) return e;
   TnArgs a = {};
   a.P = (const uint16_t *)dY; a.Q = (const uint16_t *)A; a.out = split > 1 ? (float *)ws : dW;
   a.p_gs = y_gs; a.q_gs = a_gs; a.c_gs = w_gs;
   a.M = M; a.Ni = N; a.Nj = K; a.ldp = ldy; a.ldq = lda; a.ldc = ldc; a.groups = groups; a.S = split;
-  a.shift = 32;
   const int64_t grid = (int64_t)((N + 127) / 128) * ((K + 127) / 128) * groups * split;
-  hipLaunchKernelGGL(k_gemm_tn_bf16, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
+  hipLaunchKernelGGL(k_gemm_tn_bf16<false>, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
   if (split > 1) {
     const int64_t per_group = (int64_t)N * ldc, per_slab = per_group * groups;
     hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, stream,
@@ -816,17 +796,16 @@ extern "C" int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, vo
   Geom g;
   if (int e = conv_geom(B, Cin, Cout, D, ks, stride, pad, dil, &g)) return e;
   if (split < 1 || !ws) return bad("conv3d wgrad: workspace required");
-  if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16, kTnLds)) return e;
+  if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16<true>, kTnLds)) return e;
   TnArgs a = {};
   a.P = (const uint16_t *)dy; a.Q = (const uint16_t *)x; a.out = (float *)ws;
   a.M = B * g.Do * g.Do * g.Do; a.Ni = Cout; a.Nj = g.taps * Cin; a.ldp = Cout; a.ldc = g.taps * Cin; a.groups = 1;
   a.S = split;
   a.conv = 1; a.B = B; a.D = D; a.Do = g.Do; a.olog = g.olog; a.Cin = Cin;
   a.ks = ks; a.stride = stride; a.pad = pad; a.dil = dil;
-  a.shift = 32;
   // (S == 1 also goes through the workspace: the finish pass permutes (tap, cin) -> (cin, tap))
   const int64_t grid = (int64_t)((Cout + 127) / 128) * ((g.taps * Cin + 127) / 128) * a.S;
-  hipLaunchKernelGGL(k_gemm_tn_bf16, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
+  hipLaunchKernelGGL(k_gemm_tn_bf16<true>, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
   const int64_t per_slab = (int64_t)Cout * g.taps * Cin;
   const int keep = w_cin - c_off < Cin ? w_cin - c_off : Cin;
   hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, stream,

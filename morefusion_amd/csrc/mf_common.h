@@ -66,6 +66,20 @@ __device__ __forceinline__ uint4 buf_load16(const BufRsrc &b, uint32_t byte_off)
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// ---- gfx950's transposing LDS read (round 4: the TN engine of csrc/gemm_bf16.hip) -------------------------------
+// ds_read_b64_tr_b16: every lane gives the address of 4 contiguous 16-bit elements; within each group of 16 lanes the
+// 16 x 4 elements are taken as a matrix [4 rows][16 columns] -- row r = lanes 4 r .. 4 r + 3 of the group, in lane
+// order -- and lane c of the group receives column c: element r of its result = element (c & 3) of lane 4 r + (c >> 2).
+// lds_read_tr16_b64x2(p, d): the reads at p and p + d as one MFMA operand (8 values: rows 0..3 of each block).
+__device__ __forceinline__ uint4 lds_read_tr16_b64x2(const unsigned char *p, int second) {
+  typedef short v4i16 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) v4i16 *lds_v4i16;
+  const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16)(p));
+  const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16)(p + second));
+  const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
 // dynamic LDS of the workgroup (tests/host_emul/mf_common.h gives the host-emulation form)
 #define MF_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 

@@ -469,6 +469,21 @@ inline int fill_bytes(void *dst, int value, int64_t nbytes, hipStream_t st) {  /
   mf_emul::enqueue(st, [=]() { memset(dst, value, (size_t)nbytes); });
   return 0;
 }
+// csrc/mf_common.h's transposing LDS read (ds_read_b64_tr_b16), as documented there: lane c of a 16-lane group
+// receives, as element r, element (c & 3) of what lane 4 r + (c >> 2) of the group addressed
+inline uint2 lds_read_tr16_b64(const unsigned char *p) {
+  uint64_t mine, act;
+  memcpy(&mine, p, 8);
+  const uint64_t *all = mf_emul::wave_exchange(mine, &act);
+  const int lane = mf_emul::g_block.cur % 64, base = lane & ~15, c = lane & 15;
+  uint16_t e[4];
+  for (int r = 0; r < 4; ++r) e[r] = (uint16_t)(all[base + 4 * r + (c >> 2)] >> (16 * (c & 3)));
+  return make_uint2((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16));
+}
+inline uint4 lds_read_tr16_b64x2(const unsigned char *p, int second) {
+  const uint2 lo = lds_read_tr16_b64(p), hi = lds_read_tr16_b64(p + second);
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
 // csrc/mf_common.h's range-checked buffer loads: out of range reads as zeros and touches nothing
 constexpr uint32_t kBufSpan = 0x80000000u, kBufMasked = 0x80000000u;
 struct BufRsrc {
