@@ -415,8 +415,9 @@ int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, void *ws, int
  *   mf_average_voxelization_cl_bf16_fwd  values bf16 [n, ldv] -> x bf16 [B, D^3, ldx] columns [0, C): voxel means
  *     (fp32 sum in increasing point index), zeros elsewhere; counts / head [B*D^3], link [n]: int32 scratch
  *   mf_average_voxelization_cl_bf16_bwd  gvalues[p] = gx[b, voxel(p)] / count
- *   mf_interpolate_voxel_grid_cl_bf16_fwd / _bwd   vox bf16 [B, X*Y*Z, C] <-> rows bf16 [n, ld]; the backward
- *     accumulates fp32 into a zero-filled gvox [B, X*Y*Z, C] */
+ *   mf_interpolate_voxel_grid_cl_bf16_fwd / _bwd   vox bf16 [B, X*Y*Z, C] <-> rows bf16 [n, ld]; the backward gathers
+ *     per voxel range (fp32 sums in LDS) and writes every element of gvox [B, X*Y*Z, C] once, as bf16 (out_bf16 = 1)
+ *     or fp32; batch_start = B + 1 row offsets of points sorted by item, or NULL (any order, slower) */
 int mf_average_voxelization_cl_bf16_fwd(const void *values, int64_t ldv, const float *points,
                                         const int32_t *batch_indices, int64_t n, int32_t C, int32_t B, int32_t D,
                                         void *x, int64_t ldx, int32_t *counts, int32_t *head, int32_t *link,
@@ -428,8 +429,8 @@ int mf_interpolate_voxel_grid_cl_bf16_fwd(const void *vox, const float *points, 
                                           int64_t n, int B, int C, int X, int Y, int Z, void *out, int64_t ldo,
                                           mfStream_t stream);
 int mf_interpolate_voxel_grid_cl_bf16_bwd(const void *gout, int64_t ldg, const float *points,
-                                          const int32_t *batch_indices, int64_t n, int B, int C, int X, int Y, int Z,
-                                          float *gvox, mfStream_t stream);
+                                          const int32_t *batch_indices, const int32_t *batch_start, int64_t n, int B,
+                                          int C, int X, int Y, int Z, void *gvox, int32_t out_bf16, mfStream_t stream);
 
 /* Element-wise pieces of the 2-D backbone's decoder (morefusion/models/dense_fusion/pspnet.py:10-35,40-73:
  * F.resize_images bilinear align_corners, L.PReLU with one slope), forward and backward, channels-last tensors

@@ -95,7 +95,7 @@ _SIGNATURES = {
     "mf_average_voxelization_cl_bf16_bwd": ([_p, _i64, _p, _p, _p, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p,
                                              _i64, _p], _i),
     "mf_interpolate_voxel_grid_cl_bf16_fwd": ([_p, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _i64, _p], _i),
-    "mf_interpolate_voxel_grid_cl_bf16_bwd": ([_p, _i64, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _p], _i),
+    "mf_interpolate_voxel_grid_cl_bf16_bwd": ([_p, _i64, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _i, _p], _i),
     "mf_upsample_bilinear_cl_fwd": ([_p, _p] + [ctypes.c_int32] * 7 + [_p], _i),
     "mf_upsample_bilinear_cl_bwd": ([_p, _p] + [ctypes.c_int32] * 7 + [_p], _i),
     "mf_upsample_bilinear_cf_fwd": ([_p, _p, _i64] + [ctypes.c_int32] * 5 + [_p], _i),

@@ -245,7 +245,9 @@ class InterpolateVoxelGridCL(torch.autograd.Function):
     at contrib/singleview_3d/models/model.py:131,141."""
 
     @staticmethod
-    def forward(ctx, vox, points, batch_indices, X):
+    def forward(ctx, vox, points, batch_indices, X, batch_start=None):
+        """``batch_start`` (optional, int32 [B + 1]): row offsets of the items when the points are sorted by item --
+        the backward then visits only an item's own rows per workgroup."""
         _lib.require_gpu(vox, points, batch_indices)
         vox = _bf16c(vox)
         B, V, C = vox.shape
@@ -256,21 +258,17 @@ class InterpolateVoxelGridCL(torch.autograd.Function):
         _lib.check(_lib.lib().mf_interpolate_voxel_grid_cl_bf16_fwd(vox.data_ptr(), pts.data_ptr(), bi.data_ptr(), n, B,
                                                                     C, X, X, X, out.data_ptr(), C, _lib.stream_ptr()),
                    "mf_interpolate_voxel_grid_cl_bf16_fwd")
-        ctx.save_for_backward(pts, bi)
+        ctx.save_for_backward(pts, bi, _lib.i32c(batch_start) if batch_start is not None else None)
         ctx.geom = (n, B, C, X)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        pts, bi = ctx.saved_tensors
+        pts, bi, bs = ctx.saved_tensors
         n, B, C, X = ctx.geom
-        L = _lib.lib()
         g = _bf16c(g)
-        gv32 = _empty((B, X ** 3, C), torch.float32, g)
-        _lib.check(L.mf_interpolate_voxel_grid_cl_bf16_bwd(g.data_ptr(), C, pts.data_ptr(), bi.data_ptr(), n, B, C, X, X,
-                                                           X, gv32.data_ptr(), _lib.stream_ptr()),
-                   "mf_interpolate_voxel_grid_cl_bf16_bwd")
-        gv = _empty((B, X ** 3, C), BF16, g)
-        _lib.check(L.mf_cast_rows_bf16(gv32.data_ptr(), C, gv.data_ptr(), C, B * X ** 3, C, _lib.stream_ptr()),
-                   "mf_cast_rows_bf16")
-        return gv, None, None, None
+        gv = _empty((B, X ** 3, C), BF16, g)   # every element written by the kernel: bf16 straight from the fp32 sums
+        _lib.check(_lib.lib().mf_interpolate_voxel_grid_cl_bf16_bwd(
+            g.data_ptr(), C, pts.data_ptr(), bi.data_ptr(), bs.data_ptr() if bs is not None else None, n, B, C, X, X, X,
+            gv.data_ptr(), 1, _lib.stream_ptr()), "mf_interpolate_voxel_grid_cl_bf16_bwd")
+        return gv, None, None, None, None

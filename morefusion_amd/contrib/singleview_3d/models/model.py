@@ -385,6 +385,7 @@ class Model(nn.Module):
         pts = ((points.float() - origin[:, :, None]) / pitch[:, None, None]).transpose(1, 2).reshape(n, 3).contiguous()
         to_center = (D / 2.0 - 0.5) - pts
         batch_indices = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(P)
+        batch_start = torch.arange(B + 1, dtype=torch.int32, device=dev) * P          # rows of item b: sorted by item
         x_rgb = values.transpose(1, 2).reshape(n, values.shape[1])
         h1_rgb = K.linear(x_rgb, self.conv1_rgb)
         h1_pcd = K.linear(to_center, self.conv1_pcd)
@@ -400,9 +401,9 @@ class Model(nn.Module):
             x3[:, :, 144:] = h_occ
         h3 = K.conv3d_k4s2(x3, self.conv3, D)                                         # [B,16^3,256] bf16
         Dh = D // 2
-        feat3 = K.InterpolateVoxelGridCL.apply(h3, pts / 2.0, batch_indices, Dh)      # [n,256] bf16
+        feat3 = K.InterpolateVoxelGridCL.apply(h3, pts / 2.0, batch_indices, Dh, batch_start)  # [n,256] bf16
         h4 = K.conv3d_k4s2(h3, self.conv4, Dh)                                        # [B,8^3,512] bf16
-        feat4 = K.InterpolateVoxelGridCL.apply(h4, pts / 4.0, batch_indices, D // 4)  # [n,512] bf16
+        feat4 = K.InterpolateVoxelGridCL.apply(h4, pts / 4.0, batch_indices, D // 4, batch_start)  # [n,512]
         feat = torch.cat((h1_rgb, h1_pcd, h2_rgb, h2_pcd, feat3, feat4), dim=1)       # [n,984] bf16
         names = ("rot", "trans", "conf")
         w1 = torch.cat([getattr(self, f"conv1_{k}").weight for k in names])           # one GEMM for the 3 heads

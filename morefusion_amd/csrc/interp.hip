@@ -486,29 +486,133 @@ __global__ __launch_bounds__(kInterpThreads) void k_interp_cl_bf16_fwd(
   }
 }
 
-__global__ __launch_bounds__(kInterpThreads) void k_interp_cl_bf16_bwd(
+// Backward of the channels-last sampler WITHOUT float atomics: workgroup (cc, r, b) owns CPW channels of the voxels
+// [r Vr, (r + 1) Vr) of item b, Vr = 512: every thread keeps the sums of two voxels in registers.  The item's points
+// come 256 at a time; per pass
+//   1. every lane computes its point's 8 corners, takes a slot in the per-voxel counter of each corner inside the
+//      range (integer LDS atomics: 8 per point) and stages the point's CPW gradient values (32 bytes) in LDS;
+//   2. an exclusive scan of the 512 counters turns the slots into a list sorted by voxel: (point, weight) pairs;
+//   3. every thread walks the lists of its two voxels and accumulates weight x value from the staged rows.
+// At the end each thread writes its voxels' CPW channels (bf16 or fp32): every element, zeros included.
+// Earlier versions of round 4, measured in the training step (16000 points, 16^3 x 256 and 8^3 x 512 grids):
+//  * one wave per point, fp32 atomics into a zero-filled global grid: 0.42 ms per call (78 G atomics/s);
+//  * voxel-range owner with all channels, one wave per (point, corner) and LDS float atomics: 0.66 ms (the object
+//    fills an eighth of the grid: a few workgroups held all the pairs and walked them one 1 KB row read at a time);
+//  * this decomposition with LDS float atomics (CPW x Vr accumulators, 128 ds_add_f32 per point): 0.28 ms -- the LDS
+//    atomic unit retires about one lane per clock, whatever the bank pattern.
+constexpr int kBwdVr = 2 * kInterpThreads;
+
+template <int CPW>
+__global__ __launch_bounds__(kInterpThreads) void k_interp_cl_bf16_bwd_sorted(
     const uint16_t *__restrict__ gout, int64_t ldg, const float *__restrict__ points,
-    const int32_t *__restrict__ batch_indices, int64_t n, int B, int C, int X, int Y, int Z,
-    float *__restrict__ gvox) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t V = (int64_t)X * Y * Z;
-  const int64_t p = (int64_t)blockIdx.x * (kInterpThreads / 64) + wave;
-  if (p >= n) return;
-  const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
-  const int b = batch_indices[p];
-  if (!(b >= 0 && b < B && plausible(px, py, pz))) return;
-  Corner k;
-  corners(px, py, pz, X, Y, Z, k);
-  float *grid = gvox + (int64_t)b * V * C;
-  for (int c = 2 * lane; c < C; c += 128) {  // two channels per lane: consecutive lanes -> consecutive addresses
-    const uint32_t w = *reinterpret_cast<const uint32_t *>(gout + p * ldg + c);
-    const float g0 = mf::bf16_lo(w), g1 = mf::bf16_hi(w);
+    const int32_t *__restrict__ batch_indices, const int32_t *__restrict__ batch_start, int64_t n, int B, int C,
+    int X, int Y, int Z, void *__restrict__ gvox, int out_bf16) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_g[kInterpThreads][CPW];  // the pass's gradient rows (this chunk)
+  __shared__ int s_cnt[kBwdVr];        // entries per voxel, then (after the scan) the voxel's first entry
+  __shared__ int s_wave[kInterpThreads / 64];
+  __shared__ uint2 s_ent[kInterpThreads * 8];  // sorted by voxel: (point of the pass, weight bits)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c0 = blockIdx.x * CPW, v0 = blockIdx.y * kBwdVr, b = blockIdx.z, V = X * Y * Z;
+  float acc[2][CPW];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (k.off[j] < 0) continue;
-      float *dst = grid + (int64_t)k.off[j] * C + c;
-      atomicAdd(dst, k.w[j] * g0);
-      atomicAdd(dst + 1, k.w[j] * g1);
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) acc[u][c] = 0.0f;
+  // this item's rows: [batch_start[b], batch_start[b + 1]) when the caller has the offsets (points sorted by item),
+  // else all n rows filtered by batch_indices (correct for any order)
+  const int64_t p0 = batch_start ? row_clamp(batch_start[b], n) : 0;
+  const int64_t p1 = batch_start ? row_clamp(batch_start[b + 1], n) : n;
+  for (int64_t base = p0; base < p1; base += kInterpThreads) {  // block-uniform
+    s_cnt[tid] = 0;
+    s_cnt[tid + kInterpThreads] = 0;
+    __syncthreads();
+    const int64_t p = base + tid;
+    int vox[8], slot[8];
+    float wgt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vox[j] = -1;
+    if (p < p1 && (batch_start || batch_indices[p] == b)) {
+      const float px = points[3 * p], py = points[3 * p + 1], pz = points[3 * p + 2];
+      if (plausible(px, py, pz)) {
+        Corner k;
+        corners(px, py, pz, X, Y, Z, k);
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int v = k.off[j] - v0;
+          if (k.off[j] >= 0 && v >= 0 && v < kBwdVr) {
+            vox[j] = v;
+            wgt[j] = k.w[j];
+            slot[j] = atomicAdd(&s_cnt[v], 1);
+            any = true;
+          }
+        }
+        if (any) {
+          const uint16_t *row = gout + p * ldg + c0;
+#pragma unroll
+          for (int q = 0; q < CPW / 4; ++q)
+            *reinterpret_cast<uint2 *>(&s_g[tid][4 * q]) = *reinterpret_cast<const uint2 *>(row + 4 * q);
+        }
+      }
+    }
+    __syncthreads();
+    // exclusive scan of the 512 counters (thread t: counters 2 t, 2 t + 1)
+    const int c_lo = s_cnt[2 * tid], c_hi = s_cnt[2 * tid + 1];
+    int incl = c_lo + c_hi;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = incl - (c_lo + c_hi);
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < kInterpThreads / 64; ++w) {
+      if (w < wave) before += s_wave[w];
+      total += s_wave[w];
+    }
+    if (total == 0) continue;  // block-uniform: no corner of this pass inside the range (no barrier pending)
+    s_cnt[2 * tid] = before;
+    s_cnt[2 * tid + 1] = before + c_lo;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (vox[j] >= 0) s_ent[s_cnt[vox[j]] + slot[j]] = make_uint2((unsigned)tid, __float_as_uint(wgt[j]));
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int v = tid + u * kInterpThreads;
+      const int e0 = s_cnt[v], e1 = v + 1 < kBwdVr ? s_cnt[v + 1] : total;
+      for (int e = e0; e < e1; ++e) {
+        const uint2 ent = s_ent[e];
+        const float w = __uint_as_float(ent.y);
+#pragma unroll
+        for (int q = 0; q < CPW / 4; ++q) {
+          const uint2 g = *reinterpret_cast<const uint2 *>(&s_g[ent.x][4 * q]);
+          acc[u][4 * q] += w * mf::bf16_lo(g.x);
+          acc[u][4 * q + 1] += w * mf::bf16_hi(g.x);
+          acc[u][4 * q + 2] += w * mf::bf16_lo(g.y);
+          acc[u][4 * q + 3] += w * mf::bf16_hi(g.y);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int v = v0 + tid + u * kInterpThreads;
+    if (v >= V) continue;
+    const int64_t o = ((int64_t)b * V + v) * C + c0;
+#pragma unroll
+    for (int q = 0; q < CPW / 4; ++q) {
+      if (out_bf16)
+        *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(gvox) + o + 4 * q) = make_uint2(
+            mf::pack_bf16x2(acc[u][4 * q], acc[u][4 * q + 1]), mf::pack_bf16x2(acc[u][4 * q + 2], acc[u][4 * q + 3]));
+      else
+        *reinterpret_cast<float4 *>(static_cast<float *>(gvox) + o + 4 * q) =
+            make_float4(acc[u][4 * q], acc[u][4 * q + 1], acc[u][4 * q + 2], acc[u][4 * q + 3]);
     }
   }
 }
@@ -594,7 +698,8 @@ extern "C" int mf_interpolate_voxel_grid_cl_fwd(const float *vox, const float *p
 }
 
 /* Channels-last bf16 sampler of the training path: vox bf16 [B, X*Y*Z, C] -> out bf16 [n, ldo >= C] (C % 8 == 0,
- * 16-byte aligned rows); backward: gout bf16 [n, ldg] -> gvox fp32 [B, X*Y*Z, C] (zero-filled here, fp32 atomics). */
+ * 16-byte aligned rows); backward: gout bf16 [n, ldg] -> gvox [B, X*Y*Z, C], bf16 (out_bf16 = 1) or fp32, every element
+ * written (no zero fill needed); batch_start: B + 1 row offsets when the points are sorted by item, or NULL. */
 extern "C" int mf_interpolate_voxel_grid_cl_bf16_fwd(const void *vox, const float *points,
                                                      const int32_t *batch_indices, int64_t n, int B, int C, int X,
                                                      int Y, int Z, void *out, int64_t ldo, mfStream_t stream_) {
@@ -611,19 +716,28 @@ extern "C" int mf_interpolate_voxel_grid_cl_bf16_fwd(const void *vox, const floa
 }
 
 extern "C" int mf_interpolate_voxel_grid_cl_bf16_bwd(const void *gout, int64_t ldg, const float *points,
-                                                     const int32_t *batch_indices, int64_t n, int B, int C, int X,
-                                                     int Y, int Z, float *gvox, mfStream_t stream_) {
+                                                     const int32_t *batch_indices, const int32_t *batch_start,
+                                                     int64_t n, int B, int C, int X, int Y, int Z, void *gvox,
+                                                     int32_t out_bf16, mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t V = (int64_t)X * Y * Z;
   if ((int64_t)B * V * C == 0) return 0;
-  if (C % 2 || ldg % 2) {
-    mf::set_last_error(hipErrorInvalidValue, "interpolate_voxel_grid_cl_bf16 backward: even C and ldg");
+  if (C % 4 || ldg % 4 || B > 65535 || V > (1 << 24) || (((uintptr_t)gout | (uintptr_t)gvox) & 15)) {
+    mf::set_last_error(hipErrorInvalidValue,
+                       "interpolate_voxel_grid_cl_bf16 backward: C % 4 == 0, ldg % 4 == 0, 16-byte aligned, B < 65536");
     return -(int)hipErrorInvalidValue;
   }
-  if (int e_ = mf::fill_bytes(gvox, 0, sizeof(float) * B * V * C, stream)) return e_;
-  if (n > 0)
-    hipLaunchKernelGGL(k_interp_cl_bf16_bwd, dim3((unsigned)((n + kInterpThreads / 64 - 1) / (kInterpThreads / 64))),
-                       dim3(kInterpThreads), 0, stream, (const uint16_t *)gout, ldg, points, batch_indices, n, B, C, X,
-                       Y, Z, gvox);
+  const int cpw = C % 16 == 0 ? 16 : (C % 8 == 0 ? 8 : 4);
+  const dim3 grid(C / cpw, (unsigned)((V + kBwdVr - 1) / kBwdVr), B);
+  const int64_t nn = n > 0 ? n : 0;
+  if (cpw == 16)
+    hipLaunchKernelGGL(k_interp_cl_bf16_bwd_sorted<16>, grid, dim3(kInterpThreads), 0, stream, (const uint16_t *)gout,
+                       ldg, points, batch_indices, batch_start, nn, B, C, X, Y, Z, gvox, out_bf16);
+  else if (cpw == 8)
+    hipLaunchKernelGGL(k_interp_cl_bf16_bwd_sorted<8>, grid, dim3(kInterpThreads), 0, stream, (const uint16_t *)gout,
+                       ldg, points, batch_indices, batch_start, nn, B, C, X, Y, Z, gvox, out_bf16);
+  else
+    hipLaunchKernelGGL(k_interp_cl_bf16_bwd_sorted<4>, grid, dim3(kInterpThreads), 0, stream, (const uint16_t *)gout,
+                       ldg, points, batch_indices, batch_start, nn, B, C, X, Y, Z, gvox, out_bf16);
   return mf::check_launch("mf_interpolate_voxel_grid_cl_bf16_bwd");
 }

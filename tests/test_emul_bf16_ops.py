@@ -171,3 +171,40 @@ def test_channels_last_bf16_voxelization_and_sampling_vs_oracle(KV):
     gv_o = O.interpolate_voxel_grid_backward(g.float().numpy(), sp, bi, (B, Cs, X, X, X))
     gv_cl = torch.from_numpy(gv_o).reshape(B, Cs, X ** 3).transpose(1, 2)
     assert float((vg.grad.float() - gv_cl).abs().max()) <= 2.0 ** -7 * float(gv_cl.abs().max()) + 1e-5
+    # the same backward with the items' row offsets (the model passes them: points sorted by item), and the C-ABI's
+    # fp32 output: float sums in LDS, only the summation order differs from the oracle
+    vg2 = vox.clone().requires_grad_(True)
+    bs = torch.tensor([0, n // B, n], dtype=torch.int32)
+    KV.InterpolateVoxelGridCL.apply(vg2, torch.from_numpy(sp), torch.from_numpy(bi), X, bs).backward(g)
+    assert float((vg2.grad.float() - gv_cl).abs().max()) <= 2.0 ** -7 * float(gv_cl.abs().max()) + 1e-5
+    from morefusion_amd import _lib
+    g32 = torch.full((B, X ** 3, Cs), 7.0)
+    spt, bit = torch.from_numpy(sp), torch.from_numpy(bi)
+    for start in (None, bs):
+        g32.fill_(7.0)   # every element is written: no zero fill by the caller
+        _lib.check(_lib.lib().mf_interpolate_voxel_grid_cl_bf16_bwd(
+            g.data_ptr(), Cs, spt.data_ptr(), bit.data_ptr(), start.data_ptr() if start is not None else None, n, B, Cs,
+            X, X, X, g32.data_ptr(), 0, _lib.stream_ptr()), "bwd")
+        assert float((g32 - gv_cl).abs().max()) <= 1e-5 * float(gv_cl.abs().max()) + 1e-6
+    # a 12^3 grid: four voxel ranges of 512, the last one partial; rows in any order (no offsets)
+    X2, n2 = 12, 90
+    sp2 = rs.uniform(-0.6, X2 - 0.4, (n2, 3)).astype(np.float32)
+    bi2 = rs.randint(0, B, n2).astype(np.int32)
+    g2 = torch.from_numpy(rs.uniform(-1, 1, (n2, 4)).astype(np.float32)).to(torch.bfloat16)
+    want2 = O.interpolate_voxel_grid_backward(g2.float().numpy(), sp2, bi2, (B, 4, X2, X2, X2))
+    want2 = torch.from_numpy(want2).reshape(B, 4, X2 ** 3).transpose(1, 2)
+    got2 = torch.full((B, X2 ** 3, 4), 7.0)
+    sp2t, bi2t = torch.from_numpy(sp2), torch.from_numpy(bi2)
+    _lib.check(_lib.lib().mf_interpolate_voxel_grid_cl_bf16_bwd(
+        g2.data_ptr(), 4, sp2t.data_ptr(), bi2t.data_ptr(), None, n2, B, 4, X2, X2, X2, got2.data_ptr(), 0,
+        _lib.stream_ptr()), "bwd")
+    assert float((got2 - want2).abs().max()) <= 1e-5 * float(want2.abs().max()) + 1e-6
+    for c_small in (8, 12):   # 8 and 4 channels per workgroup (the network's layers take the 16-channel variant)
+        gs = g[:, :c_small].contiguous()
+        want_s = O.interpolate_voxel_grid_backward(gs.float().numpy(), sp, bi, (B, c_small, X, X, X))
+        want_s = torch.from_numpy(want_s).reshape(B, c_small, X ** 3).transpose(1, 2)
+        got_s = torch.full((B, X ** 3, c_small), 7.0)
+        _lib.check(_lib.lib().mf_interpolate_voxel_grid_cl_bf16_bwd(
+            gs.data_ptr(), c_small, spt.data_ptr(), bit.data_ptr(), bs.data_ptr(), n, B, c_small, X, X, X,
+            got_s.data_ptr(), 0, _lib.stream_ptr()), "bwd")
+        assert float((got_s - want_s).abs().max()) <= 1e-5 * float(want_s.abs().max()) + 1e-6

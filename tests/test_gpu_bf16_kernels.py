@@ -142,3 +142,31 @@ def test_occupancy_branch_on_the_bf16_kernels_vs_fp32():
     h1.backward((h1l.grad * (h1b > 0)).to(torch.bfloat16).float())
     grad_close(c1.weight.grad, r1.weight.grad)
     grad_close(c1.bias.grad, r1.bias.grad)
+
+
+@pytest.mark.parametrize("B,X,C,P,sorted_rows", [(4, 16, 256, 1000, True), (4, 8, 512, 1000, True),
+                                                  (3, 16, 64, 700, False)])
+def test_channels_last_sampler_forward_backward_vs_oracle(B, X, C, P, sorted_rows):
+    """InterpolateVoxelGridCL at the network's sizes (h3: 16^3 x 256, h4: 8^3 x 512, 1000 points per object;
+    model.py:131,141) against the oracle's channels-first float32 restatement of interpolate_voxel_grid.py:61-215 on
+    the same bf16-rounded inputs.  Points outside the grid and a NaN row included; with and without the items' row
+    offsets (shuffled rows: the any-order scan of the backward)."""
+    from oracle import oracle_np as O
+    rs = np.random.RandomState(5)
+    n = B * P
+    vox = torch.from_numpy(rs.uniform(-1, 1, (B, X ** 3, C)).astype(np.float32)).to(torch.bfloat16)
+    sp = rs.uniform(-0.6, X - 0.4, (n, 3)).astype(np.float32)
+    sp[11] = np.nan
+    bi = np.repeat(np.arange(B), P).astype(np.int32)
+    if not sorted_rows:
+        bi = bi[rs.permutation(n)]
+    g = torch.from_numpy(rs.uniform(-1, 1, (n, C)).astype(np.float32)).to(torch.bfloat16)
+    vg = vox.cuda().requires_grad_(True)
+    bs = torch.arange(B + 1, dtype=torch.int32, device="cuda") * P if sorted_rows else None
+    out = K.InterpolateVoxelGridCL.apply(vg, torch.from_numpy(sp).cuda(), torch.from_numpy(bi).cuda(), X, bs)
+    out.backward(g.cuda())
+    want = O.interpolate_voxel_grid(vox.float().transpose(1, 2).reshape(B, C, X, X, X).numpy(), sp, bi)
+    assert float((out.float().cpu() - torch.from_numpy(want)).abs().max()) <= 2.0 ** -8 * float(np.abs(want).max()) + 1e-6
+    gv = O.interpolate_voxel_grid_backward(g.float().numpy(), sp, bi, (B, C, X, X, X))
+    gv_cl = torch.from_numpy(gv).reshape(B, C, X ** 3).transpose(1, 2)
+    assert float((vg.grad.float().cpu() - gv_cl).abs().max()) <= 2.0 ** -7 * float(gv_cl.abs().max()) + 1e-5
