@@ -46,6 +46,25 @@ def test_add_loss_kernel_source_vs_oracle():
     for b in range(B):
         ref = O.average_distance(pts[b], Tt[b], Tp[b], symmetric=bool(sym[b]))
         np.testing.assert_allclose(out[b], ref, rtol=2e-6, atol=1e-8)
+        if sym[b]:  # the arg-min itself, bit for bit (knn/nn.py:48: first minimum); M = 300: the last group of 4 is full,
+            pt = O.transform_points(pts[b], Tt[b])  # M2 below: padded
+            want = O.nn(pt, O.transform_points(pts[b], Tp[b]).reshape(-1, 3)).reshape(P, M)
+            assert np.array_equal(idx[b], want)
+    # ties and a tile that is not a multiple of 4: duplicated model points -> equal distances, lowest index wins
+    M2 = 37
+    pts2 = np.ascontiguousarray(pts[:, :M2]).copy()
+    pts2[:, 20:30] = pts2[:, 5:15]
+    out2 = np.zeros((B, P), np.float32)
+    idx2 = np.zeros((B, P, M2), np.int32)
+    sym2 = np.ones(B, np.uint8)
+    assert lib.mf_average_distance_fwd(pts2.ctypes.data, Tt.ctypes.data, Tp.ctypes.data, sym2.ctypes.data, B, M2, P,
+                                       out2.ctypes.data, idx2.ctypes.data, None) == 0
+    for b in range(B):
+        pt = O.transform_points(pts2[b], Tt[b])
+        want = O.nn(pt, O.transform_points(pts2[b], Tp[b]).reshape(-1, 3)).reshape(P, M2)
+        assert np.array_equal(idx2[b], want)
+        assert not np.isin(idx2[b], np.arange(20, 30)).any()  # never the later copy
+        np.testing.assert_allclose(out2[b], O.average_distance(pts2[b], Tt[b], Tp[b], symmetric=True), rtol=2e-6, atol=1e-8)
     # backward: against central differences of the forward (float64 restatement of the same formula)
     gout = rs.uniform(0.5, 1.5, (B, P)).astype(np.float32)
     for use_idx in (True, False):

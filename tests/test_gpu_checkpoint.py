@@ -31,6 +31,19 @@ def _check(outs, g, tag, tol):
     np.testing.assert_allclose(q, g[f"{tag}__quaternion"], rtol=0, atol=tol)
     np.testing.assert_allclose(c, g[f"{tag}__confidence"], rtol=0, atol=tol)
     np.testing.assert_allclose(t, g[f"{tag}__translation"], rtol=0, atol=tol * 0.01)
+    # the north-star tolerance itself: ADD between the GPU pose and the reference network's pose of the same point
+    # (the reference's most confident one per object), over a 0.1 m model cloud -- within 1e-4 m
+    from oracle import oracle_np as O
+    cloud = np.random.RandomState(0).uniform(-0.05, 0.05, (500, 3)).astype(np.float32)
+    worst = 0.0
+    for b in range(q.shape[0]):
+        i = int(np.argmax(g[f"{tag}__confidence"][b]))
+        Tg = O.transformation_matrix(q[b, i].astype(np.float64), t[b, i].astype(np.float64))
+        Tr = O.transformation_matrix(g[f"{tag}__quaternion"][b, i].astype(np.float64),
+                                     g[f"{tag}__translation"][b, i].astype(np.float64))
+        worst = max(worst, float(O.metrics_average_distance(cloud, Tg, Tr)[0]))
+    print(f"ADD GPU vs reference network ({tag}): {worst:.3e} m")
+    assert worst <= 1e-4
 
 
 def test_chainer_checkpoint_round_trip_reproduces_reference_predict(tmp_path):
