@@ -465,9 +465,10 @@ def latency_batch1_measure(model, one, reps=12):
 def latency_probe_main():
     """`python bench.py --probe-latency-b1`: BASELINE configs[1] (batch 1) in a process of its own."""
     torch.cuda.set_device(0)
-    # immediate-mode solver selection: with MIOpen's find mode on, the graph phases of this probe faulted or hung
-    # in 2 of 3 processes (and never in 6 of 6 without it); MF_PROBE_BENCHMARK=1 re-enables it for experiments
-    torch.backends.cudnn.benchmark = os.environ.get("MF_PROBE_BENCHMARK", "0") == "1"
+    # MIOpen find mode on, like the bench's own model (round 3 ran this probe with immediate-mode solvers because the
+    # graph phases faulted with find mode on; the cause -- memset nodes in the captured graph, DESIGN.md 6 -- is gone
+    # since round 4: 6 of 6 processes clean with find mode, 20 of 20 without).  MF_PROBE_BENCHMARK=0: immediate mode.
+    torch.backends.cudnn.benchmark = os.environ.get("MF_PROBE_BENCHMARK", "1") == "1"
     torch.manual_seed(0)
     model = Model(n_fg_class=21, with_occupancy=True).cuda().eval()
     batch = mf.synthetic.make_singleview_batch(1, seed=0)
@@ -479,9 +480,9 @@ def latency_probe_main():
 def latency_batch1(wl):
     """BASELINE configs[1]: singleview_3d inference at batch = 1.  ``predict`` (eager launches, incl. the host
     synchronisation of the point selection) is measured here, in this process, with the bench's own model
-    (MIOpen find mode on).  The hipGraph replay is measured in a CHILD process (``probe``): replaying the stock
-    2-D backbone from a graph is not reliable on this stack (intermittent GPU faults), and a fault
-    must not cost the headline line.  A failed probe is reported as such."""
+    (MIOpen find mode on).  The hipGraph replay is measured in a CHILD process (``probe``), a leftover of round 3's
+    intermittent replay faults (memset nodes, replaced by fill kernels in round 4) that costs nothing
+    and keeps a failure of the probe from costing the headline line.  A failed probe is reported as such."""
     import subprocess
     one = {k: v[:1].contiguous() for k, v in wl.inputs.items()}
     out = {}
@@ -496,7 +497,7 @@ def latency_batch1(wl):
         out["predict"] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    probe = {"note": "own process, cudnn.benchmark off (immediate-mode MIOpen solvers), host clock incl. device sync"}
+    probe = {"note": "own process, MIOpen find mode on, host clock incl. device sync"}
     try:
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-latency-b1"], env=env,
                            capture_output=True, text=True, timeout=150)

@@ -245,8 +245,9 @@ class Model(nn.Module):
         into the graph's static buffers (skipped for tensors that still live at the captured address) and
         replay.  ``pix`` [B,P]: a point selection computed ahead (``select_points_async``), which removes the
         call's only host synchronisation.  ``clone=False`` returns the graph's static output tensors (valid
-        until the next call).  Run it with ``torch.backends.cudnn.benchmark = False``: with MIOpen's find mode on,
-        replays of the stock 2-D backbone faulted or hung intermittently on this stack."""
+        until the next call).  (Round 3's intermittent replay faults came from memset nodes in the captured graph;
+        the kernels fill through launches since round 4 -- DESIGN.md 6 -- and replays are clean with MIOpen's find
+        mode on or off.)"""
         if self.training or torch.is_grad_enabled():
             raise RuntimeError("predict_graphed is an inference path: call under torch.no_grad() in eval mode")
         dev = rgb.device
