@@ -110,12 +110,9 @@ class Conv3d(torch.autograd.Function):
 
 
 def _wgrad_split(M, N, K, groups):
+    """Slabs of the weight-gradient reduction (csrc/gemm_bf16.hip: mf_wgrad_split's cost model)."""
     tiles = -(-N // 128) * -(-K // 128) * groups
-    ktiles = -(-M // 64)
-    s = 1
-    while tiles * s < 512 and ktiles // (s * 2) >= 8:
-        s *= 2
-    return s
+    return int(_lib.lib().mf_wgrad_split(tiles, -(-M // 64), N * K * 4 * groups))
 
 
 class Linear(torch.autograd.Function):

@@ -353,12 +353,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave & 1, wn = wave >> 1;
   const int lrow = lane & 31, lhalf = lane >> 5;
-  // staging: load r (0..3) of this lane is row 16 r + 4 wave + kr of the K-tile, columns 16 sub + 8 half .. + 7.  Eight
+  // staging: load r (0..3) of this lane goes to LDS row 16 r + 4 wave + kr of the K-tile, columns 16 sub + 8 half .. + 7.  Eight
   // consecutive lanes (the unit a ds_write_b128 is served in) fill 4 rows x 32 bytes = 128 contiguous bytes of one
   // subtile: 32 distinct banks; a wave's load covers 4 rows x 256 contiguous bytes.
   const int half = lane & 1, kr = (lane >> 1) & 3, sub = lane >> 3;
   const int col = 16 * sub + 8 * half;
   const int st_off = sub * kTnSub + (4 * wave + kr) * 32 + 16 * half;  // + 512 r
+  const int mrow = 16 * kr + 4 * wave;  // this lane's rows of a K-tile: mrow .. mrow + 3 (see MF_TN_LOAD)
 
   const uint16_t *P = a.P + grp * a.p_gs;
   const uint16_t *Q = a.Q + grp * a.q_gs;
@@ -408,25 +409,32 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
   // load at an out-of-range offset and comes back as zeros (see the NT kernel)
   const mf::BufRsrc Prs = mf::make_rsrc(P), Qrs = mf::make_rsrc(Q);
   uint4 rp0, rp1, rp2, rp3, rq0, rq1, rq2, rq3;
+  // Load r of this lane is row 16 kr + 4 wave + r of the K-tile (it lands in LDS row 16 r + 4 wave + kr: any
+  // permutation of the reduction index is fine as long as both operands use it): the lane's four rows are consecutive,
+  // so with an output size that is a multiple of 4 they share (b, ox, oy) and differ in oz only -- one voxel decode,
+  // two range tests and one address per K-tile, then a z test and an add per load (the per-load decode was 20 of the
+  // kernel's 29 VALU instructions per load: 7.3 per MFMA).
 #define MF_TN_LOAD(r_, rp_, rq_)                                                                      \
   {                                                                                                   \
-    const int m_ = t_ * 64 + 16 * (r_) + 4 * wave + kr;                                               \
-    const bool ok_ = m_ < a.M;                                                                        \
-    rp_ = mf::buf_load16(Prs, ok_ && pcol_ok ? 2u * (uint32_t)(m_ * a.ldp + i0 + col) : mf::kBufMasked); \
-    bool qok_ = ok_ && qcol_ok;                                                                       \
-    int qaddr_ = m_ * a.ldq + q_off;                                                                  \
-    if (CONV) {                                                                                       \
-      const int b_ = m_ >> (3 * dol), ox_ = (m_ >> (2 * dol)) & (Do - 1), oy_ = (m_ >> dol) & (Do - 1), \
-                oz_ = m_ & (Do - 1);                                                                  \
-      qok_ = qok_ && (unsigned)(ox_ - lo_x) <= span_x && (unsigned)(oy_ - lo_y) <= span_y &&          \
-             (unsigned)(oz_ - lo_z) <= span_z;                                                        \
-      qaddr_ = tap_const + b_ * cb + ox_ * cxs + oy_ * cys + oz_ * czs;                               \
-    }                                                                                                 \
-    rq_ = mf::buf_load16(Qrs, qok_ ? 2u * (uint32_t)qaddr_ : mf::kBufMasked);                         \
+    const bool ok_ = mb_ + (r_) < a.M;                                                                \
+    rp_ = mf::buf_load16(Prs, ok_ && pcol_ok ? 2u * (uint32_t)(pb_ + (r_) * a.ldp) : mf::kBufMasked); \
+    bool qok_ = ok_ && qrow_ok_;                                                                      \
+    if (CONV) qok_ = qok_ && (unsigned)(zrel_ + (r_)) <= span_z;                                      \
+    rq_ = mf::buf_load16(Qrs, qok_ ? 2u * (uint32_t)(qb_ + (r_) * (CONV ? czs : a.ldq)) : mf::kBufMasked); \
   }
 #define MF_TN_FETCH(tt_)                                                                              \
   {                                                                                                   \
-    const int t_ = (tt_);                                                                             \
+    const int mb_ = (tt_) * 64 + mrow;                                                                \
+    const int pb_ = mb_ * a.ldp + i0 + col;                                                           \
+    int qb_ = mb_ * a.ldq + q_off, zrel_ = 0;                                                         \
+    bool qrow_ok_ = qcol_ok;                                                                          \
+    if (CONV) {                                                                                       \
+      const int b_ = mb_ >> (3 * dol), ox_ = (mb_ >> (2 * dol)) & (Do - 1), oy_ = (mb_ >> dol) & (Do - 1), \
+                oz_ = mb_ & (Do - 1);                                                                 \
+      qrow_ok_ = qcol_ok && (unsigned)(ox_ - lo_x) <= span_x && (unsigned)(oy_ - lo_y) <= span_y;     \
+      qb_ = tap_const + b_ * cb + ox_ * cxs + oy_ * cys + oz_ * czs;                                  \
+      zrel_ = oz_ - lo_z;                                                                             \
+    }                                                                                                 \
     MF_TN_LOAD(0, rp0, rq0) MF_TN_LOAD(1, rp1, rq1) MF_TN_LOAD(2, rp2, rq2) MF_TN_LOAD(3, rp3, rq3)   \
   }
 #define MF_TN_STASH(buf_)                                                                             \
@@ -834,12 +842,30 @@ extern "C" int64_t mf_conv3d_bf16_wgrad_workspace_bytes(int32_t Cin, int32_t Cou
   return (int64_t)(split > 1 ? split : 1) * Cout * ks * ks * ks * Cin * 4;
 }
 
+/* Split of the reduction (rows) of a weight-gradient GEMM over S workgroups per output tile, S fp32 slabs summed by
+ * the finish pass.  ``tiles`` output tiles of 128 x 128, ``ktiles`` row tiles of 64, ``slab_bytes`` = size of one
+ * slab.  Cost model in units of one K-tile of one workgroup (~1 us at two workgroups per CU, 512 slots on the chip):
+ *   ceil(tiles S / 512) rounds x (ceil(ktiles / S) + 8 K-tiles of prologue / epilogue)  +  S slabs read by the finish
+ * -- the first version doubled S until tiles * S >= 512, which put conv3 (160 tiles) at S = 4: 640 workgroups, a
+ * second round a quarter full; S = 3 fills one round. */
+extern "C" int32_t mf_wgrad_split(int64_t tiles, int64_t ktiles, int64_t slab_bytes) {
+  if (tiles <= 0 || ktiles <= 0) return 1;
+  const double per_slab = slab_bytes / 3.0e6 > 0.05 ? slab_bytes / 3.0e6 : 0.05;  // us at ~3 TB/s, launch floor
+  int best = 1;
+  double best_cost = 1e30;
+  for (int S = 1; S <= 512; ++S) {
+    if (S > 1 && ktiles / S < 8) break;
+    const int64_t rounds = (tiles * S + 511) / 512;
+    const double cost = (double)rounds * (double)((ktiles + S - 1) / S + 8) + (S > 1 ? S * per_slab : 0.0);
+    if (cost < best_cost) { best_cost = cost; best = S; }
+  }
+  return best;
+}
+
 extern "C" int32_t mf_conv3d_bf16_wgrad_default_split(int32_t B, int32_t Cin, int32_t Cout, int32_t Do, int32_t ks) {
-  const int64_t tiles = (int64_t)((Cout + 127) / 128) * (((int64_t)ks * ks * ks * Cin + 127) / 128);
-  const int64_t ktiles = ((int64_t)B * Do * Do * Do + 63) / 64;
-  int S = 1;
-  while (tiles * S < 512 && ktiles / (S * 2) >= 16) S *= 2;
-  return S;
+  const int64_t nj = (int64_t)ks * ks * ks * Cin;
+  return mf_wgrad_split((int64_t)((Cout + 127) / 128) * ((nj + 127) / 128), ((int64_t)B * Do * Do * Do + 63) / 64,
+                        (int64_t)Cout * nj * 4);
 }
 
 /* dW [Cout][w_cin][ks][ks][ks] (input channels c_off .., those below w_cin: fp32, the framework layout) = sum over
@@ -852,6 +878,7 @@ extern "C" int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, vo
   Geom g;
   if (int e = conv_geom(B, Cin, Cout, D, ks, stride, pad, dil, &g)) return e;
   if (split < 1 || !ws) return bad("conv3d wgrad: workspace required");
+  if (g.olog < 2) return bad("conv3d wgrad: output size >= 4 per axis");
   if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16<true>, kTnLds)) return e;
   TnArgs a = {};
   a.P = (const uint16_t *)dy; a.Q = (const uint16_t *)x; a.out = (float *)ws;

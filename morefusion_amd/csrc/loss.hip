@@ -39,7 +39,7 @@ __device__ __forceinline__ float3 apply(const Pose &p, float x, float y, float z
   return o;
 }
 
-constexpr int kPosesPerWg = 2;
+constexpr int kPosesPerWg = 1;
 
 // true images of model points [base, base + nt) into the SoA tile, padded to a multiple of 4 with +inf (never the
 // minimum); barriers on both sides
@@ -72,10 +72,11 @@ __device__ __forceinline__ void loss_walk(const float *__restrict__ points, cons
   const float *pts = points + (int64_t)b * M * 3;
   const Pose pt = load_pose(T_true + (int64_t)b * 16);
   const bool sym = symmetric != nullptr && symmetric[b] != 0;
-  // The true images are the same for every predicted pose of the object: a workgroup takes kPosesPerWg poses (two:
-  // with four, the symmetric objects' work sat in so few workgroups that the search lost its latency hiding) and,
-  // when the model fits one tile (M <= 1024: always, for the 500-point YCB clouds), stages the images ONCE -- the
-  // staging (dependent global loads, a barrier) was a third of a one-pose workgroup's time.
+  // The true images are the same for every predicted pose of the object: a workgroup takes kPosesPerWg poses and,
+  // when the model fits one tile (M <= 1024: always, for the 500-point YCB clouds), stages the images once for all
+  // of them.  kPosesPerWg = 1 is what the training step wants (measured, 16 objects x 1000 poses, the symmetric
+  // objects' searches dominate: 129 us with one pose per workgroup, 161 us with two, 175 us with four -- fewer,
+  // longer workgroups lose more latency hiding than the shared staging saves).
   const bool search = sym && !(BWD && nn_idx);
   const bool staged = search && M <= kLossTile;
   if (staged) stage_true_images(pt, pts, 0, M, s_tx, s_ty, s_tz);
@@ -117,7 +118,7 @@ __device__ __forceinline__ void loss_walk(const float *__restrict__ points, cons
           if (live) {
             float tb = best;
             int grp = -1;
-#pragma unroll 4
+#pragma unroll 2
             for (int i = 0; i < nt4; i += 4) {
               const float4 X = *reinterpret_cast<const float4 *>(&s_tx[i]);
               const float4 Y = *reinterpret_cast<const float4 *>(&s_ty[i]);
