@@ -1,3 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-bash tools/gpu_call.sh r05h "py=tools/time_gemm_bf16.py+16+--no-stock" "t=test_gpu_bf16_kernels.py" > gpurun_out/r05h_0.log 2>&1
-python examples/singleview_3d_train.py --global-batch 16 --steps 10 --json gpurun_out/r05h/train_rate.json > gpurun_out/r05h/train_rate.log 2>&1
+export MF_MARK=k_icc_scene_setup
+bash tools/gpu_call.sh r05j "prof=bench=MF_BENCH_MARK=1+python+bench.py+--no-cpu-baseline+--no-latency-probe+--steps+10" > gpurun_out/r05j_prof.log 2>&1
