@@ -8,8 +8,13 @@ Single GPU:   python examples/singleview_3d_train.py --steps 5
 N GPUs (DP):  python examples/singleview_3d_train.py --gpus N --steps 5      (launches its own N ranks;
               an external `python -m torch.distributed.run --nproc-per-node N ...` works too)
 The reference all-reduces gradients with ChainerMN `pure_nccl` (train.py:231,344); here it is
-torch DDP over RCCL (bucketed all-reduce overlapped with backward).  Convolutions / GEMMs run
-under bf16 autocast; the voxel ops and the loss stay fp32 (the HIP kernels are fp32).
+torch DDP over RCCL (bucketed all-reduce overlapped with backward).  Under bf16 autocast the 3-D CNN, the 1x1
+convolutions, voxelization and sampling run on the hand-written bf16 kernels (models/bf16_ops.py), the 2-D backbone
+on MIOpen, the loss on its fp32 HIP op.
+``--graph`` (single process): the step's device work -- forward, backward, Adam -- is captured into ONE hipGraph after
+three eager steps and replayed; the host keeps what the reference does on the host (the NumPy-RNG point selection and
+CAD subsample).  The eager step is launch-bound for a fifth of its time (~1100 launches, 22.1 ms for 17.7 ms of
+kernels): 724 -> 834 objects/s on one MI355X (profiles/r04_train_1gpu_bf16_hipgraph_step.json).
 """
 import argparse
 import json
@@ -62,6 +67,10 @@ def main():
     ap.add_argument("--no-bf16", action="store_true")
     ap.add_argument("--ddp", action="store_true",
                     help="wrap the model in DistributedDataParallel over RCCL even at world size 1")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture forward + backward + Adam of one step into a hipGraph after --graph-warmup eager "
+                         "steps and replay it (single process; the host keeps the point selection and the CAD subsample)")
+    ap.add_argument("--graph-warmup", type=int, default=3)
     ap.add_argument("--json", default=None, help="write a one-line JSON record of the run to this path")
     ap.add_argument("--dry-run-cpu", action="store_true", help="launcher + DDP plumbing on CPU/gloo, stub module")
     args = ap.parse_args()
@@ -88,7 +97,9 @@ def main():
     pcds = {c: rs.uniform(-0.05, 0.05, (2000, 3)).astype(np.float32) for c in morefusion.synthetic.CLASS_PITCH}
     model = Model(n_fg_class=21, with_occupancy=True, models=PitchTableModels(pcds)).to(device).train()
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if use_ddp else model
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+    if args.graph and use_ddp:
+        raise SystemExit("--graph captures a single-process step (DistributedDataParallel's bucket hooks are not captured)")
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=bool(args.graph))
 
     per_rank = max(1, args.global_batch // world)
     np.random.seed(1234 + rank)  # per-rank point / CAD subsampling streams
@@ -97,20 +108,61 @@ def main():
     # last two steps, so that `MF_MARK=erfinv tools/kernel_stats.py` keeps exactly one steady-state step
     mark = (lambda: torch.zeros(1, device=device).erfinv_()) if os.environ.get("MF_TRAIN_MARK") == "1" else (lambda: None)
     mark()
-    for step in range(args.steps):
-        if step >= args.steps - 2:
-            mark()
-        b = morefusion.synthetic.make_singleview_batch(per_rank, seed=1000 * rank + step)
-        inputs = {k: torch.as_tensor(b[k]).to(device) for k in
-                  ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty",
-                   "quaternion_true", "translation_true")}
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+    KEYS = ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty", "quaternion_true", "translation_true")
+    graph, static, static_loss = None, None, None
+    side = torch.cuda.Stream(device=device) if args.graph else None
+
+    def device_inputs(inp):
+        """The uploaded batch -> everything the device side of the step reads: the network inputs plus what the host
+        decides (point selection: one synchronisation; CAD subsample + ADD-S flags: host RNG, model.py:207-220,411-414)."""
+        cad, sym = model.loss_prepare(inp["class_id"], device)
+        assert torch.is_tensor(cad), "--graph needs CAD clouds of one size"
+        return dict(class_id=inp["class_id"], rgb=inp["rgb"], pcd=inp["pcd"], pix=model._select_points(inp["pcd"]),
+                    pitch=inp["pitch"].float(), origin=inp["origin"].float(),
+                    grid_nontarget_empty=inp["grid_nontarget_empty"], quaternion_true=inp["quaternion_true"],
+                    translation_true=inp["translation_true"], cad=cad, symmetric=sym)
+
+    def eager_step(inputs):
         optimizer.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.no_bf16):
             loss = net(**inputs)
         loss.backward()
         optimizer.step()
+        return loss
+
+    for step in range(args.steps):
+        if step >= args.steps - 2:
+            mark()
+        b = morefusion.synthetic.make_singleview_batch(per_rank, seed=1000 * rank + step)
+        inputs = {k: torch.as_tensor(b[k]).to(device) for k in KEYS}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if not args.graph:
+            loss = eager_step(inputs)
+        elif step < args.graph_warmup:
+            # torch's capture recipe: the eager warm-up steps run on the side stream the capture will use, so that
+            # the gradient accumulators and the optimizer state are born there
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                loss = eager_step(inputs)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            new = device_inputs(inputs)
+            if graph is None:
+                # capture: the step's device work on static tensors (torch's whole-network recipe: gradients are
+                # allocated inside the graph's pool, Adam is capturable); MIOpen's solvers were chosen by the eager steps
+                static = {k: v.clone() for k, v in new.items()}
+                optimizer.zero_grad(set_to_none=True)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.no_bf16):
+                        static_loss = model.forward_device(**static)
+                    static_loss.backward()
+                    optimizer.step()
+            for k, v in new.items():
+                static[k].copy_(v)
+            graph.replay()
+            loss = static_loss
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -123,12 +175,16 @@ def main():
         losses.append(loss_avg)
         if rank == 0:
             print(f"step {step}: loss {loss_avg:.5f}  {per_rank * world / dt:.1f} objects/s "
-                  f"(global batch {per_rank * world}, {world} GPU(s))", flush=True)
+                  f"(global batch {per_rank * world}, {world} GPU(s))"
+                  + ("  [hipGraph replay]" if args.graph and step > args.graph_warmup else
+                     "  [capture]" if args.graph and step == args.graph_warmup else ""), flush=True)
     if rank == 0 and args.json:
-        steady = rates[2:] or rates  # the first steps carry MIOpen's algorithm search
+        skip = args.graph_warmup + 1 if args.graph else 2  # the first steps carry MIOpen's algorithm search / the capture
+        steady = rates[skip:] or rates
         rec = {"what": "singleview_3d training step (BASELINE config 5 on this many GPUs), synthetic batch",
                "n_gpus": world, "global_batch": per_rank * world, "dtype": "f32" if args.no_bf16 else "bf16 autocast",
                "ddp": bool(use_ddp), "backend": "nccl (RCCL)" if use_ddp else None, "steps": args.steps,
+               "hipgraph_step": bool(args.graph),
                "objects_per_s_steady_mean": round(float(np.mean(steady)), 2),
                "objects_per_s_per_step": [round(r, 2) for r in rates], "loss_per_step": [round(x, 5) for x in losses]}
         with open(args.json, "w") as f:

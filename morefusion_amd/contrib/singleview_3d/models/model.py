@@ -471,30 +471,35 @@ class Model(nn.Module):
         return dict(add=float(np.mean(adds)), add_s=float(np.mean(add_ss)),
                     add_or_add_s=float(np.mean(mixed)))
 
-    def loss(self, *, class_id, quaternion_true, translation_true, quaternion_pred,
-             translation_pred, confidence_pred):
-        """DenseFusion pose loss (model.py:377-434): per object mean over the confident points
-        of ``ADD(-S) * conf - lambda * log(conf)``, averaged over the batch.  All B objects go
-        through ONE fused ADD / ADD-S kernel (functions.average_distance_batch) instead of the
-        reference's per-object loop of transform / nn / gather launches."""
+    def loss_prepare(self, class_id, device):
+        """The host side of ``loss`` (model.py:411-414): 500 random CAD points per object (host RNG, like the
+        reference) and the ADD-S flags.  Returns (cad, symmetric): cad a [B,500,3] device tensor -- or a list of
+        per-object arrays when the clouds differ in size -- and symmetric a [B] bool device tensor."""
+        cids = [int(c) for c in torch.as_tensor(class_id).tolist()]
+        cads = []
+        for cid in cids:
+            cad_pcd = self._models.get_pcd(cid)
+            cads.append(np.asarray(cad_pcd[np.random.permutation(cad_pcd.shape[0])[:500]], dtype=np.float32))
+        symmetric = torch.tensor([cid in CLASS_IDS_SYMMETRIC and self._loss != "add" for cid in cids],
+                                 dtype=torch.bool, device=device)
+        if len({c.shape[0] for c in cads}) == 1:
+            return torch.as_tensor(np.stack(cads), device=device), symmetric
+        return cads, symmetric
+
+    def loss_device(self, cad, symmetric, quaternion_true, translation_true, quaternion_pred, translation_pred,
+                    confidence_pred):
+        """The device side of ``loss``: no host work, no synchronisation (capturable into a hipGraph when ``cad``
+        is one tensor)."""
         B, P = quaternion_pred.shape[0], quaternion_pred.shape[1]
         dev = quaternion_pred.device
-        cids = [int(c) for c in torch.as_tensor(class_id).tolist()]
         T_pred = functions_module.transformation_matrix(
             quaternion_pred.reshape(B * P, 4), translation_pred.reshape(B * P, 3)).reshape(B, P, 4, 4)
         T_true = functions_module.transformation_matrix(quaternion_true.float(), translation_true.float())
-        cads = []
-        for cid in cids:  # model.py:411-414: 500 random CAD points per object (host RNG, like the reference)
-            cad_pcd = self._models.get_pcd(cid)
-            cads.append(np.asarray(cad_pcd[np.random.permutation(cad_pcd.shape[0])[:500]], dtype=np.float32))
-        symmetric = [cid in CLASS_IDS_SYMMETRIC and self._loss != "add" for cid in cids]
-        if len({c.shape[0] for c in cads}) == 1:
-            cad = torch.as_tensor(np.stack(cads), device=dev)
-            sym = torch.tensor(symmetric, dtype=torch.bool, device=dev) if any(symmetric) else None
-            add = functions_module.average_distance_batch(cad, T_true, T_pred, sym)  # [B,P]
+        if torch.is_tensor(cad):
+            add = functions_module.average_distance_batch(cad, T_true, T_pred, symmetric)  # [B,P]
         else:  # CAD clouds of different sizes (< 500 points): one call per object
             add = torch.stack([functions_module.average_distance(
-                torch.as_tensor(cads[i], device=dev), T_true[i], T_pred[i], symmetric=symmetric[i])
+                torch.as_tensor(cad[i], device=dev), T_true[i], T_pred[i], symmetric=bool(symmetric[i]))
                 for i in range(B)])
         keep = confidence_pred.detach() > 0
         conf = torch.where(keep, confidence_pred, torch.ones_like(confidence_pred))
@@ -502,3 +507,23 @@ class Model(nn.Module):
                                 torch.zeros_like(add))
         per_object = per_point.sum(dim=1) / keep.sum(dim=1)  # an object without a confident point -> nan, as .mean() of nothing
         return per_object.sum() / B
+
+    def loss(self, *, class_id, quaternion_true, translation_true, quaternion_pred,
+             translation_pred, confidence_pred):
+        """DenseFusion pose loss (model.py:377-434): per object mean over the confident points
+        of ``ADD(-S) * conf - lambda * log(conf)``, averaged over the batch.  All B objects go
+        through ONE fused ADD / ADD-S kernel (functions.average_distance_batch) instead of the
+        reference's per-object loop of transform / nn / gather launches."""
+        cad, symmetric = self.loss_prepare(class_id, quaternion_pred.device)
+        if not bool(symmetric.any()):
+            symmetric = None if torch.is_tensor(cad) else symmetric
+        return self.loss_device(cad, symmetric, quaternion_true, translation_true, quaternion_pred,
+                                translation_pred, confidence_pred)
+
+    def forward_device(self, class_id, rgb, pcd, pix, pitch, origin, grid_nontarget_empty, quaternion_true,
+                       translation_true, cad, symmetric):
+        """``forward`` with the host work done ahead (``_select_points`` -> pix, ``loss_prepare`` -> cad, symmetric):
+        device work only, the form a training step is captured into a hipGraph in
+        (examples/singleview_3d_train.py --graph)."""
+        q, t, c = self._predict_device(class_id, rgb, pcd, pix, pitch, origin, grid_nontarget_empty)
+        return self.loss_device(cad, symmetric, quaternion_true, translation_true, q, t, c)

@@ -12,7 +12,10 @@ def compose_transform(R, t):
         raise TypeError("R must be [N,3,3] and t [N,3]")
     N = R.shape[0]
     top = torch.cat([R, t[:, :, None]], dim=2)
-    bottom = torch.tensor([0, 0, 0, 1], dtype=R.dtype, device=R.device).expand(N, 1, 4)
+    # (built on the device: a host list would be a pageable host-to-device copy, which a hipGraph capture refuses)
+    bottom = torch.zeros((1, 1, 4), dtype=R.dtype, device=R.device)
+    bottom[..., 3] = 1
+    bottom = bottom.expand(N, 1, 4)
     matrix = torch.cat([top, bottom], dim=1)
     if squeeze_axis0:
         matrix = matrix[0, :, :]

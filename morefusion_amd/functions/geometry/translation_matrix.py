@@ -12,8 +12,9 @@ def translation_matrix(translation):
     N = translation.shape[0]
     eye = torch.eye(3, dtype=translation.dtype, device=translation.device).expand(N, 3, 3)
     top = torch.cat([eye, translation[:, :, None]], dim=2)
-    bottom = torch.tensor([0, 0, 0, 1], dtype=translation.dtype,
-                          device=translation.device).expand(N, 1, 4)
+    bottom = torch.zeros((1, 1, 4), dtype=translation.dtype, device=translation.device)  # (device-built: capture-safe)
+    bottom[..., 3] = 1
+    bottom = bottom.expand(N, 1, 4)
     matrix = torch.cat([top, bottom], dim=1)
     if squeeze_axis0:
         matrix = matrix[0, :, :]

@@ -1,3 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-export MF_MARK=k_icc_scene_setup
-bash tools/gpu_call.sh r05j "prof=bench=MF_BENCH_MARK=1+python+bench.py+--no-cpu-baseline+--no-latency-probe+--steps+10" > gpurun_out/r05j_prof.log 2>&1
+mkdir -p gpurun_out/r05k
+timeout 600 python -X faulthandler examples/singleview_3d_train.py --global-batch 16 --steps 14 --graph --json gpurun_out/r05k/train_graph.json > gpurun_out/r05k/train_graph.log 2>&1; echo "rc $?" >> gpurun_out/r05k/train_graph.log
