@@ -71,6 +71,8 @@ def main():
                     help="capture forward + backward + Adam of one step into a hipGraph after --graph-warmup eager "
                          "steps and replay it (single process; the host keeps the point selection and the CAD subsample)")
     ap.add_argument("--graph-warmup", type=int, default=3)
+    ap.add_argument("--no-dropout", action="store_true",
+                    help="PSPNet's dropouts off (pspnet.py:24-30): makes an eager and a --graph run comparable step by step")
     ap.add_argument("--json", default=None, help="write a one-line JSON record of the run to this path")
     ap.add_argument("--dry-run-cpu", action="store_true", help="launcher + DDP plumbing on CPU/gloo, stub module")
     args = ap.parse_args()
@@ -92,6 +94,8 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(parallel.free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    if args.no_dropout:
+        torch.nn.functional.dropout = lambda x, p=0.5, training=True, inplace=False: x
     torch.manual_seed(0)  # identical initial weights on every rank
     rs = np.random.RandomState(0)
     pcds = {c: rs.uniform(-0.05, 0.05, (2000, 3)).astype(np.float32) for c in morefusion.synthetic.CLASS_PITCH}

@@ -85,3 +85,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", "").replace("oracle order", "").replace("oracle)", ""), os.path.join(dp, f)
+
+
+def test_wgrad_split_cost_model_is_a_host_function_with_sane_answers():
+    """mf_wgrad_split (csrc/gemm_bf16.hip): no device call -- the slab count of a weight-gradient GEMM from the number
+    of 128 x 128 output tiles, 64-row K-tiles and the slab size.  conv3 at the training batch (160 tiles, 1024
+    K-tiles) fills exactly one round of the chip's 512 workgroup slots with 3 slabs (4 would spill a quarter-full
+    second round); conv4 (512 tiles) needs none; tiny layers split deep but keep >= 8 K-tiles per slab."""
+    import ctypes
+    from morefusion_amd import _lib
+    L = _lib.lib()
+    L.mf_wgrad_split.argtypes = [ctypes.c_int64] * 3
+    L.mf_wgrad_split.restype = ctypes.c_int32
+    assert L.mf_wgrad_split(160, 1024, 256 * 10240 * 4) == 3
+    assert L.mf_wgrad_split(512, 128, 512 * 16384 * 4) == 1
+    assert L.mf_wgrad_split(120, 250, 1920 * 984 * 4) == 4
+    for tiles, ktiles, slab in ((1, 250, 8192), (2, 8192, 6912), (7, 3, 100), (0, 0, 0), (4096, 1, 1 << 20)):
+        s = L.mf_wgrad_split(tiles, ktiles, slab)
+        assert 1 <= s <= 512 and (s == 1 or ktiles // s >= 8), (tiles, ktiles, s)

@@ -113,8 +113,9 @@ def test_bf16_autocast_training_steps_track_fp32():
 def test_hipgraph_captured_training_step_tracks_the_eager_step(tmp_path):
     """examples/singleview_3d_train.py --graph: forward + backward + Adam of one step captured into a hipGraph after
     three eager steps (the host keeps the point selection and the CAD subsample), replayed for the rest.  Same
-    seeds, same batches: the loss of every step stays within 3 % of the eager run's (the dropout masks come from a
-    different position of the generator's stream; train.py:342-369 is the loop both restate)."""
+    seeds, same batches, PSPNet's dropouts off (their masks would come from different positions of the generator's
+    stream): the loss of every step stays within 1 % of the eager run's -- a replay on stale inputs or without the
+    optimiser step would be off by the batch-to-batch spread, 10 - 20 % (train.py:342-369 is the loop both restate)."""
     import json
     import os
     import subprocess
@@ -125,7 +126,7 @@ def test_hipgraph_captured_training_step_tracks_the_eager_step(tmp_path):
     recs = {}
     for tag, extra in (("eager", []), ("graph", ["--graph"])):
         out = tmp_path / f"{tag}.json"
-        p = subprocess.run([sys.executable, script, "--global-batch", "4", "--steps", "7", "--json", str(out)] + extra,
+        p = subprocess.run([sys.executable, script, "--global-batch", "4", "--steps", "7", "--no-dropout", "--json", str(out)] + extra,
                            env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         recs[tag] = json.loads(out.read_text())
@@ -133,4 +134,5 @@ def test_hipgraph_captured_training_step_tracks_the_eager_step(tmp_path):
     le, lg = np.array(recs["eager"]["loss_per_step"]), np.array(recs["graph"]["loss_per_step"])
     assert np.isfinite(lg).all() and len(lg) == 7
     np.testing.assert_allclose(lg[:3], le[:3], rtol=2e-3)   # the eager warm-up steps (side stream): the same work
-    np.testing.assert_allclose(lg[3:], le[3:], rtol=3e-2)   # capture + three replays
+    np.testing.assert_allclose(lg[3:], le[3:], rtol=1e-2)   # capture + three replays
+    assert np.ptp(le) > 0.05 * le.mean()                    # (the batches do differ by more than the tolerance)
