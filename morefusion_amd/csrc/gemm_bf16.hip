@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
     *reinterpret_cast<uint4 *>(Bs_) = rb0##S; *reinterpret_cast<uint4 *>(Bs_ + 32 * kPitch) = rb1##S; \
     *reinterpret_cast<uint4 *>(Bs_ + 64 * kPitch) = rb2##S; *reinterpret_cast<uint4 *>(Bs_ + 96 * kPitch) = rb3##S; \
   }
-#define MF_NT_COMPUTE(buf_)                                                                           \
+  // NJ_ = 2: both 32-column blocks of the wave's 64 columns; NJ_ = 1: the first only (the second lies past N)
+#define MF_NT_COMPUTE(buf_, NJ_)                                                                      \
   {                                                                                                   \
     asm volatile("" ::: "memory");                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -218,17 +219,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
       const uint4 a0 = *reinterpret_cast<const uint4 *>(As + 32 * s);                                 \
       const uint4 b0 = *reinterpret_cast<const uint4 *>(Bs + 32 * s);                                 \
-      const uint4 b1 = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * s);                   \
       acc[0][0] = mf::mfma_bf16_32x32x16(a0, b0, acc[0][0]);                                          \
-      acc[0][1] = mf::mfma_bf16_32x32x16(a0, b1, acc[0][1]);                                          \
-      if constexpr (MI == 2) {                                                                        \
+      if constexpr (NJ_ == 2) {                                                                       \
+        const uint4 b1 = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * s);                 \
+        acc[0][1] = mf::mfma_bf16_32x32x16(a0, b1, acc[0][1]);                                        \
+        if constexpr (MI == 2) {                                                                      \
+          const uint4 a1 = *reinterpret_cast<const uint4 *>(As + 32 * kPitch + 32 * s);               \
+          acc[MI - 1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[MI - 1][0]);                            \
+          acc[MI - 1][1] = mf::mfma_bf16_32x32x16(a1, b1, acc[MI - 1][1]);                            \
+        }                                                                                             \
+      } else if constexpr (MI == 2) {                                                                 \
         const uint4 a1 = *reinterpret_cast<const uint4 *>(As + 32 * kPitch + 32 * s);                 \
         acc[MI - 1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[MI - 1][0]);                              \
-        acc[MI - 1][1] = mf::mfma_bf16_32x32x16(a1, b1, acc[MI - 1][1]);                              \
       }                                                                                               \
     }                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                \
   }
+  // Column blocks of this wave that lie past N (the last N-tile of a layer whose width is not a multiple of 128:
+  // conv3's data gradient has N = 160 -- its second tile holds 32 columns) are not multiplied: wave-uniform.
+  const int ncols = a.N - (n0 + wn * 64);  // columns of this wave's 64 that exist
   // Per K-tile t: the loads of tile t + 1 are issued, tile t is multiplied, the registers go into the other buffer,
   // barrier.  (Stash AFTER the barrier and the next fetch right behind it -- the order the 256^2-tile GEMMs of the
   // programming guide prefer -- measured 3 - 5 % slower here, at 2 workgroups per CU.)  The fetches run over the
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
   __syncthreads();
   for (int t = 0; t < T; ++t) {
     MF_NT_FETCH(P);  // tile t + 1 in flight under the MFMAs of tile t
-    MF_NT_COMPUTE(t & 1);
+    if (ncols > 32) MF_NT_COMPUTE(t & 1, 2) else if (ncols > 0) MF_NT_COMPUTE(t & 1, 1)
     MF_NT_STASH(P, (t + 1) & 1);
     __syncthreads();
   }

@@ -1,2 +1,2 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest -m gpu -x -q tests/test_gpu_training.py -k hipgraph > gpurun_out/r05l_test.log 2>&1; echo "rc $?" >> gpurun_out/r05l_test.log
+bash tools/gpu_call.sh r05m "py=tools/time_gemm_bf16.py+16+--no-stock" "t=test_gpu_bf16_kernels.py" > gpurun_out/r05m_0.log 2>&1
