@@ -6,6 +6,14 @@
                                                      conv3 dense + sparse, conv4, samplers, heads, pose epilogue)
                                                      vs the dense channels-first formulation of model.py:93-164,232-275
     python guard_case.py frontend after|before       valid-pixel order, the fused PSPNet tail, instance crops
+    python guard_case.py training after|before       the bf16 training operators (bf16_ops.py over gemm_bf16.hip,
+                                                     voxelize.hip, interp.hip): conv forward / data / weight gradient
+                                                     (k4 s2 with a channel offset, k3 with dilation), 1x1 convolutions
+                                                     with ragged N / K / row counts, channels-last voxelization and
+                                                     sampling, forward + backward -- the bodies of
+                                                     tests/test_emul_bf16_ops.py.  These kernels mask with
+                                                     out-of-range BUFFER loads over a 2 GB span (no hardware bound at
+                                                     the tensor's end): the guard pages are the bound here.
 
 Every tensor any of these kernels is handed -- inputs, packed weights, scratch, workspaces, outputs -- sits
 against an inaccessible page on the named side (emul.GuardedTensors)."""
@@ -171,5 +179,24 @@ def frontend(side):
     print(f"GUARD_OK frontend {side}")
 
 
+def training(side):
+    from morefusion_amd.contrib.singleview_3d.models import bf16_ops
+    import test_emul_bf16_ops as T   # the test bodies: operators vs torch float32 autograd / the oracle
+    L = emul.build(["gemm_bf16.hip", "voxelize.hip", "interp.hip"])
+    _bind(L)
+    log = open(os.environ["MF_GUARD_LOG"], "w") if os.environ.get("MF_GUARD_LOG") else None
+    with emul.GuardedTensors(L, side, log) as G:
+        _patch_lib(G)
+        T.test_conv3d_operator_forward_and_gradients(bf16_ops)
+        T.test_occupancy_branch_operator_chain(bf16_ops)
+        for n, Kin, N, relu in ((150, 3, 8, True), (130, 64, 63, False), (70, 200, 136, True)):
+            T.test_linear_operator_forward_and_gradients.__wrapped__(bf16_ops, n, Kin, N, relu) if hasattr(
+                T.test_linear_operator_forward_and_gradients, "__wrapped__") else \
+                T.test_linear_operator_forward_and_gradients(bf16_ops, n, Kin, N, relu)
+        T.test_channels_last_bf16_voxelization_and_sampling_vs_oracle(bf16_ops)
+    assert G.calls > 40, G.calls
+    print(f"GUARD_OK training {side}")
+
+
 if __name__ == "__main__":
-    {"volumetric": volumetric, "frontend": frontend}[sys.argv[1]](sys.argv[2])
+    {"volumetric": volumetric, "frontend": frontend, "training": training}[sys.argv[1]](sys.argv[2])

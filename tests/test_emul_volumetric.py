@@ -40,3 +40,12 @@ def test_front_end_kernels_behind_guard_pages(side, tmp_path):
     """k_psp_tail through PSPNetExtractor.forward_sampled_rows (image corners / edges, NCHW and channels-last maps)
     and k_valid_order through Model._select_points (ragged counts, an exact-chunk and a ragged-chunk image size)."""
     _run("frontend", side, tmp_path)
+
+
+@pytest.mark.parametrize("side", ["after", "before"])
+def test_bf16_training_operators_behind_guard_pages(side, tmp_path):
+    """csrc/gemm_bf16.hip (NT / TN engines, packs, finish passes) and the channels-last bf16 voxelization / sampling
+    kernels, forward and backward, with every tensor against an inaccessible page: their masked operand chunks are
+    buffer loads at an out-of-range offset over a 2 GB span -- nothing in hardware stops a wrong UNMASKED offset at
+    the end of the tensor, so the bound is checked here."""
+    _run("training", side, tmp_path)
