@@ -15,16 +15,18 @@
 //                                  (1 - p) + 2 s per axis (x = 2 h + p); a tile of 128 rows is class-homogeneous
 //                                  and multiplies that class's [Cin][8 Cout] weight slice
 //   TN   C[i][j] = sum_m P[m][i] * Q(m, j)        the reduction index is the ROW index of both operands
-//        (weight gradients: P = dY, Q = the layer's input rows / im2col rows).  Rows are staged through a
-//        4 x 8 register transpose into an LDS image [i][m] so that the MFMA fragments stay ONE ds_read_b128;
-//        split over m into fp32 slabs, summed in slab order by k_wgrad_finish (deterministic, no float atomics).
+//        (weight gradients: P = dY, Q = the layer's input rows / im2col rows).  Rows land in LDS in the global order
+//        (plain ds_write_b128); the MFMA fragments come out through gfx950's transposing LDS read
+//        ds_read_b64_tr_b16.  Split over m into fp32 slabs (mf_wgrad_split: a cost model over rounds of workgroup
+//        slots), summed in slab order by k_wgrad_finish / k_wgrad_finish_conv (deterministic, no float atomics).
 //
-// Tile: 128 x 128 x 64 per 256-lane workgroup (4 waves, each a 64 x 64 corner = 2 x 2 accumulators of 32 x 32),
-// LDS rows of 64 bf16 at a pitch of 144 bytes (36 dwords: the sixteen rows a ds_read_b128 phase touches start
-// 4 dwords apart modulo 64 banks -- conflict-free), register-staged double buffering with the next tile's
-// global loads pinned in front of this tile's 16 MFMAs, one barrier per K-tile, 2 workgroups per CU.
-// The epilogue goes through LDS: bias + ReLU on the way in, 16-byte row segments out (bf16 or fp32,
-// optionally accumulating into an fp32 tensor).
+// Tile: 128 x 128 x 64 per 256-lane workgroup (4 waves, each a 64 x 64 corner = 2 x 2 accumulators of 32 x 32).
+// NT: LDS rows of 64 bf16 at a pitch of 144 bytes (36 dwords: the sixteen rows a ds_read_b128 phase touches start
+// 4 dwords apart modulo 64 banks -- conflict-free).  Register-staged double buffering with the next tile's global
+// loads issued in front of this tile's 16 MFMAs and kept opaque until behind them, one barrier per K-tile,
+// 2 workgroups per CU.  Masked operand chunks (padding taps, tails) are buffer loads at an out-of-range offset: the
+// hardware returns zeros, nothing touches the loaded data (mf_common.h).  The epilogue goes through LDS: bias +
+// ReLU on the way in, 16-byte row segments out (bf16 or fp32, optionally accumulating into an fp32 tensor).
 #include "mf_common.h"
 
 namespace {
