@@ -554,6 +554,34 @@ __global__ __launch_bounds__(256) void k_wgrad_finish(const float *__restrict__ 
   out[g * c_gs + i * out_row_pitch + o] = v;
 }
 
+// The same sum for MANY slabs of a SMALL result (the occupancy convolutions: a few thousand weights in up to 256
+// slabs -- one thread per weight walked 256 dependent-latency loads: 62 us): one WAVE per weight, lane l adds slabs
+// l, l + 64, ... in increasing order, the 64 partial sums meet in a fixed butterfly (deterministic).
+__global__ __launch_bounds__(256) void k_wgrad_finish_deep(const float *__restrict__ slabs, float *__restrict__ out,
+                                                           int64_t per_slab, int Nj, int ldc, int S, int conv_cin,
+                                                           int64_t c_gs, int64_t per_group, int64_t out_row_pitch,
+                                                           int taps, int cin_keep) {
+  const int64_t idx = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (idx >= per_slab) return;  // wave-uniform
+  const int lane = threadIdx.x & 63;
+  float v = 0.0f;
+  for (int s = lane; s < S; s += 64) v += slabs[(int64_t)s * per_slab + idx];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  if (lane != 0) return;
+  const int64_t g = idx / per_group, in_g = idx - g * per_group;
+  const int64_t i = in_g / ldc;
+  const int j = (int)(in_g - i * ldc);
+  if (j >= Nj) return;
+  int64_t o = j;
+  if (conv_cin) {
+    const int tap = j / conv_cin, ci = j - tap * conv_cin;
+    if (ci >= cin_keep) return;
+    o = (int64_t)ci * taps + tap;
+  }
+  out[g * c_gs + i * out_row_pitch + o] = v;
+}
+
 // The convolution form of the finish pass as a tiled transpose: workgroup (ci block of 64, co) sums the slabs'
 // [tap][cin] tile -- rows of 64 consecutive cin, coalesced -- into LDS and writes it out as [cin][tap], the
 // framework's order, contiguous again.  (The element-wise form above would write 4-byte values ``taps`` floats apart:
@@ -770,8 +798,12 @@ extern "C" int mf_linear_wgrad_bf16(const void *dY, int64_t y_gs, int32_t ldy, c
   hipLaunchKernelGGL(k_gemm_tn_bf16<false>, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
   if (split > 1) {
     const int64_t per_group = (int64_t)N * ldc, per_slab = per_group * groups;
-    hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, stream,
-                       (const float *)ws, dW, per_slab, K, ldc, split, 0, w_gs, per_group, (int64_t)ldc, 0, 0);
+    if (split >= 32 && per_slab <= (1 << 16))
+      hipLaunchKernelGGL(k_wgrad_finish_deep, dim3((unsigned)((per_slab + 3) / 4)), dim3(256), 0, stream,
+                         (const float *)ws, dW, per_slab, K, ldc, split, 0, w_gs, per_group, (int64_t)ldc, 0, 0);
+    else
+      hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, stream,
+                         (const float *)ws, dW, per_slab, K, ldc, split, 0, w_gs, per_group, (int64_t)ldc, 0, 0);
   }
   return mf::check_launch("mf_linear_wgrad_bf16");
 }
@@ -908,6 +940,10 @@ extern "C" int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, vo
   if (keep > 0 && per_slab >= (1 << 20))
     hipLaunchKernelGGL(k_wgrad_finish_conv, dim3((keep + kPackTile - 1) / kPackTile, Cout), dim3(256), 0, stream,
                        (const float *)ws, dW + (int64_t)c_off * g.taps, per_slab, a.S, Cin, g.taps, w_cin, keep);
+  else if (keep > 0 && a.S >= 32 && per_slab <= (1 << 16))
+    hipLaunchKernelGGL(k_wgrad_finish_deep, dim3((unsigned)((per_slab + 3) / 4)), dim3(256), 0, stream,
+                       (const float *)ws, dW + (int64_t)c_off * g.taps, per_slab, g.taps * Cin, g.taps * Cin, a.S, Cin,
+                       (int64_t)0, per_slab, (int64_t)w_cin * g.taps, g.taps, keep);
   else if (keep > 0)
     hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, stream,
                        (const float *)ws, dW + (int64_t)c_off * g.taps, per_slab, g.taps * Cin, g.taps * Cin, a.S, Cin,

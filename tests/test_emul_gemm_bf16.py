@@ -98,7 +98,7 @@ def test_linear_bf16_forward_dgrad_wgrad(L, M, N, K, groups, relu):
     close(dA, dY.float() @ W[0].float())
     # weight gradient, with and without the split over rows
     if N % 8 == 0:
-        for split in (1, 3):
+        for split in (1, 3, 40):   # (40 slabs of a small result: the one-wave-per-weight finish)
             dW = torch.full((groups, N, K), 5.0)
             dYg = bf(torch.randn(M, groups * N))
             ws = torch.empty(max(split, 1) * groups * N * K)
@@ -186,8 +186,8 @@ def test_occupancy_branch_convolutions_on_the_general_geometry(L, name, Cin_real
                                 None) == 0
     close_bf16(out[:, :, 4:4 + Cout], cl(F.relu(y.detach())).reshape(B, D ** 3, Cout))
     assert float(out[:, :, :4].float().max()) == -3.0 and float(out[:, :, 4 + Cout:].float().max()) == -3.0
-    # weight gradient
-    for split in (1, 2):
+    # weight gradient (33 slabs: the one-wave-per-weight finish of the small layers)
+    for split in (1, 2, 33):
         dW = torch.full((Cout, Cin_real, ks, ks, ks), 9.0)
         ws = torch.empty(L.mf_conv3d_bf16_wgrad_workspace_bytes(Cin, Cout, ks, split) // 4)
         assert L.mf_conv3d_bf16_wgrad(p(dy_cl), p(x_cl), p(dW), p(ws), B, Cin, Cout, D, ks, 1, pad, dil, Cin_real, 0,
