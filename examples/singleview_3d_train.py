@@ -14,7 +14,7 @@ on MIOpen, the loss on its fp32 HIP op.
 ``--graph`` (single process): the step's device work -- forward, backward, Adam -- is captured into ONE hipGraph after
 three eager steps and replayed; the host keeps what the reference does on the host (the NumPy-RNG point selection and
 CAD subsample).  The eager step is launch-bound for a fifth of its time (~1100 launches, 22.1 ms for 17.7 ms of
-kernels): 724 -> 834 objects/s on one MI355X (profiles/r04_train_1gpu_bf16_hipgraph_step.json).
+kernels): 742 -> 841 objects/s on one MI355X (profiles/r04_train_1gpu_bf16_hipgraph_step.json).
 """
 import argparse
 import json
