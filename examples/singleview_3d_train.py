@@ -88,6 +88,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_ddp = world > 1 or args.ddp
+    if use_ddp and args.graph:
+        # Tried in round 4 with torch's recipe (asynchronous NCCL error handling off, DDP constructed on the side
+        # stream, 11 eager DDP steps, then the capture): on this stack (torch 2.10 + ROCm 7 RCCL) ProcessGroupNCCL's
+        # watchdog thread queries an event recorded in the capturing stream and the process aborts with
+        # hipErrorCapturedEvent at the first captured all-reduce (world size 1, gpurun r05q).
+        raise SystemExit("--graph captures a single-process step: under DistributedDataParallel the RCCL watchdog "
+                         "aborts the capture on this stack (hipErrorCapturedEvent)")
     if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
@@ -100,9 +107,8 @@ def main():
     rs = np.random.RandomState(0)
     pcds = {c: rs.uniform(-0.05, 0.05, (2000, 3)).astype(np.float32) for c in morefusion.synthetic.CLASS_PITCH}
     model = Model(n_fg_class=21, with_occupancy=True, models=PitchTableModels(pcds)).to(device).train()
+    side = torch.cuda.Stream(device=device) if args.graph else None
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if use_ddp else model
-    if args.graph and use_ddp:
-        raise SystemExit("--graph captures a single-process step (DistributedDataParallel's bucket hooks are not captured)")
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=bool(args.graph))
 
     per_rank = max(1, args.global_batch // world)
@@ -114,7 +120,6 @@ def main():
     mark()
     KEYS = ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty", "quaternion_true", "translation_true")
     graph, static, static_loss = None, None, None
-    side = torch.cuda.Stream(device=device) if args.graph else None
 
     def device_inputs(inp):
         """The uploaded batch -> everything the device side of the step reads: the network inputs plus what the host
@@ -160,7 +165,7 @@ def main():
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side):
                     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.no_bf16):
-                        static_loss = model.forward_device(**static)
+                        static_loss = net(**static)  # Model.forward's device form (through DDP's hooks when wrapped)
                     static_loss.backward()
                     optimizer.step()
             for k, v in new.items():

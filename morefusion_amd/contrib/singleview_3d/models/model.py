@@ -435,7 +435,10 @@ class Model(nn.Module):
 
     # ---- training (model.py:277-481) ------------------------------------------------------
     def forward(self, *, class_id, rgb, pcd, quaternion_true, translation_true, pitch=None,
-                origin=None, grid_target=None, grid_nontarget_empty=None):
+                origin=None, grid_target=None, grid_nontarget_empty=None, pix=None, cad=None, symmetric=None):
+        if pix is not None:  # the host's share was done ahead (``forward_device``: capturable, also through DDP)
+            return self.forward_device(class_id, rgb, pcd, pix, pitch, origin, grid_nontarget_empty, quaternion_true,
+                                       translation_true, cad, symmetric)
         quaternion_pred, translation_pred, confidence_pred = self.predict(
             class_id=class_id, rgb=rgb, pcd=pcd, pitch=pitch, origin=origin,
             grid_nontarget_empty=grid_nontarget_empty)
