@@ -188,7 +188,7 @@ typedef struct {
   int32_t n_scenes;  /* S */
   int32_t n_points;  /* Ptot */
   int32_t dim;       /* D (32) */
-  int32_t max_scene_objects; /* max objects in one scene (<= 32) */
+  int32_t max_scene_objects; /* max objects in one scene (<= 64) */
   float voxel_threshold;
   float sdf_offset;
   int32_t grid_ne_binary; /* != 0: the caller guarantees that every grid_ne value is exactly 0 or 1
@@ -221,6 +221,13 @@ int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float *adam_m,
                   float *adam_v, int32_t n_iter, int32_t step0, float alpha_q,
                   float alpha_t, float *losses, float *traj, void *ws,
                   mfStream_t stream);
+
+/* Launches per iteration mf_icc_refine will use for this batch: 1 = k_icc_iter (round 5: {0,1} no-entry grids,
+ * voxel_threshold 2, scenes of <= 16 objects -- what every caller of the reference passes; the tiles of iteration
+ * k read the model-point bins iteration k - 1 built and the same launch bins for k + 1), 2 = k_icc_bin +
+ * k_icc_fused (other thresholds / larger scenes, or MF_ICC_TWO_LAUNCH=1), 3 = k_icc_bin + k_icc_tile +
+ * k_icc_accum (any no-entry grid values).  Negative: invalid descriptor.  All paths give the same bits. */
+int mf_icc_iteration_launches(const mfIccBatch *batch);
 
 /* Measurement hook so that bench.py can time ONE kernel of an ICC iteration with HIP events:
  * stage 0 = (optional pose refresh from q, t if non-NULL) + empty the bins + k_icc_bin (pose ->

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "mf_icp_refine": ([_p, _p, _p, _p, ctypes.c_int32, ctypes.c_int32, _f, _p, _p, _p, _p, ctypes.c_int32,
                        ctypes.c_int32, _f, _f, _p, _p, _p], _i),
     "mf_icc_workspace_bytes": ([ctypes.POINTER(IccBatch)], _i64),
+    "mf_icc_iteration_launches": ([ctypes.POINTER(IccBatch)], _i),
     "mf_icc_launch_stage": ([ctypes.POINTER(IccBatch), _p, _p, _p, ctypes.c_int32, _p], _i),
     "mf_icc_prepare": ([ctypes.POINTER(IccBatch), _p, _p], _i),
     "mf_icc_loss_grad": ([ctypes.POINTER(IccBatch), _p, _p, _p, _p, _p, _p, _p], _i),

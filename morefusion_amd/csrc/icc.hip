@@ -86,9 +86,10 @@ struct IccArgs {
   float thr, sdf_offset;
   // workspace
   unsigned long long *W;  // [2*O][V]
-  uint32_t *Mbits;        // [2 parities][2*O] per-grid max of the raw inside weight (float bits)
+  uint32_t *Mbits;        // [3 parities][2*O] per-grid max of the raw inside weight (float bits)
+                          // (the two-launch path uses parities 0 and 1 of every three-parity array)
   int ne_binary;          // every grid_ne value is exactly 0 or 1 -> single-pass path (see k_icc_fused)
-  float *Rt;              // [O][12]  R row-major, then t
+  float *Rt;              // [2][O][12]  R row-major, then t (the two-launch path uses copy 0)
   float *bound;           // [O][4]   model-frame bounding sphere
   float *St;              // [S]
   // reduced sums of one iteration, 64-bit fixed point, two parities (iteration k adds into
@@ -120,6 +121,15 @@ struct IccArgs {
   int bin_cap_force;      // > 0: every cap_g = this (MF_ICC_BIN_CAP: exercises the overflow path in tests)
   float4 *rec;            // records {fx, fy, fz, point id bits}: voxel-frame coordinates
   int dbg;                // tuning aid: MF_ICC_DEBUG bit mask (0 in production)
+  // ---- one-launch-per-iteration path (k_icc_iter, round 5) ----
+  // The tiles of iteration k read the bins that iteration k - 1 built from ITS pose: a record is then the MODEL
+  // point {mx, my, mz, point id | scene-local object << 27} and the reader transforms it with the current pose.
+  // mg = margin in planes / rows a bin reaches beyond the exact neighbourhood (0: two-launch path, 1: k_icc_iter).
+  int mg;
+  int rec_model;          // k_icc_bin stores model points (the bins feed k_icc_iter)
+  int uniform_ns;         // > 0: every scene holds exactly this many objects (scene tables need no load)
+  int64_t rec_stride;     // records of one of the TWO record buffers (k_icc_iter reads one, fills the other)
+  int64_t par_cnt;        // words of bin_cnt per parity = 2 * O * nbins (three parities)
 };
 
 using mf::quat_backward;
@@ -195,31 +205,35 @@ __global__ __launch_bounds__(256) void k_icc_scene_setup(IccArgs a, int32_t step
   if (threadIdx.x == 0) a.St[s] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// Start of a loss evaluation / refinement: R|t from (q, t); empty accumulators of parity 0 and
-// the per-grid maxima; traj[0] = the initial pose.
-__global__ __launch_bounds__(64) void k_icc_pose(IccArgs a, const float *__restrict__ q,
-                                                 const float *__restrict__ t, float *traj) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= a.O) return;
-  float R[9];
-  quat_to_R(q + 4 * o, R);
+// Start of a loss evaluation / refinement: R|t from (q, t) (both copies); empty accumulators, per-grid
+// maxima and bin counters of every parity; traj[0] = the initial pose.  One workgroup per object.
+constexpr int kParities = 3;  // k_icc_iter rotates three parities (read / add into / empty); the two-launch path two
+__global__ __launch_bounds__(256) void k_icc_pose(IccArgs a, const float *__restrict__ q,
+                                                  const float *__restrict__ t, float *traj) {
+  const int o = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    float R[9];
+    quat_to_R(q + 4 * o, R);
+    for (int cp = 0; cp < 2; ++cp) {
+      float *Rt = a.Rt + ((int64_t)cp * a.O + o) * 12;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) a.Rt[12 * o + i] = R[i];
+      for (int i = 0; i < 9; ++i) Rt[i] = R[i];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) a.Rt[12 * o + 9 + i] = t[3 * o + i];
-  for (int par = 0; par < 2; ++par) {
-    a.Mbits[(int64_t)par * 2 * a.O + 2 * o] = 0;
-    a.Mbits[(int64_t)par * 2 * a.O + 2 * o + 1] = 0;
+      for (int i = 0; i < 3; ++i) Rt[9 + i] = t[3 * o + i];
+    }
+    if (traj) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) traj[7 * o + i] = q[4 * o + i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) traj[7 * o + 4 + i] = t[3 * o + i];
+    }
   }
-  for (int par = 0; par < 2; ++par)
-    for (int i = 0; i < 2 * a.nbins; ++i) a.bin_cnt[((int64_t)par * 2 * a.O + 2 * o) * a.nbins + i] = 0u;
-  for (int i = 0; i < kOwnSlots; ++i) a.acc_own[(int64_t)o * kOwnSlots + i] = 0;
-  for (int i = 0; i < a.max_ns * 12; ++i) a.acc_oth[(int64_t)o * a.max_ns * 12 + i] = 0;
-  if (traj) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) traj[7 * o + i] = q[4 * o + i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) traj[7 * o + 4 + i] = t[3 * o + i];
+  for (int par = 0; par < kParities; ++par) {
+    if (tid < 2) a.Mbits[(int64_t)par * 2 * a.O + 2 * o + tid] = 0;
+    for (int i = tid; i < 2 * a.nbins; i += blockDim.x) a.bin_cnt[((int64_t)par * 2 * a.O + 2 * o) * a.nbins + i] = 0u;
+    for (int i = tid; i < kOwnSlots; i += blockDim.x) a.acc_own[((int64_t)par * a.O + o) * kOwnSlots + i] = 0;
+    for (int i = tid; i < a.max_ns * 12; i += blockDim.x) a.acc_oth[((int64_t)par * a.O + o) * a.max_ns * 12 + i] = 0;
   }
 }
 
@@ -235,7 +249,7 @@ constexpr int kBinThreads = 256;
 constexpr int kBinPPT = 4;                          // points per thread (2: 23.0 vs 23.1 us/iteration, twice the redundant steps)
 constexpr int kBinChunk = kBinThreads * kBinPPT;    // points per workgroup
 constexpr int kHalves = 2;                          // y-halves of a plane: rows [0, D/2), [D/2, D)
-constexpr int kMaxBins = kHalves * (64 + 6);        // D <= 64, ks <= 7
+constexpr int kMaxBins = kHalves * (64 + 8);        // D <= 64, ks <= 7, + one margin plane per side (k_icc_iter's bins)
 constexpr int kBinShare = 8;                        // a bin holds 1/8 of its grid's source points ...
 constexpr int kBinMinCap = 64;                      // ... at least this many, the rest overflows
 
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(256) void k_icc_tables(IccArgs a) {
   }
   __syncthreads();
   for (int i = s_tab_base[0] + threadIdx.x; i < a.n_tab; i += blockDim.x) a.tab[i] = make_int4(-1, -1, 0, 0);
-  for (int i = threadIdx.x; i < 4 * a.O * a.nbins; i += blockDim.x) a.bin_cnt[i] = 0u;
+  for (int i = threadIdx.x; i < kParities * 2 * a.O * a.nbins; i += blockDim.x) a.bin_cnt[i] = 0u;
 }
 
 // ---- the optimiser step of ONE object from the reduced sums of an iteration ------------
@@ -358,75 +372,80 @@ __device__ __forceinline__ void icc_step_gather(const IccArgs &a, int par, int j
   __syncthreads();
 }
 
-// The same for the single-pass path (k_icc_fused): the accumulators hold the monomial sums, the
+// The same for the single-pass path (k_icc_fused / k_icc_iter): the accumulators hold the monomial sums, the
 // per-grid maxima M_own / M_oth give a = 1/M_own, b = 1/M_oth (b = 0 where the "other" grid is
 // empty or absent: iterative_collision_check_link.py:62-63,82), and the lanes form the sums the
-// step expects (see the table above k_icc_fused).
+// step expects (see the table above k_icc_fused).  Staged words, all converted to float by the lane that
+// fetched them (fixed point -> float, M -> 1/M: the conversions and the IEEE reciprocals run in parallel):
+//   sA[8 jo + l]   per scene object jo: {5 scene sums, non-finite flag, a = 1/M_own, b = 1/M_oth}
+//   sB[12 jo + c]  the 12 collision moments onto object j from the grid of scene object jo
+//   sC[i]          the 5 x 12 own-gradient moments of j
+__device__ __forceinline__ float fused_item_scene(const long long *own, const uint32_t *Mb, int obj, int l, int Ns) {
+  if (l < 5) return (float)((double)own[(int64_t)obj * kOwnSlots + l] * (1.0 / kFixOwn));
+  if (l == 5) return own[(int64_t)obj * kOwnSlots + kNumF] != 0 ? 1.0f : 0.0f;
+  const float M = __uint_as_float(Mb[2 * obj + (l - 6)]);  // a = 1/M_own, b = 1/M_oth (b = 0 where the "other" grid is empty)
+  return l == 6 ? 1.0f / M : ((Ns > 1 && M != 0.0f) ? 1.0f / M : 0.0f);
+}
+__device__ __forceinline__ float fused_item_oth(const long long *oth, int grid_obj, int max_ns, int jj, int c) {
+  return (float)((double)oth[((int64_t)grid_obj * max_ns + jj) * 12 + c] * (1.0 / kFixOth));
+}
+__device__ __forceinline__ float fused_item_own(const long long *own, int obj, int i) {
+  return (float)((double)own[(int64_t)obj * kOwnSlots + 5 + i] * (1.0 / kFixOwn));
+}
+// sum l (< kStepSums) of scene-local object jj from the staged words
+__device__ __forceinline__ float fused_sum(const int l, const int Ns, const int jj, const float *sA, const float *sB,
+                                           const float *sC) {
+  auto a_of = [&](int jo) { return sA[8 * jo + 6]; };
+  auto b_of = [&](int jo) { return sA[8 * jo + 7]; };
+  float r = 0.0f;
+  if (l == 0) {  // RN
+    for (int jo = 0; jo < Ns; ++jo) r += sA[8 * jo + 0] - a_of(jo) * sA[8 * jo + 1];
+  } else if (l == 1) {  // S_in
+    for (int jo = 0; jo < Ns; ++jo) r += a_of(jo) * sA[8 * jo + 2];
+  } else if (l == 2) {  // PN
+    for (int jo = 0; jo < Ns; ++jo) r += a_of(jo) * (sA[8 * jo + 3] + b_of(jo) * sA[8 * jo + 4]);
+  } else if (l < 15) {  // reward moments
+    const int c = l - 3;
+    r = sC[c] - a_of(jj) * sC[12 + c];
+  } else if (l < 27) {  // penalty numerator moments
+    const int c = l - 15;
+    r = a_of(jj) * (sC[24 + c] + b_of(jj) * sC[36 + c]);
+  } else if (l < 39) {  // penalty denominator moments
+    r = a_of(jj) * sC[48 + (l - 27)];
+  } else if (l < 51) {  // collision moments of every grid of the scene onto j
+    for (int jo = 0; jo < Ns; ++jo) r += (a_of(jo) * b_of(jo)) * sB[12 * jo + (l - 39)];
+  } else {
+    for (int jo = 0; jo < Ns; ++jo) r = sA[8 * jo + 5] != 0.0f ? 1.0f : r;
+  }
+  return r;
+}
+
 template <int NT>
 __device__ __forceinline__ void icc_step_gather_fused(const IccArgs &a, int par, int j, int ja, int Ns,
                                                       long long *s_raw, float *s_sum) {
   const long long *own = a.acc_own + (int64_t)par * a.O * kOwnSlots;
   const long long *oth = a.acc_oth + (int64_t)par * a.O * a.max_ns * 12;
   const uint32_t *Mb = a.Mbits + (int64_t)par * 2 * a.O;
-  // items: [0, 8 Ns): per scene object {5 scene sums, non-finite count, M_own bits, M_oth bits};
-  // [8 Ns, 20 Ns): the 12 collision moments onto j from every scene object's grid;
-  // [20 Ns, 20 Ns + 60): the 5 x 12 own-gradient moments of j
+  // items: [0, 8 Ns) sA; [8 Ns, 20 Ns) sB; [20 Ns, 20 Ns + 60) sC
   const int n_items = 20 * Ns + 60;
-  // every lane converts the word it fetched (fixed point -> float, M -> 1/M) before the first
-  // barrier: the conversions and the IEEE reciprocals run in parallel instead of on the summing
-  // lanes (one barrier and ~Ns serial int64 -> double -> float conversions per sum less)
   float *s_f = reinterpret_cast<float *>(s_raw);
   for (int i0 = 0; i0 < n_items; i0 += NT) {
     const int i = i0 + (int)threadIdx.x;
     float fv = 0.0f;
     if (i < n_items) {
       if (i < 8 * Ns) {
-        const int jo = i >> 3, l = i & 7;
-        if (l < 5) {
-          fv = (float)((double)own[(int64_t)(ja + jo) * kOwnSlots + l] * (1.0 / kFixOwn));
-        } else if (l == 5) {
-          fv = own[(int64_t)(ja + jo) * kOwnSlots + kNumF] != 0 ? 1.0f : 0.0f;
-        } else {  // a = 1/M_own, b = 1/M_oth (b = 0 where the "other" grid is empty)
-          const float M = __uint_as_float(Mb[2 * (ja + jo) + (l - 6)]);
-          fv = l == 6 ? 1.0f / M : ((Ns > 1 && M != 0.0f) ? 1.0f / M : 0.0f);
-        }
+        fv = fused_item_scene(own, Mb, ja + (i >> 3), i & 7, Ns);
       } else if (i < 20 * Ns) {
         const int k = i - 8 * Ns, jo = k / 12, c = k - 12 * jo;
-        fv = (float)((double)oth[((int64_t)(ja + jo) * a.max_ns + (j - ja)) * 12 + c] * (1.0 / kFixOth));
+        fv = fused_item_oth(oth, ja + jo, a.max_ns, j - ja, c);
       } else {
-        fv = (float)((double)own[(int64_t)j * kOwnSlots + 5 + (i - 20 * Ns)] * (1.0 / kFixOwn));
+        fv = fused_item_own(own, j, i - 20 * Ns);
       }
     }
     if (i < n_items) s_f[i] = fv;
   }
   __syncthreads();
-  auto a_of = [&](int jo) { return s_f[8 * jo + 6]; };
-  auto b_of = [&](int jo) { return s_f[8 * jo + 7]; };
-  if (threadIdx.x < kStepSums) {
-    const int l = threadIdx.x;
-    const int jj = j - ja;
-    float r = 0.0f;
-    if (l == 0) {  // RN
-      for (int jo = 0; jo < Ns; ++jo) r += s_f[8 * jo + 0] - a_of(jo) * s_f[8 * jo + 1];
-    } else if (l == 1) {  // S_in
-      for (int jo = 0; jo < Ns; ++jo) r += a_of(jo) * s_f[8 * jo + 2];
-    } else if (l == 2) {  // PN
-      for (int jo = 0; jo < Ns; ++jo) r += a_of(jo) * (s_f[8 * jo + 3] + b_of(jo) * s_f[8 * jo + 4]);
-    } else if (l < 15) {  // reward moments
-      const int c = l - 3;
-      r = s_f[20 * Ns + c] - a_of(jj) * s_f[20 * Ns + 12 + c];
-    } else if (l < 27) {  // penalty numerator moments
-      const int c = l - 15;
-      r = a_of(jj) * (s_f[20 * Ns + 24 + c] + b_of(jj) * s_f[20 * Ns + 36 + c]);
-    } else if (l < 39) {  // penalty denominator moments
-      r = a_of(jj) * s_f[20 * Ns + 48 + (l - 27)];
-    } else if (l < 51) {  // collision moments of every grid of the scene onto j
-      for (int jo = 0; jo < Ns; ++jo) r += (a_of(jo) * b_of(jo)) * s_f[8 * Ns + 12 * jo + (l - 39)];
-    } else {
-      for (int jo = 0; jo < Ns; ++jo) r = s_f[8 * jo + 5] != 0.0f ? 1.0f : r;
-    }
-    s_sum[l] = r;
-  }
+  if (threadIdx.x < kStepSums) s_sum[threadIdx.x] = fused_sum((int)threadIdx.x, Ns, j - ja, s_f, s_f + 8 * Ns, s_f + 20 * Ns);
   __syncthreads();
 }
 
@@ -575,7 +594,9 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
   }
   const float R0 = r0.x, R1 = r0.y, R2 = r0.z, R3 = r0.w, R4 = r1.x, R5 = r1.y, R6 = r1.z,
               R7 = r1.w, R8 = r2.x, T0 = r2.y, T1 = r2.z, T2 = r2.w;
-  const int h = min(ksize_of(a.thr, pitch) / 2, hmax);
+  // a.mg > 0 (bins that feed k_icc_iter): a record reaches a.mg planes / rows further than its kernel
+  // neighbourhood, so that the reader still finds it after one optimiser step has moved the point
+  const int h = min(ksize_of(a.thr, pitch) / 2, hmax) + a.mg;
   const float fh = (float)h, inv_pitch = 1.0f / pitch;
   {
     // whole-object rejection with the model's bounding sphere (conservative, block-uniform)
@@ -610,7 +631,7 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
       const bool surv = rx + fh >= 0.0f && rx - fh < (float)D && ry + fh >= 0.0f &&
                         ry - fh < (float)D && rz + fh >= 0.0f && rz - fh < (float)D;
       if (surv) {
-        const int plane = (int)rx + hmax;  // in [0, D + 2 hmax)
+        const int plane = (int)rx + hmax + a.mg;  // in [0, D + 2 (hmax + mg))
         const int iry = (int)ry;
         if (iry - h < Dh) {
           bin[u][0] = plane * kHalves;
@@ -638,7 +659,9 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
     for (int hf = 0; hf < kHalves; ++hf) {
       if (bin[u][hf] < 0) continue;
       const int idx = s_base[bin[u][hf]] + slot[u][hf];
-      const float4 r = make_float4(fx[u], fy[u], fz[u], __uint_as_float((uint32_t)p));
+      const float4 r = a.rec_model
+                           ? make_float4(m[u].x, m[u].y, m[u].z, __uint_as_float((uint32_t)p | ((uint32_t)(j - e2.x) << 27)))
+                           : make_float4(fx[u], fy[u], fz[u], __uint_as_float((uint32_t)p));
       if (idx < cap) {
         a.rec[base_g + (int64_t)bin[u][hf] * cap + idx] = r;
       } else {  // bin full: the grid's overflow list (its tiles find the record by the membership test)
@@ -1186,264 +1209,137 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
 // second launch, no dependent re-load of what the tile just computed.  Same arithmetic per
 // voxel as k_icc_accum up to the association of the normaliser (tests: loss within 2e-5,
 // step within 1e-5 of the oracle's).  Grids with other values take the two-kernel path.
-// static LDS of k_icc_fused (declared once in the kernel: the body is instantiated per kernel size)
-struct FusedLds {
+// LDS of the voxel phase (shared by k_icc_fused and k_icc_iter)
+struct VoxLds {
   float rows[kTileThreads / 16][kNumF + 1];
   float max[2][kTileThreads / 64];
-  float Rt[kMaxSceneObjects][12];
-  int off[kMaxSceneObjects + 1];
   // voxels with an own winner, compacted in voxel order: index, (no-entry, target), winner points
   uint16_t list[kTileThreads];
   float2 netg[kTileThreads];
   float4 mown[kTileThreads], moth[kTileThreads];
   int wcnt[kTileThreads / 64];
 };
+// static LDS of k_icc_fused (declared once in the kernel: the body is instantiated per kernel size)
+struct FusedLds {
+  VoxLds v;
+  float Rt[kMaxSceneObjects][12];
+  int off[kMaxSceneObjects + 1];
+};
 
-template <int KS>
-__device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt, const int par, FusedLds &L) {
-  MF_DYN_LDS(uint32_t, s_tile);  // dist[2][nvh] | id[2][nvh] | rows2[max_ns][32][13] floats
-  auto &s_rows = L.rows;
-  auto &s_max = L.max;
-  auto &s_Rt = L.Rt;
-  auto &s_off = L.off;
-  auto &s_list = L.list;
-  auto &s_netg = L.netg;
-  auto &s_mown = L.mown;
-  auto &s_moth = L.moth;
-  auto &s_wcnt = L.wcnt;
-  const int ks = KS > 0 ? KS : ks_rt;
-  const int h = ks / 2, K = ks * ks * ks;
-  const int D = a.D, nb = a.nbins, hmax = a.hmax, V = D * D * D;
-  const int o = blockIdx.y;
-  const int x = blockIdx.x / kHalves, half = blockIdx.x % kHalves;
-  const int Dh = (D + 1) / 2;
-  const int y0 = half * Dh, y1 = half == 0 ? Dh : D;
-  const int Wp = D + 2 * kPad, rows_p = Dh + 2 * kPad;  // padded tile (see visit)
-  const int nvh = rows_p * Wp;          // LDS stride of one (dist | id) array
-  const int nvox = (y1 - y0) * D;
-  uint32_t *s_dist = s_tile, *s_id = s_tile + 2 * nvh;
-  float *s_rows2 = reinterpret_cast<float *>(s_tile + 4 * nvh);
-  const int4 meta = a.meta[o];
-  const int ja = meta.x, Ns = meta.y - meta.x;
-  // independent loads: bin counts of both grids, capacities, offsets, scalars, scene tables
-  int c[2][8];
-  int cap[2], nov[2], tot[2];
-  int64_t base_g[2];
-  const float pitch = a.pitch[o];
-  const int bin0 = x + hmax - h;  // plane x - h
-  const int nbr = nb - 1;
-#pragma unroll
-  for (int kd = 0; kd < 2; ++kd) {
-    const int g = 2 * o + kd;
-    cap[kd] = a.bin_cap[g];
-    base_g[kd] = a.bin_base[g];
-    nov[kd] = (kd == 0 || Ns > 1)
-                  ? min((int)a.bin_cnt[((int64_t)par * 2 * a.O + g) * nb + nbr], 2 * a.bin_pts[g]) : 0;
-    c[kd][0] = 0;
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-      int n = 0;
-      if (b < ks && (kd == 0 || Ns > 1))
-        n = min((int)a.bin_cnt[((int64_t)par * 2 * a.O + g) * nb + (bin0 + b) * kHalves + half], cap[kd]);
-      c[kd][b + 1] = c[kd][b] + n;
-    }
-    tot[kd] = c[kd][7] + nov[kd];  // the tile's bins, then the grid's overflow list (filtered by fetch)
-  }
-  if (tot[0] + tot[1] == 0) return;  // block-uniform: no record of either grid reaches this tile
-  const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
-  for (int i = threadIdx.x; i < Ns * 12; i += blockDim.x) s_Rt[i / 12][i % 12] = a.Rt[12 * ja + i];  // Ns up to 64: 768 words
-  if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
-  const float trunc = a.thr * pitch;
-  for (int i = threadIdx.x; i < 2 * nvh; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
-  for (int i = threadIdx.x; i < Ns * (kTileThreads / 16) * 13; i += kTileThreads) s_rows2[i] = 0.0f;
-  for (int i = threadIdx.x; i < (kTileThreads / 16) * (kNumF + 1); i += kTileThreads) (&s_rows[0][0])[i] = 0.0f;
-  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-  auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
-    if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
-  };
-  stamp(0);
-  if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)(c[0][7] + c[1][7]);
-  // the voxel phase's first-level loads, issued now: this lane's voxel of the two input grids
-  float ne0 = 0.0f, tg0 = 0.0f;
-  if ((int)threadIdx.x < nvox) {
-    const int64_t gv = (int64_t)o * V + ((int64_t)x * D + y0) * D + (int)threadIdx.x;
-    ne0 = a.grid_ne[gv];
-    tg0 = a.grid_target[gv];
-  }
-  __syncthreads();
-  const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test in pass 2
-  const float d2_in = a.thr * a.thr * 0.999f;    // certainly inside the truncation radius
-  const float fxp = (float)x;
-  const uint32_t hi_bits = __float_as_uint(d2_hi) - 1u;  // d2 < d2_hi on the bit patterns (d2 >= 0)
-  const uint32_t in_bits = __float_as_uint(d2_in);       // d2 < d2_in  <=>  bits < in_bits
+// Constants of one padded half-plane tile (k_icc_fused / k_icc_iter, kernel size 3).
+struct Tile3 {
+  int Wp, rows_p, y0;
+  float fxp, pitch, trunc, d2_in;
+  uint32_t in_bits, hi_bits;
+};
 
-  // record i of grid kd's concatenated bins -> (plane offset b, record); rb < 0: none
-  auto fetch = [&](const int kd, const int i, float4 &rv, int &rb) {
-    rb = -1;
-    if (i >= tot[kd]) return;
-    if (i >= c[kd][7]) {  // overflow record: this tile's iff its plane is in x-h..x+h and its rows touch the half
-      rv = a.rec[base_g[kd] + (int64_t)nbr * cap[kd] + (i - c[kd][7])];
-      const int pl = (int)roundf(rv.x) - (x - h), iry_ = (int)roundf(rv.y);
-      const bool in_half = half == 0 ? (iry_ - h < Dh) : (iry_ + h >= Dh);
-      rb = (pl >= 0 && pl < ks && in_half) ? pl : -1;
-      return;
+// The two-pass (min, arg-min) of k_icc_tile on the LDS arrays of one grid, kernel size 3.  The tile
+// carries a margin of kPad cells on every side: all nine (y, z) candidates of a record of this half's
+// bins (rounded y in [y0 - 1, y1], z in [-1, D]) address cells of the padded tile, the ones
+// outside the half land in margin cells nobody reads.  ks = 3 therefore needs NO predicate:
+// pass 1 = nine fire-and-forget ds_min at constant offsets from one base address (a peek at
+// the current minimum first, or range / radius tests per candidate, cost more instructions
+// than the atomics they save: 19.9 -> 18.4 us without the peek alone), pass 2 = the nine
+// FINAL minima in one batch of reads, the exact test only where this record is within a few
+// ulp.  A minimum beyond the truncation radius simply finds no winner in pass 2.
+// (sx, sy, sz) = voxel-frame coordinates of the point, pid its id, rb = its plane's offset in x-1 .. x+1.
+__device__ __forceinline__ void icc_visit3(const int pass, uint32_t *dist, uint32_t *id, const Tile3 &tl,
+                                           const float sx, const float sy, const float sz, const uint32_t pid,
+                                           const int rb) {
+  const int Wp = tl.Wp;
+  const int iry = (int)roundf(sy), irz = (int)roundf(sz);
+  const uint32_t idb = pid * 27u;
+  const int bb = 2 - rb;
+  const float dx = sx - tl.fxp;
+  const float dx2 = dx * dx;
+  // cell of candidate (aa, cc) = (0, 0): row iry - 1, column irz - 1; clamped so that a
+  // corrupt record cannot leave the tile
+  const int r0 = min(max(iry - 1 - tl.y0 + kPad, 0), tl.rows_p - 3);
+  const int c0 = min(max(irz - 1 + kPad, 0), Wp - 3);
+  const int cbase = r0 * Wp + c0;
+  uint32_t db[9];
+#pragma unroll
+  for (int aa = 0; aa < 3; ++aa) {
+    const float dy = sy - (float)(iry + aa - 1);
+    const float dxy = dx2 + dy * dy;
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      const float dz = sz - (float)(irz + cc - 1);
+      db[aa * 3 + cc] = __float_as_uint(dxy + dz * dz);
     }
-    int b = 0;
+  }
+  if (pass == 1) {
 #pragma unroll
-    for (int k = 1; k < 7; ++k) b += (k < ks && i >= c[kd][k]) ? 1 : 0;
-    int cb = 0;
+    for (int k = 0; k < 9; ++k) atomicMin(&dist[cbase + (k / 3) * Wp + (k % 3)], db[k]);
+  } else {
+    uint32_t cur[9];
 #pragma unroll
-    for (int k = 1; k < 7; ++k) cb = (k == b) ? c[kd][k] : cb;
-    rb = b;
-    rv = a.rec[base_g[kd] + (int64_t)((bin0 + b) * kHalves + half) * cap[kd] + (i - cb)];
-  };
-  // candidate `cid` at squared distance bits `db` against the final minimum `cur` of its voxel
-  auto settle_at = [&](uint32_t *id, const int ad, const uint32_t db, const uint32_t cur, const uint32_t cid) {
-    bool win = db == cur && __uint_as_float(db) < d2_in;
-    if (!win) {
-      const float dd = pitch * sqrtf(__uint_as_float(db));
-      const float dmin = pitch * sqrtf(__uint_as_float(cur));
-      win = dd == dmin && dd < trunc;
+    for (int k = 0; k < 9; ++k) cur[k] = dist[cbase + (k / 3) * Wp + (k % 3)];
+    // fast: this record IS the minimum, certainly inside the truncation radius -> candidate
+    // for the arg-min.  slow (rare): within a few ulp of the minimum or near the radius ->
+    // the exact float test, in a ROLLED loop behind one branch that recomputes what it
+    // needs.  (Inlined next to the fast path the compiler speculated both square roots into
+    // every candidate: pass 2 took 4-5 us in every tile; unrolled behind the branch it was
+    // still 900 instructions of code per record.)
+    const uint32_t cid0 = idb + (uint32_t)(bb * 3);
+    bool any_slow = false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const bool f = db[k] == cur[k] && db[k] < tl.in_bits;
+      // (issuing it unconditionally with a neutral value instead: measured slower, 2.3 vs 1.6 us)
+      if (f) atomicMin(&id[cbase + (k / 3) * Wp + (k % 3)], cid0 + (uint32_t)((k / 3) * 9 + (k % 3)));
+      any_slow |= !f && db[k] <= min(cur[k] + 8u, tl.hi_bits);
     }
-    if (win) atomicMin(&id[ad], cid);
-  };
-  // The two-pass (min, arg-min) of k_icc_tile on the LDS arrays of grid kd.  The tile carries a
-  // margin of kPad cells on every side: all nine (y, z) candidates of a record of this half's
-  // bins (rounded y in [y0 - 1, y1], z in [-1, D]) address cells of the padded tile, the ones
-  // outside the half land in margin cells nobody reads.  ks = 3 therefore needs NO predicate:
-  // pass 1 = nine fire-and-forget ds_min at constant offsets from one base address (a peek at
-  // the current minimum first, or range / radius tests per candidate, cost more instructions
-  // than the atomics they save: 19.9 -> 18.4 us without the peek alone), pass 2 = the nine
-  // FINAL minima in one batch of reads, the exact test only where this record is within a few
-  // ulp.  A minimum beyond the truncation radius simply finds no winner in pass 2.
-  auto visit = [&](const int pass, const int kd, const float4 sv, const int rb) {
-    uint32_t *dist = s_dist + kd * nvh, *id = s_id + kd * nvh;
-    const int iry = (int)roundf(sv.y), irz = (int)roundf(sv.z);
-    const uint32_t idb = __float_as_uint(sv.w) * (uint32_t)K;
-    const int bb = ks - 1 - rb;
-    const float dx = sv.x - fxp;
-    const float dx2 = dx * dx;
-    if constexpr (KS == 3) {
-      // cell of candidate (aa, cc) = (0, 0): row iry - 1, column irz - 1; clamped so that a
-      // corrupt record cannot leave the tile
-      const int r0 = min(max(iry - 1 - y0 + kPad, 0), rows_p - 3);
-      const int c0 = min(max(irz - 1 + kPad, 0), Wp - 3);
-      const int cbase = r0 * Wp + c0;
-      uint32_t db[9];
-#pragma unroll
-      for (int aa = 0; aa < 3; ++aa) {
-        const float dy = sv.y - (float)(iry + aa - 1);
-        const float dxy = dx2 + dy * dy;
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-          const float dz = sv.z - (float)(irz + cc - 1);
-          db[aa * 3 + cc] = __float_as_uint(dxy + dz * dz);
-        }
-      }
-      if (pass == 1) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) atomicMin(&dist[cbase + (k / 3) * Wp + (k % 3)], db[k]);
-      } else {
-        uint32_t cur[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) cur[k] = dist[cbase + (k / 3) * Wp + (k % 3)];
-        // fast: this record IS the minimum, certainly inside the truncation radius -> candidate
-        // for the arg-min.  slow (rare): within a few ulp of the minimum or near the radius ->
-        // the exact float test, in a ROLLED loop behind one branch that recomputes what it
-        // needs.  (Inlined next to the fast path the compiler speculated both square roots into
-        // every candidate: pass 2 took 4-5 us in every tile; unrolled behind the branch it was
-        // still 900 instructions of code per record.)
-        const uint32_t cid0 = idb + (uint32_t)(bb * 3);
-        bool any_slow = false;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const bool f = db[k] == cur[k] && db[k] < in_bits;
-          // (issuing it unconditionally with a neutral value instead: measured slower, 2.3 vs 1.6 us)
-          if (f) atomicMin(&id[cbase + (k / 3) * Wp + (k % 3)], cid0 + (uint32_t)((k / 3) * 9 + (k % 3)));
-          any_slow |= !f && db[k] <= min(cur[k] + 8u, hi_bits);
-        }
-        if (any_slow) {
+    if (any_slow) {
 #pragma nounroll
-          for (int k = 0; k < 9; ++k) {
-            const int aa = k / 3, cc = k - 3 * aa;
-            const float dy = sv.y - (float)(iry + aa - 1), dz = sv.z - (float)(irz + cc - 1);
-            const uint32_t dbk = __float_as_uint((dx2 + dy * dy) + dz * dz);
-            const int ad = cbase + aa * Wp + cc;
-            const uint32_t curk = dist[ad];
-            const bool f = dbk == curk && dbk < in_bits;
-            if (!f && dbk <= min(curk + 8u, hi_bits)) settle_at(id, ad, dbk, curk, cid0 + (uint32_t)(aa * 9 + cc));
+      for (int k = 0; k < 9; ++k) {
+        const int aa = k / 3, cc = k - 3 * aa;
+        const float dy = sy - (float)(iry + aa - 1), dz = sz - (float)(irz + cc - 1);
+        const uint32_t dbk = __float_as_uint((dx2 + dy * dy) + dz * dz);
+        const int ad = cbase + aa * Wp + cc;
+        const uint32_t curk = dist[ad];
+        const bool f = dbk == curk && dbk < tl.in_bits;
+        if (!f && dbk <= min(curk + 8u, tl.hi_bits)) {
+          // candidate at squared distance bits dbk against the final minimum curk of its voxel
+          bool win = dbk == curk && __uint_as_float(dbk) < tl.d2_in;
+          if (!win) {
+            const float dd = tl.pitch * sqrtf(__uint_as_float(dbk));
+            const float dmin = tl.pitch * sqrtf(__uint_as_float(curk));
+            win = dd == dmin && dd < tl.trunc;
           }
-        }
-      }
-    } else {
-      for (int aa = 0; aa < ks; ++aa) {
-        const int iy = iry + aa - h;
-        if (iy < y0 || iy >= y1) continue;
-        const float dy = sv.y - (float)iy;
-        const float dxy = dx2 + dy * dy;
-        const int lrow = (iy - y0 + kPad) * Wp + kPad;
-        for (int cc = 0; cc < ks; ++cc) {
-          const int iz = irz + cc - h;
-          if (iz < 0 || iz >= D) continue;
-          const float dz = sv.z - (float)iz;
-          const float d2 = dxy + dz * dz;
-          if (!(d2 < d2_hi)) continue;
-          const uint32_t db = __float_as_uint(d2);
-          if (pass == 1) {
-            atomicMin(&dist[lrow + iz], db);
-          } else {
-            const uint32_t cur = dist[lrow + iz];
-            if (db <= cur + 8u) settle_at(id, lrow + iz, db, cur, idb + (uint32_t)((aa * ks + bb) * ks + cc));
-          }
+          if (win) atomicMin(&id[ad], cid0 + (uint32_t)(aa * 9 + cc));
         }
       }
     }
-  };
+  }
+}
 
-  // kept records: kFusedKeepOwn per lane of the own grid, kFusedKeepOth of the other grid, all
-  // loads in flight at once (ONE memory round trip); more crowded tiles stream the rest twice
-  float4 rvo[kFusedKeepOwn], rvk[kFusedKeepOth];
-  int rbo[kFusedKeepOwn], rbk[kFusedKeepOth];
-#pragma unroll
-  for (int u = 0; u < kFusedKeepOwn; ++u) fetch(0, u * kTileThreads + (int)threadIdx.x, rvo[u], rbo[u]);
-#pragma unroll
-  for (int u = 0; u < kFusedKeepOth; ++u) fetch(1, u * kTileThreads + (int)threadIdx.x, rvk[u], rbk[u]);
-  stamp(1);
-  auto pass_over = [&](const int pass) {
-#pragma unroll
-    for (int u = 0; u < kFusedKeepOwn; ++u)
-      if (rbo[u] >= 0) visit(pass, 0, rvo[u], rbo[u]);
-#pragma unroll
-    for (int u = 0; u < kFusedKeepOth; ++u)
-      if (rbk[u] >= 0) visit(pass, 1, rvk[u], rbk[u]);
-#pragma unroll
-    for (int kd = 0; kd < 2; ++kd) {
-      const int first = kTileThreads * (kd == 0 ? kFusedKeepOwn : kFusedKeepOth);
-      for (int base = first; base < tot[kd]; base += kTileThreads * kTileR) {
-        float4 xv[kTileR];
-        int xb[kTileR];
-#pragma unroll
-        for (int u = 0; u < kTileR; ++u) fetch(kd, base + u * kTileThreads + (int)threadIdx.x, xv[u], xb[u]);
-#pragma unroll
-        for (int u = 0; u < kTileR; ++u)
-          if (xb[u] >= 0) visit(pass, kd, xv[u], xb[u]);
-      }
-    }
-  };
-  if (!MF_DBG(a, 128)) pass_over(1);  // (MF_ICC_DEBUG & 128 / 256 / 512: skip a phase to time the others; results invalid)
-  __syncthreads();
-  stamp(2);
-  if (!MF_DBG(a, 256)) pass_over(2);
-  __syncthreads();
-  stamp(3);
-  if (MF_DBG(a, 512)) return;
+// ---- voxel phase of a half-plane tile whose (min distance, arg-min) arrays are final.  Only a voxel
+// WITH an own winner adds to any sum (without one g = 0 and w = 0), and those are the few voxels of
+// the surface shell, scattered over most waves of the tile: compact them, so that ceil(n / 64) waves
+// pay the arithmetic and the 65 row reductions instead of every wave the shell touches.  The maximum
+// of the OTHER grid's weights needs every voxel with an other-winner: taken here in the
+// voxel-per-lane layout, its gather is in flight during the compaction.
+// V.rows and s_rows2 must be zero on entry (a wave writes only the sets / objects it meets).
+struct TileGeom {
+  int o, ja, Ns, x, y0, nvox, nvh, Wp, D, K;
+  float pitch, trunc, ox, oy, oz;
+};
 
-  // ---- voxel phase.  Only a voxel WITH an own winner adds to any sum (without one g = 0 and
-  // w = 0), and those are the few voxels of the surface shell, scattered over most waves of
-  // the tile: compact them, so that ceil(n / 64) waves pay the arithmetic and the 65 row
-  // reductions instead of every wave the shell touches.  The maximum of the OTHER grid's
-  // weights needs every voxel with an other-winner: taken here in the voxel-per-lane layout,
-  // its gather is in flight during the compaction.
+template <class Stamp>
+__device__ __forceinline__ void icc_voxel_phase(const IccArgs &a, const int par, const TileGeom &tg_, const float ne0,
+                                                const float tg0, uint32_t *s_dist, uint32_t *s_id, float *s_rows2,
+                                                VoxLds &Vx, const float (*s_Rt)[12], const int *s_off, Stamp stamp) {
+  auto &s_rows = Vx.rows;
+  auto &s_max = Vx.max;
+  auto &s_list = Vx.list;
+  auto &s_netg = Vx.netg;
+  auto &s_mown = Vx.mown;
+  auto &s_moth = Vx.moth;
+  auto &s_wcnt = Vx.wcnt;
+  const int o = tg_.o, ja = tg_.ja, Ns = tg_.Ns, x = tg_.x, y0 = tg_.y0, nvox = tg_.nvox, nvh = tg_.nvh, Wp = tg_.Wp,
+            D = tg_.D, K = tg_.K;
+  const float pitch = tg_.pitch, trunc = tg_.trunc, ox = tg_.ox, oy = tg_.oy, oz = tg_.oz;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // voxel -> (row, column) without an integer divide: exact for vi < 1024, D <= 64
   const uint32_t rcpD = (65536u + (uint32_t)D - 1u) / (uint32_t)D;  // (scalar)
@@ -1628,6 +1524,188 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
       if (xq != 0) atomicAdd(reinterpret_cast<unsigned long long *>(po + i), (unsigned long long)xq);
     }
   }
+}
+
+template <int KS>
+__device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt, const int par, FusedLds &L) {
+  MF_DYN_LDS(uint32_t, s_tile);  // dist[2][nvh] | id[2][nvh] | rows2[max_ns][32][13] floats
+  auto &s_rows = L.v.rows;
+  auto &s_Rt = L.Rt;
+  auto &s_off = L.off;
+  const int ks = KS > 0 ? KS : ks_rt;
+  const int h = ks / 2, K = ks * ks * ks;
+  const int D = a.D, nb = a.nbins, hmax = a.hmax, V = D * D * D;
+  const int o = blockIdx.y;
+  const int x = blockIdx.x / kHalves, half = blockIdx.x % kHalves;
+  const int Dh = (D + 1) / 2;
+  const int y0 = half * Dh, y1 = half == 0 ? Dh : D;
+  const int Wp = D + 2 * kPad, rows_p = Dh + 2 * kPad;  // padded tile (see icc_visit3)
+  const int nvh = rows_p * Wp;          // LDS stride of one (dist | id) array
+  const int nvox = (y1 - y0) * D;
+  uint32_t *s_dist = s_tile, *s_id = s_tile + 2 * nvh;
+  float *s_rows2 = reinterpret_cast<float *>(s_tile + 4 * nvh);
+  const int4 meta = a.meta[o];
+  const int ja = meta.x, Ns = meta.y - meta.x;
+  // independent loads: bin counts of both grids, capacities, offsets, scalars, scene tables
+  int c[2][8];
+  int cap[2], nov[2], tot[2];
+  int64_t base_g[2];
+  const float pitch = a.pitch[o];
+  const int bin0 = x + hmax - h;  // plane x - h
+  const int nbr = nb - 1;
+#pragma unroll
+  for (int kd = 0; kd < 2; ++kd) {
+    const int g = 2 * o + kd;
+    cap[kd] = a.bin_cap[g];
+    base_g[kd] = a.bin_base[g];
+    nov[kd] = (kd == 0 || Ns > 1)
+                  ? min((int)a.bin_cnt[((int64_t)par * 2 * a.O + g) * nb + nbr], 2 * a.bin_pts[g]) : 0;
+    c[kd][0] = 0;
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+      int n = 0;
+      if (b < ks && (kd == 0 || Ns > 1))
+        n = min((int)a.bin_cnt[((int64_t)par * 2 * a.O + g) * nb + (bin0 + b) * kHalves + half], cap[kd]);
+      c[kd][b + 1] = c[kd][b] + n;
+    }
+    tot[kd] = c[kd][7] + nov[kd];  // the tile's bins, then the grid's overflow list (filtered by fetch)
+  }
+  if (tot[0] + tot[1] == 0) return;  // block-uniform: no record of either grid reaches this tile
+  const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
+  for (int i = threadIdx.x; i < Ns * 12; i += blockDim.x) s_Rt[i / 12][i % 12] = a.Rt[12 * ja + i];  // Ns up to 64: 768 words
+  if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
+  const float trunc = a.thr * pitch;
+  for (int i = threadIdx.x; i < 2 * nvh; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
+  for (int i = threadIdx.x; i < Ns * (kTileThreads / 16) * 13; i += kTileThreads) s_rows2[i] = 0.0f;
+  for (int i = threadIdx.x; i < (kTileThreads / 16) * (kNumF + 1); i += kTileThreads) (&s_rows[0][0])[i] = 0.0f;
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
+    if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
+  };
+  stamp(0);
+  if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)(c[0][7] + c[1][7]);
+  // the voxel phase's first-level loads, issued now: this lane's voxel of the two input grids
+  float ne0 = 0.0f, tg0 = 0.0f;
+  if ((int)threadIdx.x < nvox) {
+    const int64_t gv = (int64_t)o * V + ((int64_t)x * D + y0) * D + (int)threadIdx.x;
+    ne0 = a.grid_ne[gv];
+    tg0 = a.grid_target[gv];
+  }
+  __syncthreads();
+  const float d2_hi = a.thr * a.thr * 1.00002f;  // conservative inclusion; exact test in pass 2
+  const float d2_in = a.thr * a.thr * 0.999f;    // certainly inside the truncation radius
+  const float fxp = (float)x;
+  Tile3 tl;
+  tl.Wp = Wp; tl.rows_p = rows_p; tl.y0 = y0; tl.fxp = fxp; tl.pitch = pitch; tl.trunc = trunc; tl.d2_in = d2_in;
+  tl.hi_bits = __float_as_uint(d2_hi) - 1u;  // d2 < d2_hi on the bit patterns (d2 >= 0)
+  tl.in_bits = __float_as_uint(d2_in);       // d2 < d2_in  <=>  bits < in_bits
+
+  // record i of grid kd's concatenated bins -> (plane offset b, record); rb < 0: none
+  auto fetch = [&](const int kd, const int i, float4 &rv, int &rb) {
+    rb = -1;
+    if (i >= tot[kd]) return;
+    if (i >= c[kd][7]) {  // overflow record: this tile's iff its plane is in x-h..x+h and its rows touch the half
+      rv = a.rec[base_g[kd] + (int64_t)nbr * cap[kd] + (i - c[kd][7])];
+      const int pl = (int)roundf(rv.x) - (x - h), iry_ = (int)roundf(rv.y);
+      const bool in_half = half == 0 ? (iry_ - h < Dh) : (iry_ + h >= Dh);
+      rb = (pl >= 0 && pl < ks && in_half) ? pl : -1;
+      return;
+    }
+    int b = 0;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) b += (k < ks && i >= c[kd][k]) ? 1 : 0;
+    int cb = 0;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) cb = (k == b) ? c[kd][k] : cb;
+    rb = b;
+    rv = a.rec[base_g[kd] + (int64_t)((bin0 + b) * kHalves + half) * cap[kd] + (i - cb)];
+  };
+  // candidate `cid` at squared distance bits `db` against the final minimum `cur` of its voxel
+  auto settle_at = [&](uint32_t *id, const int ad, const uint32_t db, const uint32_t cur, const uint32_t cid) {
+    bool win = db == cur && __uint_as_float(db) < d2_in;
+    if (!win) {
+      const float dd = pitch * sqrtf(__uint_as_float(db));
+      const float dmin = pitch * sqrtf(__uint_as_float(cur));
+      win = dd == dmin && dd < trunc;
+    }
+    if (win) atomicMin(&id[ad], cid);
+  };
+  auto visit = [&](const int pass, const int kd, const float4 sv, const int rb) {
+    uint32_t *dist = s_dist + kd * nvh, *id = s_id + kd * nvh;
+    if constexpr (KS == 3) {
+      icc_visit3(pass, dist, id, tl, sv.x, sv.y, sv.z, __float_as_uint(sv.w), rb);
+    } else {
+      const int iry = (int)roundf(sv.y), irz = (int)roundf(sv.z);
+      const uint32_t idb = __float_as_uint(sv.w) * (uint32_t)K;
+      const int bb = ks - 1 - rb;
+      const float dx = sv.x - fxp;
+      const float dx2 = dx * dx;
+      for (int aa = 0; aa < ks; ++aa) {
+        const int iy = iry + aa - h;
+        if (iy < y0 || iy >= y1) continue;
+        const float dy = sv.y - (float)iy;
+        const float dxy = dx2 + dy * dy;
+        const int lrow = (iy - y0 + kPad) * Wp + kPad;
+        for (int cc = 0; cc < ks; ++cc) {
+          const int iz = irz + cc - h;
+          if (iz < 0 || iz >= D) continue;
+          const float dz = sv.z - (float)iz;
+          const float d2 = dxy + dz * dz;
+          if (!(d2 < d2_hi)) continue;
+          const uint32_t db = __float_as_uint(d2);
+          if (pass == 1) {
+            atomicMin(&dist[lrow + iz], db);
+          } else {
+            const uint32_t cur = dist[lrow + iz];
+            if (db <= cur + 8u) settle_at(id, lrow + iz, db, cur, idb + (uint32_t)((aa * ks + bb) * ks + cc));
+          }
+        }
+      }
+    }
+  };
+
+  // kept records: kFusedKeepOwn per lane of the own grid, kFusedKeepOth of the other grid, all
+  // loads in flight at once (ONE memory round trip); more crowded tiles stream the rest twice
+  float4 rvo[kFusedKeepOwn], rvk[kFusedKeepOth];
+  int rbo[kFusedKeepOwn], rbk[kFusedKeepOth];
+#pragma unroll
+  for (int u = 0; u < kFusedKeepOwn; ++u) fetch(0, u * kTileThreads + (int)threadIdx.x, rvo[u], rbo[u]);
+#pragma unroll
+  for (int u = 0; u < kFusedKeepOth; ++u) fetch(1, u * kTileThreads + (int)threadIdx.x, rvk[u], rbk[u]);
+  stamp(1);
+  auto pass_over = [&](const int pass) {
+#pragma unroll
+    for (int u = 0; u < kFusedKeepOwn; ++u)
+      if (rbo[u] >= 0) visit(pass, 0, rvo[u], rbo[u]);
+#pragma unroll
+    for (int u = 0; u < kFusedKeepOth; ++u)
+      if (rbk[u] >= 0) visit(pass, 1, rvk[u], rbk[u]);
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd) {
+      const int first = kTileThreads * (kd == 0 ? kFusedKeepOwn : kFusedKeepOth);
+      for (int base = first; base < tot[kd]; base += kTileThreads * kTileR) {
+        float4 xv[kTileR];
+        int xb[kTileR];
+#pragma unroll
+        for (int u = 0; u < kTileR; ++u) fetch(kd, base + u * kTileThreads + (int)threadIdx.x, xv[u], xb[u]);
+#pragma unroll
+        for (int u = 0; u < kTileR; ++u)
+          if (xb[u] >= 0) visit(pass, kd, xv[u], xb[u]);
+      }
+    }
+  };
+  if (!MF_DBG(a, 128)) pass_over(1);  // (MF_ICC_DEBUG & 128 / 256 / 512: skip a phase to time the others; results invalid)
+  __syncthreads();
+  stamp(2);
+  if (!MF_DBG(a, 256)) pass_over(2);
+  __syncthreads();
+  stamp(3);
+  if (MF_DBG(a, 512)) return;
+
+  TileGeom tg_;
+  tg_.o = o; tg_.ja = ja; tg_.Ns = Ns; tg_.x = x; tg_.y0 = y0; tg_.nvox = nvox; tg_.nvh = nvh; tg_.Wp = Wp; tg_.D = D;
+  tg_.K = K; tg_.pitch = pitch; tg_.trunc = trunc; tg_.ox = ox; tg_.oy = oy; tg_.oz = oz;
+  icc_voxel_phase(a, par, tg_, ne0, tg0, s_dist, s_id, s_rows2, L.v, s_Rt, s_off, stamp);
   stamp(4);
 }
 
@@ -1638,6 +1716,515 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_fused(IccArgs a, int pa
     icc_fused_body<3>(a, 3, par, L);
   else
     icc_fused_body<0>(a, ks, par, L);
+}
+
+// ---- ONE launch per iteration (round 5): k_icc_iter ------------------------------------------------------
+// The two-launch iteration is bin(k) -> boundary -> tiles(k) -> boundary: two kernel boundaries, ~6 dependent memory
+// round trips and the serial optimiser step on the critical path (23.7 us at 1 scene x 8 objects, rounds 2-4).  The
+// pose of iteration k needs the sums of ALL tiles of k - 1 (one global dependency per iteration is inherent), but the
+// bins need not be built from the CURRENT pose: a tile of iteration k reads the bins that iteration k - 1 built from
+// pose k - 1 -- with one plane / row of margin -- and transforms the records (MODEL points) with pose k itself; the
+// same launch bins pose k for iteration k + 1.  Per workgroup = (object o, x-plane, y-half), 512 lanes:
+//   1. ONE round trip: the reduced sums / maxima / optimiser state of EVERY object of the scene, the previous R|t,
+//      the bin counters of planes x-2 .. x+2 of both grids, its slice of the scene's points (bin duty).
+//   2. the optimiser step of every scene object (one lane each; the same bits in every workgroup); the workgroup
+//      (o, 0, 0) stores object o's state / R|t / trajectory row / loss and empties the parity two launches ahead.
+//      The record loads are in flight meanwhile.
+//   3. how far did each object move since the bins were built?  (|dR c + dt| + |dR| r) / pitch per axis over its
+//      bounding sphere: < 1 voxel -> its records are in the margin bins for certain (rounded coordinates move by
+//      at most one).  Otherwise (rare: the first iterations, a gradient spike) the object's points are read from the
+//      point array directly -- exact either way.
+//   4. records -> voxel-frame coordinates (the oracle's expressions) -> exact membership test -> survivor list in
+//      LDS -> the two TDF passes and the voxel phase of k_icc_fused, unchanged (shared code: the same bits).
+//   5. bin duty, interleaved: 1/64 of the scene's points against grid o with pose k -> counted per (plane, half)
+//      in LDS -> one global atomic per touched bin -> model-point records for iteration k + 1.
+// Accumulators, maxima and bin counters rotate over THREE parities (read / add into / being emptied), records and
+// R|t over two.  Scenes of more than kIterMaxNs objects, kernel sizes other than 3 and non-{0,1} no-entry grids
+// keep the two-launch path.
+constexpr int kIterMaxNs = 16;
+constexpr int kIterBlk = 8;                                   // 64-record blocks a wave keeps in registers
+constexpr int kIterMaxBlk = kIterBlk * (kTileThreads / 64);   // 4096 records per tile before the membership test
+constexpr int kIterBins = kHalves * (32 + 2 * 2);             // real bins of a grid (D <= 32, kernel 3, margin 1)
+constexpr int kIterSegs = 12;                                 // per grid kind: 5 planes + the overflow list
+// voxels an object may move under margin 1 (tests build with -DMF_ITER_MOVE_MAX=-1.0f: every object counts as
+// moved, every tile takes the re-read + streaming form; -DMF_ITER_SURV_CAP=n: tiny survivor lists overflow)
+#ifndef MF_ITER_MOVE_MAX
+#define MF_ITER_MOVE_MAX 0.98f
+#endif
+constexpr float kIterMoveMax = MF_ITER_MOVE_MAX;
+
+struct IterPar {
+  int acc_r, acc_w, acc_z;  // accumulators / maxima: read by the step, added into by the tiles, emptied
+  int bin_r, bin_w, bin_z;  // bin counters: read by the tiles, filled by the bin duty, emptied
+  int rec_r, rec_w;         // record buffers
+  int rt_r, rt_w;           // R|t copies: the pose the read bins were built from / this iteration's pose
+};
+
+struct IterLds {
+  float sum[kIterMaxNs][kStepSums];
+  float state[kIterMaxNs][kStateFloats];
+  float Rtp[kIterMaxNs][12];
+  float bound[kIterMaxNs][4];
+  float Rt[kIterMaxNs][12];
+  int off[kIterMaxNs + 1];
+  uint2 blk[kIterMaxBlk];  // {first record (index into the read buffer), records | grid kind << 31}
+  int bcnt[2 * kIterBins], bbase[2 * kIterBins];
+  int nlist, ovf, nblk;
+  unsigned moved, hit;
+};
+
+// dynamic LDS of k_icc_iter: [dist | id: 4 nvh words][union: survivor list | step staging | VoxLds + rows2]
+__host__ __device__ inline size_t iter_union_bytes(int max_ns) {
+  return sizeof(VoxLds) + (size_t)max_ns * (kTileThreads / 16) * 13 * sizeof(float);
+}
+
+__global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStepArgs sp, IterPar ip) {
+  MF_DYN_LDS(uint32_t, s_dyn);
+  __shared__ IterLds L;
+  constexpr int h = 1, K = 27;
+  const int D = a.D, nb = a.nbins, V = D * D * D, nbr = nb - 1;
+  const int o = blockIdx.y, tile = blockIdx.x;
+  const int x = tile / kHalves, half = tile % kHalves;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Dh = (D + 1) / 2;
+  const int y0 = half * Dh, y1 = half == 0 ? Dh : D;
+  const int Wp = D + 2 * kPad, rows_p = Dh + 2 * kPad;
+  const int nvh = rows_p * Wp, nvox = (y1 - y0) * D;
+  const int mg = a.mg, poff = a.hmax + mg;  // plane index of a rounded x: rx + poff
+  uint32_t *s_dist = s_dyn, *s_id = s_dyn + 2 * nvh;
+  unsigned char *s_un = reinterpret_cast<unsigned char *>(s_dyn + 4 * nvh);
+  VoxLds &Vx = *reinterpret_cast<VoxLds *>(s_un);
+  float *s_rows2 = reinterpret_cast<float *>(s_un + sizeof(VoxLds));
+  float4 *s_surv = reinterpret_cast<float4 *>(s_un);  // {fx, fy, fz, id | plane << 27 | kind << 29}
+  float *s_f = reinterpret_cast<float *>(s_un);       // staged accumulator words of the step
+#ifdef MF_ITER_SURV_CAP
+  const int surv_cap = MF_ITER_SURV_CAP;
+#else
+  const int surv_cap = (int)(iter_union_bytes(a.max_ns) / sizeof(float4));
+#endif
+
+  int ja, Ns, sc;
+  if (a.uniform_ns > 0) {
+    Ns = a.uniform_ns; sc = o / Ns; ja = sc * Ns;
+  } else {
+    const int4 meta = a.meta[o];
+    ja = meta.x; Ns = meta.y - meta.x; sc = a.obj_scene[o];
+  }
+  const int jj_o = o - ja;
+  const bool designated = tile == 0;  // stores object o's step and empties its words of the parity after next
+
+  // ---- 1. everything that depends on (o, tile) and the tables only: one round trip ----
+  const float pitch = a.pitch[o];
+  const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
+  const float S_t = sp.mode != 0 ? a.St[sc] : 1.0f;
+  float ne0 = 0.0f, tg0 = 0.0f;
+  if (tid < nvox) {
+    const int64_t gv = (int64_t)o * V + ((int64_t)x * D + y0) * D + tid;
+    ne0 = a.grid_ne[gv];
+    tg0 = a.grid_target[gv];
+  }
+  if (tid <= Ns) L.off[tid] = a.obj_off[ja + tid];
+  for (int i = tid; i < 4 * Ns; i += kTileThreads) (&L.bound[0][0])[i] = a.bound[4 * ja + i];
+  {
+    const float *Rp = a.Rt + (int64_t)ip.rt_r * a.O * 12 + 12 * ja;
+    for (int i = tid; i < 12 * Ns; i += kTileThreads) (&L.Rtp[0][0])[i] = Rp[i];
+    if (sp.mode == 0) {
+      const float *Rc = a.Rt + (int64_t)ip.rt_w * a.O * 12 + 12 * ja;
+      for (int i = tid; i < 12 * Ns; i += kTileThreads) (&L.Rt[0][0])[i] = Rc[i];
+    }
+  }
+  const int nA = 8 * Ns, nB = 12 * Ns * Ns, nf = nA + nB + 60 * Ns;
+  if (sp.mode != 0) {
+    const long long *own = a.acc_own + (int64_t)ip.acc_r * a.O * kOwnSlots;
+    const long long *oth = a.acc_oth + (int64_t)ip.acc_r * a.O * a.max_ns * 12;
+    const uint32_t *Mb = a.Mbits + (int64_t)ip.acc_r * 2 * a.O;
+    for (int i = tid; i < nf; i += kTileThreads) {
+      float fv;
+      if (i < nA) {
+        fv = fused_item_scene(own, Mb, ja + (i >> 3), i & 7, Ns);
+      } else if (i < nA + nB) {
+        const int k = i - nA, jj = k / (12 * Ns), r = k - jj * 12 * Ns, jo = r / 12, c = r - 12 * jo;
+        fv = fused_item_oth(oth, ja + jo, a.max_ns, jj, c);
+      } else {
+        const int k = i - nA - nB, jj = k / 60;
+        fv = fused_item_own(own, ja + jj, k - 60 * jj);
+      }
+      s_f[i] = fv;
+    }
+    for (int i = tid; i < kStateFloats * Ns; i += kTileThreads) {
+      const int jj = i / kStateFloats, c = i - kStateFloats * jj, j = ja + jj;
+      L.state[jj][c] = c < 4 ? sp.q_in[4 * j + c] : c < 7 ? sp.t_in[3 * j + c - 4]
+                       : c < 14 ? sp.m_in[7 * j + c - 7] : sp.v_in[7 * j + c - 14];
+    }
+  }
+  // block table of this tile's records: wave 0 reads the 12 segment sizes (planes x-2 .. x+2 and the overflow
+  // list of the own and the other grid) and cuts them into 64-record blocks
+  if (wave == 0) {
+    const uint32_t *cnt_r = a.bin_cnt + (int64_t)ip.bin_r * a.par_cnt;
+    int n_s[kIterSegs];
+    uint32_t r_s[kIterSegs];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd) {
+      const int g = 2 * o + kd;
+      const int cap = a.bin_cap[g];
+      const int64_t base = a.bin_base[g];
+      const bool on = kd == 0 || Ns > 1;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {  // plane x - 2 + b has index x + b (poff = 2)
+        const int bin = (x - h - mg + poff + b) * kHalves + half;
+        n_s[kd * 6 + b] = on ? min((int)cnt_r[(int64_t)g * nb + bin], cap) : 0;
+        r_s[kd * 6 + b] = (uint32_t)(base + (int64_t)bin * cap);
+      }
+      n_s[kd * 6 + 5] = on ? min((int)cnt_r[(int64_t)g * nb + nbr], 2 * a.bin_pts[g]) : 0;
+      r_s[kd * 6 + 5] = (uint32_t)(base + (int64_t)nbr * cap);
+    }
+    int pb[kIterSegs + 1];
+    pb[0] = 0;
+#pragma unroll
+    for (int s = 0; s < kIterSegs; ++s) pb[s + 1] = pb[s] + (n_s[s] + 63) / 64;
+    if (lane == 0) { L.nblk = pb[kIterSegs]; L.nlist = 0; L.ovf = 0; L.moved = 0u; L.hit = 0u; }
+    // lane b describes block b (and b + 64 ...: a tile beyond kIterMaxBlk blocks takes the streaming path)
+    for (int b = lane; b < min(pb[kIterSegs], kIterMaxBlk); b += 64) {
+      int s = 0;
+#pragma unroll
+      for (int k = 1; k < kIterSegs; ++k) s += b >= pb[k] ? 1 : 0;
+      int ps = 0, ns = 0;
+      uint32_t rs = 0u;
+#pragma unroll
+      for (int k = 0; k < kIterSegs; ++k) {
+        ps = k == s ? pb[k] : ps;
+        ns = k == s ? n_s[k] : ns;
+        rs = k == s ? r_s[k] : rs;
+      }
+      const int first = (b - ps) * 64;
+      L.blk[b] = make_uint2(rs + (uint32_t)first, (uint32_t)min(64, ns - first) | (s >= 6 ? 0x80000000u : 0u));
+    }
+  }
+  for (int i = tid; i < 2 * nvh; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
+  for (int i = tid; i < 2 * kIterBins; i += kTileThreads) L.bcnt[i] = 0;
+  __syncthreads();  // A: staged words, tables
+
+  // the record loads: in flight while the step is evaluated
+  const float4 *rec_r = a.rec + (int64_t)ip.rec_r * a.rec_stride;
+  const int nblk = L.nblk;
+  float4 rv[kIterBlk];
+  uint32_t rinfo[kIterBlk];  // kind << 31 | valid
+#pragma unroll
+  for (int u = 0; u < kIterBlk; ++u) {
+    const int b = wave + u * (kTileThreads / 64);
+    rinfo[u] = 0u;
+    rv[u] = make_float4(0, 0, 0, 0);
+    if (b < nblk && b < kIterMaxBlk) {  // wave-uniform
+      const uint2 e = L.blk[b];
+      if (lane < (int)(e.y & 0x7fffffffu)) {
+        rv[u] = rec_r[e.x + (uint32_t)lane];
+        rinfo[u] = (e.y & 0x80000000u) | 1u;
+      }
+    }
+  }
+  // the bin duty's points: slice `tile` of the scene's points (one per lane and trip)
+  const int pa = L.off[0], pb_ = L.off[Ns];
+  const int slice = (pb_ - pa + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int p_lo = pa + tile * slice, p_hi = min(p_lo + slice, pb_);
+  const int ntrip = (slice + kTileThreads - 1) / kTileThreads;
+  float4 bm = make_float4(0, 0, 0, 0);
+  if (p_lo + tid < p_hi) bm = a.pts4[p_lo + tid];
+
+  if (sp.mode != 0) {
+    for (int i = tid; i < kStepSums * Ns; i += kTileThreads) {
+      const int jj = i / kStepSums, l = i - kStepSums * jj;
+      L.sum[jj][l] = fused_sum(l, Ns, jj, s_f, s_f + nA + jj * 12 * Ns, s_f + nA + nB + 60 * jj);
+    }
+  }
+  __syncthreads();  // B: sums
+  // ---- 2. the step of every scene object; 3. displacement since the bins were built ----
+  if (tid < Ns) {
+    const int j = ja + tid;
+    float Rt[12];
+    if (sp.mode != 0) {
+      float st_new[kStateFloats], loss, gq[4], gt[3];
+      icc_step_apply(L.sum[tid], S_t, L.state[tid], sp, Rt, st_new, loss, gq, gt);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) L.Rt[tid][i] = Rt[i];
+      if (designated && tid == jj_o) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sp.q_out[4 * j + i] = st_new[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sp.t_out[3 * j + i] = st_new[4 + i];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { sp.m_out[7 * j + i] = st_new[7 + i]; sp.v_out[7 * j + i] = st_new[14 + i]; }
+        float *Rw = a.Rt + ((int64_t)ip.rt_w * a.O + j) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Rw[i] = Rt[i];
+        if (sp.traj) {
+          float *tr = sp.traj + ((int64_t)sp.it * a.O + j) * 7;
+#pragma unroll
+          for (int i = 0; i < 7; ++i) tr[i] = st_new[i];
+        }
+        if (sp.loss_out && j == ja) sp.loss_out[sc] = loss;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Rt[i] = L.Rt[tid][i];
+    }
+    // movement bound of object j in voxels of grid o, per axis, over its bounding sphere
+    const float cx = L.bound[tid][0], cy = L.bound[tid][1], cz = L.bound[tid][2], br = L.bound[tid][3];
+    const float inv_pitch = 1.0f / pitch;
+    float dmax = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float e0 = Rt[3 * d] - L.Rtp[tid][3 * d], e1 = Rt[3 * d + 1] - L.Rtp[tid][3 * d + 1],
+                  e2 = Rt[3 * d + 2] - L.Rtp[tid][3 * d + 2];
+      const float dt = Rt[9 + d] - L.Rtp[tid][9 + d];
+      const float mv = fabsf(((e0 * cx + e1 * cy) + e2 * cz) + dt) + sqrtf((e0 * e0 + e1 * e1) + e2 * e2) * fmaxf(br, 0.0f);
+      dmax = fmaxf(dmax, mv * inv_pitch);
+    }
+    // whole-object test of the bin duty: does object j (pose k) reach grid o at all? (margin included)
+    const float fh = (float)(h + mg);
+    const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
+    const float gx = (((Rt[0] * cx + Rt[1] * cy) + Rt[2] * cz) + Rt[9] - ox) * inv_pitch;
+    const float gy = (((Rt[3] * cx + Rt[4] * cy) + Rt[5] * cz) + Rt[10] - oy) * inv_pitch;
+    const float gz = (((Rt[6] * cx + Rt[7] * cy) + Rt[8] * cz) + Rt[11] - oz) * inv_pitch;
+    const float r = br * inv_pitch + 0.05f + 1e-4f * (fabsf(gx) + fabsf(gy) + fabsf(gz));
+    const bool hit = br >= 0.0f && !(gx + r < glo || gx - r > ghi || gy + r < glo || gy - r > ghi || gz + r < glo ||
+                                     gz - r > ghi);
+    // an object that moved too far (or whose pose is not finite) is re-read from the point array -- if it can
+    // reach this grid at all
+    const bool mvd = !(dmax <= kIterMoveMax) && br >= 0.0f;
+    if (hit) atomicOr(&L.hit, 1u << tid);
+    if (mvd && (hit || !(dmax == dmax))) atomicOr(&L.moved, 1u << tid);
+  }
+  if (designated && sp.mode != 0) {
+    // all lanes together: this object's accumulators, maxima and bin counters of the parity the launch after
+    // next adds into / fills
+    if (tid < 2) a.Mbits[(int64_t)ip.acc_z * 2 * a.O + 2 * o + tid] = 0;
+    long long *own = a.acc_own + ((int64_t)ip.acc_z * a.O + o) * kOwnSlots;
+    for (int i = tid; i < kOwnSlots; i += kTileThreads) own[i] = 0;
+    long long *oth = a.acc_oth + ((int64_t)ip.acc_z * a.O + o) * a.max_ns * 12;
+    for (int i = tid; i < a.max_ns * 12; i += kTileThreads) oth[i] = 0;
+    uint32_t *cz = a.bin_cnt + (int64_t)ip.bin_z * a.par_cnt + (int64_t)(2 * o) * nb;
+    for (int i = tid; i < 2 * nb; i += kTileThreads) cz[i] = 0u;
+  }
+  __syncthreads();  // C: poses, moved / hit masks
+
+  const float trunc = a.thr * pitch;
+  const float d2_hi = a.thr * a.thr * 1.00002f, d2_in = a.thr * a.thr * 0.999f;
+  Tile3 tl;
+  tl.Wp = Wp; tl.rows_p = rows_p; tl.y0 = y0; tl.fxp = (float)x; tl.pitch = pitch; tl.trunc = trunc; tl.d2_in = d2_in;
+  tl.hi_bits = __float_as_uint(d2_hi) - 1u;
+  tl.in_bits = __float_as_uint(d2_in);
+  const unsigned moved = L.moved, hitm = L.hit;
+  const float fD = (float)D;
+
+  // model point of scene-local object jl -> voxel frame of grid o (the oracle's expressions: transform_points
+  // un-fused, (p - origin) / pitch correctly rounded) -> is it a record of THIS tile (plane x-1 .. x+1, rows of
+  // this half, inside the grid's reach)?  `pl` = its plane's offset.
+  auto classify = [&](const float mx, const float my, const float mz, const int jl, float &fx, float &fy, float &fz,
+                      int &pl) -> bool {
+    const float *R = L.Rt[jl];
+    const float wx = ((R[0] * mx + R[1] * my) + R[2] * mz) + R[9];
+    const float wy = ((R[3] * mx + R[4] * my) + R[5] * mz) + R[10];
+    const float wz = ((R[6] * mx + R[7] * my) + R[8] * mz) + R[11];
+    fx = (wx - ox) / pitch; fy = (wy - oy) / pitch; fz = (wz - oz) / pitch;
+    const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
+    const float fh = (float)h;
+    const bool surv = rx + fh >= 0.0f && rx - fh < fD && ry + fh >= 0.0f && ry - fh < fD && rz + fh >= 0.0f &&
+                      rz - fh < fD;
+    pl = (int)rx - (x - h);
+    const int iry = (int)ry;
+    const bool in_half = half == 0 ? (iry - h < Dh) : (iry + h >= Dh);
+    return surv && pl >= 0 && pl < 3 && in_half;
+  };
+  auto visit_word = [&](const int pass, const float fx, const float fy, const float fz, const uint32_t w) {
+    const int kd = (int)(w >> 29) & 1;
+    icc_visit3(pass, s_dist + kd * nvh, s_id + kd * nvh, tl, fx, fy, fz, w & 0x7ffffffu, (int)(w >> 27) & 3);
+  };
+
+  // bin duty, stage A of trip 0: my point against grid o with pose k -> LDS counters
+  int bbin[kHalves] = {-1, -1}, bslot[kHalves] = {0, 0};
+  uint32_t bword = 0u;
+  auto bin_count = [&](const float4 m, const int p) {
+    bbin[0] = bbin[1] = -1;
+    if (p >= p_hi) return;
+    int jl = 0;
+    for (int k = 1; k < Ns; ++k) jl += p >= L.off[k] ? 1 : 0;
+    if (!((hitm >> jl) & 1u)) return;
+    const float *R = L.Rt[jl];
+    const float wx = ((R[0] * m.x + R[1] * m.y) + R[2] * m.z) + R[9];
+    const float wy = ((R[3] * m.x + R[4] * m.y) + R[5] * m.z) + R[10];
+    const float wz = ((R[6] * m.x + R[7] * m.y) + R[8] * m.z) + R[11];
+    const float fx = (wx - ox) / pitch, fy = (wy - oy) / pitch, fz = (wz - oz) / pitch;
+    const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
+    const int hh = h + mg;
+    const float fh = (float)hh;
+    const bool surv = rx + fh >= 0.0f && rx - fh < fD && ry + fh >= 0.0f && ry - fh < fD && rz + fh >= 0.0f &&
+                      rz - fh < fD;
+    if (!surv) return;
+    const int kd = jl == jj_o ? 0 : 1;
+    const int plane = (int)rx + poff, iry = (int)ry;
+    bword = (uint32_t)p | ((uint32_t)jl << 27);
+    if (iry - hh < Dh) {
+      bbin[0] = kd * kIterBins + plane * kHalves;
+      bslot[0] = atomicAdd(&L.bcnt[bbin[0]], 1);
+    }
+    if (iry + hh >= Dh) {
+      bbin[1] = kd * kIterBins + plane * kHalves + 1;
+      bslot[1] = atomicAdd(&L.bcnt[bbin[1]], 1);
+    }
+  };
+  uint32_t *cnt_w = a.bin_cnt + (int64_t)ip.bin_w * a.par_cnt + (int64_t)(2 * o) * nb;
+  // stage B: one global atomic per touched bin reserves the block's slots (value used in stage C)
+  auto bin_reserve = [&]() -> int {
+    int base = 0;
+    if (tid < 2 * kIterBins) {
+      const int c = L.bcnt[tid];
+      const int kd = tid / kIterBins, bin = tid - kd * kIterBins;
+      if (c > 0) base = (int)atomicAdd(&cnt_w[(int64_t)kd * nb + bin], (uint32_t)c);
+    }
+    return base;
+  };
+  float4 *rec_w = a.rec + (int64_t)ip.rec_w * a.rec_stride;
+  auto bin_store = [&](const float4 m) {
+#pragma unroll
+    for (int hf = 0; hf < kHalves; ++hf) {
+      if (bbin[hf] < 0) continue;
+      const int kd = bbin[hf] / kIterBins, bin = bbin[hf] - kd * kIterBins, g = 2 * o + kd;
+      const int cap = a.bin_cap[g];
+      const int64_t base_g = a.bin_base[g];
+      const int idx = L.bbase[bbin[hf]] + bslot[hf];
+      const float4 r = make_float4(m.x, m.y, m.z, __uint_as_float(bword));
+      if (idx < cap) {
+        rec_w[base_g + (int64_t)bin * cap + idx] = r;
+      } else {  // bin full: the grid's overflow list
+        const uint32_t k = atomicAdd(&cnt_w[(int64_t)kd * nb + nbr], 1u);
+        if ((int)k < 2 * a.bin_pts[g]) rec_w[base_g + (int64_t)nbr * cap + k] = r;
+      }
+    }
+  };
+
+  // ---- 4. records -> survivors ----
+  const bool slow_pre = nblk > kIterMaxBlk || moved != 0u;  // block-uniform
+  if (!slow_pre) {
+    float sfx[kIterBlk], sfy[kIterBlk], sfz[kIterBlk];
+    uint32_t sw[kIterBlk];
+    int npass = 0;
+    unsigned long long bal[kIterBlk];
+#pragma unroll
+    for (int u = 0; u < kIterBlk; ++u) {
+      bal[u] = 0ull;
+      if (wave + u * (kTileThreads / 64) >= nblk) continue;  // wave-uniform
+      bool ok = false;
+      int pl = 0;
+      sw[u] = 0u;
+      if (rinfo[u] & 1u) {
+        const uint32_t bits = __float_as_uint(rv[u].w);
+        ok = classify(rv[u].x, rv[u].y, rv[u].z, (int)(bits >> 27), sfx[u], sfy[u], sfz[u], pl);
+        sw[u] = (bits & 0x7ffffffu) | ((uint32_t)pl << 27) | ((rinfo[u] >> 31) << 29);
+      }
+      if (!ok) sw[u] = 0xffffffffu;
+      bal[u] = __ballot(ok);
+      npass += __popcll(bal[u]);
+    }
+    if (npass > 0) {  // wave-uniform
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&L.nlist, npass);
+      base = __shfl(base, 0);
+      int run = base;
+#pragma unroll
+      for (int u = 0; u < kIterBlk; ++u) {
+        if (bal[u] == 0ull) continue;
+        if (sw[u] != 0xffffffffu) {
+          const int slot = run + __popcll(bal[u] & ((1ull << lane) - 1ull));
+          if (slot < surv_cap) s_surv[slot] = make_float4(sfx[u], sfy[u], sfz[u], __uint_as_float(sw[u]));
+          else L.ovf = 1;
+        }
+        run += __popcll(bal[u]);
+      }
+    }
+  }
+  bin_count(bm, p_lo + tid);
+  __syncthreads();  // D: survivor list, LDS bin counters
+  const bool slow = slow_pre || L.ovf != 0;  // block-uniform
+  // streaming form (rare): every source record again for each pass, visited under its membership predicate --
+  // bins first (records of moved objects skipped), then the points of the moved objects themselves
+  auto stream_pass = [&](const int pass) {
+    const uint32_t *cnt_r = a.bin_cnt + (int64_t)ip.bin_r * a.par_cnt;
+    for (int kd = 0; kd < (Ns > 1 ? 2 : 1); ++kd) {
+      const int g = 2 * o + kd;
+      const int cap = a.bin_cap[g];
+      const int64_t base = a.bin_base[g];
+      for (int b = 0; b < 6; ++b) {
+        const int bin = b < 5 ? (x - h - mg + poff + b) * kHalves + half : nbr;
+        const int n = b < 5 ? min((int)cnt_r[(int64_t)g * nb + bin], cap)
+                            : min((int)cnt_r[(int64_t)g * nb + nbr], 2 * a.bin_pts[g]);
+        const float4 *src = rec_r + base + (int64_t)bin * cap;
+        for (int i = tid; i < n; i += kTileThreads) {
+          const float4 r = src[i];
+          const uint32_t bits = __float_as_uint(r.w);
+          const int jl = (int)(bits >> 27);
+          if ((moved >> jl) & 1u) continue;
+          float fx, fy, fz;
+          int pl;
+          if (classify(r.x, r.y, r.z, jl, fx, fy, fz, pl))
+            visit_word(pass, fx, fy, fz, (bits & 0x7ffffffu) | ((uint32_t)pl << 27) | ((uint32_t)kd << 29));
+        }
+      }
+    }
+    for (unsigned mm = moved; mm != 0u; mm &= mm - 1u) {
+      const int jl = __ffs((int)mm) - 1;
+      const int kd = jl == jj_o ? 0 : 1;
+      for (int p = L.off[jl] + tid; p < L.off[jl + 1]; p += kTileThreads) {
+        const float4 m = a.pts4[p];
+        float fx, fy, fz;
+        int pl;
+        if (classify(m.x, m.y, m.z, jl, fx, fy, fz, pl))
+          visit_word(pass, fx, fy, fz, (uint32_t)p | ((uint32_t)pl << 27) | ((uint32_t)kd << 29));
+      }
+    }
+  };
+  const int nlist = slow ? 0 : L.nlist;
+  const int rbase = bin_reserve();  // global atomics in flight during pass 1
+  if (slow) {
+    stream_pass(1);
+  } else {
+    for (int i = tid; i < nlist; i += kTileThreads) {
+      const float4 e = s_surv[i];
+      visit_word(1, e.x, e.y, e.z, __float_as_uint(e.w));
+    }
+  }
+  if (tid < 2 * kIterBins) L.bbase[tid] = rbase;
+  __syncthreads();  // E: pass 1, bin bases
+  if (slow) {
+    stream_pass(2);
+  } else {
+    for (int i = tid; i < nlist; i += kTileThreads) {
+      const float4 e = s_surv[i];
+      visit_word(2, e.x, e.y, e.z, __float_as_uint(e.w));
+    }
+  }
+  bin_store(bm);
+  __syncthreads();  // F: pass 2; the survivor list is dead, its memory becomes the voxel phase's
+  for (int i = tid; i < Ns * (kTileThreads / 16) * 13; i += kTileThreads) s_rows2[i] = 0.0f;
+  for (int i = tid; i < (kTileThreads / 16) * (kNumF + 1); i += kTileThreads) (&Vx.rows[0][0])[i] = 0.0f;
+  // further trips of the bin duty (scenes of more than 64 x 512 points): the same three stages, serially
+  for (int trip = 1; trip < ntrip; ++trip) {
+    __syncthreads();
+    for (int i = tid; i < 2 * kIterBins; i += kTileThreads) L.bcnt[i] = 0;
+    __syncthreads();
+    const int p = p_lo + trip * kTileThreads + tid;
+    const float4 m = p < p_hi ? a.pts4[p] : make_float4(0, 0, 0, 0);
+    bin_count(m, p);
+    __syncthreads();
+    const int rb2 = bin_reserve();
+    if (tid < 2 * kIterBins) L.bbase[tid] = rb2;
+    __syncthreads();
+    bin_store(m);
+  }
+
+  TileGeom tg_;
+  tg_.o = o; tg_.ja = ja; tg_.Ns = Ns; tg_.x = x; tg_.y0 = y0; tg_.nvox = nvox; tg_.nvh = nvh; tg_.Wp = Wp; tg_.D = D;
+  tg_.K = K; tg_.pitch = pitch; tg_.trunc = trunc; tg_.ox = ox; tg_.oy = oy; tg_.oz = oz;
+  icc_voxel_phase(a, ip.acc_w, tg_, ne0, tg0, s_dist, s_id, s_rows2, Vx, L.Rt, L.off, [](int) {});
 }
 
 // ---- the step as a kernel of its own: one 64-lane workgroup per object ----------------
@@ -1691,7 +2278,7 @@ inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 struct WsLayout {
   int64_t W, M, Rt, bound, St, acc_own, acc_oth, state_alt, meta, tab, tab2, bin_cnt, bin_cap, bin_pts, bin_base,
-      rec, total;
+      rec, rec_n, total;
   int NB, n_tab, nbins;
 };
 
@@ -1713,23 +2300,24 @@ WsLayout ws_layout(const mfIccBatch *b) {
   const int O = b->n_objects, S = b->n_scenes, D = b->dim, max_ns = b->max_scene_objects;
   const int64_t V = (int64_t)D * D * D;
   l.NB = (int)((V + kVoxPerBlock - 1) / kVoxPerBlock);
-  l.nbins = kHalves * (D + 2 * (ksize_host(b->voxel_threshold) / 2)) + 1;  // + the overflow counter
+  // (+ 1 plane of margin per side: the bins of k_icc_iter) + the overflow counter
+  l.nbins = kHalves * (D + 2 * (ksize_host(b->voxel_threshold) / 2 + 1)) + 1;
   // every (target, source) pair of a scene in chunks of kBinChunk points:
   // sum_pairs ceil(P_j / chunk) <= max_ns * n_points / chunk + O * max_ns (+ O designated entries)
   l.n_tab = (int)(((int64_t)max_ns * b->n_points + kBinChunk - 1) / kBinChunk) + O * max_ns + O;
   int64_t off = 0;
   l.W = off; off = align256(off + 2 * O * V * 8);
-  l.M = off; off = align256(off + 2 * 2 * O * 4);
-  l.Rt = off; off = align256(off + O * 12 * 4);
+  l.M = off; off = align256(off + kParities * 2 * O * 4);
+  l.Rt = off; off = align256(off + 2 * O * 12 * 4);
   l.bound = off; off = align256(off + O * 4 * 4);
   l.St = off; off = align256(off + S * 4);
-  l.acc_own = off; off = align256(off + (int64_t)2 * O * kOwnSlots * 8);
-  l.acc_oth = off; off = align256(off + (int64_t)2 * O * max_ns * 12 * 8);
+  l.acc_own = off; off = align256(off + (int64_t)kParities * O * kOwnSlots * 8);
+  l.acc_oth = off; off = align256(off + (int64_t)kParities * O * max_ns * 12 * 8);
   l.state_alt = off; off = align256(off + (int64_t)O * kStateFloats * 4);
   l.meta = off; off = align256(off + (int64_t)O * 16);
   l.tab = off; off = align256(off + (int64_t)l.n_tab * 16);
   l.tab2 = off; off = align256(off + (int64_t)l.n_tab * 16);
-  l.bin_cnt = off; off = align256(off + (int64_t)2 * 2 * O * l.nbins * 4);
+  l.bin_cnt = off; off = align256(off + (int64_t)kParities * 2 * O * l.nbins * 4);
   l.bin_cap = off; off = align256(off + (int64_t)2 * O * 4);
   l.bin_pts = off; off = align256(off + (int64_t)2 * O * 4);
   l.bin_base = off; off = align256(off + (int64_t)2 * O * 8);
@@ -1740,7 +2328,8 @@ WsLayout ws_layout(const mfIccBatch *b) {
     const int force = icc_bin_cap_force();
     const int64_t per_grid_extra = (force > 0 ? force : kBinMinCap) + 1;
     const int64_t binned = force > 0 ? 0 : sumP / kBinShare;
-    l.rec = off; off = align256(off + ((int64_t)(l.nbins - 1) * (binned + 2 * O * per_grid_extra) + 2 * sumP) * 16);
+    l.rec_n = (int64_t)(l.nbins - 1) * (binned + 2 * O * per_grid_extra) + 2 * sumP;
+    l.rec = off; off = align256(off + 2 * l.rec_n * 16);  // two buffers: k_icc_iter reads one and fills the other
   }
   l.total = off;
   return l;
@@ -1789,6 +2378,11 @@ IccArgs make_args(const mfIccBatch *b, void *ws) {
   a.bin_cap_force = icc_bin_cap_force();
   a.bin_base = (int64_t *)(p + l.bin_base);
   a.rec = (float4 *)(p + l.rec);
+  a.rec_stride = l.rec_n;
+  a.par_cnt = (int64_t)2 * a.O * l.nbins;
+  a.mg = 0;
+  a.rec_model = 0;
+  a.uniform_ns = (int64_t)b->n_scenes * b->max_scene_objects == b->n_objects ? b->max_scene_objects : 0;
   return a;
 }
 
@@ -1808,6 +2402,40 @@ void launch_iteration(const IccArgs &a, IccStepArgs sp, int NB, int k, hipStream
   }
   hipLaunchKernelGGL(k_icc_tile, dim3(D * kHalves, 2 * a.O), dim3(kTileThreads), lds_tile, stream, a, par);
   hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), lds_rows2, stream, a, par);
+}
+
+// One-launch iterations (k_icc_iter) apply to what every caller of the reference passes: {0,1} no-entry grids,
+// voxel_threshold 2 (kernel size 3 for every grid: (2 pitch) / pitch == 2 exactly), scenes of <= kIterMaxNs objects.
+// MF_ICC_TWO_LAUNCH=1 keeps the two-launch path (A/B measurements, bit-identity tests).
+bool icc_use_iter(const mfIccBatch *b, const IccArgs &a, const WsLayout &l) {
+  if (getenv("MF_ICC_TWO_LAUNCH") && atoi(getenv("MF_ICC_TWO_LAUNCH")) != 0) return false;
+  return a.ne_binary && b->voxel_threshold == 2.0f && b->max_scene_objects <= kIterMaxNs && b->dim <= 32 &&
+         l.rec_n < ((int64_t)1 << 31);
+}
+
+size_t iter_lds_bytes(const IccArgs &a) {
+  return 4 * (size_t)fused_tile_words(a.D) * sizeof(uint32_t) + iter_union_bytes(a.max_ns);
+}
+
+// The bins iteration 0 reads: model-point records with one plane / row of margin, from the pose in a.Rt (copy 0),
+// into counter parity 0 and record buffer 0.
+void launch_iter_prebin(IccArgs a, hipStream_t stream) {
+  a.mg = 1;
+  a.rec_model = 1;
+  IccStepArgs sp = {};
+  hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, sp);
+}
+
+// Iteration k as ONE launch: [step k - 1 (k > 0)] -> tiles on the bins of k - 1 -> bins for k + 1.
+void launch_iter(IccArgs a, const IccStepArgs &sp, int k, hipStream_t stream) {
+  a.mg = 1;
+  a.rec_model = 1;
+  IterPar ip;
+  ip.acc_r = (k + 2) % 3; ip.acc_w = k % 3; ip.acc_z = (k + 1) % 3;
+  ip.bin_r = k % 3; ip.bin_w = (k + 1) % 3; ip.bin_z = (k + 2) % 3;
+  ip.rec_r = k & 1; ip.rec_w = (k + 1) & 1;
+  ip.rt_r = (k + 1) & 1; ip.rt_w = k & 1;
+  hipLaunchKernelGGL(k_icc_iter, dim3(a.D * kHalves, a.O), dim3(kTileThreads), iter_lds_bytes(a), stream, a, sp, ip);
 }
 
 // chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once
@@ -1846,10 +2474,19 @@ extern "C" int mf_pack_points_sdf(const float *points, const float *sdf, int64_t
   return mf::check_launch("mf_pack_points_sdf");
 }
 
+extern "C" int mf_icc_iteration_launches(const mfIccBatch *batch) {
+  if (!icc_batch_ok(batch)) return -1;
+  char dummy[8];
+  const IccArgs a = make_args(batch, dummy);  // (pointers are offsets from a dummy base: not dereferenced)
+  if (!a.ne_binary) return 3;
+  return icc_use_iter(batch, a, ws_layout(batch)) ? 1 : 2;
+}
+
 static int icc_validate(const mfIccBatch *b) {
   // collision-moment rows: max_scene_objects x 1664 B of dynamic LDS (106 KB at 64 objects)
   if (int e = mf::allow_big_lds((const void *)k_icc_fused, 124 * 1024)) return e;
   if (int e = mf::allow_big_lds((const void *)k_icc_accum, 124 * 1024)) return e;
+  if (int e = mf::allow_big_lds((const void *)k_icc_iter, 124 * 1024)) return e;
   if (!icc_batch_ok(b)) {
     mf::set_last_error(hipErrorInvalidValue, "mf_icc: invalid batch descriptor");
     return -(int)hipErrorInvalidValue;
@@ -1872,7 +2509,7 @@ extern "C" int mf_icc_launch_stage(const mfIccBatch *batch, const float *q, cons
   IccArgs a = make_args(batch, ws);
   const int D = a.D;
   if (stage == 0) {
-    if (q && t) hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t, (float *)nullptr);
+    if (q && t) hipLaunchKernelGGL(k_icc_pose, dim3(a.O), dim3(256), 0, stream, a, q, t, (float *)nullptr);
     // inside an iteration k_icc_accum empties the bins; this hook has no accum launch
     if (int e_ = mf::fill_bytes(a.bin_cnt, 0, sizeof(uint32_t) * 2 * a.O * a.nbins, stream)) return e_;
     IccStepArgs sp = {};
@@ -1912,7 +2549,7 @@ extern "C" int mf_icc_loss_grad(const mfIccBatch *batch, const float *q, const f
   if (int e = icc_validate(batch)) return e;
   IccArgs a = make_args(batch, ws);
   const WsLayout l = ws_layout(batch);
-  hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, stream, a, q, t, (float *)nullptr);
+  hipLaunchKernelGGL(k_icc_pose, dim3(a.O), dim3(256), 0, stream, a, q, t, (float *)nullptr);
   IccStepArgs none = {};
   launch_iteration(a, none, l.NB, 0, stream);
   IccStepArgs sp = {};
@@ -1955,7 +2592,8 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
   int dev = 0;
   MF_TRY(hipGetDevice(&dev));
   key.v.push_back(((uint64_t)(uint32_t)dev << 32) | ((uint32_t)max_ns << 1) | (uint32_t)a.ne_binary);
-  key.v.push_back((uint64_t)(uint32_t)a.bin_cap_force);
+  const bool iter = icc_use_iter(batch, a, l);
+  key.v.push_back(((uint64_t)(iter ? 1u : 0u) << 32) | (uint64_t)(uint32_t)a.bin_cap_force);
 
   std::lock_guard<std::mutex> lock(g_graph_mu);
   auto itg = g_graphs.find(key);
@@ -1973,14 +2611,15 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
     float *alt = a.state_alt;
     float *sq[2] = {q, alt}, *st[2] = {t, alt + 4 * a.O}, *sm[2] = {adam_m, alt + 7 * a.O},
           *sv[2] = {adam_v, alt + 14 * a.O};
-    hipLaunchKernelGGL(k_icc_pose, dim3((a.O + 63) / 64), dim3(64), 0, cap, a, (const float *)q,
+    hipLaunchKernelGGL(k_icc_pose, dim3(a.O), dim3(256), 0, cap, a, (const float *)q,
                        (const float *)t, traj);
+    if (iter) launch_iter_prebin(a, cap);
     for (int k = 0; k <= n_iter; ++k) {
       IccStepArgs sp = {};
       if (k > 0) {
         const int in = (k - 1) & 1, out = k == n_iter ? 0 : (k & 1);
         sp.mode = 1;
-        sp.par = (k - 1) & 1;
+        sp.par = iter ? (k - 1) % 3 : (k - 1) & 1;
         sp.it = k;
         sp.aq = adam_alpha_t(alpha_q, step0 + k);
         sp.at = adam_alpha_t(alpha_t, step0 + k);
@@ -1994,7 +2633,10 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
         hipLaunchKernelGGL(k_icc_step, dim3(a.O), dim3(64), 0, cap, a, sp);
         break;
       }
-      launch_iteration(a, sp, l.NB, k, cap);
+      if (iter)
+        launch_iter(a, sp, k, cap);
+      else
+        launch_iteration(a, sp, l.NB, k, cap);
     }
     hipError_t ce = hipStreamEndCapture(cap, &graph);
     if (ce != hipSuccess) {
