@@ -10,7 +10,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libmfhip.so")
+# MF_LIBMFHIP=<file name in this directory>: a differently built copy of the same library (tools/stamps_*.py use
+# libmfhip_dbg.so = `make ICC_DEBUG=1 OUT=../libmfhip_dbg.so OBJDIR=_obj_dbg`: per-phase time stamps in the ICC kernels)
+SO_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("MF_LIBMFHIP", "libmfhip.so")))
 _lib = None
 
 _p = ctypes.c_void_p

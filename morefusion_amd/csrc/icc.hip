@@ -318,6 +318,9 @@ struct IccStepArgs {
   float *loss_out;                         // [S] or NULL
   float *gq_out, *gt_out;                  // mode 2
   float *traj;                             // [n_iter][O][7] or NULL
+  // k_icc_step between k_icc_iter launches: which R|t copy it writes, and the parities (+ 1; 0 = none) whose
+  // accumulators / maxima and bin counters of this object it empties
+  int rt_w, zero_acc1, zero_bin1;
 };
 
 // The calling workgroup (NT lanes) gathers the kStepSums sums of object j into s_sum.  Every
@@ -1725,21 +1728,22 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_fused(IccArgs a, int pa
 // bins need not be built from the CURRENT pose: a tile of iteration k reads the bins that iteration k - 1 built from
 // pose k - 1 -- with one plane / row of margin -- and transforms the records (MODEL points) with pose k itself; the
 // same launch bins pose k for iteration k + 1.  Per workgroup = (object o, x-plane, y-half), 512 lanes:
-//   1. ONE round trip: the reduced sums / maxima / optimiser state of EVERY object of the scene, the previous R|t,
-//      the bin counters of planes x-2 .. x+2 of both grids, its slice of the scene's points (bin duty).
-//   2. the optimiser step of every scene object (one lane each; the same bits in every workgroup); the workgroup
-//      (o, 0, 0) stores object o's state / R|t / trajectory row / loss and empties the parity two launches ahead.
-//      The record loads are in flight meanwhile.
-//   3. how far did each object move since the bins were built?  (|dR c + dt| + |dR| r) / pitch per axis over its
+//   1. ONE round trip: this iteration's and the previous R|t of every scene object (written by k_icc_step, one
+//      small workgroup per object between the iterations: the step is computed ONCE -- the first version of this
+//      kernel recomputed it in every workgroup and spent 10 us of instruction issue on it), the bin counters of
+//      planes x-2 .. x+2 of both grids, its slice of the scene's points (bin duty).
+//   2. how far did each object move since the bins were built?  (|dR c + dt| + |dR| r) / pitch per axis over its
 //      bounding sphere: < 1 voxel -> its records are in the margin bins for certain (rounded coordinates move by
 //      at most one).  Otherwise (rare: the first iterations, a gradient spike) the object's points are read from the
 //      point array directly -- exact either way.
-//   4. records -> voxel-frame coordinates (the oracle's expressions) -> exact membership test -> survivor list in
-//      LDS -> the two TDF passes and the voxel phase of k_icc_fused, unchanged (shared code: the same bits).
-//   5. bin duty, interleaved: 1/64 of the scene's points against grid o with pose k -> counted per (plane, half)
+//   3. records -> numerators of the voxel-frame coordinates (the oracle's expressions) -> a cheap conservative
+//      membership test on reciprocal multiplies -> survivor list in LDS; pass 1 divides exactly (IEEE), applies the
+//      exact membership test and runs the TDF minimum; pass 2 and the voxel phase are k_icc_fused's, unchanged
+//      (shared code: the same bits).
+//   4. bin duty, interleaved: 1/64 of the scene's points against grid o with this pose -> counted per (plane, half)
 //      in LDS -> one global atomic per touched bin -> model-point records for iteration k + 1.
-// Accumulators, maxima and bin counters rotate over THREE parities (read / add into / being emptied), records and
-// R|t over two.  Scenes of more than kIterMaxNs objects, kernel sizes other than 3 and non-{0,1} no-entry grids
+// Accumulators, maxima and bin counters rotate over THREE parities (read by the step / added into / emptied by the
+// step kernel), records and R|t over two.  Scenes of more than kIterMaxNs objects, kernel sizes other than 3 and non-{0,1} no-entry grids
 // keep the two-launch path.
 constexpr int kIterMaxNs = 16;
 constexpr int kIterBlk = 8;                                   // 64-record blocks a wave keeps in registers
@@ -1754,17 +1758,13 @@ constexpr int kIterSegs = 12;                                 // per grid kind: 
 constexpr float kIterMoveMax = MF_ITER_MOVE_MAX;
 
 struct IterPar {
-  int acc_r, acc_w, acc_z;  // accumulators / maxima: read by the step, added into by the tiles, emptied
-  int bin_r, bin_w, bin_z;  // bin counters: read by the tiles, filled by the bin duty, emptied
-  int rec_r, rec_w;         // record buffers
-  int rt_r, rt_w;           // R|t copies: the pose the read bins were built from / this iteration's pose
+  int acc_w;         // accumulators / maxima the tiles add into (the step kernels read and empty the others)
+  int bin_r, bin_w;  // bin counters: read by the tiles, filled by the bin duty
+  int rec_r, rec_w;  // record buffers
+  int rt_r, rt_w;    // R|t copies: the pose the read bins were built from / this iteration's pose
 };
 
 struct IterLds {
-  float sum[kIterMaxNs][kStepSums];
-  float state[kIterMaxNs][kStateFloats];
-  float Rtp[kIterMaxNs][12];
-  float bound[kIterMaxNs][4];
   float Rt[kIterMaxNs][12];
   int off[kIterMaxNs + 1];
   uint2 blk[kIterMaxBlk];  // {first record (index into the read buffer), records | grid kind << 31}
@@ -1773,12 +1773,12 @@ struct IterLds {
   unsigned moved, hit;
 };
 
-// dynamic LDS of k_icc_iter: [dist | id: 4 nvh words][union: survivor list | step staging | VoxLds + rows2]
+// dynamic LDS of k_icc_iter: [dist | id: 4 nvh words][union: survivor list | VoxLds + rows2]
 __host__ __device__ inline size_t iter_union_bytes(int max_ns) {
   return sizeof(VoxLds) + (size_t)max_ns * (kTileThreads / 16) * 13 * sizeof(float);
 }
 
-__global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStepArgs sp, IterPar ip) {
+__global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IterPar ip) {
   MF_DYN_LDS(uint32_t, s_dyn);
   __shared__ IterLds L;
   constexpr int h = 1, K = 27;
@@ -1795,71 +1795,43 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStep
   unsigned char *s_un = reinterpret_cast<unsigned char *>(s_dyn + 4 * nvh);
   VoxLds &Vx = *reinterpret_cast<VoxLds *>(s_un);
   float *s_rows2 = reinterpret_cast<float *>(s_un + sizeof(VoxLds));
-  float4 *s_surv = reinterpret_cast<float4 *>(s_un);  // {fx, fy, fz, id | plane << 27 | kind << 29}
-  float *s_f = reinterpret_cast<float *>(s_un);       // staged accumulator words of the step
+  // survivor list: pushed as {wx - ox, wy - oy, wz - oz, id | kind << 29} (numerators of the voxel-frame
+  // coordinates); pass 1 divides exactly, tests membership and rewrites {fx, fy, fz, id | plane << 27 | kind << 29}
+  float4 *s_surv = reinterpret_cast<float4 *>(s_un);
 #ifdef MF_ITER_SURV_CAP
   const int surv_cap = MF_ITER_SURV_CAP;
 #else
   const int surv_cap = (int)(iter_union_bytes(a.max_ns) / sizeof(float4));
 #endif
 
-  int ja, Ns, sc;
+  int ja, Ns;
   if (a.uniform_ns > 0) {
-    Ns = a.uniform_ns; sc = o / Ns; ja = sc * Ns;
+    Ns = a.uniform_ns; ja = (o / Ns) * Ns;
   } else {
     const int4 meta = a.meta[o];
-    ja = meta.x; Ns = meta.y - meta.x; sc = a.obj_scene[o];
+    ja = meta.x; Ns = meta.y - meta.x;
   }
   const int jj_o = o - ja;
-  const bool designated = tile == 0;  // stores object o's step and empties its words of the parity after next
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32): [wg][0..7] times, [2048 + wg][0..7] counts
+    if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
+  };
+  stamp(0);
 
   // ---- 1. everything that depends on (o, tile) and the tables only: one round trip ----
   const float pitch = a.pitch[o];
   const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
-  const float S_t = sp.mode != 0 ? a.St[sc] : 1.0f;
+  const float inv_pitch = 1.0f / pitch;
   float ne0 = 0.0f, tg0 = 0.0f;
   if (tid < nvox) {
     const int64_t gv = (int64_t)o * V + ((int64_t)x * D + y0) * D + tid;
     ne0 = a.grid_ne[gv];
     tg0 = a.grid_target[gv];
   }
-  if (tid <= Ns) L.off[tid] = a.obj_off[ja + tid];
-  for (int i = tid; i < 4 * Ns; i += kTileThreads) (&L.bound[0][0])[i] = a.bound[4 * ja + i];
-  {
-    const float *Rp = a.Rt + (int64_t)ip.rt_r * a.O * 12 + 12 * ja;
-    for (int i = tid; i < 12 * Ns; i += kTileThreads) (&L.Rtp[0][0])[i] = Rp[i];
-    if (sp.mode == 0) {
-      const float *Rc = a.Rt + (int64_t)ip.rt_w * a.O * 12 + 12 * ja;
-      for (int i = tid; i < 12 * Ns; i += kTileThreads) (&L.Rt[0][0])[i] = Rc[i];
-    }
-  }
-  const int nA = 8 * Ns, nB = 12 * Ns * Ns, nf = nA + nB + 60 * Ns;
-  if (sp.mode != 0) {
-    const long long *own = a.acc_own + (int64_t)ip.acc_r * a.O * kOwnSlots;
-    const long long *oth = a.acc_oth + (int64_t)ip.acc_r * a.O * a.max_ns * 12;
-    const uint32_t *Mb = a.Mbits + (int64_t)ip.acc_r * 2 * a.O;
-    for (int i = tid; i < nf; i += kTileThreads) {
-      float fv;
-      if (i < nA) {
-        fv = fused_item_scene(own, Mb, ja + (i >> 3), i & 7, Ns);
-      } else if (i < nA + nB) {
-        const int k = i - nA, jj = k / (12 * Ns), r = k - jj * 12 * Ns, jo = r / 12, c = r - 12 * jo;
-        fv = fused_item_oth(oth, ja + jo, a.max_ns, jj, c);
-      } else {
-        const int k = i - nA - nB, jj = k / 60;
-        fv = fused_item_own(own, ja + jj, k - 60 * jj);
-      }
-      s_f[i] = fv;
-    }
-    for (int i = tid; i < kStateFloats * Ns; i += kTileThreads) {
-      const int jj = i / kStateFloats, c = i - kStateFloats * jj, j = ja + jj;
-      L.state[jj][c] = c < 4 ? sp.q_in[4 * j + c] : c < 7 ? sp.t_in[3 * j + c - 4]
-                       : c < 14 ? sp.m_in[7 * j + c - 7] : sp.v_in[7 * j + c - 14];
-    }
-  }
-  // block table of this tile's records: wave 0 reads the 12 segment sizes (planes x-2 .. x+2 and the overflow
-  // list of the own and the other grid) and cuts them into 64-record blocks
+  if (tid >= 64 && tid <= 64 + Ns) L.off[tid - 64] = a.obj_off[ja + tid - 64];
   if (wave == 0) {
+    // block table of this tile's records: the 12 segment sizes (planes x-2 .. x+2 and the overflow list of the own
+    // and the other grid) cut into 64-record blocks
     const uint32_t *cnt_r = a.bin_cnt + (int64_t)ip.bin_r * a.par_cnt;
     int n_s[kIterSegs];
     uint32_t r_s[kIterSegs];
@@ -1878,12 +1850,50 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStep
       n_s[kd * 6 + 5] = on ? min((int)cnt_r[(int64_t)g * nb + nbr], 2 * a.bin_pts[g]) : 0;
       r_s[kd * 6 + 5] = (uint32_t)(base + (int64_t)nbr * cap);
     }
+    // 2. this iteration's pose of scene object `lane` and 3. how far it moved since the bins were built
+    bool hit = false, mvd = false;
+    if (lane < Ns) {
+      const float4 *Rc = reinterpret_cast<const float4 *>(a.Rt + ((int64_t)ip.rt_w * a.O + ja + lane) * 12);
+      const float4 *Rp = reinterpret_cast<const float4 *>(a.Rt + ((int64_t)ip.rt_r * a.O + ja + lane) * 12);
+      const float4 c0 = Rc[0], c1 = Rc[1], c2 = Rc[2], p0 = Rp[0], p1 = Rp[1], p2 = Rp[2];
+      const float4 bnd = *reinterpret_cast<const float4 *>(a.bound + 4 * (ja + lane));
+      *reinterpret_cast<float4 *>(&L.Rt[lane][0]) = c0;
+      *reinterpret_cast<float4 *>(&L.Rt[lane][4]) = c1;
+      *reinterpret_cast<float4 *>(&L.Rt[lane][8]) = c2;
+      const float Rt[12] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
+      const float Rq[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+      // movement bound of the object in voxels of grid o, per axis, over its bounding sphere
+      const float cx = bnd.x, cy = bnd.y, cz = bnd.z, br = bnd.w;
+      float dmax = 0.0f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float e0 = Rt[3 * d] - Rq[3 * d], e1 = Rt[3 * d + 1] - Rq[3 * d + 1], e2 = Rt[3 * d + 2] - Rq[3 * d + 2];
+        const float dt = Rt[9 + d] - Rq[9 + d];
+        const float mv = fabsf(((e0 * cx + e1 * cy) + e2 * cz) + dt) + sqrtf((e0 * e0 + e1 * e1) + e2 * e2) * fmaxf(br, 0.0f);
+        dmax = fmaxf(dmax, mv * inv_pitch);
+      }
+      // whole-object test: does the object (this pose) reach grid o at all? (margin included)
+      const float fh = (float)(h + mg);
+      const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
+      const float gx = (((Rt[0] * cx + Rt[1] * cy) + Rt[2] * cz) + Rt[9] - ox) * inv_pitch;
+      const float gy = (((Rt[3] * cx + Rt[4] * cy) + Rt[5] * cz) + Rt[10] - oy) * inv_pitch;
+      const float gz = (((Rt[6] * cx + Rt[7] * cy) + Rt[8] * cz) + Rt[11] - oz) * inv_pitch;
+      const float r = br * inv_pitch + 0.05f + 1e-4f * (fabsf(gx) + fabsf(gy) + fabsf(gz));
+      hit = br >= 0.0f && !(gx + r < glo || gx - r > ghi || gy + r < glo || gy - r > ghi || gz + r < glo || gz - r > ghi);
+      // an object that moved too far (or whose pose is not finite) is re-read from the point array -- if it can
+      // reach this grid at all
+      mvd = !(dmax <= kIterMoveMax) && br >= 0.0f && (hit || !(dmax == dmax));
+    }
+    const unsigned long long hb = __ballot(hit), mb = __ballot(mvd);
     int pb[kIterSegs + 1];
     pb[0] = 0;
 #pragma unroll
     for (int s = 0; s < kIterSegs; ++s) pb[s + 1] = pb[s] + (n_s[s] + 63) / 64;
-    if (lane == 0) { L.nblk = pb[kIterSegs]; L.nlist = 0; L.ovf = 0; L.moved = 0u; L.hit = 0u; }
-    // lane b describes block b (and b + 64 ...: a tile beyond kIterMaxBlk blocks takes the streaming path)
+    if (lane == 0) {
+      L.nblk = pb[kIterSegs]; L.nlist = 0; L.ovf = 0;
+      L.moved = (unsigned)mb; L.hit = (unsigned)hb;
+    }
+    // lane b describes block b (a tile beyond kIterMaxBlk blocks takes the streaming path)
     for (int b = lane; b < min(pb[kIterSegs], kIterMaxBlk); b += 64) {
       int s = 0;
 #pragma unroll
@@ -1902,9 +1912,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStep
   }
   for (int i = tid; i < 2 * nvh; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
   for (int i = tid; i < 2 * kIterBins; i += kTileThreads) L.bcnt[i] = 0;
-  __syncthreads();  // A: staged words, tables
+  __syncthreads();  // A: tables, poses, masks
+  stamp(1);
 
-  // the record loads: in flight while the step is evaluated
+  // the record loads
   const float4 *rec_r = a.rec + (int64_t)ip.rec_r * a.rec_stride;
   const int nblk = L.nblk;
   float4 rv[kIterBlk];
@@ -1930,83 +1941,6 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStep
   float4 bm = make_float4(0, 0, 0, 0);
   if (p_lo + tid < p_hi) bm = a.pts4[p_lo + tid];
 
-  if (sp.mode != 0) {
-    for (int i = tid; i < kStepSums * Ns; i += kTileThreads) {
-      const int jj = i / kStepSums, l = i - kStepSums * jj;
-      L.sum[jj][l] = fused_sum(l, Ns, jj, s_f, s_f + nA + jj * 12 * Ns, s_f + nA + nB + 60 * jj);
-    }
-  }
-  __syncthreads();  // B: sums
-  // ---- 2. the step of every scene object; 3. displacement since the bins were built ----
-  if (tid < Ns) {
-    const int j = ja + tid;
-    float Rt[12];
-    if (sp.mode != 0) {
-      float st_new[kStateFloats], loss, gq[4], gt[3];
-      icc_step_apply(L.sum[tid], S_t, L.state[tid], sp, Rt, st_new, loss, gq, gt);
-#pragma unroll
-      for (int i = 0; i < 12; ++i) L.Rt[tid][i] = Rt[i];
-      if (designated && tid == jj_o) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sp.q_out[4 * j + i] = st_new[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) sp.t_out[3 * j + i] = st_new[4 + i];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) { sp.m_out[7 * j + i] = st_new[7 + i]; sp.v_out[7 * j + i] = st_new[14 + i]; }
-        float *Rw = a.Rt + ((int64_t)ip.rt_w * a.O + j) * 12;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) Rw[i] = Rt[i];
-        if (sp.traj) {
-          float *tr = sp.traj + ((int64_t)sp.it * a.O + j) * 7;
-#pragma unroll
-          for (int i = 0; i < 7; ++i) tr[i] = st_new[i];
-        }
-        if (sp.loss_out && j == ja) sp.loss_out[sc] = loss;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Rt[i] = L.Rt[tid][i];
-    }
-    // movement bound of object j in voxels of grid o, per axis, over its bounding sphere
-    const float cx = L.bound[tid][0], cy = L.bound[tid][1], cz = L.bound[tid][2], br = L.bound[tid][3];
-    const float inv_pitch = 1.0f / pitch;
-    float dmax = 0.0f;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const float e0 = Rt[3 * d] - L.Rtp[tid][3 * d], e1 = Rt[3 * d + 1] - L.Rtp[tid][3 * d + 1],
-                  e2 = Rt[3 * d + 2] - L.Rtp[tid][3 * d + 2];
-      const float dt = Rt[9 + d] - L.Rtp[tid][9 + d];
-      const float mv = fabsf(((e0 * cx + e1 * cy) + e2 * cz) + dt) + sqrtf((e0 * e0 + e1 * e1) + e2 * e2) * fmaxf(br, 0.0f);
-      dmax = fmaxf(dmax, mv * inv_pitch);
-    }
-    // whole-object test of the bin duty: does object j (pose k) reach grid o at all? (margin included)
-    const float fh = (float)(h + mg);
-    const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
-    const float gx = (((Rt[0] * cx + Rt[1] * cy) + Rt[2] * cz) + Rt[9] - ox) * inv_pitch;
-    const float gy = (((Rt[3] * cx + Rt[4] * cy) + Rt[5] * cz) + Rt[10] - oy) * inv_pitch;
-    const float gz = (((Rt[6] * cx + Rt[7] * cy) + Rt[8] * cz) + Rt[11] - oz) * inv_pitch;
-    const float r = br * inv_pitch + 0.05f + 1e-4f * (fabsf(gx) + fabsf(gy) + fabsf(gz));
-    const bool hit = br >= 0.0f && !(gx + r < glo || gx - r > ghi || gy + r < glo || gy - r > ghi || gz + r < glo ||
-                                     gz - r > ghi);
-    // an object that moved too far (or whose pose is not finite) is re-read from the point array -- if it can
-    // reach this grid at all
-    const bool mvd = !(dmax <= kIterMoveMax) && br >= 0.0f;
-    if (hit) atomicOr(&L.hit, 1u << tid);
-    if (mvd && (hit || !(dmax == dmax))) atomicOr(&L.moved, 1u << tid);
-  }
-  if (designated && sp.mode != 0) {
-    // all lanes together: this object's accumulators, maxima and bin counters of the parity the launch after
-    // next adds into / fills
-    if (tid < 2) a.Mbits[(int64_t)ip.acc_z * 2 * a.O + 2 * o + tid] = 0;
-    long long *own = a.acc_own + ((int64_t)ip.acc_z * a.O + o) * kOwnSlots;
-    for (int i = tid; i < kOwnSlots; i += kTileThreads) own[i] = 0;
-    long long *oth = a.acc_oth + ((int64_t)ip.acc_z * a.O + o) * a.max_ns * 12;
-    for (int i = tid; i < a.max_ns * 12; i += kTileThreads) oth[i] = 0;
-    uint32_t *cz = a.bin_cnt + (int64_t)ip.bin_z * a.par_cnt + (int64_t)(2 * o) * nb;
-    for (int i = tid; i < 2 * nb; i += kTileThreads) cz[i] = 0u;
-  }
-  __syncthreads();  // C: poses, moved / hit masks
-
   const float trunc = a.thr * pitch;
   const float d2_hi = a.thr * a.thr * 1.00002f, d2_in = a.thr * a.thr * 0.999f;
   Tile3 tl;
@@ -2016,16 +1950,9 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStep
   const unsigned moved = L.moved, hitm = L.hit;
   const float fD = (float)D;
 
-  // model point of scene-local object jl -> voxel frame of grid o (the oracle's expressions: transform_points
-  // un-fused, (p - origin) / pitch correctly rounded) -> is it a record of THIS tile (plane x-1 .. x+1, rows of
-  // this half, inside the grid's reach)?  `pl` = its plane's offset.
-  auto classify = [&](const float mx, const float my, const float mz, const int jl, float &fx, float &fy, float &fz,
-                      int &pl) -> bool {
-    const float *R = L.Rt[jl];
-    const float wx = ((R[0] * mx + R[1] * my) + R[2] * mz) + R[9];
-    const float wy = ((R[3] * mx + R[4] * my) + R[5] * mz) + R[10];
-    const float wz = ((R[6] * mx + R[7] * my) + R[8] * mz) + R[11];
-    fx = (wx - ox) / pitch; fy = (wy - oy) / pitch; fz = (wz - oz) / pitch;
+  // voxel-frame coordinates (the oracle's (p - origin) / pitch, correctly rounded) -> is it a record of THIS tile
+  // (plane x-1 .. x+1, rows of this half, inside the grid's reach)?  `pl` = its plane's offset.
+  auto member = [&](const float fx, const float fy, const float fz, int &pl) -> bool {
     const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
     const float fh = (float)h;
     const bool surv = rx + fh >= 0.0f && rx - fh < fD && ry + fh >= 0.0f && ry - fh < fD && rz + fh >= 0.0f &&
@@ -2035,12 +1962,38 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStep
     const bool in_half = half == 0 ? (iry - h < Dh) : (iry + h >= Dh);
     return surv && pl >= 0 && pl < 3 && in_half;
   };
+  // model point of scene-local object jl -> numerators (world point - grid origin; transform_points un-fused,
+  // the oracle's expressions)
+  auto numer = [&](const float mx, const float my, const float mz, const int jl, float &nx, float &ny, float &nz) {
+    const float4 q0 = *reinterpret_cast<const float4 *>(&L.Rt[jl][0]);
+    const float4 q1 = *reinterpret_cast<const float4 *>(&L.Rt[jl][4]);
+    const float4 q2 = *reinterpret_cast<const float4 *>(&L.Rt[jl][8]);
+    nx = (((q0.x * mx + q0.y * my) + q0.z * mz) + q2.y) - ox;
+    ny = (((q0.w * mx + q1.x * my) + q1.y * mz) + q2.z) - oy;
+    nz = (((q1.z * mx + q1.w * my) + q2.x * mz) + q2.w) - oz;
+  };
+  auto classify = [&](const float mx, const float my, const float mz, const int jl, float &fx, float &fy, float &fz,
+                      int &pl) -> bool {
+    float nx, ny, nz;
+    numer(mx, my, mz, jl, nx, ny, nz);
+    fx = nx / pitch; fy = ny / pitch; fz = nz / pitch;
+    return member(fx, fy, fz, pl);
+  };
+  // cheap conservative form of the same test on reciprocal-multiplied coordinates (|error| < 1e-4 voxel): every
+  // member passes, the few extra near a boundary are dropped by the exact test in pass 1
+  const float xlo = (float)x - 1.5f - 1e-3f, xhi = (float)x + 1.5f + 1e-3f;
+  const float ylo = (half == 0 ? -1.5f : (float)Dh - 1.5f) - 1e-3f, yhi = (half == 0 ? (float)Dh + 0.5f : fD + 0.5f) + 1e-3f;
+  const float zlo = -1.5f - 1e-3f, zhi = fD + 0.5f + 1e-3f;
+  auto maybe_member = [&](const float nx, const float ny, const float nz) -> bool {
+    const float ax = nx * inv_pitch, ay = ny * inv_pitch, az = nz * inv_pitch;
+    return ax >= xlo && ax <= xhi && ay >= ylo && ay <= yhi && az >= zlo && az <= zhi;
+  };
   auto visit_word = [&](const int pass, const float fx, const float fy, const float fz, const uint32_t w) {
     const int kd = (int)(w >> 29) & 1;
     icc_visit3(pass, s_dist + kd * nvh, s_id + kd * nvh, tl, fx, fy, fz, w & 0x7ffffffu, (int)(w >> 27) & 3);
   };
 
-  // bin duty, stage A of trip 0: my point against grid o with pose k -> LDS counters
+  // bin duty, stage A: my point against grid o with this pose -> LDS counters
   int bbin[kHalves] = {-1, -1}, bslot[kHalves] = {0, 0};
   uint32_t bword = 0u;
   auto bin_count = [&](const float4 m, const int p) {
@@ -2049,11 +2002,9 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStep
     int jl = 0;
     for (int k = 1; k < Ns; ++k) jl += p >= L.off[k] ? 1 : 0;
     if (!((hitm >> jl) & 1u)) return;
-    const float *R = L.Rt[jl];
-    const float wx = ((R[0] * m.x + R[1] * m.y) + R[2] * m.z) + R[9];
-    const float wy = ((R[3] * m.x + R[4] * m.y) + R[5] * m.z) + R[10];
-    const float wz = ((R[6] * m.x + R[7] * m.y) + R[8] * m.z) + R[11];
-    const float fx = (wx - ox) / pitch, fy = (wy - oy) / pitch, fz = (wz - oz) / pitch;
+    float nx, ny, nz;
+    numer(m.x, m.y, m.z, jl, nx, ny, nz);
+    const float fx = nx / pitch, fy = ny / pitch, fz = nz / pitch;
     const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
     const int hh = h + mg;
     const float fh = (float)hh;
@@ -2102,11 +2053,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStep
     }
   };
 
+  bin_count(bm, p_lo + tid);  // (the record loads are in flight)
   // ---- 4. records -> survivors ----
   const bool slow_pre = nblk > kIterMaxBlk || moved != 0u;  // block-uniform
   if (!slow_pre) {
-    float sfx[kIterBlk], sfy[kIterBlk], sfz[kIterBlk];
-    uint32_t sw[kIterBlk];
     int npass = 0;
     unsigned long long bal[kIterBlk];
 #pragma unroll
@@ -2114,14 +2064,14 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStep
       bal[u] = 0ull;
       if (wave + u * (kTileThreads / 64) >= nblk) continue;  // wave-uniform
       bool ok = false;
-      int pl = 0;
-      sw[u] = 0u;
       if (rinfo[u] & 1u) {
         const uint32_t bits = __float_as_uint(rv[u].w);
-        ok = classify(rv[u].x, rv[u].y, rv[u].z, (int)(bits >> 27), sfx[u], sfy[u], sfz[u], pl);
-        sw[u] = (bits & 0x7ffffffu) | ((uint32_t)pl << 27) | ((rinfo[u] >> 31) << 29);
+        float nx, ny, nz;
+        numer(rv[u].x, rv[u].y, rv[u].z, (int)(bits >> 27), nx, ny, nz);
+        ok = maybe_member(nx, ny, nz);
+        rv[u] = make_float4(nx, ny, nz, __uint_as_float((bits & 0x7ffffffu) | ((rinfo[u] >> 31) << 29)));
       }
-      if (!ok) sw[u] = 0xffffffffu;
+      rinfo[u] = ok ? 1u : 0u;
       bal[u] = __ballot(ok);
       npass += __popcll(bal[u]);
     }
@@ -2133,17 +2083,17 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStep
 #pragma unroll
       for (int u = 0; u < kIterBlk; ++u) {
         if (bal[u] == 0ull) continue;
-        if (sw[u] != 0xffffffffu) {
+        if (rinfo[u]) {
           const int slot = run + __popcll(bal[u] & ((1ull << lane) - 1ull));
-          if (slot < surv_cap) s_surv[slot] = make_float4(sfx[u], sfy[u], sfz[u], __uint_as_float(sw[u]));
+          if (slot < surv_cap) s_surv[slot] = rv[u];
           else L.ovf = 1;
         }
         run += __popcll(bal[u]);
       }
     }
   }
-  bin_count(bm, p_lo + tid);
   __syncthreads();  // D: survivor list, LDS bin counters
+  stamp(4);
   const bool slow = slow_pre || L.ovf != 0;  // block-uniform
   // streaming form (rare): every source record again for each pass, visited under its membership predicate --
   // bins first (records of moved objects skipped), then the points of the moved objects themselves
@@ -2189,21 +2139,41 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStep
   } else {
     for (int i = tid; i < nlist; i += kTileThreads) {
       const float4 e = s_surv[i];
-      visit_word(1, e.x, e.y, e.z, __float_as_uint(e.w));
+      const uint32_t w0 = __float_as_uint(e.w);
+      const float fx = e.x / pitch, fy = e.y / pitch, fz = e.z / pitch;  // the exact coordinates
+      int pl;
+      if (member(fx, fy, fz, pl)) {
+        const uint32_t w = w0 | ((uint32_t)pl << 27);
+        s_surv[i] = make_float4(fx, fy, fz, __uint_as_float(w));
+        visit_word(1, fx, fy, fz, w);
+      } else {
+        s_surv[i].w = __uint_as_float(0xffffffffu);  // passed the cheap test only
+      }
     }
   }
   if (tid < 2 * kIterBins) L.bbase[tid] = rbase;
   __syncthreads();  // E: pass 1, bin bases
+  stamp(5);
   if (slow) {
     stream_pass(2);
   } else {
     for (int i = tid; i < nlist; i += kTileThreads) {
       const float4 e = s_surv[i];
-      visit_word(2, e.x, e.y, e.z, __float_as_uint(e.w));
+      const uint32_t w = __float_as_uint(e.w);
+      if (w != 0xffffffffu) visit_word(2, e.x, e.y, e.z, w);
     }
   }
   bin_store(bm);
   __syncthreads();  // F: pass 2; the survivor list is dead, its memory becomes the voxel phase's
+  stamp(6);
+  if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) {
+    g_dbg_stamps[(2048 + wg) * 8 + 0] = (unsigned long long)nblk;
+    g_dbg_stamps[(2048 + wg) * 8 + 1] = (unsigned long long)nlist;
+    g_dbg_stamps[(2048 + wg) * 8 + 2] = (unsigned long long)(slow ? 1 : 0);
+    int nb_t = 0;
+    for (int i = 0; i < 2 * kIterBins; ++i) nb_t += L.bcnt[i] > 0 ? 1 : 0;
+    g_dbg_stamps[(2048 + wg) * 8 + 3] = (unsigned long long)nb_t;
+  }
   for (int i = tid; i < Ns * (kTileThreads / 16) * 13; i += kTileThreads) s_rows2[i] = 0.0f;
   for (int i = tid; i < (kTileThreads / 16) * (kNumF + 1); i += kTileThreads) (&Vx.rows[0][0])[i] = 0.0f;
   // further trips of the bin duty (scenes of more than 64 x 512 points): the same three stages, serially
@@ -2225,6 +2195,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStep
   tg_.o = o; tg_.ja = ja; tg_.Ns = Ns; tg_.x = x; tg_.y0 = y0; tg_.nvox = nvox; tg_.nvh = nvh; tg_.Wp = Wp; tg_.D = D;
   tg_.K = K; tg_.pitch = pitch; tg_.trunc = trunc; tg_.ox = ox; tg_.oy = oy; tg_.oz = oz;
   icc_voxel_phase(a, ip.acc_w, tg_, ne0, tg0, s_dist, s_id, s_rows2, Vx, L.Rt, L.off, [](int) {});
+  stamp(7);
 }
 
 // ---- the step as a kernel of its own: one 64-lane workgroup per object ----------------
@@ -2246,6 +2217,18 @@ __global__ __launch_bounds__(64) void k_icc_step(IccArgs a, IccStepArgs sp) {
     icc_step_gather_fused<64>(a, sp.par, j, ja, Ns, s_raw, s_sum);
   else
     icc_step_gather<64>(a, sp.par, j, ja, Ns, s_raw, s_sum);
+  if (sp.zero_acc1 > 0) {
+    const int pz = sp.zero_acc1 - 1;
+    if (threadIdx.x < 2) a.Mbits[(int64_t)pz * 2 * a.O + 2 * j + threadIdx.x] = 0;
+    long long *own = a.acc_own + ((int64_t)pz * a.O + j) * kOwnSlots;
+    for (int i = threadIdx.x; i < kOwnSlots; i += 64) own[i] = 0;
+    long long *oth = a.acc_oth + ((int64_t)pz * a.O + j) * a.max_ns * 12;
+    for (int i = threadIdx.x; i < a.max_ns * 12; i += 64) oth[i] = 0;
+  }
+  if (sp.zero_bin1 > 0) {
+    uint32_t *cz = a.bin_cnt + (int64_t)(sp.zero_bin1 - 1) * a.par_cnt + (int64_t)(2 * j) * a.nbins;
+    for (int i = threadIdx.x; i < 2 * a.nbins; i += 64) cz[i] = 0u;
+  }
   if (threadIdx.x != 0) return;
   float Rt[12], st_new[kStateFloats], loss, gq[4], gt[3];
   icc_step_apply(s_sum, S_t, s_state, sp, Rt, st_new, loss, gq, gt);
@@ -2258,7 +2241,12 @@ __global__ __launch_bounds__(64) void k_icc_step(IccArgs a, IccStepArgs sp) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) { sp.m_out[7 * j + i] = st_new[7 + i]; sp.v_out[7 * j + i] = st_new[14 + i]; }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) a.Rt[12 * j + i] = Rt[i];
+    for (int i = 0; i < 12; ++i) a.Rt[((int64_t)sp.rt_w * a.O + j) * 12 + i] = Rt[i];
+    if (sp.traj) {
+      float *tr = sp.traj + ((int64_t)sp.it * a.O + j) * 7;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) tr[i] = st_new[i];
+    }
   } else if (sp.gq_out) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) sp.gq_out[4 * j + i] = gq[i];
@@ -2426,16 +2414,24 @@ void launch_iter_prebin(IccArgs a, hipStream_t stream) {
   hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, sp);
 }
 
-// Iteration k as ONE launch: [step k - 1 (k > 0)] -> tiles on the bins of k - 1 -> bins for k + 1.
-void launch_iter(IccArgs a, const IccStepArgs &sp, int k, hipStream_t stream) {
+// Iteration k: [k_icc_step: step k (k > 0), one small workgroup per object] -> k_icc_iter: tiles on the bins of
+// k - 1, bins for k + 1.
+void launch_iter(IccArgs a, IccStepArgs sp, int k, hipStream_t stream) {
   a.mg = 1;
   a.rec_model = 1;
+  if (k > 0) {
+    sp.fused = 1;
+    sp.rt_w = k & 1;
+    sp.zero_acc1 = (k + 1) % 3 + 1;
+    sp.zero_bin1 = (k + 2) % 3 + 1;
+    hipLaunchKernelGGL(k_icc_step, dim3(a.O), dim3(64), 0, stream, a, sp);
+  }
   IterPar ip;
-  ip.acc_r = (k + 2) % 3; ip.acc_w = k % 3; ip.acc_z = (k + 1) % 3;
-  ip.bin_r = k % 3; ip.bin_w = (k + 1) % 3; ip.bin_z = (k + 2) % 3;
+  ip.acc_w = k % 3;
+  ip.bin_r = k % 3; ip.bin_w = (k + 1) % 3;
   ip.rec_r = k & 1; ip.rec_w = (k + 1) & 1;
   ip.rt_r = (k + 1) & 1; ip.rt_w = k & 1;
-  hipLaunchKernelGGL(k_icc_iter, dim3(a.D * kHalves, a.O), dim3(kTileThreads), iter_lds_bytes(a), stream, a, sp, ip);
+  hipLaunchKernelGGL(k_icc_iter, dim3(a.D * kHalves, a.O), dim3(kTileThreads), iter_lds_bytes(a), stream, a, ip);
 }
 
 // chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once

@@ -173,7 +173,7 @@ def test_icc_compact_bins_overflow_list_gives_the_same_bits(scene8, monkeypatch,
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     if sizes[0] is not None:
-        assert sizes[0] < 60e6, sizes
+        assert sizes[0] < 100e6, sizes  # (round 5: two record buffers + margin planes for k_icc_iter; round 2: 242 MB)
 
 
 def test_icc_multi_scene_batch_equals_single_scenes(fixtures3):
