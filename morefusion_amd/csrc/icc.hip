@@ -402,10 +402,13 @@ __device__ __forceinline__ float fused_sum(const int l, const int Ns, const int 
   auto b_of = [&](int jo) { return sA[8 * jo + 7]; };
   float r = 0.0f;
   if (l == 0) {  // RN
+#pragma unroll 8
     for (int jo = 0; jo < Ns; ++jo) r += sA[8 * jo + 0] - a_of(jo) * sA[8 * jo + 1];
   } else if (l == 1) {  // S_in
+#pragma unroll 8
     for (int jo = 0; jo < Ns; ++jo) r += a_of(jo) * sA[8 * jo + 2];
   } else if (l == 2) {  // PN
+#pragma unroll 8
     for (int jo = 0; jo < Ns; ++jo) r += a_of(jo) * (sA[8 * jo + 3] + b_of(jo) * sA[8 * jo + 4]);
   } else if (l < 15) {  // reward moments
     const int c = l - 3;
@@ -416,8 +419,10 @@ __device__ __forceinline__ float fused_sum(const int l, const int Ns, const int 
   } else if (l < 39) {  // penalty denominator moments
     r = a_of(jj) * sC[48 + (l - 27)];
   } else if (l < 51) {  // collision moments of every grid of the scene onto j
+#pragma unroll 8
     for (int jo = 0; jo < Ns; ++jo) r += (a_of(jo) * b_of(jo)) * sB[12 * jo + (l - 39)];
   } else {
+#pragma unroll 8
     for (int jo = 0; jo < Ns; ++jo) r = sA[8 * jo + 5] != 0.0f ? 1.0f : r;
   }
   return r;
@@ -448,7 +453,15 @@ __device__ __forceinline__ void icc_step_gather_fused(const IccArgs &a, int par,
     if (i < n_items) s_f[i] = fv;
   }
   __syncthreads();
-  if (threadIdx.x < kStepSums) s_sum[threadIdx.x] = fused_sum((int)threadIdx.x, Ns, j - ja, s_f, s_f + 8 * Ns, s_f + 20 * Ns);
+  if constexpr (NT >= 256) {
+    // the three scene sums are loops over the scene's objects: one wave each, the other 49 sums on a fourth (as 52
+    // lanes of one wave the loops ran one after the other)
+    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int l = w < 3 ? (ln == 0 ? w : -1) : (w == 3 && ln < kStepSums - 3 ? 3 + ln : -1);
+    if (l >= 0) s_sum[l] = fused_sum(l, Ns, j - ja, s_f, s_f + 8 * Ns, s_f + 20 * Ns);
+  } else {
+    if (threadIdx.x < kStepSums) s_sum[threadIdx.x] = fused_sum((int)threadIdx.x, Ns, j - ja, s_f, s_f + 8 * Ns, s_f + 20 * Ns);
+  }
   __syncthreads();
 }
 
@@ -506,10 +519,72 @@ __device__ __forceinline__ void icc_step_apply(const float *sv, float S_t, const
   for (int i = 0; i < 3; ++i) Rt_out[9 + i] = tt[i];
 }
 
+// The same step spread over the 16 lanes `c` of a lane group (one object per group): the twelve gradient
+// components, the seven Adam updates and the rotation are evaluated by different lanes with the expressions of
+// icc_step_apply -> the same bits, a third of its dependent instruction chain (one lane's chain was 1.5 us of
+// every iteration).  xg: kStepLaneWords floats of LDS scratch owned by the group; the state after the step is left
+// in xg[12 ..] (q, t, m, v); every lane returns R|t and the loss, and the gradients in (gq, gt).
+// Call from wave-uniform control flow (contains wave-level LDS hand-overs).
+constexpr int kStepLaneWords = 12 + kStateFloats;
+__device__ __forceinline__ void icc_step_lanes(const float *sv, float S_t, const float *st, const IccStepArgs &sp,
+                                               const int c, float *xg, float *Rt_out, float &loss, float *gq,
+                                               float *gt) {
+  const float RN = sv[0], S_in = sv[1], PN = sv[2];
+  const float reward = RN / S_t, penalty = PN / S_in;
+  loss = sv[51] != 0.0f ? __builtin_nanf("") : penalty - reward;
+  const float c0 = 1.0f / S_t, c1 = 1.0f / S_in, c2 = PN / (S_in * S_in);
+  if (c < 12) xg[c] = ((c0 * sv[3 + c] - c1 * sv[15 + c]) + c2 * sv[27 + c]) - c1 * sv[39 + c];
+  __builtin_amdgcn_wave_barrier();
+  float gR[9];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const float G = xg[4 * d + cc];
+      if (cc < 3) gR[3 * d + cc] = G; else gt[d] = G;
+    }
+  float qq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qq[i] = st[i];
+  quat_backward(qq, gR, gq);
+  if (sv[51] != 0.0f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gq[i] = loss;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gt[i] = loss;
+  }
+  float *so = xg + 12;
+  if (c < 7) {
+    float th = st[c];
+    if (sp.mode == 1) {
+      // chainer.optimizers.Adam (v7) update rule in float32, parameter c
+      const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-8f;
+      const float gi = c == 0 ? gq[0] : c == 1 ? gq[1] : c == 2 ? gq[2] : c == 3 ? gq[3] : c == 4 ? gt[0] : c == 5 ? gt[1] : gt[2];
+      float mm = st[7 + c], vv = st[14 + c];
+      mm += omb1 * (gi - mm);
+      vv += omb2 * (gi * gi - vv);
+      so[7 + c] = mm;
+      so[14 + c] = vv;
+      const float upd = (c < 4 ? sp.aq : sp.at) * mm / (sqrtf(vv) + eps);
+      th -= upd;
+    }
+    so[c] = th;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float qn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qn[i] = so[i];
+  quat_to_R(qn, Rt_out);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Rt_out[9 + i] = so[4 + i];
+}
+
 // launch 1: one workgroup per (target grid, source object, chunk of <= 1024 points)
 __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs sp) {
   __shared__ int s_cnt[kMaxBins], s_base[kMaxBins];
   __shared__ float s_sum[kStepSums], s_state[kStateFloats];
+  __shared__ __attribute__((aligned(16))) float s_Rt12[16];
+  __shared__ float s_x[kStepLaneWords];
   __shared__ long long s_raw[kStepRawWords];
   auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
     if (MF_DBG(a, 32) && threadIdx.x == 0 && blockIdx.x < 1024)
@@ -559,13 +634,28 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
     else
       icc_step_gather<kBinThreads>(a, sp.par, j, e2.x, e2.y, s_raw, s_sum);
     stamp(4);
-    // every lane evaluates the same step from LDS (broadcast reads): no further barrier
-    float Rt[12], st_new[kStateFloats], loss, gq[4], gt[3];
-    icc_step_apply(s_sum, S_t, s_state, sp, Rt, st_new, loss, gq, gt);
+    // The step on the first 16 lanes (icc_step_lanes: gradient components, Adam updates and rotation on different
+    // lanes), R|t to the others through LDS.  (Rounds 2-4: every lane of every wave evaluated the serial step --
+    // 850 dependent instructions, 1.5 us of the critical path and of every SIMD's issue time.)
+    if (threadIdx.x < 16) {
+      float Rt[12], loss, gq[4], gt[3];
+      icc_step_lanes(s_sum, S_t, s_state, sp, (int)threadIdx.x, s_x, Rt, loss, gq, gt);
+      if (threadIdx.x < 12) {
+        float rv = Rt[0];
+#pragma unroll
+        for (int i = 1; i < 12; ++i) rv = (int)threadIdx.x == i ? Rt[i] : rv;
+        s_Rt12[threadIdx.x] = rv;
+      }
+      if (threadIdx.x == 0) s_Rt12[12] = loss;
+    }
+    __syncthreads();
     stamp(5);
-    r0 = make_float4(Rt[0], Rt[1], Rt[2], Rt[3]);
-    r1 = make_float4(Rt[4], Rt[5], Rt[6], Rt[7]);
-    r2 = make_float4(Rt[8], Rt[9], Rt[10], Rt[11]);
+    r0 = *reinterpret_cast<const float4 *>(&s_Rt12[0]);
+    r1 = *reinterpret_cast<const float4 *>(&s_Rt12[4]);
+    r2 = *reinterpret_cast<const float4 *>(&s_Rt12[8]);
+    const float *st_new = s_x + 12;
+    const float loss = s_Rt12[12];
+    const float Rt[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
     if (e2.w != 0 && threadIdx.x == 0) {  // the designated workgroup of object j stores the step
 #pragma unroll
       for (int i = 0; i < 4; ++i) sp.q_out[4 * j + i] = st_new[i];
@@ -1728,10 +1818,14 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_fused(IccArgs a, int pa
 // bins need not be built from the CURRENT pose: a tile of iteration k reads the bins that iteration k - 1 built from
 // pose k - 1 -- with one plane / row of margin -- and transforms the records (MODEL points) with pose k itself; the
 // same launch bins pose k for iteration k + 1.  Per workgroup = (object o, x-plane, y-half), 512 lanes:
-//   1. ONE round trip: this iteration's and the previous R|t of every scene object (written by k_icc_step, one
-//      small workgroup per object between the iterations: the step is computed ONCE -- the first version of this
-//      kernel recomputed it in every workgroup and spent 10 us of instruction issue on it), the bin counters of
-//      planes x-2 .. x+2 of both grids, its slice of the scene's points (bin duty).
+//   1. ONE round trip: the reduced sums / maxima / optimiser state of EVERY object of the scene (all lanes fetch and
+//      convert; the index arithmetic is multiplications by reciprocals), the previous R|t, its slice of the scene's
+//      points (bin duty); the LAST wave reads the bin counters of planes x-2 .. x+2 of both grids and cuts them
+//      into 64-record blocks meanwhile.  Then the sums (lane = (sum, object): a wave takes one branch) and the step
+//      of every scene object on 16 lanes each (icc_step_lanes; Ns / 4 waves -- the first version ran the
+//      serial step and a divergent gather in all eight waves of all 512 workgroups: 10 us of instruction issue).
+//      The workgroup (o, 0, 0) stores object o's state / R|t / trajectory row / loss and empties the parity after
+//      next.  The record loads are in flight meanwhile.
 //   2. how far did each object move since the bins were built?  (|dR c + dt| + |dR| r) / pitch per axis over its
 //      bounding sphere: < 1 voxel -> its records are in the margin bins for certain (rounded coordinates move by
 //      at most one).  Otherwise (rare: the first iterations, a gradient spike) the object's points are read from the
@@ -1758,13 +1852,16 @@ constexpr int kIterSegs = 12;                                 // per grid kind: 
 constexpr float kIterMoveMax = MF_ITER_MOVE_MAX;
 
 struct IterPar {
-  int acc_w;         // accumulators / maxima the tiles add into (the step kernels read and empty the others)
-  int bin_r, bin_w;  // bin counters: read by the tiles, filled by the bin duty
+  int acc_r, acc_w, acc_z;  // accumulators / maxima: read by the step, added into by the tiles, emptied
+  int bin_r, bin_w, bin_z;  // bin counters: read by the tiles, filled by the bin duty, emptied
   int rec_r, rec_w;  // record buffers
   int rt_r, rt_w;    // R|t copies: the pose the read bins were built from / this iteration's pose
 };
 
 struct IterLds {
+  float sum[kIterMaxNs][kStepSums];
+  float state[kIterMaxNs][kStateFloats];
+  float xg[kIterMaxNs][kStepLaneWords];
   float Rt[kIterMaxNs][12];
   int off[kIterMaxNs + 1];
   uint2 blk[kIterMaxBlk];  // {first record (index into the read buffer), records | grid kind << 31}
@@ -1773,17 +1870,22 @@ struct IterLds {
   unsigned moved, hit;
 };
 
-// dynamic LDS of k_icc_iter: [dist | id: 4 nvh words][union: survivor list | VoxLds + rows2]
+// dynamic LDS of k_icc_iter: [dist | id: 4 nvh words][union: staged step words | survivor list | VoxLds + rows2]
 __host__ __device__ inline size_t iter_union_bytes(int max_ns) {
   return sizeof(VoxLds) + (size_t)max_ns * (kTileThreads / 16) * 13 * sizeof(float);
 }
 
-__global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IterPar ip) {
+__global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStepArgs sp, IterPar ip) {
+  mf::warm_kernargs((int)(sizeof(IccArgs) + sizeof(IccStepArgs) + sizeof(IterPar)) + 16);
   MF_DYN_LDS(uint32_t, s_dyn);
   __shared__ IterLds L;
   constexpr int h = 1, K = 27;
   const int D = a.D, nb = a.nbins, V = D * D * D, nbr = nb - 1;
-  const int o = blockIdx.y, tile = blockIdx.x;
+  // Workgroups w and w + 256 share a CU (512 resident workgroups, dispatched round-robin over the XCDs and their
+  // CUs): rotating the planes by D / 2 in every other block of 256 puts a central (crowded) plane next to an outer
+  // (empty) one instead of next to the central plane of another object.
+  const int o = blockIdx.y;
+  const int tile = (int)((blockIdx.x + (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1u) * (gridDim.x / 2)) % gridDim.x);
   const int x = tile / kHalves, half = tile % kHalves;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Dh = (D + 1) / 2;
@@ -1798,25 +1900,30 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IterPar
   // survivor list: pushed as {wx - ox, wy - oy, wz - oz, id | kind << 29} (numerators of the voxel-frame
   // coordinates); pass 1 divides exactly, tests membership and rewrites {fx, fy, fz, id | plane << 27 | kind << 29}
   float4 *s_surv = reinterpret_cast<float4 *>(s_un);
+  float *s_f = reinterpret_cast<float *>(s_un);  // staged accumulator words of the step (dead before the list is filled)
 #ifdef MF_ITER_SURV_CAP
   const int surv_cap = MF_ITER_SURV_CAP;
 #else
   const int surv_cap = (int)(iter_union_bytes(a.max_ns) / sizeof(float4));
 #endif
 
-  int ja, Ns;
+  int ja, Ns, sc;
   if (a.uniform_ns > 0) {
-    Ns = a.uniform_ns; ja = (o / Ns) * Ns;
+    Ns = a.uniform_ns; sc = o / Ns; ja = sc * Ns;
   } else {
     const int4 meta = a.meta[o];
-    ja = meta.x; Ns = meta.y - meta.x;
+    ja = meta.x; Ns = meta.y - meta.x; sc = a.obj_scene[o];
   }
   const int jj_o = o - ja;
+  const bool designated = tile == 0;  // stores object o's step and empties its words of the parity after next
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
   auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32): [wg][0..7] times, [2048 + wg][0..7] counts
     if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
   };
   stamp(0);
+  auto sub = [&](int i) {  // finer stamps of the first phases: [1024 + wg][i], by the calling wave's first lane
+    if (MF_DBG(a, 32) && (threadIdx.x & 63) == 0 && wg < 1024) g_dbg_stamps[(1024 + wg) * 8 + i] = wall_clock64();
+  };
 
   // ---- 1. everything that depends on (o, tile) and the tables only: one round trip ----
   const float pitch = a.pitch[o];
@@ -1829,9 +1936,114 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IterPar
     tg0 = a.grid_target[gv];
   }
   if (tid >= 64 && tid <= 64 + Ns) L.off[tid - 64] = a.obj_off[ja + tid - 64];
-  if (wave == 0) {
-    // block table of this tile's records: the 12 segment sizes (planes x-2 .. x+2 and the overflow list of the own
-    // and the other grid) cut into 64-record blocks
+  // movement / reach of scene object jl under this iteration's pose Rt (vs the pose Rq the read bins were built
+  // from): how far can a point of it have moved, in voxels of grid o, per axis, over its bounding sphere; does the
+  // object reach grid o at all (margin included)?
+  auto reach = [&](const float *Rt, const float *Rq, const float4 bnd, bool &hit, bool &mvd) {
+    const float cx = bnd.x, cy = bnd.y, cz = bnd.z, br = bnd.w;
+    float dmax = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float e0 = Rt[3 * d] - Rq[3 * d], e1 = Rt[3 * d + 1] - Rq[3 * d + 1], e2 = Rt[3 * d + 2] - Rq[3 * d + 2];
+      const float dt = Rt[9 + d] - Rq[9 + d];
+      const float mv = fabsf(((e0 * cx + e1 * cy) + e2 * cz) + dt) + sqrtf((e0 * e0 + e1 * e1) + e2 * e2) * fmaxf(br, 0.0f);
+      dmax = fmaxf(dmax, mv * inv_pitch);
+    }
+    const float fh = (float)(h + mg);
+    const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
+    const float gx = (((Rt[0] * cx + Rt[1] * cy) + Rt[2] * cz) + Rt[9] - ox) * inv_pitch;
+    const float gy = (((Rt[3] * cx + Rt[4] * cy) + Rt[5] * cz) + Rt[10] - oy) * inv_pitch;
+    const float gz = (((Rt[6] * cx + Rt[7] * cy) + Rt[8] * cz) + Rt[11] - oz) * inv_pitch;
+    const float r = br * inv_pitch + 0.05f + 1e-4f * (fabsf(gx) + fabsf(gy) + fabsf(gz));
+    hit = br >= 0.0f && !(gx + r < glo || gx - r > ghi || gy + r < glo || gy - r > ghi || gz + r < glo || gz - r > ghi);
+    // an object that moved too far (or whose pose is not finite) is re-read from the point array -- if it can
+    // reach this grid at all
+    mvd = !(dmax <= kIterMoveMax) && br >= 0.0f && (hit || !(dmax == dmax));
+  };
+  // the pose the read bins were built from and the bounding sphere: lane 16 jj of the step groups (mode 1) /
+  // lane jj (mode 0: no step, this iteration's pose is in memory too)
+  const bool pose_lane = sp.mode != 0 ? (tid < 16 * Ns && (tid & 15) == 0) : tid < Ns;
+  const int pose_jj = sp.mode != 0 ? tid >> 4 : tid;
+  float Rq[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float4 bnd = make_float4(0, 0, 0, -1.0f);
+  if (pose_lane) {
+    const float4 *Rp = reinterpret_cast<const float4 *>(a.Rt + ((int64_t)ip.rt_r * a.O + ja + pose_jj) * 12);
+    const float4 p0 = Rp[0], p1 = Rp[1], p2 = Rp[2];
+    bnd = *reinterpret_cast<const float4 *>(a.bound + 4 * (ja + pose_jj));
+    Rq[0] = p0.x; Rq[1] = p0.y; Rq[2] = p0.z; Rq[3] = p0.w; Rq[4] = p1.x; Rq[5] = p1.y; Rq[6] = p1.z; Rq[7] = p1.w;
+    Rq[8] = p2.x; Rq[9] = p2.y; Rq[10] = p2.z; Rq[11] = p2.w;
+  }
+  const float S_t = sp.mode != 0 ? a.St[sc] : 1.0f;
+  const float invNs = 1.0f / (float)Ns;
+  const int nA = 8 * Ns, nB = 12 * Ns * Ns, nf = nA + nB + 60 * Ns;
+  if (tid == 0) { L.nlist = 0; L.ovf = 0; L.moved = 0u; L.hit = 0u; }
+  if (sp.mode != 0) {
+    // the reduced sums / maxima of the previous iteration for EVERY object of the scene (the step of each is
+    // needed: their points are the "other" records), every word converted by the lane that fetched it
+    const long long *own = a.acc_own + (int64_t)ip.acc_r * a.O * kOwnSlots;
+    const long long *oth = a.acc_oth + (int64_t)ip.acc_r * a.O * a.max_ns * 12;
+    const uint32_t *Mb = a.Mbits + (int64_t)ip.acc_r * 2 * a.O;
+    // Four words per lane and trip, ONE unconditional 8-byte load each from a selected address (the maxima are
+    // 4-byte words: the aligned pair is loaded and the half selected): every load of a trip is in flight before the
+    // first conversion.  (Loads behind per-region branches were each preceded by a wait for the one before: three
+    // to twelve dependent memory round trips.)
+    constexpr int kG = 4;
+    const long long *Mb8 = reinterpret_cast<const long long *>(Mb);
+    for (int i0 = 0; i0 < nf; i0 += kG * kTileThreads) {
+      long long raw[kG];
+      int reg[kG];  // 0: fixed point 2^32, 1: 2^40, 2: non-finite flag, 3: 1/M_own, 4: 1/M_oth
+#pragma unroll
+      for (int u = 0; u < kG; ++u) {
+        const int i = min(i0 + u * kTileThreads + tid, nf - 1);
+        // region A: per scene object {5 sums, flag, M_own, M_oth}
+        const int objA = ja + (i >> 3), lA = i & 7;
+        const long long *pA = lA < 6 ? own + (int64_t)objA * kOwnSlots + (lA < 5 ? lA : kNumF) : Mb8 + objA;
+        // region B: [jj][jo][12] collision moments onto jj from the grid of jo
+        const int kB = max(i - nA, 0), rB = kB / 12, cB = kB - 12 * rB;
+        const int jjB = (int)(((float)rB + 0.5f) * invNs), joB = rB - jjB * Ns;
+        const long long *pB = oth + ((int64_t)(ja + joB) * a.max_ns + jjB) * 12 + cB;
+        // region C: the 60 own-gradient moments of jj
+        const int kC = max(i - nA - nB, 0), jjC = kC / 60;
+        const long long *pC = own + (int64_t)(ja + jjC) * kOwnSlots + 5 + (kC - 60 * jjC);
+        const long long *pp = i < nA ? pA : i < nA + nB ? pB : pC;
+        reg[u] = i < nA ? (lA < 5 ? 0 : lA == 5 ? 2 : lA - 3) : i < nA + nB ? 1 : 0;
+        raw[u] = *pp;
+      }
+#pragma unroll
+      for (int u = 0; u < kG; ++u) {
+        const int i = i0 + u * kTileThreads + tid;
+        // the conversions of fused_item_scene / _oth / _own
+        const float f0 = (float)((double)raw[u] * (1.0 / kFixOwn));
+        const float f1 = (float)((double)raw[u] * (1.0 / kFixOth));
+        const float f2 = raw[u] != 0 ? 1.0f : 0.0f;
+        const float M = __uint_as_float(reg[u] == 4 ? (uint32_t)((unsigned long long)raw[u] >> 32) : (uint32_t)raw[u]);
+        const float f3 = reg[u] == 3 ? 1.0f / M : ((Ns > 1 && M != 0.0f) ? 1.0f / M : 0.0f);
+        const float fv = reg[u] == 0 ? f0 : reg[u] == 1 ? f1 : reg[u] == 2 ? f2 : f3;
+        if (i < nf) s_f[i] = fv;
+      }
+    }
+    if (wave == 0) sub(0);
+    for (int i = tid; i < kStateFloats * Ns; i += kTileThreads) {
+      const int jj = i / kStateFloats, c = i - kStateFloats * jj, j = ja + jj;
+      L.state[jj][c] = c < 4 ? sp.q_in[4 * j + c] : c < 7 ? sp.t_in[3 * j + c - 4]
+                       : c < 14 ? sp.m_in[7 * j + c - 7] : sp.v_in[7 * j + c - 14];
+    }
+  } else if (pose_lane) {
+    const float4 *Rc = reinterpret_cast<const float4 *>(a.Rt + ((int64_t)ip.rt_w * a.O + ja + pose_jj) * 12);
+    const float4 c0 = Rc[0], c1 = Rc[1], c2 = Rc[2];
+    *reinterpret_cast<float4 *>(&L.Rt[pose_jj][0]) = c0;
+    *reinterpret_cast<float4 *>(&L.Rt[pose_jj][4]) = c1;
+    *reinterpret_cast<float4 *>(&L.Rt[pose_jj][8]) = c2;
+    const float Rt[12] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
+    bool hit, mvd;
+    reach(Rt, Rq, bnd, hit, mvd);
+    if (hit) atomicOr(&L.hit, 1u << pose_jj);
+    if (mvd) atomicOr(&L.moved, 1u << pose_jj);
+  }
+  if (wave == 0) sub(1);
+  if (wave == kTileThreads / 64 - 1) {
+    // block table of this tile's records (pose-independent, on the last wave while the first ones step): the 12
+    // segment sizes (planes x-2 .. x+2 and the overflow list of the own and the other grid) cut into 64-record blocks
     const uint32_t *cnt_r = a.bin_cnt + (int64_t)ip.bin_r * a.par_cnt;
     int n_s[kIterSegs];
     uint32_t r_s[kIterSegs];
@@ -1850,49 +2062,11 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IterPar
       n_s[kd * 6 + 5] = on ? min((int)cnt_r[(int64_t)g * nb + nbr], 2 * a.bin_pts[g]) : 0;
       r_s[kd * 6 + 5] = (uint32_t)(base + (int64_t)nbr * cap);
     }
-    // 2. this iteration's pose of scene object `lane` and 3. how far it moved since the bins were built
-    bool hit = false, mvd = false;
-    if (lane < Ns) {
-      const float4 *Rc = reinterpret_cast<const float4 *>(a.Rt + ((int64_t)ip.rt_w * a.O + ja + lane) * 12);
-      const float4 *Rp = reinterpret_cast<const float4 *>(a.Rt + ((int64_t)ip.rt_r * a.O + ja + lane) * 12);
-      const float4 c0 = Rc[0], c1 = Rc[1], c2 = Rc[2], p0 = Rp[0], p1 = Rp[1], p2 = Rp[2];
-      const float4 bnd = *reinterpret_cast<const float4 *>(a.bound + 4 * (ja + lane));
-      *reinterpret_cast<float4 *>(&L.Rt[lane][0]) = c0;
-      *reinterpret_cast<float4 *>(&L.Rt[lane][4]) = c1;
-      *reinterpret_cast<float4 *>(&L.Rt[lane][8]) = c2;
-      const float Rt[12] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
-      const float Rq[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
-      // movement bound of the object in voxels of grid o, per axis, over its bounding sphere
-      const float cx = bnd.x, cy = bnd.y, cz = bnd.z, br = bnd.w;
-      float dmax = 0.0f;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const float e0 = Rt[3 * d] - Rq[3 * d], e1 = Rt[3 * d + 1] - Rq[3 * d + 1], e2 = Rt[3 * d + 2] - Rq[3 * d + 2];
-        const float dt = Rt[9 + d] - Rq[9 + d];
-        const float mv = fabsf(((e0 * cx + e1 * cy) + e2 * cz) + dt) + sqrtf((e0 * e0 + e1 * e1) + e2 * e2) * fmaxf(br, 0.0f);
-        dmax = fmaxf(dmax, mv * inv_pitch);
-      }
-      // whole-object test: does the object (this pose) reach grid o at all? (margin included)
-      const float fh = (float)(h + mg);
-      const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
-      const float gx = (((Rt[0] * cx + Rt[1] * cy) + Rt[2] * cz) + Rt[9] - ox) * inv_pitch;
-      const float gy = (((Rt[3] * cx + Rt[4] * cy) + Rt[5] * cz) + Rt[10] - oy) * inv_pitch;
-      const float gz = (((Rt[6] * cx + Rt[7] * cy) + Rt[8] * cz) + Rt[11] - oz) * inv_pitch;
-      const float r = br * inv_pitch + 0.05f + 1e-4f * (fabsf(gx) + fabsf(gy) + fabsf(gz));
-      hit = br >= 0.0f && !(gx + r < glo || gx - r > ghi || gy + r < glo || gy - r > ghi || gz + r < glo || gz - r > ghi);
-      // an object that moved too far (or whose pose is not finite) is re-read from the point array -- if it can
-      // reach this grid at all
-      mvd = !(dmax <= kIterMoveMax) && br >= 0.0f && (hit || !(dmax == dmax));
-    }
-    const unsigned long long hb = __ballot(hit), mb = __ballot(mvd);
     int pb[kIterSegs + 1];
     pb[0] = 0;
 #pragma unroll
     for (int s = 0; s < kIterSegs; ++s) pb[s + 1] = pb[s] + (n_s[s] + 63) / 64;
-    if (lane == 0) {
-      L.nblk = pb[kIterSegs]; L.nlist = 0; L.ovf = 0;
-      L.moved = (unsigned)mb; L.hit = (unsigned)hb;
-    }
+    if (lane == 0) L.nblk = pb[kIterSegs];
     // lane b describes block b (a tile beyond kIterMaxBlk blocks takes the streaming path)
     for (int b = lane; b < min(pb[kIterSegs], kIterMaxBlk); b += 64) {
       int s = 0;
@@ -1909,9 +2083,11 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IterPar
       const int first = (b - ps) * 64;
       L.blk[b] = make_uint2(rs + (uint32_t)first, (uint32_t)min(64, ns - first) | (s >= 6 ? 0x80000000u : 0u));
     }
+    sub(2);
   }
   for (int i = tid; i < 2 * nvh; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
   for (int i = tid; i < 2 * kIterBins; i += kTileThreads) L.bcnt[i] = 0;
+  if (wave == 0) sub(3);
   __syncthreads();  // A: tables, poses, masks
   stamp(1);
 
@@ -1940,6 +2116,68 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IterPar
   const int ntrip = (slice + kTileThreads - 1) / kTileThreads;
   float4 bm = make_float4(0, 0, 0, 0);
   if (p_lo + tid < p_hi) bm = a.pts4[p_lo + tid];
+  if (wave == 0) sub(4);
+
+  if (sp.mode != 0) {
+    // the kStepSums sums of every scene object, lane = (sum l, object jj) with l slowest: the lanes of a wave take
+    // the same branch of fused_sum
+    for (int i = tid; i < kStepSums * Ns; i += kTileThreads) {
+      const int l = (int)(((float)i + 0.5f) * invNs), jj = i - l * Ns;
+      L.sum[jj][l] = fused_sum(l, Ns, jj, s_f, s_f + nA + jj * 12 * Ns, s_f + nA + nB + 60 * jj);
+    }
+    if (wave == 0) sub(5);
+    __syncthreads();  // B: sums
+    stamp(2);
+    // ---- 2. the step of every scene object: 16 lanes each ----
+    if ((tid & ~63) < 16 * Ns) {  // wave-uniform
+      const int jj = min(tid >> 4, Ns - 1), c = tid & 15;
+      float Rt[12], loss, gq[4], gt[3];
+      icc_step_lanes(L.sum[jj], S_t, L.state[jj], sp, c, L.xg[jj], Rt, loss, gq, gt);
+      if (pose_lane) {
+        const int j = ja + jj;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) L.Rt[jj][i] = Rt[i];
+        bool hit, mvd;
+        reach(Rt, Rq, bnd, hit, mvd);
+        if (hit) atomicOr(&L.hit, 1u << jj);
+        if (mvd) atomicOr(&L.moved, 1u << jj);
+        if (designated && jj == jj_o) {
+          const float *st_new = L.xg[jj] + 12;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sp.q_out[4 * j + i] = st_new[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) sp.t_out[3 * j + i] = st_new[4 + i];
+#pragma unroll
+          for (int i = 0; i < 7; ++i) { sp.m_out[7 * j + i] = st_new[7 + i]; sp.v_out[7 * j + i] = st_new[14 + i]; }
+          float *Rw = a.Rt + ((int64_t)ip.rt_w * a.O + j) * 12;
+#pragma unroll
+          for (int i = 0; i < 12; ++i) Rw[i] = Rt[i];
+          if (sp.traj) {
+            float *tr = sp.traj + ((int64_t)sp.it * a.O + j) * 7;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) tr[i] = st_new[i];
+          }
+          if (sp.loss_out && j == ja) sp.loss_out[sc] = loss;
+        }
+      }
+    } else if (designated) {
+      // the other waves of the designated workgroup: this object's accumulators, maxima and bin counters of the
+      // parity the launch after next adds into / fills
+      const int z0 = (16 * Ns + 63) & ~63;  // first lane of the first wave without a step group
+      const int t2 = tid - z0, nt2 = kTileThreads - z0;
+      if (t2 >= 0) {
+        if (t2 < 2) a.Mbits[(int64_t)ip.acc_z * 2 * a.O + 2 * o + t2] = 0;
+        long long *own = a.acc_own + ((int64_t)ip.acc_z * a.O + o) * kOwnSlots;
+        for (int i = t2; i < kOwnSlots; i += nt2) own[i] = 0;
+        long long *oth = a.acc_oth + ((int64_t)ip.acc_z * a.O + o) * a.max_ns * 12;
+        for (int i = t2; i < a.max_ns * 12; i += nt2) oth[i] = 0;
+        uint32_t *cz = a.bin_cnt + (int64_t)ip.bin_z * a.par_cnt + (int64_t)(2 * o) * nb;
+        for (int i = t2; i < 2 * nb; i += nt2) cz[i] = 0u;
+      }
+    }
+    __syncthreads();  // C: poses, moved / hit masks
+    stamp(3);
+  }
 
   const float trunc = a.thr * pitch;
   const float d2_hi = a.thr * a.thr * 1.00002f, d2_in = a.thr * a.thr * 0.999f;
@@ -2004,7 +2242,9 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IterPar
     if (!((hitm >> jl) & 1u)) return;
     float nx, ny, nz;
     numer(m.x, m.y, m.z, jl, nx, ny, nz);
-    const float fx = nx / pitch, fy = ny / pitch, fz = nz / pitch;
+    // (reciprocal multiplies: a bin key that is one off at an exact .5 is inside what kIterMoveMax < 1 leaves of
+    // the margin; the readers test membership exactly)
+    const float fx = nx * inv_pitch, fy = ny * inv_pitch, fz = nz * inv_pitch;
     const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
     const int hh = h + mg;
     const float fh = (float)hh;
@@ -2229,9 +2469,13 @@ __global__ __launch_bounds__(64) void k_icc_step(IccArgs a, IccStepArgs sp) {
     uint32_t *cz = a.bin_cnt + (int64_t)(sp.zero_bin1 - 1) * a.par_cnt + (int64_t)(2 * j) * a.nbins;
     for (int i = threadIdx.x; i < 2 * a.nbins; i += 64) cz[i] = 0u;
   }
+  if (threadIdx.x >= 16) return;
+  __shared__ float s_x[kStepLaneWords];
+  float Rt[12], loss, gq[4], gt[3];
+  icc_step_lanes(s_sum, S_t, s_state, sp, (int)threadIdx.x, s_x, Rt, loss, gq, gt);
+  __builtin_amdgcn_wave_barrier();
   if (threadIdx.x != 0) return;
-  float Rt[12], st_new[kStateFloats], loss, gq[4], gt[3];
-  icc_step_apply(s_sum, S_t, s_state, sp, Rt, st_new, loss, gq, gt);
+  const float *st_new = s_x + 12;
   if (sp.loss_out && j == ja) sp.loss_out[sc] = loss;
   if (sp.mode == 1) {
 #pragma unroll
@@ -2394,9 +2638,10 @@ void launch_iteration(const IccArgs &a, IccStepArgs sp, int NB, int k, hipStream
 
 // One-launch iterations (k_icc_iter) apply to what every caller of the reference passes: {0,1} no-entry grids,
 // voxel_threshold 2 (kernel size 3 for every grid: (2 pitch) / pitch == 2 exactly), scenes of <= kIterMaxNs objects.
-// MF_ICC_TWO_LAUNCH=1 keeps the two-launch path (A/B measurements, bit-identity tests).
 bool icc_use_iter(const mfIccBatch *b, const IccArgs &a, const WsLayout &l) {
-  if (getenv("MF_ICC_TWO_LAUNCH") && atoi(getenv("MF_ICC_TWO_LAUNCH")) != 0) return false;
+  // opt-in (MF_ICC_ONE_LAUNCH=1): measured 23.3 - 27.7 us per iteration against 22-23 us of the two-launch path at
+  // 1 scene x 8 objects and 1.4x its time at 8 scenes -- see the comment above k_icc_iter and DESIGN.md 4
+  if (!(getenv("MF_ICC_ONE_LAUNCH") && atoi(getenv("MF_ICC_ONE_LAUNCH")) != 0)) return false;
   return a.ne_binary && b->voxel_threshold == 2.0f && b->max_scene_objects <= kIterMaxNs && b->dim <= 32 &&
          l.rec_n < ((int64_t)1 << 31);
 }
@@ -2414,24 +2659,17 @@ void launch_iter_prebin(IccArgs a, hipStream_t stream) {
   hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, sp);
 }
 
-// Iteration k: [k_icc_step: step k (k > 0), one small workgroup per object] -> k_icc_iter: tiles on the bins of
-// k - 1, bins for k + 1.
+// Iteration k as ONE launch: [step k (k > 0)] -> tiles on the bins of k - 1 -> bins for k + 1.
 void launch_iter(IccArgs a, IccStepArgs sp, int k, hipStream_t stream) {
   a.mg = 1;
   a.rec_model = 1;
-  if (k > 0) {
-    sp.fused = 1;
-    sp.rt_w = k & 1;
-    sp.zero_acc1 = (k + 1) % 3 + 1;
-    sp.zero_bin1 = (k + 2) % 3 + 1;
-    hipLaunchKernelGGL(k_icc_step, dim3(a.O), dim3(64), 0, stream, a, sp);
-  }
+  sp.fused = 1;
   IterPar ip;
-  ip.acc_w = k % 3;
-  ip.bin_r = k % 3; ip.bin_w = (k + 1) % 3;
+  ip.acc_r = (k + 2) % 3; ip.acc_w = k % 3; ip.acc_z = (k + 1) % 3;
+  ip.bin_r = k % 3; ip.bin_w = (k + 1) % 3; ip.bin_z = (k + 2) % 3;
   ip.rec_r = k & 1; ip.rec_w = (k + 1) & 1;
   ip.rt_r = (k + 1) & 1; ip.rt_w = k & 1;
-  hipLaunchKernelGGL(k_icc_iter, dim3(a.D * kHalves, a.O), dim3(kTileThreads), iter_lds_bytes(a), stream, a, ip);
+  hipLaunchKernelGGL(k_icc_iter, dim3(a.D * kHalves, a.O), dim3(kTileThreads), iter_lds_bytes(a), stream, a, sp, ip);
 }
 
 // chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once

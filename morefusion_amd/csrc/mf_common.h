@@ -80,6 +80,20 @@ __device__ __forceinline__ uint4 lds_read_tr16_b64x2(const unsigned char *p, int
   return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 
+// Touch every 64-byte line of the kernel-argument segment with ONE batch of scalar loads.  A kernel with a few hundred
+// bytes of by-value arguments and high SGPR pressure re-reads its arguments piecemeal (s_load ... s_waitcnt pairs
+// all through its prologue); the scalar cache is cold at kernel start, so each first touch of a line is a memory
+// round trip on the critical path -- after this they hit.  (tests/host_emul/mf_common.h: a no-op.)
+__device__ __forceinline__ void warm_kernargs(int bytes) {
+  typedef const uint32_t __attribute__((address_space(4))) *kptr_t;
+  kptr_t kp = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  uint32_t acc = 0;
+#pragma unroll
+  for (int off = 0; off < 1024; off += 64)
+    if (off < bytes) acc |= kp[off / 4];
+  asm volatile("" ::"s"(acc));
+}
+
 // dynamic LDS of the workgroup (tests/host_emul/mf_common.h gives the host-emulation form)
 #define MF_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 

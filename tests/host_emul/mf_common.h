@@ -496,6 +496,7 @@ inline uint4 buf_load16(const BufRsrc &b, uint32_t byte_off) {
   return v;
 }
 constexpr int kWave = 64;
+inline void warm_kernargs(int) {}
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline float voxel_coord(float p, float o, float pitch) { return (p - o) / pitch; }
 // same association as the DPP butterflies of csrc/mf_common.h

@@ -3,6 +3,7 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MF_ICC_DEBUG"] = "32"
+os.environ.setdefault("MF_LIBMFHIP", "libmfhip_dbg.so")
 import morefusion_amd as mf  # noqa: E402
 from bench import Workload, parse  # noqa: E402
 args = parse(); wl = Workload(args, 0, torch.device("cuda", 0))

@@ -29,6 +29,13 @@ print("WGs", nwg, "span", (st[:, 7].max() - t0) / 100.0, "us; start skew", (st[:
 for n, a, b in names:
     x = us(a, b); print(f"{n:16s} mean {x.mean():6.2f} p90 {np.percentile(x, 90):6.2f} max {x.max():6.2f}")
 print("end time after kernel start: mean %.2f p90 %.2f max %.2f" % (((st[:, 7] - t0) / 100.0).mean(), np.percentile((st[:, 7] - t0) / 100.0, 90), ((st[:, 7] - t0) / 100.0).max()))
+sb = buf.reshape(4096, 8)[1024:1024 + nwg].astype(np.int64)
+rel = lambda col: (sb[:, col] - st[:, 0]) / 100.0
+for nm, col in (("gather done", 0), ("state issued", 1), ("table done (last wave)", 2), ("zero fill done", 3)):
+    print(f"  since start: {nm:24s} mean {rel(col).mean():6.2f} max {rel(col).max():6.2f}")
+relA = lambda col: (sb[:, col] - st[:, 1]) / 100.0
+for nm, col in (("record loads issued", 4), ("sums done (wave 0)", 5)):
+    print(f"  since barrier A: {nm:20s} mean {relA(col).mean():6.2f} max {relA(col).max():6.2f}")
 tot = us(0, 7)
 for w in np.argsort(-tot)[:6]:
     print(f"wg {w:3d} obj {w // 64} plane {(w % 64) // 2:2d} half {w % 2} blocks {info[w,0]} surv {info[w,1]} slow {info[w,2]} bins {info[w,3]} start {(st[w,0]-t0)/100.0:5.2f} " +

@@ -12,7 +12,7 @@ for scenes in (1, 8):
     wl = Workload(args, 0, torch.device("cuda", 0))
     res = {}
     for two in (0, 1):
-        os.environ["MF_ICC_TWO_LAUNCH"] = str(two)
+        os.environ["MF_ICC_ONE_LAUNCH"] = str(1 - two)
 
         def run(n):
             wl.q.copy_(wl.q0); wl.t.copy_(wl.t0); wl.m.zero_(); wl.v.zero_()
