@@ -15,7 +15,7 @@ import sys
 import morefusion_amd as _impl
 
 for _m in pkgutil.walk_packages(_impl.__path__, prefix="morefusion_amd."):
-    if "csrc" not in _m.name and not _m.name.endswith("libmfhip"):  # (the C-ABI library is not a Python module)
+    if "csrc" not in _m.name and "libmfhip" not in _m.name.rsplit(".", 1)[-1]:  # (the C-ABI library is not a Python module)
         importlib.import_module(_m.name)
 for _name, _mod in list(sys.modules.items()):
     if _name == "morefusion_amd" or _name.startswith("morefusion_amd."):

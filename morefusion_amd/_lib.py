@@ -31,7 +31,7 @@ class IccBatch(ctypes.Structure):
         ("n_objects", ctypes.c_int32), ("n_scenes", ctypes.c_int32),
         ("n_points", ctypes.c_int32), ("dim", ctypes.c_int32),
         ("max_scene_objects", ctypes.c_int32),
-        ("voxel_threshold", _f), ("sdf_offset", _f), ("grid_ne_binary", ctypes.c_int32),
+        ("voxel_threshold", _f), ("sdf_offset", _f), ("grid_ne_binary", ctypes.c_int32), ("flags", ctypes.c_int32),
     ]
 
 

@@ -2532,8 +2532,9 @@ WsLayout ws_layout(const mfIccBatch *b) {
   const int O = b->n_objects, S = b->n_scenes, D = b->dim, max_ns = b->max_scene_objects;
   const int64_t V = (int64_t)D * D * D;
   l.NB = (int)((V + kVoxPerBlock - 1) / kVoxPerBlock);
-  // (+ 1 plane of margin per side: the bins of k_icc_iter) + the overflow counter
-  l.nbins = kHalves * (D + 2 * (ksize_host(b->voxel_threshold) / 2 + 1)) + 1;
+  // (+ 1 plane of margin per side for the bins of k_icc_iter) + the overflow counter
+  const int one = (b->flags & MF_ICC_FLAG_ONE_LAUNCH) ? 1 : 0;
+  l.nbins = kHalves * (D + 2 * (ksize_host(b->voxel_threshold) / 2 + one)) + 1;
   // every (target, source) pair of a scene in chunks of kBinChunk points:
   // sum_pairs ceil(P_j / chunk) <= max_ns * n_points / chunk + O * max_ns (+ O designated entries)
   l.n_tab = (int)(((int64_t)max_ns * b->n_points + kBinChunk - 1) / kBinChunk) + O * max_ns + O;
@@ -2561,7 +2562,7 @@ WsLayout ws_layout(const mfIccBatch *b) {
     const int64_t per_grid_extra = (force > 0 ? force : kBinMinCap) + 1;
     const int64_t binned = force > 0 ? 0 : sumP / kBinShare;
     l.rec_n = (int64_t)(l.nbins - 1) * (binned + 2 * O * per_grid_extra) + 2 * sumP;
-    l.rec = off; off = align256(off + 2 * l.rec_n * 16);  // two buffers: k_icc_iter reads one and fills the other
+    l.rec = off; off = align256(off + (1 + one) * l.rec_n * 16);  // k_icc_iter reads one buffer and fills the other
   }
   l.total = off;
   return l;
@@ -2639,9 +2640,10 @@ void launch_iteration(const IccArgs &a, IccStepArgs sp, int NB, int k, hipStream
 // One-launch iterations (k_icc_iter) apply to what every caller of the reference passes: {0,1} no-entry grids,
 // voxel_threshold 2 (kernel size 3 for every grid: (2 pitch) / pitch == 2 exactly), scenes of <= kIterMaxNs objects.
 bool icc_use_iter(const mfIccBatch *b, const IccArgs &a, const WsLayout &l) {
-  // opt-in (MF_ICC_ONE_LAUNCH=1): measured 23.3 - 27.7 us per iteration against 22-23 us of the two-launch path at
-  // 1 scene x 8 objects and 1.4x its time at 8 scenes -- see the comment above k_icc_iter and DESIGN.md 4
-  if (!(getenv("MF_ICC_ONE_LAUNCH") && atoi(getenv("MF_ICC_ONE_LAUNCH")) != 0)) return false;
+  // opt-in (mfIccBatch.flags: the workspace is sized for it): measured 23.3 - 27.7 us per iteration against 23 us
+  // of the two-launch path at 1 scene x 8 objects and 1.4x its time at 8 scenes -- see the comment above
+  // k_icc_iter and DESIGN.md 4
+  if (!(b->flags & MF_ICC_FLAG_ONE_LAUNCH)) return false;
   return a.ne_binary && b->voxel_threshold == 2.0f && b->max_scene_objects <= kIterMaxNs && b->dim <= 32 &&
          l.rec_n < ((int64_t)1 << 31);
 }

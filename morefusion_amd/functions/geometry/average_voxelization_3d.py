@@ -7,6 +7,7 @@ forward/backward kernels it launched (:42-118, :146-220) are replaced by
 import torch
 
 from ... import _lib
+from . import _cpu
 from .voxelization_3d import check_dimensions, check_inputs
 
 
@@ -62,7 +63,12 @@ def average_voxelization_3d(
     values, points, batch_indices, *, batch_size, origin, pitch, dimensions,
     return_counts=False, check_nan=True,
 ):
-    """``check_nan=False`` skips the reference's NaN validation (and its host sync)."""
+    """``check_nan=False`` skips the reference's NaN validation (and its host sync).  NumPy arrays / CPU tensors take
+    the product's CPU path (``_cpu.average_voxelization_3d`` = ``forward_cpu`` / ``backward_cpu``,
+    average_voxelization_3d.py:8-40,120-145: indices round half to even there), CUDA tensors the HIP kernels."""
+    if _cpu.is_cpu_input(values, points, batch_indices):
+        return _cpu.average_voxelization_3d(values, points, batch_indices, batch_size=batch_size, origin=origin,
+                                            pitch=pitch, dimensions=dimensions, return_counts=return_counts)
     voxel, counts = AverageVoxelization3D.apply(
         values, points, batch_indices, batch_size, origin, pitch, dimensions, check_nan)
     if return_counts:

@@ -2,11 +2,13 @@
 
 API of morefusion/functions/geometry/occupancy_grid_3d.py:77-85.  The reference
 materialises three [X,Y,Z,P] tensors; here a single fused min-over-points kernel
-(``mf_occupancy_grid_3d_{fwd,bwd}``, morefusion_amd/csrc/occgrid_knn.hip).
+(``mf_occupancy_grid_3d_{fwd,bwd}``, morefusion_amd/csrc/occgrid_knn.hip) for CUDA tensors, and the
+reference's own expressions in x-plane chunks for NumPy arrays / CPU tensors (``_cpu.py``).
 """
 import torch
 
 from ... import _lib
+from . import _cpu
 
 
 class OccupancyGrid3D(torch.autograd.Function):
@@ -44,4 +46,9 @@ class OccupancyGrid3D(torch.autograd.Function):
 
 
 def occupancy_grid_3d(points, *, pitch, origin, dims, threshold=1):
+    """Device chosen by the array type, like the reference's ``get_array_module`` (occupancy_grid_3d.py:32): a NumPy
+    array or a CPU tensor takes the product's CPU path (``_cpu.occupancy_grid_3d``: the reference's float32
+    expressions, BASELINE config 1), a CUDA tensor the fused HIP kernel."""
+    if _cpu.is_cpu_input(points):
+        return _cpu.occupancy_grid_3d(points, pitch=pitch, origin=origin, dims=dims, threshold=threshold)
     return OccupancyGrid3D.apply(points, pitch, origin, dims, threshold)

@@ -33,7 +33,7 @@ def test_icc_batch_struct_matches_header():
     body = text[text.index("typedef struct {"):text.index("} mfIccBatch;")]
     fields = re.findall(r"\b(\w+);", body)
     assert fields == [f[0] for f in mf._lib.IccBatch._fields_]
-    assert ctypes.sizeof(mf._lib.IccBatch) == 8 * 8 + 5 * 4 + 2 * 4 + 4
+    assert ctypes.sizeof(mf._lib.IccBatch) == 8 * 8 + 5 * 4 + 2 * 4 + 4 + 4 + 4  # (+ flags, + tail padding to 8)
 
 
 def test_workspace_size_is_host_only_arithmetic():
@@ -42,6 +42,9 @@ def test_workspace_size_is_host_only_arithmetic():
                                 n_points, 32, max_ns, thr, 0.0, 1)
     ws = mf._lib.lib().mf_icc_workspace_bytes
     n = ws(ctypes.byref(desc(8, 1, 28000, 8)))
+    one = desc(8, 1, 28000, 8)
+    one.flags = 1  # MF_ICC_FLAG_ONE_LAUNCH: a second record buffer and one more plane of bins per side
+    assert 1.9 * (n - 2 * 8 * 32 ** 3 * 8) < ws(ctypes.byref(one)) - 2 * 8 * 32 ** 3 * 8 < 2.3 * (n - 2 * 8 * 32 ** 3 * 8)
     # winners of 16 grids + compact bins: per grid 68 bins of max(64, P_g / 8) records + an overflow list of 2 P_g,
     # summed over the grids (sum_g P_g = Ns * P_scene) -- O(N * sum P), not nbins x that (round 2: 68 x 8 x 28000 x 16 B)
     sumP = 8 * 28000
@@ -58,17 +61,15 @@ def test_ops_refuse_cpu_tensors_loudly():
     v = torch.zeros(4, 2)
     p = torch.zeros(4, 3)
     b = torch.zeros(4, dtype=torch.int32)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        mf.functions.average_voxelization_3d(v, p, b, batch_size=1, origin=(0, 0, 0), pitch=1.0,
-                                             dimensions=(4, 4, 4))
+    # (round 5: average_voxelization_3d and occupancy_grid_3d dispatch NumPy arrays / CPU tensors to the product's own
+    # CPU path, like the reference's get_array_module -- tests/test_cpu_path.py; the GPU-only ops still refuse)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         mf.functions.interpolate_voxel_grid(torch.zeros(1, 1, 2, 2, 2), p, b)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         mf.functions.truncated_distance_function(p, pitch=1.0, origin=(0, 0, 0), dims=(4, 4, 4), truncation=2.0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
-        mf.functions.occupancy_grid_3d(p, pitch=1.0, origin=(0, 0, 0), dims=(4, 4, 4))
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
         mf.geometry.nn(p, p)
+    assert not mf.functions.occupancy_grid_3d(p, pitch=1.0, origin=(0, 0, 0), dims=(4, 4, 4)).is_cuda
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -275,8 +275,7 @@ def test_icc_one_launch_iteration_gives_the_bits_of_the_two_launch_path(fixtures
         monkeypatch.setenv("MF_ICC_BIN_CAP", "3")
 
     def run(lib, one):
-        monkeypatch.setenv("MF_ICC_ONE_LAUNCH", "1" if one else "0")
-        S = emul.EmulIccScenes(lib, [_dict(s) for s in scenes], sdf_offset=0.02)
+        S = emul.EmulIccScenes(lib, [_dict(s) for s in scenes], sdf_offset=0.02, one_launch=one)
         import ctypes
         assert lib.mf_icc_iteration_launches(ctypes.byref(S.desc)) == (1 if one else 2)
         q = np.concatenate([_pose0(s)[0] for s in scenes])
