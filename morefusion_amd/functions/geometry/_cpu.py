@@ -7,7 +7,8 @@ average_voxelization_3d.py:8-40).  The wrappers of this package do the same: a N
 tensor takes the implementations below -- float32 torch-CPU expressions in the order of the
 reference's NumPy code, so the results equal its CPU fork bit for bit (voxel indices round half to
 even like ``ndarray.round``; the GPU fork rounds half away) -- a CUDA tensor takes the HIP kernels.
-This module is part of the product: it does not import ``oracle/`` (tests/test_cabi.py enforces it).
+This module is part of the product and self-contained: the test-only CPU restatements of the repository are
+never imported from here (tests/test_cabi.py enforces it).
 """
 import numpy as np
 import torch
