@@ -124,9 +124,10 @@ def main():
     def device_inputs(inp):
         """The uploaded batch -> everything the device side of the step reads: the network inputs plus what the host
         decides (point selection: one synchronisation; CAD subsample + ADD-S flags: host RNG, model.py:207-220,411-414)."""
+        pix = model._select_points(inp["pcd"])  # first: the eager step draws the point subsample before the CAD one
         cad, sym = model.loss_prepare(inp["class_id"], device)
         assert torch.is_tensor(cad), "--graph needs CAD clouds of one size"
-        return dict(class_id=inp["class_id"], rgb=inp["rgb"], pcd=inp["pcd"], pix=model._select_points(inp["pcd"]),
+        return dict(class_id=inp["class_id"], rgb=inp["rgb"], pcd=inp["pcd"], pix=pix,
                     pitch=inp["pitch"].float(), origin=inp["origin"].float(),
                     grid_nontarget_empty=inp["grid_nontarget_empty"], quaternion_true=inp["quaternion_true"],
                     translation_true=inp["translation_true"], cad=cad, symmetric=sym)

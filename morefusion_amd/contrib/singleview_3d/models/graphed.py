@@ -28,7 +28,16 @@ class GraphedPredict:
         the parameters (volumetric_cl._packs, SparseVoxelConv3d.Wp, the PSPNet tail pack), so after
         ``load_state_dict`` / an optimiser step / ``.to()`` the old graph would replay stale -- or freed -- packs.
         A changed parameter drops every entry (their packs are rebuilt by the next warm-up)."""
-        params = tuple((t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers()))
+        # (the tensor LIST is cached -- walking the module tree every call was ~150 us in front of a 1.6 ms replay, ADVICE
+        # round 4; a replaced parameter object, e.g. after ``.to()`` / ``load_state_dict(assign=True)``, is caught by
+        # comparing the count and identities once per call through the cheap id() tuple of the module's own dicts)
+        cached = getattr(self, "_tensors", None)
+        ident = (len(self.model._parameters), len(self.model._buffers), len(self.model._modules))
+        if cached is None or getattr(self, "_tensors_ident", None) != ident or getattr(self, "_calls", 0) % 64 == 0:
+            cached = list(self.model.parameters()) + list(self.model.buffers())
+            self._tensors, self._tensors_ident = cached, ident
+        self._calls = getattr(self, "_calls", 0) + 1
+        params = tuple((t.data_ptr(), t._version) for t in cached)
         if params != getattr(self, "_params_seen", None):
             self.entries.clear()
             self._params_seen = params

@@ -419,13 +419,19 @@ class Model(nn.Module):
         cls_trans = outs["trans"].reshape(B, P, nf, 3)
         cls_conf = torch.sigmoid(outs["conf"]).reshape(B, P, nf)
         fg = (class_id - 1).long()
+        # a class id outside 1 .. n_fg (0 = background) has no head: NaN, like the channels-last epilogue
+        # (k_pose_epilogue) -- plain advanced indexing would wrap -1 to the LAST class silently
+        bad = ((fg < 0) | (fg >= nf))[:, None, None]
+        fg = fg.clamp(0, nf - 1)
         ar = torch.arange(B, device=dev)
         rot = cls_rot[ar, :, fg]
         rot = rot / (rot.norm(dim=2, keepdim=True) + 1e-5)             # chainer F.normalize: x / (|x| + eps)
         pts_b = pts.reshape(B, P, 3)
         points_back = pts_b * pitch[:, None, None] + origin[:, None, :]
         trans = points_back + cls_trans[ar, :, fg] * pitch[:, None, None]
-        return rot, trans, cls_conf[ar, :, fg]
+        nan = torch.full((), float("nan"), device=dev)
+        return (torch.where(bad, nan, rot), torch.where(bad, nan, trans),
+                torch.where(bad[:, :, 0], nan, cls_conf[ar, :, fg]))
 
     def _pose_from_features_cl(self, class_id, values, points, pitch, origin, grid_nontarget_empty):
         """``_pose_from_features`` (camera-frame points) on the channels-last kernels (volumetric_cl.py)."""
@@ -528,5 +534,13 @@ class Model(nn.Module):
         """``forward`` with the host work done ahead (``_select_points`` -> pix, ``loss_prepare`` -> cad, symmetric):
         device work only, the form a training step is captured into a hipGraph in
         (examples/singleview_3d_train.py --graph)."""
+        if pitch is None or origin is None or cad is None or symmetric is None:
+            # (predict() derives pitch / origin from the class and the cloud's median on the HOST: model.py:195-205)
+            raise ValueError("forward(pix=...) / forward_device is the device-only form: pitch, origin, cad and "
+                             "symmetric must be given (Model._select_points, Model.loss_prepare; pitch / origin as "
+                             "predict() computes them)")
+        dev = rgb.device
+        pitch = torch.as_tensor(pitch, dtype=torch.float32, device=dev)  # predict()'s casts
+        origin = torch.as_tensor(origin, dtype=torch.float32, device=dev)
         q, t, c = self._predict_device(class_id, rgb, pcd, pix, pitch, origin, grid_nontarget_empty)
         return self.loss_device(cad, symmetric, quaternion_true, translation_true, q, t, c)

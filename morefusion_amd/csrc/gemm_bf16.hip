@@ -731,6 +731,7 @@ int launch_nt(const NtArgs &a, hipStream_t stream) {
   return 0;
 }
 
+constexpr int64_t kMaxBf16Elems = 1ll << 30;  // 2^31 bytes: the span of a buffer resource (mf_common.h kBufSpan)
 int bad(const char *msg) {
   mf::set_last_error(hipErrorInvalidValue, msg);
   return -(int)hipErrorInvalidValue;
@@ -770,6 +771,8 @@ extern "C" int mf_linear_bf16(const void *A, int64_t a_gs, int32_t lda, const vo
   if (K <= 0 || K % 8 || lda % 8 || ldw % 8 || a_gs % 8 || w_gs % 8 || lda < K || ldw < K || ldo < N ||
       (((uintptr_t)A | (uintptr_t)W) & 15) || (accumulate && !out_f32))
     return bad("linear_bf16: K, lda, ldw, group strides % 8 == 0, 16-byte aligned A / W, accumulate needs fp32 out");
+  if ((int64_t)M * lda >= kMaxBf16Elems || (int64_t)N * ldw >= kMaxBf16Elems)
+    return bad("linear_bf16: an operand of one group spans >= 2^31 bytes (32-bit byte offsets: split the rows)");
   NtArgs a = {};
   a.A = (const uint16_t *)A; a.W = (const uint16_t *)W; a.bias = bias; a.out = out;
   a.a_gs = a_gs; a.w_gs = w_gs; a.b_gs = b_gs; a.o_gs = o_gs;
@@ -789,6 +792,8 @@ extern "C" int mf_linear_wgrad_bf16(const void *dY, int64_t y_gs, int32_t ldy, c
   if (N % 8 || K % 8 || ldy % 8 || lda % 8 || y_gs % 8 || a_gs % 8 || split < 1 || (split > 1 && !ws) || ldc < K ||
       (((uintptr_t)dY | (uintptr_t)A) & 15))
     return bad("linear_wgrad_bf16: N, K, ldy, lda, group strides % 8 == 0, 16-byte aligned operands");
+  if ((int64_t)M * ldy >= kMaxBf16Elems || (int64_t)M * lda >= kMaxBf16Elems)
+    return bad("linear_wgrad_bf16: an operand of one group spans >= 2^31 bytes (32-bit byte offsets: split the rows)");
   if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16<false>, kTnLds)) return e;
   TnArgs a = {};
   a.P = (const uint16_t *)dY; a.Q = (const uint16_t *)A; a.out = split > 1 ? (float *)ws : dW;
@@ -821,9 +826,11 @@ int conv_geom(int32_t B, int32_t Cin, int32_t Cout, int32_t D, int32_t ks, int32
   g->Do = (D + 2 * pad - span) / stride + 1;
   g->olog = ilog2_exact(g->Do);
   g->taps = ks * ks * ks;
-  if (g->olog < 1 || Cin % 8 || Cout % 8 || (int64_t)B * D * D * D * Cin >= (1ll << 31) ||
-      (int64_t)B * g->Do * g->Do * g->Do * Cout >= (1ll << 31) || (int64_t)Cout * g->taps * Cin >= (1ll << 31))
-    return bad("conv3d (bf16): output size a power of two, Cin % 8 == 0, Cout % 8 == 0, tensors < 2^31 elements");
+  // operands are addressed with 32-bit BYTE offsets from a buffer resource of 2^31 bytes (mf_common.h: an offset
+  // >= 2^31 is the masked value and reads zeros): every bf16 tensor must stay below 2^30 ELEMENTS
+  if (g->olog < 1 || Cin % 8 || Cout % 8 || (int64_t)B * D * D * D * Cin >= kMaxBf16Elems ||
+      (int64_t)B * g->Do * g->Do * g->Do * Cout >= kMaxBf16Elems || (int64_t)Cout * g->taps * Cin >= kMaxBf16Elems)
+    return bad("conv3d (bf16): output size a power of two, Cin % 8 == 0, Cout % 8 == 0, tensors < 2^30 elements (2^31 bytes)");
   return 0;
 }
 }  // namespace

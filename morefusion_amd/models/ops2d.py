@@ -24,7 +24,16 @@ def _dense(x):
 
 
 def supported(x, n_slope=1):
-    return x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and n_slope == 1
+    """The kernels' own preconditions (callers fall back to the stock op otherwise): a 4-D float32 / bfloat16 CUDA
+    tensor, one PReLU slope, an element count that is a multiple of 8 and storage the 16-byte vector accesses can
+    address in place (a slice with a storage offset is neither dense nor aligned: `_dense` would copy it into an
+    aligned tensor, so only the dense layouts need the pointer check)."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and n_slope == 1):
+        return False
+    if x.numel() % 8:
+        return False
+    dense = x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)
+    return not dense or x.data_ptr() % 16 == 0
 
 
 class _Upsample(torch.autograd.Function):

@@ -104,3 +104,19 @@ def test_wgrad_split_cost_model_is_a_host_function_with_sane_answers():
     for tiles, ktiles, slab in ((1, 250, 8192), (2, 8192, 6912), (7, 3, 100), (0, 0, 0), (4096, 1, 1 << 20)):
         s = L.mf_wgrad_split(tiles, ktiles, slab)
         assert 1 <= s <= 512 and (s == 1 or ktiles // s >= 8), (tiles, ktiles, s)
+
+
+def test_bf16_engines_reject_operands_beyond_the_32_bit_byte_offsets():
+    """the bf16 GEMM engines address operands with 32-bit BYTE offsets from a 2^31-byte buffer
+    resource (an offset >= 2^31 is the masked value and reads zeros), so a tensor of 2^30 .. 2^31 ELEMENTS must be
+    refused -- the old guard let it through and convolved the tail of the batch as zeros.  Host-side argument checks
+    only (no launch)."""
+    from morefusion_amd import _lib
+    L = _lib.lib()
+    # conv3 at D = 32, Cin = 160: B = 205 is the first batch beyond 2^30 input elements (204 fits)
+    assert 205 * 32 ** 3 * 160 >= 1 << 30 > 204 * 32 ** 3 * 160
+    assert L.mf_conv3d_bf16_fwd(None, None, None, None, 205, 160, 256, 32, 4, 2, 1, 1, 1, 0, 256, None) < 0
+    assert b"2^30" in L.mf_last_error_string()
+    assert L.mf_linear_bf16(None, 0, 1024, None, 0, 1024, None, 0, None, 0, 1024, 1 << 20, 1024, 1024, 1, 0, 0, 0, None) < 0
+    assert b"2^31 bytes" in L.mf_last_error_string()
+    assert L.mf_linear_wgrad_bf16(None, 0, 1024, None, 0, 1024, None, 0, 1024, None, 1 << 20, 1024, 1024, 1, 1, None) < 0
