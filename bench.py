@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--icc-cu-pattern", choices=["low", "spread"], default="spread")
     ap.add_argument("--stage-breakdown", action="store_true", default=True)
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the batch-1 latency child process")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the un-timed extras value_scenes8 (8 scenes x 8 objects on this GPU) and "
+                         "train_objects_per_s (the training step of BASELINE config 5's per-GPU share, child process)")
     ap.add_argument("--probe-latency-b1", action="store_true", help="(internal) batch-1 latency probe, own process")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher / collective plumbing check without a GPU: N gloo ranks on the CPU, a stub "
@@ -688,6 +691,42 @@ def cpu_baseline(wl, args):
                        f"({t_pred1:.2f}s + {t_icc1:.2f}s per step)")
 
 
+def extra_scenes8(args, rank, device):
+    """BASELINE configs[3]'s per-GPU share as a driver-run number: the same pipelined step with 8 scenes x 8 objects
+    (64 objects: predict at B = 64 -> ICC of 8 scenes in one batch) on this one GPU.  Not the headline (`value` stays
+    configs[1] + configs[2]); reported beside it."""
+    import copy
+    a8 = copy.copy(args)
+    a8.scenes_per_gpu = 8
+    wl8 = Workload(a8, rank, device)
+    steps, warm = 6, 2
+    el = parallel.timed_steps(wl8.step, steps, warm, device=device)
+    return {"value": round(wl8.B * steps / el, 3), "unit": "objects/sec", "ms_per_step": round(el / steps * 1e3, 4),
+            "objects_per_gpu": wl8.B, "steps": steps, "warmup": warm,
+            "workload": "8 scenes x 8 objects on one GPU, full pipelined step (BASELINE configs[3] per-GPU share)"}
+
+
+def extra_training():
+    """BASELINE configs[4]'s per-GPU share as a driver-run number: examples/singleview_3d_train.py (global batch 16,
+    bf16 autocast, every 3-D / 1x1 convolution + voxel op hand-written, forward + backward + Adam) in a child
+    process on this GPU; the steady mean of its per-step rates (first two steps excluded there)."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        rec = os.path.join(td, "train.json")
+        cmd = [sys.executable, os.path.join(ROOT, "examples", "singleview_3d_train.py"), "--global-batch", "16",
+               "--steps", "10", "--json", rec]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            d = json.load(open(rec))
+        except Exception as e:  # the extras must never take the headline line down
+            return {"error": repr(e)[:200]}
+    return {"train_objects_per_s": d.get("objects_per_s_steady_mean"), "global_batch": d.get("global_batch"),
+            "dtype": d.get("dtype"), "steps": d.get("steps"), "hipgraph_step": d.get("hipgraph_step"),
+            "loss_first_last": [d["loss_per_step"][0], d["loss_per_step"][-1]] if d.get("loss_per_step") else None,
+            "workload": "singleview_3d training step, global batch 16 on this GPU (BASELINE configs[4] per-GPU share)"}
+
+
 def dry_run_cpu(args, world, rank):
     """N gloo ranks, stub step, the bench's own timing contract and JSON shape."""
     device = torch.device("cpu")
@@ -810,6 +849,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args)
         torch.cuda.synchronize()
+        if world == 1 and not args.no_extras and args.scenes_per_gpu == 1:
+            # configs[3] / configs[4] per-GPU shares inside the driver-run line (round-4 verdict item 7)
+            s8 = extra_scenes8(args, rank, device)
+            out["value_scenes8"] = s8["value"]
+            out["scenes8"] = s8
+            tr = extra_training()
+            out["train_objects_per_s"] = tr.get("train_objects_per_s")
+            out["training"] = tr
+            torch.cuda.synchronize()
         if not args.no_latency_probe:
             out["latency_batch1_ms"] = latency_batch1(wl)  # child process, last: nothing of this one depends on it
         print(json.dumps(out))

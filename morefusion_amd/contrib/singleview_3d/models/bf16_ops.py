@@ -59,7 +59,7 @@ def _cached_pack(weight, key, build):
     """``weight`` must be the module's own Parameter for a hit: the entry holds a weak reference to it and is valid only
     for that very object at that in-place version (an address alone can be reused by another tensor -- e.g. the
     per-call ``torch.cat`` of the three heads' first layers lands at the same address every step)."""
-    if torch.cuda.is_current_stream_capturing() or not isinstance(weight, torch.nn.Parameter):
+    if not isinstance(weight, torch.nn.Parameter) or (weight.is_cuda and torch.cuda.is_current_stream_capturing()):
         return build()
     key = (id(weight), weight._version) + key
     hit = _PACKS.get(key)
