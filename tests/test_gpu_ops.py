@@ -87,8 +87,14 @@ def test_average_voxelization_3d_errors():
         F.average_voxelization_3d(v, pn, b, dimensions=(4, 4, 4), **kw)
     with pytest.raises(TypeError):
         F.average_voxelization_3d(v, p, b.long(), dimensions=(4, 4, 4), **kw)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        F.average_voxelization_3d(v.cpu(), p.cpu(), b.cpu(), dimensions=(4, 4, 4), **kw)
+    # CPU tensors take the product's CPU path (round 5, like the reference's get_array_module): same values as the GPU
+    # path here (no coordinate sits on a rounding boundary: the forks differ only at exact .5)
+    y_cpu = F.average_voxelization_3d(v.cpu(), p.cpu(), b.cpu(), dimensions=(4, 4, 4), **kw)
+    assert not y_cpu.is_cuda
+    np.testing.assert_allclose(y_cpu.numpy(), F.average_voxelization_3d(v, p, b, dimensions=(4, 4, 4), **kw).cpu().numpy(),
+                               rtol=1e-6, atol=1e-7)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):  # mixed devices are still an error
+        F.average_voxelization_3d(v, p.cpu(), b, dimensions=(4, 4, 4), **kw)
 
 
 # ---- A3 ------------------------------------------------------------------------------
