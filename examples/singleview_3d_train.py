@@ -11,10 +11,12 @@ The reference all-reduces gradients with ChainerMN `pure_nccl` (train.py:231,344
 torch DDP over RCCL (bucketed all-reduce overlapped with backward).  Under bf16 autocast the 3-D CNN, the 1x1
 convolutions, voxelization and sampling run on the hand-written bf16 kernels (models/bf16_ops.py), the 2-D backbone
 on MIOpen, the loss on its fp32 HIP op.
-``--graph`` (single process): the step's device work -- forward, backward, Adam -- is captured into ONE hipGraph after
-three eager steps and replayed; the host keeps what the reference does on the host (the NumPy-RNG point selection and
-CAD subsample).  The eager step is launch-bound for a fifth of its time (~1100 launches, 22.1 ms for 17.7 ms of
-kernels): 742 -> 841 objects/s on one MI355X (profiles/r04_train_1gpu_bf16_hipgraph_step.json).
+``--graph``: the step's device work is captured into TWO hipGraphs after three eager steps and replayed -- forward +
+backward (+ the copy of every gradient into one flat bucket), then Adam; between them, eager, ONE all-reduce of the
+bucket over RCCL when the run is data-parallel (``--ddp`` / ``--gpus N``: parallel.DataParallelStep -- torch's DDP
+cannot be captured on this stack).  The host keeps what the reference does on the host (the NumPy-RNG point
+selection and CAD subsample).  The eager step is launch-bound for a fifth of its time (~1100 launches, 22.1 ms for
+17.7 ms of kernels): 742 -> 841 objects/s on one MI355X (profiles/r04_train_1gpu_bf16_hipgraph_step.json).
 """
 import argparse
 import json
@@ -88,13 +90,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_ddp = world > 1 or args.ddp
-    if use_ddp and args.graph:
-        # Tried in round 4 with torch's recipe (asynchronous NCCL error handling off, DDP constructed on the side
-        # stream, 11 eager DDP steps, then the capture): on this stack (torch 2.10 + ROCm 7 RCCL) ProcessGroupNCCL's
-        # watchdog thread queries an event recorded in the capturing stream and the process aborts with
-        # hipErrorCapturedEvent at the first captured all-reduce (world size 1, gpurun r05q).
-        raise SystemExit("--graph captures a single-process step: under DistributedDataParallel the RCCL watchdog "
-                         "aborts the capture on this stack (hipErrorCapturedEvent)")
+    # --graph with data parallelism: NOT through DistributedDataParallel (its all-reduces run inside the backward
+    # pass: captured, ProcessGroupNCCL's watchdog aborts the process with hipErrorCapturedEvent on this stack, round 4)
+    # but through parallel.DataParallelStep -- forward + backward and the optimiser step are two graphs, ONE flat
+    # gradient all-reduce over RCCL sits between them, eager.
     if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
@@ -108,8 +107,14 @@ def main():
     pcds = {c: rs.uniform(-0.05, 0.05, (2000, 3)).astype(np.float32) for c in morefusion.synthetic.CLASS_PITCH}
     model = Model(n_fg_class=21, with_occupancy=True, models=PitchTableModels(pcds)).to(device).train()
     side = torch.cuda.Stream(device=device) if args.graph else None
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if use_ddp else model
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if use_ddp and not args.graph else model
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=bool(args.graph))
+
+    def autocast_loss(**kw):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.no_bf16):
+            return net(**kw)
+
+    dp = parallel.DataParallelStep(model.parameters(), optimizer, autocast_loss, exchange=use_ddp) if args.graph else None
 
     per_rank = max(1, args.global_batch // world)
     np.random.seed(1234 + rank)  # per-rank point / CAD subsampling streams
@@ -119,7 +124,6 @@ def main():
     mark = (lambda: torch.zeros(1, device=device).erfinv_()) if os.environ.get("MF_TRAIN_MARK") == "1" else (lambda: None)
     mark()
     KEYS = ("class_id", "rgb", "pcd", "pitch", "origin", "grid_nontarget_empty", "quaternion_true", "translation_true")
-    graph, static, static_loss = None, None, None
 
     def device_inputs(inp):
         """The uploaded batch -> everything the device side of the step reads: the network inputs plus what the host
@@ -151,28 +155,19 @@ def main():
             loss = eager_step(inputs)
         elif step < args.graph_warmup:
             # torch's capture recipe: the eager warm-up steps run on the side stream the capture will use, so that
-            # the gradient accumulators and the optimizer state are born there
+            # the gradient accumulators and the optimizer state are born there (same three parts as the replay:
+            # forward + backward, flat gradient all-reduce, update)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                loss = eager_step(inputs)
+                loss = dp.step(device_inputs(inputs))
             torch.cuda.current_stream().wait_stream(side)
         else:
             new = device_inputs(inputs)
-            if graph is None:
-                # capture: the step's device work on static tensors (torch's whole-network recipe: gradients are
-                # allocated inside the graph's pool, Adam is capturable); MIOpen's solvers were chosen by the eager steps
-                static = {k: v.clone() for k, v in new.items()}
-                optimizer.zero_grad(set_to_none=True)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
-                    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.no_bf16):
-                        static_loss = net(**static)  # Model.forward's device form (through DDP's hooks when wrapped)
-                    static_loss.backward()
-                    optimizer.step()
-            for k, v in new.items():
-                static[k].copy_(v)
-            graph.replay()
-            loss = static_loss
+            if dp.graph_fb is None:
+                # capture: the step's device work on static tensors (gradients are allocated inside the graph's pool,
+                # Adam is capturable); MIOpen's solvers were chosen by the eager steps
+                dp.capture(new, side)
+            loss = dp.replay(new)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:

@@ -211,6 +211,8 @@ class Linear(torch.autograd.Function):
                                               Kp, _lib.ptr(ws), n, Np, Kp, 1, split, _lib.stream_ptr()),
                        "mf_linear_wgrad_bf16")
             dw = dwp[:N, :K].reshape(wshape)
+            if Np != N or Kp != K:  # a slice of the padded buffer: dense strides for the gradient buckets (DDP warns
+                dw = dw.contiguous()  # "grad strides do not match bucket view strides" and copies otherwise)
         if has_bias and ctx.needs_input_grad[2]:
             db = dz.sum(dim=0, dtype=torch.float32)
         return dx, dw, db, None

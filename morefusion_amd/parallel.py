@@ -131,3 +131,96 @@ def timed_steps(step, steps, warmup, device=None, group=None):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(tt.item())
     return elapsed
+
+
+class DataParallelStep:
+    """Data-parallel optimiser step whose device work can be replayed from hipGraphs (BASELINE config 5:
+    ``train.py:228-233,342-344`` -- ChainerMN's multi-node optimizer all-reduces the gradients of every rank's
+    share of the batch before the update).
+
+    torch's ``DistributedDataParallel`` issues its bucketed all-reduces from autograd hooks, i.e. INSIDE the backward
+    pass: captured into a hipGraph on this stack (torch 2.10 + ROCm 7 RCCL) ProcessGroupNCCL's watchdog queries an
+    event of the capturing stream and the process aborts (``hipErrorCapturedEvent``,
+    profiles/r04_train_hipgraph_under_ddp_abort.log).  Here the exchange sits BETWEEN two graphs instead:
+
+    * phase 1 (capturable): forward, backward, then every gradient is copied into ONE flat float32 bucket
+      (a few multi-tensor copies);
+    * exchange (always eager): one ``all_reduce`` of the bucket over the process group -- RCCL over xGMI on the GPUs
+      (124 MB fp32 for the pose network: ~1.4 ms ring lower bound over one xGMI link pair), gloo in the
+      CPU tests -- followed by the division by the world size inside phase 2;
+    * phase 2 (capturable): the optimiser step on the bucket's views (``param.grad`` aliases its slice).
+
+    What is lost against DDP is the overlap of the exchange with the backward pass; what is gained is the replay of
+    the ~1100 launches of the step (22.1 -> 19.0 ms on one MI355X).  ``loss_fn(**inputs)`` runs the module's forward
+    and returns the scalar loss; ``group=None`` with an initialised default group reduces over it, without one the
+    exchange is skipped (single process)."""
+
+    def __init__(self, params, optimizer, loss_fn, group=None, exchange=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.optimizer = optimizer
+        self.loss_fn = loss_fn
+        self.group = group
+        self.exchange = (dist.is_available() and dist.is_initialized()) if exchange is None else exchange
+        self.world = dist.get_world_size(group) if self.exchange else 1
+        dev, n = self.params[0].device, sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.graph_fb = self.graph_opt = self.static = self.static_loss = None
+
+    # -- the three parts of a step ------------------------------------------------------------------
+    def _forward_backward(self, inputs):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.loss_fn(**inputs)
+        loss.backward()
+        self._pack()
+        return loss
+
+    def _pack(self):
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(self.views, self.params):
+            if p.grad is None:  # a parameter the loss does not reach contributes zeros (DDP's find_unused_parameters)
+                v.zero_()
+
+    def _all_reduce(self):
+        if self.exchange:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _update(self):
+        if self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+        for v, p in zip(self.views, self.params):
+            p.grad = v
+        self.optimizer.step()
+
+    # -- eager ----------------------------------------------------------------------------------------
+    def step(self, inputs):
+        loss = self._forward_backward(inputs)
+        self._all_reduce()
+        self._update()
+        return loss
+
+    # -- captured ---------------------------------------------------------------------------------------
+    def capture(self, inputs, stream):
+        """Capture phase 1 and phase 2 on ``stream`` (the side stream the eager warm-up steps ran on, torch's capture
+        recipe; the optimiser must be ``capturable``).  ``inputs``: dict of device tensors; their clones become the
+        graphs' static inputs."""
+        self.static = {k: v.clone() for k, v in inputs.items()}
+        self.optimizer.zero_grad(set_to_none=True)
+        self.graph_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_fb, stream=stream):
+            self.static_loss = self._forward_backward(self.static)
+        self.graph_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_opt, stream=stream, pool=self.graph_fb.pool()):
+            self._update()
+
+    def replay(self, inputs):
+        for k, v in inputs.items():
+            self.static[k].copy_(v)
+        self.graph_fb.replay()
+        self._all_reduce()
+        self.graph_opt.replay()
+        return self.static_loss

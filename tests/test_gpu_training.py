@@ -136,3 +136,32 @@ def test_hipgraph_captured_training_step_tracks_the_eager_step(tmp_path):
     np.testing.assert_allclose(lg[:3], le[:3], rtol=2e-3)   # the eager warm-up steps (side stream): the same work
     np.testing.assert_allclose(lg[3:], le[3:], rtol=1e-2)   # capture + three replays
     assert np.ptp(le) > 0.05 * le.mean()                    # (the batches do differ by more than the tolerance)
+
+
+def test_hipgraph_captured_data_parallel_step_over_rccl_tracks_the_eager_ddp_step(tmp_path):
+    """examples/singleview_3d_train.py --ddp --graph (round 5, BASELINE config 5's step under data parallelism):
+    parallel.DataParallelStep -- forward + backward and the optimiser step replayed from two hipGraphs, ONE flat
+    gradient all-reduce over the nccl backend (RCCL) between them, eager -- at world size 1 on the MI355X, against
+    the eager DistributedDataParallel run on the same seeds and batches (PSPNet's dropouts off): every step's loss
+    within 1 % (round 4: the capture through DDP's hooks aborted in RCCL's watchdog,
+    profiles/r04_train_hipgraph_under_ddp_abort.log)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "examples", "singleview_3d_train.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    recs = {}
+    for tag, extra in (("eager_ddp", ["--ddp"]), ("graph_dp", ["--ddp", "--graph"])):
+        out = tmp_path / f"{tag}.json"
+        p = subprocess.run([sys.executable, script, "--global-batch", "4", "--steps", "8", "--no-dropout", "--json", str(out)] + extra,
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        recs[tag] = json.loads(out.read_text())
+        assert recs[tag]["ddp"] and recs[tag]["backend"] == "nccl (RCCL)"
+    assert recs["graph_dp"]["hipgraph_step"] and not recs["eager_ddp"]["hipgraph_step"]
+    le, lg = np.array(recs["eager_ddp"]["loss_per_step"]), np.array(recs["graph_dp"]["loss_per_step"])
+    assert np.isfinite(lg).all() and len(lg) == 8
+    np.testing.assert_allclose(lg, le, rtol=1e-2)
+    assert np.ptp(le) > 0.05 * le.mean()

@@ -12,6 +12,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -102,23 +103,38 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(4)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         model = _build(_install_standins())
-        net = torch.nn.parallel.DistributedDataParallel(model)
-        loss = _local_step(net, rank)
+        extra = {}
+        if mode == "ddp":
+            net = torch.nn.parallel.DistributedDataParallel(model)
+            loss = _local_step(net, rank)
+        else:
+            # parallel.DataParallelStep (round 5): forward + backward, ONE flat gradient all-reduce, update -- the
+            # form whose two device phases are captured into hipGraphs on the GPU (`--ddp --graph`)
+            from morefusion_amd.parallel import DataParallelStep
+            w0 = {n: p.detach().clone() for n, p in model.named_parameters() if n in WATCH}
+            opt = torch.optim.SGD(model.parameters(), lr=0.5)
+            dp = DataParallelStep(model.parameters(), opt, lambda **kw: model(**kw))
+            assert dp.world == 2 and dp.flat.numel() == sum(p.numel() for p in model.parameters())
+            np.random.seed(1234 + rank)
+            torch.manual_seed(77 + rank)  # dropout masks
+            loss = float(dp.step(_batch(rank)).detach())
+            extra["update"] = {n: (w0[n] - p.detach()) / 0.5 for n, p in model.named_parameters() if n in WATCH}
         grads = {n: p.grad.clone() for n, p in model.named_parameters() if n in WATCH}
-        torch.save({"loss": loss, "grads": grads}, os.path.join(out_dir, f"rank{rank}.pt"))
+        torch.save(dict({"loss": loss, "grads": grads}, **extra), os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-def test_ddp_training_step_averages_the_two_ranks_gradients(tmp_path):
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("mode", ["ddp", "flat_bucket"])
+def test_ddp_training_step_averages_the_two_ranks_gradients(tmp_path, mode):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), mode), nprocs=2, join=True)
     got = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
     # single-process references on the same data / seeds
     import morefusion_amd.contrib.singleview_3d.models.model as model_mod
@@ -146,3 +162,6 @@ def test_ddp_training_step_averages_the_two_ranks_gradients(tmp_path):
         for r in range(2):
             torch.testing.assert_close(got[r]["grads"][n], mean, rtol=2e-4, atol=1e-7 + 2e-4 * float(mean.abs().max()))
         torch.testing.assert_close(got[0]["grads"][n], got[1]["grads"][n], rtol=0, atol=0)  # identical on both ranks
+        if mode == "flat_bucket":  # ... and the SGD update it drove is that mean, on both ranks
+            for r in range(2):
+                torch.testing.assert_close(got[r]["update"][n], mean, rtol=2e-3, atol=1e-6 + 2e-3 * float(mean.abs().max()))
