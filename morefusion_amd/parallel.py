@@ -210,11 +210,17 @@ class DataParallelStep:
         graphs' static inputs."""
         self.static = {k: v.clone() for k, v in inputs.items()}
         self.optimizer.zero_grad(set_to_none=True)
+        # ProcessGroupNCCL's watchdog THREAD polls the events of the eager all-reduces (hipEventQuery): under the
+        # default global capture mode any such call from any thread while this thread captures is an error and the
+        # process aborts (seen at world size 1 when a warm-up step's all-reduce was still being reaped).  The exchange
+        # is never part of a capture here, so thread-local mode is exact: only this thread's calls are checked.
+        torch.cuda.synchronize()
+        mode = dict(capture_error_mode="thread_local")
         self.graph_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fb, stream=stream):
+        with torch.cuda.graph(self.graph_fb, stream=stream, **mode):
             self.static_loss = self._forward_backward(self.static)
         self.graph_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_opt, stream=stream, pool=self.graph_fb.pool()):
+        with torch.cuda.graph(self.graph_opt, stream=stream, pool=self.graph_fb.pool(), **mode):
             self._update()
 
     def replay(self, inputs):
