@@ -421,6 +421,52 @@ int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, void *ws, int
                          int32_t D, int32_t ks, int32_t stride, int32_t pad, int32_t dil, int32_t w_cin, int32_t c_off,
                          int32_t split, mfStream_t stream);
 
+/* ---- conv3 of the bf16 training path on OCCUPIED VOXELS only (round 5; csrc/sparseconv_bf16.hip) -----------------
+ * replaces the dense forward / backward-data / backward-filter of `L.Convolution3D(None, 256, 4, 2, pad=1)` over the
+ * voxelized point features (contrib/singleview_3d/models/model.py:73,114-128; train.py:342-369): average_voxelization_3d
+ * leaves <= 1000 of an object's 32768 voxels occupied in 144 of the 160 input channels.  Compact CLASS-MAJOR rows
+ * (8 parity classes of the k4 / s2 / p1 geometry, each padded to a multiple of 128 rows):
+ *   mf_sparse_conv3_bf16_index      points [n,3] (voxel frame: origin 0, pitch 1), batch_indices -> chains, row map,
+ *                                   row -> voxel map, class row ranges, class of every 64-row block (all in ws)
+ *   mf_sparse_conv3_bf16_tables     device addresses of those tables (see csrc/sparseconv_bf16.hip)
+ *   mf_average_voxelization_rows_bf16_fwd / _bwd   voxel means into / gradients out of the compact rows A [rows, lda]
+ *   mf_sparse_conv3_bf16_pack       W fp32 [Cout, w_cin, 4,4,4] channels c_off.. -> Wp bf16 [8][8 Cout][Cs] (forward /
+ *                                   weight-gradient operand) and Wq bf16 [8][Cs][8 Cout] (data-gradient operand, or NULL)
+ *   mf_linear_bf16_tiles            C = A Wp[class(row)]^T, the class of every 64-row block from the device table
+ *   mf_sparse_conv3_bf16_reduce     out [B, (D/2)^3, Cout] bf16 = relu?(dense fp32 (or NULL) + bias + the <= 64
+ *                                   (voxel, tap) contributions of every output voxel, in tap order)
+ *   mf_sparse_conv3_bf16_gather_dy  dYg [rows, 8 Cout] = dz at the 8 output voxels each row feeds (zeros outside)
+ *   mf_linear_wgrad_bf16_ranges     dWp[class] = dYg^T A over the class's row range (device table)
+ *   mf_sparse_conv3_bf16_unpack_dw  dWp fp32 [8][8 Cout][Cs] -> dW fp32 [Cout, w_cin, 4,4,4] channels c_off..
+ * rows = mf_sparse_conv3_bf16_max_rows(n) = n + 8 * 127 rounded up to 128.  Asynchronous, never allocate. */
+int64_t mf_sparse_conv3_bf16_max_rows(int64_t n_points);
+int64_t mf_sparse_conv3_bf16_workspace_bytes(int64_t n_points, int32_t B, int32_t D);
+int mf_sparse_conv3_bf16_tables(void *ws, int64_t n_points, int32_t B, int32_t D, int64_t *out7);
+int mf_sparse_conv3_bf16_index(const float *points, const int32_t *batch_indices, int64_t n, int32_t B, int32_t D,
+                               void *ws, mfStream_t stream);
+int mf_sparse_conv3_bf16_pack(const float *W, int32_t Cout, int32_t Cs, int32_t w_cin, int32_t c_off, void *Wp, void *Wq,
+                              mfStream_t stream);
+int mf_sparse_conv3_bf16_unpack_dw(const float *dWp, int32_t Cout, int32_t Cs, int32_t w_cin, int32_t c_off, float *dW,
+                                   mfStream_t stream);
+int mf_sparse_conv3_bf16_reduce(const void *C, const float *dense, const float *bias, void *ws, int64_t n_points,
+                                int32_t B, int32_t D, int32_t Cout, int32_t relu, void *out, mfStream_t stream);
+int mf_sparse_conv3_bf16_gather_dy(const void *dz, void *ws, int64_t n_points, int32_t B, int32_t D, int32_t Cout,
+                                   void *dYg, mfStream_t stream);
+int mf_linear_bf16_tiles(const void *A, int32_t lda, const void *W, int64_t w_group_stride, int32_t ldw,
+                         const int32_t *tile_group, void *out, int32_t ldo, int32_t M, int32_t N, int32_t K,
+                         int32_t out_f32, mfStream_t stream);
+int mf_linear_wgrad_bf16_ranges(const void *dY, int32_t ldy, const void *A, int32_t lda, float *dW,
+                                int64_t w_group_stride, int32_t ldc, const int32_t *m_range, int32_t groups, int32_t N,
+                                int32_t K, mfStream_t stream);
+int mf_average_voxelization_rows_bf16_fwd(const void *values, int64_t ldv, const float *points,
+                                          const int32_t *batch_indices, int64_t n, int32_t C, int32_t B, int32_t D,
+                                          const int32_t *counts, const int32_t *head, const int32_t *link,
+                                          const int32_t *rowmap, void *A, int64_t lda, mfStream_t stream);
+int mf_average_voxelization_rows_bf16_bwd(const void *dA, int64_t lda, const float *points,
+                                          const int32_t *batch_indices, const int32_t *counts, const int32_t *rowmap,
+                                          int64_t n, int32_t C, int32_t B, int32_t D, void *gvalues, int64_t ldg,
+                                          mfStream_t stream);
+
 /* Channels-last bf16 voxelization and trilinear sampling of the bf16 training path (K1/K2 and K5/K6 of SURVEY 2.1 --
  * functions/geometry/average_voxelization_3d.py:8-113, interpolate_voxel_grid.py:61-215 -- on the layout the bf16
  * convolutions consume; origin 0, pitch 1, cubic grids, as contrib/singleview_3d/models/model.py:113,131,141 call them):

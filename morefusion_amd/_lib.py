@@ -94,6 +94,18 @@ _SIGNATURES = {
     "mf_wgrad_split": ([_i64, _i64, _i64], _i),
     "mf_conv3d_bf16_wgrad_default_split": ([ctypes.c_int32] * 5, ctypes.c_int32),
     "mf_conv3d_bf16_wgrad": ([_p, _p, _p, _p] + [ctypes.c_int32] * 11 + [_p], _i),
+    "mf_sparse_conv3_bf16_max_rows": ([_i64], _i64),
+    "mf_sparse_conv3_bf16_workspace_bytes": ([_i64, ctypes.c_int32, ctypes.c_int32], _i64),
+    "mf_sparse_conv3_bf16_tables": ([_p, _i64, ctypes.c_int32, ctypes.c_int32, _p], _i),
+    "mf_sparse_conv3_bf16_index": ([_p, _p, _i64, ctypes.c_int32, ctypes.c_int32, _p, _p], _i),
+    "mf_sparse_conv3_bf16_pack": ([_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p, _p], _i),
+    "mf_sparse_conv3_bf16_unpack_dw": ([_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p], _i),
+    "mf_sparse_conv3_bf16_reduce": ([_p, _p, _p, _p, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p], _i),
+    "mf_sparse_conv3_bf16_gather_dy": ([_p, _p, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p], _i),
+    "mf_linear_bf16_tiles": ([_p, ctypes.c_int32, _p, _i64, ctypes.c_int32, _p, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p], _i),
+    "mf_linear_wgrad_bf16_ranges": ([_p, ctypes.c_int32, _p, ctypes.c_int32, _p, _i64, ctypes.c_int32, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p], _i),
+    "mf_average_voxelization_rows_bf16_fwd": ([_p, _i64, _p, _p, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p, _p, _p, _p, _i64, _p], _i),
+    "mf_average_voxelization_rows_bf16_bwd": ([_p, _i64, _p, _p, _p, _p, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _i64, _p], _i),
     "mf_average_voxelization_cl_bf16_fwd": ([_p, _i64, _p, _p, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _i64,
                                              _p, _p, _p, _p], _i),
     "mf_average_voxelization_cl_bf16_bwd": ([_p, _i64, _p, _p, _p, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p,

@@ -12,6 +12,7 @@ they change every optimiser step; the pack is ~0.1 ms for conv4's 8.4 M weights.
 bf16, gradients of parameters fp32 (what ``torch.autocast`` produces with stock operators).
 No fallback: a CPU tensor or a missing libmfhip.so raises.
 """
+import ctypes
 import weakref
 
 import torch
@@ -271,6 +272,110 @@ class AverageVoxelizationCL(torch.autograd.Function):
                                                                   _lib.stream_ptr()),
                    "mf_average_voxelization_cl_bf16_bwd")
         return gv, None, None, None, None, None
+
+
+class SparseConv3(torch.autograd.Function):
+    """conv3 of the pose network WITHOUT the dense 160-channel grid (round 5; csrc/sparseconv_bf16.hip):
+    ``relu(Convolution3D(160, Cout, 4, 2, pad=1)([average_voxelization_3d(feat2) | h_occ]) + bias)`` where the
+    voxelized 144 channels exist only as compact rows of the occupied voxels (<= 1000 of an object's 32768) -- forward,
+    data gradient (to the point rows ``feat2`` and to the dense occupancy channels ``h_occ``) and weight gradient.
+    Reference: contrib/singleview_3d/models/model.py:73,113-128 (``_voxelize`` -> ``conv3``), trained by
+    examples/ycb_video/singleview_3d/train.py:342-369.
+
+    feat2 [n, Cs] bf16 point rows, points [n, 3] float32 in the voxel frame (origin 0, pitch 1), batch_indices [n]
+    int32, h_occ [B, D^3, Co] bf16 channels-last or None (Co = weight.shape[1] - Cs), weight fp32
+    [Cout, Cs + Co, 4, 4, 4], bias fp32 [Cout] -> [B, (D/2)^3, Cout] bf16."""
+
+    @staticmethod
+    def forward(ctx, feat2, h_occ, points, batch_indices, weight, bias, B, D):
+        _lib.require_gpu(feat2, points, batch_indices, weight)
+        L = _lib.lib()
+        feat2 = _bf16c(feat2)
+        n, Cs = feat2.shape
+        Cout, w_cin = weight.shape[0], weight.shape[1]
+        Co = w_cin - Cs
+        assert tuple(weight.shape[2:]) == (4, 4, 4) and Co >= 0 and (h_occ is None) == (Co == 0)
+        pts, bi = _lib.f32c(points), _lib.i32c(batch_indices)
+        Vo, N8 = (D // 2) ** 3, 8 * Cout
+        ws = _empty((L.mf_sparse_conv3_bf16_workspace_bytes(n, B, D),), torch.uint8, feat2)
+        _lib.check(L.mf_sparse_conv3_bf16_index(pts.data_ptr(), bi.data_ptr(), n, B, D, ws.data_ptr(), _lib.stream_ptr()),
+                   "mf_sparse_conv3_bf16_index")
+        tabs = (ctypes.c_int64 * 7)()
+        L.mf_sparse_conv3_bf16_tables(ws.data_ptr(), n, B, D, tabs)
+        t_group, t_range, t_rowmap, t_counts, _, t_head, t_link = (int(v) for v in tabs)
+        Mp = int(L.mf_sparse_conv3_bf16_max_rows(n))
+        A = torch.zeros((Mp, Cs), dtype=BF16, device=feat2.device)   # pad rows stay zero (the weight gradient sums them)
+        _lib.check(L.mf_average_voxelization_rows_bf16_fwd(feat2.data_ptr(), feat2.stride(0), pts.data_ptr(), bi.data_ptr(),
+                                                           n, Cs, B, D, t_counts, t_head, t_link, t_rowmap, A.data_ptr(),
+                                                           Cs, _lib.stream_ptr()), "mf_average_voxelization_rows_bf16_fwd")
+        need_df = ctx.needs_input_grad[0]
+        need_do = h_occ is not None and ctx.needs_input_grad[1]
+        w32 = weight.detach().float().contiguous()
+        Wp = _empty((8, N8, Cs), BF16, feat2)
+        Wq = _empty((8, Cs, N8), BF16, feat2) if need_df else None
+        _lib.check(L.mf_sparse_conv3_bf16_pack(w32.data_ptr(), Cout, Cs, w_cin, 0, Wp.data_ptr(), _lib.ptr(Wq),
+                                               _lib.stream_ptr()), "mf_sparse_conv3_bf16_pack")
+        C = _empty((Mp, N8), BF16, feat2)
+        _lib.check(L.mf_linear_bf16_tiles(A.data_ptr(), Cs, Wp.data_ptr(), N8 * Cs, Cs, t_group, C.data_ptr(), N8, Mp, N8, Cs,
+                                          0, _lib.stream_ptr()), "mf_linear_bf16_tiles")
+        dense = wd = None
+        if h_occ is not None:  # the dense channels: the dense engine at Cin = Co, fp32 pre-activation, no bias
+            h_occ = _bf16c(h_occ)
+            wt = _empty((Cout, 64, Co), BF16, feat2)
+            wd = _empty((8, Co, 8, Cout), BF16, feat2) if need_do else None
+            _lib.check(L.mf_conv3d_bf16_pack(w32.data_ptr(), Cout, Co, w_cin, Cs, 4, wt.data_ptr(), _lib.ptr(wd), None,
+                                             _lib.stream_ptr()), "mf_conv3d_bf16_pack")
+            dense = _empty((B, Vo, Cout), torch.float32, feat2)
+            _lib.check(L.mf_conv3d_bf16_fwd(h_occ.data_ptr(), wt.data_ptr(), None, dense.data_ptr(), B, Co, Cout, D, 4, 2, 1,
+                                            1, 0, 1, Cout, _lib.stream_ptr()), "mf_conv3d_bf16_fwd (occupancy channels)")
+        out = _empty((B, Vo, Cout), BF16, feat2)
+        b = bias.detach().float().contiguous() if bias is not None else None
+        _lib.check(L.mf_sparse_conv3_bf16_reduce(C.data_ptr(), _lib.ptr(dense), _lib.ptr(b), ws.data_ptr(), n, B, D, Cout, 1,
+                                                 out.data_ptr(), _lib.stream_ptr()), "mf_sparse_conv3_bf16_reduce")
+        ctx.save_for_backward(A, Wq, wd, h_occ, out, pts, bi, ws)
+        ctx.geom = (n, Cs, Co, Cout, w_cin, B, D, Mp, bias is not None, tuple(weight.shape),
+                    (t_group, t_range, t_rowmap, t_counts))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        A, Wq, wd, h_occ, out, pts, bi, ws = ctx.saved_tensors
+        n, Cs, Co, Cout, w_cin, B, D, Mp, has_bias, wshape, (t_group, t_range, t_rowmap, t_counts) = ctx.geom
+        L = _lib.lib()
+        N8 = 8 * Cout
+        dz = relu_mask(out, dy)
+        dYg = _empty((Mp, N8), BF16, dz)
+        _lib.check(L.mf_sparse_conv3_bf16_gather_dy(dz.data_ptr(), ws.data_ptr(), n, B, D, Cout, dYg.data_ptr(),
+                                                    _lib.stream_ptr()), "mf_sparse_conv3_bf16_gather_dy")
+        dfeat = docc = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dA = _empty((Mp, Cs), BF16, dz)
+            _lib.check(L.mf_linear_bf16_tiles(dYg.data_ptr(), N8, Wq.data_ptr(), Cs * N8, N8, t_group, dA.data_ptr(), Cs, Mp,
+                                              Cs, N8, 0, _lib.stream_ptr()), "mf_linear_bf16_tiles (data gradient)")
+            dfeat = _empty((n, Cs), BF16, dz)
+            _lib.check(L.mf_average_voxelization_rows_bf16_bwd(dA.data_ptr(), Cs, pts.data_ptr(), bi.data_ptr(), t_counts,
+                                                               t_rowmap, n, Cs, B, D, dfeat.data_ptr(), Cs,
+                                                               _lib.stream_ptr()), "mf_average_voxelization_rows_bf16_bwd")
+        if h_occ is not None and ctx.needs_input_grad[1]:
+            docc = torch.empty_like(h_occ)
+            _lib.check(L.mf_conv3d_k4s2_bf16_dgrad(dz.data_ptr(), wd.data_ptr(), docc.data_ptr(), B, Co, Cout, D, 0, 0,
+                                                   _lib.stream_ptr()), "mf_conv3d_k4s2_bf16_dgrad (occupancy channels)")
+        if ctx.needs_input_grad[4]:
+            dWp = _empty((8, N8, Cs), torch.float32, dz)
+            _lib.check(L.mf_linear_wgrad_bf16_ranges(dYg.data_ptr(), N8, A.data_ptr(), Cs, dWp.data_ptr(), N8 * Cs, Cs,
+                                                     t_range, 8, N8, Cs, _lib.stream_ptr()), "mf_linear_wgrad_bf16_ranges")
+            dw = _empty(wshape, torch.float32, dz)
+            _lib.check(L.mf_sparse_conv3_bf16_unpack_dw(dWp.data_ptr(), Cout, Cs, w_cin, 0, dw.data_ptr(), _lib.stream_ptr()),
+                       "mf_sparse_conv3_bf16_unpack_dw")
+            if h_occ is not None:
+                split = L.mf_conv3d_bf16_wgrad_default_split(B, Co, Cout, D // 2, 4)
+                ws2 = _empty((L.mf_conv3d_bf16_wgrad_workspace_bytes(Co, Cout, 4, split),), torch.uint8, dz)
+                _lib.check(L.mf_conv3d_bf16_wgrad(dz.data_ptr(), h_occ.data_ptr(), dw.data_ptr(), ws2.data_ptr(), B, Co, Cout,
+                                                  D, 4, 2, 1, 1, w_cin, Cs, split, _lib.stream_ptr()),
+                           "mf_conv3d_bf16_wgrad (occupancy channels)")
+        if has_bias and ctx.needs_input_grad[5]:
+            db = dz.reshape(-1, Cout).sum(dim=0, dtype=torch.float32)
+        return dfeat, docc, None, None, dw, db, None, None
 
 
 class InterpolateVoxelGridCL(torch.autograd.Function):

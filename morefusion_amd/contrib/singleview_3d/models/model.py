@@ -394,13 +394,21 @@ class Model(nn.Module):
         h2_pcd = K.linear(h1_pcd, self.conv2_pcd)
         feat2 = torch.cat((h2_rgb, h2_pcd), dim=1)                                    # [n,144] bf16
         c3 = self.conv3.in_channels
-        x3 = K.AverageVoxelizationCL.apply(feat2, pts, batch_indices, B, D, c3)       # [B,D^3,160] bf16, cols 0:144
+        h_occ = None
         if self._with_occupancy:
             g8 = torch.zeros((B, D ** 3, 8), dtype=torch.bfloat16, device=dev)        # 1 channel + 7 zeros (16 B / voxel)
             g8[:, :, 0] = grid_nontarget_empty.reshape(B, D ** 3)
             h_occ = K.conv3d(K.conv3d(g8, self.conv1_occ, D), self.conv2_occ, D)      # [B,D^3,16] bf16
-            x3[:, :, 144:] = h_occ
-        h3 = K.conv3d_k4s2(x3, self.conv3, D)                                         # [B,16^3,256] bf16
+        if os.environ.get("MF_DENSE_CONV3", "0") not in ("", "0"):
+            # round 4's form (A/B measurements): the dense [B,D^3,160] grid through the dense engines
+            x3 = K.AverageVoxelizationCL.apply(feat2, pts, batch_indices, B, D, c3)   # cols 0:144
+            if h_occ is not None:
+                x3[:, :, 144:] = h_occ
+            h3 = K.conv3d_k4s2(x3, self.conv3, D)                                     # [B,16^3,256] bf16
+        else:
+            # conv3 on the occupied voxels only (<= P of 32768 per object in 144 of the 160 channels): compact rows,
+            # forward + data + weight gradients (csrc/sparseconv_bf16.hip); the occupancy channels stay dense
+            h3 = K.SparseConv3.apply(feat2, h_occ, pts, batch_indices, self.conv3.weight, self.conv3.bias, B, D)
         Dh = D // 2
         feat3 = K.InterpolateVoxelGridCL.apply(h3, pts / 2.0, batch_indices, Dh, batch_start)  # [n,256] bf16
         h4 = K.conv3d_k4s2(h3, self.conv4, Dh)                                        # [B,8^3,512] bf16

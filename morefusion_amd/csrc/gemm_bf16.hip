@@ -50,6 +50,10 @@ struct NtArgs {
   int64_t a_gs, w_gs, b_gs, o_gs;
   int M, N, K, lda, ldw, ldo, groups;
   int relu, out_f32, accumulate;
+  // rows mode only: weight group of every 64-row block of A (device array, -1 = no rows: the tile exits).  Row
+  // tiles must not straddle groups (the producer pads each group to a multiple of 128 rows): the compact
+  // parity-class rows of the sparse conv3 (csrc/sparseconv_bf16.hip) multiply their class's weight slice.
+  const int32_t *tile_group;
   // conv geometry: D = INPUT grid size, Do = OUTPUT grid size = 1 << olog; forward taps ks^3 at x = stride * o - pad
   // + dil * k per axis (dgrad: the k4 / s2 / p1 parity-class form only)
   int B, D, Do, olog, Cin, Cout, ks, stride, pad, dil;
@@ -78,6 +82,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
   const int Do = a.Do, dol = a.olog;
   const uint16_t *A = a.A + grp * a.a_gs;
   const uint16_t *W = a.W + grp * a.w_gs;
+  if (MODE == kRows && a.tile_group) {
+    const int g = a.tile_group[m0 >> 6];  // (block-uniform)
+    if (g < 0) return;
+    W += (int64_t)g * a.w_gs;
+  }
   int cls = 0;
   if (MODE == kConvDgrad) {  // tile-uniform parity class: its weight slice
     cls = (m0 >> (3 * dol)) & 7;
@@ -340,6 +349,7 @@ struct TnArgs {
   float *out;         // S == 1: C [Ni][ldc] (group g at out + g * c_gs); S > 1: slabs [S][groups][Ni][ldc]
   int64_t p_gs, q_gs, c_gs;
   int M, Ni, Nj, ldp, ldq, ldc, groups, S;
+  const int32_t *m_range;  // rows mode, S == 1: group g reduces rows [m_range[g], m_range[g + 1]) of P / Q (device array)
   int conv, B, D, Do, olog, Cin, ks, stride, pad, dil;  // conv: Q(m, j = tap * Cin + cin) = x[b][stride o - pad + dil tap][cin], m = (b, o)
 };
 
@@ -357,7 +367,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
   const int rem = rem0 - grp * per_group;
   const int i0 = (rem % tiles_i) * 128, j0 = (rem / tiles_i) * 128;  // i tile fastest: neighbours share Q columns
   // this split's rows: K-tiles of 64 rows, contiguous ranges
-  const int Tall = (a.M + 63) / 64;
+  int m_lo = 0, M = a.M;
+  if (!CONV && a.m_range) {  // (block-uniform)
+    m_lo = a.m_range[grp];
+    M = a.m_range[grp + 1] - m_lo;
+  }
+  const int Tall = (M + 63) / 64;
   const int Tper = (Tall + a.S - 1) / a.S;
   const int t0 = split * Tper, t1 = min(Tall, t0 + Tper);
 
@@ -372,8 +387,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
   const int st_off = sub * kTnSub + (4 * wave + kr) * 32 + 16 * half;  // + 512 r
   const int mrow = 16 * kr + 4 * wave;  // this lane's rows of a K-tile: mrow .. mrow + 3 (see MF_TN_LOAD)
 
-  const uint16_t *P = a.P + grp * a.p_gs;
-  const uint16_t *Q = a.Q + grp * a.q_gs;
+  const uint16_t *P = a.P + grp * a.p_gs + (int64_t)m_lo * a.ldp;
+  const uint16_t *Q = a.Q + grp * a.q_gs + (CONV ? 0 : (int64_t)m_lo * a.ldq);
   const int Do = a.Do, dol = a.olog;
   const bool pcol_ok = i0 + col + 8 <= a.Ni;
   // conv: this lane's column chunk is one (tap, cin .. cin + 7) for the whole loop, so per row only the output voxel
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
   // kernel's 29 VALU instructions per load: 7.3 per MFMA).
 #define MF_TN_LOAD(r_, rp_, rq_)                                                                      \
   {                                                                                                   \
-    const bool ok_ = mb_ + (r_) < a.M;                                                                \
+    const bool ok_ = mb_ + (r_) < M;                                                                \
     rp_ = mf::buf_load16(Prs, ok_ && pcol_ok ? 2u * (uint32_t)(pb_ + (r_) * a.ldp) : mf::kBufMasked); \
     bool qok_ = ok_ && qrow_ok_;                                                                      \
     if (CONV) qok_ = qok_ && (unsigned)(zrel_ + (r_)) <= span_z;                                      \
@@ -811,6 +826,50 @@ extern "C" int mf_linear_wgrad_bf16(const void *dY, int64_t y_gs, int32_t ldy, c
                          (const float *)ws, dW, per_slab, K, ldc, split, 0, w_gs, per_group, (int64_t)ldc, 0, 0);
   }
   return mf::check_launch("mf_linear_wgrad_bf16");
+}
+
+/* mf_linear_bf16 for rows that come in GROUPS with their own weights, the group of every 64-row block read from a
+ * device table (``tile_group`` [ceil(M / 64)], -1 = empty block; groups are padded to multiples of 128 rows by the
+ * producer): out[m][:] = A[m][:] W[group(m)]^T.  W: [n_groups][N][ldw] at group stride ``w_gs``.  No bias / ReLU. */
+extern "C" int mf_linear_bf16_tiles(const void *A, int32_t lda, const void *W, int64_t w_gs, int32_t ldw,
+                                    const int32_t *tile_group, void *out, int32_t ldo, int32_t M, int32_t N, int32_t K,
+                                    int32_t out_f32, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M <= 0 || N <= 0) return 0;
+  if (K <= 0 || K % 8 || lda % 8 || ldw % 8 || w_gs % 8 || lda < K || ldw < K || ldo < N || M % 128 || !tile_group ||
+      (((uintptr_t)A | (uintptr_t)W) & 15))
+    return bad("linear_bf16_tiles: K, lda, ldw, w_gs % 8 == 0, M % 128 == 0, 16-byte aligned A / W, a group table");
+  if ((int64_t)M * lda >= kMaxBf16Elems || (int64_t)N * ldw >= kMaxBf16Elems)
+    return bad("linear_bf16_tiles: an operand spans >= 2^31 bytes");
+  NtArgs a = {};
+  a.A = (const uint16_t *)A; a.W = (const uint16_t *)W; a.out = out;
+  a.w_gs = w_gs;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.groups = 1;
+  a.out_f32 = out_f32;
+  a.tile_group = tile_group;
+  if (int e = launch_nt<kRows>(a, stream)) return e;
+  return mf::check_launch("mf_linear_bf16_tiles");
+}
+
+/* mf_linear_wgrad_bf16 over row RANGES read from the device: dW[g][n][k] = sum over rows m in
+ * [m_range[g], m_range[g + 1]) of dY[m][n] A[m][k] for g < groups (ranges are multiples of 64 rows; rows of a range
+ * that hold no data must be zero in one operand).  dW fp32 [groups][N][ldc] at group stride ``w_gs``. */
+extern "C" int mf_linear_wgrad_bf16_ranges(const void *dY, int32_t ldy, const void *A, int32_t lda, float *dW,
+                                           int64_t w_gs, int32_t ldc, const int32_t *m_range, int32_t groups, int32_t N,
+                                           int32_t K, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N <= 0 || K <= 0 || groups <= 0) return 0;
+  if (N % 8 || K % 8 || ldy % 8 || lda % 8 || ldc < K || !m_range || (((uintptr_t)dY | (uintptr_t)A) & 15))
+    return bad("linear_wgrad_bf16_ranges: N, K, ldy, lda % 8 == 0, 16-byte aligned operands, a range table");
+  if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16<false>, kTnLds)) return e;
+  TnArgs a = {};
+  a.P = (const uint16_t *)dY; a.Q = (const uint16_t *)A; a.out = dW;
+  a.c_gs = w_gs;
+  a.M = 0; a.Ni = N; a.Nj = K; a.ldp = ldy; a.ldq = lda; a.ldc = ldc; a.groups = groups; a.S = 1;
+  a.m_range = m_range;
+  const int64_t grid = (int64_t)((N + 127) / 128) * ((K + 127) / 128) * groups;
+  hipLaunchKernelGGL(k_gemm_tn_bf16<false>, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
+  return mf::check_launch("mf_linear_wgrad_bf16_ranges");
 }
 
 /* Convolution3D on channels-last bf16 grids: kernel ks in {3, 4}, stride in {1, 2}, any pad / dilation whose output

@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void k_avgvox_cl_fwd(const uint16_t *__restric
                                                        const int32_t *__restrict__ counts,
                                                        const int32_t *__restrict__ head,
                                                        const int32_t *__restrict__ link, int64_t n, int C, int B, int D,
-                                                       uint16_t *__restrict__ x, int64_t ldx) {
+                                                       uint16_t *__restrict__ x, int64_t ldx,
+                                                       const int32_t *__restrict__ rowmap) {
   __shared__ int s_ids[4][64];
   __shared__ int s_sorted[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -190,7 +191,11 @@ __global__ __launch_bounds__(256) void k_avgvox_cl_fwd(const uint16_t *__restric
   const int64_t key = (int64_t)b * D * D * D + v;
   if (head[key] != (int32_t)i) return;  // one wave per occupied voxel: its chain head's
   const int cnt = counts[key];
-  uint16_t *dst = x + key * ldx;
+  // rowmap (the sparse conv3 of the training path, csrc/sparseconv_bf16.hip): the mean row goes to the voxel's
+  // COMPACT row instead of its place in a dense grid
+  const int64_t row = rowmap ? (int64_t)rowmap[key] : key;
+  if (row < 0) return;
+  uint16_t *dst = x + row * ldx;
   const float inv = (float)cnt;
   if (cnt <= 64) {
     if (lane == 0) {
@@ -240,7 +245,8 @@ __global__ __launch_bounds__(256) void k_avgvox_cl_bwd(const uint16_t *__restric
                                                        const float *__restrict__ points,
                                                        const int32_t *__restrict__ batch_indices,
                                                        const int32_t *__restrict__ counts, int64_t n, int C, int B,
-                                                       int D, uint16_t *__restrict__ gvalues, int64_t ldg) {
+                                                       int D, uint16_t *__restrict__ gvalues, int64_t ldg,
+                                                       const int32_t *__restrict__ rowmap) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + wave;
   if (i >= n) return;
@@ -248,13 +254,15 @@ __global__ __launch_bounds__(256) void k_avgvox_cl_bwd(const uint16_t *__restric
   bool has_nan;
   const bool ok = mf::voxel_of(points, i, 0.0f, 0.0f, 0.0f, 1.0f, D, D, D, v, has_nan);
   const int b = batch_indices[i];
-  const bool in = ok && b >= 0 && b < B;
+  bool in = ok && b >= 0 && b < B;
   const int64_t key = in ? (int64_t)b * D * D * D + v : 0;
   const float cnt = in ? (float)counts[key] : 1.0f;
+  const int64_t row = (in && rowmap) ? (int64_t)rowmap[key] : key;  // (gradient rows of the compact layout)
+  in = in && row >= 0;
   for (int c2 = lane; 2 * c2 < C; c2 += 64) {
     uint32_t w = 0u;
     if (in) {
-      const uint32_t g = *reinterpret_cast<const uint32_t *>(gx + key * ldx + 2 * c2);
+      const uint32_t g = *reinterpret_cast<const uint32_t *>(gx + row * ldx + 2 * c2);
       w = mf::pack_bf16x2(mf::bf16_lo(g) / cnt, mf::bf16_hi(g) / cnt);
     }
     *reinterpret_cast<uint32_t *>(gvalues + i * ldg + 2 * c2) = w;
@@ -347,7 +355,8 @@ extern "C" int mf_average_voxelization_cl_bf16_fwd(const void *values, int64_t l
   }
   if (n > 0)
     hipLaunchKernelGGL(k_avgvox_cl_fwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const uint16_t *)values,
-                       ldv, points, batch_indices, counts, head, link, n, C, B, D, (uint16_t *)x, ldx);
+                       ldv, points, batch_indices, counts, head, link, n, C, B, D, (uint16_t *)x, ldx,
+                       (const int32_t *)nullptr);
   return mf::check_launch("mf_average_voxelization_cl_bf16_fwd");
 }
 
@@ -359,8 +368,39 @@ extern "C" int mf_average_voxelization_cl_bf16_bwd(const void *gx, int64_t ldx, 
   hipStream_t stream = (hipStream_t)stream_;
   if (n <= 0 || C <= 0) return 0;
   hipLaunchKernelGGL(k_avgvox_cl_bwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const uint16_t *)gx, ldx,
-                     points, batch_indices, counts, n, C, B, D, (uint16_t *)gvalues, ldg);
+                     points, batch_indices, counts, n, C, B, D, (uint16_t *)gvalues, ldg, (const int32_t *)nullptr);
   return mf::check_launch("mf_average_voxelization_cl_bf16_bwd");
+}
+
+/* The same pair for COMPACT rows (csrc/sparseconv_bf16.hip: the sparse conv3 of the bf16 training path): the mean
+ * row of an occupied voxel goes to A[rowmap[voxel]] (rows the map does not name are left as they are: the caller
+ * zero-fills A), the backward reads the gradient rows through the same map.  counts / head / link / rowmap: the
+ * tables of mf_sparse_conv3_bf16_index (mf_sparse_conv3_bf16_tables). */
+extern "C" int mf_average_voxelization_rows_bf16_fwd(const void *values, int64_t ldv, const float *points,
+                                                     const int32_t *batch_indices, int64_t n, int32_t C, int32_t B,
+                                                     int32_t D, const int32_t *counts, const int32_t *head,
+                                                     const int32_t *link, const int32_t *rowmap, void *A, int64_t lda,
+                                                     mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n <= 0 || C <= 0) return 0;
+  if (C % 2 || ldv % 2 || lda % 2 || lda < C || ldv < C || !rowmap) {
+    mf::set_last_error(hipErrorInvalidValue, "average_voxelization_rows_bf16: even C, ldv, lda; a row map");
+    return -(int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(k_avgvox_cl_fwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const uint16_t *)values, ldv,
+                     points, batch_indices, counts, head, link, n, C, B, D, (uint16_t *)A, lda, rowmap);
+  return mf::check_launch("mf_average_voxelization_rows_bf16_fwd");
+}
+
+extern "C" int mf_average_voxelization_rows_bf16_bwd(const void *dA, int64_t lda, const float *points,
+                                                     const int32_t *batch_indices, const int32_t *counts,
+                                                     const int32_t *rowmap, int64_t n, int32_t C, int32_t B, int32_t D,
+                                                     void *gvalues, int64_t ldg, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(k_avgvox_cl_bwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, (const uint16_t *)dA, lda, points,
+                     batch_indices, counts, n, C, B, D, (uint16_t *)gvalues, ldg, rowmap);
+  return mf::check_launch("mf_average_voxelization_rows_bf16_bwd");
 }
 
 extern "C" int mf_max_voxelization_3d_fwd(const float *values, const float *points,

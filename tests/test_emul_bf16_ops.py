@@ -208,3 +208,84 @@ def test_channels_last_bf16_voxelization_and_sampling_vs_oracle(KV):
             gs.data_ptr(), c_small, spt.data_ptr(), bit.data_ptr(), bs.data_ptr(), n, B, c_small, X, X, X,
             got_s.data_ptr(), 0, _lib.stream_ptr()), "bwd")
         assert float((got_s - want_s).abs().max()) <= 1e-5 * float(want_s.abs().max()) + 1e-6
+
+
+@pytest.fixture()
+def KS(monkeypatch):
+    """bf16_ops over the emulated engines + the sparse conv3 kernels + the voxelization kernels."""
+    from morefusion_amd import _lib
+    from morefusion_amd.contrib.singleview_3d.models import bf16_ops
+    L = emul.build(["gemm_bf16.hip", "sparseconv_bf16.hip", "voxelize.hip"])
+    for name, (argtypes, restype) in _lib._SIGNATURES.items():
+        fn = getattr(L, name, None)
+        if fn is not None:
+            fn.argtypes, fn.restype = argtypes, restype
+    monkeypatch.setattr(_lib, "lib", lambda: L)
+    monkeypatch.setattr(_lib, "require_gpu", lambda *a: None)
+    monkeypatch.setattr(_lib, "stream_ptr", lambda: None)
+    monkeypatch.setattr(_lib, "check", lambda code, what: (_ for _ in ()).throw(RuntimeError(what)) if code else None)
+    return bf16_ops
+
+
+@pytest.mark.parametrize("with_occ", [True, False])
+def test_sparse_conv3_operator_forward_and_all_gradients_vs_dense_float32(KS, with_occ):
+    """SparseConv3 (csrc/sparseconv_bf16.hip, round 5): conv3 on the compact rows of the occupied voxels + the dense
+    engine on the occupancy channels, against torch's float32 ``conv3d`` over the DENSE grid built from the same
+    bf16-rounded operands (model.py:113-128: average_voxelization_3d -> concat -> conv3 -> ReLU): values, and the
+    gradients to the point rows (through the voxel means), to the occupancy channels, to the weight (both channel
+    ranges) and to the bias.  Points sit on and outside the grid faces, several share a voxel, one class of the
+    k4 / s2 / p1 parity split stays empty in the second batch item."""
+    torch.manual_seed(1)
+    rs = np.random.RandomState(3)
+    B, D, Cs, Co, Cout = 2, 16, 16, 8 if with_occ else 0, 256   # (the k4s2 data gradient wants (D / 2)^3 % 128 == 0)
+    n0 = 70
+    pts = rs.uniform(-0.4, D - 0.6, (2 * n0, 3)).astype(np.float32)
+    pts[:6] = rs.uniform(-2, D + 1, (6, 3))                  # outside the grid
+    pts[6:12] = pts[12:18] + rs.uniform(-0.2, 0.2, (6, 3))   # shared voxels
+    pts[n0:] = np.round(pts[n0:] / 2) * 2 + 0.1              # item 1: even coordinates only -> one parity class
+    pts = np.clip(pts, -3, D + 2).astype(np.float32)
+    bi = np.repeat(np.arange(B, dtype=np.int32), n0)
+    conv = torch.nn.Conv3d(Cs + Co, Cout, 4, 2, padding=1)
+    feat = torch.randn(2 * n0, Cs).to(torch.bfloat16).requires_grad_(True)
+    hocc = torch.randn(B, D ** 3, Co).to(torch.bfloat16).requires_grad_(True) if with_occ else None
+    out = KS.SparseConv3.apply(feat, hocc, torch.from_numpy(pts), torch.from_numpy(bi), conv.weight, conv.bias, B, D)
+    g = torch.randn(out.shape).to(torch.bfloat16)
+    out.backward(g)
+
+    # reference: dense grid of bf16-rounded voxel means (fp32 sum in point order, one rounding), float32 convolution
+    fr = feat.detach().float().requires_grad_(True)
+    idx = np.round(pts).astype(np.int64)
+    ok = ((idx >= 0) & (idx < D)).all(1)
+    key = bi.astype(np.int64) * D ** 3 + (idx[:, 0] * D + idx[:, 1]) * D + idx[:, 2]
+    keys = torch.from_numpy(np.where(ok, key, 0))
+    okt = torch.from_numpy(ok)
+    cnt = torch.zeros(B * D ** 3).index_add_(0, keys[okt], torch.ones(int(ok.sum())))
+    sums = torch.zeros(B * D ** 3, Cs).index_add_(0, keys[okt], fr[okt])
+    means = sums / cnt.clamp(min=1)[:, None]
+    means_b = means + (means.detach().to(torch.bfloat16).float() - means.detach())   # value rounded, gradient straight through
+    x = means_b.reshape(B, D, D, D, Cs)
+    if with_occ:
+        hr = hocc.detach().float().requires_grad_(True)
+        x = torch.cat((x, hr.reshape(B, D, D, D, Co)), dim=4)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True)
+    y_pre = F.conv3d(x.permute(0, 4, 1, 2, 3), wr, br, stride=2, padding=1)
+    y_cl = F.relu(y_pre).detach().permute(0, 2, 3, 4, 1).reshape(B, -1, Cout)
+    assert rel(out, y_cl) < 2 ** -7
+    # The sparse contributions are rounded to bf16 row by row before they are summed, so a pre-activation next to 0
+    # can land on the other side of the ReLU than the float32 reference's (each flip moves a whole gradient row by
+    # a few per cent of the maximum): the gradient kernels are checked with the OPERATOR's mask, the masks
+    # themselves must agree on all but a fraction of the elements.
+    mask = (out.detach().float() > 0)
+    flips = (mask != (y_cl > 0)).float().mean()
+    assert float(flips) < 5e-3
+    gz = (g.float() * mask).reshape(B, D // 2, D // 2, D // 2, Cout).permute(0, 4, 1, 2, 3)
+    y_pre.backward(gz)
+    assert int(ok.sum()) < 2 * n0 and int((cnt > 1).sum()) >= 3
+    assert rel(feat.grad, fr.grad) < 1e-2                      # (bf16 gradient rows)
+    assert float(feat.grad[~okt].abs().max()) == 0.0           # points outside the grid receive nothing
+    assert rel(conv.weight.grad[:, :Cs], wr.grad[:, :Cs]) < 1e-2
+    assert rel(conv.bias.grad, br.grad) < 1e-2
+    if with_occ:
+        assert rel(conv.weight.grad[:, Cs:], wr.grad[:, Cs:]) < 1e-2
+        assert rel(hocc.grad, hr.grad) < 1e-2

@@ -170,3 +170,71 @@ def test_channels_last_sampler_forward_backward_vs_oracle(B, X, C, P, sorted_row
     gv = O.interpolate_voxel_grid_backward(g.float().numpy(), sp, bi, (B, C, X, X, X))
     gv_cl = torch.from_numpy(gv).reshape(B, C, X ** 3).transpose(1, 2)
     assert float((vg.grad.float().cpu() - gv_cl).abs().max()) <= 2.0 ** -7 * float(gv_cl.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("B,P", [(4, 1000), (1, 300)])
+def test_sparse_conv3_forward_and_all_gradients_vs_float32_dense_conv3d(B, P):
+    """SparseConv3 (round 5, csrc/sparseconv_bf16.hip) at the network's shapes -- 144 voxelized channels as compact
+    rows of the occupied voxels + 16 dense occupancy channels, conv3 = Convolution3D(160, 256, 4, 2, pad=1) + ReLU
+    (model.py:73,113-128) -- against torch's float32 ``conv3d`` over the dense grid built from the same bf16-rounded
+    operands: values within one bf16 rounding, the ReLU masks agree on all but a sliver, and with the operator's mask
+    the gradients to the point rows (through the voxel means), to the occupancy channels, to both channel ranges of
+    the weight and to the bias agree to 1 % -- and the dense bf16 engines on the [B, 32^3, 160] grid (round 4's path)
+    give the same result."""
+    torch.manual_seed(0)
+    rs = np.random.RandomState(1)
+    D, Cs, Co, Cout = 32, 144, 16, 256
+    n = B * P
+    # a surface-like cloud: points on a sphere shell + noise, some outside the grid
+    u = rs.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    pts = (15.5 + 11.0 * u + rs.normal(scale=0.4, size=(n, 3))).astype(np.float32)
+    pts[:5] = rs.uniform(-3, D + 2, (5, 3))
+    bi = np.repeat(np.arange(B, dtype=np.int32), P)
+    dev = torch.device("cuda", 0)
+    conv = torch.nn.Conv3d(Cs + Co, Cout, 4, 2, padding=1).to(dev)
+    feat = torch.randn(n, Cs, device=dev).to(torch.bfloat16).requires_grad_(True)
+    hocc = torch.randn(B, D ** 3, Co, device=dev).to(torch.bfloat16).requires_grad_(True)
+    pts_d, bi_d = torch.from_numpy(pts).to(dev), torch.from_numpy(bi).to(dev)
+    out = K.SparseConv3.apply(feat, hocc, pts_d, bi_d, conv.weight, conv.bias, B, D)
+    g = torch.randn(out.shape, device=dev).to(torch.bfloat16)
+    out.backward(g)
+    got = dict(out=out.detach(), feat=feat.grad.clone(), occ=hocc.grad.clone(), w=conv.weight.grad.clone(),
+               b=conv.bias.grad.clone())
+
+    # float32 reference on the dense grid
+    fr = feat.detach().float().requires_grad_(True)
+    idx = np.round(pts).astype(np.int64)
+    ok = ((idx >= 0) & (idx < D)).all(1)
+    key = bi.astype(np.int64) * D ** 3 + (idx[:, 0] * D + idx[:, 1]) * D + idx[:, 2]
+    keys, okt = torch.from_numpy(np.where(ok, key, 0)).to(dev), torch.from_numpy(ok).to(dev)
+    cnt = torch.zeros(B * D ** 3, device=dev).index_add_(0, keys[okt], torch.ones(int(ok.sum()), device=dev))
+    sums = torch.zeros(B * D ** 3, Cs, device=dev).index_add_(0, keys[okt], fr[okt])
+    means = sums / cnt.clamp(min=1)[:, None]
+    means_b = means + (means.detach().to(torch.bfloat16).float() - means.detach())
+    hr = hocc.detach().float().requires_grad_(True)
+    x = torch.cat((means_b.reshape(B, D, D, D, Cs), hr.reshape(B, D, D, D, Co)), dim=4)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True)
+    y_pre = F.conv3d(x.permute(0, 4, 1, 2, 3), wr, br, stride=2, padding=1)
+    y_cl = F.relu(y_pre).detach().permute(0, 2, 3, 4, 1).reshape(B, -1, Cout)
+    assert rel(got["out"], y_cl) < 2 ** -7
+    mask = got["out"].float() > 0
+    assert float((mask != (y_cl > 0)).float().mean()) < 5e-3
+    y_pre.backward((g.float() * mask).reshape(B, D // 2, D // 2, D // 2, Cout).permute(0, 4, 1, 2, 3))
+    assert rel(got["feat"], fr.grad) < 1e-2 and float(got["feat"][~okt].abs().max()) == 0.0
+    assert rel(got["occ"], hr.grad) < 1e-2
+    assert rel(got["w"][:, :Cs], wr.grad[:, :Cs]) < 1e-2 and rel(got["w"][:, Cs:], wr.grad[:, Cs:]) < 1e-2
+    assert rel(got["b"], br.grad) < 1e-2
+    assert int((cnt > 1).sum()) > 10 and int(ok.sum()) < n
+
+    # round 4's dense path on the same operands: the same operator result up to bf16 rounding
+    conv.zero_grad()
+    f2 = feat.detach().clone().requires_grad_(True)
+    h2 = hocc.detach().clone().requires_grad_(True)
+    x3 = K.AverageVoxelizationCL.apply(f2, pts_d, bi_d, B, D, Cs + Co)
+    x3 = torch.cat((x3[:, :, :Cs], h2), dim=2)
+    out_d = K.conv3d_k4s2(x3, conv, D)
+    out_d.backward(g)
+    assert rel(out_d, got["out"]) < 2 ** -6
+    grad_close(f2.grad, got["feat"])
+    grad_close(conv.weight.grad, got["w"])

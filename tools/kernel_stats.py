@@ -30,6 +30,12 @@ def main():
         if len(marks) >= 3:
             rows = rows[marks[1] + 1: marks[2]]
             note = f"launches between the 2nd and 3rd {mark}"
+    if os.environ.get("MF_SEQ"):  # the launches in order: index, start offset (us), duration (us), name
+        t0 = int(rows[0]["Start_Timestamp"]) if rows else 0
+        with open(os.environ["MF_SEQ"], "w") as f:
+            for i, r in enumerate(rows):
+                f.write(f'{i},{(int(r["Start_Timestamp"]) - t0) / 1e3:.1f},'
+                        f'{(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3:.1f},{short(r["Kernel_Name"])}\n')
     agg = collections.OrderedDict()
     for r in rows:
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
