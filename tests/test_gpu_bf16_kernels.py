@@ -236,5 +236,9 @@ def test_sparse_conv3_forward_and_all_gradients_vs_float32_dense_conv3d(B, P):
     out_d = K.conv3d_k4s2(x3, conv, D)
     out_d.backward(g)
     assert rel(out_d, got["out"]) < 2 ** -6
-    grad_close(f2.grad, got["feat"])
-    grad_close(conv.weight.grad, got["w"])
+
+    def l2(a, b):
+        return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+
+    # (two bf16 paths, each with its own ReLU mask next to zero: twice the flip noise of a comparison with float32)
+    assert l2(f2.grad, got["feat"]) < 5e-2 and l2(conv.weight.grad, got["w"]) < 5e-2
