@@ -458,6 +458,11 @@ int mf_linear_bf16_tiles(const void *A, int32_t lda, const void *W, int64_t w_gr
 int mf_linear_wgrad_bf16_ranges(const void *dY, int32_t ldy, const void *A, int32_t lda, float *dW,
                                 int64_t w_group_stride, int32_t ldc, const int32_t *m_range, int32_t groups, int32_t N,
                                 int32_t K, mfStream_t stream);
+/* Narrow-input data gradient of Convolution3D(.., 4, 2, pad=1) "columns first" (the 16 occupancy channels of conv3):
+ * W2 bf16 [64 Cin][Cout]; T [B (D/2)^3][64 Cin] = dz W2^T through mf_linear_bf16; dx [B, D^3, Cin] = col2im gather. */
+int mf_conv3d_k4s2_bf16_pack_cols(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin, int32_t c_off, void *W2,
+                                  mfStream_t stream);
+int mf_conv3d_k4s2_bf16_col2im(const void *T, int32_t B, int32_t D, int32_t Cin, void *dx, mfStream_t stream);
 int mf_average_voxelization_rows_bf16_fwd(const void *values, int64_t ldv, const float *points,
                                           const int32_t *batch_indices, int64_t n, int32_t C, int32_t B, int32_t D,
                                           const int32_t *counts, const int32_t *head, const int32_t *link,

@@ -104,6 +104,8 @@ _SIGNATURES = {
     "mf_sparse_conv3_bf16_gather_dy": ([_p, _p, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p], _i),
     "mf_linear_bf16_tiles": ([_p, ctypes.c_int32, _p, _i64, ctypes.c_int32, _p, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p], _i),
     "mf_linear_wgrad_bf16_ranges": ([_p, ctypes.c_int32, _p, ctypes.c_int32, _p, _i64, ctypes.c_int32, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p], _i),
+    "mf_conv3d_k4s2_bf16_pack_cols": ([_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p], _i),
+    "mf_conv3d_k4s2_bf16_col2im": ([_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p], _i),
     "mf_average_voxelization_rows_bf16_fwd": ([_p, _i64, _p, _p, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p, _p, _p, _p, _i64, _p], _i),
     "mf_average_voxelization_rows_bf16_bwd": ([_p, _i64, _p, _p, _p, _p, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _i64, _p], _i),
     "mf_average_voxelization_cl_bf16_fwd": ([_p, _i64, _p, _p, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _i64,

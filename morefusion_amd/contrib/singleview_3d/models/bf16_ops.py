@@ -322,9 +322,12 @@ class SparseConv3(torch.autograd.Function):
         if h_occ is not None:  # the dense channels: the dense engine at Cin = Co, fp32 pre-activation, no bias
             h_occ = _bf16c(h_occ)
             wt = _empty((Cout, 64, Co), BF16, feat2)
-            wd = _empty((8, Co, 8, Cout), BF16, feat2) if need_do else None
-            _lib.check(L.mf_conv3d_bf16_pack(w32.data_ptr(), Cout, Co, w_cin, Cs, 4, wt.data_ptr(), _lib.ptr(wd), None,
+            _lib.check(L.mf_conv3d_bf16_pack(w32.data_ptr(), Cout, Co, w_cin, Cs, 4, wt.data_ptr(), None, None,
                                              _lib.stream_ptr()), "mf_conv3d_bf16_pack")
+            if need_do:  # data-gradient operand of the narrow "columns first" form: [64 Co][Cout]
+                wd = _empty((64 * Co, Cout), BF16, feat2)
+                _lib.check(L.mf_conv3d_k4s2_bf16_pack_cols(w32.data_ptr(), Cout, Co, w_cin, Cs, wd.data_ptr(),
+                                                           _lib.stream_ptr()), "mf_conv3d_k4s2_bf16_pack_cols")
             dense = _empty((B, Vo, Cout), torch.float32, feat2)
             _lib.check(L.mf_conv3d_bf16_fwd(h_occ.data_ptr(), wt.data_ptr(), None, dense.data_ptr(), B, Co, Cout, D, 4, 2, 1,
                                             1, 0, 1, Cout, _lib.stream_ptr()), "mf_conv3d_bf16_fwd (occupancy channels)")
@@ -357,9 +360,16 @@ class SparseConv3(torch.autograd.Function):
                                                                t_rowmap, n, Cs, B, D, dfeat.data_ptr(), Cs,
                                                                _lib.stream_ptr()), "mf_average_voxelization_rows_bf16_bwd")
         if h_occ is not None and ctx.needs_input_grad[1]:
+            # columns first: T[o][tap * Co + c] = dz[o] . W[:, c, tap] (one plain GEMM, dz read once), then every
+            # input voxel gathers its 8 contributions (the parity-class engine paid a 128-column tile and 2.1 GB of
+            # gathered operand reads for these 16 columns: 268 us -> measured below 130)
+            Mo = B * (D // 2) ** 3
+            T = _empty((Mo, 64 * Co), BF16, dz)
+            _lib.check(L.mf_linear_bf16(dz.data_ptr(), 0, Cout, wd.data_ptr(), 0, Cout, None, 0, T.data_ptr(), 0, 64 * Co, Mo,
+                                        64 * Co, Cout, 1, 0, 0, 0, _lib.stream_ptr()), "mf_linear_bf16 (occupancy dgrad)")
             docc = torch.empty_like(h_occ)
-            _lib.check(L.mf_conv3d_k4s2_bf16_dgrad(dz.data_ptr(), wd.data_ptr(), docc.data_ptr(), B, Co, Cout, D, 0, 0,
-                                                   _lib.stream_ptr()), "mf_conv3d_k4s2_bf16_dgrad (occupancy channels)")
+            _lib.check(L.mf_conv3d_k4s2_bf16_col2im(T.data_ptr(), B, D, Co, docc.data_ptr(), _lib.stream_ptr()),
+                       "mf_conv3d_k4s2_bf16_col2im")
         if ctx.needs_input_grad[4]:
             dWp = _empty((8, N8, Cs), torch.float32, dz)
             _lib.check(L.mf_linear_wgrad_bf16_ranges(dYg.data_ptr(), N8, A.data_ptr(), Cs, dWp.data_ptr(), N8 * Cs, Cs,

@@ -277,6 +277,54 @@ __global__ __launch_bounds__(256) void k_scb_gather_dy(const uint16_t *__restric
   }
 }
 
+// ---- data gradient of the k4 / s2 / p1 convolution for a NARROW input (the 16 occupancy channels) ---------------
+// The parity-class engine (k_gemm_nt_bf16<conv dgrad>) gathers 8 x Cout gradient values per input voxel and pays a
+// 128-column tile for Cin = 16 columns: 268 us at B = 16, bound by the 2.1 GB of gathered operand reads.  Turned
+// around -- "columns first": T[o][tap * Cin + c] = sum_co dz[o][co] W[co][c][tap] is ONE plain GEMM over the output
+// voxels (dz read once: 33 MB), then every input voxel sums its 8 contributions (col2im as a gather: deterministic).
+// W2[n = tap * Cin + c][k = co] bf16 from W fp32 [Cout][w_cin][64], channels c_off ..
+__global__ void k_scb_pack_cols(const float *__restrict__ W, int Cout, int Cin, int w_cin, int c_off,
+                                uint16_t *__restrict__ W2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)64 * Cin * Cout;
+  if (i >= total) return;
+  const int co = (int)(i % Cout);
+  const int c = (int)((i / Cout) % Cin);
+  const int tap = (int)(i / ((int64_t)Cout * Cin));
+  W2[i] = (uint16_t)mf::bf16_bits(W[((int64_t)co * w_cin + c_off + c) * 64 + tap]);
+}
+
+// dx[b][v][c0 .. c0 + 7] = sum over the 8 slots of T[b][o(v, slot)][tap(v, slot) * Cin + c0 ..] (fp32 sum in slot
+// order, outputs outside the grid skipped): one lane per (input voxel, 8-channel chunk)
+__global__ __launch_bounds__(256) void k_scb_col2im(const uint16_t *__restrict__ T, int B, int D, int Cin,
+                                                    uint16_t *__restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int chunks = Cin / 8;
+  const int64_t V = (int64_t)D * D * D, total = (int64_t)B * V * chunks;
+  if (i >= total) return;
+  const int ch = (int)(i % chunks);
+  const int64_t bv = i / chunks;
+  const int b = (int)(bv / V), v = (int)(bv % V);
+  const int vx = v / (D * D), vy = (v / D) % D, vz = v % D;
+  const int Do = D / 2;
+  const int64_t Vo = (int64_t)Do * Do * Do, ldt = (int64_t)64 * Cin;
+  const int px = (vx + 1) & 1, py = (vy + 1) & 1, pz = (vz + 1) & 1;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int slot = 0; slot < 8; ++slot) {
+    const int ax = slot & 1, ay = (slot >> 1) & 1, az = (slot >> 2) & 1;
+    const int ox = ((vx + 1) >> 1) - ax, oy = ((vy + 1) >> 1) - ay, oz = ((vz + 1) >> 1) - az;
+    if (ox < 0 || ox >= Do || oy < 0 || oy >= Do || oz < 0 || oz >= Do) continue;
+    const int tap = ((px + 2 * ax) * 4 + (py + 2 * ay)) * 4 + (pz + 2 * az);
+    const uint4 w = *reinterpret_cast<const uint4 *>(T + ((int64_t)b * Vo + (ox * Do + oy) * Do + oz) * ldt + tap * Cin + 8 * ch);
+    acc[0] += mf::bf16_lo(w.x); acc[1] += mf::bf16_hi(w.x); acc[2] += mf::bf16_lo(w.y); acc[3] += mf::bf16_hi(w.y);
+    acc[4] += mf::bf16_lo(w.z); acc[5] += mf::bf16_hi(w.z); acc[6] += mf::bf16_lo(w.w); acc[7] += mf::bf16_hi(w.w);
+  }
+  *reinterpret_cast<uint4 *>(dx + bv * Cin + 8 * ch) =
+      make_uint4(mf::pack_bf16x2(acc[0], acc[1]), mf::pack_bf16x2(acc[2], acc[3]), mf::pack_bf16x2(acc[4], acc[5]),
+                 mf::pack_bf16x2(acc[6], acc[7]));
+}
+
 int bad(const char *msg) {
   mf::set_last_error(hipErrorInvalidValue, msg);
   return -(int)hipErrorInvalidValue;
@@ -381,4 +429,28 @@ extern "C" int mf_sparse_conv3_bf16_gather_dy(const void *dz, void *ws, int64_t 
   hipLaunchKernelGGL(k_scb_gather_dy, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, (const uint16_t *)dz, w.rowvox,
                      w.class_off, D, Cout, (uint16_t *)dYg);
   return mf::check_launch("mf_sparse_conv3_bf16_gather_dy");
+}
+
+/* Narrow-input data gradient of Convolution3D(.., 4, 2, pad=1), "columns first" (see k_scb_pack_cols):
+ *   mf_conv3d_k4s2_bf16_pack_cols   W fp32 [Cout, w_cin, 4,4,4] channels c_off .. c_off + Cin -> W2 bf16 [64 Cin][Cout]
+ *   T [B (D/2)^3][64 Cin] = dz W2^T is a plain mf_linear_bf16 call (the caller's)
+ *   mf_conv3d_k4s2_bf16_col2im      dx [B, D^3, Cin] bf16 = the 8 contributions of every input voxel, summed */
+extern "C" int mf_conv3d_k4s2_bf16_pack_cols(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin, int32_t c_off,
+                                             void *W2, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (Cout <= 0 || Cin <= 0 || Cout % 8 || c_off < 0 || c_off + Cin > w_cin) return bad("conv3d_k4s2_bf16_pack_cols: Cout % 8 == 0, c_off + Cin <= w_cin");
+  const int64_t total = (int64_t)64 * Cin * Cout;
+  hipLaunchKernelGGL(k_scb_pack_cols, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, W, Cout, Cin, w_cin, c_off,
+                     (uint16_t *)W2);
+  return mf::check_launch("mf_conv3d_k4s2_bf16_pack_cols");
+}
+
+extern "C" int mf_conv3d_k4s2_bf16_col2im(const void *T, int32_t B, int32_t D, int32_t Cin, void *dx, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0) return 0;
+  if (Cin % 8 || D % 2) return bad("conv3d_k4s2_bf16_col2im: Cin % 8 == 0, even D");
+  const int64_t total = (int64_t)B * D * D * D * (Cin / 8);
+  hipLaunchKernelGGL(k_scb_col2im, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)T, B, D, Cin,
+                     (uint16_t *)dx);
+  return mf::check_launch("mf_conv3d_k4s2_bf16_col2im");
 }

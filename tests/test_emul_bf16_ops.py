@@ -237,7 +237,7 @@ def test_sparse_conv3_operator_forward_and_all_gradients_vs_dense_float32(KS, wi
     k4 / s2 / p1 parity split stays empty in the second batch item."""
     torch.manual_seed(1)
     rs = np.random.RandomState(3)
-    B, D, Cs, Co, Cout = 2, 16, 16, 8 if with_occ else 0, 256   # (the k4s2 data gradient wants (D / 2)^3 % 128 == 0)
+    B, D, Cs, Co, Cout = 2, 8, 16, 8 if with_occ else 0, 256
     n0 = 70
     pts = rs.uniform(-0.4, D - 0.6, (2 * n0, 3)).astype(np.float32)
     pts[:6] = rs.uniform(-2, D + 1, (6, 3))                  # outside the grid
