@@ -394,7 +394,7 @@ def roofline_icc(wl, us_per_iter):
     kname = "k_icc_fused" if single_pass else "k_icc_tile"
     achieved = alg / (ms * 1e-3) / 1e9
     traffic = None  # PMC passes of THIS round committed under profiles/ (tools/gpu_call.sh pmc=...), same scene; else null
-    for name in ("r04_icc_pmc.json", "r03_icc_pmc.json"):  # newest PMC passes of these kernels, same scene
+    for name in ("r05_icc_pmc.json", "r04_icc_pmc.json", "r03_icc_pmc.json"):  # newest PMC passes of these kernels, same scene
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             rec = json.load(open(pmc)).get(kname)
