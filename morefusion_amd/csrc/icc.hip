@@ -130,6 +130,7 @@ struct IccArgs {
   int uniform_ns;         // > 0: every scene holds exactly this many objects (scene tables need no load)
   int64_t rec_stride;     // records of one of the TWO record buffers (k_icc_iter reads one, fills the other)
   int64_t par_cnt;        // words of bin_cnt per parity = 2 * O * nbins (three parities)
+  int xcd_order;          // k_icc_fused: XCD-contiguous logical workgroup order (see there)
 };
 
 using mf::quat_backward;
@@ -591,13 +592,17 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
       g_dbg_stamps[(3072 + blockIdx.x) * 8 + i] = wall_clock64();
   };
   stamp(0);
-  const int4 e = a.tab[blockIdx.x];
+  // (batches of >= 32 objects: the same XCD-contiguous logical order as k_icc_fused -- the workgroups that bin for a
+  // grid run on the XCD whose L2 its tiles will read the records from)
+  int bi = blockIdx.x;
+  if (a.xcd_order && (gridDim.x & 7) == 0) bi = (bi & 7) * (int)(gridDim.x >> 3) + (bi >> 3);
+  const int4 e = a.tab[bi];
   const int o = e.x, j = e.y;
   if (o < 0) return;  // block-uniform
   const int D = a.D, nb = a.nbins, hmax = a.hmax;
   const int g = 2 * o + (j != o ? 1 : 0);
   // everything below depends on the table entries only: one memory round trip
-  const int4 e2 = a.tab2[blockIdx.x];  // {scene first object, objects in scene, scene, designated}
+  const int4 e2 = a.tab2[bi];  // {scene first object, objects in scene, scene, designated}
   float4 r0, r1, r2;
   float S_t = 1.0f;
   if (sp.mode == 0) {
@@ -1620,7 +1625,8 @@ __device__ __forceinline__ void icc_voxel_phase(const IccArgs &a, const int par,
 }
 
 template <int KS>
-__device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt, const int par, FusedLds &L) {
+__device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt, const int par, FusedLds &L,
+                                               const int o, const int tile_) {
   MF_DYN_LDS(uint32_t, s_tile);  // dist[2][nvh] | id[2][nvh] | rows2[max_ns][32][13] floats
   auto &s_rows = L.v.rows;
   auto &s_Rt = L.Rt;
@@ -1628,8 +1634,7 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   const int ks = KS > 0 ? KS : ks_rt;
   const int h = ks / 2, K = ks * ks * ks;
   const int D = a.D, nb = a.nbins, hmax = a.hmax, V = D * D * D;
-  const int o = blockIdx.y;
-  const int x = blockIdx.x / kHalves, half = blockIdx.x % kHalves;
+  const int x = tile_ / kHalves, half = tile_ % kHalves;
   const int Dh = (D + 1) / 2;
   const int y0 = half * Dh, y1 = half == 0 ? Dh : D;
   const int Wp = D + 2 * kPad, rows_p = Dh + 2 * kPad;  // padded tile (see icc_visit3)
@@ -1804,11 +1809,26 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
 
 __global__ __launch_bounds__(kTileThreads, 4) void k_icc_fused(IccArgs a, int par) {  // 2 workgroups per CU
   __shared__ FusedLds L;
-  const int ks = min(ksize_of(a.thr, a.pitch[blockIdx.y]), 2 * a.hmax + 1);  // block-uniform
+  // Workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md): with the plain (tile, object)
+  // numbering the 64 tiles of a grid are spread over all eight L2s and each of them fetches the grid's records,
+  // points and voxels over the fabric.  XCD-contiguous logical order (a.dbg bit 2048 for now): XCD k takes the logical
+  // workgroups [k G/8, (k + 1) G/8) -- whole objects -- and inside an XCD workgroups i and i + 32 share a CU: planes x
+  // and x + 16, a central with an outer one.  *Measured* (round 5): 8 scenes x 8 objects 96.6 -> 89.5 us per
+  // iteration (the working set of a grid stays in one L2), but ONE scene 23.0 -> 24.2 us: eight objects of different
+  // size on eight XCDs, the largest one's XCD is the straggler, while the plain order spreads every object over all
+  // of them.  Hence by batch size: a.xcd_order is set for >= 32 objects (MF_ICC_DEBUG bit 2048 forces it on, 4096
+  // off; bit 1024: the plane rotation that was measured slower, 24.0 vs 22.6 us).
+  int lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int G_ = gridDim.x * gridDim.y;
+  if (a.xcd_order && (G_ & 7) == 0) lin = (lin & 7) * (G_ >> 3) + (lin >> 3);
+  const int o = lin / (int)gridDim.x;
+  const int bx_ = lin - o * (int)gridDim.x;
+  const int tile_ = (a.dbg & 1024) ? (int)((bx_ + ((lin >> 8) & 1) * (int)(gridDim.x / 2)) % (int)gridDim.x) : bx_;
+  const int ks = min(ksize_of(a.thr, a.pitch[o]), 2 * a.hmax + 1);  // block-uniform
   if (ks == 3)
-    icc_fused_body<3>(a, 3, par, L);
+    icc_fused_body<3>(a, 3, par, L, o, tile_);
   else
-    icc_fused_body<0>(a, ks, par, L);
+    icc_fused_body<0>(a, ks, par, L, o, tile_);
 }
 
 // ---- ONE launch per iteration (round 5): k_icc_iter ------------------------------------------------------
@@ -2538,6 +2558,7 @@ WsLayout ws_layout(const mfIccBatch *b) {
   // every (target, source) pair of a scene in chunks of kBinChunk points:
   // sum_pairs ceil(P_j / chunk) <= max_ns * n_points / chunk + O * max_ns (+ O designated entries)
   l.n_tab = (int)(((int64_t)max_ns * b->n_points + kBinChunk - 1) / kBinChunk) + O * max_ns + O;
+  l.n_tab = (l.n_tab + 7) & ~7;  // (a multiple of 8: the XCD-contiguous order of k_icc_bin)
   int64_t off = 0;
   l.W = off; off = align256(off + 2 * O * V * 8);
   l.M = off; off = align256(off + kParities * 2 * O * 4);
@@ -2616,6 +2637,7 @@ IccArgs make_args(const mfIccBatch *b, void *ws) {
   a.mg = 0;
   a.rec_model = 0;
   a.uniform_ns = (int64_t)b->n_scenes * b->max_scene_objects == b->n_objects ? b->max_scene_objects : 0;
+  a.xcd_order = ((a.O >= 32) || (a.dbg & 2048)) && !(a.dbg & 4096);
   return a;
 }
 
@@ -2830,6 +2852,7 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
   key.v.push_back(((uint64_t)(uint32_t)dev << 32) | ((uint32_t)max_ns << 1) | (uint32_t)a.ne_binary);
   const bool iter = icc_use_iter(batch, a, l);
   key.v.push_back(((uint64_t)(iter ? 1u : 0u) << 32) | (uint64_t)(uint32_t)a.bin_cap_force);
+  key.v.push_back((uint64_t)(uint32_t)a.dbg);
 
   std::lock_guard<std::mutex> lock(g_graph_mu);
   auto itg = g_graphs.find(key);
