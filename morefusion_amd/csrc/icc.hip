@@ -1682,6 +1682,15 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   };
   stamp(0);
   if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + 6] = (unsigned long long)(c[0][7] + c[1][7]);
+#if MF_ICC_DEBUG_BUILD
+  if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) {  // where did this workgroup run? (HW_ID: CU / SH / SE; XCC_ID)
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_dbg_stamps[(2048 + wg) * 8 + 0] = hw;
+    g_dbg_stamps[(2048 + wg) * 8 + 1] = xcc;
+  }
+#endif
   // the voxel phase's first-level loads, issued now: this lane's voxel of the two input grids
   float ne0 = 0.0f, tg0 = 0.0f;
   if ((int)threadIdx.x < nvox) {
@@ -1817,13 +1826,14 @@ __global__ __launch_bounds__(kTileThreads, 4) void k_icc_fused(IccArgs a, int pa
   // iteration (the working set of a grid stays in one L2), but ONE scene 23.0 -> 24.2 us: eight objects of different
   // size on eight XCDs, the largest one's XCD is the straggler, while the plain order spreads every object over all
   // of them.  Hence by batch size: a.xcd_order is set for >= 32 objects (MF_ICC_DEBUG bit 2048 forces it on, 4096
-  // off; bit 1024: the plane rotation that was measured slower, 24.0 vs 22.6 us).
+  // off).  Two other placements for ONE scene, both measured slower than the plain order (22.6-22.9 us) and removed:
+  // planes rotated by D / 2 in every other block of 256 workgroups (a central next to an outer plane on a CU:
+  // 23.9-24.1), centre-out dispatch with the objects rotating over the XCDs (23.3); profiles/r05_icc_xcd_order_ab.log.
   int lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int G_ = gridDim.x * gridDim.y;
   if (a.xcd_order && (G_ & 7) == 0) lin = (lin & 7) * (G_ >> 3) + (lin >> 3);
   const int o = lin / (int)gridDim.x;
-  const int bx_ = lin - o * (int)gridDim.x;
-  const int tile_ = (a.dbg & 1024) ? (int)((bx_ + ((lin >> 8) & 1) * (int)(gridDim.x / 2)) % (int)gridDim.x) : bx_;
+  const int tile_ = lin - o * (int)gridDim.x;
   const int ks = min(ksize_of(a.thr, a.pitch[o]), 2 * a.hmax + 1);  // block-uniform
   if (ks == 3)
     icc_fused_body<3>(a, 3, par, L, o, tile_);

@@ -29,3 +29,17 @@ tot = us(0, 4); tot[~ran] = -1
 for w in np.argsort(-tot)[:8]:
     print(f"wg {w:3d} grid {w // 64} plane {(w % 64) // 2:2d} half {w % 2} recs {st[w, 6]:5d} start {(st[w,0]-t0)/100.0:5.2f} " +
           " ".join(f"{n} {us(a, b)[w]:.2f}" for n, a, b in names))
+# placement: HW_REG_HW_ID bits: wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13] ...; XCC_ID low bits
+pl = buf.reshape(4096, 8)[2048:2048 + 512].astype(np.int64)
+hw, xcc = pl[:, 0], pl[:, 1] & 0xf
+cu, sh, se = (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 7
+key = xcc * 1000 + se * 100 + sh * 20 + cu
+import collections
+groups = collections.defaultdict(list)
+for w in range(512):
+    if started[w]: groups[int(key[w])].append(w)
+print("distinct (xcc,se,sh,cu):", len(groups), " workgroups per CU histogram:", collections.Counter(len(v) for v in groups.values()))
+print("xcc of wg 0..15:", list(xcc[:16]), " first CU groups:", [v for v in list(groups.values())[:12]])
+dur = tot.copy()
+pair = [sum(max(dur[w], 0) for w in v) for v in groups.values()]
+print("sum of workgroup durations per CU: mean %.2f max %.2f min %.2f" % (np.mean(pair), np.max(pair), np.min(pair)))
