@@ -523,6 +523,11 @@ int mf_prelu_bwd(const void *x, const void *dy, const float *slope, void *dx, fl
  *     4c / 3c / c) -> rot [n,4] = q / (|q| + 1e-5) (chainer F.normalize), trans [n,3] = (p*pitch + origin) +
  *     t*pitch (:264-266), conf [n] = sigmoid (:262) of each object's class (class_id int64 [B], 1-based; an id
  *     outside 1 .. n_fg gives NaN outputs, never a read outside the row). */
+/* transformation_matrix of a batch of poses and its backward (functions/geometry/transformation_matrix.py:5-18 =
+ * quaternion_matrix.py:36-78 + compose_transform.py:5-48): T [n,4,4] row-major from q [n,4] (wxyz, any norm), t [n,3];
+ * gq [n,4], gt [n,3] from gT [n,4,4].  One launch each (the torch composite: ~25 / ~60). */
+int mf_transformation_matrix_fwd(const float *q, const float *t, int64_t n, float *T, mfStream_t stream);
+int mf_transformation_matrix_bwd(const float *q, const float *gT, int64_t n, float *gq, float *gt, mfStream_t stream);
 int mf_point_prep(const float *points_cam, const float *values, const float *origin, const float *pitch,
                   int32_t B, int32_t P, int32_t Cv, float center, float *pts, float *tc4, float *x_rows,
                   int32_t *batch_indices, mfStream_t stream);

@@ -509,7 +509,8 @@ class Model(nn.Module):
         is one tensor)."""
         B, P = quaternion_pred.shape[0], quaternion_pred.shape[1]
         dev = quaternion_pred.device
-        T_pred = functions_module.transformation_matrix(
+        from ....functions.geometry.transformation_matrix import transformation_matrix_batch
+        T_pred = transformation_matrix_batch(  # (one fused launch forward / backward for the B * P predicted poses)
             quaternion_pred.reshape(B * P, 4), translation_pred.reshape(B * P, 3)).reshape(B, P, 4, 4)
         T_true = functions_module.transformation_matrix(quaternion_true.float(), translation_true.float())
         if torch.is_tensor(cad):

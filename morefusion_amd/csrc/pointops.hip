@@ -12,6 +12,7 @@
 //                    confidence [B,P]) of each object's class
 // Arithmetic is the torch expression order ((p - origin) / pitch with an IEEE divide; p * pitch + origin).
 #include "mf_common.h"
+#include "quat.h"
 
 namespace {
 
@@ -75,6 +76,43 @@ __global__ __launch_bounds__(256) void k_pose_epilogue(const float *__restrict__
   conf[i] = 1.0f / (1.0f + expf(-row[2 * np4 + fg]));
 }
 
+// ---- transformation_matrix of a batch of poses, forward and backward (round 5: the training loss) ---------------
+// functions/geometry/transformation_matrix.py:5-18 = quaternion_matrix.py:65-78 (wxyz, any norm: scaled by
+// sqrt(2 / |q|^2)) + compose_transform.py:5-48.  The torch composite is ~25 launches forward and ~60 backward for the
+// B * P = 16000 predicted poses of a training step; here one lane per pose (quat.h: the expressions of the
+// refinement loops).  T [n][4][4] row-major; backward: gq, gt from gT (only its top three rows matter).
+__global__ __launch_bounds__(256) void k_tfm_fwd(const float *__restrict__ q, const float *__restrict__ t, int64_t n,
+                                                 float *__restrict__ T) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 qq = *reinterpret_cast<const float4 *>(q + 4 * i);
+  const float qa[4] = {qq.x, qq.y, qq.z, qq.w};
+  float R[9];
+  mf::quat_to_R(qa, R);
+  float4 *o = reinterpret_cast<float4 *>(T + 16 * i);
+  o[0] = make_float4(R[0], R[1], R[2], t[3 * i]);
+  o[1] = make_float4(R[3], R[4], R[5], t[3 * i + 1]);
+  o[2] = make_float4(R[6], R[7], R[8], t[3 * i + 2]);
+  o[3] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+}
+
+__global__ __launch_bounds__(256) void k_tfm_bwd(const float *__restrict__ q, const float *__restrict__ gT, int64_t n,
+                                                 float *__restrict__ gq, float *__restrict__ gt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 qq = *reinterpret_cast<const float4 *>(q + 4 * i);
+  const float qa[4] = {qq.x, qq.y, qq.z, qq.w};
+  const float4 *g = reinterpret_cast<const float4 *>(gT + 16 * i);
+  const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+  const float gR[9] = {g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, g2.x, g2.y, g2.z};
+  float go[4];
+  mf::quat_backward(qa, gR, go);
+  *reinterpret_cast<float4 *>(gq + 4 * i) = make_float4(go[0], go[1], go[2], go[3]);
+  gt[3 * i] = g0.w;
+  gt[3 * i + 1] = g1.w;
+  gt[3 * i + 2] = g2.w;
+}
+
 }  // namespace
 
 extern "C" int mf_point_prep(const float *points_cam, const float *values, const float *origin, const float *pitch,
@@ -105,4 +143,22 @@ extern "C" int mf_pose_epilogue(const float *heads_out, int64_t ldo, int32_t np4
   hipLaunchKernelGGL(k_pose_epilogue, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, heads_out, ldo, np4,
                      class_id, pts, origin, pitch, B, P, n_fg, rot, trans, conf);
   return mf::check_launch("mf_pose_epilogue");
+}
+
+/* T [n,4,4] = transformation_matrix(q [n,4] wxyz, t [n,3]) and its backward (gq [n,4], gt [n,3] from gT [n,4,4]):
+ * functions/geometry/transformation_matrix.py:5-18 (quaternion_matrix.py:36-78 + compose_transform.py), one launch
+ * each.  q, T, gT, gq 16-byte aligned. */
+extern "C" int mf_transformation_matrix_fwd(const float *q, const float *t, int64_t n, float *T, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_tfm_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q, t, n, T);
+  return mf::check_launch("mf_transformation_matrix_fwd");
+}
+
+extern "C" int mf_transformation_matrix_bwd(const float *q, const float *gT, int64_t n, float *gq, float *gt,
+                                            mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_tfm_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q, gT, n, gq, gt);
+  return mf::check_launch("mf_transformation_matrix_bwd");
 }

@@ -165,3 +165,25 @@ def test_hipgraph_captured_data_parallel_step_over_rccl_tracks_the_eager_ddp_ste
     assert np.isfinite(lg).all() and len(lg) == 8
     np.testing.assert_allclose(lg, le, rtol=1e-2)
     assert np.ptp(le) > 0.05 * le.mean()
+
+
+def test_fused_transformation_matrix_matches_the_composite_forward_and_backward():
+    """mf_transformation_matrix_fwd/_bwd (csrc/pointops.hip, round 5: one launch for the 16000 predicted poses of the
+    training loss) against the torch composite of functions.transformation_matrix
+    (quaternion_matrix.py:36-78 + compose_transform.py:5-48): un-normalised quaternions, values to 1e-6, gradients of
+    a random cotangent to 1e-5."""
+    from morefusion_amd.functions.geometry.transformation_matrix import transformation_matrix, transformation_matrix_batch
+    torch.manual_seed(0)
+    n = 4097
+    q = (torch.randn(n, 4, device="cuda") * 1.5).requires_grad_(True)
+    t = torch.randn(n, 3, device="cuda").requires_grad_(True)
+    g = torch.randn(n, 4, 4, device="cuda")
+    T = transformation_matrix_batch(q, t)
+    T.backward(g)
+    q2, t2 = q.detach().clone().requires_grad_(True), t.detach().clone().requires_grad_(True)
+    T2 = transformation_matrix(q2, t2)
+    T2.backward(g)
+    torch.testing.assert_close(T, T2, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(q.grad, q2.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(t.grad, t2.grad, rtol=0, atol=0)
+    assert float(T[:, 3].sub(torch.tensor([0.0, 0.0, 0.0, 1.0], device="cuda")).abs().max()) == 0.0
