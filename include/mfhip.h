@@ -523,6 +523,32 @@ int mf_prelu_bwd(const void *x, const void *dy, const float *slope, void *dx, fl
  *     4c / 3c / c) -> rot [n,4] = q / (|q| + 1e-5) (chainer F.normalize), trans [n,3] = (p*pitch + origin) +
  *     t*pitch (:264-266), conf [n] = sigmoid (:262) of each object's class (class_id int64 [B], 1-based; an id
  *     outside 1 .. n_fg gives NaN outputs, never a read outside the row). */
+/* PSPNet's sampled tail under bf16 training (pspnet.py:18-22,50-56 at model.py:222's pixels): the 3 x 3 windows of
+ * the virtually x2 up-sampled map as GEMM rows [B * P, 576] bf16 (column c * 9 + ky * 3 + kx) from the channels-last
+ * bf16 map u2 [B, H, W, 64], pix [B * P] flat indices into [2H, 2W]; and the backward: grows -> gu2 [B, H, W, 64] bf16
+ * through the fp32 workspace acc [B, H, W, 64] (zeroed by the call; fp32 atomics). */
+int mf_psp_tail_rows_bf16_fwd(const void *u2, const int64_t *pix, int32_t B, int32_t P, int32_t H, int32_t W, void *rows,
+                              mfStream_t stream);
+int mf_psp_tail_rows_bf16_bwd(const void *grows, const int64_t *pix, int32_t B, int32_t P, int32_t H, int32_t W,
+                              float *acc, void *gu2, mfStream_t stream);
+
+/* The confidence terms of the pose loss and their reduction (contrib/singleview_3d/models/model.py:417-434):
+ * loss[0] = mean over objects of the mean over confident points (conf > 0) of add * conf - lambda * log(conf);
+ * cnt [B] is kept for the backward (dadd, dconf [B, P] from the scalar gradient gloss[0]). */
+int mf_confidence_loss_fwd(const float *add, const float *conf, int32_t B, int32_t P, float lambda, float *loss,
+                           int32_t *cnt, mfStream_t stream);
+int mf_confidence_loss_bwd(const float *add, const float *conf, const int32_t *cnt, const float *gloss, int32_t B,
+                           int32_t P, float lambda, float *dadd, float *dconf, mfStream_t stream);
+
+/* Pose epilogue of the TRAINING path (model.py:262-273: class selection, F.normalize, translation, sigmoid) on the
+ * three heads' fp32 outputs orot [n, 4 n_fg], otrn [n, 3 n_fg], ocnf [n, n_fg]; the backward writes the three gradient
+ * row blocks completely.  One launch each (torch: ~27 / ~47 incl. three index_put sorts). */
+int mf_pose_epilogue_train_fwd(const float *orot, const float *otrn, const float *ocnf, const int64_t *class_id,
+                               const float *pts, const float *origin, const float *pitch, int32_t B, int32_t P,
+                               int32_t n_fg, float *rot, float *trans, float *conf, mfStream_t stream);
+int mf_pose_epilogue_train_bwd(const float *orot, const float *ocnf, const int64_t *class_id, const float *pitch,
+                               const float *grot, const float *gtrans, const float *gconf, int32_t B, int32_t P,
+                               int32_t n_fg, float *drot, float *dtrn, float *dcnf, mfStream_t stream);
 /* transformation_matrix of a batch of poses and its backward (functions/geometry/transformation_matrix.py:5-18 =
  * quaternion_matrix.py:36-78 + compose_transform.py:5-48): T [n,4,4] row-major from q [n,4] (wxyz, any norm), t [n,3];
  * gq [n,4], gt [n,3] from gT [n,4,4].  One launch each (the torch composite: ~25 / ~60). */

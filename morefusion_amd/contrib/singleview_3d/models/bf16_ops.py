@@ -388,6 +388,46 @@ class SparseConv3(torch.autograd.Function):
         return dfeat, docc, None, None, dw, db, None, None
 
 
+class PoseEpilogue(torch.autograd.Function):
+    """Class selection + ``F.normalize`` + translation + sigmoid on the three heads' outputs (model.py:262-273), one
+    launch forward and one backward (csrc/pointops.hip) instead of ~27 / ~47 torch launches (the advanced-indexing
+    backward is an index_put with a radix sort, three times).  orot [n, 4 nf], otrn [n, 3 nf], ocnf [n, nf] fp32,
+    class_id [B] (1-based), pts [n, 3] voxel frame, pitch [B], origin [B, 3] -> rot [B,P,4], trans [B,P,3], conf [B,P]."""
+
+    @staticmethod
+    def forward(ctx, orot, otrn, ocnf, class_id, pts, pitch, origin, B, P, nf):
+        _lib.require_gpu(orot, otrn, ocnf, pts)
+        L = _lib.lib()
+        orot, otrn, ocnf = _lib.f32c(orot), _lib.f32c(otrn), _lib.f32c(ocnf)
+        cid = class_id.detach().to(torch.int64).contiguous()
+        pts_, pit, org = _lib.f32c(pts), _lib.f32c(pitch), _lib.f32c(origin)
+        rot = _empty((B, P, 4), torch.float32, orot)
+        trans = _empty((B, P, 3), torch.float32, orot)
+        conf = _empty((B, P), torch.float32, orot)
+        _lib.check(L.mf_pose_epilogue_train_fwd(orot.data_ptr(), otrn.data_ptr(), ocnf.data_ptr(), cid.data_ptr(),
+                                                pts_.data_ptr(), org.data_ptr(), pit.data_ptr(), B, P, nf, rot.data_ptr(),
+                                                trans.data_ptr(), conf.data_ptr(), _lib.stream_ptr()),
+                   "mf_pose_epilogue_train_fwd")
+        ctx.save_for_backward(orot, ocnf, cid, pit)
+        ctx.geom = (B, P, nf)
+        return rot, trans, conf
+
+    @staticmethod
+    def backward(ctx, grot, gtrans, gconf):
+        orot, ocnf, cid, pit = ctx.saved_tensors
+        B, P, nf = ctx.geom
+        n = B * P
+        grot, gtrans, gconf = _lib.f32c(grot), _lib.f32c(gtrans), _lib.f32c(gconf)
+        drot = _empty((n, 4 * nf), torch.float32, orot)
+        dtrn = _empty((n, 3 * nf), torch.float32, orot)
+        dcnf = _empty((n, nf), torch.float32, orot)
+        _lib.check(_lib.lib().mf_pose_epilogue_train_bwd(orot.data_ptr(), ocnf.data_ptr(), cid.data_ptr(), pit.data_ptr(),
+                                                         grot.data_ptr(), gtrans.data_ptr(), gconf.data_ptr(), B, P, nf,
+                                                         drot.data_ptr(), dtrn.data_ptr(), dcnf.data_ptr(),
+                                                         _lib.stream_ptr()), "mf_pose_epilogue_train_bwd")
+        return drot, dtrn, dcnf, None, None, None, None, None, None, None
+
+
 class InterpolateVoxelGridCL(torch.autograd.Function):
     """``interpolate_voxel_grid`` on a channels-last bf16 grid: vox [B, X^3, C], points [n, 3] (voxel units),
     batch_indices [n] -> rows [n, C] bf16.  Reference: functions/geometry/interpolate_voxel_grid.py:61-215 as called

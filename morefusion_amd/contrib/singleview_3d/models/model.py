@@ -327,8 +327,7 @@ class Model(nn.Module):
             values = self.pspnet_extractor.forward_sampled_rows(self.resnet_extractor(rgb), pix)
         elif self.sparse_pspnet_tail:
             # last PSPNet level evaluated only at the sampled pixels (identical features)
-            plan = self.pspnet_extractor.plan(pix, rgb.shape[2] // 8, rgb.shape[3] // 8)
-            values = self.pspnet_extractor.forward_sampled(self.resnet_extractor(rgb), pix, plan=plan)
+            values = self.pspnet_extractor.forward_sampled(self.resnet_extractor(rgb), pix)
         else:
             h_rgb = self.pspnet_extractor(self.resnet_extractor(rgb))
             values = torch.gather(h_rgb.reshape(B, h_rgb.shape[1], -1), 2,
@@ -423,23 +422,9 @@ class Model(nn.Module):
             x = K.linear(h[:, 640 * i:640 * (i + 1)], getattr(self, f"conv2_{k}"))
             x = K.linear(x, getattr(self, f"conv3_{k}"))
             outs[k] = K.linear(x, getattr(self, f"conv4_{k}"), relu=False).float()
-        cls_rot = outs["rot"].reshape(B, P, nf, 4)
-        cls_trans = outs["trans"].reshape(B, P, nf, 3)
-        cls_conf = torch.sigmoid(outs["conf"]).reshape(B, P, nf)
-        fg = (class_id - 1).long()
-        # a class id outside 1 .. n_fg (0 = background) has no head: NaN, like the channels-last epilogue
-        # (k_pose_epilogue) -- plain advanced indexing would wrap -1 to the LAST class silently
-        bad = ((fg < 0) | (fg >= nf))[:, None, None]
-        fg = fg.clamp(0, nf - 1)
-        ar = torch.arange(B, device=dev)
-        rot = cls_rot[ar, :, fg]
-        rot = rot / (rot.norm(dim=2, keepdim=True) + 1e-5)             # chainer F.normalize: x / (|x| + eps)
-        pts_b = pts.reshape(B, P, 3)
-        points_back = pts_b * pitch[:, None, None] + origin[:, None, :]
-        trans = points_back + cls_trans[ar, :, fg] * pitch[:, None, None]
-        nan = torch.full((), float("nan"), device=dev)
-        return (torch.where(bad, nan, rot), torch.where(bad, nan, trans),
-                torch.where(bad[:, :, 0], nan, cls_conf[ar, :, fg]))
+        # class selection + F.normalize + translation + sigmoid (model.py:262-273): one launch forward, one backward;
+        # a class id outside 1 .. n_fg (0 = background) has no head and gives NaN, like the inference epilogue
+        return K.PoseEpilogue.apply(outs["rot"], outs["trans"], outs["conf"], class_id, pts, pitch, origin, B, P, nf)
 
     def _pose_from_features_cl(self, class_id, values, points, pitch, origin, grid_nontarget_empty):
         """``_pose_from_features`` (camera-frame points) on the channels-last kernels (volumetric_cl.py)."""
@@ -512,19 +497,15 @@ class Model(nn.Module):
         from ....functions.geometry.transformation_matrix import transformation_matrix_batch
         T_pred = transformation_matrix_batch(  # (one fused launch forward / backward for the B * P predicted poses)
             quaternion_pred.reshape(B * P, 4), translation_pred.reshape(B * P, 3)).reshape(B, P, 4, 4)
-        T_true = functions_module.transformation_matrix(quaternion_true.float(), translation_true.float())
+        T_true = transformation_matrix_batch(quaternion_true.float(), translation_true.float())
         if torch.is_tensor(cad):
             add = functions_module.average_distance_batch(cad, T_true, T_pred, symmetric)  # [B,P]
         else:  # CAD clouds of different sizes (< 500 points): one call per object
             add = torch.stack([functions_module.average_distance(
                 torch.as_tensor(cad[i], device=dev), T_true[i], T_pred[i], symmetric=bool(symmetric[i]))
                 for i in range(B)])
-        keep = confidence_pred.detach() > 0
-        conf = torch.where(keep, confidence_pred, torch.ones_like(confidence_pred))
-        per_point = torch.where(keep, add * conf - self._lambda_confidence * torch.log(conf),
-                                torch.zeros_like(add))
-        per_object = per_point.sum(dim=1) / keep.sum(dim=1)  # an object without a confident point -> nan, as .mean() of nothing
-        return per_object.sum() / B
+        from ....functions.loss.confidence_loss import confidence_loss
+        return confidence_loss(add, confidence_pred.float(), self._lambda_confidence)  # (one launch each way)
 
     def loss(self, *, class_id, quaternion_true, translation_true, quaternion_pred,
              translation_pred, confidence_pred):

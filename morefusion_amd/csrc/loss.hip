@@ -199,6 +199,65 @@ __global__ __launch_bounds__(kLossThreads) void k_add_bwd(const float *points, c
   loss_walk<true>(points, T_true, T_pred, symmetric, M, P, gout, nullptr, nn_idx, gT);
 }
 
+// ---- the confidence terms of the pose loss and their reduction (round 5) --------------------------------------
+// contrib/singleview_3d/models/model.py:417-434: per object the mean over the confident points (conf > 0) of
+// add * conf - lambda * log(conf); the loss is the mean over objects.  ~28 torch launches forward and ~20 backward
+// -> one each.  One workgroup: wave w owns objects w, w + 16, ...; per-lane partial sums in point order, a fixed
+// butterfly over the wave, the objects added in index order -> the value does not depend on the launch.
+constexpr int kConfThreads = 1024;
+
+__global__ __launch_bounds__(kConfThreads) void k_conf_loss_fwd(const float *__restrict__ add,
+                                                                const float *__restrict__ conf, int B, int P,
+                                                                float lambda, float *__restrict__ loss,
+                                                                int32_t *__restrict__ cnt) {
+  MF_DYN_LDS(float, s_obj);  // [B]
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  for (int b = w; b < B; b += kConfThreads / 64) {
+    float acc = 0.0f;
+    int n = 0;
+    for (int p = l; p < P; p += 64) {
+      const float c = conf[(int64_t)b * P + p];
+      if (c > 0.0f) {
+        acc += add[(int64_t)b * P + p] * c - lambda * logf(c);
+        ++n;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      acc += __shfl_xor(acc, o, 64);
+      n += __shfl_xor(n, o, 64);
+    }
+    if (l == 0) {
+      s_obj[b] = acc / (float)n;  // no confident point: 0 / 0 = NaN, like .mean() of nothing
+      cnt[b] = n;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int b = 0; b < B; ++b) t += s_obj[b];
+    loss[0] = t / (float)B;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_conf_loss_bwd(const float *__restrict__ add, const float *__restrict__ conf,
+                                                       const int32_t *__restrict__ cnt, const float *__restrict__ gloss,
+                                                       int B, int P, float lambda, float *__restrict__ dadd,
+                                                       float *__restrict__ dconf) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * P) return;
+  const int b = (int)(i / P);
+  const float c = conf[i];
+  float ga = 0.0f, gc = 0.0f;
+  if (c > 0.0f) {
+    const float g = gloss[0] / (float)B / (float)cnt[b];
+    ga = g * c;
+    gc = g * (add[i] - lambda / c);
+  }
+  dadd[i] = ga;
+  dconf[i] = gc;
+}
+
 }  // namespace
 
 extern "C" int mf_average_distance_fwd(const float *points, const float *T_true, const float *T_pred,
@@ -228,4 +287,30 @@ extern "C" int mf_average_distance_bwd(const float *points, const float *T_true,
   hipLaunchKernelGGL(k_add_bwd, dim3((P + kPosesPerWg - 1) / kPosesPerWg, B), dim3(kLossThreads), 0, stream, points, T_true, T_pred,
                      symmetric, M, P, gout, const_cast<int32_t *>(nn_idx), gT_pred);
   return mf::check_launch("mf_average_distance_bwd");
+}
+
+/* The confidence terms of the pose loss (contrib/singleview_3d/models/model.py:417-434): loss[0] = mean over objects
+ * of the mean over the confident points (conf > 0) of add * conf - lambda * log(conf), add / conf [B, P]; cnt [B]
+ * (confident points per object) is kept for the backward: dadd, dconf [B, P] from the scalar gradient gloss[0]. */
+extern "C" int mf_confidence_loss_fwd(const float *add, const float *conf, int32_t B, int32_t P, float lambda,
+                                      float *loss, int32_t *cnt, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || P <= 0 || B > 8192) {
+    mf::set_last_error(hipErrorInvalidValue, "mf_confidence_loss_fwd: 1 <= B <= 8192, P >= 1");
+    return -(int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(k_conf_loss_fwd, dim3(1), dim3(kConfThreads), (size_t)B * sizeof(float), stream, add, conf, B, P,
+                     lambda, loss, cnt);
+  return mf::check_launch("mf_confidence_loss_fwd");
+}
+
+extern "C" int mf_confidence_loss_bwd(const float *add, const float *conf, const int32_t *cnt, const float *gloss,
+                                      int32_t B, int32_t P, float lambda, float *dadd, float *dconf,
+                                      mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || P <= 0) return 0;
+  const int64_t n = (int64_t)B * P;
+  hipLaunchKernelGGL(k_conf_loss_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, add, conf, cnt, gloss, B, P,
+                     lambda, dadd, dconf);
+  return mf::check_launch("mf_confidence_loss_bwd");
 }

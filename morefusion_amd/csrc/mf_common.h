@@ -94,6 +94,10 @@ __device__ __forceinline__ void warm_kernargs(int bytes) {
   asm volatile("" ::"s"(acc));
 }
 
+// fp32 add to global memory as ONE hardware atomic (global_atomic_add_f32, no return value, device scope) -- plain
+// atomicAdd(float*) compiles to a compare-and-swap loop without -munsafe-fp-atomics
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
+
 // dynamic LDS of the workgroup (tests/host_emul/mf_common.h gives the host-emulation form)
 #define MF_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 

@@ -76,6 +76,74 @@ __global__ __launch_bounds__(256) void k_pose_epilogue(const float *__restrict__
   conf[i] = 1.0f / (1.0f + expf(-row[2 * np4 + fg]));
 }
 
+// ---- the pose epilogue of the TRAINING path, forward and backward (round 5) -------------------------------------
+// model.py:262-273 on the three heads' separate outputs (fp32 rows [n, n_fg * 4 | n_fg * 3 | n_fg]): class selection,
+// F.normalize (chainer: x / (|x| + 1e-5)), translation = voxel point * pitch + origin + raw * pitch, sigmoid.  The
+// torch form is ~27 launches forward and ~47 backward -- three advanced-indexing backward passes, each an
+// index_put(accumulate) with a radix sort.  One lane per point; the backward writes the three gradient rows
+// completely (zeros outside the object's class).
+__global__ __launch_bounds__(256) void k_pose_epi3_fwd(const float *__restrict__ orot, const float *__restrict__ otrn,
+                                                       const float *__restrict__ ocnf, const int64_t *__restrict__ class_id,
+                                                       const float *__restrict__ pts, const float *__restrict__ origin,
+                                                       const float *__restrict__ pitch, int B, int P, int n_fg,
+                                                       float *__restrict__ rot, float *__restrict__ trans,
+                                                       float *__restrict__ conf) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * P) return;
+  const int b = (int)(i / P);
+  const int fg = (int)class_id[b] - 1;
+  const float pit = pitch[b];
+  if (fg < 0 || fg >= n_fg) {  // no head for this id: NaN (k_pose_epilogue's rule)
+    const float nan = __uint_as_float(0x7fc00000u);
+    *reinterpret_cast<float4 *>(rot + 4 * i) = make_float4(nan, nan, nan, nan);
+    trans[3 * i] = trans[3 * i + 1] = trans[3 * i + 2] = nan;
+    conf[i] = nan;
+    return;
+  }
+  const float *r = orot + i * (int64_t)(4 * n_fg) + 4 * fg;
+  const float q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+  const float nrm = sqrtf(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3) + 1e-5f;
+  *reinterpret_cast<float4 *>(rot + 4 * i) = make_float4(q0 / nrm, q1 / nrm, q2 / nrm, q3 / nrm);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float pc = pts[3 * i + a] * pit + origin[3 * b + a];
+    trans[3 * i + a] = pc + otrn[i * (int64_t)(3 * n_fg) + 3 * fg + a] * pit;
+  }
+  conf[i] = 1.0f / (1.0f + expf(-ocnf[i * (int64_t)n_fg + fg]));
+}
+
+__global__ __launch_bounds__(256) void k_pose_epi3_bwd(const float *__restrict__ orot, const float *__restrict__ ocnf,
+                                                       const int64_t *__restrict__ class_id, const float *__restrict__ pitch,
+                                                       const float *__restrict__ grot, const float *__restrict__ gtrans,
+                                                       const float *__restrict__ gconf, int B, int P, int n_fg,
+                                                       float *__restrict__ drot, float *__restrict__ dtrn,
+                                                       float *__restrict__ dcnf) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * P) return;
+  const int b = (int)(i / P);
+  const int fg = (int)class_id[b] - 1;
+  float *dr = drot + i * (int64_t)(4 * n_fg), *dt = dtrn + i * (int64_t)(3 * n_fg), *dc = dcnf + i * (int64_t)n_fg;
+  for (int k = 0; k < 4 * n_fg; ++k) dr[k] = 0.0f;
+  for (int k = 0; k < 3 * n_fg; ++k) dt[k] = 0.0f;
+  for (int k = 0; k < n_fg; ++k) dc[k] = 0.0f;
+  if (fg < 0 || fg >= n_fg) return;
+  const float pit = pitch[b];
+  const float *r = orot + i * (int64_t)(4 * n_fg) + 4 * fg;
+  const float q[4] = {r[0], r[1], r[2], r[3]};
+  const float g[4] = {grot[4 * i], grot[4 * i + 1], grot[4 * i + 2], grot[4 * i + 3]};
+  // y = x / (s + eps), s = |x|:  dx = g / (s + eps) - x (x . g) / (s (s + eps)^2)
+  const float s = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+  const float d = s + 1e-5f;
+  const float dot = ((q[0] * g[0] + q[1] * g[1]) + q[2] * g[2]) + q[3] * g[3];
+  const float c2 = s > 0.0f ? dot / (s * d * d) : 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dr[4 * fg + k] = g[k] / d - q[k] * c2;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) dt[3 * fg + a] = gtrans[3 * i + a] * pit;
+  const float c = 1.0f / (1.0f + expf(-ocnf[i * (int64_t)n_fg + fg]));
+  dc[fg] = gconf[i] * c * (1.0f - c);
+}
+
 // ---- transformation_matrix of a batch of poses, forward and backward (round 5: the training loss) ---------------
 // functions/geometry/transformation_matrix.py:5-18 = quaternion_matrix.py:65-78 (wxyz, any norm: scaled by
 // sqrt(2 / |q|^2)) + compose_transform.py:5-48.  The torch composite is ~25 launches forward and ~60 backward for the
@@ -161,4 +229,35 @@ extern "C" int mf_transformation_matrix_bwd(const float *q, const float *gT, int
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_tfm_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q, gT, n, gq, gt);
   return mf::check_launch("mf_transformation_matrix_bwd");
+}
+
+/* The pose epilogue of the training path (contrib/singleview_3d/models/model.py:262-273) on the three heads' fp32
+ * outputs orot [n, 4 n_fg], otrn [n, 3 n_fg], ocnf [n, n_fg] (n = B * P rows, object b = row / P, class_id 1-based):
+ * rot [n,4] normalised (x / (|x| + 1e-5)), trans [n,3] = (pts * pitch + origin) + raw * pitch, conf [n] = sigmoid --
+ * and the backward: the three gradient row blocks, written completely (zeros outside the object's class). */
+extern "C" int mf_pose_epilogue_train_fwd(const float *orot, const float *otrn, const float *ocnf, const int64_t *class_id,
+                                          const float *pts, const float *origin, const float *pitch, int32_t B, int32_t P,
+                                          int32_t n_fg, float *rot, float *trans, float *conf, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || P <= 0) return 0;
+  if (((uintptr_t)rot & 15) || n_fg < 1) {
+    mf::set_last_error(hipErrorInvalidValue, "pose_epilogue_train: 16-byte aligned rot, n_fg >= 1");
+    return -(int)hipErrorInvalidValue;
+  }
+  const int64_t n = (int64_t)B * P;
+  hipLaunchKernelGGL(k_pose_epi3_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, orot, otrn, ocnf, class_id,
+                     pts, origin, pitch, B, P, n_fg, rot, trans, conf);
+  return mf::check_launch("mf_pose_epilogue_train_fwd");
+}
+
+extern "C" int mf_pose_epilogue_train_bwd(const float *orot, const float *ocnf, const int64_t *class_id,
+                                          const float *pitch, const float *grot, const float *gtrans, const float *gconf,
+                                          int32_t B, int32_t P, int32_t n_fg, float *drot, float *dtrn, float *dcnf,
+                                          mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || P <= 0) return 0;
+  const int64_t n = (int64_t)B * P;
+  hipLaunchKernelGGL(k_pose_epi3_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, orot, ocnf, class_id, pitch,
+                     grot, gtrans, gconf, B, P, n_fg, drot, dtrn, dcnf);
+  return mf::check_launch("mf_pose_epilogue_train_bwd");
 }

@@ -6,6 +6,8 @@ No BatchNorm anywhere (the reference has none); ``F.resize_images`` == bilinear 
 align_corners=True; PReLU has one shared slope initialised to 0.25.
 """
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -247,6 +249,8 @@ class PSPNetExtractor(nn.Module):
         self.up3 = PSPUpsample(64, 64)
         self.conv1 = nn.Conv2d(64, 32, 1)
 
+    bf16_tail_kernels = True  # the sampled tail under bf16 autocast on the hand-written kernels (_tail_rows_bf16)
+
     def __getstate__(self):  # the tail kernel's packed weights are a cache
         state = dict(self.__dict__)
         state.pop("_tail_pack", None)
@@ -272,11 +276,30 @@ class PSPNetExtractor(nn.Module):
         same weights.  Mathematically identical; differs only by summation order.
         (Restricting up1/up2 to the outputs the samples depend on as well was built in round 1
         and measured in round 2: 8.13 ms vs 7.96 ms per 8-object predict -- slower, removed.)"""
-        taps = plan if plan is not None else self.plan(pix, x.shape[2], x.shape[3])
         h = F.dropout(self.psp(x), 0.3, self.training)
         h = F.dropout(self.up1(h), 0.15, self.training)
         u2 = F.dropout(self.up2(h), 0.15, self.training)  # [B,64,H,W], H = W = 128
+        if (plan is None and self.bf16_tail_kernels and u2.is_cuda and u2.shape[1] == 64 and self.conv1.out_channels == 32
+                and self.up3.prelu.weight.numel() == 1 and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and os.environ.get("MF_TORCH_TAIL") != "1"):
+            B, P = pix.shape
+            return self._tail_rows_bf16(u2, pix).reshape(B, P, -1).transpose(1, 2)  # (a view: the rows are the data)
+        taps = plan if plan is not None else self.plan(pix, x.shape[2], x.shape[3])
         return self._tail(u2, taps)
+
+    def _tail_rows_bf16(self, u2, pix):
+        """``_tail`` under bf16 autocast (training, ``--dtype bf16``) -> rows [B*P, 32] fp32: the windows as GEMM rows
+        from one launch (ops2d.tail_rows), up3's 3x3 convolution and the 1x1 head as GEMMs on the bf16 MFMA engines with
+        their data / weight gradients (bf16_ops.Linear on the convolutions' own parameters), the single-slope PReLU
+        on its kernel, log-softmax in fp32 -- ~12 launches forward + ~25 backward where the torch formulation takes
+        ~85 + ~46 (MF_TORCH_TAIL=1 keeps that form for A/B runs)."""
+        from ..contrib.singleview_3d.models import bf16_ops as K
+        n = pix.numel()
+        rows = ops2d.tail_rows(u2, pix)                                               # [n, 576] bf16
+        pre = K.Linear.apply(rows, self.up3.conv.weight, self.up3.conv.bias, False)   # [n, 64] bf16
+        h = ops2d._PReLU.apply(pre.view(1, 1, n, 64), self.up3.prelu.weight).view(n, 64)
+        z = K.Linear.apply(h, self.conv1.weight, self.conv1.bias, False)              # [n, 32] bf16
+        return F.log_softmax(z.float(), dim=1)
 
     def forward_sampled_rows(self, x, pix):
         """``forward_sampled`` through ONE HIP launch (csrc/psp_tail.hip) -> rows [B*P, 32] (the point MLP's

@@ -98,6 +98,44 @@ class _PReLU(torch.autograd.Function):
         return dx, da.to(dtype).reshape(shape)
 
 
+class _TailRows(torch.autograd.Function):
+    """The 3 x 3 windows of the (virtually) x2 up-sampled map at the sampled pixels as GEMM rows: u2 [B,64,H,W] bf16
+    channels-last, pix [B,P] flat indices into [2H,2W] -> [B*P, 576] bf16 (column c * 9 + ky * 3 + kx: the flattened
+    layout of Convolution2D's own weight).  One launch forward (taps + four gathers + blend: ~75 torch launches), three
+    backward (zero, patch-wise fp32 atomics, round) instead of four scatter-adds and their glue (~46)."""
+
+    @staticmethod
+    def forward(ctx, u2, pix):
+        _lib.require_gpu(u2, pix)
+        B, C, H, W = u2.shape
+        if C != 64:
+            raise ValueError("tail_rows: the map must have 64 channels")
+        u = u2.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        pixc = pix.reshape(-1).to(torch.int64).contiguous()
+        P = pix.shape[1]
+        rows = torch.empty((B * P, 576), dtype=torch.bfloat16, device=u.device)
+        _lib.check(_lib.lib().mf_psp_tail_rows_bf16_fwd(u.data_ptr(), pixc.data_ptr(), B, P, H, W, rows.data_ptr(),
+                                                        _lib.stream_ptr()), "mf_psp_tail_rows_bf16_fwd")
+        ctx.save_for_backward(pixc)
+        ctx.geom = (B, P, H, W, u2.dtype)
+        return rows
+
+    @staticmethod
+    def backward(ctx, grows):
+        (pixc,) = ctx.saved_tensors
+        B, P, H, W, dtype = ctx.geom
+        g = grows.to(torch.bfloat16).contiguous()
+        acc = torch.empty((B, H, W, 64), dtype=torch.float32, device=g.device)
+        gu = torch.empty((B, 64, H, W), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().mf_psp_tail_rows_bf16_bwd(g.data_ptr(), pixc.data_ptr(), B, P, H, W, acc.data_ptr(),
+                                                        gu.data_ptr(), _lib.stream_ptr()), "mf_psp_tail_rows_bf16_bwd")
+        return gu.to(dtype), None
+
+
+def tail_rows(u2, pix):
+    return _TailRows.apply(u2, pix)
+
+
 def _autocast_dtype(x):
     if x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
         return x.to(torch.bfloat16)  # the convolution behind the resize would round to bf16 anyway

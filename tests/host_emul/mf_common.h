@@ -497,6 +497,7 @@ inline uint4 buf_load16(const BufRsrc &b, uint32_t byte_off) {
 }
 constexpr int kWave = 64;
 inline void warm_kernargs(int) {}
+inline void atomic_add_f32(float *p, float v) { *p += v; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline float voxel_coord(float p, float o, float pitch) { return (p - o) / pitch; }
 // same association as the DPP butterflies of csrc/mf_common.h

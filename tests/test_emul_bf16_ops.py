@@ -28,6 +28,7 @@ def K(monkeypatch):
 
 
 def rel(a, b):
+    a, b = a.detach(), b.detach()
     return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-30))
 
 
@@ -289,3 +290,167 @@ def test_sparse_conv3_operator_forward_and_all_gradients_vs_dense_float32(KS, wi
     if with_occ:
         assert rel(conv.weight.grad[:, Cs:], wr.grad[:, Cs:]) < 1e-2
         assert rel(hocc.grad, hr.grad) < 1e-2
+
+
+@pytest.fixture()
+def KP(monkeypatch):
+    from morefusion_amd import _lib
+    from morefusion_amd.contrib.singleview_3d.models import bf16_ops
+    L = emul.build(["pointops.hip"])
+    for name, (argtypes, restype) in _lib._SIGNATURES.items():
+        fn = getattr(L, name, None)
+        if fn is not None:
+            fn.argtypes, fn.restype = argtypes, restype
+    monkeypatch.setattr(_lib, "lib", lambda: L)
+    monkeypatch.setattr(_lib, "require_gpu", lambda *a: None)
+    monkeypatch.setattr(_lib, "stream_ptr", lambda: None)
+    monkeypatch.setattr(_lib, "check", lambda code, what: (_ for _ in ()).throw(RuntimeError(what)) if code else None)
+    return bf16_ops
+
+
+def pose_epilogue_torch(orot, otrn, ocnf, class_id, pts, pitch, origin, B, P, nf):
+    """model.py:262-273 as the torch composite the fused operator replaces."""
+    ar = torch.arange(B)
+    fg = (class_id - 1).long()
+    q = orot.reshape(B, P, nf, 4)[ar, :, fg]
+    q = q / (q.norm(dim=2, keepdim=True) + 1e-5)
+    pc = pts.reshape(B, P, 3) * pitch[:, None, None] + origin[:, None, :]
+    t = pc + otrn.reshape(B, P, nf, 3)[ar, :, fg] * pitch[:, None, None]
+    c = torch.sigmoid(ocnf).reshape(B, P, nf)[ar, :, fg]
+    return q, t, c
+
+
+def test_training_pose_epilogue_forward_and_gradients(KP):
+    """K.PoseEpilogue (csrc/pointops.hip k_pose_epi3_fwd / _bwd) vs the torch composite of model.py:262-273:
+    values, the three heads' gradient rows (zeros outside the object's class), NaN for a class id without a head."""
+    torch.manual_seed(5)
+    B, P, nf = 3, 70, 21
+    n = B * P
+    orot = torch.randn(n, 4 * nf, requires_grad=True)
+    otrn = torch.randn(n, 3 * nf, requires_grad=True)
+    ocnf = torch.randn(n, nf, requires_grad=True)
+    class_id = torch.tensor([1, 21, 7])
+    pts = torch.rand(n, 3) * 32
+    pitch = torch.tensor([0.004, 0.0075, 0.01])
+    origin = torch.randn(B, 3) * 0.1
+    q, t, c = KP.PoseEpilogue.apply(orot, otrn, ocnf, class_id, pts, pitch, origin, B, P, nf)
+    gq, gt, gc = torch.randn_like(q), torch.randn_like(t), torch.randn_like(c)
+    torch.autograd.backward([q, t, c], [gq, gt, gc])
+    got = [x.grad.clone() for x in (orot, otrn, ocnf)]
+    for x in (orot, otrn, ocnf):
+        x.grad = None
+    qr, tr, cr = pose_epilogue_torch(orot, otrn, ocnf, class_id, pts, pitch, origin, B, P, nf)
+    torch.autograd.backward([qr, tr, cr], [gq, gt, gc])
+    np.testing.assert_allclose(q.detach().numpy(), qr.detach().numpy(), rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(t.detach().numpy(), tr.detach().numpy(), rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(c.detach().numpy(), cr.detach().numpy(), rtol=2e-6, atol=2e-7)
+    for a, b in zip(got, (orot.grad, otrn.grad, ocnf.grad)):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-5, atol=2e-6)
+        assert (a != 0).sum() == (b != 0).sum()
+    # background (0) and an id past the heads: NaN outputs, zero gradients, no out-of-range read
+    bad = torch.tensor([0, 22, 7])
+    q, t, c = KP.PoseEpilogue.apply(orot, otrn, ocnf, bad, pts, pitch, origin, B, P, nf)
+    assert torch.isnan(q[:2]).all() and torch.isnan(t[:2]).all() and torch.isnan(c[:2]).all()
+    assert torch.isfinite(q[2]).all()
+    for x in (orot, otrn, ocnf):
+        x.grad = None
+    torch.autograd.backward([q, t, c], [gq, gt, gc])
+    assert float(orot.grad[:2 * P].abs().max()) == 0.0 and float(orot.grad[2 * P:].abs().max()) > 0
+
+
+def test_confidence_loss_forward_and_gradients(monkeypatch):
+    """functions.loss.confidence_loss (csrc/loss.hip k_conf_loss_fwd / _bwd) vs the torch composite of
+    model.py:417-434, incl. non-confident points (conf <= 0) and an object without any (NaN, zero gradients)."""
+    from morefusion_amd import _lib
+    import importlib
+    CL = importlib.import_module("morefusion_amd.functions.loss.confidence_loss")
+    L = emul.build(["loss.hip"])
+    for name, (argtypes, restype) in _lib._SIGNATURES.items():
+        fn = getattr(L, name, None)
+        if fn is not None:
+            fn.argtypes, fn.restype = argtypes, restype
+    monkeypatch.setattr(_lib, "lib", lambda: L)
+    monkeypatch.setattr(_lib, "stream_ptr", lambda: None)
+    torch.manual_seed(3)
+    for B, P, dead in ((5, 333, False), (18, 70, False), (3, 100, True)):
+        add = torch.rand(B, P, requires_grad=True)
+        conf = (torch.rand(B, P) - 0.2).requires_grad_(True)  # a fifth of the points not confident
+        if dead:
+            with torch.no_grad():
+                conf[1] = -conf[1].abs()
+        loss = CL._ConfidenceLoss.apply(add, conf, 0.015)
+        loss.backward(torch.tensor(1.7))
+        got = add.grad.clone(), conf.grad.clone()
+        add.grad = conf.grad = None
+        ref = CL.confidence_loss(add, conf, 0.015)  # CPU tensors: the composite
+        ref.backward(torch.tensor(1.7))
+        if dead:
+            assert torch.isnan(loss) and torch.isnan(ref)
+            assert float(got[0][1].abs().max()) == 0.0 and float(got[1][1].abs().max()) == 0.0
+            continue
+        np.testing.assert_allclose(float(loss.detach()), float(ref.detach()), rtol=2e-6)
+        np.testing.assert_allclose(got[0].numpy(), add.grad.numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(got[1].numpy(), conf.grad.numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_sampled_pspnet_tail_training_rows_vs_torch_formulation(monkeypatch):
+    """PSPNetExtractor._tail_rows_bf16 (csrc/psp_tail.hip k_tail_rows_fwd / _bwd + the bf16 GEMM engines + the PReLU
+    kernel) vs the float32 torch formulation ``_tail`` (taps, four gathers, einsum, conv1d, log-softmax): the window
+    rows bit-for-bit against the same arithmetic in torch, the features and every gradient within bf16 tolerance."""
+    from morefusion_amd import _lib
+    from morefusion_amd.models import backbone2d, ops2d
+    L = emul.build(["psp_tail.hip", "gemm_bf16.hip", "backbone2d.hip"])
+    for name, (argtypes, restype) in _lib._SIGNATURES.items():
+        fn = getattr(L, name, None)
+        if fn is not None:
+            fn.argtypes, fn.restype = argtypes, restype
+    monkeypatch.setattr(_lib, "lib", lambda: L)
+    monkeypatch.setattr(_lib, "require_gpu", lambda *a: None)
+    monkeypatch.setattr(_lib, "stream_ptr", lambda: None)
+    monkeypatch.setattr(_lib, "check", lambda code, what: (_ for _ in ()).throw(RuntimeError(what)) if code else None)
+    torch.manual_seed(11)
+    B, H, W, P = 2, 8, 12, 48
+    net = backbone2d.PSPNetExtractor()
+    with torch.no_grad():
+        net.up3.prelu.weight.fill_(0.3)
+    u2 = torch.randn(B, 64, H, W).to(torch.bfloat16).float().contiguous(memory_format=torch.channels_last)
+    pix = torch.randint(0, 4 * H * W, (B, P))
+    pix[0, :4] = torch.tensor([0, 2 * W - 1, (2 * H - 1) * 2 * W, 4 * H * W - 1])   # the four image corners
+    # ---- the window rows against the torch taps, in float32 before the bf16 rounding
+    rows = ops2d.tail_rows(u2.to(torch.bfloat16), pix)
+    taps = net._tail_taps(pix, H, W)
+    flat = u2.permute(0, 2, 3, 1).reshape(B, H * W, 64)
+
+    def tap(iy, ix):
+        return torch.gather(flat, 1, (iy * W + ix)[:, :, None].expand(B, P * 9, 64))
+    ly, lx = taps["ly"][:, :, None], taps["lx"][:, :, None]
+    up = (1 - ly) * ((1 - lx) * tap(taps["y0"], taps["x0"]) + lx * tap(taps["y0"], taps["x1"])) + \
+        ly * ((1 - lx) * tap(taps["y1"], taps["x0"]) + lx * tap(taps["y1"], taps["x1"]))
+    up = (up * taps["valid"][:, :, None]).reshape(B * P, 9, 64).permute(0, 2, 1).reshape(B * P, 576)
+    assert torch.equal(rows, up.to(torch.bfloat16))
+    # ---- the whole tail and its gradients.  Slope 1: PReLU is the identity, every gradient within the bf16 rounding of
+    # its chain; slope 0.3: a pre-activation that rounds across 0 in bf16 takes the other slope (the weight gradients
+    # sum only n = 96 such terms here) -> the L2 sense
+    def l2(a, b):
+        return float((a.detach().float() - b.detach().float()).norm() / b.detach().float().norm())
+
+    for slope, err, tol in ((1.0, rel, 2e-2), (0.3, l2, 6e-2)):
+        with torch.no_grad():
+            net.up3.prelu.weight.fill_(slope)
+        net.zero_grad()
+        ua = u2.clone().requires_grad_(True)
+        out = net._tail_rows_bf16(ua, pix)                                             # [n, 32]
+        g = torch.randn_like(out)
+        out.backward(g)
+        got = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        got_u = ua.grad.clone()
+        net.zero_grad()
+        ub = u2.clone().contiguous().requires_grad_(True)                              # NCHW: the gather form of _tail
+        ref = net._tail(ub, taps)                                                      # [B, 32, P]
+        ref.backward(g.reshape(B, P, 32).transpose(1, 2))
+        assert rel(out, ref.transpose(1, 2).reshape(B * P, 32)) < 2e-2
+        assert err(got_u, ub.grad) < tol
+        assert set(got) == {"up3.conv.weight", "up3.conv.bias", "up3.prelu.weight", "conv1.weight", "conv1.bias"}
+        for k, v in got.items():
+            assert v.shape == dict(net.named_parameters())[k].shape
+            assert err(v, dict(net.named_parameters())[k].grad) < tol, (slope, k)

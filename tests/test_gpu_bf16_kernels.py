@@ -93,6 +93,7 @@ def test_training_step_on_bf16_kernels_matches_stock_autocast_step():
     for flag in (True, False):
         model = copy.deepcopy(base)
         model.bf16_kernels = flag
+        model.pspnet_extractor.bf16_tail_kernels = flag
         np.random.seed(1)
         torch.manual_seed(1)
         with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -103,12 +104,13 @@ def test_training_step_on_bf16_kernels_matches_stock_autocast_step():
     assert np.isfinite(losses[True]) and abs(losses[True] - losses[False]) < 0.01 * abs(losses[False]), losses
     checked = 0
     for name, g_hw in grads[True].items():
-        if name.startswith(("conv", )):  # the volumetric part: point MLP, occupancy convs, conv3/4, heads
+        # the volumetric part (point MLP, occupancy convs, conv3/4, heads) and PSPNet's sampled tail
+        if name.startswith(("conv", "pspnet_extractor.up3", "pspnet_extractor.conv1")):
             g_st = grads[False][name]
             cos = float(torch.dot(g_hw, g_st) / (g_hw.norm() * g_st.norm() + 1e-30))
             assert cos > 0.98, (name, cos)
             checked += 1
-    assert checked >= 30
+    assert checked >= 35
 
 
 def test_occupancy_branch_on_the_bf16_kernels_vs_fp32():
@@ -242,3 +244,114 @@ def test_sparse_conv3_forward_and_all_gradients_vs_float32_dense_conv3d(B, P):
 
     # (two bf16 paths, each with its own ReLU mask next to zero: twice the flip noise of a comparison with float32)
     assert l2(f2.grad, got["feat"]) < 5e-2 and l2(conv.weight.grad, got["w"]) < 5e-2
+
+
+def test_training_pose_epilogue_forward_and_gradients_vs_torch_composite():
+    """K.PoseEpilogue (csrc/pointops.hip k_pose_epi3_fwd / _bwd) vs the torch composite of model.py:262-273 at the
+    training batch's shape: values and the three heads' gradient rows; NaN for a class id without a head."""
+    torch.manual_seed(5)
+    B, P, nf = 16, 1000, 21
+    n = B * P
+    dev = "cuda"
+    orot = torch.randn(n, 4 * nf, device=dev, requires_grad=True)
+    otrn = torch.randn(n, 3 * nf, device=dev, requires_grad=True)
+    ocnf = torch.randn(n, nf, device=dev, requires_grad=True)
+    class_id = torch.randint(1, nf + 1, (B,), device=dev)
+    pts = torch.rand(n, 3, device=dev) * 32
+    pitch = torch.rand(B, device=dev) * 0.01 + 0.002
+    origin = torch.randn(B, 3, device=dev) * 0.1
+
+    def composite(cid):
+        ar = torch.arange(B, device=dev)
+        fg = (cid - 1).long()
+        q = orot.reshape(B, P, nf, 4)[ar, :, fg]
+        q = q / (q.norm(dim=2, keepdim=True) + 1e-5)
+        pc = pts.reshape(B, P, 3) * pitch[:, None, None] + origin[:, None, :]
+        t = pc + otrn.reshape(B, P, nf, 3)[ar, :, fg] * pitch[:, None, None]
+        return q, t, torch.sigmoid(ocnf).reshape(B, P, nf)[ar, :, fg]
+
+    q, t, c = K.PoseEpilogue.apply(orot, otrn, ocnf, class_id, pts, pitch, origin, B, P, nf)
+    gq, gt, gc = torch.randn_like(q), torch.randn_like(t), torch.randn_like(c)
+    torch.autograd.backward([q, t, c], [gq, gt, gc])
+    got = [x.grad.clone() for x in (orot, otrn, ocnf)]
+    for x in (orot, otrn, ocnf):
+        x.grad = None
+    qr, tr, cr = composite(class_id)
+    torch.autograd.backward([qr, tr, cr], [gq, gt, gc])
+    for a, b in ((q, qr), (t, tr), (c, cr)):
+        torch.testing.assert_close(a, b, rtol=3e-6, atol=3e-7)
+    for a, b in zip(got, (orot.grad, otrn.grad, ocnf.grad)):
+        torch.testing.assert_close(a, b, rtol=3e-5, atol=3e-6)
+    bad = class_id.clone()
+    bad[0], bad[1] = 0, nf + 1
+    q, t, c = K.PoseEpilogue.apply(orot, otrn, ocnf, bad, pts, pitch, origin, B, P, nf)
+    assert torch.isnan(q[:2]).all() and torch.isnan(t[:2]).all() and torch.isnan(c[:2]).all()
+    assert torch.isfinite(q[2:]).all()
+
+
+def test_confidence_loss_forward_and_gradients_vs_torch_composite():
+    """functions.loss.confidence_loss on the GPU (csrc/loss.hip) vs its torch composite (model.py:417-434)."""
+    import importlib
+    CL = importlib.import_module("morefusion_amd.functions.loss.confidence_loss")
+    torch.manual_seed(3)
+    for B, P in ((16, 1000), (3, 77)):
+        add = torch.rand(B, P, device="cuda", requires_grad=True)
+        conf = (torch.rand(B, P, device="cuda") - 0.2).requires_grad_(True)
+        loss = CL.confidence_loss(add, conf, 0.015)
+        loss.backward()
+        ga, gc = add.grad.clone(), conf.grad.clone()
+        a2, c2 = add.detach().cpu().requires_grad_(True), conf.detach().cpu().requires_grad_(True)
+        ref = CL.confidence_loss(a2, c2, 0.015)   # CPU tensors: the composite
+        ref.backward()
+        np.testing.assert_allclose(float(loss.detach()), float(ref.detach()), rtol=3e-6)
+        torch.testing.assert_close(ga.cpu(), a2.grad, rtol=2e-5, atol=1e-9)
+        torch.testing.assert_close(gc.cpu(), c2.grad, rtol=2e-5, atol=1e-9)
+
+
+def test_sampled_pspnet_tail_on_the_bf16_kernels_vs_torch_formulation():
+    """PSPNetExtractor._tail_rows_bf16 at the training shape (128^2 map, 1000 pixels per object): the window rows
+    bit-for-bit against the same float32 arithmetic in torch; features and gradients against the float32 torch
+    formulation ``_tail`` (PReLU slope 1 -> no mask flips: max-norm 2 %; the trained slope: L2)."""
+    from morefusion_amd.models import backbone2d, ops2d
+    torch.manual_seed(11)
+    B, H, W, P = 4, 128, 128, 1000
+    net = backbone2d.PSPNetExtractor().cuda()
+    u2 = torch.randn(B, 64, H, W, device="cuda").to(torch.bfloat16).float().contiguous(memory_format=torch.channels_last)
+    pix = torch.randint(0, 4 * H * W, (B, P), device="cuda")
+    pix[0, :4] = torch.tensor([0, 2 * W - 1, (2 * H - 1) * 2 * W, 4 * H * W - 1], device="cuda")
+    rows = ops2d.tail_rows(u2.to(torch.bfloat16), pix)
+    taps = net._tail_taps(pix, H, W)
+    flat = u2.permute(0, 2, 3, 1).reshape(B, H * W, 64)
+
+    def tap(iy, ix):
+        return torch.gather(flat, 1, (iy * W + ix)[:, :, None].expand(B, P * 9, 64))
+    ly, lx = taps["ly"][:, :, None], taps["lx"][:, :, None]
+    up = (1 - ly) * ((1 - lx) * tap(taps["y0"], taps["x0"]) + lx * tap(taps["y0"], taps["x1"])) + \
+        ly * ((1 - lx) * tap(taps["y1"], taps["x0"]) + lx * tap(taps["y1"], taps["x1"]))
+    up = (up * taps["valid"][:, :, None]).reshape(B * P, 9, 64).permute(0, 2, 1).reshape(B * P, 576)
+    assert torch.equal(rows, up.to(torch.bfloat16))
+
+    def l2(a, b):
+        return float((a.detach().float() - b.detach().float()).norm() / b.detach().float().norm())
+
+    for slope, err, tol in ((1.0, rel, 2e-2), (0.25, l2, 2e-2)):
+        with torch.no_grad():
+            net.up3.prelu.weight.fill_(slope)
+        net.zero_grad()
+        ua = u2.clone().requires_grad_(True)
+        out = net._tail_rows_bf16(ua, pix)
+        g = torch.randn_like(out)
+        out.backward(g)
+        got = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        got_u = ua.grad.clone()
+        net.zero_grad()
+        ub = u2.clone().contiguous().requires_grad_(True)
+        ref = net._tail(ub, taps)
+        ref.backward(g.reshape(B, P, 32).transpose(1, 2))
+        assert rel(out, ref.transpose(1, 2).reshape(B * P, 32)) < 2e-2
+        assert l2(got_u, ub.grad) < 1e-2 and err(got_u, ub.grad) < 5e-2
+        assert set(got) == {"up3.conv.weight", "up3.conv.bias", "up3.prelu.weight", "conv1.weight", "conv1.bias"}
+        for k, v in got.items():
+            # (the slope's gradient is ONE number: a sum of 256 000 products of either sign that cancels to ~1e-4 of
+            # its absolute mass, so the bf16 rounding of the addends shows at the per-cent level)
+            assert err(v, dict(net.named_parameters())[k].grad) < (0.1 if k == "up3.prelu.weight" else tol), (slope, k)
