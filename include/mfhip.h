@@ -511,6 +511,12 @@ int mf_upsample_bilinear_cf_fwd(const void *x, void *y, int64_t BC, int32_t H, i
 int mf_upsample_bilinear_cf_bwd(const void *gy, void *gx, int64_t BC, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
                                 int32_t bf16, mfStream_t stream);
 int mf_prelu_fwd(const void *x, const float *slope, void *y, int64_t n, int32_t bf16, mfStream_t stream);
+/* BatchNorm with inference statistics (+ residual add) (+ ReLU) in one launch (models/resnet.py:44: ResNet18Extractor's
+ * BatchNorm never updates): y = relu?((x - mean) * (weight / sqrt(var + eps)) + bias (+ identity)) over a dense
+ * [B, C, H, W] tensor, NCHW (8 | H W) or channels-last (8 | C); fp32 / bf16 activations, fp32 parameters. */
+int mf_bn_act_fwd(const void *x, const void *identity, const float *mean, const float *var, const float *weight,
+                  const float *bias, float eps, void *y, int64_t n, int32_t C, int64_t HW, int32_t channels_last,
+                  int32_t relu, int32_t bf16, mfStream_t stream);
 int64_t mf_prelu_bwd_workspace_floats(int64_t n);
 int mf_prelu_bwd(const void *x, const void *dy, const float *slope, void *dx, float *dslope, float *ws, int64_t n,
                  int32_t bf16, mfStream_t stream);

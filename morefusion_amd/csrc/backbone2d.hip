@@ -308,6 +308,33 @@ __global__ __launch_bounds__(256) void k_prelu_fwd(const void *__restrict__ x, c
   store8<BF16>(y, 8 * i, v);
 }
 
+// BatchNorm in inference mode (+ residual add) (+ ReLU) of ResNet18Extractor (models/resnet.py:44: the statistics are
+// never updated): y = relu?((x - mean) * (weight * invstd) + bias (+ identity)), invstd = 1 / sqrt(var + eps) -- torch's
+// own operation order.  torch: one elementwise launch for the normalisation, one for the add, one for the ReLU.
+// CL: channels-last (8 consecutive elements = 8 consecutive channels); otherwise NCHW with HW % 8 == 0 (8 consecutive
+// elements = one channel).
+template <bool BF16, bool CL>
+__global__ __launch_bounds__(256) void k_bn_act(const void *__restrict__ x, const void *__restrict__ identity,
+                                                const float *__restrict__ mean, const float *__restrict__ var,
+                                                const float *__restrict__ weight, const float *__restrict__ bias,
+                                                float eps, void *__restrict__ y, int64_t n8, int C, int64_t HW, int relu) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float v[8], r[8];
+  load8<BF16>(x, 8 * i, v);
+  if (identity) load8<BF16>(identity, 8 * i, r);
+  const int c0 = CL ? (int)((8 * i) % C) : (int)(((8 * i) / HW) % C);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = CL ? c0 + k : c0;
+    const float invstd = 1.0f / sqrtf(var[c] + eps);
+    float o = (v[k] - mean[c]) * (weight[c] * invstd) + bias[c];
+    if (identity) o += r[k];
+    v[k] = relu ? (o > 0.0f ? o : 0.0f) : o;
+  }
+  store8<BF16>(y, 8 * i, v);
+}
+
 // dx = dy (x > 0 ? 1 : a); partial[block] = sum over the block's elements with x <= 0 of dy x
 constexpr int kPreluPerThread = 4;  // 8-element chunks per lane: 8192 elements per workgroup
 
@@ -448,4 +475,24 @@ extern "C" int mf_prelu_bwd(const void *x, const void *dy, const float *slope, v
   else hipLaunchKernelGGL(k_prelu_bwd<false>, dim3((unsigned)nblk), dim3(256), 0, stream, x, dy, slope, dx, ws, n / 8);
   hipLaunchKernelGGL(k_prelu_finish, dim3(1), dim3(256), 0, stream, (const float *)ws, (int)nblk, dslope);
   return mf::check_launch("mf_prelu_bwd");
+}
+
+/* BatchNorm (inference statistics) + optional residual add + optional ReLU over a dense [B, C, H, W] tensor, NCHW
+ * (channels_last = 0; H * W % 8 == 0) or channels-last (C % 8 == 0); fp32 or bf16 activations, fp32 parameters. */
+extern "C" int mf_bn_act_fwd(const void *x, const void *identity, const float *mean, const float *var, const float *weight,
+                             const float *bias, float eps, void *y, int64_t n, int32_t C, int64_t HW, int32_t channels_last,
+                             int32_t relu, int32_t bf16, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n <= 0) return 0;
+  if (n % 8 || C <= 0 || HW <= 0 || (channels_last ? C % 8 : HW % 8) ||
+      (((uintptr_t)x | (uintptr_t)y | (uintptr_t)identity) & 15))
+    return bad2d("bn_act: n % 8 == 0, 8 | C (channels-last) or 8 | H W (NCHW), aligned");
+  const unsigned nb = (unsigned)((n / 8 + 255) / 256);
+#define MF_BN_LAUNCH(BF, CL_)                                                                                   \
+  hipLaunchKernelGGL((k_bn_act<BF, CL_>), dim3(nb), dim3(256), 0, stream, x, identity, mean, var, weight, bias, eps, y, \
+                     n / 8, C, HW, relu)
+  if (bf16) { if (channels_last) MF_BN_LAUNCH(true, true); else MF_BN_LAUNCH(true, false); }
+  else { if (channels_last) MF_BN_LAUNCH(false, true); else MF_BN_LAUNCH(false, false); }
+#undef MF_BN_LAUNCH
+  return mf::check_launch("mf_bn_act_fwd");
 }

@@ -72,7 +72,10 @@ class _ConvBlock(nn.Module):
         self.activate = activate
 
     def forward(self, x):
-        h = self.bn(self.conv(x))
+        h = self.conv(x)
+        if ops2d.bn_act_supported(h, self.bn):  # inference: BatchNorm + ReLU in one launch
+            return ops2d.bn_act(h, self.bn, relu=self.activate)
+        h = self.bn(h)
         return F.relu(h) if self.activate else h
 
 
@@ -96,7 +99,11 @@ class _ResUnit(nn.Module):
 
     def forward(self, x):
         identity = x if self.identity_conv is None else self.identity_conv(x)
-        return F.relu(self.body(x) + identity)
+        last = self.body.conv2
+        h = last.conv(self.body.conv1(x))
+        if ops2d.bn_act_supported(h, last.bn) and identity.shape == h.shape:
+            return ops2d.bn_act(h, last.bn, identity=identity, relu=True)  # BatchNorm + add + ReLU in one launch
+        return F.relu(last.bn(h) + identity)
 
 
 class _InitBlock(nn.Module):

@@ -98,6 +98,34 @@ class _PReLU(torch.autograd.Function):
         return dx, da.to(dtype).reshape(shape)
 
 
+def bn_act_supported(x, bn):
+    """The fused BatchNorm(inference) kernel's preconditions: no autograd graph to build, BatchNorm in eval mode with
+    running statistics and affine parameters, a dense fp32 / bf16 CUDA tensor whose layout gives 8-element runs."""
+    if torch.is_grad_enabled() or bn.training or bn.running_mean is None or bn.weight is None:
+        return False
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)) or x.data_ptr() % 16:
+        return False
+    if x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 8 == 0 and x.shape[1] > 1:
+        return True
+    return x.is_contiguous() and (x.shape[2] * x.shape[3]) % 8 == 0
+
+
+def bn_act(x, bn, identity=None, relu=True):
+    """``relu?(bn(x) (+ identity))`` for a BatchNorm2d in eval mode, one launch (csrc/backbone2d.hip k_bn_act)."""
+    _lib.require_gpu(x)
+    B, C, H, W = x.shape
+    cl = not x.is_contiguous()
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    if identity is not None:
+        identity = identity.to(x.dtype).contiguous(memory_format=fmt)
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().mf_bn_act_fwd(x.data_ptr(), _lib.ptr(identity), bn.running_mean.data_ptr(),
+                                        bn.running_var.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                        float(bn.eps), y.data_ptr(), x.numel(), C, H * W, int(cl), int(relu),
+                                        int(x.dtype == torch.bfloat16), _lib.stream_ptr()), "mf_bn_act_fwd")
+    return y
+
+
 class _TailRows(torch.autograd.Function):
     """The 3 x 3 windows of the (virtually) x2 up-sampled map at the sampled pixels as GEMM rows: u2 [B,64,H,W] bf16
     channels-last, pix [B,P] flat indices into [2H,2W] -> [B*P, 576] bf16 (column c * 9 + ky * 3 + kx: the flattened

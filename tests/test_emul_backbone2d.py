@@ -67,3 +67,37 @@ def test_single_slope_prelu_forward_and_backward(ops, dtype, tol):
     assert float((y.float() - yr).abs().max()) <= tol * float(yr.abs().max())
     assert float((xa.grad.float() - xr.grad).abs().max()) <= tol * float(xr.grad.abs().max())
     assert abs(float(slope.grad) - float(sr.grad)) <= 1e-4 * abs(float(sr.grad)) + 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize("layout", ["channels_first", "channels_last"])
+@pytest.mark.parametrize("residual,relu", [(False, True), (True, True), (False, False)])
+def test_batchnorm_inference_add_relu_in_one_launch(ops, monkeypatch, dtype, tol, layout, residual, relu):
+    """ops2d.bn_act (k_bn_act) vs torch's BatchNorm2d in eval mode (+ add) (+ ReLU): ResNet18Extractor's units
+    (models/resnet.py:44; chainercv2 ResUnit)."""
+    torch.manual_seed(4)
+    B, C, H, W = 2, 16, 6, 4
+    bn = torch.nn.BatchNorm2d(C).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.3, 2.0)
+        bn.weight.normal_()
+        bn.bias.normal_()
+    fmt = torch.channels_last if layout == "channels_last" else torch.contiguous_format
+    x = torch.randn(B, C, H, W).to(dtype).contiguous(memory_format=fmt)
+    idn = torch.randn(B, C, H, W).to(dtype).contiguous(memory_format=fmt) if residual else None
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    with torch.no_grad():
+        assert ops.bn_act_supported(x, bn)
+        y = ops.bn_act(x, bn, identity=idn, relu=relu)
+    monkeypatch.undo()
+    with torch.no_grad():
+        ref = bn(x.float())
+        if residual:
+            ref = ref + idn.float()
+        if relu:
+            ref = F.relu(ref)
+    assert y.dtype == dtype and y.shape == x.shape and y.is_contiguous(memory_format=fmt)
+    assert float((y.float() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    assert not ops.bn_act_supported(x, bn)            # a CPU tensor
+    assert not ops.bn_act_supported(x, bn.train())    # training statistics

@@ -50,3 +50,28 @@ def test_prelu_vs_torch(dtype, tol):
     s2 = torch.tensor([0.25], device="cuda", requires_grad=True)
     ops2d.prelu(xa2, s2).backward(g)
     assert float(s2.grad) == float(slope.grad)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize("fmt", [torch.channels_last, torch.contiguous_format], ids=["channels_last", "channels_first"])
+@pytest.mark.parametrize("residual", [False, True])
+def test_batchnorm_inference_add_relu_vs_torch(dtype, tol, fmt, residual):
+    """ops2d.bn_act at ResNet18Extractor's shapes vs torch's BatchNorm2d(eval) (+ add) + ReLU on the GPU."""
+    torch.manual_seed(4)
+    for shape in ((8, 64, 64, 64), (8, 512, 32, 32)):
+        C = shape[1]
+        bn = torch.nn.BatchNorm2d(C).cuda().eval()
+        with torch.no_grad():
+            bn.running_mean.normal_()
+            bn.running_var.uniform_(0.3, 2.0)
+            bn.weight.normal_()
+            bn.bias.normal_()
+            x = torch.randn(shape, device="cuda").to(dtype).contiguous(memory_format=fmt)
+            idn = torch.randn(shape, device="cuda").to(dtype).contiguous(memory_format=fmt) if residual else None
+            assert ops2d.bn_act_supported(x, bn)
+            y = ops2d.bn_act(x, bn, identity=idn, relu=True)
+            ref = bn(x.float())
+            ref = F.relu(ref + idn.float() if residual else ref)
+        assert y.is_contiguous(memory_format=fmt)
+        assert float((y.float() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    assert not ops2d.bn_act_supported(x.requires_grad_(True) if False else x, bn.train())
