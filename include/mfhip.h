@@ -511,6 +511,10 @@ int mf_upsample_bilinear_cf_fwd(const void *x, void *y, int64_t BC, int32_t H, i
 int mf_upsample_bilinear_cf_bwd(const void *gy, void *gx, int64_t BC, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
                                 int32_t bf16, mfStream_t stream);
 int mf_prelu_fwd(const void *x, const float *slope, void *y, int64_t n, int32_t bf16, mfStream_t stream);
+/* ResNet18Extractor's input normalisation (models/resnet.py:33-36): (rgb / 255 - mean) / std on a [B, H, W, 3] image,
+ * uint8 (u8 = 1) or float32 -> float32 [B, H, W, 3]; mean3 / std3 are HOST arrays of three floats. */
+int mf_rgb_normalize(const void *rgb, int32_t u8, const float *mean3, const float *std3, float *out, int64_t npix,
+                     mfStream_t stream);
 /* BatchNorm with inference statistics (+ residual add) (+ ReLU) in one launch (models/resnet.py:44: ResNet18Extractor's
  * BatchNorm never updates): y = relu?((x - mean) * (weight / sqrt(var + eps)) + bias (+ identity)) over a dense
  * [B, C, H, W] tensor, NCHW (8 | H W) or channels-last (8 | C); fp32 / bf16 activations, fp32 parameters. */

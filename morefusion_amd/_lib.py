@@ -119,6 +119,7 @@ _SIGNATURES = {
     "mf_upsample_bilinear_cf_fwd": ([_p, _p, _i64] + [ctypes.c_int32] * 5 + [_p], _i),
     "mf_upsample_bilinear_cf_bwd": ([_p, _p, _i64] + [ctypes.c_int32] * 5 + [_p], _i),
     "mf_prelu_fwd": ([_p, _p, _p, _i64, ctypes.c_int32, _p], _i),
+    "mf_rgb_normalize": ([_p, ctypes.c_int32, _p, _p, _p, _i64, _p], _i),
     "mf_bn_act_fwd": ([_p, _p, _p, _p, _p, _p, ctypes.c_float, _p, _i64, ctypes.c_int32, _i64, ctypes.c_int32,
                        ctypes.c_int32, ctypes.c_int32, _p], _i),
     "mf_prelu_bwd_workspace_floats": ([_i64], _i64),

@@ -321,7 +321,7 @@ class Model(nn.Module):
         -> per-point image features [B,32,P] (``rows=True``: [B*P,32] from the fused tail kernel) and
         camera-frame points [B,3,P]."""
         B = rgb.shape[0]
-        rgb = rgb.float().permute(0, 3, 1, 2)
+        rgb = rgb.permute(0, 3, 1, 2)  # (uint8 or float: the extractor normalises the image as it arrives)
         pcd = pcd.float().permute(0, 3, 1, 2)
         if self.sparse_pspnet_tail and rows:
             values = self.pspnet_extractor.forward_sampled_rows(self.resnet_extractor(rgb), pix)

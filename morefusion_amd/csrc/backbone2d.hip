@@ -335,6 +335,61 @@ __global__ __launch_bounds__(256) void k_bn_act(const void *__restrict__ x, cons
   store8<BF16>(y, 8 * i, v);
 }
 
+// The channels-last form at ResNet widths (C / 8 = G in {8, 16, 32, 64} channel groups): a lane keeps ONE channel group
+// (its 4 x 8 parameters arrive as eight 16-byte loads -- read per element they would be 32 dword loads for 8 elements
+// of data, and the kernel would be bound by its own parameter traffic) and walks `ppt` pixels with it.
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_bn_act_cl(const void *__restrict__ x, const void *__restrict__ identity,
+                                                   const float *__restrict__ mean, const float *__restrict__ var,
+                                                   const float *__restrict__ weight, const float *__restrict__ bias,
+                                                   float eps, void *__restrict__ y, int64_t npix, int G, int ppt, int relu) {
+  const int cg = threadIdx.x % G, lp = threadIdx.x / G, ppb = 256 / G;  // pixels per block pass
+  float mu[8], sc[8], sh[8], vr[8];
+  load8<false>(mean, 8 * cg, mu);
+  load8<false>(var, 8 * cg, vr);
+  load8<false>(weight, 8 * cg, sc);
+  load8<false>(bias, 8 * cg, sh);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sc[k] = sc[k] * (1.0f / sqrtf(vr[k] + eps));
+  const int64_t p0 = (int64_t)blockIdx.x * ppb * ppt + lp;
+  for (int u = 0; u < ppt; ++u) {
+    const int64_t pix = p0 + (int64_t)u * ppb;
+    if (pix >= npix) break;
+    const int64_t e = (pix * G + cg) * 8;
+    float v[8], r[8];
+    load8<BF16>(x, e, v);
+    if (identity) load8<BF16>(identity, e, r);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float o = (v[k] - mu[k]) * sc[k] + sh[k];
+      if (identity) o += r[k];
+      v[k] = relu ? (o > 0.0f ? o : 0.0f) : o;
+    }
+    store8<BF16>(y, e, v);
+  }
+}
+
+// ResNet18Extractor's input normalisation (models/resnet.py:33-36): (rgb / 255 - mean) / std per channel, torch's
+// operation order, on the [B, H, W, 3] image as it arrives (uint8 or float32) -> float32 in the same (channels-last)
+// memory order.  torch: cast, divide, subtract, divide = four launches.
+template <bool U8>
+__global__ __launch_bounds__(256) void k_rgb_norm(const void *__restrict__ rgb, float m0, float m1, float m2, float s0,
+                                                  float s1, float s2, float *__restrict__ out, int64_t npix) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  float r, g, b;
+  if (U8) {
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(rgb) + 3 * i;
+    r = (float)p[0]; g = (float)p[1]; b = (float)p[2];
+  } else {
+    const float *p = reinterpret_cast<const float *>(rgb) + 3 * i;
+    r = p[0]; g = p[1]; b = p[2];
+  }
+  out[3 * i] = (r / 255.0f - m0) / s0;
+  out[3 * i + 1] = (g / 255.0f - m1) / s1;
+  out[3 * i + 2] = (b / 255.0f - m2) / s2;
+}
+
 // dx = dy (x > 0 ? 1 : a); partial[block] = sum over the block's elements with x <= 0 of dy x
 constexpr int kPreluPerThread = 4;  // 8-element chunks per lane: 8192 elements per workgroup
 
@@ -487,6 +542,19 @@ extern "C" int mf_bn_act_fwd(const void *x, const void *identity, const float *m
   if (n % 8 || C <= 0 || HW <= 0 || (channels_last ? C % 8 : HW % 8) ||
       (((uintptr_t)x | (uintptr_t)y | (uintptr_t)identity) & 15))
     return bad2d("bn_act: n % 8 == 0, 8 | C (channels-last) or 8 | H W (NCHW), aligned");
+  const int G = C / 8;
+  if (channels_last && G <= 256 && 256 % G == 0 &&
+      ((((uintptr_t)mean | (uintptr_t)var | (uintptr_t)weight | (uintptr_t)bias) & 15) == 0)) {
+    const int64_t npix = n / C, ppb = 256 / G;
+    int ppt = 1;  // pixels per lane: as many as still leave >= 2048 workgroups (8 per CU), at most 4
+    while (ppt < 4 && npix / (ppb * ppt * 2) >= 2048) ppt *= 2;
+    const unsigned nbp = (unsigned)((npix + ppb * ppt - 1) / (ppb * ppt));
+    if (bf16) hipLaunchKernelGGL(k_bn_act_cl<true>, dim3(nbp), dim3(256), 0, stream, x, identity, mean, var, weight, bias,
+                                 eps, y, npix, G, ppt, relu);
+    else hipLaunchKernelGGL(k_bn_act_cl<false>, dim3(nbp), dim3(256), 0, stream, x, identity, mean, var, weight, bias, eps,
+                            y, npix, G, ppt, relu);
+    return mf::check_launch("mf_bn_act_fwd");
+  }
   const unsigned nb = (unsigned)((n / 8 + 255) / 256);
 #define MF_BN_LAUNCH(BF, CL_)                                                                                   \
   hipLaunchKernelGGL((k_bn_act<BF, CL_>), dim3(nb), dim3(256), 0, stream, x, identity, mean, var, weight, bias, eps, y, \
@@ -495,4 +563,17 @@ extern "C" int mf_bn_act_fwd(const void *x, const void *identity, const float *m
   else { if (channels_last) MF_BN_LAUNCH(false, true); else MF_BN_LAUNCH(false, false); }
 #undef MF_BN_LAUNCH
   return mf::check_launch("mf_bn_act_fwd");
+}
+
+/* (rgb / 255 - mean) / std of a [B, H, W, 3] image, uint8 (u8 = 1) or float32, -> float32 [B, H, W, 3]. */
+extern "C" int mf_rgb_normalize(const void *rgb, int32_t u8, const float *mean3, const float *std3, float *out,
+                                int64_t npix, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (npix <= 0) return 0;
+  const unsigned nb = (unsigned)((npix + 255) / 256);
+  if (u8) hipLaunchKernelGGL(k_rgb_norm<true>, dim3(nb), dim3(256), 0, stream, rgb, mean3[0], mean3[1], mean3[2], std3[0],
+                             std3[1], std3[2], out, npix);
+  else hipLaunchKernelGGL(k_rgb_norm<false>, dim3(nb), dim3(256), 0, stream, rgb, mean3[0], mean3[1], mean3[2], std3[0],
+                          std3[1], std3[2], out, npix);
+  return mf::check_launch("mf_rgb_normalize");
 }

@@ -148,10 +148,16 @@ class ResNet18Extractor(nn.Module):
         return self
 
     def forward(self, x):
-        h = (x / 255.0 - self.mean) / self.std
-        h = self.init_block(h)
-        h = self.res2.unit2(self.res2.unit1(h))
-        h = h.detach()  # unchain_at="res2"
+        hwc = x.permute(0, 2, 3, 1)
+        if (x.is_cuda and x.shape[1] == 3 and x.dtype in (torch.uint8, torch.float32) and hwc.is_contiguous()
+                and not x.requires_grad):
+            h = ops2d.normalize_rgb(hwc, self.mean_rgb, self.std_rgb)  # the image as it arrives, one launch
+        else:
+            h = (x.float() / 255.0 - self.mean) / self.std
+        with torch.no_grad():  # unchain_at="res2" (resnet.py:47-48): no gradient reaches these layers -- no graph either
+            h = self.init_block(h)
+            h = self.res2.unit2(self.res2.unit1(h))
+        h = h.detach()
         for n in (3, 4, 5):
             stage = getattr(self, f"res{n}")
             h = stage.unit2(stage.unit1(h))

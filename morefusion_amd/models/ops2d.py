@@ -5,6 +5,8 @@ PReLU (:57) -- forward and backward, on channels-last float32 / bfloat16 tensors
 The stock kernels run these far below the HBM roofline (the resize backward is a float-atomic scatter, the PReLU slope
 gradient a whole-tensor reduction: 2.8 + 1.3 ms of a 25 ms bf16 training step); here the backward passes are a
 deterministic gather and a two-stage block sum.  No fallback: tensors must live on the GPU."""
+import os
+
 import torch
 
 from .. import _lib
@@ -98,10 +100,28 @@ class _PReLU(torch.autograd.Function):
         return dx, da.to(dtype).reshape(shape)
 
 
+def normalize_rgb(rgb_hwc, mean, std):
+    """``(rgb / 255 - mean) / std`` of a [B, H, W, 3] image (uint8 or float32, contiguous) in one launch -> float32
+    [B, 3, H, W] in channels-last memory (what ``rgb.float().permute(0, 3, 1, 2)`` followed by the three elementwise
+    operations gives)."""
+    import ctypes
+    _lib.require_gpu(rgb_hwc)
+    B, H, W, _ = rgb_hwc.shape
+    out = torch.empty((B, H, W, 3), dtype=torch.float32, device=rgb_hwc.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    _lib.check(_lib.lib().mf_rgb_normalize(rgb_hwc.data_ptr(), int(rgb_hwc.dtype == torch.uint8),
+                                           ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p),
+                                           out.data_ptr(), B * H * W, _lib.stream_ptr()), "mf_rgb_normalize")
+    return out.permute(0, 3, 1, 2)
+
+
 def bn_act_supported(x, bn):
     """The fused BatchNorm(inference) kernel's preconditions: no autograd graph to build, BatchNorm in eval mode with
     running statistics and affine parameters, a dense fp32 / bf16 CUDA tensor whose layout gives 8-element runs."""
     if torch.is_grad_enabled() or bn.training or bn.running_mean is None or bn.weight is None:
+        return False
+    if os.environ.get("MF_TORCH_BN") == "1":  # (A/B knob: torch's three launches)
         return False
     if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)) or x.data_ptr() % 16:
         return False

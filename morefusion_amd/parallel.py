@@ -213,9 +213,16 @@ class DataParallelStep:
         # ProcessGroupNCCL's watchdog THREAD polls the events of the eager all-reduces (hipEventQuery): under the
         # default global capture mode any such call from any thread while this thread captures is an error and the
         # process aborts (seen at world size 1 when a warm-up step's all-reduce was still being reaped).  The exchange
-        # is never part of a capture here, so thread-local mode is exact: only this thread's calls are checked.
+        # is never part of a capture here.
+        # Thread-local mode was not enough on every run (one abort in six processes: the watchdog's query landed inside
+        # the capture and was still refused), so: relaxed mode -- no call of any thread is checked; nothing this thread
+        # does while capturing is unsafe (allocations come from the graph's pool) -- and the watchdog gets time to
+        # reap the finished all-reduces (its poll period is 100 ms) before the capture begins.
         torch.cuda.synchronize()
-        mode = dict(capture_error_mode="thread_local")
+        if self.exchange:
+            import time
+            time.sleep(0.3)
+        mode = dict(capture_error_mode="relaxed")
         self.graph_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_fb, stream=stream, **mode):
             self.static_loss = self._forward_backward(self.static)

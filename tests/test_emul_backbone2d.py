@@ -101,3 +101,16 @@ def test_batchnorm_inference_add_relu_in_one_launch(ops, monkeypatch, dtype, tol
     assert float((y.float() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
     assert not ops.bn_act_supported(x, bn)            # a CPU tensor
     assert not ops.bn_act_supported(x, bn.train())    # training statistics
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.float32])
+def test_rgb_normalisation_in_one_launch_is_bit_equal_to_the_composite(ops, dtype):
+    """ops2d.normalize_rgb (k_rgb_norm) vs ``(rgb / 255 - mean) / std`` (models/resnet.py:33-36), same operation order."""
+    from morefusion_amd.models.backbone2d import ResNet18Extractor as R
+    torch.manual_seed(0)
+    rgb = torch.randint(0, 256, (2, 5, 7, 3), dtype=torch.uint8).to(dtype)
+    y = ops.normalize_rgb(rgb, R.mean_rgb, R.std_rgb)
+    x = rgb.float().permute(0, 3, 1, 2)
+    ref = (x / 255.0 - torch.tensor(R.mean_rgb).view(1, 3, 1, 1)) / torch.tensor(R.std_rgb).view(1, 3, 1, 1)
+    assert y.shape == ref.shape and y.stride() == ref.stride()
+    assert torch.equal(y, ref)

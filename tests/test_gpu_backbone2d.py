@@ -75,3 +75,48 @@ def test_batchnorm_inference_add_relu_vs_torch(dtype, tol, fmt, residual):
         assert y.is_contiguous(memory_format=fmt)
         assert float((y.float() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
     assert not ops2d.bn_act_supported(x.requires_grad_(True) if False else x, bn.train())
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.float32])
+def test_rgb_normalisation_is_bit_equal_to_the_torch_composite(dtype):
+    from morefusion_amd.models.backbone2d import ResNet18Extractor as R
+    torch.manual_seed(0)
+    rgb = torch.randint(0, 256, (8, 256, 256, 3), dtype=torch.uint8, device="cuda").to(dtype)
+    import numpy as np
+    y = ops2d.normalize_rgb(rgb, R.mean_rgb, R.std_rgb)
+    x = rgb.float().permute(0, 3, 1, 2)
+    # the reference divides (models/resnet.py:43, NumPy / CuPy true division): bit-equal to that; torch's CUDA
+    # `x / 255.0` multiplies by the rounded reciprocal -- the composite differs from both by up to an ulp of the quotient
+    xn = x.cpu().numpy()
+    ref_np = (xn / np.float32(255.0) - np.asarray(R.mean_rgb, np.float32)[None, :, None, None]) / \
+        np.asarray(R.std_rgb, np.float32)[None, :, None, None]
+    assert ref_np.dtype == np.float32 and np.array_equal(y.cpu().numpy(), ref_np)
+    ref = (x / 255.0 - torch.tensor(R.mean_rgb, device="cuda").view(1, 3, 1, 1)) / \
+        torch.tensor(R.std_rgb, device="cuda").view(1, 3, 1, 1)
+    assert y.stride() == ref.stride()
+    torch.testing.assert_close(y, ref, rtol=0, atol=1e-6)
+    net = R().cuda().eval()
+    with torch.no_grad():   # the extractor takes the image as it arrives (uint8 or float) and gives the same features
+        a = net(rgb.permute(0, 3, 1, 2))
+        b = net(x.contiguous())   # NCHW-contiguous float: the composite branch
+    assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+
+
+def test_resnet18_extractor_inference_runs_on_the_fused_batchnorm_launch(monkeypatch):
+    """Under no_grad every BatchNorm of ResNet18Extractor goes through ops2d.bn_act (20 of them, 8 with the residual
+    add); with MF_TORCH_BN=1 none does, and the features agree."""
+    from morefusion_amd.models.backbone2d import ResNet18Extractor as R
+    torch.manual_seed(1)
+    net = R().cuda().eval()
+    rgb = torch.randint(0, 256, (2, 256, 256, 3), dtype=torch.uint8, device="cuda")
+    calls = []
+    real = ops2d.bn_act
+    monkeypatch.setattr(ops2d, "bn_act", lambda x, bn, identity=None, relu=True:
+                        (calls.append(identity is not None), real(x, bn, identity=identity, relu=relu))[1])
+    with torch.no_grad():
+        a = net(rgb.permute(0, 3, 1, 2))
+        assert len(calls) == 20 and sum(calls) == 8
+        monkeypatch.setenv("MF_TORCH_BN", "1")
+        b = net(rgb.permute(0, 3, 1, 2))
+        assert len(calls) == 20
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())

@@ -334,7 +334,9 @@ def test_sampled_pspnet_tail_on_the_bf16_kernels_vs_torch_formulation():
     def l2(a, b):
         return float((a.detach().float() - b.detach().float()).norm() / b.detach().float().norm())
 
-    for slope, err, tol in ((1.0, rel, 2e-2), (0.25, l2, 2e-2)):
+    # slope 0.25 (the initial value): a pre-activation that the bf16 forward rounds across 0 takes the other slope -- a
+    # quarter of a per cent of them do, each moving its 576 window gradients by 75 % -> a few per cent in L2
+    for slope, err, tol in ((1.0, rel, 2e-2), (0.25, l2, 6e-2)):
         with torch.no_grad():
             net.up3.prelu.weight.fill_(slope)
         net.zero_grad()
@@ -349,7 +351,7 @@ def test_sampled_pspnet_tail_on_the_bf16_kernels_vs_torch_formulation():
         ref = net._tail(ub, taps)
         ref.backward(g.reshape(B, P, 32).transpose(1, 2))
         assert rel(out, ref.transpose(1, 2).reshape(B * P, 32)) < 2e-2
-        assert l2(got_u, ub.grad) < 1e-2 and err(got_u, ub.grad) < 5e-2
+        assert l2(got_u, ub.grad) < (1e-2 if slope == 1.0 else tol) and err(got_u, ub.grad) < 6e-2
         assert set(got) == {"up3.conv.weight", "up3.conv.bias", "up3.prelu.weight", "conv1.weight", "conv1.bias"}
         for k, v in got.items():
             # (the slope's gradient is ONE number: a sum of 256 000 products of either sign that cancels to ~1e-4 of

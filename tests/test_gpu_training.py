@@ -128,7 +128,7 @@ def test_hipgraph_captured_training_step_tracks_the_eager_step(tmp_path):
         out = tmp_path / f"{tag}.json"
         p = subprocess.run([sys.executable, script, "--global-batch", "4", "--steps", "7", "--no-dropout", "--json", str(out)] + extra,
                            env=env, capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-2000:]
+        assert p.returncode == 0, (tag, p.stderr[:1500], p.stderr[-2500:])
         recs[tag] = json.loads(out.read_text())
     assert recs["graph"]["hipgraph_step"] and not recs["eager"]["hipgraph_step"]
     le, lg = np.array(recs["eager"]["loss_per_step"]), np.array(recs["graph"]["loss_per_step"])
@@ -157,7 +157,7 @@ def test_hipgraph_captured_data_parallel_step_over_rccl_tracks_the_eager_ddp_ste
         out = tmp_path / f"{tag}.json"
         p = subprocess.run([sys.executable, script, "--global-batch", "4", "--steps", "8", "--no-dropout", "--json", str(out)] + extra,
                            env=env, capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-2000:]
+        assert p.returncode == 0, (tag, p.stderr[:1500], p.stderr[-2500:])
         recs[tag] = json.loads(out.read_text())
         assert recs[tag]["ddp"] and recs[tag]["backend"] == "nccl (RCCL)"
     assert recs["graph_dp"]["hipgraph_step"] and not recs["eager_ddp"]["hipgraph_step"]
