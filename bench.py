@@ -870,6 +870,7 @@ def main():
             torch.cuda.synchronize()
         if not args.no_latency_probe:
             out["latency_batch1_ms"] = latency_batch1(wl)  # child process, last: nothing of this one depends on it
+        out["bench_wall_s"] = round(time.perf_counter() - T_START, 1)  # this process, after the imports
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
