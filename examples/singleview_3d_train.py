@@ -106,6 +106,8 @@ def main():
     rs = np.random.RandomState(0)
     pcds = {c: rs.uniform(-0.05, 0.05, (2000, 3)).astype(np.float32) for c in morefusion.synthetic.CLASS_PITCH}
     model = Model(n_fg_class=21, with_occupancy=True, models=PitchTableModels(pcds)).to(device).train()
+    if use_ddp:
+        parallel.dense_grad_strides(model)  # (MIOpen's 1x1-convolution weight gradients: see there)
     side = torch.cuda.Stream(device=device) if args.graph else None
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if use_ddp and not args.graph else model
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=bool(args.graph))

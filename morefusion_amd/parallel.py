@@ -133,6 +133,24 @@ def timed_steps(step, steps, warmup, device=None, group=None):
     return elapsed
 
 
+def dense_grad_strides(module):
+    """Give every parameter gradient the parameter's own strides.  MIOpen returns the weight gradient of a 1 x 1
+    convolution with channels-last strides ([2560, 1, 2560, 2560] for a [1024, 2560, 1, 1] weight: the same bytes as
+    the contiguous [2560, 1, 1, 1], the size-1 dimensions carry no information); DistributedDataParallel compares
+    strides literally, warns "Grad strides do not match bucket view strides" and copies through a slower path.  A
+    hook re-views such a gradient with the parameter's strides (no copy, no launch)."""
+    def hook_for(p):
+        def hook(g):
+            if g.stride() != p.stride() and g.is_contiguous() and p.is_contiguous():
+                return g.as_strided(g.shape, p.stride())
+            return g
+        return hook
+    for p in module.parameters():
+        if p.requires_grad and p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1:
+            p.register_hook(hook_for(p))
+    return module
+
+
 class DataParallelStep:
     """Data-parallel optimiser step whose device work can be replayed from hipGraphs (BASELINE config 5:
     ``train.py:228-233,342-344`` -- ChainerMN's multi-node optimizer all-reduces the gradients of every rank's

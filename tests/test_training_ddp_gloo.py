@@ -165,3 +165,19 @@ def test_ddp_training_step_averages_the_two_ranks_gradients(tmp_path, mode):
         if mode == "flat_bucket":  # ... and the SGD update it drove is that mean, on both ranks
             for r in range(2):
                 torch.testing.assert_close(got[r]["update"][n], mean, rtol=2e-3, atol=1e-6 + 2e-3 * float(mean.abs().max()))
+
+
+def test_dense_grad_strides_reviews_a_channels_last_strided_1x1_weight_gradient():
+    """parallel.dense_grad_strides: the hook hands DDP a gradient with the parameter's strides (MIOpen returns the
+    1 x 1 convolutions' weight gradients with channels-last strides; same bytes), without copying."""
+    import torch
+    from morefusion_amd import parallel
+    conv = parallel.dense_grad_strides(torch.nn.Conv2d(8, 4, 1))
+    g = torch.randn(4, 8, 1, 1).as_strided((4, 8, 1, 1), (8, 1, 8, 8))
+    (hook,) = conv.weight._backward_hooks.values()
+    out = hook(g)
+    assert out.stride() == conv.weight.stride() and out.data_ptr() == g.data_ptr() and torch.equal(out, g)
+    assert hook(out) is out
+    assert not getattr(torch.nn.Conv2d(8, 4, 3).weight, "_backward_hooks", None)  # (only 1 x 1 kernels get one)
+    conv(torch.randn(2, 8, 3, 3)).sum().backward()
+    assert conv.weight.grad.stride() == conv.weight.stride()
