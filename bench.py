@@ -780,7 +780,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    walls = {}
+    t_sec = [time.perf_counter()]
+
+    def lap(name):  # wall seconds of the bench's sections (reported as bench_wall_sections_s)
+        now = time.perf_counter()
+        walls[name] = round(now - t_sec[0], 1)
+        t_sec[0] = now
+
     wl = Workload(args, rank, device)
+    lap("setup")
 
     mark = os.environ.get("MF_BENCH_MARK")  # profiling aid: bracket the timed steps in the kernel trace
     if mark:  # (k_icc_scene_setup only runs in mf_icc_prepare: its 2nd / 3rd instance are the brackets)
@@ -793,6 +802,7 @@ def main():
         wl.icc.prepare()
         torch.cuda.synchronize()
 
+    lap("warmup_and_timed_steps")
     # un-timed extras: stage breakdown, live kernel timing, CPU baseline (rank 0, N=1)
     wl.events = []
     for _ in range(5):
@@ -848,10 +858,13 @@ def main():
         out["roofline"] = roofline_icc(wl, t_icc * 1e3 / args.icc_iters)  # all scenes share the launches
         out["roofline_voxelize"] = roofline_voxelize(wl)
         out["roofline_bf16_kernels"] = roofline_bf16_kernels(wl)
+        lap("rooflines")
         out["accuracy"] = accuracy(wl)
+        lap("accuracy")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args)
         torch.cuda.synchronize()
+        lap("cpu_baseline")
         if world == 1 and not args.no_extras and args.scenes_per_gpu == 1:
             # configs[3] / configs[4] per-GPU shares inside the driver-run line (round-4 verdict item 7)
             try:  # (the extras must never take the headline line down)
@@ -860,9 +873,11 @@ def main():
                 out["scenes8"] = s8
             except Exception as e:
                 out["scenes8"] = {"error": repr(e)[:200]}
+            lap("extra_scenes8")
             tr = extra_training()
             out["train_objects_per_s"] = tr.get("train_objects_per_s")
             out["training"] = tr
+            lap("extra_training")
             if time.perf_counter() - T_START < 75.0:  # the same step replayed from hipGraphs (--graph), time permitting
                 tg = extra_training(graph=True)
                 out["train_objects_per_s_hipgraph"] = tg.get("train_objects_per_s")
@@ -870,6 +885,10 @@ def main():
             torch.cuda.synchronize()
         if not args.no_latency_probe:
             out["latency_batch1_ms"] = latency_batch1(wl)  # child process, last: nothing of this one depends on it
+            lap("latency_probe")
+        # (where the wall time goes: MIOpen's solver search runs its candidates on the GPU for every new shape --
+        # ~12 s for the headline's B = 8, ~45 s for the 8-scene extra's B = 64, ~30 s for the training child)
+        out["bench_wall_sections_s"] = walls
         out["bench_wall_s"] = round(time.perf_counter() - T_START, 1)  # this process, after the imports
         print(json.dumps(out))
     if world > 1:
