@@ -1816,7 +1816,10 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   stamp(4);
 }
 
-__global__ __launch_bounds__(kTileThreads, 4) void k_icc_fused(IccArgs a, int par) {  // 2 workgroups per CU
+#ifndef MF_ICC_FUSED_WPE
+#define MF_ICC_FUSED_WPE 4  // waves per SIMD the register budget is cut for (4: 128 VGPRs; 5: 96; 6: 80; 8: 64)
+#endif
+__global__ __launch_bounds__(kTileThreads, MF_ICC_FUSED_WPE) void k_icc_fused(IccArgs a, int par) {  // 2 workgroups per CU
   __shared__ FusedLds L;
   // Workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md): with the plain (tile, object)
   // numbering the 64 tiles of a grid are spread over all eight L2s and each of them fetches the grid's records,
