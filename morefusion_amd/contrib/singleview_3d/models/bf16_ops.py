@@ -399,8 +399,9 @@ class PoseEpilogue(torch.autograd.Function):
         _lib.require_gpu(orot, otrn, ocnf, pts)
         L = _lib.lib()
         orot, otrn, ocnf = _lib.f32c(orot), _lib.f32c(otrn), _lib.f32c(ocnf)
-        cid = class_id.detach().to(torch.int64).contiguous()
+        cid = torch.as_tensor(class_id).detach().to(device=orot.device, dtype=torch.int64).contiguous()
         pts_, pit, org = _lib.f32c(pts), _lib.f32c(pitch), _lib.f32c(origin)
+        _lib.require_gpu(pit, org)
         rot = _empty((B, P, 4), torch.float32, orot)
         trans = _empty((B, P, 3), torch.float32, orot)
         conf = _empty((B, P), torch.float32, orot)
