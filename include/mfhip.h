@@ -533,6 +533,11 @@ int mf_prelu_bwd(const void *x, const void *dy, const float *slope, void *dx, fl
  *     4c / 3c / c) -> rot [n,4] = q / (|q| + 1e-5) (chainer F.normalize), trans [n,3] = (p*pitch + origin) +
  *     t*pitch (:264-266), conf [n] = sigmoid (:262) of each object's class (class_id int64 [B], 1-based; an id
  *     outside 1 .. n_fg gives NaN outputs, never a read outside the row). */
+/* Tile height (64 / 128 / 256 rows) the bf16 NT engine used for its most recent launch in this process (the
+ * 256 x 256 form -- eight waves of 128 x 64 -- takes problems with >= 224 such tiles; MF_NT_BIG = 0 / 2 in the
+ * environment forces never / wherever possible). */
+int mf_gemm_bf16_last_tile(void);
+
 /* PSPNet's sampled tail under bf16 training (pspnet.py:18-22,50-56 at model.py:222's pixels): the 3 x 3 windows of
  * the virtually x2 up-sampled map as GEMM rows [B * P, 576] bf16 (column c * 9 + ky * 3 + kx) from the channels-last
  * bf16 map u2 [B, H, W, 64], pix [B * P] flat indices into [2H, 2W]; and the backward: grows -> gu2 [B, H, W, 64] bf16

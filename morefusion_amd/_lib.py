@@ -124,6 +124,7 @@ _SIGNATURES = {
                        ctypes.c_int32, ctypes.c_int32, _p], _i),
     "mf_prelu_bwd_workspace_floats": ([_i64], _i64),
     "mf_prelu_bwd": ([_p, _p, _p, _p, _p, _p, _i64, ctypes.c_int32, _p], _i),
+    "mf_gemm_bf16_last_tile": ([], _i),
     "mf_psp_tail_rows_bf16_fwd": ([_p, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p], _i),
     "mf_psp_tail_rows_bf16_bwd": ([_p, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _p, _p, _p], _i),
     "mf_confidence_loss_fwd": ([_p, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, _p, _p, _p], _i),

@@ -27,6 +27,8 @@
 // 2 workgroups per CU.  Masked operand chunks (padding taps, tails) are buffer loads at an out-of-range offset: the
 // hardware returns zeros, nothing touches the loaded data (mf_common.h).  The epilogue goes through LDS: bias +
 // ReLU on the way in, 16-byte row segments out (bf16 or fp32, optionally accumulating into an fp32 tensor).
+#include <cstdlib>
+
 #include "mf_common.h"
 
 namespace {
@@ -327,6 +329,286 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
         for (int j = 0; j < nv; ++j) o[j] = (uint16_t)mf::bf16_bits(v[j]);
       }
     }
+  }
+}
+
+// ---- the 256 x 256 x 64 form of the NT engine (round 5): eight waves, each a 128 x 64 corner = 4 x 2 accumulators ----
+// A wave of the 128 x 128 tile reads one LDS fragment (ds_read_b128) per MFMA: at the MFMA rate of gfx950 that alone
+// keeps the LDS pipe busy all the time (1 KB per wave per 32-cycle MFMA, four SIMDs, 128 B / clock).  With a 128 x 64
+// wave tile a k-step reads 4 + 2 fragments for 8 MFMAs -- 0.75 per MFMA; one workgroup of 512 lanes per CU (2 x 74 KB
+// of operand buffers), two waves per SIMD.  Same loaders, masks and staging order as k_gemm_nt_bf16 (rows r0 + 64 i);
+// the epilogue goes through LDS in four passes of 64 rows.  Used when the problem has enough 256 x 256 tiles to
+// fill the chip (launch_nt); conv dgrad tiles stay class-homogeneous for Do^3 % 256 == 0.
+constexpr int kBigM = 256, kBigN = 256;
+#ifndef MF_NT_BIG_UNROLL  // k-steps of a K-tile in flight (fragments held): 2 -> 218-226 VGPRs, no spill (budget 256)
+#define MF_NT_BIG_UNROLL _Pragma("unroll 2")
+#endif
+constexpr int nt_big_lds() { return 2 * (kBigM + kBigN) * kPitch; }
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_big(NtArgs a) {
+  MF_DYN_LDS(unsigned char, s_raw);
+  constexpr int kBM = kBigM, kBNb = kBigN, kBuf = (kBigM + kBigN) * kPitch;
+  const int tiles_m = (a.M + kBM - 1) / kBM, tiles_n = (a.N + kBNb - 1) / kBNb;
+  const int per_group = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  int L = blockIdx.x;
+  if ((G & 7) == 0) L = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous logical order
+  const int grp = L / per_group;
+  const int rem = L - grp * per_group;
+  const int m0 = (rem / tiles_n) * kBM, n0 = (rem % tiles_n) * kBNb;  // N tile fastest (csrc/linear.hip)
+  const int T = (a.K + kBK - 1) / kBK;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wn = wave >> 1;  // 2 x 4 waves of 128 x 64
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  const int chunk = tid & 7, r0 = tid >> 3;  // this lane stages rows r0 + 64 i, bf16 8 chunk .. + 7 of the K-tile
+
+  const int Do = a.Do, dol = a.olog;
+  const uint16_t *A = a.A + grp * a.a_gs;
+  const uint16_t *W = a.W + grp * a.w_gs;
+  if (MODE == kRows && a.tile_group) {
+    const int g = a.tile_group[m0 >> 6];  // (block-uniform)
+    if (g < 0) return;
+    W += (int64_t)g * a.w_gs;
+  }
+  int cls = 0;
+  if (MODE == kConvDgrad) {  // tile-uniform parity class: its weight slice
+    cls = (m0 >> (3 * dol)) & 7;
+    W += (int64_t)cls * a.N * a.ldw;
+  }
+  // per staged row: element offset of its k = 0 chunk and validity bits
+  //   rows:        bit 12 = row exists
+  //   conv fwd:    bits kx | 4 + ky | 8 + kz = tap coordinate inside the grid (csrc/conv3d.hip)
+  //   conv dgrad:  bits sx | 4 + sy | 8 + sz = contributing output voxel h + p - s inside the output grid
+  int base[4], mask[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r0 + 64 * i;
+    const bool row_ok = m < a.M;
+    const int mm = row_ok ? m : 0;
+    int mk = row_ok ? 1 << 12 : 0;
+    if (MODE == kRows) {
+      base[i] = mm * a.lda;
+    } else if (MODE == kConvFwd) {
+      const int b = mm >> (3 * dol), o = mm & ((1 << (3 * dol)) - 1);
+      const int ox = o >> (2 * dol), oy = (o >> dol) & (Do - 1), oz = o & (Do - 1);
+      const int x0 = a.stride * ox - a.pad, y0 = a.stride * oy - a.pad, z0 = a.stride * oz - a.pad;
+      base[i] = (((b * a.D + x0) * a.D + y0) * a.D + z0) * a.Cin;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // (k >= ks: never asked for)
+        mk |= ((unsigned)(x0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << k;
+        mk |= ((unsigned)(y0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (4 + k);
+        mk |= ((unsigned)(z0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (8 + k);
+      }
+    } else {
+      // m = ((b * 8 + p) * Do^3 + h): input voxel x = 2 h + p per axis
+      const int h = mm & ((1 << (3 * dol)) - 1), b = mm >> (3 * dol + 3);
+      const int hx = h >> (2 * dol), hy = (h >> dol) & (Do - 1), hz = h & (Do - 1);
+      const int ux = hx + (cls & 1), uy = hy + ((cls >> 1) & 1), uz = hz + ((cls >> 2) & 1);  // slot (0,0,0)
+      base[i] = (((b * Do + ux) * Do + uy) * Do + uz) * a.Cout;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        mk |= ((unsigned)(ux - s) < (unsigned)Do ? 1 : 0) << s;
+        mk |= ((unsigned)(uy - s) < (unsigned)Do ? 1 : 0) << (4 + s);
+        mk |= ((unsigned)(uz - s) < (unsigned)Do ? 1 : 0) << (8 + s);
+      }
+    }
+    mask[i] = mk;
+  }
+  uint32_t wrow[4];  // byte offsets into W (weights: far below 2^32 bytes)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + r0 + 64 * i;
+    wrow[i] = 2u * (uint32_t)((int64_t)(n < a.N ? n : 0) * a.ldw);
+  }
+
+  mf_f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // K-tile kt -> registers.  Nothing touches the loaded data before the stash: a select right behind a load would
+  // make the wave wait for its own data at once (s_waitcnt vmcnt(0) in front of the MFMAs) and the prefetch would
+  // hide nothing.
+  // (Scalars and macros, not arrays in lambdas: behind the "memory" clobber that pins the loads in front of the MFMAs,
+  // arrays captured by reference were kept in scratch memory -- every load waited for and stored.)
+  // ONE register set, one tile ahead.  (Two sets -- tile t + 2 in flight while t + 1 waits -- were measured twice in
+  // round 4, before and after the VALU diet: no gain on any shape, 90 more registers.)
+  uint4 ra0P, ra1P, ra2P, ra3P, rb0P, rb1P, rb2P, rb3P;
+  // This lane's position in K, advanced by one K-tile per fetch (the fetches run over kt = 0, 1, 2, ... in order): the
+  // chunk's k offset and, for the convolutions, its (tap, channel) -- tracked incrementally (round 4, first version:
+  // two integer divisions per fetch and 64-bit address arithmetic per load, 12 VALU instructions per MFMA by
+  // SQ_INSTS_VALU; the MFMA pipe at 0.37).
+  int kg = 8 * chunk, tc = 0, tx = 0, ty = 0, tz = 0;  // conv fwd: tap (tx, ty, tz), channel tc; dgrad: slot tx, cout tc
+  if (MODE == kConvFwd) {
+    const int tap = kg / a.Cin;
+    tc = kg - tap * a.Cin;
+    const int kxy = tap / a.ks;
+    tz = tap - kxy * a.ks; tx = kxy / a.ks; ty = kxy - tx * a.ks;
+  } else if (MODE == kConvDgrad) {
+    tx = kg / a.Cout;
+    tc = kg - tx * a.Cout;
+  }
+  // A masked chunk (padding tap, row past the edge, K tail) is a buffer load at an OUT-OF-RANGE offset: the hardware
+  // returns zeros (mf_common.h).  No select or AND on the loaded data (that was 44 VALU instructions per K-tile in
+  // every wave that touches a border -- nearly all of them in a 16^3 grid), and the stash is eight plain
+  // ds_write_b128.  The weight operand needs no mask at all: behind the K tail it re-reads k = 0 (finite; the A chunk
+  // there is zero), and a column past N re-reads row 0 into an accumulator column the epilogue never stores.
+  const mf::BufRsrc Ars = mf::make_rsrc(A), Wrs = mf::make_rsrc(W);
+#define MF_NT_LOAD_A(S, i_, reg_)                                                                     \
+  reg_ = mf::buf_load16(Ars, (mask[i_] & bits_) == bits_ ? 2u * (uint32_t)(base[i_] + off_) : mf::kBufMasked);
+#define MF_NT_LOAD_B(S, i_, reg_) reg_ = mf::buf_load16(Wrs, wrow[i_] + kofs_);
+#define MF_NT_FETCH(S)                                                                                \
+  {                                                                                                   \
+    const bool kin_ = kg + 8 <= a.K;                                                                  \
+    const uint32_t kofs_ = kin_ ? 2u * (uint32_t)kg : 0u;                                             \
+    int off_ = kg, bits_ = 1 << 12;                                                                   \
+    if (MODE == kConvFwd) {                                                                           \
+      off_ = ((tx * a.D + ty) * a.D + tz) * a.dil * a.Cin + tc;                                       \
+      bits_ = tx < a.ks ? (1 << tx) | (16 << ty) | (256 << tz) | (1 << 12) : 1 << 13;                 \
+    } else if (MODE == kConvDgrad) {                                                                  \
+      const int sx = tx & 1, sy = (tx >> 1) & 1, sz = tx >> 2;                                        \
+      off_ = tc - ((sx * Do + sy) * Do + sz) * a.Cout;                                                \
+      bits_ = (1 << sx) | (16 << sy) | (256 << sz) | (1 << 12);                                       \
+    }                                                                                                 \
+    if (!kin_) bits_ = 1 << 13; /* (no row has bit 13) */                                             \
+    MF_NT_LOAD_A(S, 0, ra0##S) MF_NT_LOAD_A(S, 1, ra1##S) MF_NT_LOAD_A(S, 2, ra2##S) MF_NT_LOAD_A(S, 3, ra3##S) \
+    MF_NT_LOAD_B(S, 0, rb0##S) MF_NT_LOAD_B(S, 1, rb1##S) MF_NT_LOAD_B(S, 2, rb2##S) MF_NT_LOAD_B(S, 3, rb3##S) \
+    kg += kBK;                                                                                        \
+    if (MODE == kConvFwd) {                                                                           \
+      tc += kBK;                                                                                      \
+      while (tc >= a.Cin) {                                                                           \
+        tc -= a.Cin;                                                                                  \
+        if (++tz == a.ks) { tz = 0; if (++ty == a.ks) { ty = 0; ++tx; } }                             \
+      }                                                                                               \
+    } else if (MODE == kConvDgrad) {                                                                  \
+      tc += kBK;                                                                                      \
+      while (tc >= a.Cout) { tc -= a.Cout; ++tx; }                                                    \
+    }                                                                                                 \
+  }
+  // (MF_HOLD: the staged registers stay opaque until here, BEHIND the MFMAs -- and with them the wait for the loads.)
+#define MF_NT_STASH(S, buf_)                                                                          \
+  {                                                                                                   \
+    MF_HOLD(ra0##S); MF_HOLD(ra1##S); MF_HOLD(ra2##S); MF_HOLD(ra3##S);                               \
+    MF_HOLD(rb0##S); MF_HOLD(rb1##S); MF_HOLD(rb2##S); MF_HOLD(rb3##S);                               \
+    unsigned char *As_ = s_raw + (buf_) * kBuf + r0 * kPitch + 16 * chunk;                            \
+    unsigned char *Bs_ = As_ + kBM * kPitch;                                                          \
+    *reinterpret_cast<uint4 *>(As_) = ra0##S; *reinterpret_cast<uint4 *>(As_ + 64 * kPitch) = ra1##S; \
+    *reinterpret_cast<uint4 *>(As_ + 128 * kPitch) = ra2##S; *reinterpret_cast<uint4 *>(As_ + 192 * kPitch) = ra3##S; \
+    *reinterpret_cast<uint4 *>(Bs_) = rb0##S; *reinterpret_cast<uint4 *>(Bs_ + 64 * kPitch) = rb1##S; \
+    *reinterpret_cast<uint4 *>(Bs_ + 128 * kPitch) = rb2##S; *reinterpret_cast<uint4 *>(Bs_ + 192 * kPitch) = rb3##S; \
+  }
+  // NJ_ = 2: both 32-column blocks of the wave's 64 columns; NJ_ = 1: the first only (the second lies past N)
+#define MF_NT_COMPUTE(buf_, NJ_)                                                                      \
+  {                                                                                                   \
+    asm volatile("" ::: "memory");                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    const unsigned char *As = s_raw + (buf_) * kBuf + (wm * 128 + lrow) * kPitch + 16 * lhalf;        \
+    const unsigned char *Bs = s_raw + (buf_) * kBuf + (kBM + wn * 64 + lrow) * kPitch + 16 * lhalf;   \
+    MF_NT_BIG_UNROLL for (int s = 0; s < 4; ++s) {                                                   \
+      const uint4 b0 = *reinterpret_cast<const uint4 *>(Bs + 32 * s);                                 \
+      uint4 b1 = b0;                                                                                  \
+      if constexpr (NJ_ == 2) b1 = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * s);       \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                              \
+        const uint4 am = *reinterpret_cast<const uint4 *>(As + mi * 32 * kPitch + 32 * s);            \
+        acc[mi][0] = mf::mfma_bf16_32x32x16(am, b0, acc[mi][0]);                                      \
+        if constexpr (NJ_ == 2) acc[mi][1] = mf::mfma_bf16_32x32x16(am, b1, acc[mi][1]);              \
+      }                                                                                               \
+    }                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  }
+  // Column blocks of this wave that lie past N (the last N-tile of a layer whose width is not a multiple of 128:
+  // conv3's data gradient has N = 160 -- its second tile holds 32 columns) are not multiplied: wave-uniform.
+  const int ncols = a.N - (n0 + wn * 64);  // columns of this wave's 64 that exist
+  // Per K-tile t: the loads of tile t + 1 are issued, tile t is multiplied, the registers go into the other buffer,
+  // barrier.  (Stash AFTER the barrier and the next fetch right behind it -- the order the 256^2-tile GEMMs of the
+  // programming guide prefer -- measured 3 - 5 % slower here, at 2 workgroups per CU.)  The fetches run over the
+  // K-tiles in order, one past the last (k beyond K: every chunk masked, zeros into the buffer nobody reads again) --
+  // NOT under "if (t + 1 < T)": behind a branch the compiler copies the loaded registers at the join and waits for
+  // the loads right where they are issued (measured: 2x slower).
+  MF_NT_FETCH(P);  // tile 0
+  MF_NT_STASH(P, 0);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    MF_NT_FETCH(P);  // tile t + 1 in flight under the MFMAs of tile t
+    if (ncols > 32) MF_NT_COMPUTE(t & 1, 2) else if (ncols > 0) MF_NT_COMPUTE(t & 1, 1)
+    MF_NT_STASH(P, (t + 1) & 1);
+    __syncthreads();
+  }
+#undef MF_NT_COMPUTE
+#undef MF_NT_STASH
+#undef MF_NT_FETCH
+#undef MF_NT_LOAD_B
+#undef MF_NT_LOAD_A
+
+  // epilogue through LDS in four passes of 64 rows (the loop ended on a barrier: the operand buffers are free)
+  constexpr int kEp = kBNb + 4;
+  float *s_out = reinterpret_cast<float *>(s_raw);  // [64][kEp]
+  const float *bias = a.bias ? a.bias + grp * a.b_gs : nullptr;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    if (wm == (pass >> 1)) {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int nl = wn * 64 + ni * 32 + lrow;
+          const float bn = (bias && n0 + nl < a.N) ? bias[n0 + nl] : 0.0f;
+          const mf_f32x16 &c = (pass & 1) ? acc[2 + mh][ni] : acc[mh][ni];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int ml = mh * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+            float v = c[e] + bn;
+            if (a.relu) v = v > 0.0f ? v : 0.0f;
+            s_out[ml * kEp + nl] = v;
+          }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * (kBNb / 8); i += 512) {
+      const int ml = i / (kBNb / 8), c8 = i - ml * (kBNb / 8);
+      const int m = m0 + 64 * pass + ml, n = n0 + 8 * c8;
+      if (m >= a.M || n >= a.N) continue;
+      int64_t orow = m;
+      if (MODE == kConvDgrad) {  // class-ordered row -> channels-last voxel row of the input gradient
+        const int h = m & ((1 << (3 * dol)) - 1), p = (m >> (3 * dol)) & 7, b = m >> (3 * dol + 3);
+        const int x = 2 * (h >> (2 * dol)) + (p & 1), y = 2 * ((h >> dol) & (Do - 1)) + ((p >> 1) & 1),
+                  z = 2 * (h & (Do - 1)) + (p >> 2);
+        orow = (((int64_t)b * a.D + x) * a.D + y) * a.D + z;
+      }
+      const float4 v0 = *reinterpret_cast<const float4 *>(s_out + ml * kEp + 8 * c8);
+      const float4 v1 = *reinterpret_cast<const float4 *>(s_out + ml * kEp + 8 * c8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      const int nv = a.N - n < 8 ? a.N - n : 8;
+      if (a.out_f32) {
+        float *o = reinterpret_cast<float *>(a.out) + grp * a.o_gs + orow * a.ldo + n;
+        if (nv == 8 && (a.ldo & 3) == 0 && ((uintptr_t)o & 15) == 0) {
+          float4 *o4 = reinterpret_cast<float4 *>(o);
+          if (a.accumulate) {
+            const float4 p0 = o4[0], p1 = o4[1];
+            v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
+            v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+          }
+          o4[0] = make_float4(v[0], v[1], v[2], v[3]);
+          o4[1] = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          for (int j = 0; j < nv; ++j) o[j] = a.accumulate ? o[j] + v[j] : v[j];
+        }
+      } else {
+        uint16_t *o = reinterpret_cast<uint16_t *>(a.out) + grp * a.o_gs + orow * a.ldo + n;
+        if (nv == 8 && (a.ldo & 7) == 0 && ((uintptr_t)o & 15) == 0) {
+          *reinterpret_cast<uint4 *>(o) = make_uint4(mf::pack_bf16x2(v[0], v[1]), mf::pack_bf16x2(v[2], v[3]),
+                                                     mf::pack_bf16x2(v[4], v[5]), mf::pack_bf16x2(v[6], v[7]));
+        } else {
+          for (int j = 0; j < nv; ++j) o[j] = (uint16_t)mf::bf16_bits(v[j]);
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -731,9 +1013,32 @@ int ilog2_exact(int x) {
   return (1 << l) == x ? l : -1;
 }
 
+// MF_NT_BIG in the environment: 0 = never the 256 x 256 tile, 1 = by problem size (the default), 2 = wherever its
+// structure allows (tests of small problems)
+int nt_big_override() {
+  const char *e = getenv("MF_NT_BIG");
+  return e ? atoi(e) : -1;
+}
+
+int g_nt_last_tile = 0;  // rows of the tile the last NT launch used (64 / 128 / 256): mf_gemm_bf16_last_tile
+
 template <int MODE>
 int launch_nt(const NtArgs &a, hipStream_t stream) {
   const int64_t full = (int64_t)((a.M + 127) / 128) * ((a.N + kBN - 1) / kBN) * a.groups;
+  const int64_t big = (int64_t)((a.M + kBigM - 1) / kBigM) * ((a.N + kBigN - 1) / kBigN) * a.groups;
+  bool use_big = big >= 224 && a.N >= 192 && !(MODE == kRows && a.tile_group) &&
+                 !(MODE == kConvDgrad && ((a.Do * a.Do * a.Do) & (kBigM - 1)));
+  if (nt_big_override() == 2)  // (tests: the big tile wherever its structure allows, whatever the tile count)
+    use_big = !(MODE == kRows && a.tile_group) && !(MODE == kConvDgrad && ((a.Do * a.Do * a.Do) & (kBigM - 1)));
+  else if (nt_big_override() >= 0)
+    use_big = use_big && nt_big_override() == 1;
+  if (use_big) {
+    if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16_big<MODE>, nt_big_lds())) return e;
+    hipLaunchKernelGGL((k_gemm_nt_bf16_big<MODE>), dim3((unsigned)big), dim3(512), nt_big_lds(), stream, a);
+    g_nt_last_tile = kBigM;
+    return 0;
+  }
+  g_nt_last_tile = full < 256 && MODE != kConvDgrad ? 64 : 128;
   const bool half = full < 256 && MODE != kConvDgrad;  // (dgrad tiles must stay class-homogeneous: 128 | Do^3)
   if (half) {
     if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16<MODE, 1>, nt_lds<1>())) return e;
@@ -1038,3 +1343,7 @@ extern "C" int mf_conv3d_k4s2_bf16_wgrad(const void *dy, const void *x, float *d
                                          mfStream_t stream) {
   return mf_conv3d_bf16_wgrad(dy, x, dW, ws, B, Cin, Cout, D, 4, 2, 1, 1, w_cin, c_off, split, stream);
 }
+
+/* Tile height (64 / 128 / 256 rows) of the NT engine's most recent launch in this process: lets tests and the
+ * timing tools see which form of the engine a problem was given to (launch_nt's choice, MF_NT_BIG). */
+extern "C" int mf_gemm_bf16_last_tile(void) { return g_nt_last_tile; }

@@ -26,6 +26,16 @@ def L():
     return lib
 
 
+@pytest.fixture(params=["tile128", "tile256"], autouse=True)
+def tile_choice(request, monkeypatch):
+    """Every test runs on the 128 x 128 tile of the NT engine and again with MF_NT_BIG=2: the 256 x 256 form
+    (k_gemm_nt_bf16_big: eight waves of 128 x 64) wherever its structure allows, whatever the tile count."""
+    if request.param == "tile256":
+        monkeypatch.setenv("MF_NT_BIG", "2")
+    else:
+        monkeypatch.setenv("MF_NT_BIG", "0")
+
+
 def bf(x):
     """float32 tensor rounded to bf16 (kept as bf16)."""
     return x.to(torch.bfloat16)
@@ -81,6 +91,8 @@ def test_linear_bf16_forward_dgrad_wgrad(L, M, N, K, groups, relu):
             want = F.relu(want) if relu else want
             (close if out_f32 else close_bf16)(out[:, g * N:(g + 1) * N], want)
         assert float(out[:, groups * N:].float().min()) == -9.0   # nothing written past the last block
+    import os
+    assert L.mf_gemm_bf16_last_tile() == (256 if os.environ["MF_NT_BIG"] == "2" else 64)  # (which form of the engine ran)
     # accumulate into fp32
     acc = torch.ones(M, ldo)
     assert L.mf_linear_bf16(p(A), K, lda, p(W), N * K, K, None, 0, p(acc), N, ldo, M, N, K, groups, 0, 1, 1, None) == 0
