@@ -503,20 +503,50 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_big(NtArgs a) {
     *reinterpret_cast<uint4 *>(Bs_ + 128 * kPitch) = rb2##S; *reinterpret_cast<uint4 *>(Bs_ + 192 * kPitch) = rb3##S; \
   }
   // NJ_ = 2: both 32-column blocks of the wave's 64 columns; NJ_ = 1: the first only (the second lies past N)
+  // One K-tile = four k-steps of 16.  The fragments of step s + 1 are read while the MFMAs of step s run: two register
+  // sets, and sched_group_barrier pins the order "6 LDS reads, 8 MFMAs" per step (left to itself the scheduler put
+  // each A fragment's read right in front of the two MFMAs that use it: every pair waited out an LDS round trip).
+  // MF_NT_BIG_PIPE=0 keeps that first form (A/B measurements).
+#ifndef MF_NT_BIG_PIPE
+#define MF_NT_BIG_PIPE 1
+#endif
+#define MF_NT_FRAGS(set_, s_, NJ_)                                                                    \
+  {                                                                                                   \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
+      fa[set_][mi] = *reinterpret_cast<const uint4 *>(As + mi * 32 * kPitch + 32 * (s_));             \
+    fb[set_][0] = *reinterpret_cast<const uint4 *>(Bs + 32 * (s_));                                   \
+    if constexpr (NJ_ == 2) fb[set_][1] = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * (s_)); \
+  }
 #define MF_NT_COMPUTE(buf_, NJ_)                                                                      \
   {                                                                                                   \
     asm volatile("" ::: "memory");                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     const unsigned char *As = s_raw + (buf_) * kBuf + (wm * 128 + lrow) * kPitch + 16 * lhalf;        \
     const unsigned char *Bs = s_raw + (buf_) * kBuf + (kBM + wn * 64 + lrow) * kPitch + 16 * lhalf;   \
-    MF_NT_BIG_UNROLL for (int s = 0; s < 4; ++s) {                                                   \
-      const uint4 b0 = *reinterpret_cast<const uint4 *>(Bs + 32 * s);                                 \
-      uint4 b1 = b0;                                                                                  \
-      if constexpr (NJ_ == 2) b1 = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * s);       \
-      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                              \
-        const uint4 am = *reinterpret_cast<const uint4 *>(As + mi * 32 * kPitch + 32 * s);            \
-        acc[mi][0] = mf::mfma_bf16_32x32x16(am, b0, acc[mi][0]);                                      \
-        if constexpr (NJ_ == 2) acc[mi][1] = mf::mfma_bf16_32x32x16(am, b1, acc[mi][1]);              \
+    if constexpr (MF_NT_BIG_PIPE) {                                                                   \
+      uint4 fa[2][4], fb[2][2];                                                                       \
+      MF_NT_FRAGS(0, 0, NJ_)                                                                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 + NJ_, 0);                                        \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                 \
+        const int c = s & 1;                                                                          \
+        if (s < 3) MF_NT_FRAGS(c ^ 1, s + 1, NJ_)                                                     \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                            \
+          acc[mi][0] = mf::mfma_bf16_32x32x16(fa[c][mi], fb[c][0], acc[mi][0]);                       \
+          if constexpr (NJ_ == 2) acc[mi][1] = mf::mfma_bf16_32x32x16(fa[c][mi], fb[c][1], acc[mi][1]); \
+        }                                                                                             \
+        if (s < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4 + NJ_, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ_, 0);                                      \
+      }                                                                                               \
+    } else {                                                                                          \
+      MF_NT_BIG_UNROLL for (int s = 0; s < 4; ++s) {                                                  \
+        const uint4 b0 = *reinterpret_cast<const uint4 *>(Bs + 32 * s);                               \
+        uint4 b1 = b0;                                                                                \
+        if constexpr (NJ_ == 2) b1 = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * s);     \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                            \
+          const uint4 am = *reinterpret_cast<const uint4 *>(As + mi * 32 * kPitch + 32 * s);          \
+          acc[mi][0] = mf::mfma_bf16_32x32x16(am, b0, acc[mi][0]);                                    \
+          if constexpr (NJ_ == 2) acc[mi][1] = mf::mfma_bf16_32x32x16(am, b1, acc[mi][1]);            \
+        }                                                                                             \
       }                                                                                               \
     }                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -539,6 +569,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_big(NtArgs a) {
     MF_NT_STASH(P, (t + 1) & 1);
     __syncthreads();
   }
+#undef MF_NT_FRAGS
 #undef MF_NT_COMPUTE
 #undef MF_NT_STASH
 #undef MF_NT_FETCH

@@ -403,6 +403,7 @@ inline mf_emul_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, mf_
   return c;
 }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 #define MF_HOLD(r_) ((void)0)
 namespace mf {
 typedef mf_emul_f32x16 mf_f32x16;
