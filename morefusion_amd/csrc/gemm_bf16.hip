@@ -222,28 +222,56 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
     *reinterpret_cast<uint4 *>(Bs_) = rb0##S; *reinterpret_cast<uint4 *>(Bs_ + 32 * kPitch) = rb1##S; \
     *reinterpret_cast<uint4 *>(Bs_ + 64 * kPitch) = rb2##S; *reinterpret_cast<uint4 *>(Bs_ + 96 * kPitch) = rb3##S; \
   }
-  // NJ_ = 2: both 32-column blocks of the wave's 64 columns; NJ_ = 1: the first only (the second lies past N)
+  // NJ_ = 2: both 32-column blocks of the wave's 64 columns; NJ_ = 1: the first only (the second lies past N).
+  // The fragments of k-step s + 1 are read while the MFMAs of step s run (round 5, as in k_gemm_nt_bf16_big below: two
+  // register sets, the order pinned with sched_group_barrier; MF_NT_PIPE=0: the scheduler's own order).
+#ifndef MF_NT_PIPE
+#define MF_NT_PIPE 1
+#endif
+#define MF_NT_FRAGS(set_, s_, NJ_)                                                                    \
+  {                                                                                                   \
+    fa[set_][0] = *reinterpret_cast<const uint4 *>(As + 32 * (s_));                                   \
+    if constexpr (MI == 2) fa[set_][1] = *reinterpret_cast<const uint4 *>(As + 32 * kPitch + 32 * (s_)); \
+    fb[set_][0] = *reinterpret_cast<const uint4 *>(Bs + 32 * (s_));                                   \
+    if constexpr (NJ_ == 2) fb[set_][1] = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * (s_)); \
+  }
 #define MF_NT_COMPUTE(buf_, NJ_)                                                                      \
   {                                                                                                   \
     asm volatile("" ::: "memory");                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     const unsigned char *As = s_raw + (buf_) * kBuf + (wm * 32 * MI + lrow) * kPitch + 16 * lhalf;    \
     const unsigned char *Bs = s_raw + (buf_) * kBuf + (kBM + wn * 64 + lrow) * kPitch + 16 * lhalf;   \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
-      const uint4 a0 = *reinterpret_cast<const uint4 *>(As + 32 * s);                                 \
-      const uint4 b0 = *reinterpret_cast<const uint4 *>(Bs + 32 * s);                                 \
-      acc[0][0] = mf::mfma_bf16_32x32x16(a0, b0, acc[0][0]);                                          \
-      if constexpr (NJ_ == 2) {                                                                       \
-        const uint4 b1 = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * s);                 \
-        acc[0][1] = mf::mfma_bf16_32x32x16(a0, b1, acc[0][1]);                                        \
-        if constexpr (MI == 2) {                                                                      \
+    if constexpr (MF_NT_PIPE) {                                                                       \
+      uint4 fa[2][2], fb[2][2];                                                                       \
+      MF_NT_FRAGS(0, 0, NJ_)                                                                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ_, 0);                                       \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                 \
+        const int c = s & 1;                                                                          \
+        if (s < 3) MF_NT_FRAGS(c ^ 1, s + 1, NJ_)                                                     \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                           \
+          acc[mi][0] = mf::mfma_bf16_32x32x16(fa[c][mi], fb[c][0], acc[mi][0]);                       \
+          if constexpr (NJ_ == 2) acc[mi][1] = mf::mfma_bf16_32x32x16(fa[c][mi], fb[c][1], acc[mi][1]); \
+        }                                                                                             \
+        if (s < 3) __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ_, 0);                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ_, 0);                                     \
+      }                                                                                               \
+    } else {                                                                                          \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                 \
+        const uint4 a0 = *reinterpret_cast<const uint4 *>(As + 32 * s);                               \
+        const uint4 b0 = *reinterpret_cast<const uint4 *>(Bs + 32 * s);                               \
+        acc[0][0] = mf::mfma_bf16_32x32x16(a0, b0, acc[0][0]);                                        \
+        if constexpr (NJ_ == 2) {                                                                     \
+          const uint4 b1 = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * s);               \
+          acc[0][1] = mf::mfma_bf16_32x32x16(a0, b1, acc[0][1]);                                      \
+          if constexpr (MI == 2) {                                                                    \
+            const uint4 a1 = *reinterpret_cast<const uint4 *>(As + 32 * kPitch + 32 * s);             \
+            acc[MI - 1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[MI - 1][0]);                          \
+            acc[MI - 1][1] = mf::mfma_bf16_32x32x16(a1, b1, acc[MI - 1][1]);                          \
+          }                                                                                           \
+        } else if constexpr (MI == 2) {                                                               \
           const uint4 a1 = *reinterpret_cast<const uint4 *>(As + 32 * kPitch + 32 * s);               \
           acc[MI - 1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[MI - 1][0]);                            \
-          acc[MI - 1][1] = mf::mfma_bf16_32x32x16(a1, b1, acc[MI - 1][1]);                            \
         }                                                                                             \
-      } else if constexpr (MI == 2) {                                                                 \
-        const uint4 a1 = *reinterpret_cast<const uint4 *>(As + 32 * kPitch + 32 * s);                 \
-        acc[MI - 1][0] = mf::mfma_bf16_32x32x16(a1, b0, acc[MI - 1][0]);                              \
       }                                                                                               \
     }                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -266,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
     MF_NT_STASH(P, (t + 1) & 1);
     __syncthreads();
   }
+#undef MF_NT_FRAGS
 #undef MF_NT_COMPUTE
 #undef MF_NT_STASH
 #undef MF_NT_FETCH
