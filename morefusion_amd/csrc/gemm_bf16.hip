@@ -1098,8 +1098,11 @@ int launch_nt(const NtArgs &a, hipStream_t stream) {
     g_nt_last_tile = kBigM;
     return 0;
   }
-  g_nt_last_tile = full < 256 && MODE != kConvDgrad ? 64 : 128;
-  const bool half = full < 256 && MODE != kConvDgrad;  // (dgrad tiles must stay class-homogeneous: 128 | Do^3)
+  // 64-row tiles when the 128-row ones would leave CUs with fewer than two workgroups (MF_NT_HALF_MAX: the largest
+  // count of 128-row tiles that still takes the half-height tile; tuning knob)
+  static const int half_max = getenv("MF_NT_HALF_MAX") ? atoi(getenv("MF_NT_HALF_MAX")) : 255;
+  const bool half = full <= half_max && MODE != kConvDgrad;  // (dgrad tiles must stay class-homogeneous: 128 | Do^3)
+  g_nt_last_tile = half ? 64 : 128;
   if (half) {
     if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16<MODE, 1>, nt_lds<1>())) return e;
     const int64_t grid = (int64_t)((a.M + 63) / 64) * ((a.N + kBN - 1) / kBN) * a.groups;
