@@ -59,6 +59,7 @@ struct NtArgs {
   // conv geometry: D = INPUT grid size, Do = OUTPUT grid size = 1 << olog; forward taps ks^3 at x = stride * o - pad
   // + dil * k per axis (dgrad: the k4 / s2 / p1 parity-class form only)
   int B, D, Do, olog, Cin, Cout, ks, stride, pad, dil;
+  int dbg;  // k_gemm_nt_bf16_pp ablations (MF_PP_DBG; timing experiments only, results are wrong): see launch_nt
 };
 
 
@@ -672,6 +673,325 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_big(NtArgs a) {
   }
 }
 
+// ---- the 256 x 256 x 64 tile with LDS-DMA operands and two wave groups in ping-pong (round 6) ------------------------
+// k_gemm_nt_bf16_big above moves every operand chunk global -> VGPR -> ds_write_b128 -> barrier, once per K-tile: all
+// eight waves meet at that barrier, wait out their loads, store, and start reading fragments at the same moment --
+// the MFMA pipe idles through every one of these episodes (0.42-0.43 busy).  Here
+//   * operands go global -> LDS directly (buffer_load_dwordx4 ... lds, mf::glds16: 1 KiB = 8 tile rows per wave
+//     instruction; masked chunks are out-of-range offsets and land as zeros): no staging registers, no store pass;
+//   * the LDS image of an operand is [256 rows][128 bytes] with the 16-byte chunk index XORed with (row >> 1) & 7.  The
+//     DMA writes a wave's 1 KiB lane-linear, so the swizzle is applied to the SOURCE: the lane whose slot is chunk
+//     position q of row r fetches global chunk q ^ ((r >> 1) & 7); a fragment read (row = lane % 32, chunk
+//     2 s + lane / 32) XORs the same value: every 16-lane group of a ds_read_b128 covers all 64 banks once;
+//   * a K-tile is two phases of two k-steps: 12 fragment reads and 4 DMA requests in the phase's load section, 16
+//     MFMAs in its MFMA section, a barrier behind each.  The waves with the upper and the lower 128 rows of the tile
+//     (waves 0-3 / 4-7: one of each per SIMD) run ONE BARRIER APART: while one group multiplies (s_setprio 1) the
+//     other reads the fragments of its next phase and issues DMA -- the SIMD's MFMA pipe always has a wave with
+//     operands in registers, and the LDS round trip and the DMA issue time (60-180 cycles of the issuing wave per
+//     request) are paid beside the other group's MFMAs;
+//   * the 160 KiB of LDS are THREE A stages + TWO W stages (the weight panel is shared by every workgroup and comes
+//     from L2; the activation rows come from HBM): in tile t, phase 0 requests W(t + 1) into the stage W(t - 1) was
+//     read from, phase 1 requests A(t + 2) into the stage of A(t - 1) and then waits with a COUNTED vmcnt(4) --
+//     everything but A(t + 2), which stays in flight across the barriers.
+// Ordering, in barrier intervals (group 0's load section of phase (t, p) is interval 4 t + 2 p, its MFMA section
+// 4 t + 2 p + 1; group 1 one interval later):
+//   WAR  the last reads of tile t - 1 are group 1's phase (t - 1, 1) in interval 4 t - 1, retired by lgkmcnt(0) BEFORE
+//        the barrier that ends it; the earliest request into a stage of tile t - 1 is group 0's in interval 4 t.
+//   RAW  every wave waits for its own requests of A(t + 1) and W(t + 1) in the load section of its phase (t, 1)
+//        (intervals 4 t + 2 / 4 t + 3) in front of a barrier; the first read of tile t + 1 is group 0's in 4 t + 4.
+// The fragment reads are inline asm (mf::lds_read16_async): the compiler puts s_waitcnt vmcnt(0) in front of any LDS
+// read it can see while a DMA is pending.  Same loaders, masks, tile order and epilogue as the kernel above.
+constexpr int kPpOp = 256 * 128;             // bytes of one operand stage: [256 rows][128]
+constexpr int kPpW0 = 3 * kPpOp;             // A stages at 0, 1, 2 x kPpOp; W stages behind them
+constexpr int nt_pp_lds() { return 5 * kPpOp; }  // 160 KiB: all of a CU's LDS (the epilogue's 64 x 260 floats fit inside)
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
+  MF_DYN_LDS(unsigned char, s_raw);
+  constexpr int kBM = kBigM, kBNb = kBigN;
+  const int tiles_m = (a.M + kBM - 1) / kBM, tiles_n = (a.N + kBNb - 1) / kBNb;
+  const int per_group = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  int L = blockIdx.x;
+  if ((G & 7) == 0) L = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous logical order
+  const int grp = L / per_group;
+  const int rem = L - grp * per_group;
+  const int m0 = (rem / tiles_n) * kBM, n0 = (rem % tiles_n) * kBNb;  // N tile fastest (csrc/linear.hip)
+  const int T = (a.K + kBK - 1) / kBK;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = mf::wave_uniform(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // wm = the ping-pong group: waves w and w + 4 share a SIMD
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  // DMA slot of this lane: tile rows r0 + 64 i, chunk position tid & 7 of the row -> global chunk ``chunk``
+  const int r0 = tid >> 3;
+  const int chunk = (tid & 7) ^ ((r0 >> 1) & 7);
+
+  const int Do = a.Do, dol = a.olog;
+  const uint16_t *A = a.A + grp * a.a_gs;
+  const uint16_t *W = a.W + grp * a.w_gs;
+  int cls = 0;
+  if (MODE == kConvDgrad) {  // tile-uniform parity class: its weight slice
+    cls = (m0 >> (3 * dol)) & 7;
+    W += (int64_t)cls * a.N * a.ldw;
+  }
+  // per staged row: element offset of its k = 0 chunk and validity bits (as in k_gemm_nt_bf16)
+  int base[4], mask[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r0 + 64 * i;
+    const bool row_ok = m < a.M;
+    const int mm = row_ok ? m : 0;
+    int mk = row_ok ? 1 << 12 : 0;
+    if (MODE == kRows) {
+      base[i] = mm * a.lda;
+    } else if (MODE == kConvFwd) {
+      const int b = mm >> (3 * dol), o = mm & ((1 << (3 * dol)) - 1);
+      const int ox = o >> (2 * dol), oy = (o >> dol) & (Do - 1), oz = o & (Do - 1);
+      const int x0 = a.stride * ox - a.pad, y0 = a.stride * oy - a.pad, z0 = a.stride * oz - a.pad;
+      base[i] = (((b * a.D + x0) * a.D + y0) * a.D + z0) * a.Cin;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // (k >= ks: never asked for)
+        mk |= ((unsigned)(x0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << k;
+        mk |= ((unsigned)(y0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (4 + k);
+        mk |= ((unsigned)(z0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (8 + k);
+      }
+    } else {
+      const int h = mm & ((1 << (3 * dol)) - 1), b = mm >> (3 * dol + 3);
+      const int hx = h >> (2 * dol), hy = (h >> dol) & (Do - 1), hz = h & (Do - 1);
+      const int ux = hx + (cls & 1), uy = hy + ((cls >> 1) & 1), uz = hz + ((cls >> 2) & 1);  // slot (0,0,0)
+      base[i] = (((b * Do + ux) * Do + uy) * Do + uz) * a.Cout;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        mk |= ((unsigned)(ux - s) < (unsigned)Do ? 1 : 0) << s;
+        mk |= ((unsigned)(uy - s) < (unsigned)Do ? 1 : 0) << (4 + s);
+        mk |= ((unsigned)(uz - s) < (unsigned)Do ? 1 : 0) << (8 + s);
+      }
+    }
+    mask[i] = mk;
+  }
+  uint32_t wrow[4];  // byte offsets into W (weights: far below 2^32 bytes)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + r0 + 64 * i;
+    wrow[i] = 2u * (uint32_t)((int64_t)(n < a.N ? n : 0) * a.ldw);
+  }
+
+  mf_f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // this lane's position in K, advanced by one K-tile per request (see k_gemm_nt_bf16); the A requests run one tile
+  // ahead of the W requests
+  int kg = 8 * chunk, tc = 0, tx = 0, ty = 0, tz = 0, kgw = 8 * chunk;
+  if (MODE == kConvFwd) {
+    const int tap = kg / a.Cin;
+    tc = kg - tap * a.Cin;
+    const int kxy = tap / a.ks;
+    tz = tap - kxy * a.ks; tx = kxy / a.ks; ty = kxy - tx * a.ks;
+  } else if (MODE == kConvDgrad) {
+    tx = kg / a.Cout;
+    tc = kg - tx * a.Cout;
+  }
+  const mf::BufRsrc Ars = mf::make_rsrc(A), Wrs = mf::make_rsrc(W);
+  // the 1 KiB of LDS a DMA instruction of this wave fills: rows 64 i + 8 wave .. + 7 of an operand stage
+  unsigned char *const dma0 = s_raw + 8 * wave * 128;
+  // rows 128 h_ .. + 127 (h_ = 0, 1) of A's next K-tile -> A stage sa_; the position advances behind the second half
+#define MF_PP_REQ_A(sa_, h_)                                                                          \
+  {                                                                                                   \
+    const bool kin_ = kg + 8 <= a.K;                                                                  \
+    int off_ = kg, bits_ = 1 << 12;                                                                   \
+    if (MODE == kConvFwd) {                                                                           \
+      off_ = ((tx * a.D + ty) * a.D + tz) * a.dil * a.Cin + tc;                                       \
+      bits_ = tx < a.ks ? (1 << tx) | (16 << ty) | (256 << tz) | (1 << 12) : 1 << 13;                 \
+    } else if (MODE == kConvDgrad) {                                                                  \
+      const int sx = tx & 1, sy = (tx >> 1) & 1, sz = tx >> 2;                                        \
+      off_ = tc - ((sx * Do + sy) * Do + sz) * a.Cout;                                                \
+      bits_ = (1 << sx) | (16 << sy) | (256 << sz) | (1 << 12);                                       \
+    }                                                                                                 \
+    if (!kin_) bits_ = 1 << 13; /* (no row has bit 13) */                                             \
+    _Pragma("unroll") for (int i = 2 * (h_); i < 2 * (h_) + 2; ++i)                                   \
+      mf::glds16(Ars, (mask[i] & bits_) == bits_ ? 2u * (uint32_t)(base[i] + off_) : mf::kBufMasked,  \
+                 dma0 + (sa_) * kPpOp + i * 64 * 128);                                                \
+    if ((h_) == 1) {                                                                                  \
+      kg += kBK;                                                                                      \
+      if (MODE == kConvFwd) {                                                                         \
+        tc += kBK;                                                                                    \
+        while (tc >= a.Cin) {                                                                         \
+          tc -= a.Cin;                                                                                \
+          if (++tz == a.ks) { tz = 0; if (++ty == a.ks) { ty = 0; ++tx; } }                           \
+        }                                                                                             \
+      } else if (MODE == kConvDgrad) {                                                                \
+        tc += kBK;                                                                                    \
+        while (tc >= a.Cout) { tc -= a.Cout; ++tx; }                                                  \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+  // (the weight operand needs no mask: behind the K tail it re-reads k = 0 -- finite, and the A chunk there is zero --
+  // and a column past N re-reads row 0 into an accumulator column the epilogue never stores)
+#define MF_PP_REQ_W(sw_, h_)                                                                          \
+  {                                                                                                   \
+    const uint32_t kofs_ = kgw + 8 <= a.K ? 2u * (uint32_t)kgw : 0u;                                  \
+    _Pragma("unroll") for (int i = 2 * (h_); i < 2 * (h_) + 2; ++i)                                   \
+      mf::glds16(Wrs, wrow[i] + kofs_, dma0 + kPpW0 + (sw_) * kPpOp + i * 64 * 128);                  \
+    if ((h_) == 1) kgw += kBK;                                                                        \
+  }
+  // fragment addresses inside a stage: row R = 128 wm + 32 mi + lrow of A (64 wn + 32 ni + lrow of W), chunk
+  // (2 s + lhalf) ^ ((lrow >> 1) & 7) = ((s ^ (lrow >> 2 & 3)) << 1) | ((lhalf ^ (lrow >> 1)) & 1)
+  const int gh = (lrow >> 2) & 3, c0 = ((lhalf ^ (lrow >> 1)) & 1) << 4;
+  const mf::lds_addr_t fragA = mf::lds_addr(s_raw) + (128 * wm + lrow) * 128 + c0;
+  const mf::lds_addr_t fragW = mf::lds_addr(s_raw) + kPpW0 + (64 * wn + lrow) * 128 + c0;
+  const int ncols = a.N - (n0 + wn * 64);  // columns of this wave's 64 that exist (wave-uniform)
+  // A phase = two k-steps of 16: twelve fragment reads and four DMA requests in its load section, sixteen MFMAs
+  // (every accumulator twice, eight MFMAs apart) in its MFMA section.  (One k-step per phase -- eight barriers per
+  // K-tile -- left the MFMA pipe at 0.55 of its peak even with NO DMA at all, whether the load section waited for its
+  // own six reads or they were issued between the previous phase's MFMAs: the barrier hand-over itself, ~100 cycles
+  // per 256 cycles of MFMAs.  MF_PP_DBG ablations, tools/ab_gemm.sh.)
+  uint4 fa[2][4], fb[2][2];
+#define MF_PP_READS(NJ_, kk_, sa_, sw_, s_)                                                           \
+  if ((NJ_) > 0) {                                                                                    \
+    const mf::lds_addr_t va_ = fragA + (sa_) * kPpOp + (((s_) ^ gh) << 5);                            \
+    const mf::lds_addr_t vb_ = fragW + (sw_) * kPpOp + (((s_) ^ gh) << 5);                            \
+    fa[kk_][0] = mf::lds_read16_async<0>(va_);                                                        \
+    fb[kk_][0] = mf::lds_read16_async<0>(vb_);                                                        \
+    fa[kk_][1] = mf::lds_read16_async<4096>(va_);                                                     \
+    if ((NJ_) > 1) fb[kk_][1] = mf::lds_read16_async<4096>(vb_);                                      \
+    fa[kk_][2] = mf::lds_read16_async<8192>(va_);                                                     \
+    fa[kk_][3] = mf::lds_read16_async<12288>(va_);                                                    \
+  }
+  // NJ_ = the wave's 32-column blocks that exist (2, 1 or 0: wave-uniform, one loop per value).  A fragment that no
+  // MFMA uses is NOT read: the compiler takes the asm's result register as written when the statement ends and hands
+  // a dead one out again at once -- the data then lands on top of whatever lives there (seen: the offset of the next
+  // DMA request, a memory fault).  MF_HOLD behind the wait keeps every fragment register reserved up to there.
+#define MF_PP_PHASE(NJ_, p_, REQ_)                                                                    \
+  {                                                                                                   \
+    MF_PP_READS(NJ_, 0, sa, sw, 2 * (p_))                                                             \
+    MF_PP_READS(NJ_, 1, sa, sw, 2 * (p_) + 1)                                                         \
+    REQ_                                                                                              \
+    mf::wait_lds_reads();                                                                             \
+    if ((NJ_) > 0) {                                                                                  \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                              \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) MF_HOLD(fa[kk][mi]);                         \
+        MF_HOLD(fb[kk][0]);                                                                           \
+        if ((NJ_) > 1) MF_HOLD(fb[kk][1]);                                                            \
+      }                                                                                               \
+    }                                                                                                 \
+    mf::raw_barrier();                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                  \
+      const int kk = q >> 3, mi = q & 3, nj = (q >> 2) & 1;                                           \
+      if (nj < (NJ_)) acc[mi][nj] = mf::mfma_bf16_32x32x16(fa[kk][mi], fb[kk][nj], acc[mi][nj]);      \
+    }                                                                                                 \
+    __builtin_amdgcn_s_setprio(0);                                                                    \
+    mf::raw_barrier();                                                                                \
+  }
+#define MF_PP_LOOP(NJ_)                                                                               \
+  for (int t = 0; t < T; ++t) {                                                                       \
+    const int sw = t & 1;                                                                             \
+    const bool more1 = t + 1 < T && !(a.dbg & 1), more2 = t + 2 < T && !(a.dbg & 1);                  \
+    if (a.dbg & 2) { kg = kgw = 8 * chunk; tc = kg; tx = ty = tz = 0; }                               \
+    MF_PP_PHASE(NJ_, 0, if (more1) { MF_PP_REQ_W(sw ^ 1, 0) MF_PP_REQ_W(sw ^ 1, 1) })                 \
+    MF_PP_PHASE(NJ_, 1, if (more2) { MF_PP_REQ_A(sa2, 0) MF_PP_REQ_A(sa2, 1) mf::wait_dma<4>(); }     \
+                        else { mf::wait_dma<0>(); })                                                  \
+    sa = sa == 2 ? 0 : sa + 1;                                                                        \
+    sa2 = sa2 == 2 ? 0 : sa2 + 1;                                                                     \
+  }
+  // tiles 0 (A, W) and 1 (A) before the loop; the requests of A(1) stay in flight
+  MF_PP_REQ_A(0, 0) MF_PP_REQ_A(0, 1) MF_PP_REQ_W(0, 0) MF_PP_REQ_W(0, 1)
+  if (T > 1 && !(a.dbg & 1)) {
+    MF_PP_REQ_A(1, 0) MF_PP_REQ_A(1, 1)
+    mf::wait_dma<4>();
+  } else {
+    mf::wait_dma<0>();
+  }
+  mf::raw_barrier();
+  int sa = 0, sa2 = 2;  // A stages of tiles t and t + 2
+  if (wm == 1 && !(a.dbg & 4)) mf::raw_barrier();  // the lower half runs one barrier behind from here on
+  if (ncols > 32) {
+    MF_PP_LOOP(2)
+  } else if (ncols > 0) {
+    MF_PP_LOOP(1)
+  } else {
+    MF_PP_LOOP(0)
+  }
+  if (wm == 0 && !(a.dbg & 4)) mf::raw_barrier();  // the groups meet again: every fragment read is retired, no DMA is pending
+#undef MF_PP_LOOP
+#undef MF_PP_READS
+#undef MF_PP_PHASE
+#undef MF_PP_REQ_W
+#undef MF_PP_REQ_A
+
+  // epilogue through LDS in four passes of 64 rows (as in k_gemm_nt_bf16_big)
+  constexpr int kEp = kBNb + 4;
+  float *s_out = reinterpret_cast<float *>(s_raw);  // [64][kEp]
+  const float *bias = a.bias ? a.bias + grp * a.b_gs : nullptr;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    if (wm == (pass >> 1)) {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int nl = wn * 64 + ni * 32 + lrow;
+          const float bn = (bias && n0 + nl < a.N) ? bias[n0 + nl] : 0.0f;
+          const mf_f32x16 &c = (pass & 1) ? acc[2 + mh][ni] : acc[mh][ni];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int ml = mh * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+            float v = c[e] + bn;
+            if (a.relu) v = v > 0.0f ? v : 0.0f;
+            s_out[ml * kEp + nl] = v;
+          }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * (kBNb / 8); i += 512) {
+      const int ml = i / (kBNb / 8), c8 = i - ml * (kBNb / 8);
+      const int m = m0 + 128 * (pass >> 1) + 64 * (pass & 1) + ml, n = n0 + 8 * c8;
+      if (m >= a.M || n >= a.N) continue;
+      int64_t orow = m;
+      if (MODE == kConvDgrad) {  // class-ordered row -> channels-last voxel row of the input gradient
+        const int h = m & ((1 << (3 * dol)) - 1), p = (m >> (3 * dol)) & 7, b = m >> (3 * dol + 3);
+        const int x = 2 * (h >> (2 * dol)) + (p & 1), y = 2 * ((h >> dol) & (Do - 1)) + ((p >> 1) & 1),
+                  z = 2 * (h & (Do - 1)) + (p >> 2);
+        orow = (((int64_t)b * a.D + x) * a.D + y) * a.D + z;
+      }
+      const float4 v0 = *reinterpret_cast<const float4 *>(s_out + ml * kEp + 8 * c8);
+      const float4 v1 = *reinterpret_cast<const float4 *>(s_out + ml * kEp + 8 * c8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      const int nv = a.N - n < 8 ? a.N - n : 8;
+      if (a.out_f32) {
+        float *o = reinterpret_cast<float *>(a.out) + grp * a.o_gs + orow * a.ldo + n;
+        if (nv == 8 && (a.ldo & 3) == 0 && ((uintptr_t)o & 15) == 0) {
+          float4 *o4 = reinterpret_cast<float4 *>(o);
+          if (a.accumulate) {
+            const float4 p0 = o4[0], p1 = o4[1];
+            v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
+            v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+          }
+          o4[0] = make_float4(v[0], v[1], v[2], v[3]);
+          o4[1] = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          for (int j = 0; j < nv; ++j) o[j] = a.accumulate ? o[j] + v[j] : v[j];
+        }
+      } else {
+        uint16_t *o = reinterpret_cast<uint16_t *>(a.out) + grp * a.o_gs + orow * a.ldo + n;
+        if (nv == 8 && (a.ldo & 7) == 0 && ((uintptr_t)o & 15) == 0) {
+          *reinterpret_cast<uint4 *>(o) = make_uint4(mf::pack_bf16x2(v[0], v[1]), mf::pack_bf16x2(v[2], v[3]),
+                                                     mf::pack_bf16x2(v[4], v[5]), mf::pack_bf16x2(v[6], v[7]));
+        } else {
+          for (int j = 0; j < nv; ++j) o[j] = (uint16_t)mf::bf16_bits(v[j]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- TN engine: C[i][j] = sum_m P[m][i] * Q(m, j) -------------------------------------------------------------
 // Both operands arrive with the reduction index m as the SLOW dimension (rows of dY, rows of x / of the im2col view),
 // the MFMA wants 8 consecutive m per lane.  The LDS image keeps the global order -- 16-byte chunks land with a plain
@@ -1093,8 +1413,20 @@ int launch_nt(const NtArgs &a, hipStream_t stream) {
   else if (nt_big_override() >= 0)
     use_big = use_big && nt_big_override() == 1;
   if (use_big) {
-    if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16_big<MODE>, nt_big_lds())) return e;
-    hipLaunchKernelGGL((k_gemm_nt_bf16_big<MODE>), dim3((unsigned)big), dim3(512), nt_big_lds(), stream, a);
+    // MF_NT_PP=0: the register-staged form of the 256 x 256 tile (round 5) instead of the LDS-DMA ping-pong form
+    static const bool pp = !(getenv("MF_NT_PP") && atoi(getenv("MF_NT_PP")) == 0);
+    if (pp) {
+      // MF_PP_DBG (timing ablations, WRONG results): 1 = no operand requests after tile 0, 2 = every request re-reads
+      // K-tile 0 (cache hits), 4 = the two wave groups in lockstep instead of one barrier apart
+      static const int dbg = getenv("MF_PP_DBG") ? atoi(getenv("MF_PP_DBG")) : 0;
+      NtArgs b = a;
+      b.dbg = dbg;
+      if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16_pp<MODE>, nt_pp_lds())) return e;
+      hipLaunchKernelGGL((k_gemm_nt_bf16_pp<MODE>), dim3((unsigned)big), dim3(512), nt_pp_lds(), stream, b);
+    } else {
+      if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16_big<MODE>, nt_big_lds())) return e;
+      hipLaunchKernelGGL((k_gemm_nt_bf16_big<MODE>), dim3((unsigned)big), dim3(512), nt_big_lds(), stream, a);
+    }
     g_nt_last_tile = kBigM;
     return 0;
   }

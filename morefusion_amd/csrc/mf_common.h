@@ -66,6 +66,47 @@ __device__ __forceinline__ uint4 buf_load16(const BufRsrc &b, uint32_t byte_off)
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// ---- LDS-DMA and hand-counted waits (round 6: k_gemm_nt_bf16_pp of csrc/gemm_bf16.hip) ---------------------------
+// glds16(rs, off, dst): ONE buffer_load_dwordx4 ... lds -- every lane's 16 bytes at byte offset `off` of the resource
+// go straight into LDS at dst + 16 * lane (dst wave-uniform: it travels in M0), no VGPR in between; an out-of-range
+// offset (kBufMasked) lands ZEROS.  The transfer counts on the wave's vmcnt like any load; nothing else orders it:
+// a reader needs the issuing wave's wait_dma(), then a barrier it has passed.
+// lds_read16_async<IMM>(addr): ds_read_b128 as inline asm.  The compiler waits vmcnt(0) in front of every LDS read
+// it can see while an LDS-DMA is in flight (it cannot tell which bytes the DMA writes); it does not look into asm.
+// The result is valid only behind wait_lds_reads() -- the caller's obligation, the compiler does not track it -- and
+// its register must stay LIVE up to that wait (use every result behind it, e.g. MF_HOLD): the compiler takes the
+// register as written when the asm statement ends and re-uses a dead one while the data is still on its way.
+typedef uint32_t lds_addr_t;  // byte address inside the workgroup's LDS
+__device__ __forceinline__ lds_addr_t lds_addr(const void *p) {
+  return (lds_addr_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+__device__ __forceinline__ void glds16(const BufRsrc &b, uint32_t byte_off, unsigned char *lds_wave_base) {
+  typedef __attribute__((address_space(3))) void *lds_void;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (lds_void)lds_wave_base, 16, (int)byte_off, 0, 0, 0);
+}
+template <int IMM>
+__device__ __forceinline__ uint4 lds_read16_async(lds_addr_t addr) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void wait_lds_reads() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);  // (register-only instructions would be hoisted over the asm wait)
+}
+template <int N>
+__device__ __forceinline__ void wait_dma() {  // until at most N of this wave's DMA requests (the latest N) are pending
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// s_barrier alone: no fence, no counter drained (__syncthreads() waits vmcnt(0) while an LDS-DMA is pending)
+__device__ __forceinline__ void raw_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // ---- gfx950's transposing LDS read (round 4: the TN engine of csrc/gemm_bf16.hip) -------------------------------
 // ds_read_b64_tr_b16: every lane gives the address of 4 contiguous 16-bit elements; within each group of 16 lanes the
 // 16 x 4 elements are taken as a matrix [4 rows][16 columns] -- row r = lanes 4 r .. 4 r + 3 of the group, in lane

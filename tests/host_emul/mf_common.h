@@ -404,6 +404,7 @@ inline mf_emul_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, mf_
 }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
+inline void __builtin_amdgcn_s_setprio(int) {}
 #define MF_HOLD(r_) ((void)0)
 namespace mf {
 typedef mf_emul_f32x16 mf_f32x16;
@@ -496,6 +497,24 @@ inline uint4 buf_load16(const BufRsrc &b, uint32_t byte_off) {
   if (byte_off < kBufSpan && byte_off + 16u <= kBufSpan) memcpy(&v, b.p + byte_off, 16);
   return v;
 }
+// csrc/mf_common.h's LDS-DMA and hand-counted waits: the transfer lands at issue (the EARLIEST it could: a buffer that
+// is re-filled while a wave still has to read it shows up as wrong results), LDS addresses are host pointers
+typedef uintptr_t lds_addr_t;
+inline lds_addr_t lds_addr(const void *p) { return (lds_addr_t)p; }
+inline void glds16(const BufRsrc &b, uint32_t byte_off, unsigned char *lds_wave_base) {
+  const uint4 v = buf_load16(b, byte_off);
+  memcpy(lds_wave_base + 16 * (mf_emul::g_block.cur % 64), &v, 16);
+}
+template <int IMM>
+inline uint4 lds_read16_async(lds_addr_t addr) {
+  uint4 v;
+  memcpy(&v, (const unsigned char *)addr + IMM, 16);
+  return v;
+}
+inline void wait_lds_reads() {}
+template <int N> inline void wait_dma() {}
+inline void raw_barrier() { __syncthreads(); }
+inline int wave_uniform(int v) { return v; }
 constexpr int kWave = 64;
 inline void warm_kernargs(int) {}
 inline void atomic_add_f32(float *p, float v) { *p += v; }

@@ -34,6 +34,7 @@ def p(t):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     stock = "--no-stock" not in sys.argv
+    quick = "--quick" in sys.argv  # conv3 / conv4 / the heads' first layer only
     L = _lib.lib()
     st = _lib.stream_ptr
     dev = "cuda"
@@ -78,7 +79,7 @@ def main():
         out[name] = r
         print(json.dumps({name: r}), flush=True)
     n = B * 1000
-    for name, K, N in (("heads1", 992, 1920), ("heads2", 640, 256), ("mlp_conv2_rgb", 64, 128)):
+    for name, K, N in (("heads1", 992, 1920), ("heads2", 640, 256), ("mlp_conv2_rgb", 64, 128))[:1 if quick else 3]:
         flop = 2.0 * n * K * N
         A = torch.randn(n, K, device=dev).to(torch.bfloat16)
         W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
