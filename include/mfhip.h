@@ -386,6 +386,9 @@ int mf_linear_fwd(const float *A, int64_t a_group_stride, int32_t lda, const flo
  *                       of a stride-1 layer's data-gradient convolution (dx = conv(dy, flipT), pad' = dil (ks-1) - pad);
  *                       input channels at or beyond w_cin pack as zeros
  * mf_conv3d_bf16_fwd    out rows have pitch ldo >= Cout (a column block of a wider channels-last grid)
+ * mf_conv3d_bf16_fwd_ws the same with a workspace of mf_conv3d_bf16_fwd_workspace_bytes(...) bytes (0: not needed): a
+ *                       layer with too few 256 x 256 output tiles for the chip (conv4 at 16 objects: 64) splits its
+ *                       reduction over fp32 slabs in the workspace, added in order (deterministic) with bias / ReLU
  * mf_conv3d_bf16_wgrad  as above; only the channels below w_cin are written */
 int mf_cast_rows_bf16(const float *src, int64_t src_ld, void *dst, int64_t dst_ld, int64_t rows, int32_t cols,
                       mfStream_t stream);
@@ -414,6 +417,11 @@ int mf_conv3d_bf16_pack(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin
 int mf_conv3d_bf16_fwd(const void *x, const void *wt, const float *bias, void *out, int32_t B, int32_t Cin,
                        int32_t Cout, int32_t D, int32_t ks, int32_t stride, int32_t pad, int32_t dil, int32_t relu,
                        int32_t out_f32, int32_t ldo, mfStream_t stream);
+int64_t mf_conv3d_bf16_fwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t D, int32_t ks, int32_t stride,
+                                           int32_t pad, int32_t dil);
+int mf_conv3d_bf16_fwd_ws(const void *x, const void *wt, const float *bias, void *out, void *ws, int64_t ws_bytes,
+                          int32_t B, int32_t Cin, int32_t Cout, int32_t D, int32_t ks, int32_t stride, int32_t pad,
+                          int32_t dil, int32_t relu, int32_t out_f32, int32_t ldo, mfStream_t stream);
 int64_t mf_conv3d_bf16_wgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t ks, int32_t split);
 int32_t mf_wgrad_split(int64_t tiles, int64_t ktiles, int64_t slab_bytes);
 int32_t mf_conv3d_bf16_wgrad_default_split(int32_t B, int32_t Cin, int32_t Cout, int32_t Do, int32_t ks);

@@ -90,6 +90,8 @@ _SIGNATURES = {
     "mf_conv3d_k4s2_bf16_wgrad": ([_p, _p, _p, _p] + [ctypes.c_int32] * 7 + [_p], _i),
     "mf_conv3d_bf16_pack": ([_p] + [ctypes.c_int32] * 5 + [_p, _p, _p, _p], _i),
     "mf_conv3d_bf16_fwd": ([_p, _p, _p, _p] + [ctypes.c_int32] * 11 + [_p], _i),
+    "mf_conv3d_bf16_fwd_workspace_bytes": ([ctypes.c_int32] * 8, _i64),
+    "mf_conv3d_bf16_fwd_ws": ([_p, _p, _p, _p, _p, _i64] + [ctypes.c_int32] * 11 + [_p], _i),
     "mf_conv3d_bf16_wgrad_workspace_bytes": ([ctypes.c_int32] * 4, _i64),
     "mf_wgrad_split": ([_i64, _i64, _i64], _i),
     "mf_conv3d_bf16_wgrad_default_split": ([ctypes.c_int32] * 5, ctypes.c_int32),

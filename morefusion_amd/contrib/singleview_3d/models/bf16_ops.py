@@ -104,8 +104,12 @@ class Conv3d(torch.autograd.Function):
         wt, wd, wf = _cached_pack(weight, ("conv3d", Cin, c_off, bool(need_dx), x.device.index), build)
         out = _empty((B, Do ** 3, Cout), BF16, x)
         b = bias.detach().float().contiguous() if bias is not None else None
-        _lib.check(L.mf_conv3d_bf16_fwd(x.data_ptr(), wt.data_ptr(), _lib.ptr(b), out.data_ptr(), B, Cin, Cout, D, ks,
-                                        stride, pad, dil, int(relu), 0, Cout, _lib.stream_ptr()), "mf_conv3d_bf16_fwd")
+        # a layer with too few output tiles for the chip (conv4 at 16 objects) splits its reduction over fp32 slabs
+        nws = L.mf_conv3d_bf16_fwd_workspace_bytes(B, Cin, Cout, D, ks, stride, pad, dil)
+        ws = _empty((nws,), torch.uint8, x) if nws > 0 else None
+        _lib.check(L.mf_conv3d_bf16_fwd_ws(x.data_ptr(), wt.data_ptr(), _lib.ptr(b), out.data_ptr(), _lib.ptr(ws), nws,
+                                           B, Cin, Cout, D, ks, stride, pad, dil, int(relu), 0, Cout,
+                                           _lib.stream_ptr()), "mf_conv3d_bf16_fwd_ws")
         ctx.save_for_backward(x, wd, wf, out if relu else None)
         ctx.geom = (B, Cin, Cout, D, Do, ks, stride, pad, dil, w_cin, c_off, bool(relu), bias is not None, weight.shape)
         return out

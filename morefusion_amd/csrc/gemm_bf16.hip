@@ -59,6 +59,10 @@ struct NtArgs {
   // conv geometry: D = INPUT grid size, Do = OUTPUT grid size = 1 << olog; forward taps ks^3 at x = stride * o - pad
   // + dil * k per axis (dgrad: the k4 / s2 / p1 parity-class form only)
   int B, D, Do, olog, Cin, Cout, ks, stride, pad, dil;
+  // k_gemm_nt_bf16_pp only: S > 1 splits the K-tiles into S contiguous ranges; split s writes its fp32 partial
+  // sums (no bias / ReLU) to slab + s * M * N (row pitch N), k_splitk_finish adds them in order
+  int S;
+  float *slab;
   int dbg;  // k_gemm_nt_bf16_pp ablations (MF_PP_DBG; timing experiments only, results are wrong): see launch_nt
 };
 
@@ -714,10 +718,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
   const int G = gridDim.x;
   int L = blockIdx.x;
   if ((G & 7) == 0) L = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous logical order
+  const int split = L / (per_group * a.groups);  // (0 unless a.S > 1: the splits of a tile are S whole rounds apart)
+  L -= split * per_group * a.groups;
   const int grp = L / per_group;
   const int rem = L - grp * per_group;
   const int m0 = (rem / tiles_n) * kBM, n0 = (rem % tiles_n) * kBNb;  // N tile fastest (csrc/linear.hip)
-  const int T = (a.K + kBK - 1) / kBK;
+  const int Tall = (a.K + kBK - 1) / kBK, Tper = (Tall + a.S - 1) / a.S;
+  const int t0 = split * Tper;
+  const int T = max(0, min(Tall, t0 + Tper) - t0);  // this workgroup's K-tiles: t0 .. t0 + T - 1
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = mf::wave_uniform(tid >> 6);
@@ -787,7 +795,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
 
   // this lane's position in K, advanced by one K-tile per request (see k_gemm_nt_bf16); the A requests run one tile
   // ahead of the W requests
-  int kg = 8 * chunk, tc = 0, tx = 0, ty = 0, tz = 0, kgw = 8 * chunk;
+  int kg = 8 * chunk + kBK * t0, tc = 0, tx = 0, ty = 0, tz = 0, kgw = kg;
   if (MODE == kConvFwd) {
     const int tap = kg / a.Cin;
     tc = kg - tap * a.Cin;
@@ -800,8 +808,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
   const mf::BufRsrc Ars = mf::make_rsrc(A), Wrs = mf::make_rsrc(W);
   // the 1 KiB of LDS a DMA instruction of this wave fills: rows 64 i + 8 wave .. + 7 of an operand stage
   unsigned char *const dma0 = s_raw + 8 * wave * 128;
-  // rows 128 h_ .. + 127 (h_ = 0, 1) of A's next K-tile -> A stage sa_; the position advances behind the second half
-#define MF_PP_REQ_A(sa_, h_)                                                                          \
+  // requests i0_ .. i1_ - 1 (rows 64 i .. + 63) of A's next K-tile -> A stage sa_; the position advances behind the last
+#define MF_PP_REQ_A(sa_, i0_, i1_)                                                                    \
   {                                                                                                   \
     const bool kin_ = kg + 8 <= a.K;                                                                  \
     int off_ = kg, bits_ = 1 << 12;                                                                   \
@@ -814,10 +822,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
       bits_ = (1 << sx) | (16 << sy) | (256 << sz) | (1 << 12);                                       \
     }                                                                                                 \
     if (!kin_) bits_ = 1 << 13; /* (no row has bit 13) */                                             \
-    _Pragma("unroll") for (int i = 2 * (h_); i < 2 * (h_) + 2; ++i)                                   \
+    _Pragma("unroll") for (int i = (i0_); i < (i1_); ++i)                                             \
       mf::glds16(Ars, (mask[i] & bits_) == bits_ ? 2u * (uint32_t)(base[i] + off_) : mf::kBufMasked,  \
                  dma0 + (sa_) * kPpOp + i * 64 * 128);                                                \
-    if ((h_) == 1) {                                                                                  \
+    if ((i1_) == 4) {                                                                                 \
       kg += kBK;                                                                                      \
       if (MODE == kConvFwd) {                                                                         \
         tc += kBK;                                                                                    \
@@ -833,12 +841,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
   }
   // (the weight operand needs no mask: behind the K tail it re-reads k = 0 -- finite, and the A chunk there is zero --
   // and a column past N re-reads row 0 into an accumulator column the epilogue never stores)
-#define MF_PP_REQ_W(sw_, h_)                                                                          \
+#define MF_PP_REQ_W(sw_, i0_, i1_)                                                                    \
   {                                                                                                   \
     const uint32_t kofs_ = kgw + 8 <= a.K ? 2u * (uint32_t)kgw : 0u;                                  \
-    _Pragma("unroll") for (int i = 2 * (h_); i < 2 * (h_) + 2; ++i)                                   \
+    _Pragma("unroll") for (int i = (i0_); i < (i1_); ++i)                                             \
       mf::glds16(Wrs, wrow[i] + kofs_, dma0 + kPpW0 + (sw_) * kPpOp + i * 64 * 128);                  \
-    if ((h_) == 1) kgw += kBK;                                                                        \
+    if ((i1_) == 4) kgw += kBK;                                                                       \
   }
   // fragment addresses inside a stage: row R = 128 wm + 32 mi + lrow of A (64 wn + 32 ni + lrow of W), chunk
   // (2 s + lhalf) ^ ((lrow >> 1) & 7) = ((s ^ (lrow >> 2 & 3)) << 1) | ((lhalf ^ (lrow >> 1)) & 1)
@@ -852,26 +860,40 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
   // own six reads or they were issued between the previous phase's MFMAs: the barrier hand-over itself, ~100 cycles
   // per 256 cycles of MFMAs.  MF_PP_DBG ablations, tools/ab_gemm.sh.)
   uint4 fa[2][4], fb[2][2];
-#define MF_PP_READS(NJ_, kk_, sa_, sw_, s_)                                                           \
+#define MF_PP_READS(NJ_, kk_, sa_, sw_, s_, r0_, r1_)                                                  \
   if ((NJ_) > 0) {                                                                                    \
     const mf::lds_addr_t va_ = fragA + (sa_) * kPpOp + (((s_) ^ gh) << 5);                            \
     const mf::lds_addr_t vb_ = fragW + (sw_) * kPpOp + (((s_) ^ gh) << 5);                            \
-    fa[kk_][0] = mf::lds_read16_async<0>(va_);                                                        \
-    fb[kk_][0] = mf::lds_read16_async<0>(vb_);                                                        \
-    fa[kk_][1] = mf::lds_read16_async<4096>(va_);                                                     \
-    if ((NJ_) > 1) fb[kk_][1] = mf::lds_read16_async<4096>(vb_);                                      \
-    fa[kk_][2] = mf::lds_read16_async<8192>(va_);                                                     \
-    fa[kk_][3] = mf::lds_read16_async<12288>(va_);                                                    \
+    if ((r0_) <= 0 && 0 < (r1_)) fa[kk_][0] = mf::lds_read16_async<0>(va_);                           \
+    if ((r0_) <= 1 && 1 < (r1_)) fb[kk_][0] = mf::lds_read16_async<0>(vb_);                           \
+    if ((r0_) <= 2 && 2 < (r1_)) fa[kk_][1] = mf::lds_read16_async<4096>(va_);                        \
+    if ((r0_) <= 3 && 3 < (r1_) && (NJ_) > 1) fb[kk_][1] = mf::lds_read16_async<4096>(vb_);           \
+    if ((r0_) <= 4 && 4 < (r1_)) fa[kk_][2] = mf::lds_read16_async<8192>(va_);                        \
+    if ((r0_) <= 5 && 5 < (r1_)) fa[kk_][3] = mf::lds_read16_async<12288>(va_);                       \
   }
   // NJ_ = the wave's 32-column blocks that exist (2, 1 or 0: wave-uniform, one loop per value).  A fragment that no
   // MFMA uses is NOT read: the compiler takes the asm's result register as written when the statement ends and hands
   // a dead one out again at once -- the data then lands on top of whatever lives there (seen: the offset of the next
   // DMA request, a memory fault).  MF_HOLD behind the wait keeps every fragment register reserved up to there.
-#define MF_PP_PHASE(NJ_, p_, REQ_)                                                                    \
+#ifndef MF_PP_NL  // DMA requests of a phase issued in its load section; the other 4 - MF_PP_NL between its MFMAs
+#define MF_PP_NL 4
+#endif
+#ifndef MF_PP_MIX  // 1: the load section alternates three fragment reads and one request
+#define MF_PP_MIX 0
+#endif
+#define MF_PP_PHASE(NJ_, p_, REQ_, WAIT_)                                                             \
   {                                                                                                   \
-    MF_PP_READS(NJ_, 0, sa, sw, 2 * (p_))                                                             \
-    MF_PP_READS(NJ_, 1, sa, sw, 2 * (p_) + 1)                                                         \
-    REQ_                                                                                              \
+    if (MF_PP_MIX) {                                                                                  \
+      MF_PP_READS(NJ_, 0, sa, sw, 2 * (p_), 0, 3) REQ_(0, 1)                                          \
+      MF_PP_READS(NJ_, 0, sa, sw, 2 * (p_), 3, 6) if (MF_PP_NL > 1) { REQ_(1, 2) }                    \
+      MF_PP_READS(NJ_, 1, sa, sw, 2 * (p_) + 1, 0, 3) if (MF_PP_NL > 2) { REQ_(2, 3) }                \
+      MF_PP_READS(NJ_, 1, sa, sw, 2 * (p_) + 1, 3, 6) if (MF_PP_NL > 3) { REQ_(3, 4) }                \
+    } else {                                                                                          \
+      MF_PP_READS(NJ_, 0, sa, sw, 2 * (p_), 0, 6)                                                     \
+      MF_PP_READS(NJ_, 1, sa, sw, 2 * (p_) + 1, 0, 6)                                                 \
+      REQ_(0, MF_PP_NL)                                                                               \
+    }                                                                                                 \
+    WAIT_                                                                                             \
     mf::wait_lds_reads();                                                                             \
     if ((NJ_) > 0) {                                                                                  \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                              \
@@ -885,25 +907,29 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
     _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                  \
       const int kk = q >> 3, mi = q & 3, nj = (q >> 2) & 1;                                           \
       if (nj < (NJ_)) acc[mi][nj] = mf::mfma_bf16_32x32x16(fa[kk][mi], fb[kk][nj], acc[mi][nj]);      \
+      if (MF_PP_NL == 3 && q == 7) { __builtin_amdgcn_sched_barrier(0); REQ_(3, 4) __builtin_amdgcn_sched_barrier(0); } \
+      if (MF_PP_NL == 2 && q == 4) { __builtin_amdgcn_sched_barrier(0); REQ_(2, 3) __builtin_amdgcn_sched_barrier(0); } \
+      if (MF_PP_NL == 2 && q == 10) { __builtin_amdgcn_sched_barrier(0); REQ_(3, 4) __builtin_amdgcn_sched_barrier(0); } \
     }                                                                                                 \
     __builtin_amdgcn_s_setprio(0);                                                                    \
     mf::raw_barrier();                                                                                \
   }
+#define MF_PP_RW(i0_, i1_) if (more1) MF_PP_REQ_W(sw ^ 1, i0_, i1_)
+#define MF_PP_RA(i0_, i1_) if (more2) MF_PP_REQ_A(sa2, i0_, i1_)
 #define MF_PP_LOOP(NJ_)                                                                               \
   for (int t = 0; t < T; ++t) {                                                                       \
     const int sw = t & 1;                                                                             \
     const bool more1 = t + 1 < T && !(a.dbg & 1), more2 = t + 2 < T && !(a.dbg & 1);                  \
     if (a.dbg & 2) { kg = kgw = 8 * chunk; tc = kg; tx = ty = tz = 0; }                               \
-    MF_PP_PHASE(NJ_, 0, if (more1) { MF_PP_REQ_W(sw ^ 1, 0) MF_PP_REQ_W(sw ^ 1, 1) })                 \
-    MF_PP_PHASE(NJ_, 1, if (more2) { MF_PP_REQ_A(sa2, 0) MF_PP_REQ_A(sa2, 1) mf::wait_dma<4>(); }     \
-                        else { mf::wait_dma<0>(); })                                                  \
+    MF_PP_PHASE(NJ_, 0, MF_PP_RW, )                                                                   \
+    MF_PP_PHASE(NJ_, 1, MF_PP_RA, if (more2) mf::wait_dma<MF_PP_NL>(); else mf::wait_dma<0>();)              \
     sa = sa == 2 ? 0 : sa + 1;                                                                        \
     sa2 = sa2 == 2 ? 0 : sa2 + 1;                                                                     \
   }
   // tiles 0 (A, W) and 1 (A) before the loop; the requests of A(1) stay in flight
-  MF_PP_REQ_A(0, 0) MF_PP_REQ_A(0, 1) MF_PP_REQ_W(0, 0) MF_PP_REQ_W(0, 1)
+  MF_PP_REQ_A(0, 0, 4) MF_PP_REQ_W(0, 0, 4)
   if (T > 1 && !(a.dbg & 1)) {
-    MF_PP_REQ_A(1, 0) MF_PP_REQ_A(1, 1)
+    MF_PP_REQ_A(1, 0, 4)
     mf::wait_dma<4>();
   } else {
     mf::wait_dma<0>();
@@ -920,6 +946,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
   }
   if (wm == 0 && !(a.dbg & 4)) mf::raw_barrier();  // the groups meet again: every fragment read is retired, no DMA is pending
 #undef MF_PP_LOOP
+#undef MF_PP_RW
+#undef MF_PP_RA
 #undef MF_PP_READS
 #undef MF_PP_PHASE
 #undef MF_PP_REQ_W
@@ -928,7 +956,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
   // epilogue through LDS in four passes of 64 rows (as in k_gemm_nt_bf16_big)
   constexpr int kEp = kBNb + 4;
   float *s_out = reinterpret_cast<float *>(s_raw);  // [64][kEp]
-  const float *bias = a.bias ? a.bias + grp * a.b_gs : nullptr;
+  const float *bias = a.bias && a.S == 1 ? a.bias + grp * a.b_gs : nullptr;
+  const bool relu = a.relu && a.S == 1, out_f32 = a.out_f32 || a.S > 1;
+  const int ldo = a.S > 1 ? a.N : a.ldo;
+  void *const outp = a.S > 1 ? (void *)(a.slab + (int64_t)split * a.M * a.N) : a.out;
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     if (wm == (pass >> 1)) {
@@ -943,7 +974,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
           for (int e = 0; e < 16; ++e) {
             const int ml = mh * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
             float v = c[e] + bn;
-            if (a.relu) v = v > 0.0f ? v : 0.0f;
+            if (relu) v = v > 0.0f ? v : 0.0f;
             s_out[ml * kEp + nl] = v;
           }
         }
@@ -964,11 +995,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
       const float4 v1 = *reinterpret_cast<const float4 *>(s_out + ml * kEp + 8 * c8 + 4);
       float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
       const int nv = a.N - n < 8 ? a.N - n : 8;
-      if (a.out_f32) {
-        float *o = reinterpret_cast<float *>(a.out) + grp * a.o_gs + orow * a.ldo + n;
-        if (nv == 8 && (a.ldo & 3) == 0 && ((uintptr_t)o & 15) == 0) {
+      if (out_f32) {
+        float *o = reinterpret_cast<float *>(outp) + grp * a.o_gs + orow * ldo + n;
+        if (nv == 8 && (ldo & 3) == 0 && ((uintptr_t)o & 15) == 0) {
           float4 *o4 = reinterpret_cast<float4 *>(o);
-          if (a.accumulate) {
+          if (a.accumulate && a.S == 1) {
             const float4 p0 = o4[0], p1 = o4[1];
             v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
             v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
@@ -976,11 +1007,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
           o4[0] = make_float4(v[0], v[1], v[2], v[3]);
           o4[1] = make_float4(v[4], v[5], v[6], v[7]);
         } else {
-          for (int j = 0; j < nv; ++j) o[j] = a.accumulate ? o[j] + v[j] : v[j];
+          for (int j = 0; j < nv; ++j) o[j] = a.accumulate && a.S == 1 ? o[j] + v[j] : v[j];
         }
       } else {
-        uint16_t *o = reinterpret_cast<uint16_t *>(a.out) + grp * a.o_gs + orow * a.ldo + n;
-        if (nv == 8 && (a.ldo & 7) == 0 && ((uintptr_t)o & 15) == 0) {
+        uint16_t *o = reinterpret_cast<uint16_t *>(outp) + grp * a.o_gs + orow * ldo + n;
+        if (nv == 8 && (ldo & 7) == 0 && ((uintptr_t)o & 15) == 0) {
           *reinterpret_cast<uint4 *>(o) = make_uint4(mf::pack_bf16x2(v[0], v[1]), mf::pack_bf16x2(v[2], v[3]),
                                                      mf::pack_bf16x2(v[4], v[5]), mf::pack_bf16x2(v[6], v[7]));
         } else {
@@ -1387,6 +1418,49 @@ __global__ __launch_bounds__(256) void k_relu_mask_bf16(const uint16_t *__restri
   reinterpret_cast<uint4 *>(dz)[i] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
+// out[m][n] = act(sum_s slab[s][m][n] + bias[n]) (increasing s: deterministic), bf16 or fp32 rows of pitch ldo: the
+// second half of a split-K launch of k_gemm_nt_bf16_pp.  Eight columns per lane (N % 8 == 0).
+__global__ __launch_bounds__(256) void k_splitk_finish(const float *__restrict__ slab, const float *__restrict__ bias,
+                                                       void *__restrict__ out, int64_t M, int N, int S, int ldo,
+                                                       int relu, int out_f32) {
+  const int n8 = N >> 3;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * n8) return;
+  const int64_t m = i / n8;
+  const int n = (int)(i - m * n8) * 8;
+  const float4 *src = reinterpret_cast<const float4 *>(slab + m * N + n);
+  float4 a0 = src[0], a1 = src[1];
+  for (int s = 1; s < S; ++s) {
+    const float4 *p = reinterpret_cast<const float4 *>(slab + (int64_t)s * M * N + m * N + n);
+    const float4 b0 = p[0], b1 = p[1];
+    a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+  }
+  float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (bias) v[j] += bias[n + j];
+    if (relu) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+  }
+  if (out_f32) {
+    float *o = reinterpret_cast<float *>(out) + m * ldo + n;
+    if ((ldo & 3) == 0 && ((uintptr_t)o & 15) == 0) {
+      reinterpret_cast<float4 *>(o)[0] = make_float4(v[0], v[1], v[2], v[3]);
+      reinterpret_cast<float4 *>(o)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      for (int j = 0; j < 8; ++j) o[j] = v[j];
+    }
+  } else {
+    uint16_t *o = reinterpret_cast<uint16_t *>(out) + m * ldo + n;
+    if ((ldo & 7) == 0 && ((uintptr_t)o & 15) == 0) {
+      *reinterpret_cast<uint4 *>(o) = make_uint4(mf::pack_bf16x2(v[0], v[1]), mf::pack_bf16x2(v[2], v[3]),
+                                                 mf::pack_bf16x2(v[4], v[5]), mf::pack_bf16x2(v[6], v[7]));
+    } else {
+      for (int j = 0; j < 8; ++j) o[j] = (uint16_t)mf::bf16_bits(v[j]);
+    }
+  }
+}
+
 int ilog2_exact(int x) {
   int l = 0;
   while ((1 << l) < x) ++l;
@@ -1408,6 +1482,7 @@ int launch_nt(const NtArgs &a, hipStream_t stream) {
   const int64_t big = (int64_t)((a.M + kBigM - 1) / kBigM) * ((a.N + kBigN - 1) / kBigN) * a.groups;
   bool use_big = big >= 224 && a.N >= 192 && !(MODE == kRows && a.tile_group) &&
                  !(MODE == kConvDgrad && ((a.Do * a.Do * a.Do) & (kBigM - 1)));
+  if (a.S > 1) use_big = true;  // (a split-K launch: the caller checked the structure, nt_splitk)
   if (nt_big_override() == 2)  // (tests: the big tile wherever its structure allows, whatever the tile count)
     use_big = !(MODE == kRows && a.tile_group) && !(MODE == kConvDgrad && ((a.Do * a.Do * a.Do) & (kBigM - 1)));
   else if (nt_big_override() >= 0)
@@ -1421,8 +1496,13 @@ int launch_nt(const NtArgs &a, hipStream_t stream) {
       static const int dbg = getenv("MF_PP_DBG") ? atoi(getenv("MF_PP_DBG")) : 0;
       NtArgs b = a;
       b.dbg = dbg;
+      if (b.S < 1) b.S = 1;
       if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16_pp<MODE>, nt_pp_lds())) return e;
-      hipLaunchKernelGGL((k_gemm_nt_bf16_pp<MODE>), dim3((unsigned)big), dim3(512), nt_pp_lds(), stream, b);
+      hipLaunchKernelGGL((k_gemm_nt_bf16_pp<MODE>), dim3((unsigned)(big * b.S)), dim3(512), nt_pp_lds(), stream, b);
+      if (b.S > 1)
+        hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)(((int64_t)a.M * (a.N / 8) + 255) / 256)), dim3(256), 0,
+                           stream, (const float *)b.slab, a.bias, a.out, (int64_t)a.M, a.N, b.S, a.ldo, a.relu,
+                           a.out_f32);
     } else {
       if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16_big<MODE>, nt_big_lds())) return e;
       hipLaunchKernelGGL((k_gemm_nt_bf16_big<MODE>), dim3((unsigned)big), dim3(512), nt_big_lds(), stream, a);
@@ -1594,6 +1674,32 @@ int conv_geom(int32_t B, int32_t Cin, int32_t Cout, int32_t D, int32_t ks, int32
 }
 }  // namespace
 
+namespace {
+// Split of K for a forward / data-gradient GEMM with too few 256 x 256 tiles to fill the chip (conv4's forward at 16
+// objects: 32 x 2 tiles for 256 CUs): S workgroups per tile, each over a contiguous range of >= 16 K-tiles, fp32
+// partial sums in S slabs, added in order by k_splitk_finish (deterministic).  1 = no split.
+int nt_splitk(int64_t M, int N, int K) {
+  const int forced = getenv("MF_NT_SPLITK") ? atoi(getenv("MF_NT_SPLITK")) : 0;  // (tests; 0 = by problem size)
+  if (N < 192 || N % 8 || nt_big_override() == 0 || (getenv("MF_NT_PP") && atoi(getenv("MF_NT_PP")) == 0)) return 1;
+  const int64_t big = ((M + kBigM - 1) / kBigM) * ((N + kBigN - 1) / kBigN);
+  const int T = (K + kBK - 1) / kBK;
+  if (forced > 0) return forced <= T ? forced : 1;
+  if (big >= 160 || big < 16) return 1;
+  int S = (int)(256 / big);
+  while (S > 1 && T / S < 16) --S;
+  return S;
+}
+}  // namespace
+
+extern "C" int64_t mf_conv3d_bf16_fwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t D, int32_t ks,
+                                                      int32_t stride, int32_t pad, int32_t dil) {
+  Geom g;
+  if (B <= 0 || conv_geom(B, Cin, Cout, D, ks, stride, pad, dil, &g)) return 0;
+  const int64_t M = (int64_t)B * g.Do * g.Do * g.Do;
+  const int S = nt_splitk(M, Cout, g.taps * Cin);
+  return S > 1 ? (int64_t)S * M * Cout * 4 : 0;
+}
+
 extern "C" int mf_conv3d_bf16_pack(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin, int32_t c_off, int32_t ks,
                                    void *fwd, void *dgrad_k4s2, void *flipT, mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -1625,6 +1731,32 @@ extern "C" int mf_conv3d_bf16_fwd(const void *x, const void *wt, const float *bi
   a.ks = ks; a.stride = stride; a.pad = pad; a.dil = dil;
   if (int e = launch_nt<kConvFwd>(a, stream)) return e;
   return mf::check_launch("mf_conv3d_bf16_fwd");
+}
+
+/* mf_conv3d_bf16_fwd with a workspace of mf_conv3d_bf16_fwd_workspace_bytes(...) bytes (0: none needed, ws may be
+ * null): a layer with too few output tiles for the chip splits its reduction over the workspace's fp32 slabs. */
+extern "C" int mf_conv3d_bf16_fwd_ws(const void *x, const void *wt, const float *bias, void *out, void *ws,
+                                     int64_t ws_bytes, int32_t B, int32_t Cin, int32_t Cout, int32_t D, int32_t ks,
+                                     int32_t stride, int32_t pad, int32_t dil, int32_t relu, int32_t out_f32,
+                                     int32_t ldo, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0) return 0;
+  Geom g;
+  if (int e = conv_geom(B, Cin, Cout, D, ks, stride, pad, dil, &g)) return e;
+  if (ldo < Cout) return bad("conv3d_bf16_fwd_ws: ldo >= Cout");
+  const int64_t M = (int64_t)B * g.Do * g.Do * g.Do;
+  const int S = nt_splitk(M, Cout, g.taps * Cin);
+  if (S <= 1 || !ws) return mf_conv3d_bf16_fwd(x, wt, bias, out, B, Cin, Cout, D, ks, stride, pad, dil, relu, out_f32, ldo, stream_);
+  if (ws_bytes < (int64_t)S * M * Cout * 4 || ((uintptr_t)ws & 15)) return bad("conv3d_bf16_fwd_ws: workspace too small / unaligned");
+  NtArgs a = {};
+  a.A = (const uint16_t *)x; a.W = (const uint16_t *)wt; a.bias = bias; a.out = out;
+  a.M = (int)M; a.N = Cout; a.K = g.taps * Cin; a.ldw = g.taps * Cin; a.ldo = ldo; a.groups = 1;
+  a.relu = relu; a.out_f32 = out_f32;
+  a.B = B; a.D = D; a.Do = g.Do; a.olog = g.olog; a.Cin = Cin; a.Cout = Cout;
+  a.ks = ks; a.stride = stride; a.pad = pad; a.dil = dil;
+  a.S = S; a.slab = (float *)ws;
+  if (int e = launch_nt<kConvFwd>(a, stream)) return e;
+  return mf::check_launch("mf_conv3d_bf16_fwd_ws");
 }
 
 /* dx [B][D^3][Cin] (+)= conv^T(dy [B][(D/2)^3][Cout]) of the k4 / s2 / p1 layers: dy, wd (packed parity-class layout)

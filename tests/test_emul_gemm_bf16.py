@@ -4,6 +4,7 @@ chains (model.py:76-91,239-258) against torch's float32 operators evaluated on t
 (products of two bf16 are exact in fp32, so the only difference is the summation order: tolerance 1e-4 relative
 to the largest output, 1 bf16 ulp where the kernel rounds its output to bf16)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -120,7 +121,8 @@ def test_linear_bf16_forward_dgrad_wgrad(L, M, N, K, groups, relu):
                 close(dW[g], dYg[:, g * N:(g + 1) * N].float().t() @ A[:, g * K:(g + 1) * K].float())
 
 
-@pytest.mark.parametrize("B,Cin,Cout,D,w_cin,c_off", [(1, 8, 136, 8, 8, 0), (2, 16, 128, 16, 24, 8), (1, 40, 64, 16, 40, 0)])
+@pytest.mark.parametrize("B,Cin,Cout,D,w_cin,c_off", [(1, 8, 136, 8, 8, 0), (2, 16, 128, 16, 24, 8), (1, 40, 64, 16, 40, 0),
+                                                   (1, 24, 200, 8, 24, 0)])
 def test_conv3d_k4s2_bf16_forward_dgrad_wgrad(L, B, Cin, Cout, D, w_cin, c_off):
     """Convolution3D(Cin, Cout, 4, 2, pad = 1) on channels-last bf16 grids: forward (+ bias + ReLU), data gradient
     (parity-class GEMMs, scattered back to voxel rows; bf16, fp32 and accumulating outputs) and weight gradient
@@ -146,6 +148,24 @@ def test_conv3d_k4s2_bf16_forward_dgrad_wgrad(L, B, Cin, Cout, D, w_cin, c_off):
         assert L.mf_conv3d_k4s2_bf16_fwd(p(x_cl), p(wt), p(bias), p(out), B, Cin, Cout, D, relu, out_f32, None) == 0
         want = cl(F.relu(y_ref.detach()) if relu else y_ref.detach()).reshape(B, Do ** 3, Cout)
         (close if out_f32 else close_bf16)(out, want)
+    # forward with the reduction split over fp32 slabs of a workspace (what conv4 at 16 objects takes: 64 tiles for 256
+    # CUs; forced here): the same values, bias / ReLU applied once by the finish pass, pitch / dtype of the output kept
+    if Cout >= 192 and os.environ.get("MF_NT_BIG") == "2":
+        os.environ["MF_NT_SPLITK"] = "3"
+        try:
+            nws = L.mf_conv3d_bf16_fwd_workspace_bytes(B, Cin, Cout, D, 4, 2, 1, 1)
+            assert nws == 3 * B * Do ** 3 * Cout * 4
+            ws = torch.empty(nws, dtype=torch.uint8)
+            for relu, out_f32 in ((0, 1), (1, 0)):
+                out = torch.full((B, Do ** 3, Cout + 8), 5.0, dtype=torch.float32 if out_f32 else torch.bfloat16)
+                assert L.mf_conv3d_bf16_fwd_ws(p(x_cl), p(wt), p(bias), p(out), p(ws), nws, B, Cin, Cout, D, 4, 2, 1, 1,
+                                               relu, out_f32, Cout + 8, None) == 0
+                want = cl(F.relu(y_ref.detach()) if relu else y_ref.detach()).reshape(B, Do ** 3, Cout)
+                (close if out_f32 else close_bf16)(out[:, :, :Cout], want)
+                assert float((out[:, :, Cout:].float() - 5.0).abs().max()) == 0.0
+        finally:
+            del os.environ["MF_NT_SPLITK"]
+        assert L.mf_conv3d_bf16_fwd_workspace_bytes(B, Cin, Cout, D, 4, 2, 1, 1) == 0  # (few tiles, short K: no split)
     # data gradient
     if Do ** 3 % 128 == 0:
         want = cl(x_cf.grad).reshape(B, D ** 3, Cin)

@@ -56,7 +56,10 @@ def main():
         split = L.mf_conv3d_k4s2_bf16_wgrad_default_split(B, Cin, Cout, D)
         ws = torch.empty(L.mf_conv3d_k4s2_bf16_wgrad_workspace_bytes(Cin, Cout, split), dtype=torch.uint8, device=dev)
         r = {"gflop": round(flop / 1e9, 1), "wgrad_split": split}
-        t = timeit(lambda: _lib.check(L.mf_conv3d_k4s2_bf16_fwd(p(x), p(wt), p(bias), p(y), B, Cin, Cout, D, 1, 0, st()), "fwd"))
+        nws = L.mf_conv3d_bf16_fwd_workspace_bytes(B, Cin, Cout, D, 4, 2, 1, 1)   # > 0: the layer splits its reduction
+        fws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+        r["fwd_splitk_ws_mb"] = round(nws / 2 ** 20, 1)
+        t = timeit(lambda: _lib.check(L.mf_conv3d_bf16_fwd_ws(p(x), p(wt), p(bias), p(y), p(fws), nws, B, Cin, Cout, D, 4, 2, 1, 1, 1, 0, Cout, st()), "fwd"))
         r["fwd_ms"], r["fwd_tflops"] = round(t, 4), round(flop / t / 1e9, 1)
         t = timeit(lambda: _lib.check(L.mf_conv3d_k4s2_bf16_dgrad(p(dy), p(wd), p(dx), B, Cin, Cout, D, 0, 0, st()), "dgrad"))
         r["dgrad_ms"], r["dgrad_tflops"] = round(t, 4), round(flop / t / 1e9, 1)
