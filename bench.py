@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import morefusion_amd as mf  # noqa: E402
-from morefusion_amd import parallel  # noqa: E402
+from morefusion_amd import miopen_cache, parallel  # noqa: E402
 from morefusion_amd.contrib.singleview_3d.models import Model  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--icc-cus", type=int, default=0,
                     help="run the ICC stream on this many of the 256 CUs only (CU-masked HIP stream; 0 = no mask)")
     ap.add_argument("--icc-cu-pattern", choices=["low", "spread"], default="spread")
+    ap.add_argument("--split-chip", action="store_true",
+                    help="with --icc-cus N: the network runs on a stream masked to the OTHER 256 - N CUs (tuning knob)")
     ap.add_argument("--stage-breakdown", action="store_true", default=True)
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the batch-1 latency child process")
     ap.add_argument("--no-extras", action="store_true",
@@ -97,9 +99,10 @@ def _low_priority_stream(device):
     return torch.cuda.ExternalStream(handle.value, device=device)
 
 
-def _cu_masked_stream(device, n_cus, pattern="low"):
+def _cu_masked_stream(device, n_cus, pattern="low", complement=False):
     """A HIP stream whose kernels may only run on ``n_cus`` of the 256 CUs (hipExtStreamCreateWithCUMask):
-    confines the refinement's many short launches to a part of the chip while the network keeps the rest."""
+    confines the refinement's many short launches to a part of the chip while the network keeps the rest.
+    ``complement``: the stream gets the OTHER 256 - n_cus CUs instead (the network's side of a split chip)."""
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
     words = (ctypes.c_uint32 * 8)()
@@ -107,6 +110,9 @@ def _cu_masked_stream(device, n_cus, pattern="low"):
     picked = range(n_cus) if pattern == "low" else range(0, total, max(1, total // n_cus))
     for cu in list(picked)[:n_cus]:
         words[cu // 32] |= 1 << (cu % 32)
+    if complement:
+        for w in range(8):
+            words[w] = ~words[w] & 0xffffffff
     handle = ctypes.c_void_p()
     rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), 8, words)
     assert rc == 0, f"hipExtStreamCreateWithCUMask failed ({rc})"
@@ -155,6 +161,8 @@ class Workload:
             self.icc_stream = _low_priority_stream(device)
         if args.icc_cus:
             self.icc_stream = _cu_masked_stream(device, args.icc_cus, args.icc_cu_pattern)
+            if args.split_chip:
+                self.net_stream = _cu_masked_stream(device, args.icc_cus, args.icc_cu_pattern, complement=True)
 
     def _mark(self, name):
         if self._timing:
@@ -552,13 +560,26 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 
 
 def roofline_bf16_kernels(wl, B=16):
-    """The bf16 MFMA kernels of csrc/gemm_bf16.hip (BASELINE config 5's 3-D CNN: forward, data and weight gradients
-    of conv3 160 -> 256 on 32^3 and conv4 256 -> 512 on 16^3, at the per-GPU training batch of 16 objects), timed live
-    with HIP events; TFLOP/s against the dense bf16 MFMA peak."""
+    """The bf16 MFMA kernels of csrc/gemm_bf16.hip at BASELINE config 5's per-GPU training batch (16 objects, 1000
+    points each), timed live with HIP events; TFLOP/s against the dense bf16 MFMA peak.
+    * conv4 256 -> 512 on 16^3: forward (split-K over fp32 slabs), data gradient, weight gradient -- what the step runs;
+    * sparse_conv3_*: the three GEMMs of conv3 on the compact parity-class rows of the OCCUPIED voxels (what the step
+      runs since round 5; effective FLOP = 2 x rows x 144 x 2048, the rows incl. the class padding);
+    * heads1_*: the largest 1 x 1 convolution (all heads' first layer: [n, 984] x [984, 1920]);
+    * conv3_dense_*: conv3 160 -> 256 on the dense 32^3 grid -- NOT in the training step any more (sparse conv3), kept
+      as the engine's large-shape reference (the shapes the round-4/5 fractions were quoted on)."""
     L, st, p = mf._lib.lib(), mf._lib.stream_ptr, (lambda t: t.data_ptr())
     dev, bf = wl.device, torch.bfloat16
     out = {}
-    for name, Cin, Cout, D in (("conv3", 160, 256, 32), ("conv4", 256, 512, 16)):
+
+    def rec(key, kernel, fn, flop, shape, **extra):
+        ms = time_kernel_live(fn, 10)
+        tf = flop / (ms * 1e-3) / 1e12
+        out[key] = dict(kernel=kernel, bound="mfma", achieved=round(tf, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), flop_per_launch=flop, avg_launch_ms=round(ms, 5),
+                        shape=shape, **extra)
+
+    for name, key, Cin, Cout, D in (("conv3", "conv3_dense", 160, 256, 32), ("conv4", "conv4", 256, 512, 16)):
         Do = D // 2
         flop = 2.0 * B * Do ** 3 * Cout * 64 * Cin
         x = torch.randn(B, D ** 3, Cin, device=dev).to(bf)
@@ -572,18 +593,60 @@ def roofline_bf16_kernels(wl, B=16):
         dW = torch.empty_like(W)
         split = L.mf_conv3d_k4s2_bf16_wgrad_default_split(B, Cin, Cout, D)
         ws = torch.empty(L.mf_conv3d_k4s2_bf16_wgrad_workspace_bytes(Cin, Cout, split), dtype=torch.uint8, device=dev)
-        runs = dict(
-            fwd=lambda: L.mf_conv3d_k4s2_bf16_fwd(p(x), p(wt), None, p(y), B, Cin, Cout, D, 1, 0, st()),
-            dgrad=lambda: L.mf_conv3d_k4s2_bf16_dgrad(p(dy), p(wd), p(dx), B, Cin, Cout, D, 0, 0, st()),
-            wgrad=lambda: L.mf_conv3d_k4s2_bf16_wgrad(p(dy), p(x), p(dW), p(ws), B, Cin, Cout, D, Cin, 0, split, st()))
-        for kind, fn in runs.items():
-            ms = time_kernel_live(fn, 10)
-            tf = flop / (ms * 1e-3) / 1e12
-            out[f"{name}_{kind}"] = dict(kernel={"fwd": "k_gemm_nt_bf16<conv forward>", "dgrad": "k_gemm_nt_bf16<conv dgrad>",
-                                                 "wgrad": "k_gemm_tn_bf16 (+ k_wgrad_finish)"}[kind], bound="mfma",
-                                         achieved=round(tf, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                                         frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), flop_per_launch=flop,
-                                         avg_launch_ms=round(ms, 5), shape=dict(B=B, Cin=Cin, Cout=Cout, D=D))
+        nws = L.mf_conv3d_bf16_fwd_workspace_bytes(B, Cin, Cout, D, 4, 2, 1, 1)
+        fws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+        shape = dict(B=B, Cin=Cin, Cout=Cout, D=D)
+        rec(f"{key}_fwd", "k_gemm_nt_bf16_pp<conv forward>" + (" split-K + k_splitk_finish" if nws else ""),
+            lambda: L.mf_conv3d_bf16_fwd_ws(p(x), p(wt), None, p(y), p(fws), nws, B, Cin, Cout, D, 4, 2, 1, 1, 1, 0, Cout, st()),
+            flop, shape, splitk_workspace_mb=round(nws / 2 ** 20, 1))
+        rec(f"{key}_dgrad", "k_gemm_nt_bf16_pp<conv dgrad>" if Cin >= 192 else "k_gemm_nt_bf16<conv dgrad> (N = 160: 128 x 128 tile)",
+            lambda: L.mf_conv3d_k4s2_bf16_dgrad(p(dy), p(wd), p(dx), B, Cin, Cout, D, 0, 0, st()), flop, shape)
+        rec(f"{key}_wgrad", "k_gemm_tn_bf16 (+ k_wgrad_finish)",
+            lambda: L.mf_conv3d_k4s2_bf16_wgrad(p(dy), p(x), p(dW), p(ws), B, Cin, Cout, D, Cin, 0, split, st()), flop, shape)
+        del x, dy, y, dx, ws, fws
+    # the heads' first layer
+    n, K, N = B * 1000, 984, 1920
+    A = torch.randn(n, K, device=dev).to(bf)
+    Wl = (torch.randn(N, K, device=dev) / K ** 0.5).to(bf)
+    Wlt = Wl.t().contiguous()
+    yl = torch.empty(n, N, dtype=bf, device=dev)
+    dA = torch.empty(n, K, dtype=bf, device=dev)
+    dWl = torch.empty(N, K, device=dev)
+    wsl = torch.empty(4 * N * K, device=dev)
+    flop = 2.0 * n * K * N
+    shape = dict(M=n, K=K, N=N)
+    rec("heads1_fwd", "k_gemm_nt_bf16_pp<rows>", lambda: L.mf_linear_bf16(p(A), 0, K, p(Wl), 0, K, None, 0, p(yl), 0, N, n, N, K, 1, 1, 0, 0, st()), flop, shape)
+    rec("heads1_dgrad", "k_gemm_nt_bf16_pp<rows>", lambda: L.mf_linear_bf16(p(yl), 0, N, p(Wlt), 0, N, None, 0, p(dA), 0, K, n, K, N, 1, 0, 0, 0, st()), flop, shape)
+    rec("heads1_wgrad", "k_gemm_tn_bf16 (+ k_wgrad_finish), split 4", lambda: L.mf_linear_wgrad_bf16(p(yl), 0, N, p(A), 0, K, p(dWl), 0, K, p(wsl), n, N, K, 1, 4, st()), flop, shape)
+    del A, yl, dA, wsl
+    # conv3 on the compact rows of the occupied voxels (clustered surface points as the model sees them)
+    import ctypes
+    P, Cs, Cout, D = 1000, 144, 256, 32
+    n = B * P
+    torch.manual_seed(5)
+    u = torch.rand(n, 2, device=dev) * 2 - 1
+    pts = torch.stack([16 + 9 * u[:, 0], 16 + 9 * u[:, 1], 16 - 8 * torch.sqrt((1 - (u ** 2).sum(1) / 2).clamp(min=0))], 1).contiguous()
+    bi = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(P)
+    wsb = torch.empty(L.mf_sparse_conv3_bf16_workspace_bytes(n, B, D), dtype=torch.uint8, device=dev)
+    mf._lib.check(L.mf_sparse_conv3_bf16_index(p(pts), p(bi), n, B, D, p(wsb), st()), "index")
+    tabs = (ctypes.c_int64 * 7)()
+    L.mf_sparse_conv3_bf16_tables(p(wsb), n, B, D, tabs)
+    t_group, t_range = int(tabs[0]), int(tabs[1])
+    Mp, N8 = int(L.mf_sparse_conv3_bf16_max_rows(n)), 8 * Cout
+    off = t_range - p(wsb)  # the 9 class offsets live inside the workspace tensor
+    rows = int(wsb[off:off + 36].view(torch.int32)[8])  # rows incl. the padding of each class to a multiple of 128
+    A = torch.randn(Mp, Cs, device=dev).to(bf)
+    Wp = (torch.randn(8, N8, Cs, device=dev) / Cs ** 0.5).to(bf)
+    Wq = Wp.transpose(1, 2).contiguous()
+    C = torch.empty(Mp, N8, dtype=bf, device=dev)
+    dAr = torch.empty(Mp, Cs, dtype=bf, device=dev)
+    dWp = torch.empty(8, N8, Cs, device=dev)
+    flop = 2.0 * rows * Cs * N8
+    shape = dict(B=B, P=P, rows=rows, K=Cs, N=N8)
+    rec("sparse_conv3_fwd", "k_gemm_nt_bf16<rows + tile_group>", lambda: L.mf_linear_bf16_tiles(p(A), Cs, p(Wp), N8 * Cs, Cs, t_group, p(C), N8, Mp, N8, Cs, 0, st()), flop, shape,
+        note="K = 144: 2.25 K-tiles per output tile -- bound by writing C [rows, 2048] bf16, not by the MFMA pipe")
+    rec("sparse_conv3_dgrad", "k_gemm_nt_bf16<rows + tile_group>", lambda: L.mf_linear_bf16_tiles(p(C), N8, p(Wq), Cs * N8, N8, t_group, p(dAr), Cs, Mp, Cs, N8, 0, st()), flop, shape)
+    rec("sparse_conv3_wgrad", "k_gemm_tn_bf16<m_range>", lambda: L.mf_linear_wgrad_bf16_ranges(p(C), N8, p(A), Cs, p(dWp), N8 * Cs, Cs, t_range, 8, N8, Cs, st()), flop, shape)
     return out
 
 
@@ -754,6 +817,9 @@ def dry_run_cpu(args, world, rank):
 
 
 T_START = time.perf_counter()
+# the stock 2-D backbone's MIOpen solver choices for the bench's shapes, found once on an MI355X and shipped as a
+# find-db (morefusion_amd/miopen_cache.py): without it the un-timed search costs ~100 s of wall per bench run
+miopen_cache.enable()
 
 
 def main():
@@ -878,7 +944,7 @@ def main():
             out["train_objects_per_s"] = tr.get("train_objects_per_s")
             out["training"] = tr
             lap("extra_training")
-            if time.perf_counter() - T_START < 75.0:  # the same step replayed from hipGraphs (--graph), time permitting
+            if time.perf_counter() - T_START < 150.0:  # the same step replayed from hipGraphs (--graph), time permitting
                 tg = extra_training(graph=True)
                 out["train_objects_per_s_hipgraph"] = tg.get("train_objects_per_s")
                 out["training_hipgraph"] = tg

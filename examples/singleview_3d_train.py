@@ -30,7 +30,9 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import morefusion_amd as morefusion  # noqa: E402
-from morefusion_amd import parallel  # noqa: E402
+from morefusion_amd import miopen_cache, parallel  # noqa: E402
+
+miopen_cache.enable()  # shipped MIOpen solver choices for the stock 2-D backbone's shapes (no search on a fresh box)
 from morefusion_amd.contrib.singleview_3d.models import Model, PitchTableModels  # noqa: E402
 
 

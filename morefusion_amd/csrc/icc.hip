@@ -466,64 +466,11 @@ __device__ __forceinline__ void icc_step_gather_fused(const IccArgs &a, int par,
   __syncthreads();
 }
 
-// sv: the gathered sums; st: (q, t, m, v) before the step.  Returns the pose to use next
-// (R|t, 12 floats) and, for mode 1, the state after the step.
-__device__ __forceinline__ void icc_step_apply(const float *sv, float S_t, const float *st,
-                                               const IccStepArgs &sp, float *Rt_out, float *st_out,
-                                               float &loss, float *gq, float *gt) {
-  const float RN = sv[0], S_in = sv[1], PN = sv[2];
-  const float reward = RN / S_t, penalty = PN / S_in;
-  loss = sv[51] != 0.0f ? __builtin_nanf("") : penalty - reward;
-  const float c0 = 1.0f / S_t, c1 = 1.0f / S_in, c2 = PN / (S_in * S_in);
-  float gR[9];
-#pragma unroll
-  for (int d = 0; d < 3; ++d)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int i = 4 * d + c;
-      const float G = ((c0 * sv[3 + i] - c1 * sv[15 + i]) + c2 * sv[27 + i]) - c1 * sv[39 + i];
-      if (c < 3) gR[3 * d + c] = G; else gt[d] = G;
-    }
-  float qq[4], tt[3];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) qq[i] = st[i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) tt[i] = st[4 + i];
-  quat_backward(qq, gR, gq);
-  if (sv[51] != 0.0f) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) gq[i] = loss;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) gt[i] = loss;
-  }
-  if (sp.mode == 1) {
-    // chainer.optimizers.Adam (v7) update rule in float32
-    const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-8f;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const float gi = i < 4 ? gq[i] : gt[i - 4];
-      float mm = st[7 + i], vv = st[14 + i];
-      mm += omb1 * (gi - mm);
-      vv += omb2 * (gi * gi - vv);
-      st_out[7 + i] = mm;
-      st_out[14 + i] = vv;
-      const float upd = (i < 4 ? sp.aq : sp.at) * mm / (sqrtf(vv) + eps);
-      if (i < 4) qq[i] -= upd; else tt[i - 4] -= upd;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) st_out[i] = qq[i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) st_out[4 + i] = tt[i];
-  quat_to_R(qq, Rt_out);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) Rt_out[9 + i] = tt[i];
-}
-
-// The same step spread over the 16 lanes `c` of a lane group (one object per group): the twelve gradient
-// components, the seven Adam updates and the rotation are evaluated by different lanes with the expressions of
-// icc_step_apply -> the same bits, a third of its dependent instruction chain (one lane's chain was 1.5 us of
-// every iteration).  xg: kStepLaneWords floats of LDS scratch owned by the group; the state after the step is left
+// The optimiser step of one object spread over the 16 lanes `c` of a lane group (sv: the gathered sums; st: (q, t,
+// m, v) before the step): the twelve gradient components, the seven Adam updates (chainer.optimizers.Adam v7 rule in
+// float32) and the rotation are evaluated by different lanes -- a third of the dependent instruction chain of one
+// lane doing all of it (that chain was 1.5 us of every iteration; the one-lane form is gone, the bits are its).
+// xg: kStepLaneWords floats of LDS scratch owned by the group; the state after the step is left
 // in xg[12 ..] (q, t, m, v); every lane returns R|t and the loss, and the gradients in (gq, gt).
 // Call from wave-uniform control flow (contains wave-level LDS hand-overs).
 constexpr int kStepLaneWords = 12 + kStateFloats;
@@ -2664,8 +2611,12 @@ void launch_iteration(const IccArgs &a, IccStepArgs sp, int NB, int k, hipStream
   const size_t lds_tile = (size_t)((D + 1) / 2) * D * 2 * sizeof(uint32_t);  // 4 KB at D = 32
   const size_t lds_rows2 = (size_t)a.max_ns * (kAccThreads / 16) * 13 * sizeof(float);  // 53 KB at 32, 106 KB at 64 objects
   if (a.ne_binary) {
-    hipLaunchKernelGGL(k_icc_fused, dim3(D * kHalves, a.O), dim3(kTileThreads),
-                       4 * fused_tile_words(D) * sizeof(uint32_t) + lds_rows2, stream, a, par);
+    // MF_ICC_LDS_PAD (bytes, tuning): unused dynamic LDS on top -- from ~48 KB on only ONE workgroup of k_icc_fused
+    // fits a CU (half the resident waves: the experiment of leaving wave slots to a network running beside it)
+    static const size_t pad = getenv("MF_ICC_LDS_PAD") ? (size_t)atoi(getenv("MF_ICC_LDS_PAD")) : 0;
+    const size_t lds = 4 * fused_tile_words(D) * sizeof(uint32_t) + lds_rows2 + pad;
+    if (pad) mf::allow_big_lds((const void *)k_icc_fused, (int)lds);
+    hipLaunchKernelGGL(k_icc_fused, dim3(D * kHalves, a.O), dim3(kTileThreads), lds, stream, a, par);
     return;
   }
   hipLaunchKernelGGL(k_icc_tile, dim3(D * kHalves, 2 * a.O), dim3(kTileThreads), lds_tile, stream, a, par);

@@ -13,6 +13,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    from morefusion_amd import miopen_cache
+    miopen_cache.enable()  # stock-backbone solver choices shipped with the package: no MIOpen search per test process
 
 
 def golden(name):
