@@ -11,10 +11,12 @@ The reference all-reduces gradients with ChainerMN `pure_nccl` (train.py:231,344
 torch DDP over RCCL (bucketed all-reduce overlapped with backward).  Under bf16 autocast the 3-D CNN, the 1x1
 convolutions, voxelization and sampling run on the hand-written bf16 kernels (models/bf16_ops.py), the 2-D backbone
 on MIOpen, the loss on its fp32 HIP op.
-``--graph``: the step's device work is captured into TWO hipGraphs after three eager steps and replayed -- forward +
-backward (+ the copy of every gradient into one flat bucket), then Adam; between them, eager, ONE all-reduce of the
-bucket over RCCL when the run is data-parallel (``--ddp`` / ``--gpus N``: parallel.DataParallelStep -- torch's DDP
-cannot be captured on this stack).  The host keeps what the reference does on the host (the NumPy-RNG point
+``--graph``: the step's device work is captured into TWO hipGraphs and replayed -- forward + backward (+ the copy of
+every gradient into one flat bucket), then Adam; between them, eager, the all-reduce of the bucket over RCCL (in
+``--exchange-chunks`` pieces) when the run is data-parallel (``--ddp`` / ``--gpus N``: parallel.DataParallelStep --
+torch's DDP cannot be captured on this stack).  The capture comes FIRST: three eager warm-up steps without the
+exchange, their effect on parameters / BatchNorm statistics / Adam's state undone, the capture, and only then the
+process's first collective (no ProcessGroupNCCL watchdog polls events during the capture); every step is a replay.  The host keeps what the reference does on the host (the NumPy-RNG point
 selection and CAD subsample).  The eager step is launch-bound for a fifth of its time (~1100 launches, 22.1 ms for
 17.7 ms of kernels): 742 -> 841 objects/s on one MI355X (profiles/r04_train_1gpu_bf16_hipgraph_step.json).
 """
@@ -75,6 +77,9 @@ def main():
                     help="capture forward + backward + Adam of one step into a hipGraph after --graph-warmup eager "
                          "steps and replay it (single process; the host keeps the point selection and the CAD subsample)")
     ap.add_argument("--graph-warmup", type=int, default=3)
+    ap.add_argument("--exchange-chunks", type=int, default=4,
+                    help="--graph --ddp: the flat gradient bucket is all-reduced in this many chunks (async, awaited "
+                         "in front of the update)")
     ap.add_argument("--no-dropout", action="store_true",
                     help="PSPNet's dropouts off (pspnet.py:24-30): makes an eager and a --graph run comparable step by step")
     ap.add_argument("--json", default=None, help="write a one-line JSON record of the run to this path")
@@ -118,7 +123,8 @@ def main():
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.no_bf16):
             return net(**kw)
 
-    dp = parallel.DataParallelStep(model.parameters(), optimizer, autocast_loss, exchange=use_ddp) if args.graph else None
+    dp = parallel.DataParallelStep(model.parameters(), optimizer, autocast_loss, exchange=use_ddp,
+                                   chunks=args.exchange_chunks) if args.graph else None
 
     per_rank = max(1, args.global_batch // world)
     np.random.seed(1234 + rank)  # per-rank point / CAD subsampling streams
@@ -157,20 +163,19 @@ def main():
         t0 = time.perf_counter()
         if not args.graph:
             loss = eager_step(inputs)
-        elif step < args.graph_warmup:
-            # torch's capture recipe: the eager warm-up steps run on the side stream the capture will use, so that
-            # the gradient accumulators and the optimizer state are born there (same three parts as the replay:
-            # forward + backward, flat gradient all-reduce, update)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                loss = dp.step(device_inputs(inputs))
-            torch.cuda.current_stream().wait_stream(side)
         else:
             new = device_inputs(inputs)
-            if dp.graph_fb is None:
-                # capture: the step's device work on static tensors (gradients are allocated inside the graph's pool,
-                # Adam is capturable); MIOpen's solvers were chosen by the eager steps
-                dp.capture(new, side)
+            if step == 0:
+                # Capture FIRST, exchange afterwards (parallel.DataParallelStep.capture_before_exchange): the eager
+                # warm-up steps of torch's capture recipe run on the side stream WITHOUT the gradient exchange --
+                # they only bring the gradient accumulators, Adam's state and MIOpen's solver choices into being --,
+                # parameters / BatchNorm statistics / optimiser state go back to their initial values, the two
+                # graphs are captured, and only then does this process issue its first collective: no
+                # ProcessGroupNCCL watchdog has an event to poll while the capture runs.  A failed capture leaves
+                # the step eager (dp.capture_error).
+                captured = dp.capture_before_exchange(new, side, warmup=args.graph_warmup, buffers=model.buffers())
+                if rank == 0:
+                    print("hipGraph capture:", "ok" if captured else f"FAILED, eager steps ({dp.capture_error})", flush=True)
             loss = dp.replay(new)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -185,15 +190,17 @@ def main():
         if rank == 0:
             print(f"step {step}: loss {loss_avg:.5f}  {per_rank * world / dt:.1f} objects/s "
                   f"(global batch {per_rank * world}, {world} GPU(s))"
-                  + ("  [hipGraph replay]" if args.graph and step > args.graph_warmup else
-                     "  [capture]" if args.graph and step == args.graph_warmup else ""), flush=True)
+                  + ("  [hipGraph replay]" if args.graph and dp.graph_fb is not None and step > 0 else
+                     "  [warm-up + capture + replay]" if args.graph and step == 0 else ""), flush=True)
     if rank == 0 and args.json:
-        skip = args.graph_warmup + 1 if args.graph else 2  # the first steps carry MIOpen's algorithm search / the capture
+        skip = 2  # the first steps carry MIOpen's algorithm search / the warm-up and the capture
         steady = rates[skip:] or rates
         rec = {"what": "singleview_3d training step (BASELINE config 5 on this many GPUs), synthetic batch",
                "n_gpus": world, "global_batch": per_rank * world, "dtype": "f32" if args.no_bf16 else "bf16 autocast",
                "ddp": bool(use_ddp), "backend": "nccl (RCCL)" if use_ddp else None, "steps": args.steps,
-               "hipgraph_step": bool(args.graph),
+               "hipgraph_step": bool(args.graph and dp.graph_fb is not None),
+               "hipgraph_capture_error": dp.capture_error if args.graph else None,
+               "exchange_chunks": len(dp.chunk_flat) if args.graph else None,
                "objects_per_s_steady_mean": round(float(np.mean(steady)), 2),
                "objects_per_s_per_step": [round(r, 2) for r in rates], "loss_per_step": [round(x, 5) for x in losses]}
         with open(args.json, "w") as f:

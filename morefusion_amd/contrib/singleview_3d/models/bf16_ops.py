@@ -48,27 +48,42 @@ def relu_mask(y, dy):
     return dz
 
 
-# Packed (cast + permuted) bf16 weight operands, keyed by the weight's storage and in-place version: an eager
-# inference pass (``--dtype bf16``: constant weights) packs once instead of once per call; a training step misses
-# once per optimiser step, as before.  Never used while a stream is being captured (the graph must hold the pack
-# kernels: the weights change between replays).  Bounded: cleared when it outgrows its cap.
+# Packed (cast + permuted) bf16 weight operands, keyed by the weight's storage, in-place version and the pack epoch: an
+# eager inference pass (``--dtype bf16``: constant weights) packs once instead of once per call; a training step
+# misses once per optimiser step, as before.  Never used while a stream is being captured (the graph must hold the
+# pack kernels: the weights change between replays).
+# A hipGraph REPLAY that contains an optimiser step changes the parameters on the device WITHOUT bumping
+# ``_version``: whoever replays such a graph calls ``invalidate_packs()`` (parallel.DataParallelStep.replay, the
+# ``--graph`` training loop) -- the epoch in the key makes every older entry unreachable, an eager forward between
+# replayed steps re-packs from the current weights.  One entry per (weight, kind): a miss drops the weight's older
+# versions (hundreds of MB of stale conv3 / conv4 packs would otherwise pile up during eager training).
 _PACKS = {}
 _PACKS_CAP = 256
+_PACK_EPOCH = [0]
+
+
+def invalidate_packs():
+    """Forget every cached weight pack (call after the parameters changed behind autograd's back: a graph replay with
+    an optimiser step, ``load_state_dict(assign=True)`` on captured storage, a manual ``copy_`` under ``no_grad`` bumps
+    the version itself and needs nothing)."""
+    _PACK_EPOCH[0] += 1
+    _PACKS.clear()
 
 
 def _cached_pack(weight, key, build):
     """``weight`` must be the module's own Parameter for a hit: the entry holds a weak reference to it and is valid only
-    for that very object at that in-place version (an address alone can be reused by another tensor -- e.g. the
-    per-call ``torch.cat`` of the three heads' first layers lands at the same address every step)."""
+    for that very object at that in-place version and pack epoch (an address alone can be reused by another tensor --
+    e.g. the per-call ``torch.cat`` of the three heads' first layers lands at the same address every step)."""
     if not isinstance(weight, torch.nn.Parameter) or (weight.is_cuda and torch.cuda.is_current_stream_capturing()):
         return build()
-    key = (id(weight), weight._version) + key
-    hit = _PACKS.get(key)
-    if hit is None or hit[0]() is not weight:
+    slot = (id(weight),) + key
+    hit = _PACKS.get(slot)
+    stamp = (weight._version, _PACK_EPOCH[0])
+    if hit is None or hit[0]() is not weight or hit[1] != stamp:
         if len(_PACKS) >= _PACKS_CAP:
             _PACKS.clear()
-        hit = _PACKS[key] = (weakref.ref(weight), build())
-    return hit[1]
+        hit = _PACKS[slot] = (weakref.ref(weight), stamp, build())  # (replaces the slot's older version)
+    return hit[2]
 
 
 class Conv3d(torch.autograd.Function):

@@ -163,29 +163,68 @@ class DataParallelStep:
 
     * phase 1 (capturable): forward, backward, then every gradient is copied into ONE flat float32 bucket
       (a few multi-tensor copies);
-    * exchange (always eager): one ``all_reduce`` of the bucket over the process group -- RCCL over xGMI on the GPUs
+    * exchange (always eager): the bucket's all-reduce over the process group -- RCCL over xGMI on the GPUs
       (124 MB fp32 for the pose network: ~1.4 ms ring lower bound over one xGMI link pair), gloo in the
       CPU tests -- followed by the division by the world size inside phase 2;
     * phase 2 (capturable): the optimiser step on the bucket's views (``param.grad`` aliases its slice).
 
-    What is lost against DDP is the overlap of the exchange with the backward pass; what is gained is the replay of
-    the ~1100 launches of the step (22.1 -> 19.0 ms on one MI355X).  ``loss_fn(**inputs)`` runs the module's forward
-    and returns the scalar loss; ``group=None`` with an initialised default group reduces over it, without one the
-    exchange is skipped (single process)."""
+    ``chunks`` > 1 cuts the bucket into that many contiguous ranges of whole parameters, each all-reduced on its own
+    (``async_op``), all awaited in front of the update.  In the EAGER step the chunks are issued from autograd hooks as
+    the backward pass completes them -- the last layers' chunk first, while the earlier layers are still being
+    differentiated (what DDP's buckets do) --; a replayed step has no hooks and issues them back to back.  The
+    result is the same rank mean either way (tests/test_training_ddp_gloo.py).
 
-    def __init__(self, params, optimizer, loss_fn, group=None, exchange=None):
+    The capture must not run while ProcessGroupNCCL's watchdog thread still polls the events of earlier eager
+    collectives (any ``hipEventQuery`` of another thread during a capture is an error in the default mode).
+    ``capture_before_exchange`` makes that impossible by construction: the warm-up steps torch's capture recipe
+    asks for run WITHOUT the exchange, parameters / buffers / optimiser state are put back to their initial values,
+    the graphs are captured, and only then does the process issue its first collective.  A capture that fails for any
+    reason leaves the object in eager mode (``replay`` == ``step``, ``capture_error`` says why).
+
+    What is lost against DDP is the overlap of the exchange with the backward pass of a REPLAYED step; what is gained
+    is the replay of the ~750 launches of the step.  ``loss_fn(**inputs)`` runs the module's forward and returns the
+    scalar loss; ``group=None`` with an initialised default group reduces over it, without one the exchange is
+    skipped (single process).  Every trainable parameter must be a contiguous float32 tensor on one device (the
+    bucket is one fp32 array; its views become ``param.grad``).  A parameter the loss does not reach contributes a
+    ZERO gradient and is stepped like the others (Adam: its moments decay) -- under DDP's default such a parameter
+    keeps ``grad = None`` and is skipped; the pose network has none."""
+
+    def __init__(self, params, optimizer, loss_fn, group=None, exchange=None, chunks=1):
         self.params = [p for p in params if p.requires_grad]
+        assert self.params, "DataParallelStep: no trainable parameter"
+        dev = self.params[0].device
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev or not p.is_contiguous():
+                raise TypeError("DataParallelStep: every trainable parameter must be a contiguous float32 tensor on "
+                                f"one device (got {p.dtype}, {p.device}, contiguous={p.is_contiguous()})")
         self.optimizer = optimizer
         self.loss_fn = loss_fn
         self.group = group
         self.exchange = (dist.is_available() and dist.is_initialized()) if exchange is None else exchange
         self.world = dist.get_world_size(group) if self.exchange else 1
-        dev, n = self.params[0].device, sum(p.numel() for p in self.params)
+        n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.views, off = [], 0
+        self.views, off, offs = [], 0, []
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            offs.append(off)
             off += p.numel()
+        # chunk c = parameters [first[c], first[c + 1]): contiguous in the bucket, cut nearest to equal sizes
+        chunks = max(1, min(int(chunks), len(self.params)))
+        first, target = [0], n / chunks
+        for i, o in enumerate(offs):
+            if len(first) < chunks and i > first[-1] and o >= target * len(first):
+                first.append(i)
+        first.append(len(self.params))
+        self.chunk_first = first
+        self.chunk_flat = [self.flat[offs[a]:(offs[b] if b < len(offs) else n)] for a, b in zip(first[:-1], first[1:])]
+        self._chunk_of = [c for c, (a, b) in enumerate(zip(first[:-1], first[1:])) for _ in range(b - a)]
+        self._pending = [0] * len(self.chunk_flat)
+        self._works = []
+        self._hooks = []
+        self._in_hooked_backward = False
+        self.exchanges = 0  # eager collectives issued so far (capture_before_exchange insists on 0)
+        self.capture_error = None
         self.graph_fb = self.graph_opt = self.static = self.static_loss = None
 
     # -- the three parts of a step ------------------------------------------------------------------
@@ -203,9 +242,21 @@ class DataParallelStep:
             if p.grad is None:  # a parameter the loss does not reach contributes zeros (DDP's find_unused_parameters)
                 v.zero_()
 
+    def _reduce_chunk(self, c):
+        self.exchanges += 1
+        self._works.append(dist.all_reduce(self.chunk_flat[c], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def _all_reduce(self):
+        """Every chunk not yet in flight, then wait for all of them (``work.wait()``: the bucket is final on the
+        current stream / in memory before the update reads it)."""
         if self.exchange:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            for c in range(len(self.chunk_flat)):
+                if self._pending[c] >= 0:
+                    self._reduce_chunk(c)
+            for w in self._works:
+                w.wait()
+        self._works = []
+        self._pending = [0] * len(self.chunk_flat)
 
     def _update(self):
         if self.world > 1:
@@ -215,43 +266,134 @@ class DataParallelStep:
         self.optimizer.step()
 
     # -- eager ----------------------------------------------------------------------------------------
+    def _forward_backward_hooked(self, inputs):
+        """The eager phase 1 with the exchange issued chunk by chunk from the backward pass: a hook per parameter
+        copies its finished gradient into the bucket; the hook that completes a chunk starts that chunk's all-reduce
+        (the chunk of the LAST layers completes first).  Parameters the loss never reaches fire no hook: their views
+        are zeroed and their chunks issued by ``_all_reduce`` behind the backward pass."""
+        if not self._hooks:
+            def hook_for(i):
+                def hook(p):
+                    if not self._in_hooked_backward:
+                        return
+                    self.views[i].copy_(p.grad)
+                    self._seen[i] = True
+                    c = self._chunk_of[i]
+                    self._pending[c] -= 1
+                    if self._pending[c] == 0:
+                        self._pending[c] = -1  # in flight
+                        self._reduce_chunk(c)
+                return hook
+            self._hooks = [p.register_post_accumulate_grad_hook(hook_for(i)) for i, p in enumerate(self.params)]
+        self.optimizer.zero_grad(set_to_none=True)
+        self._seen = [False] * len(self.params)
+        self._pending = [b - a for a, b in zip(self.chunk_first[:-1], self.chunk_first[1:])]
+        self._in_hooked_backward = True
+        try:
+            loss = self.loss_fn(**inputs)
+            loss.backward()
+        finally:
+            self._in_hooked_backward = False
+        for i, seen in enumerate(self._seen):
+            if not seen:
+                self.views[i].zero_()
+        return loss
+
     def step(self, inputs):
-        loss = self._forward_backward(inputs)
+        if self.exchange and len(self.chunk_flat) > 1:
+            loss = self._forward_backward_hooked(inputs)
+        else:
+            loss = self._forward_backward(inputs)
         self._all_reduce()
         self._update()
         return loss
 
     # -- captured ---------------------------------------------------------------------------------------
-    def capture(self, inputs, stream):
+    def capture_before_exchange(self, inputs, stream, warmup=3, buffers=()):
+        """The deterministic capture: ``warmup`` eager steps on ``stream`` with the exchange switched OFF (they only
+        let the gradient accumulators, the optimiser state and the library's solver choices come into being on the
+        capture stream), parameters, ``buffers`` (e.g. ``module.buffers()``: BatchNorm statistics) and the optimiser
+        state put back, then the capture -- all before this object has issued a single collective, so no watchdog
+        thread has an event to poll.  Raises if an exchange has already happened.  Returns True when the step is
+        captured, False when it stays eager (``capture_error``)."""
+        if self.exchanges:
+            raise RuntimeError("DataParallelStep.capture_before_exchange: an eager all-reduce has already been issued; "
+                               "capture first, exchange afterwards")
+        buffers = list(buffers)
+        saved_p = [p.detach().clone() for p in self.params]
+        saved_b = [b.detach().clone() for b in buffers]
+        exchange, self.exchange = self.exchange, False
+        world, self.world = self.world, 1
+        try:
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                for _ in range(warmup):
+                    self.step(inputs)
+            torch.cuda.current_stream().wait_stream(stream)
+        finally:
+            self.exchange, self.world = exchange, world
+        with torch.no_grad():
+            torch._foreach_copy_(self.params, saved_p)
+            if buffers:
+                torch._foreach_copy_(buffers, saved_b)
+            for st in self.optimizer.state.values():  # in place: the captured update reads these very tensors
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        torch.cuda.synchronize()
+        return self.capture(inputs, stream)
+
+    def capture(self, inputs, stream, allow_after_exchange=False):
         """Capture phase 1 and phase 2 on ``stream`` (the side stream the eager warm-up steps ran on, torch's capture
         recipe; the optimiser must be ``capturable``).  ``inputs``: dict of device tensors; their clones become the
-        graphs' static inputs."""
+        graphs' static inputs.  After eager exchanges (``allow_after_exchange``) the capture runs in the relaxed error
+        mode behind a pause of three watchdog periods: ProcessGroupNCCL's watchdog thread polls the events of earlier
+        all-reduces (hipEventQuery every 100 ms until it has seen them complete) and any such call of any thread
+        during a capture is an error in the stricter modes -- timing-based, kept for callers that cannot capture first;
+        ``capture_before_exchange`` is the form without that race.  Any exception during the capture leaves the object
+        in eager mode."""
+        if self.exchanges and not allow_after_exchange:
+            raise RuntimeError("DataParallelStep.capture: eager all-reduces were issued before the capture "
+                               "(use capture_before_exchange, or allow_after_exchange=True for the timing-based form)")
         self.static = {k: v.clone() for k, v in inputs.items()}
         self.optimizer.zero_grad(set_to_none=True)
-        # ProcessGroupNCCL's watchdog THREAD polls the events of the eager all-reduces (hipEventQuery): under the
-        # default global capture mode any such call from any thread while this thread captures is an error and the
-        # process aborts (seen at world size 1 when a warm-up step's all-reduce was still being reaped).  The exchange
-        # is never part of a capture here.
-        # Thread-local mode was not enough on every run (one abort in six processes: the watchdog's query landed inside
-        # the capture and was still refused), so: relaxed mode -- no call of any thread is checked; nothing this thread
-        # does while capturing is unsafe (allocations come from the graph's pool) -- and the watchdog gets time to
-        # reap the finished all-reduces (its poll period is 100 ms) before the capture begins.
         torch.cuda.synchronize()
-        if self.exchange:
+        mode = {}
+        if self.exchanges:
             import time
             time.sleep(0.3)
-        mode = dict(capture_error_mode="relaxed")
-        self.graph_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fb, stream=stream, **mode):
-            self.static_loss = self._forward_backward(self.static)
-        self.graph_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_opt, stream=stream, pool=self.graph_fb.pool(), **mode):
-            self._update()
+            mode = dict(capture_error_mode="relaxed")
+        try:
+            graph_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_fb, stream=stream, **mode):
+                static_loss = self._forward_backward(self.static)
+            graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_opt, stream=stream, pool=graph_fb.pool(), **mode):
+                self._update()
+        except Exception as e:  # noqa: BLE001 -- whatever it was, the eager step still works
+            self.capture_error = repr(e)
+            self.graph_fb = self.graph_opt = None
+            torch.cuda.synchronize()
+            return False
+        self.graph_fb, self.graph_opt, self.static_loss = graph_fb, graph_opt, static_loss
+        return True
 
     def replay(self, inputs):
+        if self.graph_fb is None:  # not captured (or the capture failed): the eager step
+            return self.step(inputs)
         for k, v in inputs.items():
             self.static[k].copy_(v)
         self.graph_fb.replay()
         self._all_reduce()
         self.graph_opt.replay()
+        _invalidate_weight_packs()  # the parameters changed on the device without a version bump
         return self.static_loss
+
+
+def _invalidate_weight_packs():
+    """Cached bf16 weight packs of the hand-written layers are keyed by the parameters' in-place version, which a
+    graph replay does not bump (contrib/singleview_3d/models/bf16_ops.py)."""
+    import sys
+    mod = sys.modules.get("morefusion_amd.contrib.singleview_3d.models.bf16_ops")
+    if mod is not None:
+        mod.invalidate_packs()

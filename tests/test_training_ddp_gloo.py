@@ -115,16 +115,23 @@ def _worker(rank, world, port, out_dir, mode):
             net = torch.nn.parallel.DistributedDataParallel(model)
             loss = _local_step(net, rank)
         else:
-            # parallel.DataParallelStep (round 5): forward + backward, ONE flat gradient all-reduce, update -- the
+            # parallel.DataParallelStep (round 5): forward + backward, the flat gradient bucket all-reduced (whole, or
+            # -- round 6 -- in chunks issued from autograd hooks while the backward pass still runs), update -- the
             # form whose two device phases are captured into hipGraphs on the GPU (`--ddp --graph`)
             from morefusion_amd.parallel import DataParallelStep
             w0 = {n: p.detach().clone() for n, p in model.named_parameters() if n in WATCH}
             opt = torch.optim.SGD(model.parameters(), lr=0.5)
-            dp = DataParallelStep(model.parameters(), opt, lambda **kw: model(**kw))
+            chunks = 5 if mode == "flat_bucket_chunked" else 1
+            dp = DataParallelStep(model.parameters(), opt, lambda **kw: model(**kw), chunks=chunks)
             assert dp.world == 2 and dp.flat.numel() == sum(p.numel() for p in model.parameters())
+            # the chunks tile the bucket: whole parameters each, in order, nothing lost
+            assert len(dp.chunk_flat) == chunks and sum(c.numel() for c in dp.chunk_flat) == dp.flat.numel()
+            assert dp.chunk_first[0] == 0 and dp.chunk_first[-1] == len(dp.params)
             np.random.seed(1234 + rank)
             torch.manual_seed(77 + rank)  # dropout masks
             loss = float(dp.step(_batch(rank)).detach())
+            # chunked: every chunk went out on its own (issued from the backward pass' hooks, the last layers' first)
+            assert dp.exchanges == chunks
             extra["update"] = {n: (w0[n] - p.detach()) / 0.5 for n, p in model.named_parameters() if n in WATCH}
         grads = {n: p.grad.clone() for n, p in model.named_parameters() if n in WATCH}
         torch.save(dict({"loss": loss, "grads": grads}, **extra), os.path.join(out_dir, f"rank{rank}.pt"))
@@ -132,7 +139,7 @@ def _worker(rank, world, port, out_dir, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["ddp", "flat_bucket"])
+@pytest.mark.parametrize("mode", ["ddp", "flat_bucket", "flat_bucket_chunked"])
 def test_ddp_training_step_averages_the_two_ranks_gradients(tmp_path, mode):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), mode), nprocs=2, join=True)
     got = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
@@ -162,7 +169,7 @@ def test_ddp_training_step_averages_the_two_ranks_gradients(tmp_path, mode):
         for r in range(2):
             torch.testing.assert_close(got[r]["grads"][n], mean, rtol=2e-4, atol=1e-7 + 2e-4 * float(mean.abs().max()))
         torch.testing.assert_close(got[0]["grads"][n], got[1]["grads"][n], rtol=0, atol=0)  # identical on both ranks
-        if mode == "flat_bucket":  # ... and the SGD update it drove is that mean, on both ranks
+        if mode.startswith("flat_bucket"):  # ... and the SGD update it drove is that mean, on both ranks
             for r in range(2):
                 torch.testing.assert_close(got[r]["update"][n], mean, rtol=2e-3, atol=1e-6 + 2e-3 * float(mean.abs().max()))
 
@@ -181,3 +188,26 @@ def test_dense_grad_strides_reviews_a_channels_last_strided_1x1_weight_gradient(
     assert not getattr(torch.nn.Conv2d(8, 4, 3).weight, "_backward_hooks", None)  # (only 1 x 1 kernels get one)
     conv(torch.randn(2, 8, 3, 3)).sum().backward()
     assert conv.weight.grad.stride() == conv.weight.stride()
+
+
+def test_data_parallel_step_guards():
+    """parallel.DataParallelStep refuses what its flat fp32 bucket cannot hold, and a capture after an eager exchange
+    (the watchdog race) unless the caller asks for the timing-based form."""
+    import torch
+    from morefusion_amd.parallel import DataParallelStep
+    lin = torch.nn.Linear(4, 3)
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+    dp = DataParallelStep(lin.parameters(), opt, lambda x: lin(x).sum(), exchange=False, chunks=8)
+    assert len(dp.chunk_flat) == 2 and dp.exchanges == 0  # (never more chunks than parameters)
+    w0 = lin.weight.detach().clone()
+    dp.step(dict(x=torch.ones(2, 4)))
+    torch.testing.assert_close(lin.weight, w0 - 0.1 * 2.0 * torch.ones(3, 4))
+    assert dp.replay(dict(x=torch.ones(2, 4))) is not None  # not captured: replay is the eager step
+    half = torch.nn.Linear(4, 3).to(torch.bfloat16)
+    with pytest.raises(TypeError):
+        DataParallelStep(half.parameters(), opt, lambda x: half(x).sum(), exchange=False)
+    dp.exchanges = 1
+    with pytest.raises(RuntimeError):
+        dp.capture_before_exchange(dict(x=torch.ones(2, 4)), None)
+    with pytest.raises(RuntimeError):
+        dp.capture(dict(x=torch.ones(2, 4)), None)
