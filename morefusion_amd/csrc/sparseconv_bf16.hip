@@ -22,7 +22,8 @@
 //             dWp[class] = dYg^T A over the class's row range (k_gemm_tn_bf16 + m_range table) -> scattered into the
 //             framework layout [Cout][160][4][4][4]
 //   the 16 occupancy channels keep the dense engines with Cin = 16 (1 / 10 of the dense arithmetic).
-// Everything is deterministic (fixed summation orders; integer atomics only in the index build).
+// Everything is deterministic: fixed summation orders; the compact rows are handed out by a prefix scan over the
+// voxel index (integer atomics only build the per-voxel point chains, whose sums are taken in point order).
 #include "mf_common.h"
 
 namespace {
@@ -30,11 +31,14 @@ namespace {
 constexpr int kPadRows = 128;
 
 struct ScbWs {  // workspace carve-up (device pointers)
-  int32_t *counts, *head, *link, *rowmap, *rowvox, *class_cnt, *class_fill, *class_off, *tile_group;
+  int32_t *counts, *head, *link, *rowmap, *rowvox, *class_cnt, *blk_cnt, *class_off, *tile_group;
   int64_t max_rows;
 };
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+constexpr int kIdxPerThread = 8;  // voxels per thread of the index kernels
+inline int64_t scb_blocks(int64_t BV) { return (BV + 256 * kIdxPerThread - 1) / (256 * kIdxPerThread); }
 
 inline int64_t scb_max_rows(int64_t n) { return ((n + 8 * (kPadRows - 1) + kPadRows - 1) / kPadRows) * kPadRows; }
 
@@ -49,7 +53,7 @@ inline int64_t scb_carve(void *ws, int64_t n, int B, int D, ScbWs *w) {
   w->rowmap = (int32_t *)take(BV * 4);
   w->rowvox = (int32_t *)take(Mp * 4);
   w->class_cnt = (int32_t *)take(8 * 4);
-  w->class_fill = (int32_t *)take(8 * 4);
+  w->blk_cnt = (int32_t *)take(scb_blocks(BV) * 8 * 4);  // per (index workgroup, class): count, then exclusive prefix
   w->class_off = (int32_t *)take(9 * 4);
   w->tile_group = (int32_t *)take((Mp / 64) * 4);
   w->max_rows = Mp;
@@ -60,8 +64,6 @@ __device__ __forceinline__ int parity_class(int ix, int iy, int iz) {
   return ((ix + 1) & 1) | (((iy + 1) & 1) << 1) | (((iz + 1) & 1) << 2);
 }
 
-constexpr int kIdxPerThread = 8;
-
 __device__ __forceinline__ int voxel_class(const int32_t *counts, int D, int64_t i, int64_t total) {
   if (i >= total || counts[i] <= 0) return -1;
   const int V = D * D * D;
@@ -69,7 +71,13 @@ __device__ __forceinline__ int voxel_class(const int32_t *counts, int D, int64_t
   return parity_class(v / (D * D), (v / D) % D, v % D);
 }
 
-// rows per class (LDS counters, one global atomic per class and workgroup)
+// Row assignment is a DETERMINISTIC prefix scan over the voxel index (round 6; it handed rows out with LDS / global
+// atomicAdd before: the order of the voxels inside a class then changed from launch to launch, and with it the
+// fp32 summation order of conv3's weight gradient -- dW was not bitwise reproducible):
+//   k_scb_count    per (workgroup of 2048 voxels, class): occupied voxels            -> blk_cnt
+//   k_scb_offsets  per class: total, padded class offsets; blk_cnt -> exclusive prefix over the workgroups
+//   k_scb_assign   row = class offset + workgroup prefix + rank of the voxel among the workgroup's voxels of its class
+//                  in increasing voxel index (ballot / popcount)
 __global__ __launch_bounds__(256) void k_scb_count(ScbWs w, int B, int D) {
   __shared__ int s_cnt[8];
   if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
@@ -79,20 +87,40 @@ __global__ __launch_bounds__(256) void k_scb_count(ScbWs w, int B, int D) {
 #pragma unroll
   for (int j = 0; j < kIdxPerThread; ++j) {
     const int cls = voxel_class(w.counts, D, base + j * 256 + threadIdx.x, total);
-    if (cls >= 0) atomicAdd(&s_cnt[cls], 1);
+    if (cls >= 0) atomicAdd(&s_cnt[cls], 1);  // (integer count: the order does not matter)
   }
   __syncthreads();
-  if (threadIdx.x < 8 && s_cnt[threadIdx.x] > 0) atomicAdd(&w.class_cnt[threadIdx.x], s_cnt[threadIdx.x]);
+  if (threadIdx.x < 8) w.blk_cnt[(int64_t)blockIdx.x * 8 + threadIdx.x] = s_cnt[threadIdx.x];
 }
 
-// padded class offsets (the row ranges of the weight-gradient GEMM) and the class of every 64-row block
-__global__ __launch_bounds__(256) void k_scb_offsets(ScbWs w) {
-  __shared__ int s_off[9];
+// class totals + exclusive prefixes over the index workgroups (32 lanes per class: chunks of 32 workgroups, a
+// shuffle scan inside the chunk), padded class offsets (the row ranges of the weight-gradient GEMM) and the class of
+// every 64-row block
+__global__ __launch_bounds__(256) void k_scb_offsets(ScbWs w, int nblocks) {
+  __shared__ int s_off[9], s_tot[8];
+  {
+    const int c = threadIdx.x >> 5, l = threadIdx.x & 31;
+    int carry = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += 32) {
+      const int b = b0 + l;
+      const int v = b < nblocks ? w.blk_cnt[(int64_t)b * 8 + c] : 0;
+      int inc = v;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) {
+        const int up = __shfl_up(inc, d);  // (lanes below d of a half read across the half's edge: unused)
+        if (l >= d) inc += up;
+      }
+      if (b < nblocks) w.blk_cnt[(int64_t)b * 8 + c] = carry + inc - v;
+      carry += __shfl(inc, (int)(threadIdx.x & 32) | 31);  // the last lane of this class's 32-lane half
+    }
+    if (l == 0) { s_tot[c] = carry; w.class_cnt[c] = carry; }
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     int off = 0;
     for (int c = 0; c < 8; ++c) {
       s_off[c] = off;
-      off += (w.class_cnt[c] + kPadRows - 1) / kPadRows * kPadRows;
+      off += (s_tot[c] + kPadRows - 1) / kPadRows * kPadRows;
     }
     s_off[8] = off;
     for (int c = 0; c < 9; ++c) w.class_off[c] = s_off[c];
@@ -110,31 +138,38 @@ __global__ __launch_bounds__(256) void k_scb_offsets(ScbWs w) {
 
 // compact row ids (class-major, padded class starts), row -> voxel map; pad rows keep rowvox = -1
 __global__ __launch_bounds__(256) void k_scb_assign(ScbWs w, int B, int D) {
-  __shared__ int s_cnt[8], s_base[8], s_fill[8];
-  if (threadIdx.x < 8) { s_cnt[threadIdx.x] = 0; s_fill[threadIdx.x] = 0; }
+  __shared__ int s_run[8], s_wave[4][8];
+  if (threadIdx.x < 8)
+    s_run[threadIdx.x] = w.class_off[threadIdx.x] + w.blk_cnt[(int64_t)blockIdx.x * 8 + threadIdx.x];
   __syncthreads();
   const int64_t total = (int64_t)B * D * D * D;
   const int64_t base = (int64_t)blockIdx.x * 256 * kIdxPerThread;
-  int cls[kIdxPerThread];
-#pragma unroll
-  for (int j = 0; j < kIdxPerThread; ++j) {
-    cls[j] = voxel_class(w.counts, D, base + j * 256 + threadIdx.x, total);
-    if (cls[j] >= 0) atomicAdd(&s_cnt[cls[j]], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x < 8)
-    s_base[threadIdx.x] = w.class_off[threadIdx.x] +
-                          (s_cnt[threadIdx.x] > 0 ? atomicAdd(&w.class_fill[threadIdx.x], s_cnt[threadIdx.x]) : 0);
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < kIdxPerThread; ++j) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j = 0; j < kIdxPerThread; ++j) {  // voxel index order: j, then the thread
     const int64_t i = base + j * 256 + threadIdx.x;
-    if (i >= total) continue;
+    const int cls = voxel_class(w.counts, D, i, total);
+    int before = 0;  // voxels of my class in lower lanes of my wave
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const unsigned long long m = __ballot(cls == c);
+      if (cls == c) before = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wave[wave][c] = __popcll(m);
+    }
+    __syncthreads();
     int row = -1;
-    if (cls[j] >= 0) row = s_base[cls[j]] + atomicAdd(&s_fill[cls[j]], 1);
-    if (row >= w.max_rows) row = -1;
-    w.rowmap[i] = row;
-    if (row >= 0) w.rowvox[row] = (int32_t)i;
+    if (cls >= 0) {
+      row = s_run[cls] + before;
+      for (int w2 = 0; w2 < wave; ++w2) row += s_wave[w2][cls];
+      if (row >= w.max_rows) row = -1;
+    }
+    if (i < total) {
+      w.rowmap[i] = row;
+      if (row >= 0) w.rowvox[row] = (int32_t)i;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+      s_run[threadIdx.x] += s_wave[0][threadIdx.x] + s_wave[1][threadIdx.x] + s_wave[2][threadIdx.x] + s_wave[3][threadIdx.x];
+    __syncthreads();
   }
 }
 
@@ -368,15 +403,13 @@ extern "C" int mf_sparse_conv3_bf16_index(const float *points, const int32_t *ba
   const int64_t BV = (int64_t)B * D * D * D;
   if (int e = mf::fill_bytes(w.counts, 0, BV * 4, stream)) return e;
   if (int e = mf::fill_bytes(w.head, 0xff, BV * 4, stream)) return e;
-  if (int e = mf::fill_bytes(w.class_cnt, 0, 8 * 4, stream)) return e;
-  if (int e = mf::fill_bytes(w.class_fill, 0, 8 * 4, stream)) return e;
   if (int e = mf::fill_bytes(w.rowvox, 0xff, w.max_rows * 4, stream)) return e;
   if (n > 0)
     hipLaunchKernelGGL(k_scb_link, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, points, batch_indices, n, B,
                        D, w);
-  const unsigned blocks = (unsigned)((BV + 256 * kIdxPerThread - 1) / (256 * kIdxPerThread));
+  const unsigned blocks = (unsigned)scb_blocks(BV);
   hipLaunchKernelGGL(k_scb_count, dim3(blocks), dim3(256), 0, stream, w, B, D);
-  hipLaunchKernelGGL(k_scb_offsets, dim3(1), dim3(256), 0, stream, w);
+  hipLaunchKernelGGL(k_scb_offsets, dim3(1), dim3(256), 0, stream, w, (int)blocks);
   hipLaunchKernelGGL(k_scb_assign, dim3(blocks), dim3(256), 0, stream, w, B, D);
   return mf::check_launch("mf_sparse_conv3_bf16_index");
 }
