@@ -28,16 +28,21 @@ class GraphedPredict:
         the parameters (volumetric_cl._packs, SparseVoxelConv3d.Wp, the PSPNet tail pack), so after
         ``load_state_dict`` / an optimiser step / ``.to()`` the old graph would replay stale -- or freed -- packs.
         A changed parameter drops every entry (their packs are rebuilt by the next warm-up)."""
-        # (the tensor LIST is cached -- walking the module tree every call was ~150 us in front of a 1.6 ms replay, ADVICE
-        # round 4; a replaced parameter object, e.g. after ``.to()`` / ``load_state_dict(assign=True)``, is caught by
-        # comparing the count and identities once per call through the cheap id() tuple of the module's own dicts)
-        cached = getattr(self, "_tensors", None)
+        # What is cached is the list of SLOTS -- (a module's own ``_parameters`` / ``_buffers`` dict, name) -- not the
+        # tensors: every call reads the tensor currently in each slot (one dict lookup each, ~20 us for the pose
+        # network; walking the module tree was ~150 us in front of a 1.6 ms replay, ADVICE round 4), so a REPLACED
+        # parameter object -- ``module.weight = nn.Parameter(..)``, ``load_state_dict(assign=True)``, ``.to()`` -- is
+        # seen by the very next call (ADVICE round 5: a cached tensor list kept the old objects alive and replayed the
+        # old weights for up to 63 calls).  The slot list itself is rebuilt when the module tree changes size
+        # (checked every call on the top level, every 64th call on the whole tree).
+        slots = getattr(self, "_slots", None)
         ident = (len(self.model._parameters), len(self.model._buffers), len(self.model._modules))
-        if cached is None or getattr(self, "_tensors_ident", None) != ident or getattr(self, "_calls", 0) % 64 == 0:
-            cached = list(self.model.parameters()) + list(self.model.buffers())
-            self._tensors, self._tensors_ident = cached, ident
         self._calls = getattr(self, "_calls", 0) + 1
-        params = tuple((t.data_ptr(), t._version) for t in cached)
+        if slots is None or getattr(self, "_slots_ident", None) != ident or self._calls % 64 == 0:
+            slots = [(m._parameters, n) for m in self.model.modules() for n in m._parameters] + \
+                    [(m._buffers, n) for m in self.model.modules() for n in m._buffers]
+            self._slots, self._slots_ident = slots, ident
+        params = tuple((id(t), t.data_ptr(), t._version) for t in (d.get(n) for d, n in slots) if t is not None)
         if params != getattr(self, "_params_seen", None):
             self.entries.clear()
             self._params_seen = params

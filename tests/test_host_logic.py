@@ -494,3 +494,30 @@ def test_grids_for_network_vs_the_executed_reference_transform():
         np.testing.assert_array_equal(nte, c["out_grid_nontarget_empty"], err_msg=f"{tag} case {c['case']}")
         cases.add(str(c["case"]))
     assert len(cases) == 9
+
+
+def test_graphed_predict_sees_a_replaced_parameter_on_the_next_call():
+    """contrib/singleview_3d/models/graphed.py: the replay cache is keyed by the identity, address and in-place version
+    of whatever tensor currently sits in every parameter / buffer slot of the module tree -- a replaced Parameter
+    object (``module.weight = nn.Parameter(..)``, ``load_state_dict(assign=True)``) or an in-place update drops every
+    captured entry on the very next call (a cached tensor list kept replaying the old weights)."""
+    import torch
+    from morefusion_amd.contrib.singleview_3d.models.graphed import GraphedPredict
+    m = torch.nn.Sequential(torch.nn.Linear(3, 3), torch.nn.BatchNorm1d(3))
+    g = GraphedPredict(m)
+    args = (torch.zeros(2, 3),)
+    k = g._key(args)
+    g.entries[k] = object()
+    assert g._key(args) == k and g.entries                      # nothing changed: the entry survives
+    m[0].weight = torch.nn.Parameter(m[0].weight.detach().clone())  # a new object, same values
+    g._key(args)
+    assert not g.entries
+    g.entries[k] = object()
+    with torch.no_grad():
+        m[1].running_mean.add_(1.0)                              # a buffer updated in place
+    g._key(args)
+    assert not g.entries
+    g.entries[k] = object()
+    m.load_state_dict({n: v.clone() for n, v in m.state_dict().items()}, assign=True)
+    g._key(args)
+    assert not g.entries
