@@ -424,6 +424,8 @@ int mf_conv3d_bf16_fwd_ws(const void *x, const void *wt, const float *bias, void
                           int32_t dil, int32_t relu, int32_t out_f32, int32_t ldo, mfStream_t stream);
 int64_t mf_conv3d_bf16_wgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t ks, int32_t split);
 int32_t mf_wgrad_split(int64_t tiles, int64_t ktiles, int64_t slab_bytes);
+/* slabs mf_linear_wgrad_bf16 should be given for dW [N][K] over M rows (answers for the tile form that will run) */
+int32_t mf_linear_wgrad_bf16_default_split(int64_t M, int32_t N, int32_t K, int32_t groups);
 int32_t mf_conv3d_bf16_wgrad_default_split(int32_t B, int32_t Cin, int32_t Cout, int32_t Do, int32_t ks);
 int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, void *ws, int32_t B, int32_t Cin, int32_t Cout,
                          int32_t D, int32_t ks, int32_t stride, int32_t pad, int32_t dil, int32_t w_cin, int32_t c_off,

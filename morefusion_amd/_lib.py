@@ -94,6 +94,7 @@ _SIGNATURES = {
     "mf_conv3d_bf16_fwd_ws": ([_p, _p, _p, _p, _p, _i64] + [ctypes.c_int32] * 11 + [_p], _i),
     "mf_conv3d_bf16_wgrad_workspace_bytes": ([ctypes.c_int32] * 4, _i64),
     "mf_wgrad_split": ([_i64, _i64, _i64], _i),
+    "mf_linear_wgrad_bf16_default_split": ([_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32], ctypes.c_int32),
     "mf_conv3d_bf16_wgrad_default_split": ([ctypes.c_int32] * 5, ctypes.c_int32),
     "mf_conv3d_bf16_wgrad": ([_p, _p, _p, _p] + [ctypes.c_int32] * 11 + [_p], _i),
     "mf_sparse_conv3_bf16_max_rows": ([_i64], _i64),

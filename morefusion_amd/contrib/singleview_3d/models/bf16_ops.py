@@ -160,9 +160,8 @@ class Conv3d(torch.autograd.Function):
 
 
 def _wgrad_split(M, N, K, groups):
-    """Slabs of the weight-gradient reduction (csrc/gemm_bf16.hip: mf_wgrad_split's cost model)."""
-    tiles = -(-N // 128) * -(-K // 128) * groups
-    return int(_lib.lib().mf_wgrad_split(tiles, -(-M // 64), N * K * 4 * groups))
+    """Slabs of the weight-gradient reduction (csrc/gemm_bf16.hip: the cost model on the tile form that will run)."""
+    return int(_lib.lib().mf_linear_wgrad_bf16_default_split(M, N, K, groups))
 
 
 class Linear(torch.autograd.Function):

@@ -1238,6 +1238,247 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(TnArgs a) {
   }
 }
 
+// ---- the TN engine on the 256 x 256 tile with LDS-DMA operands and two wave groups in ping-pong (round 6) -----------
+// The structure of k_gemm_nt_bf16_pp (see there: phases of two k-steps, the groups one barrier apart, counted vmcnt,
+// inline-asm fragment reads) for C[i][j] = sum_m P[m][i] Q(m, j): a K-tile is 64 rows m of both operands, 256 columns
+// each -- [64][512 bytes] per operand and stage, THREE Q stages (the im2col rows: re-read from far away) + TWO P stages
+// (dY: shared by every workgroup of a column of tiles).
+//   * DMA: one request = two LDS rows (2 x 512 bytes: whole contiguous row segments of the tile).  LDS row
+//     rho = 16 i + 2 wave + h (request i of the wave, h = lane / 32) holds global row 64 t + 8 wave + 4 h + i: any
+//     permutation of the reduction index is fine as long as both operands use it, and this one gives a lane four
+//     CONSECUTIVE rows per K-tile -- for a convolution one voxel decode, an oz test and an add per request.
+//   * fragments: ds_read_b64_tr_b16 (a 16-lane group reads a [4 rows][16 columns] block, lane c receives column c):
+//     the four rows of a group are 512 bytes apart -- the same banks -- so the 16-byte chunk index of LDS row rho is
+//     XORed with 4 (rho & 3) (applied to the SOURCE column of the DMA lane, as in the NT kernel): the four rows of a
+//     group land in the four 64-byte quarters of the 256-byte bank row.  rho & 3 is the lane's r = (lane & 15) / 4 in
+//     every read, so a lane's address of column block n is (n ^ r) * 64 + const: one address register per block.
+
+template <bool CONV>
+__global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_pp(TnArgs a) {
+  MF_DYN_LDS(unsigned char, s_raw);
+  const int tiles_i = (a.Ni + 255) / 256, tiles_j = (a.Nj + 255) / 256;
+  const int per_group = tiles_i * tiles_j;
+  const int G = gridDim.x;
+  int L = blockIdx.x;
+  if ((G & 7) == 0) L = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int split = L / (per_group * a.groups);
+  const int rem0 = L - split * per_group * a.groups;
+  const int grp = rem0 / per_group;
+  const int rem = rem0 - grp * per_group;
+  const int i0 = (rem % tiles_i) * 256, j0 = (rem / tiles_i) * 256;  // i tile fastest: neighbours share Q columns
+  int m_lo = 0, M = a.M;
+  if (!CONV && a.m_range) {  // (block-uniform)
+    m_lo = a.m_range[grp];
+    M = a.m_range[grp + 1] - m_lo;
+  }
+  const int Tall = (M + 63) / 64;
+  const int Tper = (Tall + a.S - 1) / a.S;
+  const int t0 = split * Tper;
+  const int T = max(0, min(Tall, t0 + Tper) - t0);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = mf::wave_uniform(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  // DMA slot: LDS rows 16 i + 2 wave + h, chunk position lane & 31 -> this lane's column chunk (the same for every row)
+  const int h = lane >> 5;
+  const int cq = (lane & 31) ^ (4 * ((2 * wave + h) & 3));
+  const int col = 8 * cq;
+  const int mrow = 8 * wave + 4 * h;  // this lane's rows of a K-tile: mrow + i
+
+  const uint16_t *P = a.P + grp * a.p_gs + (int64_t)m_lo * a.ldp;
+  const uint16_t *Q = a.Q + grp * a.q_gs + (CONV ? 0 : (int64_t)m_lo * a.ldq);
+  const int Do = a.Do, dol = a.olog;
+  const bool pcol_ok = i0 + col + 8 <= a.Ni;
+  // conv: the lane's column chunk is one (tap, cin .. cin + 7) for the whole loop (see k_gemm_tn_bf16)
+  const int q_off = j0 + col;
+  int tap_const = 0, lo_x = 0, lo_y = 0, lo_z = 0;
+  unsigned span_x = 0, span_y = 0, span_z = 0;
+  bool qcol_ok = j0 + col + 8 <= a.Nj;
+  const int cxs = a.stride * a.D * a.D * a.Cin, cys = a.stride * a.D * a.Cin, czs = a.stride * a.Cin;
+  const int cb = a.D * a.D * a.D * a.Cin;
+  if (CONV) {
+    const int jj = qcol_ok ? j0 + col : 0;
+    const int tap = jj / a.Cin, tap_c = jj - tap * a.Cin;
+    const int kxy = tap / a.ks, kz = tap - kxy * a.ks, kx = kxy / a.ks, ky = kxy - kx * a.ks;
+    const int tx = a.dil * kx - a.pad, ty = a.dil * ky - a.pad, tz = a.dil * kz - a.pad;
+    tap_const = ((tx * a.D + ty) * a.D + tz) * a.Cin + tap_c;
+    qcol_ok = qcol_ok && kx < a.ks;
+    const int t3[3] = {tx, ty, tz};
+    int lo3[3];
+    unsigned sp3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // 0 <= stride * o + t < D
+      const int lo = t3[k] >= 0 ? 0 : (-t3[k] + a.stride - 1) / a.stride;
+      const int hi = a.D - 1 - t3[k] >= 0 ? min((a.D - 1 - t3[k]) / a.stride, Do - 1) : -1;
+      qcol_ok = qcol_ok && hi >= lo;
+      lo3[k] = lo;
+      sp3[k] = (unsigned)max(hi - lo, 0);
+    }
+    lo_x = lo3[0]; lo_y = lo3[1]; lo_z = lo3[2];
+    span_x = sp3[0]; span_y = sp3[1]; span_z = sp3[2];
+  }
+
+  mf_f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const mf::BufRsrc Prs = mf::make_rsrc(P), Qrs = mf::make_rsrc(Q);
+  unsigned char *const dma0 = s_raw + wave * 1024;  // request i of this wave fills LDS rows 16 i + 2 wave, + 1
+  constexpr int kQ0 = 0, kP0 = 3 * kPpOp;            // Q stages at 0, 1, 2 x kPpOp; P stages behind them
+  int tq = t0, tp = t0;                              // K-tiles the next Q / P requests fetch (Q runs one ahead)
+  // requests i0_ .. i1_ - 1 of Q's next K-tile -> Q stage sq_ (rows 64 tq + mrow + i); the tile advances behind the last
+#define MF_TP_REQ_Q(sq_, i0_, i1_)                                                                    \
+  {                                                                                                   \
+    const int mb_ = tq * 64 + mrow;                                                                   \
+    int qb_ = mb_ * a.ldq + q_off, zrel_ = 0;                                                         \
+    bool qrow_ok_ = qcol_ok;                                                                          \
+    if (CONV) {                                                                                       \
+      const int b_ = mb_ >> (3 * dol), ox_ = (mb_ >> (2 * dol)) & (Do - 1), oy_ = (mb_ >> dol) & (Do - 1), \
+                oz_ = mb_ & (Do - 1);                                                                 \
+      qrow_ok_ = qcol_ok && (unsigned)(ox_ - lo_x) <= span_x && (unsigned)(oy_ - lo_y) <= span_y;     \
+      qb_ = tap_const + b_ * cb + ox_ * cxs + oy_ * cys + oz_ * czs;                                  \
+      zrel_ = oz_ - lo_z;                                                                             \
+    }                                                                                                 \
+    _Pragma("unroll") for (int i = (i0_); i < (i1_); ++i) {                                           \
+      bool ok_ = mb_ + i < M && qrow_ok_;                                                             \
+      if (CONV) ok_ = ok_ && (unsigned)(zrel_ + i) <= span_z;                                         \
+      mf::glds16(Qrs, ok_ ? 2u * (uint32_t)(qb_ + i * (CONV ? czs : a.ldq)) : mf::kBufMasked,         \
+                 dma0 + kQ0 + (sq_) * kPpOp + i * 8192);                                              \
+    }                                                                                                 \
+    if ((i1_) == 4) ++tq;                                                                             \
+  }
+#define MF_TP_REQ_P(sp_, i0_, i1_)                                                                    \
+  {                                                                                                   \
+    const int mb_ = tp * 64 + mrow;                                                                   \
+    const int pb_ = mb_ * a.ldp + i0 + col;                                                           \
+    _Pragma("unroll") for (int i = (i0_); i < (i1_); ++i)                                             \
+      mf::glds16(Prs, mb_ + i < M && pcol_ok ? 2u * (uint32_t)(pb_ + i * a.ldp) : mf::kBufMasked,     \
+                 dma0 + kP0 + (sp_) * kPpOp + i * 8192);                                              \
+    if ((i1_) == 4) ++tp;                                                                             \
+  }
+  // fragment addresses inside a stage (k-step s: + s * 8192, second half of a fragment: + 2048)
+  const int r = (lane & 15) >> 2, q4 = lane & 3, g = lane >> 4;
+  const int rowpart = (8 * (g >> 1) + r) * 512 + (2 * (g & 1) + (q4 >> 1)) * 16 + 8 * (q4 & 1);
+  mf::lds_addr_t fragP[4], fragQ[2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) fragP[mi] = mf::lds_addr(s_raw) + kP0 + rowpart + ((4 * wm + mi) ^ r) * 64;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) fragQ[ni] = mf::lds_addr(s_raw) + kQ0 + rowpart + ((2 * wn + ni) ^ r) * 64;
+  const int ncols = a.Nj - (j0 + wn * 64);  // columns of this wave's 64 that exist (wave-uniform)
+  uint4 fa[2][4], fb[2][2];
+  // (a fragment is two 8-byte transposing reads into the halves of one 16-byte register: mf::lds_read_tr16_x2_async)
+#define MF_TP_READS(NJ_, kk_, sq_, sp_, s_)                                                           \
+  if ((NJ_) > 0) {                                                                                    \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
+      fa[kk_][mi] = mf::lds_read_tr16_x2_async<(s_) * 8192>(fragP[mi] + (sp_) * kPpOp);               \
+    fb[kk_][0] = mf::lds_read_tr16_x2_async<(s_) * 8192>(fragQ[0] + (sq_) * kPpOp);                   \
+    if ((NJ_) > 1) fb[kk_][1] = mf::lds_read_tr16_x2_async<(s_) * 8192>(fragQ[1] + (sq_) * kPpOp);    \
+  }
+#define MF_TP_PHASE(NJ_, p_, REQ_, WAIT_)                                                             \
+  {                                                                                                   \
+    MF_TP_READS(NJ_, 0, sq, sp, 2 * (p_))                                                             \
+    MF_TP_READS(NJ_, 1, sq, sp, 2 * (p_) + 1)                                                         \
+    REQ_(0, 4)                                                                                        \
+    WAIT_                                                                                             \
+    mf::wait_lds_reads();                                                                             \
+    if ((NJ_) > 0) {                                                                                  \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                              \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) MF_HOLD(fa[kk][mi]);                         \
+        MF_HOLD(fb[kk][0]);                                                                           \
+        if ((NJ_) > 1) MF_HOLD(fb[kk][1]);                                                            \
+      }                                                                                               \
+    }                                                                                                 \
+    mf::raw_barrier();                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int qq = 0; qq < 16; ++qq) {                                               \
+      const int kk = qq >> 3, mi = qq & 3, nj = (qq >> 2) & 1;                                        \
+      if (nj < (NJ_)) acc[mi][nj] = mf::mfma_bf16_32x32x16(fa[kk][mi], fb[kk][nj], acc[mi][nj]);      \
+    }                                                                                                 \
+    __builtin_amdgcn_s_setprio(0);                                                                    \
+    mf::raw_barrier();                                                                                \
+  }
+#define MF_TP_RP(i0_, i1_) if (more1) MF_TP_REQ_P(sp ^ 1, i0_, i1_)
+#define MF_TP_RQ(i0_, i1_) if (more2) MF_TP_REQ_Q(sq2, i0_, i1_)
+#define MF_TP_LOOP(NJ_)                                                                               \
+  for (int t = 0; t < T; ++t) {                                                                       \
+    const int sp = t & 1;                                                                             \
+    const bool more1 = t + 1 < T, more2 = t + 2 < T;                                                  \
+    MF_TP_PHASE(NJ_, 0, MF_TP_RP, )                                                                   \
+    MF_TP_PHASE(NJ_, 1, MF_TP_RQ, if (more2) mf::wait_dma<4>(); else mf::wait_dma<0>();)              \
+    sq = sq == 2 ? 0 : sq + 1;                                                                        \
+    sq2 = sq2 == 2 ? 0 : sq2 + 1;                                                                     \
+  }
+  // tiles 0 (Q, P) and 1 (Q) before the loop; the requests of Q(1) stay in flight
+  MF_TP_REQ_Q(0, 0, 4) MF_TP_REQ_P(0, 0, 4)
+  if (T > 1) {
+    MF_TP_REQ_Q(1, 0, 4)
+    mf::wait_dma<4>();
+  } else {
+    mf::wait_dma<0>();
+  }
+  mf::raw_barrier();
+  int sq = 0, sq2 = 2;  // Q stages of tiles t and t + 2
+  if (wm == 1) mf::raw_barrier();  // the lower half runs one barrier behind from here on
+  if (ncols > 32) {
+    MF_TP_LOOP(2)
+  } else if (ncols > 0) {
+    MF_TP_LOOP(1)
+  } else {
+    MF_TP_LOOP(0)
+  }
+  if (wm == 0) mf::raw_barrier();  // the groups meet again
+#undef MF_TP_LOOP
+#undef MF_TP_RQ
+#undef MF_TP_RP
+#undef MF_TP_PHASE
+#undef MF_TP_READS
+#undef MF_TP_REQ_P
+#undef MF_TP_REQ_Q
+
+  // epilogue through LDS in four passes of 64 rows (fp32 tile rows i, columns j)
+  constexpr int kEp = 256 + 4;
+  float *s_out = reinterpret_cast<float *>(s_raw);  // [64][kEp]
+  float *dst = a.out + ((int64_t)split * a.groups + grp) * (a.S > 1 ? (int64_t)a.Ni * a.ldc : 0) +
+               (a.S > 1 ? 0 : grp * a.c_gs);
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    if (wm == (pass >> 1)) {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int nl = wn * 64 + ni * 32 + lrow;
+          const mf_f32x16 &c = (pass & 1) ? acc[2 + mh][ni] : acc[mh][ni];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int ml = mh * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+            s_out[ml * kEp + nl] = c[e];
+          }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 64; i += 512) {
+      const int il = i >> 6, c4 = i & 63;
+      const int ii = i0 + 64 * pass + il, jj = j0 + 4 * c4;
+      if (ii >= a.Ni || jj >= a.Nj) continue;
+      const float4 v = *reinterpret_cast<const float4 *>(s_out + il * kEp + 4 * c4);
+      float *o = dst + (int64_t)ii * a.ldc + jj;
+      if (jj + 4 <= a.Nj && (a.ldc & 3) == 0 && ((uintptr_t)o & 15) == 0) {
+        *reinterpret_cast<float4 *>(o) = v;
+      } else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int j = 0; j < 4 && jj + j < a.Nj; ++j) o[j] = vv[j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // out[g][i][f(j)] = sum_s slab[s][g][i][j] (increasing s); conv: j = tap * Cin + cin -> f(j) = cin * taps + tap
 // (the torch / Chainer ConvolutionND weight layout [Cout][w_cin][ks][ks][ks]); channels cin >= cin_keep (the zero
 // padding of a narrow layer's input up to 8 channels) are dropped.
@@ -1534,6 +1775,51 @@ int bad(const char *msg) {
 
 }  // namespace
 
+namespace {
+int wgrad_split_model(int64_t tiles, int64_t ktiles, int64_t slab_bytes, int slots) {
+  if (tiles <= 0 || ktiles <= 0) return 1;
+  const double per_slab = slab_bytes / 3.0e6 > 0.05 ? slab_bytes / 3.0e6 : 0.05;  // us at ~3 TB/s, launch floor
+  int best = 1;
+  double best_cost = 1e30;
+  for (int S = 1; S <= 512; ++S) {
+    if (S > 1 && ktiles / S < 8) break;
+    const int64_t rounds = (tiles * S + slots - 1) / slots;
+    const double cost = (double)rounds * (double)((ktiles + S - 1) / S + 8) + (S > 1 ? S * per_slab : 0.0);
+    if (cost < best_cost) { best_cost = cost; best = S; }
+  }
+  return best;
+}
+// The 256 x 256 ping-pong form of the TN engine (k_gemm_tn_bf16_pp) takes the weight gradients whose result has at
+// least 192 rows and columns (MF_TN_PP=0: never; MF_NT_BIG=2, the tests' switch: wherever the shape allows).
+bool tn_use_pp(int Ni, int Nj, bool ranges) {
+  if (getenv("MF_TN_PP") && atoi(getenv("MF_TN_PP")) == 0) return false;
+  if (nt_big_override() == 0 || ranges) return false;
+  if (nt_big_override() == 2) return true;
+  return Ni >= 192 && Nj >= 192;
+}
+// slabs of a weight gradient [Ni][Nj] reduced over ``ktiles`` row tiles of 64, ``groups`` results side by side: the
+// cost model below on the tile / workgroup-slot counts of the form that will run it (the pp form: one 256 x 256 tile
+// per CU and K-tiles of twice the work)
+int wgrad_split_for(int Ni, int Nj, int64_t ktiles, int groups) {
+  const int64_t slab = (int64_t)Ni * Nj * 4 * groups;
+  if (tn_use_pp(Ni, Nj, false))
+    return wgrad_split_model((int64_t)((Ni + 255) / 256) * ((Nj + 255) / 256) * groups, 2 * ktiles, slab, 256);
+  return wgrad_split_model((int64_t)((Ni + 127) / 128) * ((Nj + 127) / 128) * groups, ktiles, slab, 512);
+}
+template <bool CONV>
+void launch_tn(const TnArgs &a, bool ranges, hipStream_t stream) {
+  if (tn_use_pp(a.Ni, a.Nj, ranges)) {
+    if (mf::allow_big_lds((const void *)k_gemm_tn_bf16_pp<CONV>, 5 * kPpOp)) return;
+    const int64_t grid = (int64_t)((a.Ni + 255) / 256) * ((a.Nj + 255) / 256) * a.groups * a.S;
+    hipLaunchKernelGGL(k_gemm_tn_bf16_pp<CONV>, dim3((unsigned)grid), dim3(512), 5 * kPpOp, stream, a);
+    return;
+  }
+  if (mf::allow_big_lds((const void *)k_gemm_tn_bf16<CONV>, kTnLds)) return;
+  const int64_t grid = (int64_t)((a.Ni + 127) / 128) * ((a.Nj + 127) / 128) * a.groups * a.S;
+  hipLaunchKernelGGL(k_gemm_tn_bf16<CONV>, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
+}
+}  // namespace
+
 extern "C" int mf_cast_rows_bf16(const float *src, int64_t src_ld, void *dst, int64_t dst_ld, int64_t rows,
                                  int32_t cols, mfStream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -1589,13 +1875,11 @@ extern "C" int mf_linear_wgrad_bf16(const void *dY, int64_t y_gs, int32_t ldy, c
     return bad("linear_wgrad_bf16: N, K, ldy, lda, group strides % 8 == 0, 16-byte aligned operands");
   if ((int64_t)M * ldy >= kMaxBf16Elems || (int64_t)M * lda >= kMaxBf16Elems)
     return bad("linear_wgrad_bf16: an operand of one group spans >= 2^31 bytes (32-bit byte offsets: split the rows)");
-  if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16<false>, kTnLds)) return e;
   TnArgs a = {};
   a.P = (const uint16_t *)dY; a.Q = (const uint16_t *)A; a.out = split > 1 ? (float *)ws : dW;
   a.p_gs = y_gs; a.q_gs = a_gs; a.c_gs = w_gs;
   a.M = M; a.Ni = N; a.Nj = K; a.ldp = ldy; a.ldq = lda; a.ldc = ldc; a.groups = groups; a.S = split;
-  const int64_t grid = (int64_t)((N + 127) / 128) * ((K + 127) / 128) * groups * split;
-  hipLaunchKernelGGL(k_gemm_tn_bf16<false>, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
+  launch_tn<false>(a, false, stream);
   if (split > 1) {
     const int64_t per_group = (int64_t)N * ldc, per_slab = per_group * groups;
     if (split >= 32 && per_slab <= (1 << 16))
@@ -1641,14 +1925,12 @@ extern "C" int mf_linear_wgrad_bf16_ranges(const void *dY, int32_t ldy, const vo
   if (N <= 0 || K <= 0 || groups <= 0) return 0;
   if (N % 8 || K % 8 || ldy % 8 || lda % 8 || ldc < K || !m_range || (((uintptr_t)dY | (uintptr_t)A) & 15))
     return bad("linear_wgrad_bf16_ranges: N, K, ldy, lda % 8 == 0, 16-byte aligned operands, a range table");
-  if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16<false>, kTnLds)) return e;
   TnArgs a = {};
   a.P = (const uint16_t *)dY; a.Q = (const uint16_t *)A; a.out = dW;
   a.c_gs = w_gs;
   a.M = 0; a.Ni = N; a.Nj = K; a.ldp = ldy; a.ldq = lda; a.ldc = ldc; a.groups = groups; a.S = 1;
   a.m_range = m_range;
-  const int64_t grid = (int64_t)((N + 127) / 128) * ((K + 127) / 128) * groups;
-  hipLaunchKernelGGL(k_gemm_tn_bf16<false>, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
+  launch_tn<false>(a, true, stream);
   return mf::check_launch("mf_linear_wgrad_bf16_ranges");
 }
 
@@ -1789,24 +2071,23 @@ extern "C" int64_t mf_conv3d_bf16_wgrad_workspace_bytes(int32_t Cin, int32_t Cou
  *   ceil(tiles S / 512) rounds x (ceil(ktiles / S) + 8 K-tiles of prologue / epilogue)  +  S slabs read by the finish
  * -- the first version doubled S until tiles * S >= 512, which put conv3 (160 tiles) at S = 4: 640 workgroups, a
  * second round a quarter full; S = 3 fills one round. */
+/* Split of the reduction (rows) of a weight-gradient GEMM over S workgroups per output tile, S fp32 slabs summed by
+ * the finish pass.  ``tiles`` output tiles of 128 x 128, ``ktiles`` row tiles of 64, ``slab_bytes`` = size of one
+ * slab.  Cost model in units of one K-tile of one workgroup (~1 us at two workgroups per CU, 512 slots on the chip):
+ *   ceil(tiles S / 512) rounds x (ceil(ktiles / S) + 8 K-tiles of prologue / epilogue)  +  S slabs read by the finish
+ * -- the first version doubled S until tiles * S >= 512, which put conv3 (160 tiles) at S = 4: 640 workgroups, a
+ * second round a quarter full; S = 3 fills one round.  (The 128 x 128 form's model; mf_linear_wgrad_bf16_default_split
+ * / mf_conv3d_bf16_wgrad_default_split answer for the form that will actually run.) */
 extern "C" int32_t mf_wgrad_split(int64_t tiles, int64_t ktiles, int64_t slab_bytes) {
-  if (tiles <= 0 || ktiles <= 0) return 1;
-  const double per_slab = slab_bytes / 3.0e6 > 0.05 ? slab_bytes / 3.0e6 : 0.05;  // us at ~3 TB/s, launch floor
-  int best = 1;
-  double best_cost = 1e30;
-  for (int S = 1; S <= 512; ++S) {
-    if (S > 1 && ktiles / S < 8) break;
-    const int64_t rounds = (tiles * S + 511) / 512;
-    const double cost = (double)rounds * (double)((ktiles + S - 1) / S + 8) + (S > 1 ? S * per_slab : 0.0);
-    if (cost < best_cost) { best_cost = cost; best = S; }
-  }
-  return best;
+  return wgrad_split_model(tiles, ktiles, slab_bytes, 512);
+}
+
+extern "C" int32_t mf_linear_wgrad_bf16_default_split(int64_t M, int32_t N, int32_t K, int32_t groups) {
+  return wgrad_split_for(N, K, (M + 63) / 64, groups);
 }
 
 extern "C" int32_t mf_conv3d_bf16_wgrad_default_split(int32_t B, int32_t Cin, int32_t Cout, int32_t Do, int32_t ks) {
-  const int64_t nj = (int64_t)ks * ks * ks * Cin;
-  return mf_wgrad_split((int64_t)((Cout + 127) / 128) * ((nj + 127) / 128), ((int64_t)B * Do * Do * Do + 63) / 64,
-                        (int64_t)Cout * nj * 4);
+  return wgrad_split_for(Cout, ks * ks * ks * Cin, ((int64_t)B * Do * Do * Do + 63) / 64, 1);
 }
 
 /* dW [Cout][w_cin][ks][ks][ks] (input channels c_off .., those below w_cin: fp32, the framework layout) = sum over
@@ -1820,7 +2101,6 @@ extern "C" int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, vo
   if (int e = conv_geom(B, Cin, Cout, D, ks, stride, pad, dil, &g)) return e;
   if (split < 1 || !ws) return bad("conv3d wgrad: workspace required");
   if (g.olog < 2) return bad("conv3d wgrad: output size >= 4 per axis");
-  if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16<true>, kTnLds)) return e;
   TnArgs a = {};
   a.P = (const uint16_t *)dy; a.Q = (const uint16_t *)x; a.out = (float *)ws;
   a.M = B * g.Do * g.Do * g.Do; a.Ni = Cout; a.Nj = g.taps * Cin; a.ldp = Cout; a.ldc = g.taps * Cin; a.groups = 1;
@@ -1828,8 +2108,7 @@ extern "C" int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, vo
   a.conv = 1; a.B = B; a.D = D; a.Do = g.Do; a.olog = g.olog; a.Cin = Cin;
   a.ks = ks; a.stride = stride; a.pad = pad; a.dil = dil;
   // (S == 1 also goes through the workspace: the finish pass permutes (tap, cin) -> (cin, tap))
-  const int64_t grid = (int64_t)((Cout + 127) / 128) * ((g.taps * Cin + 127) / 128) * a.S;
-  hipLaunchKernelGGL(k_gemm_tn_bf16<true>, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
+  launch_tn<true>(a, false, stream);
   const int64_t per_slab = (int64_t)Cout * g.taps * Cin;
   const int keep = w_cin - c_off < Cin ? w_cin - c_off : Cin;
   // big layers: the tiled transpose; small ones (the occupancy convolutions: a few thousand weights in up to 256

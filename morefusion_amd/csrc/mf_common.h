@@ -91,6 +91,16 @@ __device__ __forceinline__ uint4 lds_read16_async(lds_addr_t addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+// The same for an MFMA operand that comes out of gfx950's transposing read (lds_read_tr16_b64x2 below): the two
+// ds_read_b64_tr_b16 at addr + IMM and addr + IMM + 2048 write the low and the high half of one 16-byte register.
+template <int IMM>
+__device__ __forceinline__ uint4 lds_read_tr16_x2_async(lds_addr_t addr) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(IMM));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(IMM + 2048));
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
 __device__ __forceinline__ void wait_lds_reads() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);  // (register-only instructions would be hoisted over the asm wait)

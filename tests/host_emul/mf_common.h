@@ -511,6 +511,10 @@ inline uint4 lds_read16_async(lds_addr_t addr) {
   memcpy(&v, (const unsigned char *)addr + IMM, 16);
   return v;
 }
+template <int IMM>
+inline uint4 lds_read_tr16_x2_async(lds_addr_t addr) {
+  return lds_read_tr16_b64x2((const unsigned char *)addr + IMM, 2048);
+}
 inline void wait_lds_reads() {}
 template <int N> inline void wait_dma() {}
 inline void raw_barrier() { __syncthreads(); }
