@@ -1790,25 +1790,31 @@ int wgrad_split_model(int64_t tiles, int64_t ktiles, int64_t slab_bytes, int slo
   return best;
 }
 // The 256 x 256 ping-pong form of the TN engine (k_gemm_tn_bf16_pp) takes the weight gradients whose result has at
-// least 192 rows and columns (MF_TN_PP=0: never; MF_NT_BIG=2, the tests' switch: wherever the shape allows).
-bool tn_use_pp(int Ni, int Nj, bool ranges) {
+// least 192 rows and columns AND whose reduction is long enough that a split filling the 256 CUs still leaves every
+// workgroup >= 48 K-tiles (its prologue / epilogue -- 256 KB of fp32 tile through LDS -- weigh on shorter ones: the
+// heads' first layer, 32 tiles x 250 K-tiles, measured 570 TFLOP/s on it against 670 on the 128 x 128 form).
+// MF_TN_PP=0: never; MF_NT_BIG=2, the tests' switch: wherever the shape allows.
+bool tn_use_pp(int Ni, int Nj, int64_t ktiles, int groups, bool ranges) {
   if (getenv("MF_TN_PP") && atoi(getenv("MF_TN_PP")) == 0) return false;
   if (nt_big_override() == 0 || ranges) return false;
   if (nt_big_override() == 2) return true;
-  return Ni >= 192 && Nj >= 192;
+  if (Ni < 192 || Nj < 192) return false;
+  const int64_t tiles = (int64_t)((Ni + 255) / 256) * ((Nj + 255) / 256) * groups;
+  const int64_t fill = tiles >= 256 ? 1 : (256 + tiles - 1) / tiles;  // splits that fill the chip
+  return ktiles >= 48 * fill;
 }
 // slabs of a weight gradient [Ni][Nj] reduced over ``ktiles`` row tiles of 64, ``groups`` results side by side: the
 // cost model below on the tile / workgroup-slot counts of the form that will run it (the pp form: one 256 x 256 tile
 // per CU and K-tiles of twice the work)
 int wgrad_split_for(int Ni, int Nj, int64_t ktiles, int groups) {
   const int64_t slab = (int64_t)Ni * Nj * 4 * groups;
-  if (tn_use_pp(Ni, Nj, false))
+  if (tn_use_pp(Ni, Nj, ktiles, groups, false))
     return wgrad_split_model((int64_t)((Ni + 255) / 256) * ((Nj + 255) / 256) * groups, 2 * ktiles, slab, 256);
   return wgrad_split_model((int64_t)((Ni + 127) / 128) * ((Nj + 127) / 128) * groups, ktiles, slab, 512);
 }
 template <bool CONV>
 void launch_tn(const TnArgs &a, bool ranges, hipStream_t stream) {
-  if (tn_use_pp(a.Ni, a.Nj, ranges)) {
+  if (tn_use_pp(a.Ni, a.Nj, ((int64_t)a.M + 63) / 64, a.groups, ranges)) {
     if (mf::allow_big_lds((const void *)k_gemm_tn_bf16_pp<CONV>, 5 * kPpOp)) return;
     const int64_t grid = (int64_t)((a.Ni + 255) / 256) * ((a.Nj + 255) / 256) * a.groups * a.S;
     hipLaunchKernelGGL(k_gemm_tn_bf16_pp<CONV>, dim3((unsigned)grid), dim3(512), 5 * kPpOp, stream, a);
