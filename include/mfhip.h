@@ -195,12 +195,9 @@ typedef struct {
                              (what the reference's callers pass: bool grids cast to float32) ->
                              single-pass iteration (TDF tiles and weights/sums in one kernel, two
                              launches per iteration); 0: any values, two-kernel path */
-  int32_t flags;          /* bit 0 (MF_ICC_FLAG_ONE_LAUNCH): experimental one-launch iterations (k_icc_iter: needs
-                             grid_ne_binary, voxel_threshold 2, <= 16 objects per scene -- the workspace then holds a
-                             second record buffer and one more plane of bins per side).  Same bits, measured
-                             slower than the default two launches. */
+  int32_t flags;          /* reserved, must be 0 (round 5: bit 0 selected the experimental one-launch iteration
+                             k_icc_iter -- same bits, measured slower, removed in round 6) */
 } mfIccBatch;
-#define MF_ICC_FLAG_ONE_LAUNCH 1
 
 /* Bytes of workspace for this batch (negative: invalid descriptor).  Holds the winners of every
  * grid, partial sums, and the per-iteration x-plane bins of voxel-frame point records:
@@ -228,9 +225,7 @@ int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float *adam_m,
                   mfStream_t stream);
 
 /* Launches per iteration mf_icc_refine will use for this batch: 2 = k_icc_bin + k_icc_fused ({0,1} no-entry grids:
- * the default), 3 = k_icc_bin + k_icc_tile + k_icc_accum (any no-entry grid values), 1 = k_icc_iter (opt-in,
- * flags & MF_ICC_FLAG_ONE_LAUNCH: the tiles of iteration k read the model-point bins iteration k - 1 built, the
- * same launch steps the poses and bins for k + 1).  Negative: invalid descriptor.  All paths give the same bits. */
+ * the default), 3 = k_icc_bin + k_icc_tile + k_icc_accum (any no-entry grid values).  Negative: invalid descriptor. */
 int mf_icc_iteration_launches(const mfIccBatch *batch);
 
 /* Measurement hook so that bench.py can time ONE kernel of an ICC iteration with HIP events:

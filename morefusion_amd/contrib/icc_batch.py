@@ -25,13 +25,10 @@ class IccScenes:
     (points: list of [P_i,3]; sdf: list of [P_i]; pitch [N]; origin [N,3];
     grid_target, grid_nontarget_empty [N,D,D,D])."""
 
-    def __init__(self, scenes, voxel_dim=32, voxel_threshold=2, sdf_offset=0.0, device="cuda", single_pass=None,
-                 one_launch=None):
+    def __init__(self, scenes, voxel_dim=32, voxel_threshold=2, sdf_offset=0.0, device="cuda", single_pass=None):
         """``single_pass``: None = choose by the no-entry grids' values (binary -> the single-pass kernel);
         False forces the general two-kernel iteration (k_icc_tile -> W -> k_icc_accum) on any grids; True is
-        honoured only for {0,1} grids (the polynomial form of the loss holds for those alone).
-        ``one_launch``: opt in to the experimental one-launch iterations (``k_icc_iter``; default: the environment's
-        ``MF_ICC_ONE_LAUNCH``, else off -- same bits, measured slower than the default two launches)."""
+        honoured only for {0,1} grids (the polynomial form of the loss holds for those alone)."""
         dev = torch.device(device)
         self._single_pass = single_pass
         if dev.type != "cuda":
@@ -84,9 +81,7 @@ class IccScenes:
             # {0,1} no-entry grids (bool cast to float32, what every caller of the reference passes)
             # take the single-pass kernel; checked once here (pack time, not in the loop)
             int(bool(((self.grid_ne == 0) | (self.grid_ne == 1)).all())))
-        if one_launch is None:
-            one_launch = os.environ.get("MF_ICC_ONE_LAUNCH", "0") not in ("", "0")
-        self.desc.flags = 1 if one_launch else 0  # MF_ICC_FLAG_ONE_LAUNCH (sizes the workspace: set before asking)
+        self.desc.flags = 0  # (reserved)
         nbytes = L.mf_icc_workspace_bytes(ctypes.byref(self.desc))
         if nbytes < 0:
             raise ValueError("mf_icc: invalid batch descriptor (objects per scene <= 64, dim <= 64)")

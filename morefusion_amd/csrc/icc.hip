@@ -121,15 +121,7 @@ struct IccArgs {
   int bin_cap_force;      // > 0: every cap_g = this (MF_ICC_BIN_CAP: exercises the overflow path in tests)
   float4 *rec;            // records {fx, fy, fz, point id bits}: voxel-frame coordinates
   int dbg;                // tuning aid: MF_ICC_DEBUG bit mask (0 in production)
-  // ---- one-launch-per-iteration path (k_icc_iter, round 5) ----
-  // The tiles of iteration k read the bins that iteration k - 1 built from ITS pose: a record is then the MODEL
-  // point {mx, my, mz, point id | scene-local object << 27} and the reader transforms it with the current pose.
-  // mg = margin in planes / rows a bin reaches beyond the exact neighbourhood (0: two-launch path, 1: k_icc_iter).
-  int mg;
-  int rec_model;          // k_icc_bin stores model points (the bins feed k_icc_iter)
   int uniform_ns;         // > 0: every scene holds exactly this many objects (scene tables need no load)
-  int64_t rec_stride;     // records of one of the TWO record buffers (k_icc_iter reads one, fills the other)
-  int64_t par_cnt;        // words of bin_cnt per parity = 2 * O * nbins (three parities)
   int xcd_order;          // k_icc_fused: XCD-contiguous logical workgroup order (see there)
 };
 
@@ -208,7 +200,7 @@ __global__ __launch_bounds__(256) void k_icc_scene_setup(IccArgs a, int32_t step
 
 // Start of a loss evaluation / refinement: R|t from (q, t) (both copies); empty accumulators, per-grid
 // maxima and bin counters of every parity; traj[0] = the initial pose.  One workgroup per object.
-constexpr int kParities = 3;  // k_icc_iter rotates three parities (read / add into / empty); the two-launch path two
+constexpr int kParities = 2;  // iteration k fills parity k & 1 while the folded step reads (k - 1) & 1 and empties it
 __global__ __launch_bounds__(256) void k_icc_pose(IccArgs a, const float *__restrict__ q,
                                                   const float *__restrict__ t, float *traj) {
   const int o = blockIdx.x;
@@ -250,7 +242,7 @@ constexpr int kBinThreads = 256;
 constexpr int kBinPPT = 4;                          // points per thread (2: 23.0 vs 23.1 us/iteration, twice the redundant steps)
 constexpr int kBinChunk = kBinThreads * kBinPPT;    // points per workgroup
 constexpr int kHalves = 2;                          // y-halves of a plane: rows [0, D/2), [D/2, D)
-constexpr int kMaxBins = kHalves * (64 + 8);        // D <= 64, ks <= 7, + one margin plane per side (k_icc_iter's bins)
+constexpr int kMaxBins = kHalves * (64 + 8);        // D <= 64, ks <= 7, + one margin plane per side 
 constexpr int kBinShare = 8;                        // a bin holds 1/8 of its grid's source points ...
 constexpr int kBinMinCap = 64;                      // ... at least this many, the rest overflows
 
@@ -319,9 +311,6 @@ struct IccStepArgs {
   float *loss_out;                         // [S] or NULL
   float *gq_out, *gt_out;                  // mode 2
   float *traj;                             // [n_iter][O][7] or NULL
-  // k_icc_step between k_icc_iter launches: which R|t copy it writes, and the parities (+ 1; 0 = none) whose
-  // accumulators / maxima and bin counters of this object it empties
-  int rt_w, zero_acc1, zero_bin1;
 };
 
 // The calling workgroup (NT lanes) gathers the kStepSums sums of object j into s_sum.  Every
@@ -376,7 +365,7 @@ __device__ __forceinline__ void icc_step_gather(const IccArgs &a, int par, int j
   __syncthreads();
 }
 
-// The same for the single-pass path (k_icc_fused / k_icc_iter): the accumulators hold the monomial sums, the
+// The same for the single-pass path (k_icc_fused): the accumulators hold the monomial sums, the
 // per-grid maxima M_own / M_oth give a = 1/M_own, b = 1/M_oth (b = 0 where the "other" grid is
 // empty or absent: iterative_collision_check_link.py:62-63,82), and the lanes form the sums the
 // step expects (see the table above k_icc_fused).  Staged words, all converted to float by the lane that
@@ -639,9 +628,7 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
   }
   const float R0 = r0.x, R1 = r0.y, R2 = r0.z, R3 = r0.w, R4 = r1.x, R5 = r1.y, R6 = r1.z,
               R7 = r1.w, R8 = r2.x, T0 = r2.y, T1 = r2.z, T2 = r2.w;
-  // a.mg > 0 (bins that feed k_icc_iter): a record reaches a.mg planes / rows further than its kernel
-  // neighbourhood, so that the reader still finds it after one optimiser step has moved the point
-  const int h = min(ksize_of(a.thr, pitch) / 2, hmax) + a.mg;
+  const int h = min(ksize_of(a.thr, pitch) / 2, hmax);
   const float fh = (float)h, inv_pitch = 1.0f / pitch;
   {
     // whole-object rejection with the model's bounding sphere (conservative, block-uniform)
@@ -676,7 +663,7 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
       const bool surv = rx + fh >= 0.0f && rx - fh < (float)D && ry + fh >= 0.0f &&
                         ry - fh < (float)D && rz + fh >= 0.0f && rz - fh < (float)D;
       if (surv) {
-        const int plane = (int)rx + hmax + a.mg;  // in [0, D + 2 (hmax + mg))
+        const int plane = (int)rx + hmax;  // in [0, D + 2 hmax)
         const int iry = (int)ry;
         if (iry - h < Dh) {
           bin[u][0] = plane * kHalves;
@@ -704,9 +691,7 @@ __global__ __launch_bounds__(kBinThreads) void k_icc_bin(IccArgs a, IccStepArgs 
     for (int hf = 0; hf < kHalves; ++hf) {
       if (bin[u][hf] < 0) continue;
       const int idx = s_base[bin[u][hf]] + slot[u][hf];
-      const float4 r = a.rec_model
-                           ? make_float4(m[u].x, m[u].y, m[u].z, __uint_as_float((uint32_t)p | ((uint32_t)(j - e2.x) << 27)))
-                           : make_float4(fx[u], fy[u], fz[u], __uint_as_float((uint32_t)p));
+      const float4 r = make_float4(fx[u], fy[u], fz[u], __uint_as_float((uint32_t)p));
       if (idx < cap) {
         a.rec[base_g + (int64_t)bin[u][hf] * cap + idx] = r;
       } else {  // bin full: the grid's overflow list (its tiles find the record by the membership test)
@@ -1254,7 +1239,7 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
 // second launch, no dependent re-load of what the tile just computed.  Same arithmetic per
 // voxel as k_icc_accum up to the association of the normaliser (tests: loss within 2e-5,
 // step within 1e-5 of the oracle's).  Grids with other values take the two-kernel path.
-// LDS of the voxel phase (shared by k_icc_fused and k_icc_iter)
+// LDS of the voxel phase (k_icc_fused)
 struct VoxLds {
   float rows[kTileThreads / 16][kNumF + 1];
   float max[2][kTileThreads / 64];
@@ -1271,7 +1256,7 @@ struct FusedLds {
   int off[kMaxSceneObjects + 1];
 };
 
-// Constants of one padded half-plane tile (k_icc_fused / k_icc_iter, kernel size 3).
+// Constants of one padded half-plane tile (k_icc_fused, kernel size 3).
 struct Tile3 {
   int Wp, rows_p, y0;
   float fxp, pitch, trunc, d2_in;
@@ -1791,633 +1776,6 @@ __global__ __launch_bounds__(kTileThreads, MF_ICC_FUSED_WPE) void k_icc_fused(Ic
     icc_fused_body<0>(a, ks, par, L, o, tile_);
 }
 
-// ---- ONE launch per iteration (round 5): k_icc_iter ------------------------------------------------------
-// The two-launch iteration is bin(k) -> boundary -> tiles(k) -> boundary: two kernel boundaries, ~6 dependent memory
-// round trips and the serial optimiser step on the critical path (23.7 us at 1 scene x 8 objects, rounds 2-4).  The
-// pose of iteration k needs the sums of ALL tiles of k - 1 (one global dependency per iteration is inherent), but the
-// bins need not be built from the CURRENT pose: a tile of iteration k reads the bins that iteration k - 1 built from
-// pose k - 1 -- with one plane / row of margin -- and transforms the records (MODEL points) with pose k itself; the
-// same launch bins pose k for iteration k + 1.  Per workgroup = (object o, x-plane, y-half), 512 lanes:
-//   1. ONE round trip: the reduced sums / maxima / optimiser state of EVERY object of the scene (all lanes fetch and
-//      convert; the index arithmetic is multiplications by reciprocals), the previous R|t, its slice of the scene's
-//      points (bin duty); the LAST wave reads the bin counters of planes x-2 .. x+2 of both grids and cuts them
-//      into 64-record blocks meanwhile.  Then the sums (lane = (sum, object): a wave takes one branch) and the step
-//      of every scene object on 16 lanes each (icc_step_lanes; Ns / 4 waves -- the first version ran the
-//      serial step and a divergent gather in all eight waves of all 512 workgroups: 10 us of instruction issue).
-//      The workgroup (o, 0, 0) stores object o's state / R|t / trajectory row / loss and empties the parity after
-//      next.  The record loads are in flight meanwhile.
-//   2. how far did each object move since the bins were built?  (|dR c + dt| + |dR| r) / pitch per axis over its
-//      bounding sphere: < 1 voxel -> its records are in the margin bins for certain (rounded coordinates move by
-//      at most one).  Otherwise (rare: the first iterations, a gradient spike) the object's points are read from the
-//      point array directly -- exact either way.
-//   3. records -> numerators of the voxel-frame coordinates (the oracle's expressions) -> a cheap conservative
-//      membership test on reciprocal multiplies -> survivor list in LDS; pass 1 divides exactly (IEEE), applies the
-//      exact membership test and runs the TDF minimum; pass 2 and the voxel phase are k_icc_fused's, unchanged
-//      (shared code: the same bits).
-//   4. bin duty, interleaved: 1/64 of the scene's points against grid o with this pose -> counted per (plane, half)
-//      in LDS -> one global atomic per touched bin -> model-point records for iteration k + 1.
-// Accumulators, maxima and bin counters rotate over THREE parities (read by the step / added into / emptied by the
-// step kernel), records and R|t over two.  Scenes of more than kIterMaxNs objects, kernel sizes other than 3 and non-{0,1} no-entry grids
-// keep the two-launch path.
-constexpr int kIterMaxNs = 16;
-constexpr int kIterBlk = 8;                                   // 64-record blocks a wave keeps in registers
-constexpr int kIterMaxBlk = kIterBlk * (kTileThreads / 64);   // 4096 records per tile before the membership test
-constexpr int kIterBins = kHalves * (32 + 2 * 2);             // real bins of a grid (D <= 32, kernel 3, margin 1)
-constexpr int kIterSegs = 12;                                 // per grid kind: 5 planes + the overflow list
-// voxels an object may move under margin 1 (tests build with -DMF_ITER_MOVE_MAX=-1.0f: every object counts as
-// moved, every tile takes the re-read + streaming form; -DMF_ITER_SURV_CAP=n: tiny survivor lists overflow)
-#ifndef MF_ITER_MOVE_MAX
-#define MF_ITER_MOVE_MAX 0.98f
-#endif
-constexpr float kIterMoveMax = MF_ITER_MOVE_MAX;
-
-struct IterPar {
-  int acc_r, acc_w, acc_z;  // accumulators / maxima: read by the step, added into by the tiles, emptied
-  int bin_r, bin_w, bin_z;  // bin counters: read by the tiles, filled by the bin duty, emptied
-  int rec_r, rec_w;  // record buffers
-  int rt_r, rt_w;    // R|t copies: the pose the read bins were built from / this iteration's pose
-};
-
-struct IterLds {
-  float sum[kIterMaxNs][kStepSums];
-  float state[kIterMaxNs][kStateFloats];
-  float xg[kIterMaxNs][kStepLaneWords];
-  float Rt[kIterMaxNs][12];
-  int off[kIterMaxNs + 1];
-  uint2 blk[kIterMaxBlk];  // {first record (index into the read buffer), records | grid kind << 31}
-  int bcnt[2 * kIterBins], bbase[2 * kIterBins];
-  int nlist, ovf, nblk;
-  unsigned moved, hit;
-};
-
-// dynamic LDS of k_icc_iter: [dist | id: 4 nvh words][union: staged step words | survivor list | VoxLds + rows2]
-__host__ __device__ inline size_t iter_union_bytes(int max_ns) {
-  return sizeof(VoxLds) + (size_t)max_ns * (kTileThreads / 16) * 13 * sizeof(float);
-}
-
-__global__ __launch_bounds__(kTileThreads, 4) void k_icc_iter(IccArgs a, IccStepArgs sp, IterPar ip) {
-  mf::warm_kernargs((int)(sizeof(IccArgs) + sizeof(IccStepArgs) + sizeof(IterPar)) + 16);
-  MF_DYN_LDS(uint32_t, s_dyn);
-  __shared__ IterLds L;
-  constexpr int h = 1, K = 27;
-  const int D = a.D, nb = a.nbins, V = D * D * D, nbr = nb - 1;
-  // Workgroups w and w + 256 share a CU (512 resident workgroups, dispatched round-robin over the XCDs and their
-  // CUs): rotating the planes by D / 2 in every other block of 256 puts a central (crowded) plane next to an outer
-  // (empty) one instead of next to the central plane of another object.
-  const int o = blockIdx.y;
-  const int tile = (int)((blockIdx.x + (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1u) * (gridDim.x / 2)) % gridDim.x);
-  const int x = tile / kHalves, half = tile % kHalves;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Dh = (D + 1) / 2;
-  const int y0 = half * Dh, y1 = half == 0 ? Dh : D;
-  const int Wp = D + 2 * kPad, rows_p = Dh + 2 * kPad;
-  const int nvh = rows_p * Wp, nvox = (y1 - y0) * D;
-  const int mg = a.mg, poff = a.hmax + mg;  // plane index of a rounded x: rx + poff
-  uint32_t *s_dist = s_dyn, *s_id = s_dyn + 2 * nvh;
-  unsigned char *s_un = reinterpret_cast<unsigned char *>(s_dyn + 4 * nvh);
-  VoxLds &Vx = *reinterpret_cast<VoxLds *>(s_un);
-  float *s_rows2 = reinterpret_cast<float *>(s_un + sizeof(VoxLds));
-  // survivor list: pushed as {wx - ox, wy - oy, wz - oz, id | kind << 29} (numerators of the voxel-frame
-  // coordinates); pass 1 divides exactly, tests membership and rewrites {fx, fy, fz, id | plane << 27 | kind << 29}
-  float4 *s_surv = reinterpret_cast<float4 *>(s_un);
-  float *s_f = reinterpret_cast<float *>(s_un);  // staged accumulator words of the step (dead before the list is filled)
-#ifdef MF_ITER_SURV_CAP
-  const int surv_cap = MF_ITER_SURV_CAP;
-#else
-  const int surv_cap = (int)(iter_union_bytes(a.max_ns) / sizeof(float4));
-#endif
-
-  int ja, Ns, sc;
-  if (a.uniform_ns > 0) {
-    Ns = a.uniform_ns; sc = o / Ns; ja = sc * Ns;
-  } else {
-    const int4 meta = a.meta[o];
-    ja = meta.x; Ns = meta.y - meta.x; sc = a.obj_scene[o];
-  }
-  const int jj_o = o - ja;
-  const bool designated = tile == 0;  // stores object o's step and empties its words of the parity after next
-  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-  auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32): [wg][0..7] times, [2048 + wg][0..7] counts
-    if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) g_dbg_stamps[wg * 8 + i] = wall_clock64();
-  };
-  stamp(0);
-  auto sub = [&](int i) {  // finer stamps of the first phases: [1024 + wg][i], by the calling wave's first lane
-    if (MF_DBG(a, 32) && (threadIdx.x & 63) == 0 && wg < 1024) g_dbg_stamps[(1024 + wg) * 8 + i] = wall_clock64();
-  };
-
-  // ---- 1. everything that depends on (o, tile) and the tables only: one round trip ----
-  const float pitch = a.pitch[o];
-  const float ox = a.origin[3 * o], oy = a.origin[3 * o + 1], oz = a.origin[3 * o + 2];
-  const float inv_pitch = 1.0f / pitch;
-  float ne0 = 0.0f, tg0 = 0.0f;
-  if (tid < nvox) {
-    const int64_t gv = (int64_t)o * V + ((int64_t)x * D + y0) * D + tid;
-    ne0 = a.grid_ne[gv];
-    tg0 = a.grid_target[gv];
-  }
-  if (tid >= 64 && tid <= 64 + Ns) L.off[tid - 64] = a.obj_off[ja + tid - 64];
-  // movement / reach of scene object jl under this iteration's pose Rt (vs the pose Rq the read bins were built
-  // from): how far can a point of it have moved, in voxels of grid o, per axis, over its bounding sphere; does the
-  // object reach grid o at all (margin included)?
-  auto reach = [&](const float *Rt, const float *Rq, const float4 bnd, bool &hit, bool &mvd) {
-    const float cx = bnd.x, cy = bnd.y, cz = bnd.z, br = bnd.w;
-    float dmax = 0.0f;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const float e0 = Rt[3 * d] - Rq[3 * d], e1 = Rt[3 * d + 1] - Rq[3 * d + 1], e2 = Rt[3 * d + 2] - Rq[3 * d + 2];
-      const float dt = Rt[9 + d] - Rq[9 + d];
-      const float mv = fabsf(((e0 * cx + e1 * cy) + e2 * cz) + dt) + sqrtf((e0 * e0 + e1 * e1) + e2 * e2) * fmaxf(br, 0.0f);
-      dmax = fmaxf(dmax, mv * inv_pitch);
-    }
-    const float fh = (float)(h + mg);
-    const float glo = -fh - 0.51f, ghi = (float)(D - 1) + fh + 0.51f;
-    const float gx = (((Rt[0] * cx + Rt[1] * cy) + Rt[2] * cz) + Rt[9] - ox) * inv_pitch;
-    const float gy = (((Rt[3] * cx + Rt[4] * cy) + Rt[5] * cz) + Rt[10] - oy) * inv_pitch;
-    const float gz = (((Rt[6] * cx + Rt[7] * cy) + Rt[8] * cz) + Rt[11] - oz) * inv_pitch;
-    const float r = br * inv_pitch + 0.05f + 1e-4f * (fabsf(gx) + fabsf(gy) + fabsf(gz));
-    hit = br >= 0.0f && !(gx + r < glo || gx - r > ghi || gy + r < glo || gy - r > ghi || gz + r < glo || gz - r > ghi);
-    // an object that moved too far (or whose pose is not finite) is re-read from the point array -- if it can
-    // reach this grid at all
-    mvd = !(dmax <= kIterMoveMax) && br >= 0.0f && (hit || !(dmax == dmax));
-  };
-  // the pose the read bins were built from and the bounding sphere: lane 16 jj of the step groups (mode 1) /
-  // lane jj (mode 0: no step, this iteration's pose is in memory too)
-  const bool pose_lane = sp.mode != 0 ? (tid < 16 * Ns && (tid & 15) == 0) : tid < Ns;
-  const int pose_jj = sp.mode != 0 ? tid >> 4 : tid;
-  float Rq[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  float4 bnd = make_float4(0, 0, 0, -1.0f);
-  if (pose_lane) {
-    const float4 *Rp = reinterpret_cast<const float4 *>(a.Rt + ((int64_t)ip.rt_r * a.O + ja + pose_jj) * 12);
-    const float4 p0 = Rp[0], p1 = Rp[1], p2 = Rp[2];
-    bnd = *reinterpret_cast<const float4 *>(a.bound + 4 * (ja + pose_jj));
-    Rq[0] = p0.x; Rq[1] = p0.y; Rq[2] = p0.z; Rq[3] = p0.w; Rq[4] = p1.x; Rq[5] = p1.y; Rq[6] = p1.z; Rq[7] = p1.w;
-    Rq[8] = p2.x; Rq[9] = p2.y; Rq[10] = p2.z; Rq[11] = p2.w;
-  }
-  const float S_t = sp.mode != 0 ? a.St[sc] : 1.0f;
-  const float invNs = 1.0f / (float)Ns;
-  const int nA = 8 * Ns, nB = 12 * Ns * Ns, nf = nA + nB + 60 * Ns;
-  if (tid == 0) { L.nlist = 0; L.ovf = 0; L.moved = 0u; L.hit = 0u; }
-  if (sp.mode != 0) {
-    // the reduced sums / maxima of the previous iteration for EVERY object of the scene (the step of each is
-    // needed: their points are the "other" records), every word converted by the lane that fetched it
-    const long long *own = a.acc_own + (int64_t)ip.acc_r * a.O * kOwnSlots;
-    const long long *oth = a.acc_oth + (int64_t)ip.acc_r * a.O * a.max_ns * 12;
-    const uint32_t *Mb = a.Mbits + (int64_t)ip.acc_r * 2 * a.O;
-    // Four words per lane and trip, ONE unconditional 8-byte load each from a selected address (the maxima are
-    // 4-byte words: the aligned pair is loaded and the half selected): every load of a trip is in flight before the
-    // first conversion.  (Loads behind per-region branches were each preceded by a wait for the one before: three
-    // to twelve dependent memory round trips.)
-    constexpr int kG = 4;
-    const long long *Mb8 = reinterpret_cast<const long long *>(Mb);
-    for (int i0 = 0; i0 < nf; i0 += kG * kTileThreads) {
-      long long raw[kG];
-      int reg[kG];  // 0: fixed point 2^32, 1: 2^40, 2: non-finite flag, 3: 1/M_own, 4: 1/M_oth
-#pragma unroll
-      for (int u = 0; u < kG; ++u) {
-        const int i = min(i0 + u * kTileThreads + tid, nf - 1);
-        // region A: per scene object {5 sums, flag, M_own, M_oth}
-        const int objA = ja + (i >> 3), lA = i & 7;
-        const long long *pA = lA < 6 ? own + (int64_t)objA * kOwnSlots + (lA < 5 ? lA : kNumF) : Mb8 + objA;
-        // region B: [jj][jo][12] collision moments onto jj from the grid of jo
-        const int kB = max(i - nA, 0), rB = kB / 12, cB = kB - 12 * rB;
-        const int jjB = (int)(((float)rB + 0.5f) * invNs), joB = rB - jjB * Ns;
-        const long long *pB = oth + ((int64_t)(ja + joB) * a.max_ns + jjB) * 12 + cB;
-        // region C: the 60 own-gradient moments of jj
-        const int kC = max(i - nA - nB, 0), jjC = kC / 60;
-        const long long *pC = own + (int64_t)(ja + jjC) * kOwnSlots + 5 + (kC - 60 * jjC);
-        const long long *pp = i < nA ? pA : i < nA + nB ? pB : pC;
-        reg[u] = i < nA ? (lA < 5 ? 0 : lA == 5 ? 2 : lA - 3) : i < nA + nB ? 1 : 0;
-        raw[u] = *pp;
-      }
-#pragma unroll
-      for (int u = 0; u < kG; ++u) {
-        const int i = i0 + u * kTileThreads + tid;
-        // the conversions of fused_item_scene / _oth / _own
-        const float f0 = (float)((double)raw[u] * (1.0 / kFixOwn));
-        const float f1 = (float)((double)raw[u] * (1.0 / kFixOth));
-        const float f2 = raw[u] != 0 ? 1.0f : 0.0f;
-        const float M = __uint_as_float(reg[u] == 4 ? (uint32_t)((unsigned long long)raw[u] >> 32) : (uint32_t)raw[u]);
-        const float f3 = reg[u] == 3 ? 1.0f / M : ((Ns > 1 && M != 0.0f) ? 1.0f / M : 0.0f);
-        const float fv = reg[u] == 0 ? f0 : reg[u] == 1 ? f1 : reg[u] == 2 ? f2 : f3;
-        if (i < nf) s_f[i] = fv;
-      }
-    }
-    if (wave == 0) sub(0);
-    for (int i = tid; i < kStateFloats * Ns; i += kTileThreads) {
-      const int jj = i / kStateFloats, c = i - kStateFloats * jj, j = ja + jj;
-      L.state[jj][c] = c < 4 ? sp.q_in[4 * j + c] : c < 7 ? sp.t_in[3 * j + c - 4]
-                       : c < 14 ? sp.m_in[7 * j + c - 7] : sp.v_in[7 * j + c - 14];
-    }
-  } else if (pose_lane) {
-    const float4 *Rc = reinterpret_cast<const float4 *>(a.Rt + ((int64_t)ip.rt_w * a.O + ja + pose_jj) * 12);
-    const float4 c0 = Rc[0], c1 = Rc[1], c2 = Rc[2];
-    *reinterpret_cast<float4 *>(&L.Rt[pose_jj][0]) = c0;
-    *reinterpret_cast<float4 *>(&L.Rt[pose_jj][4]) = c1;
-    *reinterpret_cast<float4 *>(&L.Rt[pose_jj][8]) = c2;
-    const float Rt[12] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
-    bool hit, mvd;
-    reach(Rt, Rq, bnd, hit, mvd);
-    if (hit) atomicOr(&L.hit, 1u << pose_jj);
-    if (mvd) atomicOr(&L.moved, 1u << pose_jj);
-  }
-  if (wave == 0) sub(1);
-  if (wave == kTileThreads / 64 - 1) {
-    // block table of this tile's records (pose-independent, on the last wave while the first ones step): the 12
-    // segment sizes (planes x-2 .. x+2 and the overflow list of the own and the other grid) cut into 64-record blocks
-    const uint32_t *cnt_r = a.bin_cnt + (int64_t)ip.bin_r * a.par_cnt;
-    int n_s[kIterSegs];
-    uint32_t r_s[kIterSegs];
-#pragma unroll
-    for (int kd = 0; kd < 2; ++kd) {
-      const int g = 2 * o + kd;
-      const int cap = a.bin_cap[g];
-      const int64_t base = a.bin_base[g];
-      const bool on = kd == 0 || Ns > 1;
-#pragma unroll
-      for (int b = 0; b < 5; ++b) {  // plane x - 2 + b has index x + b (poff = 2)
-        const int bin = (x - h - mg + poff + b) * kHalves + half;
-        n_s[kd * 6 + b] = on ? min((int)cnt_r[(int64_t)g * nb + bin], cap) : 0;
-        r_s[kd * 6 + b] = (uint32_t)(base + (int64_t)bin * cap);
-      }
-      n_s[kd * 6 + 5] = on ? min((int)cnt_r[(int64_t)g * nb + nbr], 2 * a.bin_pts[g]) : 0;
-      r_s[kd * 6 + 5] = (uint32_t)(base + (int64_t)nbr * cap);
-    }
-    int pb[kIterSegs + 1];
-    pb[0] = 0;
-#pragma unroll
-    for (int s = 0; s < kIterSegs; ++s) pb[s + 1] = pb[s] + (n_s[s] + 63) / 64;
-    if (lane == 0) L.nblk = pb[kIterSegs];
-    // lane b describes block b (a tile beyond kIterMaxBlk blocks takes the streaming path)
-    for (int b = lane; b < min(pb[kIterSegs], kIterMaxBlk); b += 64) {
-      int s = 0;
-#pragma unroll
-      for (int k = 1; k < kIterSegs; ++k) s += b >= pb[k] ? 1 : 0;
-      int ps = 0, ns = 0;
-      uint32_t rs = 0u;
-#pragma unroll
-      for (int k = 0; k < kIterSegs; ++k) {
-        ps = k == s ? pb[k] : ps;
-        ns = k == s ? n_s[k] : ns;
-        rs = k == s ? r_s[k] : rs;
-      }
-      const int first = (b - ps) * 64;
-      L.blk[b] = make_uint2(rs + (uint32_t)first, (uint32_t)min(64, ns - first) | (s >= 6 ? 0x80000000u : 0u));
-    }
-    sub(2);
-  }
-  for (int i = tid; i < 2 * nvh; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
-  for (int i = tid; i < 2 * kIterBins; i += kTileThreads) L.bcnt[i] = 0;
-  if (wave == 0) sub(3);
-  __syncthreads();  // A: tables, poses, masks
-  stamp(1);
-
-  // the record loads
-  const float4 *rec_r = a.rec + (int64_t)ip.rec_r * a.rec_stride;
-  const int nblk = L.nblk;
-  float4 rv[kIterBlk];
-  uint32_t rinfo[kIterBlk];  // kind << 31 | valid
-#pragma unroll
-  for (int u = 0; u < kIterBlk; ++u) {
-    const int b = wave + u * (kTileThreads / 64);
-    rinfo[u] = 0u;
-    rv[u] = make_float4(0, 0, 0, 0);
-    if (b < nblk && b < kIterMaxBlk) {  // wave-uniform
-      const uint2 e = L.blk[b];
-      if (lane < (int)(e.y & 0x7fffffffu)) {
-        rv[u] = rec_r[e.x + (uint32_t)lane];
-        rinfo[u] = (e.y & 0x80000000u) | 1u;
-      }
-    }
-  }
-  // the bin duty's points: slice `tile` of the scene's points (one per lane and trip)
-  const int pa = L.off[0], pb_ = L.off[Ns];
-  const int slice = (pb_ - pa + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int p_lo = pa + tile * slice, p_hi = min(p_lo + slice, pb_);
-  const int ntrip = (slice + kTileThreads - 1) / kTileThreads;
-  float4 bm = make_float4(0, 0, 0, 0);
-  if (p_lo + tid < p_hi) bm = a.pts4[p_lo + tid];
-  if (wave == 0) sub(4);
-
-  if (sp.mode != 0) {
-    // the kStepSums sums of every scene object, lane = (sum l, object jj) with l slowest: the lanes of a wave take
-    // the same branch of fused_sum
-    for (int i = tid; i < kStepSums * Ns; i += kTileThreads) {
-      const int l = (int)(((float)i + 0.5f) * invNs), jj = i - l * Ns;
-      L.sum[jj][l] = fused_sum(l, Ns, jj, s_f, s_f + nA + jj * 12 * Ns, s_f + nA + nB + 60 * jj);
-    }
-    if (wave == 0) sub(5);
-    __syncthreads();  // B: sums
-    stamp(2);
-    // ---- 2. the step of every scene object: 16 lanes each ----
-    if ((tid & ~63) < 16 * Ns) {  // wave-uniform
-      const int jj = min(tid >> 4, Ns - 1), c = tid & 15;
-      float Rt[12], loss, gq[4], gt[3];
-      icc_step_lanes(L.sum[jj], S_t, L.state[jj], sp, c, L.xg[jj], Rt, loss, gq, gt);
-      if (pose_lane) {
-        const int j = ja + jj;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) L.Rt[jj][i] = Rt[i];
-        bool hit, mvd;
-        reach(Rt, Rq, bnd, hit, mvd);
-        if (hit) atomicOr(&L.hit, 1u << jj);
-        if (mvd) atomicOr(&L.moved, 1u << jj);
-        if (designated && jj == jj_o) {
-          const float *st_new = L.xg[jj] + 12;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) sp.q_out[4 * j + i] = st_new[i];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) sp.t_out[3 * j + i] = st_new[4 + i];
-#pragma unroll
-          for (int i = 0; i < 7; ++i) { sp.m_out[7 * j + i] = st_new[7 + i]; sp.v_out[7 * j + i] = st_new[14 + i]; }
-          float *Rw = a.Rt + ((int64_t)ip.rt_w * a.O + j) * 12;
-#pragma unroll
-          for (int i = 0; i < 12; ++i) Rw[i] = Rt[i];
-          if (sp.traj) {
-            float *tr = sp.traj + ((int64_t)sp.it * a.O + j) * 7;
-#pragma unroll
-            for (int i = 0; i < 7; ++i) tr[i] = st_new[i];
-          }
-          if (sp.loss_out && j == ja) sp.loss_out[sc] = loss;
-        }
-      }
-    } else if (designated) {
-      // the other waves of the designated workgroup: this object's accumulators, maxima and bin counters of the
-      // parity the launch after next adds into / fills
-      const int z0 = (16 * Ns + 63) & ~63;  // first lane of the first wave without a step group
-      const int t2 = tid - z0, nt2 = kTileThreads - z0;
-      if (t2 >= 0) {
-        if (t2 < 2) a.Mbits[(int64_t)ip.acc_z * 2 * a.O + 2 * o + t2] = 0;
-        long long *own = a.acc_own + ((int64_t)ip.acc_z * a.O + o) * kOwnSlots;
-        for (int i = t2; i < kOwnSlots; i += nt2) own[i] = 0;
-        long long *oth = a.acc_oth + ((int64_t)ip.acc_z * a.O + o) * a.max_ns * 12;
-        for (int i = t2; i < a.max_ns * 12; i += nt2) oth[i] = 0;
-        uint32_t *cz = a.bin_cnt + (int64_t)ip.bin_z * a.par_cnt + (int64_t)(2 * o) * nb;
-        for (int i = t2; i < 2 * nb; i += nt2) cz[i] = 0u;
-      }
-    }
-    __syncthreads();  // C: poses, moved / hit masks
-    stamp(3);
-  }
-
-  const float trunc = a.thr * pitch;
-  const float d2_hi = a.thr * a.thr * 1.00002f, d2_in = a.thr * a.thr * 0.999f;
-  Tile3 tl;
-  tl.Wp = Wp; tl.rows_p = rows_p; tl.y0 = y0; tl.fxp = (float)x; tl.pitch = pitch; tl.trunc = trunc; tl.d2_in = d2_in;
-  tl.hi_bits = __float_as_uint(d2_hi) - 1u;
-  tl.in_bits = __float_as_uint(d2_in);
-  const unsigned moved = L.moved, hitm = L.hit;
-  const float fD = (float)D;
-
-  // voxel-frame coordinates (the oracle's (p - origin) / pitch, correctly rounded) -> is it a record of THIS tile
-  // (plane x-1 .. x+1, rows of this half, inside the grid's reach)?  `pl` = its plane's offset.
-  auto member = [&](const float fx, const float fy, const float fz, int &pl) -> bool {
-    const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
-    const float fh = (float)h;
-    const bool surv = rx + fh >= 0.0f && rx - fh < fD && ry + fh >= 0.0f && ry - fh < fD && rz + fh >= 0.0f &&
-                      rz - fh < fD;
-    pl = (int)rx - (x - h);
-    const int iry = (int)ry;
-    const bool in_half = half == 0 ? (iry - h < Dh) : (iry + h >= Dh);
-    return surv && pl >= 0 && pl < 3 && in_half;
-  };
-  // model point of scene-local object jl -> numerators (world point - grid origin; transform_points un-fused,
-  // the oracle's expressions)
-  auto numer = [&](const float mx, const float my, const float mz, const int jl, float &nx, float &ny, float &nz) {
-    const float4 q0 = *reinterpret_cast<const float4 *>(&L.Rt[jl][0]);
-    const float4 q1 = *reinterpret_cast<const float4 *>(&L.Rt[jl][4]);
-    const float4 q2 = *reinterpret_cast<const float4 *>(&L.Rt[jl][8]);
-    nx = (((q0.x * mx + q0.y * my) + q0.z * mz) + q2.y) - ox;
-    ny = (((q0.w * mx + q1.x * my) + q1.y * mz) + q2.z) - oy;
-    nz = (((q1.z * mx + q1.w * my) + q2.x * mz) + q2.w) - oz;
-  };
-  auto classify = [&](const float mx, const float my, const float mz, const int jl, float &fx, float &fy, float &fz,
-                      int &pl) -> bool {
-    float nx, ny, nz;
-    numer(mx, my, mz, jl, nx, ny, nz);
-    fx = nx / pitch; fy = ny / pitch; fz = nz / pitch;
-    return member(fx, fy, fz, pl);
-  };
-  // cheap conservative form of the same test on reciprocal-multiplied coordinates (|error| < 1e-4 voxel): every
-  // member passes, the few extra near a boundary are dropped by the exact test in pass 1
-  const float xlo = (float)x - 1.5f - 1e-3f, xhi = (float)x + 1.5f + 1e-3f;
-  const float ylo = (half == 0 ? -1.5f : (float)Dh - 1.5f) - 1e-3f, yhi = (half == 0 ? (float)Dh + 0.5f : fD + 0.5f) + 1e-3f;
-  const float zlo = -1.5f - 1e-3f, zhi = fD + 0.5f + 1e-3f;
-  auto maybe_member = [&](const float nx, const float ny, const float nz) -> bool {
-    const float ax = nx * inv_pitch, ay = ny * inv_pitch, az = nz * inv_pitch;
-    return ax >= xlo && ax <= xhi && ay >= ylo && ay <= yhi && az >= zlo && az <= zhi;
-  };
-  auto visit_word = [&](const int pass, const float fx, const float fy, const float fz, const uint32_t w) {
-    const int kd = (int)(w >> 29) & 1;
-    icc_visit3(pass, s_dist + kd * nvh, s_id + kd * nvh, tl, fx, fy, fz, w & 0x7ffffffu, (int)(w >> 27) & 3);
-  };
-
-  // bin duty, stage A: my point against grid o with this pose -> LDS counters
-  int bbin[kHalves] = {-1, -1}, bslot[kHalves] = {0, 0};
-  uint32_t bword = 0u;
-  auto bin_count = [&](const float4 m, const int p) {
-    bbin[0] = bbin[1] = -1;
-    if (p >= p_hi) return;
-    int jl = 0;
-    for (int k = 1; k < Ns; ++k) jl += p >= L.off[k] ? 1 : 0;
-    if (!((hitm >> jl) & 1u)) return;
-    float nx, ny, nz;
-    numer(m.x, m.y, m.z, jl, nx, ny, nz);
-    // (reciprocal multiplies: a bin key that is one off at an exact .5 is inside what kIterMoveMax < 1 leaves of
-    // the margin; the readers test membership exactly)
-    const float fx = nx * inv_pitch, fy = ny * inv_pitch, fz = nz * inv_pitch;
-    const float rx = roundf(fx), ry = roundf(fy), rz = roundf(fz);
-    const int hh = h + mg;
-    const float fh = (float)hh;
-    const bool surv = rx + fh >= 0.0f && rx - fh < fD && ry + fh >= 0.0f && ry - fh < fD && rz + fh >= 0.0f &&
-                      rz - fh < fD;
-    if (!surv) return;
-    const int kd = jl == jj_o ? 0 : 1;
-    const int plane = (int)rx + poff, iry = (int)ry;
-    bword = (uint32_t)p | ((uint32_t)jl << 27);
-    if (iry - hh < Dh) {
-      bbin[0] = kd * kIterBins + plane * kHalves;
-      bslot[0] = atomicAdd(&L.bcnt[bbin[0]], 1);
-    }
-    if (iry + hh >= Dh) {
-      bbin[1] = kd * kIterBins + plane * kHalves + 1;
-      bslot[1] = atomicAdd(&L.bcnt[bbin[1]], 1);
-    }
-  };
-  uint32_t *cnt_w = a.bin_cnt + (int64_t)ip.bin_w * a.par_cnt + (int64_t)(2 * o) * nb;
-  // stage B: one global atomic per touched bin reserves the block's slots (value used in stage C)
-  auto bin_reserve = [&]() -> int {
-    int base = 0;
-    if (tid < 2 * kIterBins) {
-      const int c = L.bcnt[tid];
-      const int kd = tid / kIterBins, bin = tid - kd * kIterBins;
-      if (c > 0) base = (int)atomicAdd(&cnt_w[(int64_t)kd * nb + bin], (uint32_t)c);
-    }
-    return base;
-  };
-  float4 *rec_w = a.rec + (int64_t)ip.rec_w * a.rec_stride;
-  auto bin_store = [&](const float4 m) {
-#pragma unroll
-    for (int hf = 0; hf < kHalves; ++hf) {
-      if (bbin[hf] < 0) continue;
-      const int kd = bbin[hf] / kIterBins, bin = bbin[hf] - kd * kIterBins, g = 2 * o + kd;
-      const int cap = a.bin_cap[g];
-      const int64_t base_g = a.bin_base[g];
-      const int idx = L.bbase[bbin[hf]] + bslot[hf];
-      const float4 r = make_float4(m.x, m.y, m.z, __uint_as_float(bword));
-      if (idx < cap) {
-        rec_w[base_g + (int64_t)bin * cap + idx] = r;
-      } else {  // bin full: the grid's overflow list
-        const uint32_t k = atomicAdd(&cnt_w[(int64_t)kd * nb + nbr], 1u);
-        if ((int)k < 2 * a.bin_pts[g]) rec_w[base_g + (int64_t)nbr * cap + k] = r;
-      }
-    }
-  };
-
-  bin_count(bm, p_lo + tid);  // (the record loads are in flight)
-  // ---- 4. records -> survivors ----
-  const bool slow_pre = nblk > kIterMaxBlk || moved != 0u;  // block-uniform
-  if (!slow_pre) {
-    int npass = 0;
-    unsigned long long bal[kIterBlk];
-#pragma unroll
-    for (int u = 0; u < kIterBlk; ++u) {
-      bal[u] = 0ull;
-      if (wave + u * (kTileThreads / 64) >= nblk) continue;  // wave-uniform
-      bool ok = false;
-      if (rinfo[u] & 1u) {
-        const uint32_t bits = __float_as_uint(rv[u].w);
-        float nx, ny, nz;
-        numer(rv[u].x, rv[u].y, rv[u].z, (int)(bits >> 27), nx, ny, nz);
-        ok = maybe_member(nx, ny, nz);
-        rv[u] = make_float4(nx, ny, nz, __uint_as_float((bits & 0x7ffffffu) | ((rinfo[u] >> 31) << 29)));
-      }
-      rinfo[u] = ok ? 1u : 0u;
-      bal[u] = __ballot(ok);
-      npass += __popcll(bal[u]);
-    }
-    if (npass > 0) {  // wave-uniform
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&L.nlist, npass);
-      base = __shfl(base, 0);
-      int run = base;
-#pragma unroll
-      for (int u = 0; u < kIterBlk; ++u) {
-        if (bal[u] == 0ull) continue;
-        if (rinfo[u]) {
-          const int slot = run + __popcll(bal[u] & ((1ull << lane) - 1ull));
-          if (slot < surv_cap) s_surv[slot] = rv[u];
-          else L.ovf = 1;
-        }
-        run += __popcll(bal[u]);
-      }
-    }
-  }
-  __syncthreads();  // D: survivor list, LDS bin counters
-  stamp(4);
-  const bool slow = slow_pre || L.ovf != 0;  // block-uniform
-  // streaming form (rare): every source record again for each pass, visited under its membership predicate --
-  // bins first (records of moved objects skipped), then the points of the moved objects themselves
-  auto stream_pass = [&](const int pass) {
-    const uint32_t *cnt_r = a.bin_cnt + (int64_t)ip.bin_r * a.par_cnt;
-    for (int kd = 0; kd < (Ns > 1 ? 2 : 1); ++kd) {
-      const int g = 2 * o + kd;
-      const int cap = a.bin_cap[g];
-      const int64_t base = a.bin_base[g];
-      for (int b = 0; b < 6; ++b) {
-        const int bin = b < 5 ? (x - h - mg + poff + b) * kHalves + half : nbr;
-        const int n = b < 5 ? min((int)cnt_r[(int64_t)g * nb + bin], cap)
-                            : min((int)cnt_r[(int64_t)g * nb + nbr], 2 * a.bin_pts[g]);
-        const float4 *src = rec_r + base + (int64_t)bin * cap;
-        for (int i = tid; i < n; i += kTileThreads) {
-          const float4 r = src[i];
-          const uint32_t bits = __float_as_uint(r.w);
-          const int jl = (int)(bits >> 27);
-          if ((moved >> jl) & 1u) continue;
-          float fx, fy, fz;
-          int pl;
-          if (classify(r.x, r.y, r.z, jl, fx, fy, fz, pl))
-            visit_word(pass, fx, fy, fz, (bits & 0x7ffffffu) | ((uint32_t)pl << 27) | ((uint32_t)kd << 29));
-        }
-      }
-    }
-    for (unsigned mm = moved; mm != 0u; mm &= mm - 1u) {
-      const int jl = __ffs((int)mm) - 1;
-      const int kd = jl == jj_o ? 0 : 1;
-      for (int p = L.off[jl] + tid; p < L.off[jl + 1]; p += kTileThreads) {
-        const float4 m = a.pts4[p];
-        float fx, fy, fz;
-        int pl;
-        if (classify(m.x, m.y, m.z, jl, fx, fy, fz, pl))
-          visit_word(pass, fx, fy, fz, (uint32_t)p | ((uint32_t)pl << 27) | ((uint32_t)kd << 29));
-      }
-    }
-  };
-  const int nlist = slow ? 0 : L.nlist;
-  const int rbase = bin_reserve();  // global atomics in flight during pass 1
-  if (slow) {
-    stream_pass(1);
-  } else {
-    for (int i = tid; i < nlist; i += kTileThreads) {
-      const float4 e = s_surv[i];
-      const uint32_t w0 = __float_as_uint(e.w);
-      const float fx = e.x / pitch, fy = e.y / pitch, fz = e.z / pitch;  // the exact coordinates
-      int pl;
-      if (member(fx, fy, fz, pl)) {
-        const uint32_t w = w0 | ((uint32_t)pl << 27);
-        s_surv[i] = make_float4(fx, fy, fz, __uint_as_float(w));
-        visit_word(1, fx, fy, fz, w);
-      } else {
-        s_surv[i].w = __uint_as_float(0xffffffffu);  // passed the cheap test only
-      }
-    }
-  }
-  if (tid < 2 * kIterBins) L.bbase[tid] = rbase;
-  __syncthreads();  // E: pass 1, bin bases
-  stamp(5);
-  if (slow) {
-    stream_pass(2);
-  } else {
-    for (int i = tid; i < nlist; i += kTileThreads) {
-      const float4 e = s_surv[i];
-      const uint32_t w = __float_as_uint(e.w);
-      if (w != 0xffffffffu) visit_word(2, e.x, e.y, e.z, w);
-    }
-  }
-  bin_store(bm);
-  __syncthreads();  // F: pass 2; the survivor list is dead, its memory becomes the voxel phase's
-  stamp(6);
-  if (MF_DBG(a, 32) && threadIdx.x == 0 && wg < 2048) {
-    g_dbg_stamps[(2048 + wg) * 8 + 0] = (unsigned long long)nblk;
-    g_dbg_stamps[(2048 + wg) * 8 + 1] = (unsigned long long)nlist;
-    g_dbg_stamps[(2048 + wg) * 8 + 2] = (unsigned long long)(slow ? 1 : 0);
-    int nb_t = 0;
-    for (int i = 0; i < 2 * kIterBins; ++i) nb_t += L.bcnt[i] > 0 ? 1 : 0;
-    g_dbg_stamps[(2048 + wg) * 8 + 3] = (unsigned long long)nb_t;
-  }
-  for (int i = tid; i < Ns * (kTileThreads / 16) * 13; i += kTileThreads) s_rows2[i] = 0.0f;
-  for (int i = tid; i < (kTileThreads / 16) * (kNumF + 1); i += kTileThreads) (&Vx.rows[0][0])[i] = 0.0f;
-  // further trips of the bin duty (scenes of more than 64 x 512 points): the same three stages, serially
-  for (int trip = 1; trip < ntrip; ++trip) {
-    __syncthreads();
-    for (int i = tid; i < 2 * kIterBins; i += kTileThreads) L.bcnt[i] = 0;
-    __syncthreads();
-    const int p = p_lo + trip * kTileThreads + tid;
-    const float4 m = p < p_hi ? a.pts4[p] : make_float4(0, 0, 0, 0);
-    bin_count(m, p);
-    __syncthreads();
-    const int rb2 = bin_reserve();
-    if (tid < 2 * kIterBins) L.bbase[tid] = rb2;
-    __syncthreads();
-    bin_store(m);
-  }
-
-  TileGeom tg_;
-  tg_.o = o; tg_.ja = ja; tg_.Ns = Ns; tg_.x = x; tg_.y0 = y0; tg_.nvox = nvox; tg_.nvh = nvh; tg_.Wp = Wp; tg_.D = D;
-  tg_.K = K; tg_.pitch = pitch; tg_.trunc = trunc; tg_.ox = ox; tg_.oy = oy; tg_.oz = oz;
-  icc_voxel_phase(a, ip.acc_w, tg_, ne0, tg0, s_dist, s_id, s_rows2, Vx, L.Rt, L.off, [](int) {});
-  stamp(7);
-}
-
 // ---- the step as a kernel of its own: one 64-lane workgroup per object ----------------
 // mode 1: after the last iteration of mf_icc_refine.  mode 2: mf_icc_loss_grad (loss, gq, gt).
 __global__ __launch_bounds__(64) void k_icc_step(IccArgs a, IccStepArgs sp) {
@@ -2437,18 +1795,6 @@ __global__ __launch_bounds__(64) void k_icc_step(IccArgs a, IccStepArgs sp) {
     icc_step_gather_fused<64>(a, sp.par, j, ja, Ns, s_raw, s_sum);
   else
     icc_step_gather<64>(a, sp.par, j, ja, Ns, s_raw, s_sum);
-  if (sp.zero_acc1 > 0) {
-    const int pz = sp.zero_acc1 - 1;
-    if (threadIdx.x < 2) a.Mbits[(int64_t)pz * 2 * a.O + 2 * j + threadIdx.x] = 0;
-    long long *own = a.acc_own + ((int64_t)pz * a.O + j) * kOwnSlots;
-    for (int i = threadIdx.x; i < kOwnSlots; i += 64) own[i] = 0;
-    long long *oth = a.acc_oth + ((int64_t)pz * a.O + j) * a.max_ns * 12;
-    for (int i = threadIdx.x; i < a.max_ns * 12; i += 64) oth[i] = 0;
-  }
-  if (sp.zero_bin1 > 0) {
-    uint32_t *cz = a.bin_cnt + (int64_t)(sp.zero_bin1 - 1) * a.par_cnt + (int64_t)(2 * j) * a.nbins;
-    for (int i = threadIdx.x; i < 2 * a.nbins; i += 64) cz[i] = 0u;
-  }
   if (threadIdx.x >= 16) return;
   __shared__ float s_x[kStepLaneWords];
   float Rt[12], loss, gq[4], gt[3];
@@ -2465,7 +1811,7 @@ __global__ __launch_bounds__(64) void k_icc_step(IccArgs a, IccStepArgs sp) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) { sp.m_out[7 * j + i] = st_new[7 + i]; sp.v_out[7 * j + i] = st_new[14 + i]; }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) a.Rt[((int64_t)sp.rt_w * a.O + j) * 12 + i] = Rt[i];
+    for (int i = 0; i < 12; ++i) a.Rt[(int64_t)j * 12 + i] = Rt[i];
     if (sp.traj) {
       float *tr = sp.traj + ((int64_t)sp.it * a.O + j) * 7;
 #pragma unroll
@@ -2512,9 +1858,7 @@ WsLayout ws_layout(const mfIccBatch *b) {
   const int O = b->n_objects, S = b->n_scenes, D = b->dim, max_ns = b->max_scene_objects;
   const int64_t V = (int64_t)D * D * D;
   l.NB = (int)((V + kVoxPerBlock - 1) / kVoxPerBlock);
-  // (+ 1 plane of margin per side for the bins of k_icc_iter) + the overflow counter
-  const int one = (b->flags & MF_ICC_FLAG_ONE_LAUNCH) ? 1 : 0;
-  l.nbins = kHalves * (D + 2 * (ksize_host(b->voxel_threshold) / 2 + one)) + 1;
+  l.nbins = kHalves * (D + 2 * (ksize_host(b->voxel_threshold) / 2)) + 1;  // + the overflow counter
   // every (target, source) pair of a scene in chunks of kBinChunk points:
   // sum_pairs ceil(P_j / chunk) <= max_ns * n_points / chunk + O * max_ns (+ O designated entries)
   l.n_tab = (int)(((int64_t)max_ns * b->n_points + kBinChunk - 1) / kBinChunk) + O * max_ns + O;
@@ -2543,7 +1887,7 @@ WsLayout ws_layout(const mfIccBatch *b) {
     const int64_t per_grid_extra = (force > 0 ? force : kBinMinCap) + 1;
     const int64_t binned = force > 0 ? 0 : sumP / kBinShare;
     l.rec_n = (int64_t)(l.nbins - 1) * (binned + 2 * O * per_grid_extra) + 2 * sumP;
-    l.rec = off; off = align256(off + (1 + one) * l.rec_n * 16);  // k_icc_iter reads one buffer and fills the other
+    l.rec = off; off = align256(off + l.rec_n * 16);
   }
   l.total = off;
   return l;
@@ -2592,10 +1936,6 @@ IccArgs make_args(const mfIccBatch *b, void *ws) {
   a.bin_cap_force = icc_bin_cap_force();
   a.bin_base = (int64_t *)(p + l.bin_base);
   a.rec = (float4 *)(p + l.rec);
-  a.rec_stride = l.rec_n;
-  a.par_cnt = (int64_t)2 * a.O * l.nbins;
-  a.mg = 0;
-  a.rec_model = 0;
   a.uniform_ns = (int64_t)b->n_scenes * b->max_scene_objects == b->n_objects ? b->max_scene_objects : 0;
   a.xcd_order = ((a.O >= 32) || (a.dbg & 2048)) && !(a.dbg & 4096);
   return a;
@@ -2623,43 +1963,6 @@ void launch_iteration(const IccArgs &a, IccStepArgs sp, int NB, int k, hipStream
   hipLaunchKernelGGL(k_icc_accum, dim3(NB, a.O), dim3(kAccThreads), lds_rows2, stream, a, par);
 }
 
-// One-launch iterations (k_icc_iter) apply to what every caller of the reference passes: {0,1} no-entry grids,
-// voxel_threshold 2 (kernel size 3 for every grid: (2 pitch) / pitch == 2 exactly), scenes of <= kIterMaxNs objects.
-bool icc_use_iter(const mfIccBatch *b, const IccArgs &a, const WsLayout &l) {
-  // opt-in (mfIccBatch.flags: the workspace is sized for it): measured 23.3 - 27.7 us per iteration against 23 us
-  // of the two-launch path at 1 scene x 8 objects and 1.4x its time at 8 scenes -- see the comment above
-  // k_icc_iter and DESIGN.md 4
-  if (!(b->flags & MF_ICC_FLAG_ONE_LAUNCH)) return false;
-  return a.ne_binary && b->voxel_threshold == 2.0f && b->max_scene_objects <= kIterMaxNs && b->dim <= 32 &&
-         l.rec_n < ((int64_t)1 << 31);
-}
-
-size_t iter_lds_bytes(const IccArgs &a) {
-  return 4 * (size_t)fused_tile_words(a.D) * sizeof(uint32_t) + iter_union_bytes(a.max_ns);
-}
-
-// The bins iteration 0 reads: model-point records with one plane / row of margin, from the pose in a.Rt (copy 0),
-// into counter parity 0 and record buffer 0.
-void launch_iter_prebin(IccArgs a, hipStream_t stream) {
-  a.mg = 1;
-  a.rec_model = 1;
-  IccStepArgs sp = {};
-  hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, sp);
-}
-
-// Iteration k as ONE launch: [step k (k > 0)] -> tiles on the bins of k - 1 -> bins for k + 1.
-void launch_iter(IccArgs a, IccStepArgs sp, int k, hipStream_t stream) {
-  a.mg = 1;
-  a.rec_model = 1;
-  sp.fused = 1;
-  IterPar ip;
-  ip.acc_r = (k + 2) % 3; ip.acc_w = k % 3; ip.acc_z = (k + 1) % 3;
-  ip.bin_r = k % 3; ip.bin_w = (k + 1) % 3; ip.bin_z = (k + 2) % 3;
-  ip.rec_r = k & 1; ip.rec_w = (k + 1) & 1;
-  ip.rt_r = (k + 1) & 1; ip.rt_w = k & 1;
-  hipLaunchKernelGGL(k_icc_iter, dim3(a.D * kHalves, a.O), dim3(kTileThreads), iter_lds_bytes(a), stream, a, sp, ip);
-}
-
 // chainer Adam: alpha_t = alpha * sqrt(1 - b2^t) / (1 - b1^t), in double, cast once
 float adam_alpha_t(float alpha, int step) {
   const double fix1 = 1.0 - pow(0.9, (double)step), fix2 = 1.0 - pow(0.999, (double)step);
@@ -2679,7 +1982,7 @@ static bool icc_batch_ok(const mfIccBatch *b) {
   return b && b->n_objects > 0 && b->n_scenes > 0 && b->dim > 0 && b->dim <= 64 &&
          b->n_points >= 0 && b->max_scene_objects > 0 && b->max_scene_objects <= kMaxSceneObjects &&
          b->voxel_threshold > 0.0f && ksize_host(b->voxel_threshold) <= 7 &&
-         (double)b->n_points * 343.0 < 4294967295.0 && b->n_points < (1 << 27);
+         (double)b->n_points * 343.0 < 4294967295.0 && b->n_points < (1 << 27) && b->flags == 0;
 }
 
 extern "C" int64_t mf_icc_workspace_bytes(const mfIccBatch *batch) {
@@ -2700,15 +2003,13 @@ extern "C" int mf_icc_iteration_launches(const mfIccBatch *batch) {
   if (!icc_batch_ok(batch)) return -1;
   char dummy[8];
   const IccArgs a = make_args(batch, dummy);  // (pointers are offsets from a dummy base: not dereferenced)
-  if (!a.ne_binary) return 3;
-  return icc_use_iter(batch, a, ws_layout(batch)) ? 1 : 2;
+  return a.ne_binary ? 2 : 3;
 }
 
 static int icc_validate(const mfIccBatch *b) {
   // collision-moment rows: max_scene_objects x 1664 B of dynamic LDS (106 KB at 64 objects)
   if (int e = mf::allow_big_lds((const void *)k_icc_fused, 124 * 1024)) return e;
   if (int e = mf::allow_big_lds((const void *)k_icc_accum, 124 * 1024)) return e;
-  if (int e = mf::allow_big_lds((const void *)k_icc_iter, 124 * 1024)) return e;
   if (!icc_batch_ok(b)) {
     mf::set_last_error(hipErrorInvalidValue, "mf_icc: invalid batch descriptor");
     return -(int)hipErrorInvalidValue;
@@ -2814,8 +2115,7 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
   int dev = 0;
   MF_TRY(hipGetDevice(&dev));
   key.v.push_back(((uint64_t)(uint32_t)dev << 32) | ((uint32_t)max_ns << 1) | (uint32_t)a.ne_binary);
-  const bool iter = icc_use_iter(batch, a, l);
-  key.v.push_back(((uint64_t)(iter ? 1u : 0u) << 32) | (uint64_t)(uint32_t)a.bin_cap_force);
+  key.v.push_back((uint64_t)(uint32_t)a.bin_cap_force);
   key.v.push_back((uint64_t)(uint32_t)a.dbg);
 
   std::lock_guard<std::mutex> lock(g_graph_mu);
@@ -2836,13 +2136,12 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
           *sv[2] = {adam_v, alt + 14 * a.O};
     hipLaunchKernelGGL(k_icc_pose, dim3(a.O), dim3(256), 0, cap, a, (const float *)q,
                        (const float *)t, traj);
-    if (iter) launch_iter_prebin(a, cap);
     for (int k = 0; k <= n_iter; ++k) {
       IccStepArgs sp = {};
       if (k > 0) {
         const int in = (k - 1) & 1, out = k == n_iter ? 0 : (k & 1);
         sp.mode = 1;
-        sp.par = iter ? (k - 1) % 3 : (k - 1) & 1;
+        sp.par = (k - 1) & 1;
         sp.it = k;
         sp.aq = adam_alpha_t(alpha_q, step0 + k);
         sp.at = adam_alpha_t(alpha_t, step0 + k);
@@ -2856,10 +2155,7 @@ extern "C" int mf_icc_refine(const mfIccBatch *batch, float *q, float *t, float 
         hipLaunchKernelGGL(k_icc_step, dim3(a.O), dim3(64), 0, cap, a, sp);
         break;
       }
-      if (iter)
-        launch_iter(a, sp, k, cap);
-      else
-        launch_iteration(a, sp, l.NB, k, cap);
+      launch_iteration(a, sp, l.NB, k, cap);
     }
     hipError_t ce = hipStreamEndCapture(cap, &graph);
     if (ce != hipSuccess) {

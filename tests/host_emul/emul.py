@@ -73,7 +73,7 @@ def ptr(a):
 class EmulIccScenes:
     """NumPy twin of morefusion_amd.contrib.IccScenes over the emulated library."""
 
-    def __init__(self, lib, scenes, voxel_dim=32, voxel_threshold=2, sdf_offset=0.0, single_pass=None, one_launch=False):
+    def __init__(self, lib, scenes, voxel_dim=32, voxel_threshold=2, sdf_offset=0.0, single_pass=None):
         self.lib = lib
         lib.mf_icc_workspace_bytes.restype = _i64
         P = ctypes.POINTER(IccBatch)
@@ -111,7 +111,7 @@ class EmulIccScenes:
             self.n_points, voxel_dim, max(scene_off[i + 1] - scene_off[i] for i in range(len(scenes))),
             float(voxel_threshold), float(sdf_offset),
             int(bool(np.isin(self.grid_ne, (0, 1)).all()) if single_pass is None else single_pass))
-        self.desc.flags = 1 if one_launch else 0
+        self.desc.flags = 0
         nbytes = lib.mf_icc_workspace_bytes(ctypes.byref(self.desc))
         assert nbytes > 0
         self.ws = np.zeros(nbytes + 256, np.uint8)

@@ -43,8 +43,8 @@ def test_workspace_size_is_host_only_arithmetic():
     ws = mf._lib.lib().mf_icc_workspace_bytes
     n = ws(ctypes.byref(desc(8, 1, 28000, 8)))
     one = desc(8, 1, 28000, 8)
-    one.flags = 1  # MF_ICC_FLAG_ONE_LAUNCH: a second record buffer and one more plane of bins per side
-    assert 1.9 * (n - 2 * 8 * 32 ** 3 * 8) < ws(ctypes.byref(one)) - 2 * 8 * 32 ** 3 * 8 < 2.3 * (n - 2 * 8 * 32 ** 3 * 8)
+    one.flags = 1  # reserved since round 6 (round 5's opt-in one-launch iteration is gone): a set bit is refused
+    assert ws(ctypes.byref(one)) < 0
     # winners of 16 grids + compact bins: per grid 68 bins of max(64, P_g / 8) records + an overflow list of 2 P_g,
     # summed over the grids (sum_g P_g = Ns * P_scene) -- O(N * sum P), not nbins x that (round 2: 68 x 8 x 28000 x 16 B)
     sumP = 8 * 28000

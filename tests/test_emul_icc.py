@@ -254,38 +254,3 @@ def test_icc_scene_of_more_than_32_objects(lib, sp, n_obj):
     np.testing.assert_allclose(gq, gq_o, rtol=2e-3, atol=2e-5)
     np.testing.assert_allclose(gt, gt_o, rtol=2e-3, atol=2e-4)
     assert np.abs(gq).sum() > 0
-
-
-@pytest.mark.parametrize("variant", ["default", "moved", "list_overflow", "bin_overflow"])
-def test_icc_one_launch_iteration_gives_the_bits_of_the_two_launch_path(fixtures3, monkeypatch, variant):
-    """k_icc_iter (round 5, opt-in MF_ICC_ONE_LAUNCH=1): the tiles of iteration k read the MODEL-point bins that
-    iteration k - 1 built from ITS pose (one plane / row of margin), transform the records with pose k and test
-    membership exactly; the same launch steps every scene object (16 lanes each) and bins for k + 1.  Winners are
-    exact and the sums fixed point, so the refinement must equal the two-launch path's bit for bit -- poses, Adam
-    moments, losses and trajectory rows, over two scenes of different size (ragged tables), also when
-    * every object counts as moved further than the margin covers (-DMF_ITER_MOVE_MAX=-1: its points are re-read
-      from the point array, every tile takes the streaming form),
-    * the survivor list of a tile overflows (-DMF_ITER_SURV_CAP=40),
-    * nearly every record overflows its bin (MF_ICC_BIN_CAP=3)."""
-    flags = {"moved": ("-DMF_ITER_MOVE_MAX=-1.0f",), "list_overflow": ("-DMF_ITER_SURV_CAP=40",)}.get(variant, ())
-    lib_a, lib_b = emul.build(["icc.hip"]), emul.build(["icc.hip"], extra_flags=flags)
-    scenes = [synthetic.make_icc_scene(4, seed=0, fixtures=fixtures3), synthetic.make_icc_scene(2, seed=5)]
-    n, n_iter = 6, 4 if variant == "default" else 3
-    if variant == "bin_overflow":
-        monkeypatch.setenv("MF_ICC_BIN_CAP", "3")
-
-    def run(lib, one):
-        S = emul.EmulIccScenes(lib, [_dict(s) for s in scenes], sdf_offset=0.02, one_launch=one)
-        import ctypes
-        assert lib.mf_icc_iteration_launches(ctypes.byref(S.desc)) == (1 if one else 2)
-        q = np.concatenate([_pose0(s)[0] for s in scenes])
-        t = np.concatenate([_pose0(s)[1] for s in scenes])
-        m, v = np.zeros((n, 7), np.float32), np.zeros((n, 7), np.float32)
-        losses, traj = np.zeros((n_iter, 2), np.float32), np.zeros((n_iter, n, 7), np.float32)
-        S.refine(q, t, m, v, n_iter, losses=losses, traj=traj)
-        return q, t, m, v, losses, traj
-
-    ref, got = run(lib_a, False), run(lib_b, True)
-    for a_, b_ in zip(ref, got):
-        np.testing.assert_array_equal(a_, b_)
-    assert np.isfinite(ref[4]).all() and np.abs(ref[5][-1] - ref[5][0]).max() > 0

@@ -153,34 +153,6 @@ def test_icc_refine_is_bitwise_reproducible(scene8):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("n_iter", [30])
-def test_icc_one_launch_iteration_gives_the_bits_of_the_two_launch_path(scene8, fixtures3, monkeypatch, n_iter):
-    """k_icc_iter (opt-in, MF_ICC_ONE_LAUNCH=1 in the environment of the link / IccScenes(one_launch=True): tiles on the previous iteration's model-point bins, the step and the
-    binning for the next iteration in the same launch) walks exactly the iterates of the default two-launch path:
-    poses and losses of 30 iterations of the 8-object scene (the first iterations move objects further than the
-    margin bins cover -> the exact re-read path runs too) and of a ragged two-scene batch, bit for bit."""
-    outs = []
-    for one in ("0", "1"):
-        monkeypatch.setenv("MF_ICC_ONE_LAUNCH", one)
-        link = mf.contrib.IterativeCollisionCheckLink(scene8["transform_init"], sdf_offset=0.02).to_gpu()
-        losses, _ = link.refine(*to_dev(scene_args(scene8, 8)), n_iter=n_iter, return_history=True)
-        scenes = [mf.synthetic.make_icc_scene(n, seed=s, fixtures=fixtures3 if s == 0 else None) for n, s in ((4, 0), (3, 1))]
-        batch = mf.contrib.IccScenes([dict(points=sc["points"], sdf=sc["sdf"], pitch=sc["pitch"], origin=sc["origin"],
-                                           grid_target=sc["grid_target"],
-                                           grid_nontarget_empty=sc["grid_nontarget_empty"]) for sc in scenes],
-                                     sdf_offset=0.02, device=torch.device("cuda", 0))
-        assert mf._lib.lib().mf_icc_iteration_launches(__import__("ctypes").byref(batch.desc)) == (1 if one == "1" else 2)
-        q = torch.tensor(np.concatenate([np.stack([O.quaternion_from_matrix(T) for T in sc["transform_init"]]) for sc in scenes]),
-                         dtype=torch.float32, device="cuda")
-        t = torch.tensor(np.concatenate([sc["transform_init"][:, :3, 3] for sc in scenes]), dtype=torch.float32, device="cuda")
-        m, v = torch.zeros(7, 7, device="cuda"), torch.zeros(7, 7, device="cuda")
-        batch.refine(q, t, m, v, 12)
-        outs.append((torch.cat([link.quaternion.data, link.translation.data], 1).cpu().numpy(), losses.cpu().numpy(),
-                     torch.cat([q, t, m, v], 1).cpu().numpy()))
-    for a_, b_ in zip(*outs):
-        np.testing.assert_array_equal(a_, b_)
-
-
 @pytest.mark.parametrize("general", [False, True], ids=["single_pass", "two_kernel"])
 def test_icc_compact_bins_overflow_list_gives_the_same_bits(scene8, monkeypatch, general):
     """Compact bins (a bin holds max(64, P_g / 8) records; the excess goes to the grid's overflow list that its
