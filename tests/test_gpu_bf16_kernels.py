@@ -30,9 +30,19 @@ def grad_close(a, b):
     assert l2 < 1e-2 and rel(a, b) < 5e-2, (l2, rel(a, b))
 
 
+@pytest.fixture(params=["by_size", "ping_pong"])
+def engine_form(request, monkeypatch):
+    """``ping_pong``: MF_NT_BIG=2 -- the 256 x 256 LDS-DMA ping-pong forms (k_gemm_nt_bf16_pp, k_gemm_tn_bf16_pp, round 6)
+    wherever their structure allows, whatever the tile count (at the network's full batch they are chosen by size:
+    test_ping_pong_engines_at_full_size_...); ``by_size``: the launcher's own choice at these small batches."""
+    if request.param == "ping_pong":
+        monkeypatch.setenv("MF_NT_BIG", "2")
+    return request.param
+
+
 @pytest.mark.parametrize("B,Cin,Cout,D,w_cin,c_off", [(2, 256, 512, 16, 256, 0), (1, 160, 256, 32, 160, 0),
                                                       (2, 16, 256, 32, 160, 144)])
-def test_conv3d_k4s2_bf16_forward_backward_vs_fp32(B, Cin, Cout, D, w_cin, c_off):
+def test_conv3d_k4s2_bf16_forward_backward_vs_fp32(B, Cin, Cout, D, w_cin, c_off, engine_form):
     torch.manual_seed(0)
     conv = torch.nn.Conv3d(w_cin, Cout, 4, 2, padding=1).cuda()
     x = torch.randn(B, D ** 3, Cin, device="cuda").to(torch.bfloat16).requires_grad_(True)
@@ -55,7 +65,7 @@ def test_conv3d_k4s2_bf16_forward_backward_vs_fp32(B, Cin, Cout, D, w_cin, c_off
 
 @pytest.mark.parametrize("n,Kin,N,relu", [(2000, 3, 8, True), (2000, 128, 63, False), (16000, 984, 1920, True),
                                            (1000, 640, 256, True)])
-def test_linear_bf16_forward_backward_vs_fp32(n, Kin, N, relu):
+def test_linear_bf16_forward_backward_vs_fp32(n, Kin, N, relu, engine_form):
     torch.manual_seed(1)
     conv = torch.nn.Conv1d(Kin, N, 1).cuda()
     x = (torch.randn(n, Kin, device="cuda").to(torch.bfloat16) if Kin % 8 == 0 else torch.randn(n, Kin, device="cuda"))
@@ -73,6 +83,70 @@ def test_linear_bf16_forward_backward_vs_fp32(n, Kin, N, relu):
     grad_close(x.grad, xr.grad)
     grad_close(conv.weight.grad.reshape(N, Kin), wr.grad)
     grad_close(conv.bias.grad, br.grad)
+
+
+def test_ping_pong_engines_at_full_size_match_fp32_and_are_bitwise_reproducible():
+    """The LDS-DMA ping-pong engines at the shapes that select them by size -- conv4 (256 -> 512 on 16^3) at the
+    training batch of 16 objects: forward (split-K x 4 over fp32 slabs + finish pass), data gradient, weight gradient
+    (TN form, split 2) -- against torch's float32 convolution on the same bf16-rounded operands (the objects of a
+    slice), and a race screen: the kernels hand LDS stages between DMA requests and fragment reads of two wave groups
+    on counted waits and raw barriers; an ordering hole would show as a rare wrong tile.  Every launch of a
+    deterministic kernel must give the very same bits: 12 launches each, under load."""
+    L, st = mf._lib.lib(), mf._lib.stream_ptr
+    p = lambda t: t.data_ptr()  # noqa: E731
+    torch.manual_seed(3)
+    B, Cin, Cout, D = 16, 256, 512, 16
+    Do = D // 2
+    dev, bf = "cuda", torch.bfloat16
+    x = torch.randn(B, D ** 3, Cin, device=dev).to(bf)
+    dy = torch.randn(B, Do ** 3, Cout, device=dev).to(bf)
+    W = torch.randn(Cout, Cin, 4, 4, 4, device=dev) / (64 * Cin) ** 0.5
+    bias = torch.randn(Cout, device=dev)
+    wt = torch.empty(Cout, 64, Cin, dtype=bf, device=dev)
+    wd = torch.empty(8, Cin, 8, Cout, dtype=bf, device=dev)
+    mf._lib.check(L.mf_conv3d_k4s2_pack_bf16(p(W), Cout, Cin, Cin, 0, p(wt), p(wd), st()), "pack")
+    nws = L.mf_conv3d_bf16_fwd_workspace_bytes(B, Cin, Cout, D, 4, 2, 1, 1)
+    assert nws == 4 * B * Do ** 3 * Cout * 4  # 64 tiles of 256 x 256 for 256 CUs: split-K x 4
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    split = L.mf_conv3d_k4s2_bf16_wgrad_default_split(B, Cin, Cout, D)
+    wsw = torch.empty(L.mf_conv3d_k4s2_bf16_wgrad_workspace_bytes(Cin, Cout, split), dtype=torch.uint8, device=dev)
+
+    def fwd():
+        y = torch.empty(B, Do ** 3, Cout, dtype=bf, device=dev)
+        mf._lib.check(L.mf_conv3d_bf16_fwd_ws(p(x), p(wt), p(bias), p(y), p(ws), nws, B, Cin, Cout, D, 4, 2, 1, 1, 1, 0, Cout, st()), "fwd")
+        assert L.mf_gemm_bf16_last_tile() == 256
+        return y
+
+    def dgrad():
+        dx = torch.empty(B, D ** 3, Cin, dtype=bf, device=dev)
+        mf._lib.check(L.mf_conv3d_k4s2_bf16_dgrad(p(dy), p(wd), p(dx), B, Cin, Cout, D, 0, 0, st()), "dgrad")
+        assert L.mf_gemm_bf16_last_tile() == 256
+        return dx
+
+    def wgrad():
+        dW = torch.empty_like(W)
+        mf._lib.check(L.mf_conv3d_k4s2_bf16_wgrad(p(dy), p(x), p(dW), p(wsw), B, Cin, Cout, D, Cin, 0, split, st()), "wgrad")
+        return dW
+
+    first = {}
+    for name, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
+        first[name] = fn()
+        for _ in range(11):
+            assert torch.equal(fn(), first[name]), name
+    # float32 reference: objects 0 and 15 for forward / data gradient, all of them for the weight gradient
+    wr = W.to(bf).float().requires_grad_(True)
+    for b in (0, B - 1):
+        xr = x[b:b + 1].float().reshape(1, D, D, D, Cin).permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+        with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+            pre = F.conv3d(xr, wr, bias, stride=2, padding=1)
+            pre.backward(dy[b:b + 1].float().reshape(1, Do, Do, Do, Cout).permute(0, 4, 1, 2, 3).contiguous())
+        assert rel(first["fwd"][b], F.relu(pre.detach()).permute(0, 2, 3, 4, 1).reshape(-1, Cout)) < 2 ** -7
+        assert rel(first["dgrad"][b], xr.grad.permute(0, 2, 3, 4, 1).reshape(-1, Cin)) < 2 ** -7
+    wr.grad = None
+    xa = x.float().reshape(B, D, D, D, Cin).permute(0, 4, 1, 2, 3).contiguous()
+    with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+        F.conv3d(xa, wr, None, stride=2, padding=1).backward(dy.float().reshape(B, Do, Do, Do, Cout).permute(0, 4, 1, 2, 3).contiguous())
+    assert rel(first["wgrad"], wr.grad) < 2e-3
 
 
 def test_training_step_on_bf16_kernels_matches_stock_autocast_step():
