@@ -599,7 +599,7 @@ def roofline_bf16_kernels(wl, B=16):
         rec(f"{key}_fwd", "k_gemm_nt_bf16_pp<conv forward>" + (" split-K + k_splitk_finish" if nws else ""),
             lambda: L.mf_conv3d_bf16_fwd_ws(p(x), p(wt), None, p(y), p(fws), nws, B, Cin, Cout, D, 4, 2, 1, 1, 1, 0, Cout, st()),
             flop, shape, splitk_workspace_mb=round(nws / 2 ** 20, 1))
-        rec(f"{key}_dgrad", "k_gemm_nt_bf16_pp<conv dgrad>" if Cin >= 192 else "k_gemm_nt_bf16<conv dgrad> (N = 160: 128 x 128 tile)",
+        rec(f"{key}_dgrad", "k_gemm_nt_bf16_pp<conv dgrad>" + ("" if Cin >= 192 else " (N = 160: one 256-column tile, 96 columns idle)"),
             lambda: L.mf_conv3d_k4s2_bf16_dgrad(p(dy), p(wd), p(dx), B, Cin, Cout, D, 0, 0, st()), flop, shape)
         rec(f"{key}_wgrad", "k_gemm_tn_bf16 (+ k_wgrad_finish)",
             lambda: L.mf_conv3d_k4s2_bf16_wgrad(p(dy), p(x), p(dW), p(ws), B, Cin, Cout, D, Cin, 0, split, st()), flop, shape)

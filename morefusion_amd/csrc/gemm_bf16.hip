@@ -1721,8 +1721,10 @@ template <int MODE>
 int launch_nt(const NtArgs &a, hipStream_t stream) {
   const int64_t full = (int64_t)((a.M + 127) / 128) * ((a.N + kBN - 1) / kBN) * a.groups;
   const int64_t big = (int64_t)((a.M + kBigM - 1) / kBigM) * ((a.N + kBigN - 1) / kBigN) * a.groups;
-  bool use_big = big >= 224 && a.N >= 192 && !(MODE == kRows && a.tile_group) &&
+  bool use_big = big >= 224 && a.N >= 160 && !(MODE == kRows && a.tile_group) &&
                  !(MODE == kConvDgrad && ((a.Do * a.Do * a.Do) & (kBigM - 1)));
+  // (N >= 160: dense conv3's data gradient, N = 160 -- one tile of 256 columns, the waves of its last 96 columns idle --
+  // measured 551 -> 778 TFLOP/s on the ping-pong form against the 128 x 128 tile's two column tiles)
   if (a.S > 1) use_big = true;  // (a split-K launch: the caller checked the structure, nt_splitk)
   if (nt_big_override() == 2)  // (tests: the big tile wherever its structure allows, whatever the tile count)
     use_big = !(MODE == kRows && a.tile_group) && !(MODE == kConvDgrad && ((a.Do * a.Do * a.Do) & (kBigM - 1)));
