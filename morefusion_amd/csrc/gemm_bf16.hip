@@ -875,24 +875,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
   // MFMA uses is NOT read: the compiler takes the asm's result register as written when the statement ends and hands
   // a dead one out again at once -- the data then lands on top of whatever lives there (seen: the offset of the next
   // DMA request, a memory fault).  MF_HOLD behind the wait keeps every fragment register reserved up to there.
-#ifndef MF_PP_NL  // DMA requests of a phase issued in its load section; the other 4 - MF_PP_NL between its MFMAs
-#define MF_PP_NL 4
-#endif
-#ifndef MF_PP_MIX  // 1: the load section alternates three fragment reads and one request
-#define MF_PP_MIX 0
-#endif
+  // (the load section alternating three reads and one request, and one or two of a phase's four requests issued
+  // between its MFMAs instead, both measured slower: DESIGN.md 4)
 #define MF_PP_PHASE(NJ_, p_, REQ_, WAIT_)                                                             \
   {                                                                                                   \
-    if (MF_PP_MIX) {                                                                                  \
-      MF_PP_READS(NJ_, 0, sa, sw, 2 * (p_), 0, 3) REQ_(0, 1)                                          \
-      MF_PP_READS(NJ_, 0, sa, sw, 2 * (p_), 3, 6) if (MF_PP_NL > 1) { REQ_(1, 2) }                    \
-      MF_PP_READS(NJ_, 1, sa, sw, 2 * (p_) + 1, 0, 3) if (MF_PP_NL > 2) { REQ_(2, 3) }                \
-      MF_PP_READS(NJ_, 1, sa, sw, 2 * (p_) + 1, 3, 6) if (MF_PP_NL > 3) { REQ_(3, 4) }                \
-    } else {                                                                                          \
-      MF_PP_READS(NJ_, 0, sa, sw, 2 * (p_), 0, 6)                                                     \
-      MF_PP_READS(NJ_, 1, sa, sw, 2 * (p_) + 1, 0, 6)                                                 \
-      REQ_(0, MF_PP_NL)                                                                               \
-    }                                                                                                 \
+    MF_PP_READS(NJ_, 0, sa, sw, 2 * (p_), 0, 6)                                                       \
+    MF_PP_READS(NJ_, 1, sa, sw, 2 * (p_) + 1, 0, 6)                                                   \
+    REQ_(0, 4)                                                                                        \
     WAIT_                                                                                             \
     mf::wait_lds_reads();                                                                             \
     if ((NJ_) > 0) {                                                                                  \
@@ -907,9 +896,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
     _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                  \
       const int kk = q >> 3, mi = q & 3, nj = (q >> 2) & 1;                                           \
       if (nj < (NJ_)) acc[mi][nj] = mf::mfma_bf16_32x32x16(fa[kk][mi], fb[kk][nj], acc[mi][nj]);      \
-      if (MF_PP_NL == 3 && q == 7) { __builtin_amdgcn_sched_barrier(0); REQ_(3, 4) __builtin_amdgcn_sched_barrier(0); } \
-      if (MF_PP_NL == 2 && q == 4) { __builtin_amdgcn_sched_barrier(0); REQ_(2, 3) __builtin_amdgcn_sched_barrier(0); } \
-      if (MF_PP_NL == 2 && q == 10) { __builtin_amdgcn_sched_barrier(0); REQ_(3, 4) __builtin_amdgcn_sched_barrier(0); } \
     }                                                                                                 \
     __builtin_amdgcn_s_setprio(0);                                                                    \
     mf::raw_barrier();                                                                                \
@@ -922,7 +908,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
     const bool more1 = t + 1 < T && !(a.dbg & 1), more2 = t + 2 < T && !(a.dbg & 1);                  \
     if (a.dbg & 2) { kg = kgw = 8 * chunk; tc = kg; tx = ty = tz = 0; }                               \
     MF_PP_PHASE(NJ_, 0, MF_PP_RW, )                                                                   \
-    MF_PP_PHASE(NJ_, 1, MF_PP_RA, if (more2) mf::wait_dma<MF_PP_NL>(); else mf::wait_dma<0>();)              \
+    MF_PP_PHASE(NJ_, 1, MF_PP_RA, if (more2) mf::wait_dma<4>(); else mf::wait_dma<0>();)              \
     sa = sa == 2 ? 0 : sa + 1;                                                                        \
     sa2 = sa2 == 2 ? 0 : sa2 + 1;                                                                     \
   }
