@@ -188,7 +188,7 @@ typedef struct {
   int32_t n_scenes;  /* S */
   int32_t n_points;  /* Ptot */
   int32_t dim;       /* D (32) */
-  int32_t max_scene_objects; /* max objects in one scene (<= 64) */
+  int32_t max_scene_objects; /* max objects in one scene (<= 128 with grid_ne_binary, else <= 64) */
   float voxel_threshold;
   float sdf_offset;
   int32_t grid_ne_binary; /* != 0: the caller guarantees that every grid_ne value is exactly 0 or 1

@@ -84,7 +84,8 @@ class IccScenes:
         self.desc.flags = 0  # (reserved)
         nbytes = L.mf_icc_workspace_bytes(ctypes.byref(self.desc))
         if nbytes < 0:
-            raise ValueError("mf_icc: invalid batch descriptor (objects per scene <= 64, dim <= 64)")
+            raise ValueError("mf_icc: invalid batch descriptor (objects per scene <= 128 with {0,1} no-entry grids, <= 64 "
+                             "with other values; dim <= 64)")
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         self.prepare()
 

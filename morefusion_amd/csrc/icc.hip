@@ -70,8 +70,15 @@ constexpr int kNumF = 65;                    // single-pass path: 5 scene sums +
 constexpr int kOwnSlots = kNumF + 1;         // accumulator words per object; the slot after the sums
                                              // counts non-finite block sums (-> NaN loss)
 constexpr int kStateFloats = 21;             // q[4] t[3] m[7] v[7] of one object
-constexpr int kMaxSceneObjects = 64;  // LDS tables of a scene (R|t, offsets, staged sums); scenes beyond 32 objects
-                                      // take > 64 KB of dynamic LDS in the tile kernels (one workgroup per CU)
+// Objects per scene.  The single-pass path (k_icc_fused, {0,1} no-entry grids: what every caller of the reference
+// passes) takes up to 128 (round 6): its LDS tables of a scene (R|t, offsets) are sized for that, and the collision
+// moments -- 1664 bytes of LDS rows per other object and workgroup -- are reduced in chunks of kRows2Chunk objects (one
+// chunk up to 64: the round-3 code path; > 64: the voxels' collision terms stay in registers and a second chunk reuses
+// the rows).  The two-kernel path (k_icc_accum: any no-entry grid values) carries the objects a block meets as a
+// 64-bit mask and stays at 64.  Scenes beyond 32 objects take > 64 KB of dynamic LDS (one workgroup per CU).
+constexpr int kMaxSceneObjects = 128;
+constexpr int kMaxSceneObjectsGeneral = 64;
+constexpr int kRows2Chunk = 64;
 
 struct IccArgs {
   const float4 *pts4;
@@ -318,7 +325,9 @@ struct IccStepArgs {
 // scene's objects serially costs a dependent load per object: measured 9 us at 8 objects) --
 // staged in LDS, then summed in object order.  s_raw: >= (16 * max_ns + kNumOwn) 64-bit words.
 // Contains two barriers: call it from uniform control flow.
-constexpr int kStepRawWords = 20 * kMaxSceneObjects + 60;  // (the single-pass path stages more words)
+constexpr int kStepRawWords = 20 * 64 + 60;  // 64-bit words: the single-pass path stages 20 Ns + 60 FLOATS in them
+static_assert(20 * kMaxSceneObjects + 60 <= 2 * kStepRawWords, "staged floats of the single-pass step");
+static_assert(16 * kMaxSceneObjectsGeneral + 36 <= kStepRawWords, "staged words of the two-kernel path's step");
 
 template <int NT>
 __device__ __forceinline__ void icc_step_gather(const IccArgs &a, int par, int j, int ja, int Ns,
@@ -1023,8 +1032,8 @@ __global__ __launch_bounds__(kAccThreads) void k_icc_accum(IccArgs a, int par) {
   // 3-5 us in the crowded blocks.)
   MF_DYN_LDS(float, s_rows2);   // [max_ns][kAccThreads / 16][12 + 1] row sums per other object
   __shared__ unsigned long long s_emask;  // scene objects some voxel of this block collides with (<= 64 per scene)
-  __shared__ float s_Rt[kMaxSceneObjects][12];
-  __shared__ int s_off[kMaxSceneObjects + 1];
+  __shared__ float s_Rt[kMaxSceneObjectsGeneral][12];
+  __shared__ int s_off[kMaxSceneObjectsGeneral + 1];
   const int o = blockIdx.y;
   const int wg2 = 2048 + blockIdx.y * gridDim.x + blockIdx.x;
   auto stamp = [&](int i) {
@@ -1250,10 +1259,12 @@ struct VoxLds {
   int wcnt[kTileThreads / 64];
 };
 // static LDS of k_icc_fused (declared once in the kernel: the body is instantiated per kernel size)
+// (MAXNS = 64: the kernel every scene of <= 64 objects runs, unchanged since round 3; 128: k_icc_fused_big)
+template <int MAXNS>
 struct FusedLds {
   VoxLds v;
-  float Rt[kMaxSceneObjects][12];
-  int off[kMaxSceneObjects + 1];
+  float Rt[MAXNS][12];
+  int off[MAXNS + 1];
 };
 
 // Constants of one padded half-plane tile (k_icc_fused, kernel size 3).
@@ -1356,7 +1367,7 @@ struct TileGeom {
   float pitch, trunc, ox, oy, oz;
 };
 
-template <class Stamp>
+template <bool BIG, class Stamp>
 __device__ __forceinline__ void icc_voxel_phase(const IccArgs &a, const int par, const TileGeom &tg_, const float ne0,
                                                 const float tg0, uint32_t *s_dist, uint32_t *s_id, float *s_rows2,
                                                 VoxLds &Vx, const float (*s_Rt)[12], const int *s_off, Stamp stamp) {
@@ -1406,6 +1417,12 @@ __device__ __forceinline__ void icc_voxel_phase(const IccArgs &a, const int par,
   float wmax_oth = fmaxf(g_oth.w + 0.0f, 0.0f);
   constexpr int kRows = kTileThreads / 16;
   const int n_rows = (total + 15) / 16;
+  int ecol_keep = -1;  // (BIG only: the collision terms of the later chunks of a scene of > kRows2Chunk objects)
+  float cv_keep[12];
+  if constexpr (BIG) {
+#pragma unroll
+    for (int cc = 0; cc < 12; ++cc) cv_keep[cc] = 0.0f;
+  }
   if ((tid & ~63) < total) {  // wave-uniform
     const bool live = tid < total;
     const int rc = live ? (int)s_list[tid] : 0;
@@ -1504,9 +1521,10 @@ __device__ __forceinline__ void icc_voxel_phase(const IccArgs &a, const int par,
       }
     }
     // the 12 collision moments per other object some lane of this wave collides with (rows2
-    // starts zeroed: a wave writes only the objects it meets)
+    // starts zeroed: a wave writes only the objects it meets); objects beyond the first chunk: below
     if (__ballot(ecol >= 0) != 0ull) {
-      for (int e = 0; e < Ns; ++e) {
+      const int e1 = BIG ? min(Ns, kRows2Chunk) : Ns;
+      for (int e = 0; e < e1; ++e) {
         if (__ballot(ecol == e) == 0ull) continue;  // wave-uniform
         float r12[12];
 #pragma unroll
@@ -1516,6 +1534,11 @@ __device__ __forceinline__ void icc_voxel_phase(const IccArgs &a, const int par,
           for (int cc = 0; cc < 12; ++cc) s_rows2[(e * kRows + row) * 13 + cc] = r12[cc];
         }
       }
+    }
+    if constexpr (BIG) {  // kept for the later chunks of a scene of more than kRows2Chunk objects
+      ecol_keep = ecol;
+#pragma unroll
+      for (int cc = 0; cc < 12; ++cc) cv_keep[cc] = ecol >= 0 ? cv[cc] : 0.0f;
     }
   }
   stamp(7);
@@ -1546,7 +1569,41 @@ __device__ __forceinline__ void icc_voxel_phase(const IccArgs &a, const int par,
     }
   } else {  // (one trip up to 37 scene objects; a 64-object scene takes two)
     long long *po = a.acc_oth + ((int64_t)par * a.O + o) * a.max_ns * 12;
-    for (int i = tid - kNumF; i < 12 * Ns; i += kTileThreads - kNumF) {
+    for (int i = tid - kNumF; i < 12 * (BIG ? min(Ns, kRows2Chunk) : Ns); i += kTileThreads - kNumF) {
+      const int e = i / 12, cc = i - 12 * e;
+      float sacc = 0.0f;
+      for (int r = 0; r < n_rows; ++r) sacc += s_rows2[(e * kRows + r) * 13 + cc];
+      const long long xq = isfinite(sacc) ? __double2ll_rn((double)sacc * kFixOth) : 0;
+      if (xq != 0) atomicAdd(reinterpret_cast<unsigned long long *>(po + i), (unsigned long long)xq);
+    }
+  }
+  // Scene objects kRows2Chunk .. Ns - 1 (a scene of more than 64 objects, block-uniform): the same row sums and the
+  // same reduction on the SAME LDS rows, chunk by chunk -- zero the rows, the waves write the objects of the chunk
+  // they met (their collision terms waited in registers), all lanes add the rows.  Fixed order, fixed point: what a
+  // single pass over 1664 Ns bytes of rows would give, in 106 KB.
+  if constexpr (BIG)
+  for (int eb = kRows2Chunk; eb < Ns; eb += kRows2Chunk) {
+    const int ne_ = min(Ns - eb, kRows2Chunk);
+    __syncthreads();
+    for (int i = tid; i < ne_ * kRows * 13; i += kTileThreads) s_rows2[i] = 0.0f;
+    __syncthreads();
+    if ((tid & ~63) < total && __ballot(ecol_keep >= eb && ecol_keep < eb + ne_) != 0ull) {  // wave-uniform
+      const int row = tid >> 4;
+      const bool row_lead = (tid & 15) == 0;
+      for (int e = eb; e < eb + ne_; ++e) {
+        if (__ballot(ecol_keep == e) == 0ull) continue;  // wave-uniform
+        float r12[12];
+#pragma unroll
+        for (int cc = 0; cc < 12; ++cc) r12[cc] = mf::row16_sum(ecol_keep == e ? cv_keep[cc] : 0.0f);
+        if (row_lead) {
+#pragma unroll
+          for (int cc = 0; cc < 12; ++cc) s_rows2[((e - eb) * kRows + row) * 13 + cc] = r12[cc];
+        }
+      }
+    }
+    __syncthreads();
+    long long *po = a.acc_oth + ((int64_t)par * a.O + o) * a.max_ns * 12 + 12 * eb;
+    for (int i = tid; i < 12 * ne_; i += kTileThreads) {
       const int e = i / 12, cc = i - 12 * e;
       float sacc = 0.0f;
       for (int r = 0; r < n_rows; ++r) sacc += s_rows2[(e * kRows + r) * 13 + cc];
@@ -1556,8 +1613,8 @@ __device__ __forceinline__ void icc_voxel_phase(const IccArgs &a, const int par,
   }
 }
 
-template <int KS>
-__device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt, const int par, FusedLds &L,
+template <int KS, int MAXNS>
+__device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt, const int par, FusedLds<MAXNS> &L,
                                                const int o, const int tile_) {
   MF_DYN_LDS(uint32_t, s_tile);  // dist[2][nvh] | id[2][nvh] | rows2[max_ns][32][13] floats
   auto &s_rows = L.v.rows;
@@ -1606,7 +1663,8 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   if (threadIdx.x <= Ns) s_off[threadIdx.x] = a.obj_off[ja + threadIdx.x];
   const float trunc = a.thr * pitch;
   for (int i = threadIdx.x; i < 2 * nvh; i += kTileThreads) { s_dist[i] = 0x7f800000u; s_id[i] = kNoCand; }
-  for (int i = threadIdx.x; i < Ns * (kTileThreads / 16) * 13; i += kTileThreads) s_rows2[i] = 0.0f;
+  for (int i = threadIdx.x; i < (MAXNS > kRows2Chunk ? min(Ns, kRows2Chunk) : Ns) * (kTileThreads / 16) * 13; i += kTileThreads)
+    s_rows2[i] = 0.0f;  // (the rows of the first chunk; MAXNS = 64: Ns <= 64)
   for (int i = threadIdx.x; i < (kTileThreads / 16) * (kNumF + 1); i += kTileThreads) (&s_rows[0][0])[i] = 0.0f;
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
   auto stamp = [&](int i) {  // tuning aid (MF_ICC_DEBUG & 32)
@@ -1744,15 +1802,14 @@ __device__ __forceinline__ void icc_fused_body(const IccArgs &a, const int ks_rt
   TileGeom tg_;
   tg_.o = o; tg_.ja = ja; tg_.Ns = Ns; tg_.x = x; tg_.y0 = y0; tg_.nvox = nvox; tg_.nvh = nvh; tg_.Wp = Wp; tg_.D = D;
   tg_.K = K; tg_.pitch = pitch; tg_.trunc = trunc; tg_.ox = ox; tg_.oy = oy; tg_.oz = oz;
-  icc_voxel_phase(a, par, tg_, ne0, tg0, s_dist, s_id, s_rows2, L.v, s_Rt, s_off, stamp);
+  icc_voxel_phase<(MAXNS > kRows2Chunk)>(a, par, tg_, ne0, tg0, s_dist, s_id, s_rows2, L.v, s_Rt, s_off, stamp);
   stamp(4);
 }
 
 #ifndef MF_ICC_FUSED_WPE
 #define MF_ICC_FUSED_WPE 4  // waves per SIMD the register budget is cut for (4: 128 VGPRs; 5: 96; 6: 80; 8: 64)
 #endif
-__global__ __launch_bounds__(kTileThreads, MF_ICC_FUSED_WPE) void k_icc_fused(IccArgs a, int par) {  // 2 workgroups per CU
-  __shared__ FusedLds L;
+// (a macro, not a wrapper function: through a wrapper the standard kernel compiled to seven more SGPR spills)
   // Workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md): with the plain (tile, object)
   // numbering the 64 tiles of a grid are spread over all eight L2s and each of them fetches the grid's records,
   // points and voxels over the fabric.  XCD-contiguous logical order (a.dbg bit 2048 for now): XCD k takes the logical
@@ -1764,16 +1821,24 @@ __global__ __launch_bounds__(kTileThreads, MF_ICC_FUSED_WPE) void k_icc_fused(Ic
   // off).  Two other placements for ONE scene, both measured slower than the plain order (22.6-22.9 us) and removed:
   // planes rotated by D / 2 in every other block of 256 workgroups (a central next to an outer plane on a CU:
   // 23.9-24.1), centre-out dispatch with the objects rotating over the XCDs (23.3); profiles/r05_icc_xcd_order_ab.log.
-  int lin = blockIdx.y * gridDim.x + blockIdx.x;
-  const int G_ = gridDim.x * gridDim.y;
-  if (a.xcd_order && (G_ & 7) == 0) lin = (lin & 7) * (G_ >> 3) + (lin >> 3);
-  const int o = lin / (int)gridDim.x;
-  const int tile_ = lin - o * (int)gridDim.x;
-  const int ks = min(ksize_of(a.thr, a.pitch[o]), 2 * a.hmax + 1);  // block-uniform
-  if (ks == 3)
-    icc_fused_body<3>(a, 3, par, L, o, tile_);
-  else
+#define MF_ICC_FUSED_KERNEL_BODY(MAXNS_) \
+  __shared__ FusedLds<MAXNS_> L; \
+  int lin = blockIdx.y * gridDim.x + blockIdx.x; \
+  const int G_ = gridDim.x * gridDim.y; \
+  if (a.xcd_order && (G_ & 7) == 0) lin = (lin & 7) * (G_ >> 3) + (lin >> 3); \
+  const int o = lin / (int)gridDim.x; \
+  const int tile_ = lin - o * (int)gridDim.x; \
+  const int ks = min(ksize_of(a.thr, a.pitch[o]), 2 * a.hmax + 1); \
+  if (ks == 3) \
+    icc_fused_body<3>(a, 3, par, L, o, tile_); \
+  else \
     icc_fused_body<0>(a, ks, par, L, o, tile_);
+__global__ __launch_bounds__(kTileThreads, MF_ICC_FUSED_WPE) void k_icc_fused(IccArgs a, int par) {  // 2 workgroups per CU
+  MF_ICC_FUSED_KERNEL_BODY(kRows2Chunk)
+}
+// scenes of 65 .. 128 objects: the scene tables for 128, the collision rows re-used chunk by chunk (round 6)
+__global__ __launch_bounds__(kTileThreads, MF_ICC_FUSED_WPE) void k_icc_fused_big(IccArgs a, int par) {
+  MF_ICC_FUSED_KERNEL_BODY(kMaxSceneObjects)
 }
 
 // ---- the step as a kernel of its own: one 64-lane workgroup per object ----------------
@@ -1893,6 +1958,13 @@ WsLayout ws_layout(const mfIccBatch *b) {
   return l;
 }
 
+// {0,1} no-entry grids on a tile that fits the workgroup take the single-pass kernel; MF_ICC_GENERAL=1 asks for the
+// two-kernel path (A/B measurements)
+bool icc_single_pass(const mfIccBatch *b) {
+  return b->grid_ne_binary != 0 && ((b->dim + 1) / 2) * b->dim <= kTileThreads &&
+         !(getenv("MF_ICC_GENERAL") && atoi(getenv("MF_ICC_GENERAL")) != 0);
+}
+
 IccArgs make_args(const mfIccBatch *b, void *ws) {
   IccArgs a;
   a.pts4 = (const float4 *)b->pts4;
@@ -1910,9 +1982,7 @@ IccArgs make_args(const mfIccBatch *b, void *ws) {
   a.sdf_offset = b->sdf_offset;
   a.max_ns = b->max_scene_objects;
   // single pass only for {0,1} no-entry grids, one voxel of a half-plane per lane, and unless
-  // MF_ICC_GENERAL=1 asks for the two-kernel path (A/B measurements)
-  a.ne_binary = b->grid_ne_binary != 0 && ((b->dim + 1) / 2) * b->dim <= kTileThreads &&
-                !(getenv("MF_ICC_GENERAL") && atoi(getenv("MF_ICC_GENERAL")) != 0);
+  a.ne_binary = icc_single_pass(b);
   a.dbg = getenv("MF_ICC_DEBUG") ? atoi(getenv("MF_ICC_DEBUG")) : 0;
   const WsLayout l = ws_layout(b);
   char *p = (char *)ws;
@@ -1949,14 +2019,18 @@ void launch_iteration(const IccArgs &a, IccStepArgs sp, int NB, int k, hipStream
   sp.fused = a.ne_binary;
   hipLaunchKernelGGL(k_icc_bin, dim3(a.n_tab), dim3(kBinThreads), 0, stream, a, sp);
   const size_t lds_tile = (size_t)((D + 1) / 2) * D * 2 * sizeof(uint32_t);  // 4 KB at D = 32
-  const size_t lds_rows2 = (size_t)a.max_ns * (kAccThreads / 16) * 13 * sizeof(float);  // 53 KB at 32, 106 KB at 64 objects
+  // 53 KB at 32, 106 KB at 64 objects; beyond that the single-pass kernel re-uses the rows chunk by chunk
+  const size_t lds_rows2 = (size_t)min(a.max_ns, kRows2Chunk) * (kAccThreads / 16) * 13 * sizeof(float);
   if (a.ne_binary) {
     // MF_ICC_LDS_PAD (bytes, tuning): unused dynamic LDS on top -- from ~48 KB on only ONE workgroup of k_icc_fused
     // fits a CU (half the resident waves: the experiment of leaving wave slots to a network running beside it)
     static const size_t pad = getenv("MF_ICC_LDS_PAD") ? (size_t)atoi(getenv("MF_ICC_LDS_PAD")) : 0;
     const size_t lds = 4 * fused_tile_words(D) * sizeof(uint32_t) + lds_rows2 + pad;
     if (pad) mf::allow_big_lds((const void *)k_icc_fused, (int)lds);
-    hipLaunchKernelGGL(k_icc_fused, dim3(D * kHalves, a.O), dim3(kTileThreads), lds, stream, a, par);
+    if (a.max_ns > kRows2Chunk)
+      hipLaunchKernelGGL(k_icc_fused_big, dim3(D * kHalves, a.O), dim3(kTileThreads), lds, stream, a, par);
+    else
+      hipLaunchKernelGGL(k_icc_fused, dim3(D * kHalves, a.O), dim3(kTileThreads), lds, stream, a, par);
     return;
   }
   hipLaunchKernelGGL(k_icc_tile, dim3(D * kHalves, 2 * a.O), dim3(kTileThreads), lds_tile, stream, a, par);
@@ -1980,7 +2054,8 @@ std::mutex g_graph_mu;
 
 static bool icc_batch_ok(const mfIccBatch *b) {
   return b && b->n_objects > 0 && b->n_scenes > 0 && b->dim > 0 && b->dim <= 64 &&
-         b->n_points >= 0 && b->max_scene_objects > 0 && b->max_scene_objects <= kMaxSceneObjects &&
+         b->n_points >= 0 && b->max_scene_objects > 0 &&
+         b->max_scene_objects <= (icc_single_pass(b) ? kMaxSceneObjects : kMaxSceneObjectsGeneral) &&
          b->voxel_threshold > 0.0f && ksize_host(b->voxel_threshold) <= 7 &&
          (double)b->n_points * 343.0 < 4294967295.0 && b->n_points < (1 << 27) && b->flags == 0;
 }
@@ -2009,6 +2084,7 @@ extern "C" int mf_icc_iteration_launches(const mfIccBatch *batch) {
 static int icc_validate(const mfIccBatch *b) {
   // collision-moment rows: max_scene_objects x 1664 B of dynamic LDS (106 KB at 64 objects)
   if (int e = mf::allow_big_lds((const void *)k_icc_fused, 124 * 1024)) return e;
+  if (int e = mf::allow_big_lds((const void *)k_icc_fused_big, 124 * 1024)) return e;
   if (int e = mf::allow_big_lds((const void *)k_icc_accum, 124 * 1024)) return e;
   if (!icc_batch_ok(b)) {
     mf::set_last_error(hipErrorInvalidValue, "mf_icc: invalid batch descriptor");
@@ -2046,8 +2122,11 @@ extern "C" int mf_icc_launch_stage(const mfIccBatch *batch, const float *q, cons
       return -(int)hipErrorInvalidValue;
     }
     const size_t lds = 4 * fused_tile_words(D) * sizeof(uint32_t) +
-                       (size_t)a.max_ns * (kAccThreads / 16) * 13 * sizeof(float);
-    hipLaunchKernelGGL(k_icc_fused, dim3(D * kHalves, a.O), dim3(kTileThreads), lds, stream, a, 0);
+                       (size_t)min(a.max_ns, kRows2Chunk) * (kAccThreads / 16) * 13 * sizeof(float);
+    if (a.max_ns > kRows2Chunk)
+      hipLaunchKernelGGL(k_icc_fused_big, dim3(D * kHalves, a.O), dim3(kTileThreads), lds, stream, a, 0);
+    else
+      hipLaunchKernelGGL(k_icc_fused, dim3(D * kHalves, a.O), dim3(kTileThreads), lds, stream, a, 0);
   } else {
     mf::set_last_error(hipErrorInvalidValue, "mf_icc_launch_stage: stage must be 0, 1 or 2");
     return -(int)hipErrorInvalidValue;

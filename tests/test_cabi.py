@@ -53,7 +53,11 @@ def test_workspace_size_is_host_only_arithmetic():
     assert ws(ctypes.byref(desc(64, 8, 8 * 28000, 8))) > n
     assert ws(ctypes.byref(desc(8, 1, 28000, 8, thr=4.0))) > n       # kernel size 5: two more planes
     assert ws(ctypes.byref(desc(40, 1, 28000, 40))) > n              # 33..64 objects in a scene: allowed since round 3
-    assert ws(ctypes.byref(desc(70, 1, 28000, 70))) < 0              # > 64 objects in a scene
+    assert ws(ctypes.byref(desc(96, 1, 28000, 96))) > n              # 65..128 objects: the single-pass path (round 6)
+    assert ws(ctypes.byref(desc(130, 1, 28000, 130))) < 0            # > 128 objects in a scene
+    general = desc(70, 1, 28000, 70)
+    general.grid_ne_binary = 0                                       # any no-entry values: the two-kernel path stays at 64
+    assert ws(ctypes.byref(general)) < 0
     assert ws(ctypes.byref(desc(8, 1, 28000, 8, thr=9.0))) < 0       # kernel size > 7
 
 

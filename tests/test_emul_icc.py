@@ -254,3 +254,29 @@ def test_icc_scene_of_more_than_32_objects(lib, sp, n_obj):
     np.testing.assert_allclose(gq, gq_o, rtol=2e-3, atol=2e-5)
     np.testing.assert_allclose(gt, gt_o, rtol=2e-3, atol=2e-4)
     assert np.abs(gq).sum() > 0
+
+
+def test_icc_scene_of_more_than_64_objects_on_the_single_pass_path(lib):
+    """Round 6: the single-pass path takes scenes of up to 128 objects -- the collision moments' LDS rows (1664 bytes
+    per other object and workgroup: 106 KB at 64) are re-used chunk by chunk of 64 objects, the voxels' collision
+    terms wait in registers.  A 72-object scene (thinned point sets) gives the oracle's loss and gradients, including
+    the gradients of the objects of the second chunk; the two-kernel path (64-bit object masks) refuses it."""
+    import ctypes
+    n_obj = 72
+    sc = dict(synthetic.make_icc_scene(n_obj, seed=5))
+    sc["points"] = [p[::20].copy() for p in sc["points"]]
+    sc["sdf"] = [s[::20].copy() for s in sc["sdf"]]
+    S = emul.EmulIccScenes(lib, [_dict(sc)], sdf_offset=0.02, single_pass=True)
+    assert S.desc.max_scene_objects == n_obj and S.desc.grid_ne_binary == 1
+    q0, t0 = _pose0(sc)
+    loss, gq, gt = S.loss_grad(q0, t0)
+    l_o, gq_o, gt_o, _ = OC.icc_loss_grad(*_args(sc), q0, t0, sdf_offset=0.02)
+    np.testing.assert_allclose(loss[0], l_o, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(gq, gq_o, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(gt, gt_o, rtol=2e-3, atol=2e-4)
+    assert np.abs(gq_o[64:]).sum() > 0 and np.abs(gt_o[64:]).sum() > 0  # the second chunk's objects do collide
+    general = type(S.desc)()
+    ctypes.memmove(ctypes.byref(general), ctypes.byref(S.desc), ctypes.sizeof(general))
+    general.grid_ne_binary = 0
+    assert lib.mf_icc_workspace_bytes(ctypes.byref(general)) < 0
+

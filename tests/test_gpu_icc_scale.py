@@ -100,9 +100,11 @@ def test_config4_share_8_scenes_of_8_objects_through_rccl_gather(fixtures3, nccl
     assert worst < 1e-5, worst
 
 
-@pytest.mark.parametrize("single_pass", [True, False], ids=["single_pass", "two_kernel"])
-@pytest.mark.parametrize("n_obj", [40, 64])
+@pytest.mark.parametrize("n_obj,single_pass", [(40, True), (40, False), (64, True), (64, False), (96, True)],
+                         ids=["40-single_pass", "40-two_kernel", "64-single_pass", "64-two_kernel", "96-single_pass"])
 def test_scene_of_40_and_64_objects_vs_oracle(n_obj, single_pass):
+    """(96 objects, round 6: the single-pass path re-uses the collision moments' LDS rows chunk by chunk of 64
+    objects; the two-kernel path -- 64-bit object masks -- refuses more than 64, test_cabi.py.)"""
     sc = mf.synthetic.make_icc_scene(n_obj, seed=5)
     sc = dict(sc)
     sc["points"] = [p[::4].copy() for p in sc["points"]]       # (keeps the C oracle's O(N^2 P) pass short)
@@ -116,6 +118,7 @@ def test_scene_of_40_and_64_objects_vs_oracle(n_obj, single_pass):
     np.testing.assert_allclose(gq.cpu().numpy(), gq_o, rtol=2e-3, atol=2e-5)
     np.testing.assert_allclose(gt.cpu().numpy(), gt_o, rtol=2e-3, atol=2e-4)
     assert np.abs(gq_o[42:]).sum() > 0 if n_obj > 43 else True   # the objects past lane 511 / 12 contribute
+    assert np.abs(gq_o[64:]).sum() > 0 if n_obj > 64 else True   # ... and those of the second chunk of LDS rows
     # teacher-forced fused steps (pose table of up to 768 words, 64-bit object masks, looped moment reduction)
     iters = 6
     _, _, losses_o, traj_o, hist_o = OC.icc_refine(*_args(sc), q0, t0, n_iter=iters, sdf_offset=0.02,
