@@ -335,9 +335,20 @@ def icc_many_scenes(wl, n_scenes=8):
     it_bytes = 2 * (pts_bytes + grid_bytes)
     us = ms * 1e3 / args.icc_iters
     gbs = it_bytes / (us * 1e-6) / 1e9
-    return dict(scenes=n_scenes, objects=int(q.shape[0]), algorithmic_bytes=it_bytes, us=round(us, 3),
-                us_per_scene=round(us / n_scenes, 3), achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
-                workspace_mb=round(icc.ws.numel() / 1e6, 1))
+    out = dict(scenes=n_scenes, objects=int(q.shape[0]), algorithmic_bytes=it_bytes, us=round(us, 3),
+               us_per_scene=round(us / n_scenes, 3), achieved=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
+               workspace_mb=round(icc.ws.numel() / 1e6, 1))
+    # the throughput regime's counters (rocprofv3 --pmc passes of these launches at 8 scenes, round 6): where a wave's
+    # time goes and how much of the launch is VALU issue alone
+    pmc = os.path.join(ROOT, "profiles", "r06_icc_issue_pmc_scenes8.json")
+    if n_scenes == 8 and args.objects == 8 and os.path.exists(pmc):
+        ks = json.load(open(pmc))["kernels"]
+        out["counters"] = dict(source="profiles/r06_icc_issue_pmc_scenes8.json", **{
+            k: dict(us=v["avg_duration_us_kernel_trace"], insts_per_wave={n: v["per_wave"][n] for n in ("valu", "salu", "lds", "smem", "vmem_rd")},
+                    valu_issue_floor_us=v["valu_floor_us_at_2.4GHz"], valu_issue_frac_of_launch=v["valu_floor_frac_of_duration"],
+                    wave_life_frac=v["fractions_of_wave_lifetime"], resident_waves_per_simd=v["mean_resident_waves_per_simd"])
+            for k, v in ks.items()})
+    return out
 
 
 def icc_issue_model(kname, icc, us_live):
