@@ -417,6 +417,15 @@ int64_t mf_conv3d_bf16_fwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout,
 int mf_conv3d_bf16_fwd_ws(const void *x, const void *wt, const float *bias, void *out, void *ws, int64_t ws_bytes,
                           int32_t B, int32_t Cin, int32_t Cout, int32_t D, int32_t ks, int32_t stride, int32_t pad,
                           int32_t dil, int32_t relu, int32_t out_f32, int32_t ldo, mfStream_t stream);
+/* 3 x 3 x 3, stride 1, pad = dilation convolutions between NARROW layers (read channels 8 or 16, written channels <= 16)
+ * on channels-last bf16 grids -- the occupancy branch conv1_occ / conv2_occ (model.py:69-72,120-124) and conv2_occ's
+ * data gradient (pack with transpose = 1): voxels are the MFMA's columns, operands straight from global memory.
+ * wp: mf_conv3d_k3_narrow_bf16_pack_elems(CI) bf16, CI = channels of the tensor the convolution reads. */
+int64_t mf_conv3d_k3_narrow_bf16_pack_elems(int32_t CI);
+int mf_conv3d_k3_narrow_bf16_pack(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin, int32_t c_off,
+                                  int32_t transpose, void *wp, mfStream_t stream);
+int mf_conv3d_k3_narrow_bf16(const void *x, const void *wp, const float *bias, void *out, int32_t B, int32_t CI,
+                             int32_t CO, int32_t D, int32_t dil, int32_t relu, mfStream_t stream);
 int64_t mf_conv3d_bf16_wgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t ks, int32_t split);
 int32_t mf_wgrad_split(int64_t tiles, int64_t ktiles, int64_t slab_bytes);
 /* slabs mf_linear_wgrad_bf16 should be given for dW [N][K] over M rows (answers for the tile form that will run) */

@@ -92,6 +92,9 @@ _SIGNATURES = {
     "mf_conv3d_bf16_fwd": ([_p, _p, _p, _p] + [ctypes.c_int32] * 11 + [_p], _i),
     "mf_conv3d_bf16_fwd_workspace_bytes": ([ctypes.c_int32] * 8, _i64),
     "mf_conv3d_bf16_fwd_ws": ([_p, _p, _p, _p, _p, _i64] + [ctypes.c_int32] * 11 + [_p], _i),
+    "mf_conv3d_k3_narrow_bf16_pack_elems": ([ctypes.c_int32], _i64),
+    "mf_conv3d_k3_narrow_bf16_pack": ([_p] + [ctypes.c_int32] * 5 + [_p, _p], _i),
+    "mf_conv3d_k3_narrow_bf16": ([_p, _p, _p, _p] + [ctypes.c_int32] * 6 + [_p], _i),
     "mf_conv3d_bf16_wgrad_workspace_bytes": ([ctypes.c_int32] * 4, _i64),
     "mf_wgrad_split": ([_i64, _i64, _i64], _i),
     "mf_linear_wgrad_bf16_default_split": ([_i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32], ctypes.c_int32),

@@ -13,6 +13,7 @@ bf16, gradients of parameters fp32 (what ``torch.autocast`` produces with stock 
 No fallback: a CPU tensor or a missing libmfhip.so raises.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -107,6 +108,34 @@ class Conv3d(torch.autograd.Function):
         if need_dx and not (k4s2 or stride == 1):
             raise NotImplementedError("data gradient: k4/s2/p1 or stride-1 layers")
 
+        # 3 x 3 x 3 / stride 1 / pad = dilation between narrow layers (the occupancy branch: 8 -> 8, 8 -> 16 and the
+        # data gradient 16 -> 8): the voxels-as-columns MFMA kernel instead of 8 or 16 valid columns of a GEMM tile
+        def narrow(ci, co):
+            return (ks == 3 and stride == 1 and pad == dil and ci in (8, 16) and 4 <= co <= 16 and co % 4 == 0
+                    and D & (D - 1) == 0 and c_off == 0 and os.environ.get("MF_NARROW_CONV", "1") != "0")
+        nar_f, nar_d = narrow(Cin, Cout), need_dx and narrow(Cout, Cin)
+
+        def build_narrow(transpose):
+            w = weight.detach().float().contiguous()
+            wp = _empty((int(L.mf_conv3d_k3_narrow_bf16_pack_elems(Cout if transpose else Cin)),), BF16, x)
+            _lib.check(L.mf_conv3d_k3_narrow_bf16_pack(w.data_ptr(), Cout, Cin, w_cin, c_off, int(transpose), wp.data_ptr(),
+                                                       _lib.stream_ptr()), "mf_conv3d_k3_narrow_bf16_pack")
+            return wp
+
+        wpd = _cached_pack(weight, ("k3n_d", Cin, x.device.index), lambda: build_narrow(True)) if nar_d else None
+        if nar_f:
+            wpf = _cached_pack(weight, ("k3n_f", Cin, x.device.index), lambda: build_narrow(False))
+            out = _empty((B, Do ** 3, Cout), BF16, x)
+            b = bias.detach().float().contiguous() if bias is not None else None
+            _lib.check(L.mf_conv3d_k3_narrow_bf16(x.data_ptr(), wpf.data_ptr(), _lib.ptr(b), out.data_ptr(), B, Cin, Cout, D,
+                                                  dil, int(relu), _lib.stream_ptr()), "mf_conv3d_k3_narrow_bf16")
+            wf = None
+            if need_dx and not nar_d:
+                wf = _cached_pack(weight, ("conv3d_flipT", Cin, x.device.index), lambda: build()[2])
+            ctx.save_for_backward(x, None, wf, out if relu else None, wpd)
+            ctx.geom = (B, Cin, Cout, D, Do, ks, stride, pad, dil, w_cin, c_off, bool(relu), bias is not None, weight.shape)
+            return out
+
         def build():
             w = weight.detach().float().contiguous()
             wt = _empty((Cout, ks ** 3, Cin), BF16, x)
@@ -125,20 +154,23 @@ class Conv3d(torch.autograd.Function):
         _lib.check(L.mf_conv3d_bf16_fwd_ws(x.data_ptr(), wt.data_ptr(), _lib.ptr(b), out.data_ptr(), _lib.ptr(ws), nws,
                                            B, Cin, Cout, D, ks, stride, pad, dil, int(relu), 0, Cout,
                                            _lib.stream_ptr()), "mf_conv3d_bf16_fwd_ws")
-        ctx.save_for_backward(x, wd, wf, out if relu else None)
+        ctx.save_for_backward(x, wd, None if nar_d else wf, out if relu else None, wpd)
         ctx.geom = (B, Cin, Cout, D, Do, ks, stride, pad, dil, w_cin, c_off, bool(relu), bias is not None, weight.shape)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, wd, wf, out = ctx.saved_tensors
+        x, wd, wf, out, wpd = ctx.saved_tensors
         B, Cin, Cout, D, Do, ks, stride, pad, dil, w_cin, c_off, relu, has_bias, wshape = ctx.geom
         L = _lib.lib()
         dz = relu_mask(out, dy) if relu else _bf16c(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            if wd is not None:
+            if wpd is not None:  # narrow 3 x 3 x 3 layer: the same kernel on the transposed / flipped pack
+                _lib.check(L.mf_conv3d_k3_narrow_bf16(dz.data_ptr(), wpd.data_ptr(), None, dx.data_ptr(), B, Cout, Cin, D,
+                                                      dil, 0, _lib.stream_ptr()), "mf_conv3d_k3_narrow_bf16 (data gradient)")
+            elif wd is not None:
                 _lib.check(L.mf_conv3d_k4s2_bf16_dgrad(dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, Cin, Cout, D, 0,
                                                        0, _lib.stream_ptr()), "mf_conv3d_k4s2_bf16_dgrad")
             else:  # stride 1: dx = conv(dz, flipped / transposed weights), pad' = dil (ks - 1) - pad

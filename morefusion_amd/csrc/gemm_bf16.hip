@@ -1688,6 +1688,96 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float *__restrict__
   }
 }
 
+// ---- 3 x 3 x 3 convolutions between NARROW layers (round 6): the occupancy branch ----------------------------------
+// conv1_occ (1 -> 8, fed as 8 channels), conv2_occ (8 -> 16, dilation 2) and conv2_occ's data gradient (16 -> 8)
+// (model.py:69-72,120-124) went through k_gemm_nt_bf16<conv forward>: 8 or 16 valid columns of a 128-column tile,
+// 92-99 us each at 16 objects for 8-16 MB of operands.  Here the convolution is out^T = W (x) im2col with the VOXELS as
+// the MFMA's columns: a wave owns 32 voxels, its B operand of k-step s is one 16-byte global load per lane -- the 8
+// channels [c0, c0 + 8) of tap (16 s + 8 (lane / 32)) / CI of the voxel lane % 32, a masked (out-of-range) buffer load
+// for padding taps -- with no LDS stage at all (neighbouring voxels re-read the same 16 bytes from L1 / L2); the A
+// operand, the weights [n][k = tap * CI + ci] of <= 32 output channels, stays in registers for all the tiles a wave
+// walks (KS x 16 bytes per lane).  The accumulator's rows are channels: lane (voxel v, half h) ends up with channels
+// {0..3, 8..11} + 4 h of its voxel -> two 8-byte stores.
+template <int CI, int KS>  // KS = ceil(27 CI / 16) k-steps
+__global__ __launch_bounds__(256) void k_conv_k3_narrow_bf16(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp,
+                                                            const float *__restrict__ bias, uint16_t *__restrict__ out,
+                                                            int B, int D, int dlog, int CO, int dil, int relu,
+                                                            int tiles_per_wave) {
+  const int lane = threadIdx.x & 63, wave_g = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  // the weights: row n of wp [32][KS * 16] (rows >= CO are zero), k = 16 s + 8 h .. + 7
+  uint4 wf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) wf[s] = *reinterpret_cast<const uint4 *>(wp + (size_t)n * (KS * 16) + 16 * s + 8 * h);
+  float bn[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+    bn[e] = bias && row < CO ? bias[row] : 0.0f;
+  }
+  const mf::BufRsrc xrs = mf::make_rsrc(x);
+  const int64_t total = (int64_t)B << (3 * dlog);
+  for (int it = 0; it < tiles_per_wave; ++it) {
+    const int64_t v = ((int64_t)wave_g * tiles_per_wave + it) * 32 + n;  // this lane's voxel (columns of the MFMA)
+    if (v - n >= total) break;  // wave-uniform
+    const bool vok = v < total;
+    const int iz = (int)(v & (D - 1)), iy = (int)((v >> dlog) & (D - 1)), ix = (int)((v >> (2 * dlog)) & (D - 1));
+    const int64_t vb = v - (((int64_t)ix << (2 * dlog)) + ((int64_t)iy << dlog) + iz);  // b * D^3
+    mf_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    uint4 xf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k0 = 16 * s + 8 * h;
+      const int tap = k0 / CI, c0 = k0 - tap * CI;  // (CI = 8: tap = 2 s + h; CI = 16: tap = s, c0 = 8 h)
+      const int kx = tap / 9, ky = (tap - 9 * kx) / 3, kz = tap - 9 * kx - 3 * ky;
+      const int jx = ix + (kx - 1) * dil, jy = iy + (ky - 1) * dil, jz = iz + (kz - 1) * dil;
+      const bool ok = vok && tap < 27 && (unsigned)jx < (unsigned)D && (unsigned)jy < (unsigned)D && (unsigned)jz < (unsigned)D;
+      const int64_t src = (vb + (((int64_t)jx << (2 * dlog)) + ((int64_t)jy << dlog) + jz)) * CI + c0;
+      xf[s] = mf::buf_load16(xrs, ok ? 2u * (uint32_t)src : mf::kBufMasked);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = mf::mfma_bf16_32x32x16(wf[s], xf[s], acc);
+    if (!vok) continue;
+    // rows of the accumulator = output channels (e & 3) + 8 (e >> 2) + 4 h; columns = this lane's voxel
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      if (8 * g + 4 * h >= CO) continue;
+      float o4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float val = acc[4 * g + j] + bn[4 * g + j];
+        if (relu) val = val > 0.0f ? val : 0.0f;
+        o4[j] = val;
+      }
+      *reinterpret_cast<uint2 *>(out + v * CO + 8 * g + 4 * h) = make_uint2(mf::pack_bf16x2(o4[0], o4[1]), mf::pack_bf16x2(o4[2], o4[3]));
+    }
+  }
+}
+
+// W [Cout][w_cin][3][3][3] fp32 (framework layout) -> wp bf16 [32 rows][KS * 16]:
+//   forward        row n = output channel, k = tap * CI + ci:   W[n][c_off + ci][tap]          (CI = the layer's Cin)
+//   data gradient  row n = INPUT channel of the layer, k = tap * CI + co:  W[co][c_off + n][26 - tap]   (CI = Cout)
+// rows >= the valid count, k beyond 27 CI and channels at or beyond w_cin are zero.
+__global__ __launch_bounds__(256) void k_conv_k3_narrow_pack(const float *__restrict__ W, int Cout, int Cin, int w_cin,
+                                                            int c_off, int transpose, int CI, int Kp,
+                                                            uint16_t *__restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 32 * Kp) return;
+  const int nrow = i / Kp, k = i - nrow * Kp;
+  const int tap = k / CI, c = k - tap * CI;
+  float v = 0.0f;
+  if (tap < 27) {
+    if (!transpose) {
+      if (nrow < Cout && c < Cin && c_off + c < w_cin) v = W[((int64_t)nrow * w_cin + c_off + c) * 27 + tap];
+    } else {
+      if (nrow < Cin && c < Cout && c_off + nrow < w_cin) v = W[((int64_t)c * w_cin + c_off + nrow) * 27 + (26 - tap)];
+    }
+  }
+  wp[i] = (uint16_t)mf::bf16_bits(v);
+}
+
 int ilog2_exact(int x) {
   int l = 0;
   while ((1 << l) < x) ++l;
@@ -2120,6 +2210,46 @@ extern "C" int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, vo
                        (const float *)ws, dW + (int64_t)c_off * g.taps, per_slab, g.taps * Cin, g.taps * Cin, a.S, Cin,
                        (int64_t)0, per_slab, (int64_t)w_cin * g.taps, g.taps, keep);
   return mf::check_launch("mf_conv3d_bf16_wgrad");
+}
+
+/* 3 x 3 x 3 convolutions (stride 1, pad = dil) between narrow layers -- Cin in {8, 16}, Cout <= 16 -- on channels-last
+ * bf16 grids whose size D is a power of two: the occupancy branch's conv1_occ / conv2_occ and conv2_occ's data
+ * gradient (``transpose`` at pack time).  wp: 32 x ceil(27 CI / 16) x 16 bf16 from mf_conv3d_k3_narrow_bf16_pack
+ * (CI = the channels of the tensor the convolution READS: Cin forward, Cout for the data gradient). */
+extern "C" int64_t mf_conv3d_k3_narrow_bf16_pack_elems(int32_t CI) { return (int64_t)32 * ((27 * CI + 15) / 16) * 16; }
+
+extern "C" int mf_conv3d_k3_narrow_bf16_pack(const float *W, int32_t Cout, int32_t Cin, int32_t w_cin, int32_t c_off,
+                                             int32_t transpose, void *wp, mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int CI = transpose ? Cout : Cin, NO = transpose ? Cin : Cout;
+  if ((CI != 8 && CI != 16) || NO < 1 || NO > 16 || (NO & 3)) return bad("conv3d_k3_narrow pack: read channels 8 or 16, written channels 4 .. 16 (% 4)");
+  const int Kp = ((27 * CI + 15) / 16) * 16;
+  hipLaunchKernelGGL(k_conv_k3_narrow_pack, dim3((32 * Kp + 255) / 256), dim3(256), 0, stream, W, Cout, Cin, w_cin, c_off,
+                     transpose, CI, Kp, (uint16_t *)wp);
+  return mf::check_launch("mf_conv3d_k3_narrow_bf16_pack");
+}
+
+extern "C" int mf_conv3d_k3_narrow_bf16(const void *x, const void *wp, const float *bias, void *out, int32_t B,
+                                        int32_t CI, int32_t CO, int32_t D, int32_t dil, int32_t relu,
+                                        mfStream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0) return 0;
+  const int dlog = ilog2_exact(D);
+  if ((CI != 8 && CI != 16) || CO < 1 || CO > 16 || (CO & 3) || dlog < 1 || dil < 1 ||
+      (int64_t)B * D * D * D * 16 >= kMaxBf16Elems || (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)out) & 15))
+    return bad("conv3d_k3_narrow: read channels 8 or 16, written channels 4 .. 16 (% 4), D a power of two, 16-byte aligned");
+  const int64_t tiles = ((int64_t)B * D * D * D + 31) / 32;
+  // a wave walks a few tiles with its weights in registers; enough workgroups (4 waves) for every CU
+  int tpw = 1;
+  while (tpw < 8 && tiles / (4 * tpw * 2) >= 2048) tpw *= 2;
+  const unsigned blocks = (unsigned)((tiles + 4 * tpw - 1) / (4 * tpw));
+  if (CI == 8)
+    hipLaunchKernelGGL((k_conv_k3_narrow_bf16<8, 14>), dim3(blocks), dim3(256), 0, stream, (const uint16_t *)x,
+                       (const uint16_t *)wp, bias, (uint16_t *)out, B, D, dlog, CO, dil, relu, tpw);
+  else
+    hipLaunchKernelGGL((k_conv_k3_narrow_bf16<16, 27>), dim3(blocks), dim3(256), 0, stream, (const uint16_t *)x,
+                       (const uint16_t *)wp, bias, (uint16_t *)out, B, D, dlog, CO, dil, relu, tpw);
+  return mf::check_launch("mf_conv3d_k3_narrow_bf16");
 }
 
 /* the k4 / s2 / p1 forms (conv3, conv4) under their round-4 names */

@@ -54,9 +54,18 @@ def test_conv3d_operator_forward_and_gradients(K):
     assert rel(conv.bias.grad, br.grad) < 2e-2
 
 
-def test_occupancy_branch_operator_chain(K):
+@pytest.mark.parametrize("narrow", [True, False], ids=["narrow_kernel", "gemm_engine"])
+def test_occupancy_branch_operator_chain(K, monkeypatch, narrow):
     """conv1_occ -> conv2_occ (model.py:69-72,120-124) through the general-geometry operator: values and the
-    gradients of both layers' parameters vs torch's float32 convolutions."""
+    gradients of both layers' parameters vs torch's float32 convolutions.  ``narrow_kernel`` (the default, round 6):
+    both forward passes and conv2_occ's data gradient on k_conv_k3_narrow_bf16 (voxels as the MFMA's columns, operands
+    straight from global memory) -- three launches, counted; ``gemm_engine`` (MF_NARROW_CONV=0): round 4's path
+    through the implicit-GEMM engine."""
+    monkeypatch.setenv("MF_NARROW_CONV", "1" if narrow else "0")
+    Lh = K._lib.lib()
+    calls = []
+    real = Lh.mf_conv3d_k3_narrow_bf16
+    monkeypatch.setattr(Lh, "mf_conv3d_k3_narrow_bf16", lambda *a: (calls.append(a[5:9]), real(*a))[1], raising=False)
     torch.manual_seed(2)
     B, D = 1, 8
     c1 = torch.nn.Conv3d(1, 8, 3, 1, padding=1)
@@ -86,6 +95,9 @@ def test_occupancy_branch_operator_chain(K):
     h1_pre = r1(grid[:, None])
     h1_pre.backward(dz1)
     assert rel(c1.weight.grad, r1.weight.grad) < 3e-2
+    # (read channels, written channels, D, dilation) of the narrow kernel's launches: forward 8 -> 8, forward 8 -> 16
+    # (dilation 2), data gradient 16 -> 8
+    assert calls == ([(8, 8, D, 1), (8, 16, D, 2), (16, 8, D, 2)] if narrow else [])
 
 
 @pytest.mark.parametrize("n,Kin,N,relu", [(150, 3, 8, True), (130, 64, 63, False), (200, 984, 640, True)])
