@@ -179,6 +179,16 @@ def frontend(side):
     print(f"GUARD_OK frontend {side}")
 
 
+class _MonkeyPatch:
+    """The two pytest.MonkeyPatch calls the test bodies make, without pytest (no undo: the process ends with the case)."""
+
+    def setenv(self, k, v):
+        os.environ[k] = v
+
+    def setattr(self, obj, name, value, raising=True):
+        setattr(obj, name, value)
+
+
 def training(side):
     from morefusion_amd.contrib.singleview_3d.models import bf16_ops
     import test_emul_bf16_ops as T   # the test bodies: operators vs torch float32 autograd / the oracle
@@ -188,7 +198,10 @@ def training(side):
     with emul.GuardedTensors(L, side, log) as G:
         _patch_lib(G)
         T.test_conv3d_operator_forward_and_gradients(bf16_ops)
-        T.test_occupancy_branch_operator_chain(bf16_ops)
+        # both forms of the occupancy branch behind the guard pages: the narrow voxels-as-columns kernel (its padding taps
+        # are masked buffer loads) and the implicit-GEMM engine
+        for narrow in (True, False):
+            T.test_occupancy_branch_operator_chain(bf16_ops, _MonkeyPatch(), narrow)
         for n, Kin, N, relu in ((150, 3, 8, True), (130, 64, 63, False), (70, 200, 136, True)):
             T.test_linear_operator_forward_and_gradients.__wrapped__(bf16_ops, n, Kin, N, relu) if hasattr(
                 T.test_linear_operator_forward_and_gradients, "__wrapped__") else \
