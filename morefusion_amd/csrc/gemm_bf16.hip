@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
     *reinterpret_cast<uint4 *>(Bs_ + 64 * kPitch) = rb2##S; *reinterpret_cast<uint4 *>(Bs_ + 96 * kPitch) = rb3##S; \
   }
   // NJ_ = 2: both 32-column blocks of the wave's 64 columns; NJ_ = 1: the first only (the second lies past N).
-  // The fragments of k-step s + 1 are read while the MFMAs of step s run (round 5, as in k_gemm_nt_bf16_big below: two
+  // The fragments of k-step s + 1 are read while the MFMAs of step s run (round 5: two
   // register sets, the order pinned with sched_group_barrier; MF_NT_PIPE=0: the scheduler's own order).
 #ifndef MF_NT_PIPE
 #define MF_NT_PIPE 1
@@ -366,321 +366,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(NtArgs a) {
   }
 }
 
-// ---- the 256 x 256 x 64 form of the NT engine (round 5): eight waves, each a 128 x 64 corner = 4 x 2 accumulators ----
+// ---- the 256 x 256 x 64 tile (round 5: eight waves, each a 128 x 64 corner = 4 x 2 accumulators) --------------------
 // A wave of the 128 x 128 tile reads one LDS fragment (ds_read_b128) per MFMA: at the MFMA rate of gfx950 that alone
-// keeps the LDS pipe busy all the time (1 KB per wave per 32-cycle MFMA, four SIMDs, 128 B / clock).  With a 128 x 64
-// wave tile a k-step reads 4 + 2 fragments for 8 MFMAs -- 0.75 per MFMA; one workgroup of 512 lanes per CU (2 x 74 KB
-// of operand buffers), two waves per SIMD.  Same loaders, masks and staging order as k_gemm_nt_bf16 (rows r0 + 64 i);
-// the epilogue goes through LDS in four passes of 64 rows.  Used when the problem has enough 256 x 256 tiles to
-// fill the chip (launch_nt); conv dgrad tiles stay class-homogeneous for Do^3 % 256 == 0.
+// keeps the LDS pipe busy all the time (1 KB per wave per 32-cycle MFMA, four SIMDs).  With a 128 x 64 wave tile a
+// k-step reads 4 + 2 fragments for 8 MFMAs -- 0.75 per MFMA.  Round 5's form of this tile staged its operands through
+// registers (global -> VGPR -> ds_write_b128, one barrier per K-tile: 852 / 961 TFLOP/s on conv3 forward / conv4 data
+// gradient, MFMA pipe 0.43 busy); round 6's k_gemm_nt_bf16_pp below replaced it (1019-1059 / 1202-1225 in the same
+// measurement) and the register-staged kernel is gone from the source.
 constexpr int kBigM = 256, kBigN = 256;
-#ifndef MF_NT_BIG_UNROLL  // k-steps of a K-tile in flight (fragments held): 2 -> 218-226 VGPRs, no spill (budget 256)
-#define MF_NT_BIG_UNROLL _Pragma("unroll 2")
-#endif
-constexpr int nt_big_lds() { return 2 * (kBigM + kBigN) * kPitch; }
-
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_big(NtArgs a) {
-  MF_DYN_LDS(unsigned char, s_raw);
-  constexpr int kBM = kBigM, kBNb = kBigN, kBuf = (kBigM + kBigN) * kPitch;
-  const int tiles_m = (a.M + kBM - 1) / kBM, tiles_n = (a.N + kBNb - 1) / kBNb;
-  const int per_group = tiles_m * tiles_n;
-  const int G = gridDim.x;
-  int L = blockIdx.x;
-  if ((G & 7) == 0) L = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);  // XCD-contiguous logical order
-  const int grp = L / per_group;
-  const int rem = L - grp * per_group;
-  const int m0 = (rem / tiles_n) * kBM, n0 = (rem % tiles_n) * kBNb;  // N tile fastest (csrc/linear.hip)
-  const int T = (a.K + kBK - 1) / kBK;
-
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wm = wave & 1, wn = wave >> 1;  // 2 x 4 waves of 128 x 64
-  const int lrow = lane & 31, lhalf = lane >> 5;
-  const int chunk = tid & 7, r0 = tid >> 3;  // this lane stages rows r0 + 64 i, bf16 8 chunk .. + 7 of the K-tile
-
-  const int Do = a.Do, dol = a.olog;
-  const uint16_t *A = a.A + grp * a.a_gs;
-  const uint16_t *W = a.W + grp * a.w_gs;
-  if (MODE == kRows && a.tile_group) {
-    const int g = a.tile_group[m0 >> 6];  // (block-uniform)
-    if (g < 0) return;
-    W += (int64_t)g * a.w_gs;
-  }
-  int cls = 0;
-  if (MODE == kConvDgrad) {  // tile-uniform parity class: its weight slice
-    cls = (m0 >> (3 * dol)) & 7;
-    W += (int64_t)cls * a.N * a.ldw;
-  }
-  // per staged row: element offset of its k = 0 chunk and validity bits
-  //   rows:        bit 12 = row exists
-  //   conv fwd:    bits kx | 4 + ky | 8 + kz = tap coordinate inside the grid (csrc/conv3d.hip)
-  //   conv dgrad:  bits sx | 4 + sy | 8 + sz = contributing output voxel h + p - s inside the output grid
-  int base[4], mask[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + r0 + 64 * i;
-    const bool row_ok = m < a.M;
-    const int mm = row_ok ? m : 0;
-    int mk = row_ok ? 1 << 12 : 0;
-    if (MODE == kRows) {
-      base[i] = mm * a.lda;
-    } else if (MODE == kConvFwd) {
-      const int b = mm >> (3 * dol), o = mm & ((1 << (3 * dol)) - 1);
-      const int ox = o >> (2 * dol), oy = (o >> dol) & (Do - 1), oz = o & (Do - 1);
-      const int x0 = a.stride * ox - a.pad, y0 = a.stride * oy - a.pad, z0 = a.stride * oz - a.pad;
-      base[i] = (((b * a.D + x0) * a.D + y0) * a.D + z0) * a.Cin;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {  // (k >= ks: never asked for)
-        mk |= ((unsigned)(x0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << k;
-        mk |= ((unsigned)(y0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (4 + k);
-        mk |= ((unsigned)(z0 + a.dil * k) < (unsigned)a.D ? 1 : 0) << (8 + k);
-      }
-    } else {
-      // m = ((b * 8 + p) * Do^3 + h): input voxel x = 2 h + p per axis
-      const int h = mm & ((1 << (3 * dol)) - 1), b = mm >> (3 * dol + 3);
-      const int hx = h >> (2 * dol), hy = (h >> dol) & (Do - 1), hz = h & (Do - 1);
-      const int ux = hx + (cls & 1), uy = hy + ((cls >> 1) & 1), uz = hz + ((cls >> 2) & 1);  // slot (0,0,0)
-      base[i] = (((b * Do + ux) * Do + uy) * Do + uz) * a.Cout;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        mk |= ((unsigned)(ux - s) < (unsigned)Do ? 1 : 0) << s;
-        mk |= ((unsigned)(uy - s) < (unsigned)Do ? 1 : 0) << (4 + s);
-        mk |= ((unsigned)(uz - s) < (unsigned)Do ? 1 : 0) << (8 + s);
-      }
-    }
-    mask[i] = mk;
-  }
-  uint32_t wrow[4];  // byte offsets into W (weights: far below 2^32 bytes)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + r0 + 64 * i;
-    wrow[i] = 2u * (uint32_t)((int64_t)(n < a.N ? n : 0) * a.ldw);
-  }
-
-  mf_f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-  // K-tile kt -> registers.  Nothing touches the loaded data before the stash: a select right behind a load would
-  // make the wave wait for its own data at once (s_waitcnt vmcnt(0) in front of the MFMAs) and the prefetch would
-  // hide nothing.
-  // (Scalars and macros, not arrays in lambdas: behind the "memory" clobber that pins the loads in front of the MFMAs,
-  // arrays captured by reference were kept in scratch memory -- every load waited for and stored.)
-  // ONE register set, one tile ahead.  (Two sets -- tile t + 2 in flight while t + 1 waits -- were measured twice in
-  // round 4, before and after the VALU diet: no gain on any shape, 90 more registers.)
-  uint4 ra0P, ra1P, ra2P, ra3P, rb0P, rb1P, rb2P, rb3P;
-  // This lane's position in K, advanced by one K-tile per fetch (the fetches run over kt = 0, 1, 2, ... in order): the
-  // chunk's k offset and, for the convolutions, its (tap, channel) -- tracked incrementally (round 4, first version:
-  // two integer divisions per fetch and 64-bit address arithmetic per load, 12 VALU instructions per MFMA by
-  // SQ_INSTS_VALU; the MFMA pipe at 0.37).
-  int kg = 8 * chunk, tc = 0, tx = 0, ty = 0, tz = 0;  // conv fwd: tap (tx, ty, tz), channel tc; dgrad: slot tx, cout tc
-  if (MODE == kConvFwd) {
-    const int tap = kg / a.Cin;
-    tc = kg - tap * a.Cin;
-    const int kxy = tap / a.ks;
-    tz = tap - kxy * a.ks; tx = kxy / a.ks; ty = kxy - tx * a.ks;
-  } else if (MODE == kConvDgrad) {
-    tx = kg / a.Cout;
-    tc = kg - tx * a.Cout;
-  }
-  // A masked chunk (padding tap, row past the edge, K tail) is a buffer load at an OUT-OF-RANGE offset: the hardware
-  // returns zeros (mf_common.h).  No select or AND on the loaded data (that was 44 VALU instructions per K-tile in
-  // every wave that touches a border -- nearly all of them in a 16^3 grid), and the stash is eight plain
-  // ds_write_b128.  The weight operand needs no mask at all: behind the K tail it re-reads k = 0 (finite; the A chunk
-  // there is zero), and a column past N re-reads row 0 into an accumulator column the epilogue never stores.
-  const mf::BufRsrc Ars = mf::make_rsrc(A), Wrs = mf::make_rsrc(W);
-#define MF_NT_LOAD_A(S, i_, reg_)                                                                     \
-  reg_ = mf::buf_load16(Ars, (mask[i_] & bits_) == bits_ ? 2u * (uint32_t)(base[i_] + off_) : mf::kBufMasked);
-#define MF_NT_LOAD_B(S, i_, reg_) reg_ = mf::buf_load16(Wrs, wrow[i_] + kofs_);
-#define MF_NT_FETCH(S)                                                                                \
-  {                                                                                                   \
-    const bool kin_ = kg + 8 <= a.K;                                                                  \
-    const uint32_t kofs_ = kin_ ? 2u * (uint32_t)kg : 0u;                                             \
-    int off_ = kg, bits_ = 1 << 12;                                                                   \
-    if (MODE == kConvFwd) {                                                                           \
-      off_ = ((tx * a.D + ty) * a.D + tz) * a.dil * a.Cin + tc;                                       \
-      bits_ = tx < a.ks ? (1 << tx) | (16 << ty) | (256 << tz) | (1 << 12) : 1 << 13;                 \
-    } else if (MODE == kConvDgrad) {                                                                  \
-      const int sx = tx & 1, sy = (tx >> 1) & 1, sz = tx >> 2;                                        \
-      off_ = tc - ((sx * Do + sy) * Do + sz) * a.Cout;                                                \
-      bits_ = (1 << sx) | (16 << sy) | (256 << sz) | (1 << 12);                                       \
-    }                                                                                                 \
-    if (!kin_) bits_ = 1 << 13; /* (no row has bit 13) */                                             \
-    MF_NT_LOAD_A(S, 0, ra0##S) MF_NT_LOAD_A(S, 1, ra1##S) MF_NT_LOAD_A(S, 2, ra2##S) MF_NT_LOAD_A(S, 3, ra3##S) \
-    MF_NT_LOAD_B(S, 0, rb0##S) MF_NT_LOAD_B(S, 1, rb1##S) MF_NT_LOAD_B(S, 2, rb2##S) MF_NT_LOAD_B(S, 3, rb3##S) \
-    kg += kBK;                                                                                        \
-    if (MODE == kConvFwd) {                                                                           \
-      tc += kBK;                                                                                      \
-      while (tc >= a.Cin) {                                                                           \
-        tc -= a.Cin;                                                                                  \
-        if (++tz == a.ks) { tz = 0; if (++ty == a.ks) { ty = 0; ++tx; } }                             \
-      }                                                                                               \
-    } else if (MODE == kConvDgrad) {                                                                  \
-      tc += kBK;                                                                                      \
-      while (tc >= a.Cout) { tc -= a.Cout; ++tx; }                                                    \
-    }                                                                                                 \
-  }
-  // (MF_HOLD: the staged registers stay opaque until here, BEHIND the MFMAs -- and with them the wait for the loads.)
-#define MF_NT_STASH(S, buf_)                                                                          \
-  {                                                                                                   \
-    MF_HOLD(ra0##S); MF_HOLD(ra1##S); MF_HOLD(ra2##S); MF_HOLD(ra3##S);                               \
-    MF_HOLD(rb0##S); MF_HOLD(rb1##S); MF_HOLD(rb2##S); MF_HOLD(rb3##S);                               \
-    unsigned char *As_ = s_raw + (buf_) * kBuf + r0 * kPitch + 16 * chunk;                            \
-    unsigned char *Bs_ = As_ + kBM * kPitch;                                                          \
-    *reinterpret_cast<uint4 *>(As_) = ra0##S; *reinterpret_cast<uint4 *>(As_ + 64 * kPitch) = ra1##S; \
-    *reinterpret_cast<uint4 *>(As_ + 128 * kPitch) = ra2##S; *reinterpret_cast<uint4 *>(As_ + 192 * kPitch) = ra3##S; \
-    *reinterpret_cast<uint4 *>(Bs_) = rb0##S; *reinterpret_cast<uint4 *>(Bs_ + 64 * kPitch) = rb1##S; \
-    *reinterpret_cast<uint4 *>(Bs_ + 128 * kPitch) = rb2##S; *reinterpret_cast<uint4 *>(Bs_ + 192 * kPitch) = rb3##S; \
-  }
-  // NJ_ = 2: both 32-column blocks of the wave's 64 columns; NJ_ = 1: the first only (the second lies past N)
-  // One K-tile = four k-steps of 16.  The fragments of step s + 1 are read while the MFMAs of step s run: two register
-  // sets, and sched_group_barrier pins the order "6 LDS reads, 8 MFMAs" per step (left to itself the scheduler put
-  // each A fragment's read right in front of the two MFMAs that use it: every pair waited out an LDS round trip).
-  // MF_NT_BIG_PIPE=0 keeps that first form (A/B measurements).
-#ifndef MF_NT_BIG_PIPE
-#define MF_NT_BIG_PIPE 1
-#endif
-#define MF_NT_FRAGS(set_, s_, NJ_)                                                                    \
-  {                                                                                                   \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
-      fa[set_][mi] = *reinterpret_cast<const uint4 *>(As + mi * 32 * kPitch + 32 * (s_));             \
-    fb[set_][0] = *reinterpret_cast<const uint4 *>(Bs + 32 * (s_));                                   \
-    if constexpr (NJ_ == 2) fb[set_][1] = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * (s_)); \
-  }
-#define MF_NT_COMPUTE(buf_, NJ_)                                                                      \
-  {                                                                                                   \
-    asm volatile("" ::: "memory");                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    const unsigned char *As = s_raw + (buf_) * kBuf + (wm * 128 + lrow) * kPitch + 16 * lhalf;        \
-    const unsigned char *Bs = s_raw + (buf_) * kBuf + (kBM + wn * 64 + lrow) * kPitch + 16 * lhalf;   \
-    if constexpr (MF_NT_BIG_PIPE) {                                                                   \
-      uint4 fa[2][4], fb[2][2];                                                                       \
-      MF_NT_FRAGS(0, 0, NJ_)                                                                          \
-      __builtin_amdgcn_sched_group_barrier(0x100, 4 + NJ_, 0);                                        \
-      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                 \
-        const int c = s & 1;                                                                          \
-        if (s < 3) MF_NT_FRAGS(c ^ 1, s + 1, NJ_)                                                     \
-        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                            \
-          acc[mi][0] = mf::mfma_bf16_32x32x16(fa[c][mi], fb[c][0], acc[mi][0]);                       \
-          if constexpr (NJ_ == 2) acc[mi][1] = mf::mfma_bf16_32x32x16(fa[c][mi], fb[c][1], acc[mi][1]); \
-        }                                                                                             \
-        if (s < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4 + NJ_, 0);                           \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ_, 0);                                      \
-      }                                                                                               \
-    } else {                                                                                          \
-      MF_NT_BIG_UNROLL for (int s = 0; s < 4; ++s) {                                                  \
-        const uint4 b0 = *reinterpret_cast<const uint4 *>(Bs + 32 * s);                               \
-        uint4 b1 = b0;                                                                                \
-        if constexpr (NJ_ == 2) b1 = *reinterpret_cast<const uint4 *>(Bs + 32 * kPitch + 32 * s);     \
-        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                            \
-          const uint4 am = *reinterpret_cast<const uint4 *>(As + mi * 32 * kPitch + 32 * s);          \
-          acc[mi][0] = mf::mfma_bf16_32x32x16(am, b0, acc[mi][0]);                                    \
-          if constexpr (NJ_ == 2) acc[mi][1] = mf::mfma_bf16_32x32x16(am, b1, acc[mi][1]);            \
-        }                                                                                             \
-      }                                                                                               \
-    }                                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-  }
-  // Column blocks of this wave that lie past N (the last N-tile of a layer whose width is not a multiple of 128:
-  // conv3's data gradient has N = 160 -- its second tile holds 32 columns) are not multiplied: wave-uniform.
-  const int ncols = a.N - (n0 + wn * 64);  // columns of this wave's 64 that exist
-  // Per K-tile t: the loads of tile t + 1 are issued, tile t is multiplied, the registers go into the other buffer,
-  // barrier.  (Stash AFTER the barrier and the next fetch right behind it -- the order the 256^2-tile GEMMs of the
-  // programming guide prefer -- measured 3 - 5 % slower here, at 2 workgroups per CU.)  The fetches run over the
-  // K-tiles in order, one past the last (k beyond K: every chunk masked, zeros into the buffer nobody reads again) --
-  // NOT under "if (t + 1 < T)": behind a branch the compiler copies the loaded registers at the join and waits for
-  // the loads right where they are issued (measured: 2x slower).
-  MF_NT_FETCH(P);  // tile 0
-  MF_NT_STASH(P, 0);
-  __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    MF_NT_FETCH(P);  // tile t + 1 in flight under the MFMAs of tile t
-    if (ncols > 32) MF_NT_COMPUTE(t & 1, 2) else if (ncols > 0) MF_NT_COMPUTE(t & 1, 1)
-    MF_NT_STASH(P, (t + 1) & 1);
-    __syncthreads();
-  }
-#undef MF_NT_FRAGS
-#undef MF_NT_COMPUTE
-#undef MF_NT_STASH
-#undef MF_NT_FETCH
-#undef MF_NT_LOAD_B
-#undef MF_NT_LOAD_A
-
-  // epilogue through LDS in four passes of 64 rows (the loop ended on a barrier: the operand buffers are free)
-  constexpr int kEp = kBNb + 4;
-  float *s_out = reinterpret_cast<float *>(s_raw);  // [64][kEp]
-  const float *bias = a.bias ? a.bias + grp * a.b_gs : nullptr;
-#pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    if (wm == (pass >> 1)) {
-#pragma unroll
-      for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int nl = wn * 64 + ni * 32 + lrow;
-          const float bn = (bias && n0 + nl < a.N) ? bias[n0 + nl] : 0.0f;
-          const mf_f32x16 &c = (pass & 1) ? acc[2 + mh][ni] : acc[mh][ni];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int ml = mh * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-            float v = c[e] + bn;
-            if (a.relu) v = v > 0.0f ? v : 0.0f;
-            s_out[ml * kEp + nl] = v;
-          }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < 64 * (kBNb / 8); i += 512) {
-      const int ml = i / (kBNb / 8), c8 = i - ml * (kBNb / 8);
-      const int m = m0 + 64 * pass + ml, n = n0 + 8 * c8;
-      if (m >= a.M || n >= a.N) continue;
-      int64_t orow = m;
-      if (MODE == kConvDgrad) {  // class-ordered row -> channels-last voxel row of the input gradient
-        const int h = m & ((1 << (3 * dol)) - 1), p = (m >> (3 * dol)) & 7, b = m >> (3 * dol + 3);
-        const int x = 2 * (h >> (2 * dol)) + (p & 1), y = 2 * ((h >> dol) & (Do - 1)) + ((p >> 1) & 1),
-                  z = 2 * (h & (Do - 1)) + (p >> 2);
-        orow = (((int64_t)b * a.D + x) * a.D + y) * a.D + z;
-      }
-      const float4 v0 = *reinterpret_cast<const float4 *>(s_out + ml * kEp + 8 * c8);
-      const float4 v1 = *reinterpret_cast<const float4 *>(s_out + ml * kEp + 8 * c8 + 4);
-      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      const int nv = a.N - n < 8 ? a.N - n : 8;
-      if (a.out_f32) {
-        float *o = reinterpret_cast<float *>(a.out) + grp * a.o_gs + orow * a.ldo + n;
-        if (nv == 8 && (a.ldo & 3) == 0 && ((uintptr_t)o & 15) == 0) {
-          float4 *o4 = reinterpret_cast<float4 *>(o);
-          if (a.accumulate) {
-            const float4 p0 = o4[0], p1 = o4[1];
-            v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w;
-            v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
-          }
-          o4[0] = make_float4(v[0], v[1], v[2], v[3]);
-          o4[1] = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          for (int j = 0; j < nv; ++j) o[j] = a.accumulate ? o[j] + v[j] : v[j];
-        }
-      } else {
-        uint16_t *o = reinterpret_cast<uint16_t *>(a.out) + grp * a.o_gs + orow * a.ldo + n;
-        if (nv == 8 && (a.ldo & 7) == 0 && ((uintptr_t)o & 15) == 0) {
-          *reinterpret_cast<uint4 *>(o) = make_uint4(mf::pack_bf16x2(v[0], v[1]), mf::pack_bf16x2(v[2], v[3]),
-                                                     mf::pack_bf16x2(v[4], v[5]), mf::pack_bf16x2(v[6], v[7]));
-        } else {
-          for (int j = 0; j < nv; ++j) o[j] = (uint16_t)mf::bf16_bits(v[j]);
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
 
 // ---- the 256 x 256 x 64 tile with LDS-DMA operands and two wave groups in ping-pong (round 6) ------------------------
-// k_gemm_nt_bf16_big above moves every operand chunk global -> VGPR -> ds_write_b128 -> barrier, once per K-tile: all
-// eight waves meet at that barrier, wait out their loads, store, and start reading fragments at the same moment --
-// the MFMA pipe idles through every one of these episodes (0.42-0.43 busy).  Here
+// Round 5's form of this tile moved every operand chunk global -> VGPR -> ds_write_b128 -> barrier, once per K-tile: all
+// eight waves met at that barrier, waited out their loads, stored, and started reading fragments at the same moment --
+// the MFMA pipe idled through every one of these episodes (0.42-0.43 busy).  Here
 //   * operands go global -> LDS directly (buffer_load_dwordx4 ... lds, mf::glds16: 1 KiB = 8 tile rows per wave
 //     instruction; masked chunks are out-of-range offsets and land as zeros): no staging registers, no store pass;
 //   * the LDS image of an operand is [256 rows][128 bytes] with the 16-byte chunk index XORed with (row >> 1) & 7.  The
@@ -939,7 +637,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pp(NtArgs a) {
 #undef MF_PP_REQ_W
 #undef MF_PP_REQ_A
 
-  // epilogue through LDS in four passes of 64 rows (as in k_gemm_nt_bf16_big)
+  // epilogue through LDS in four passes of 64 rows (64 x 260 floats)
   constexpr int kEp = kBNb + 4;
   float *s_out = reinterpret_cast<float *>(s_raw);  // [64][kEp]
   const float *bias = a.bias && a.S == 1 ? a.bias + grp * a.b_gs : nullptr;
@@ -1807,25 +1505,18 @@ int launch_nt(const NtArgs &a, hipStream_t stream) {
   else if (nt_big_override() >= 0)
     use_big = use_big && nt_big_override() == 1;
   if (use_big) {
-    // MF_NT_PP=0: the register-staged form of the 256 x 256 tile (round 5) instead of the LDS-DMA ping-pong form
-    static const bool pp = !(getenv("MF_NT_PP") && atoi(getenv("MF_NT_PP")) == 0);
-    if (pp) {
-      // MF_PP_DBG (timing ablations, WRONG results): 1 = no operand requests after tile 0, 2 = every request re-reads
-      // K-tile 0 (cache hits), 4 = the two wave groups in lockstep instead of one barrier apart
-      static const int dbg = getenv("MF_PP_DBG") ? atoi(getenv("MF_PP_DBG")) : 0;
-      NtArgs b = a;
-      b.dbg = dbg;
-      if (b.S < 1) b.S = 1;
-      if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16_pp<MODE>, nt_pp_lds())) return e;
-      hipLaunchKernelGGL((k_gemm_nt_bf16_pp<MODE>), dim3((unsigned)(big * b.S)), dim3(512), nt_pp_lds(), stream, b);
-      if (b.S > 1)
-        hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)(((int64_t)a.M * (a.N / 8) + 255) / 256)), dim3(256), 0,
-                           stream, (const float *)b.slab, a.bias, a.out, (int64_t)a.M, a.N, b.S, a.ldo, a.relu,
-                           a.out_f32);
-    } else {
-      if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16_big<MODE>, nt_big_lds())) return e;
-      hipLaunchKernelGGL((k_gemm_nt_bf16_big<MODE>), dim3((unsigned)big), dim3(512), nt_big_lds(), stream, a);
-    }
+    // MF_PP_DBG (timing ablations, WRONG results): 1 = no operand requests after tile 0, 2 = every request re-reads
+    // K-tile 0 (cache hits), 4 = the two wave groups in lockstep instead of one barrier apart
+    static const int dbg = getenv("MF_PP_DBG") ? atoi(getenv("MF_PP_DBG")) : 0;
+    NtArgs b = a;
+    b.dbg = dbg;
+    if (b.S < 1) b.S = 1;
+    if (int e = mf::allow_big_lds((const void *)k_gemm_nt_bf16_pp<MODE>, nt_pp_lds())) return e;
+    hipLaunchKernelGGL((k_gemm_nt_bf16_pp<MODE>), dim3((unsigned)(big * b.S)), dim3(512), nt_pp_lds(), stream, b);
+    if (b.S > 1)
+      hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)(((int64_t)a.M * (a.N / 8) + 255) / 256)), dim3(256), 0,
+                         stream, (const float *)b.slab, a.bias, a.out, (int64_t)a.M, a.N, b.S, a.ldo, a.relu,
+                         a.out_f32);
     g_nt_last_tile = kBigM;
     return 0;
   }
@@ -2046,7 +1737,7 @@ namespace {
 // partial sums in S slabs, added in order by k_splitk_finish (deterministic).  1 = no split.
 int nt_splitk(int64_t M, int N, int K) {
   const int forced = getenv("MF_NT_SPLITK") ? atoi(getenv("MF_NT_SPLITK")) : 0;  // (tests; 0 = by problem size)
-  if (N < 192 || N % 8 || nt_big_override() == 0 || (getenv("MF_NT_PP") && atoi(getenv("MF_NT_PP")) == 0)) return 1;
+  if (N < 192 || N % 8 || nt_big_override() == 0) return 1;
   const int64_t big = ((M + kBigM - 1) / kBigM) * ((N + kBigN - 1) / kBigN);
   const int T = (K + kBK - 1) / kBK;
   if (forced > 0) return forced <= T ? forced : 1;
