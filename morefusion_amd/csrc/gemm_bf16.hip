@@ -1582,16 +1582,17 @@ int wgrad_split_for(int Ni, int Nj, int64_t ktiles, int groups) {
   return wgrad_split_model((int64_t)((Ni + 127) / 128) * ((Nj + 127) / 128) * groups, ktiles, slab, 512);
 }
 template <bool CONV>
-void launch_tn(const TnArgs &a, bool ranges, hipStream_t stream) {
+int launch_tn(const TnArgs &a, bool ranges, hipStream_t stream) {
   if (tn_use_pp(a.Ni, a.Nj, ((int64_t)a.M + 63) / 64, a.groups, ranges)) {
-    if (mf::allow_big_lds((const void *)k_gemm_tn_bf16_pp<CONV>, 5 * kPpOp)) return;
+    if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16_pp<CONV>, 5 * kPpOp)) return e;
     const int64_t grid = (int64_t)((a.Ni + 255) / 256) * ((a.Nj + 255) / 256) * a.groups * a.S;
     hipLaunchKernelGGL(k_gemm_tn_bf16_pp<CONV>, dim3((unsigned)grid), dim3(512), 5 * kPpOp, stream, a);
-    return;
+    return 0;
   }
-  if (mf::allow_big_lds((const void *)k_gemm_tn_bf16<CONV>, kTnLds)) return;
+  if (int e = mf::allow_big_lds((const void *)k_gemm_tn_bf16<CONV>, kTnLds)) return e;
   const int64_t grid = (int64_t)((a.Ni + 127) / 128) * ((a.Nj + 127) / 128) * a.groups * a.S;
   hipLaunchKernelGGL(k_gemm_tn_bf16<CONV>, dim3((unsigned)grid), dim3(256), kTnLds, stream, a);
+  return 0;
 }
 }  // namespace
 
@@ -1654,7 +1655,7 @@ extern "C" int mf_linear_wgrad_bf16(const void *dY, int64_t y_gs, int32_t ldy, c
   a.P = (const uint16_t *)dY; a.Q = (const uint16_t *)A; a.out = split > 1 ? (float *)ws : dW;
   a.p_gs = y_gs; a.q_gs = a_gs; a.c_gs = w_gs;
   a.M = M; a.Ni = N; a.Nj = K; a.ldp = ldy; a.ldq = lda; a.ldc = ldc; a.groups = groups; a.S = split;
-  launch_tn<false>(a, false, stream);
+  if (int e = launch_tn<false>(a, false, stream)) return e;
   if (split > 1) {
     const int64_t per_group = (int64_t)N * ldc, per_slab = per_group * groups;
     if (split >= 32 && per_slab <= (1 << 16))
@@ -1705,7 +1706,7 @@ extern "C" int mf_linear_wgrad_bf16_ranges(const void *dY, int32_t ldy, const vo
   a.c_gs = w_gs;
   a.M = 0; a.Ni = N; a.Nj = K; a.ldp = ldy; a.ldq = lda; a.ldc = ldc; a.groups = groups; a.S = 1;
   a.m_range = m_range;
-  launch_tn<false>(a, true, stream);
+  if (int e = launch_tn<false>(a, true, stream)) return e;
   return mf::check_launch("mf_linear_wgrad_bf16_ranges");
 }
 
@@ -1883,7 +1884,7 @@ extern "C" int mf_conv3d_bf16_wgrad(const void *dy, const void *x, float *dW, vo
   a.conv = 1; a.B = B; a.D = D; a.Do = g.Do; a.olog = g.olog; a.Cin = Cin;
   a.ks = ks; a.stride = stride; a.pad = pad; a.dil = dil;
   // (S == 1 also goes through the workspace: the finish pass permutes (tap, cin) -> (cin, tap))
-  launch_tn<true>(a, false, stream);
+  if (int e = launch_tn<true>(a, false, stream)) return e;
   const int64_t per_slab = (int64_t)Cout * g.taps * Cin;
   const int keep = w_cin - c_off < Cin ? w_cin - c_off : Cin;
   // big layers: the tiled transpose; small ones (the occupancy convolutions: a few thousand weights in up to 256
